@@ -1,0 +1,479 @@
+"""ctypes front end of the CPU oracle (oracle/liboracle.so).
+
+ORACLE = test infrastructure.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product package
+(d-liom_amd/) never does.
+
+Conventions: poses are float64[7] = [tx,ty,tz,qw,qx,qy,qz]; clouds are
+float32[n,3] C-contiguous.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (g++ only)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int)
+_u16p = C.POINTER(C.c_uint16)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def _declare(L):
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    vp = C.c_void_p
+    sig("orc_value_to_probability_table", None, _f32p)
+    sig("orc_value_to_correspondence_cost_table", None, _f32p)
+    sig("orc_probability_to_value", C.c_uint16, C.c_float)
+    sig("orc_correspondence_cost_to_value", C.c_uint16, C.c_float)
+    sig("orc_odds", C.c_float, C.c_float)
+    sig("orc_probability_from_odds", C.c_float, C.c_float)
+    sig("orc_probability_value_to_correspondence_cost_value", C.c_uint16, C.c_uint16)
+    sig("orc_correspondence_cost_value_to_probability_value", C.c_uint16, C.c_uint16)
+    sig("orc_lookup_table_to_apply_odds", None, C.c_float, _u16p)
+    sig("orc_lookup_table_to_apply_correspondence_cost_odds", None, C.c_float, _u16p)
+    sig("orc_grid_new", vp, C.c_float)
+    sig("orc_grid_free", None, vp)
+    sig("orc_grid_resolution", C.c_float, vp)
+    sig("orc_grid_bits", C.c_int, vp)
+    sig("orc_cell_indices", None, C.c_float, _f32p, C.c_int, _i32p)
+    sig("orc_grid_center_of_cell", None, vp, C.c_int, C.c_int, C.c_int, _f32p)
+    sig("orc_grid_set_probability", None, vp, C.c_int, C.c_int, C.c_int, C.c_float)
+    sig("orc_grid_set_value", None, vp, C.c_int, C.c_int, C.c_int, C.c_uint16)
+    sig("orc_grid_set_values", None, vp, _i32p, _u16p, C.c_int)
+    sig("orc_grid_value", C.c_uint16, vp, C.c_int, C.c_int, C.c_int)
+    sig("orc_grid_values", None, vp, _i32p, C.c_int, _u16p)
+    sig("orc_grid_probability", C.c_float, vp, C.c_int, C.c_int, C.c_int)
+    sig("orc_grid_is_known", C.c_int, vp, C.c_int, C.c_int, C.c_int)
+    sig("orc_grid_apply_lookup_table", C.c_int, vp, C.c_int, C.c_int, C.c_int, _u16p)
+    sig("orc_grid_finish_update", None, vp)
+    sig("orc_grid_num_cells", C.c_int64, vp)
+    sig("orc_grid_export_cells", None, vp, _i32p, _u16p)
+    sig("orc_grid_num_leaves", C.c_int64, vp)
+    sig("orc_grid_export_leaves", None, vp, _i32p, _u16p)
+    sig("orc_insert_range_data", None, vp, _f32p, _f32p, C.c_int, C.c_double, C.c_double, C.c_int)
+    sig("orc_insert_range_data_tables", None, vp, _f32p, _f32p, C.c_int, _u16p, _u16p, C.c_int)
+    sig("orc_voxel_filter", C.c_int, C.c_float, _f32p, C.c_int, _i32p)
+    sig("orc_adaptive_voxel_filter", C.c_int, C.c_float, C.c_float, C.c_float, _f32p, C.c_int, _f32p)
+    sig("orc_transform_points", None, _f32p, _f32p, C.c_int, _f32p)
+    sig("orc_rigid3d_multiply", None, _f64p, _f64p, _f64p)
+    sig("orc_rigid3d_inverse", None, _f64p, _f64p)
+    sig("orc_rtcsm3d_window", None, _f64p, C.c_float, _f32p, C.c_int, _i32p, _i32p, _f32p, _f32p)
+    sig("orc_rtcsm3d_candidates", C.c_int64, _f64p, C.c_float, _f32p, C.c_int, _f64p, _f32p, _f32p)
+    sig("orc_rtcsm3d_match", C.c_float, _f64p, _f64p, _f32p, C.c_int, vp, _f64p, _f32p, _i32p)
+    sig("orc_rtcsm3d_value_sums", None, _f64p, _f64p, _f32p, C.c_int, vp, C.c_int64, C.c_int64, _u64p)
+    sig("orc_transform_cell_indices", None, _f32p, _f32p, C.c_int, C.c_float, _i32p)
+    sig("orc_interpolated_probability", C.c_double, vp, C.c_double, C.c_double, C.c_double)
+    sig("orc_occupied_space_evaluate", None, vp, _f32p, C.c_int, C.c_double, _f64p, _f64p, _f64p, _f64p, _f64p)
+    sig("orc_rotation_delta_squared_cost", C.c_double, _f64p, C.c_double, _f64p)
+    sig("orc_csm3d_match", None, _f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+        _f64p, _f64p, C.POINTER(_f32p), _i32p, C.POINTER(vp), _f64p, _f64p)
+    sig("orc_pg_new", vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int)
+    sig("orc_pg_free", None, vp)
+    sig("orc_pg_set_probability", None, vp, C.c_int, C.c_int, C.c_float)
+    sig("orc_pg_probability", C.c_float, vp, C.c_int, C.c_int)
+    sig("orc_pg_cell_index", None, vp, C.c_float, C.c_float, _i32p)
+    sig("orc_pg_cells", None, vp, _u16p)
+    sig("orc_pg_insert", None, vp, _f32p, _f32p, C.c_int, C.c_double, C.c_double, C.c_int)
+    sig("orc_rtcsm2d_match", C.c_double, _f64p, _f64p, _f32p, C.c_int, vp, _f64p)
+    sig("orc_rtcsm2d_score_single", C.c_float, _f64p, _f32p, C.c_int, vp, C.c_int, C.c_int)
+    sig("orc_now_seconds", C.c_double)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def pose(t=(0, 0, 0), q=(1, 0, 0, 0)):
+    return np.array(list(t) + list(q), dtype=np.float64)
+
+
+def angle_axis_quat(angle, axis, normalize_axis=False):
+    """Eigen::AngleAxisd -> Quaterniond: w = cos(a/2), vec = sin(a/2) * axis.
+    Like Eigen, the axis is NOT normalised unless asked (the reference's
+    RotationAroundYZ test passes the raw axis (0,1,1))."""
+    axis = np.asarray(axis, dtype=np.float64)
+    if normalize_axis:
+        axis = axis / np.linalg.norm(axis)
+    s = np.sin(0.5 * angle)
+    return np.array([np.cos(0.5 * angle), s * axis[0], s * axis[1], s * axis[2]])
+
+
+def rigid_multiply(a, b):
+    out = np.zeros(7)
+    lib().orc_rigid3d_multiply(_p(_f64(a), _f64p), _p(_f64(b), _f64p), _p(out, _f64p))
+    return out
+
+
+def rigid_inverse(a):
+    out = np.zeros(7)
+    lib().orc_rigid3d_inverse(_p(_f64(a), _f64p), _p(out, _f64p))
+    return out
+
+
+# ------------------------------------------------------------------ probability values
+def value_to_probability_table():
+    out = np.zeros(65536, dtype=np.float32)
+    lib().orc_value_to_probability_table(_p(out, _f32p))
+    return out
+
+
+def value_to_correspondence_cost_table():
+    out = np.zeros(65536, dtype=np.float32)
+    lib().orc_value_to_correspondence_cost_table(_p(out, _f32p))
+    return out
+
+
+def lookup_table_to_apply_odds(odds):
+    out = np.zeros(32768, dtype=np.uint16)
+    lib().orc_lookup_table_to_apply_odds(C.c_float(odds), _p(out, _u16p))
+    return out
+
+
+def lookup_table_to_apply_correspondence_cost_odds(odds):
+    out = np.zeros(32768, dtype=np.uint16)
+    lib().orc_lookup_table_to_apply_correspondence_cost_odds(C.c_float(odds), _p(out, _u16p))
+    return out
+
+
+def odds(p):
+    return lib().orc_odds(C.c_float(p))
+
+
+def probability_from_odds(o):
+    return lib().orc_probability_from_odds(C.c_float(o))
+
+
+def probability_to_value(p):
+    return lib().orc_probability_to_value(C.c_float(p))
+
+
+def correspondence_cost_to_value(c):
+    return lib().orc_correspondence_cost_to_value(C.c_float(c))
+
+
+def cell_indices(resolution, pts):
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.zeros((len(pts), 3), dtype=np.int32)
+    lib().orc_cell_indices(C.c_float(resolution), _p(pts, _f32p), len(pts), _p(out, _i32p))
+    return out
+
+
+# ------------------------------------------------------------------ HybridGrid
+class HybridGrid:
+    def __init__(self, resolution):
+        self._L = lib()
+        self.h = C.c_void_p(self._L.orc_grid_new(C.c_float(resolution)))
+
+    def __del__(self):
+        try:
+            self._L.orc_grid_free(self.h)
+        except Exception:
+            pass
+
+    @property
+    def resolution(self):
+        return self._L.orc_grid_resolution(self.h)
+
+    @property
+    def bits(self):
+        return self._L.orc_grid_bits(self.h)
+
+    def get_cell_index(self, p):
+        return cell_indices(self.resolution, np.asarray(p, dtype=np.float32).reshape(1, 3))[0]
+
+    def get_center_of_cell(self, idx):
+        out = np.zeros(3, dtype=np.float32)
+        self._L.orc_grid_center_of_cell(self.h, int(idx[0]), int(idx[1]), int(idx[2]), _p(out, _f32p))
+        return out
+
+    def set_probability(self, idx, p):
+        self._L.orc_grid_set_probability(self.h, int(idx[0]), int(idx[1]), int(idx[2]), C.c_float(p))
+
+    def set_value(self, idx, v):
+        self._L.orc_grid_set_value(self.h, int(idx[0]), int(idx[1]), int(idx[2]), int(v))
+
+    def set_values(self, xyz, v):
+        xyz = _i32(xyz).reshape(-1, 3)
+        v = np.ascontiguousarray(v, dtype=np.uint16)
+        self._L.orc_grid_set_values(self.h, _p(xyz, _i32p), _p(v, _u16p), len(v))
+
+    def value(self, idx):
+        return self._L.orc_grid_value(self.h, int(idx[0]), int(idx[1]), int(idx[2]))
+
+    def values(self, xyz):
+        xyz = _i32(xyz).reshape(-1, 3)
+        out = np.zeros(len(xyz), dtype=np.uint16)
+        self._L.orc_grid_values(self.h, _p(xyz, _i32p), len(xyz), _p(out, _u16p))
+        return out
+
+    def get_probability(self, idx):
+        return self._L.orc_grid_probability(self.h, int(idx[0]), int(idx[1]), int(idx[2]))
+
+    def is_known(self, idx):
+        return bool(self._L.orc_grid_is_known(self.h, int(idx[0]), int(idx[1]), int(idx[2])))
+
+    def apply_lookup_table(self, idx, table):
+        table = np.ascontiguousarray(table, dtype=np.uint16)
+        return bool(self._L.orc_grid_apply_lookup_table(
+            self.h, int(idx[0]), int(idx[1]), int(idx[2]), _p(table, _u16p)))
+
+    def finish_update(self):
+        self._L.orc_grid_finish_update(self.h)
+
+    def export_cells(self):
+        n = self._L.orc_grid_num_cells(self.h)
+        xyz = np.zeros((n, 3), dtype=np.int32)
+        v = np.zeros(n, dtype=np.uint16)
+        if n:
+            self._L.orc_grid_export_cells(self.h, _p(xyz, _i32p), _p(v, _u16p))
+        return xyz, v
+
+    def export_leaves(self):
+        n = self._L.orc_grid_num_leaves(self.h)
+        origin = np.zeros((n, 3), dtype=np.int32)
+        v = np.zeros((n, 512), dtype=np.uint16)
+        if n:
+            self._L.orc_grid_export_leaves(self.h, _p(origin, _i32p), _p(v, _u16p))
+        return origin, v
+
+    def insert(self, origin, returns, hit_probability, miss_probability, num_free_space_voxels):
+        origin = _f32(origin)
+        returns = _f32(returns).reshape(-1, 3)
+        self._L.orc_insert_range_data(self.h, _p(origin, _f32p), _p(returns, _f32p), len(returns),
+                                      hit_probability, miss_probability, num_free_space_voxels)
+
+    def insert_tables(self, origin, returns, hit_table, miss_table, num_free_space_voxels):
+        origin = _f32(origin)
+        returns = _f32(returns).reshape(-1, 3)
+        hit_table = np.ascontiguousarray(hit_table, dtype=np.uint16)
+        miss_table = np.ascontiguousarray(miss_table, dtype=np.uint16)
+        self._L.orc_insert_range_data_tables(self.h, _p(origin, _f32p), _p(returns, _f32p), len(returns),
+                                             _p(hit_table, _u16p), _p(miss_table, _u16p),
+                                             num_free_space_voxels)
+
+    def interpolated_probability(self, x, y, z):
+        return self._L.orc_interpolated_probability(self.h, x, y, z)
+
+
+# ------------------------------------------------------------------ filters / transforms
+def voxel_filter(size, pts):
+    pts = _f32(pts).reshape(-1, 3)
+    keep = np.zeros(len(pts), dtype=np.int32)
+    n = lib().orc_voxel_filter(C.c_float(size), _p(pts, _f32p), len(pts), _p(keep, _i32p))
+    return keep[:n].copy()
+
+
+def adaptive_voxel_filter(max_length, min_num_points, max_range, pts):
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.zeros_like(pts)
+    n = lib().orc_adaptive_voxel_filter(C.c_float(max_length), C.c_float(min_num_points),
+                                        C.c_float(max_range), _p(pts, _f32p), len(pts), _p(out, _f32p))
+    return out[:n].copy()
+
+
+def transform_points(pose7_f32, pts):
+    pose7 = _f32(pose7_f32)
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.zeros_like(pts)
+    lib().orc_transform_points(_p(pose7, _f32p), _p(pts, _f32p), len(pts), _p(out, _f32p))
+    return out
+
+
+def transform_cell_indices(pose7_f32, pts, resolution):
+    pose7 = _f32(pose7_f32)
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.zeros((len(pts), 3), dtype=np.int32)
+    lib().orc_transform_cell_indices(_p(pose7, _f32p), _p(pts, _f32p), len(pts),
+                                     C.c_float(resolution), _p(out, _i32p))
+    return out
+
+
+# ------------------------------------------------------------------ RTCSM3D
+def _opts4(o):
+    return _f64([o["linear_search_window"], o["angular_search_window"],
+                 o["translation_delta_cost_weight"], o["rotation_delta_cost_weight"]])
+
+
+def rtcsm3d_window(opts, resolution, pts):
+    pts = _f32(pts).reshape(-1, 3)
+    lw, aw = C.c_int(), C.c_int()
+    step, rng = C.c_float(), C.c_float()
+    lib().orc_rtcsm3d_window(_p(_opts4(opts), _f64p), C.c_float(resolution), _p(pts, _f32p), len(pts),
+                             C.byref(lw), C.byref(aw), C.byref(step), C.byref(rng))
+    return dict(linear_window=lw.value, angular_window=aw.value, angular_step=step.value,
+                max_scan_range=rng.value)
+
+
+def rtcsm3d_candidates(opts, resolution, pts, init7):
+    pts = _f32(pts).reshape(-1, 3)
+    o = _opts4(opts)
+    init7 = _f64(init7)
+    n = lib().orc_rtcsm3d_candidates(_p(o, _f64p), C.c_float(resolution), _p(pts, _f32p), len(pts),
+                                     _p(init7, _f64p), None, None)
+    tr = np.zeros((n, 7), dtype=np.float32)
+    ca = np.zeros((n, 7), dtype=np.float32)
+    lib().orc_rtcsm3d_candidates(_p(o, _f64p), C.c_float(resolution), _p(pts, _f32p), len(pts),
+                                 _p(init7, _f64p), _p(tr, _f32p), _p(ca, _f32p))
+    return tr, ca
+
+
+def rtcsm3d_match(opts, init7, pts, grid, want_scores=False):
+    pts = _f32(pts).reshape(-1, 3)
+    o = _opts4(opts)
+    init7 = _f64(init7)
+    out = np.zeros(7)
+    best = C.c_int(-1)
+    scores = None
+    sp = None
+    if want_scores:
+        n = lib().orc_rtcsm3d_candidates(_p(o, _f64p), C.c_float(grid.resolution), _p(pts, _f32p),
+                                         len(pts), _p(init7, _f64p), None, None)
+        scores = np.zeros(n, dtype=np.float32)
+        sp = _p(scores, _f32p)
+    s = lib().orc_rtcsm3d_match(_p(o, _f64p), _p(init7, _f64p), _p(pts, _f32p), len(pts), grid.h,
+                                _p(out, _f64p), sp, C.byref(best))
+    return dict(score=s, pose=out, best_index=best.value, scores=scores)
+
+
+def rtcsm3d_value_sums(opts, init7, pts, grid, first=0, count=-1):
+    pts = _f32(pts).reshape(-1, 3)
+    o = _opts4(opts)
+    init7 = _f64(init7)
+    if count < 0:
+        total = lib().orc_rtcsm3d_candidates(_p(o, _f64p), C.c_float(grid.resolution), _p(pts, _f32p),
+                                             len(pts), _p(init7, _f64p), None, None)
+        n = total - first
+    else:
+        n = count
+    sums = np.zeros(n, dtype=np.uint64)
+    lib().orc_rtcsm3d_value_sums(_p(o, _f64p), _p(init7, _f64p), _p(pts, _f32p), len(pts), grid.h,
+                                 first, n, _p(sums, _u64p))
+    return sums
+
+
+# ------------------------------------------------------------------ CSM3D
+def occupied_space_evaluate(grid, pts, scaling, t3, q4, jacobians=True):
+    pts = _f32(pts).reshape(-1, 3)
+    n = len(pts)
+    r = np.zeros(n)
+    jt = np.zeros((n, 3)) if jacobians else None
+    jq = np.zeros((n, 4)) if jacobians else None
+    lib().orc_occupied_space_evaluate(grid.h, _p(pts, _f32p), n, scaling, _p(_f64(t3), _f64p),
+                                      _p(_f64(q4), _f64p), _p(r, _f64p),
+                                      _p(jt, _f64p) if jacobians else None,
+                                      _p(jq, _f64p) if jacobians else None)
+    return r, jt, jq
+
+
+def rotation_delta_squared_cost(q4, scaling, target4):
+    return lib().orc_rotation_delta_squared_cost(_p(_f64(q4), _f64p), scaling, _p(_f64(target4), _f64p))
+
+
+def csm3d_match(opts, target_translation, init7, clouds_and_grids):
+    """opts: dict(occupied_space_weight=[..], translation_weight, rotation_weight,
+    only_optimize_yaw, use_nonmonotonic_steps, max_num_iterations)."""
+    k = len(clouds_and_grids)
+    w = _f64(opts["occupied_space_weight"])
+    clouds = [_f32(c).reshape(-1, 3) for c, _ in clouds_and_grids]
+    ptrs = (_f32p * k)(*[_p(c, _f32p) for c in clouds])
+    ns = _i32([len(c) for c in clouds])
+    grids = (C.c_void_p * k)(*[g.h for _, g in clouds_and_grids])
+    out = np.zeros(7)
+    summ = np.zeros(10)
+    lib().orc_csm3d_match(_p(w, _f64p), k, opts["translation_weight"], opts["rotation_weight"],
+                          int(opts.get("only_optimize_yaw", False)),
+                          int(opts.get("use_nonmonotonic_steps", False)),
+                          int(opts["max_num_iterations"]), _p(_f64(target_translation), _f64p),
+                          _p(_f64(init7), _f64p), ptrs, _p(ns, _i32p), grids, _p(out, _f64p),
+                          _p(summ, _f64p))
+    return dict(pose=out, initial_cost=summ[0], final_cost=summ[1], num_successful_steps=int(summ[2]),
+                num_unsuccessful_steps=int(summ[3]), num_iterations=int(summ[4]),
+                num_residual_evaluations=int(summ[5]), num_jacobian_evaluations=int(summ[6]),
+                termination_type=int(summ[7]))
+
+
+# ------------------------------------------------------------------ 2D
+class ProbabilityGrid:
+    def __init__(self, resolution, max_xy, num_x_cells, num_y_cells):
+        self._L = lib()
+        self.num_x_cells = num_x_cells
+        self.num_y_cells = num_y_cells
+        self.h = C.c_void_p(self._L.orc_pg_new(resolution, max_xy[0], max_xy[1], num_x_cells, num_y_cells))
+
+    def __del__(self):
+        try:
+            self._L.orc_pg_free(self.h)
+        except Exception:
+            pass
+
+    def set_probability(self, x, y, p):
+        self._L.orc_pg_set_probability(self.h, x, y, C.c_float(p))
+
+    def get_probability(self, x, y):
+        return self._L.orc_pg_probability(self.h, x, y)
+
+    def cell_index(self, px, py):
+        out = np.zeros(2, dtype=np.int32)
+        self._L.orc_pg_cell_index(self.h, C.c_float(px), C.c_float(py), _p(out, _i32p))
+        return out
+
+    def insert(self, origin, returns, hit_probability, miss_probability, insert_free_space=True):
+        origin = _f32(origin)
+        returns = _f32(returns).reshape(-1, 3)
+        self._L.orc_pg_insert(self.h, _p(origin, _f32p), _p(returns, _f32p), len(returns),
+                              hit_probability, miss_probability, int(insert_free_space))
+
+
+def rtcsm2d_match(opts, init3, pts, pg):
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.zeros(3)
+    s = lib().orc_rtcsm2d_match(_p(_opts4(opts), _f64p), _p(_f64(init3), _f64p), _p(pts, _f32p),
+                                len(pts), pg.h, _p(out, _f64p))
+    return dict(score=s, pose=out)
+
+
+def rtcsm2d_score_single(opts, pts, pg, x_index_offset, y_index_offset):
+    pts = _f32(pts).reshape(-1, 3)
+    return lib().orc_rtcsm2d_score_single(_p(_opts4(opts), _f64p), _p(pts, _f32p), len(pts), pg.h,
+                                          x_index_offset, y_index_offset)

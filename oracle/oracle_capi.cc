@@ -1,0 +1,397 @@
+// ORACLE (test infrastructure, NOT product code).
+//
+// C entry points over the CPU restatement in oracle/src, loaded with ctypes by
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY.  The
+// product library (d-liom_amd/csrc) never links or loads this file.
+//
+// Pose arrays are [tx,ty,tz,qw,qx,qy,qz] (the order of CeresPose::Data,
+// optimization/ceres_pose.h:47-51); points are packed float xyz.
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "src/om_csm3d.h"
+#include "src/om_grid2d.h"
+#include "src/om_rtcsm3d.h"
+
+using namespace oracle;
+
+namespace {
+
+PointCloud ToCloud(const float* pts, int n) {
+  PointCloud c;
+  c.reserve(n);
+  for (int i = 0; i < n; ++i) c.emplace_back(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+  return c;
+}
+Rigid3d ToRigid(const double* p) {
+  return Rigid3d(Vec3d(p[0], p[1], p[2]), Quatd(p[3], p[4], p[5], p[6]));
+}
+void FromRigid(const Rigid3d& r, double* p) {
+  p[0] = r.translation.x; p[1] = r.translation.y; p[2] = r.translation.z;
+  p[3] = r.rotation.w; p[4] = r.rotation.x; p[5] = r.rotation.y; p[6] = r.rotation.z;
+}
+void FromRigidF(const Rigid3f& r, float* p) {
+  p[0] = r.translation.x; p[1] = r.translation.y; p[2] = r.translation.z;
+  p[3] = r.rotation.w; p[4] = r.rotation.x; p[5] = r.rotation.y; p[6] = r.rotation.z;
+}
+HybridGrid* G(void* g) { return static_cast<HybridGrid*>(g); }
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- probability values
+void orc_value_to_probability_table(float* out65536) {
+  const std::vector<float>& t = ValueToProbabilityTable();
+  std::memcpy(out65536, t.data(), 65536 * sizeof(float));
+}
+void orc_value_to_correspondence_cost_table(float* out65536) {
+  const std::vector<float>& t = ValueToCorrespondenceCostTable();
+  std::memcpy(out65536, t.data(), 65536 * sizeof(float));
+}
+uint16_t orc_probability_to_value(float p) { return ProbabilityToValue(p); }
+uint16_t orc_correspondence_cost_to_value(float c) { return CorrespondenceCostToValue(c); }
+float orc_odds(float p) { return Odds(p); }
+float orc_probability_from_odds(float o) { return ProbabilityFromOdds(o); }
+uint16_t orc_probability_value_to_correspondence_cost_value(uint16_t v) {
+  return ProbabilityValueToCorrespondenceCostValue(v);
+}
+uint16_t orc_correspondence_cost_value_to_probability_value(uint16_t v) {
+  return CorrespondenceCostValueToProbabilityValue(v);
+}
+void orc_lookup_table_to_apply_odds(float odds, uint16_t* out32768) {
+  const std::vector<uint16> t = ComputeLookupTableToApplyOdds(odds);
+  std::memcpy(out32768, t.data(), 32768 * sizeof(uint16_t));
+}
+void orc_lookup_table_to_apply_correspondence_cost_odds(float odds, uint16_t* out32768) {
+  const std::vector<uint16> t = ComputeLookupTableToApplyCorrespondenceCostOdds(odds);
+  std::memcpy(out32768, t.data(), 32768 * sizeof(uint16_t));
+}
+
+// ---------------------------------------------------------------- HybridGrid
+void* orc_grid_new(float resolution) { return new HybridGrid(resolution); }
+void orc_grid_free(void* g) { delete G(g); }
+float orc_grid_resolution(void* g) { return G(g)->resolution(); }
+int orc_grid_bits(void* g) { return G(g)->bits(); }
+void orc_cell_indices(float resolution, const float* pts, int n, int* out) {
+  HybridGrid tmp(resolution);
+  for (int i = 0; i < n; ++i) {
+    const Vec3i c = tmp.GetCellIndex(Vec3f(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+  }
+}
+void orc_grid_center_of_cell(void* g, int x, int y, int z, float* out3) {
+  const Vec3f c = G(g)->GetCenterOfCell(Vec3i(x, y, z));
+  out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+}
+void orc_grid_set_probability(void* g, int x, int y, int z, float p) {
+  G(g)->SetProbability(Vec3i(x, y, z), p);
+}
+void orc_grid_set_value(void* g, int x, int y, int z, uint16_t v) {
+  *G(g)->mutable_value(Vec3i(x, y, z)) = v;
+}
+void orc_grid_set_values(void* g, const int* xyz, const uint16_t* v, int n) {
+  for (int i = 0; i < n; ++i)
+    *G(g)->mutable_value(Vec3i(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])) = v[i];
+}
+uint16_t orc_grid_value(void* g, int x, int y, int z) { return G(g)->value(Vec3i(x, y, z)); }
+void orc_grid_values(void* g, const int* xyz, int n, uint16_t* out) {
+  for (int i = 0; i < n; ++i)
+    out[i] = G(g)->value(Vec3i(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+}
+float orc_grid_probability(void* g, int x, int y, int z) {
+  return G(g)->GetProbability(Vec3i(x, y, z));
+}
+int orc_grid_is_known(void* g, int x, int y, int z) { return G(g)->IsKnown(Vec3i(x, y, z)); }
+int orc_grid_apply_lookup_table(void* g, int x, int y, int z, const uint16_t* table32768) {
+  const std::vector<uint16> t(table32768, table32768 + 32768);
+  return G(g)->ApplyLookupTable(Vec3i(x, y, z), t) ? 1 : 0;
+}
+void orc_grid_finish_update(void* g) { G(g)->FinishUpdate(); }
+int64_t orc_grid_num_cells(void* g) {
+  int64_t n = 0;
+  G(g)->ForEachCell([&](const Vec3i&, uint16) { ++n; });
+  return n;
+}
+// Cells in the reference iterator's order.
+void orc_grid_export_cells(void* g, int* xyz, uint16_t* values) {
+  int64_t i = 0;
+  G(g)->ForEachCell([&](const Vec3i& c, uint16 v) {
+    xyz[3 * i] = c.x; xyz[3 * i + 1] = c.y; xyz[3 * i + 2] = c.z;
+    values[i] = v;
+    ++i;
+  });
+}
+int64_t orc_grid_num_leaves(void* g) {
+  int64_t n = 0;
+  G(g)->ForEachLeaf([&](const Vec3i&, const uint16*) { ++n; });
+  return n;
+}
+// Leaves as (origin voxel index of the 8^3 block, 512 z-major values).
+void orc_grid_export_leaves(void* g, int* origin_xyz, uint16_t* values512) {
+  int64_t i = 0;
+  G(g)->ForEachLeaf([&](const Vec3i& o, const uint16* cells) {
+    origin_xyz[3 * i] = o.x; origin_xyz[3 * i + 1] = o.y; origin_xyz[3 * i + 2] = o.z;
+    std::memcpy(values512 + 512 * i, cells, 512 * sizeof(uint16_t));
+    ++i;
+  });
+}
+
+// ---------------------------------------------------------------- insertion / filters
+void orc_insert_range_data(void* g, const float* origin3, const float* returns, int n,
+                           double hit_probability, double miss_probability,
+                           int num_free_space_voxels) {
+  // RangeDataInserter3D ctor: Odds(float(options.hit_probability()))
+  const RangeDataInserter3D inserter(static_cast<float>(hit_probability),
+                                     static_cast<float>(miss_probability),
+                                     num_free_space_voxels);
+  RangeData rd{Vec3f(origin3[0], origin3[1], origin3[2]), ToCloud(returns, n), {}};
+  inserter.Insert(rd, G(g));
+}
+// Same, but with prebuilt tables (amortises the 2 x 32768-entry table build).
+void orc_insert_range_data_tables(void* g, const float* origin3, const float* returns, int n,
+                                  const uint16_t* hit_table, const uint16_t* miss_table,
+                                  int num_free_space_voxels) {
+  const std::vector<uint16> hit(hit_table, hit_table + 32768);
+  const std::vector<uint16> miss(miss_table, miss_table + 32768);
+  HybridGrid* grid = G(g);
+  const Vec3f origin(origin3[0], origin3[1], origin3[2]);
+  for (int i = 0; i < n; ++i)
+    grid->ApplyLookupTable(
+        grid->GetCellIndex(Vec3f(returns[3 * i], returns[3 * i + 1], returns[3 * i + 2])), hit);
+  const Vec3i origin_cell = grid->GetCellIndex(origin);
+  for (int i = 0; i < n; ++i) {
+    const Vec3i hit_cell =
+        grid->GetCellIndex(Vec3f(returns[3 * i], returns[3 * i + 1], returns[3 * i + 2]));
+    const Vec3i delta = hit_cell - origin_cell;
+    const int num_samples =
+        std::max(std::abs(delta.x), std::max(std::abs(delta.y), std::abs(delta.z)));
+    for (int position = std::max(0, num_samples - num_free_space_voxels);
+         position < num_samples; ++position) {
+      grid->ApplyLookupTable(Vec3i(origin_cell.x + delta.x * position / num_samples,
+                                   origin_cell.y + delta.y * position / num_samples,
+                                   origin_cell.z + delta.z * position / num_samples),
+                             miss);
+    }
+  }
+  grid->FinishUpdate();
+}
+// Returns the number of surviving points and their indices.
+int orc_voxel_filter(float size, const float* pts, int n, int* keep_idx) {
+  VoxelFilter f(size);
+  const std::vector<int> kept = f.FilterIndices(ToCloud(pts, n));
+  std::memcpy(keep_idx, kept.data(), kept.size() * sizeof(int));
+  return static_cast<int>(kept.size());
+}
+int orc_adaptive_voxel_filter(float max_length, float min_num_points, float max_range,
+                              const float* pts, int n, float* out_pts) {
+  const PointCloud r = AdaptiveVoxelFilter(
+      AdaptiveVoxelFilterOptions{max_length, min_num_points, max_range}, ToCloud(pts, n));
+  for (size_t i = 0; i < r.size(); ++i) {
+    out_pts[3 * i] = r[i].x; out_pts[3 * i + 1] = r[i].y; out_pts[3 * i + 2] = r[i].z;
+  }
+  return static_cast<int>(r.size());
+}
+// sensor::TransformPointCloud with a float pose.
+void orc_transform_points(const float* pose7, const float* pts, int n, float* out) {
+  const Rigid3f t(Vec3f(pose7[0], pose7[1], pose7[2]),
+                  Quatf(pose7[3], pose7[4], pose7[5], pose7[6]));
+  for (int i = 0; i < n; ++i) {
+    const Vec3f p = t * Vec3f(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+  }
+}
+// Rigid3d composition / inverse / cast, for building test poses.
+void orc_rigid3d_multiply(const double* a7, const double* b7, double* out7) {
+  FromRigid(ToRigid(a7) * ToRigid(b7), out7);
+}
+void orc_rigid3d_inverse(const double* a7, double* out7) { FromRigid(ToRigid(a7).inverse(), out7); }
+
+// ---------------------------------------------------------------- RTCSM3D
+// opts = [linear_search_window, angular_search_window, translation_delta_cost_weight,
+//         rotation_delta_cost_weight]
+void orc_rtcsm3d_window(const double* opts, float resolution, const float* pts, int n,
+                        int* linear_window, int* angular_window, float* angular_step,
+                        float* max_scan_range) {
+  const RealTimeCorrelativeScanMatcher3D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  const SearchWindow3D w = m.ComputeWindow(resolution, ToCloud(pts, n));
+  *linear_window = w.linear_window_size;
+  *angular_window = w.angular_window_size;
+  *angular_step = w.angular_step_size;
+  *max_scan_range = w.max_scan_range;
+}
+// Writes, per candidate in generation order, transform (7 floats) and
+// candidate = float(init) * transform (7 floats).  Returns the count; pass
+// null outputs to query it.
+int64_t orc_rtcsm3d_candidates(const double* opts, float resolution, const float* pts, int n,
+                               const double* init7, float* transforms7, float* candidates7) {
+  const RealTimeCorrelativeScanMatcher3D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  const std::vector<Rigid3f> ts = m.GenerateExhaustiveSearchTransforms(resolution, ToCloud(pts, n));
+  if (transforms7 != nullptr || candidates7 != nullptr) {
+    const Rigid3f init = ToRigid(init7).cast<float>();
+    for (size_t i = 0; i < ts.size(); ++i) {
+      if (transforms7 != nullptr) FromRigidF(ts[i], transforms7 + 7 * i);
+      if (candidates7 != nullptr) FromRigidF(init * ts[i], candidates7 + 7 * i);
+    }
+  }
+  return static_cast<int64_t>(ts.size());
+}
+// Full match.  scores (may be null) receives every candidate's score.
+float orc_rtcsm3d_match(const double* opts, const double* init7, const float* pts, int n,
+                        void* grid, double* out7, float* scores, int* best_index) {
+  const RealTimeCorrelativeScanMatcher3D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  Rigid3d pose;
+  std::vector<float> all;
+  int best = -1;
+  const float s = m.Match(ToRigid(init7), ToCloud(pts, n), *G(grid), &pose,
+                          scores != nullptr ? &all : nullptr, &best);
+  FromRigid(pose, out7);
+  if (scores != nullptr) std::memcpy(scores, all.data(), all.size() * sizeof(float));
+  if (best_index != nullptr) *best_index = best;
+  return s;
+}
+// Per candidate: sum over points of max(value & 0x7fff, 1) (exact integers),
+// the order-independent quantity the HIP score-volume kernel accumulates.
+// Candidates [first, first+count) only (count<0: all).
+void orc_rtcsm3d_value_sums(const double* opts, const double* init7, const float* pts, int n,
+                            void* grid, int64_t first, int64_t count, uint64_t* sums) {
+  const RealTimeCorrelativeScanMatcher3D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  const PointCloud cloud = ToCloud(pts, n);
+  const HybridGrid& g = *G(grid);
+  const std::vector<Rigid3f> ts = m.GenerateExhaustiveSearchTransforms(g.resolution(), cloud);
+  const Rigid3f init = ToRigid(init7).cast<float>();
+  const int64_t end = count < 0 ? static_cast<int64_t>(ts.size()) : first + count;
+  for (int64_t c = first; c < end; ++c) {
+    const Rigid3f cand = init * ts[c];
+    uint64_t s = 0;
+    for (const Vec3f& p : cloud) {
+      const uint16 v = g.value(g.GetCellIndex(cand * p)) & 0x7fff;
+      s += v == 0 ? 1 : v;
+    }
+    sums[c - first] = s;
+  }
+}
+// Cell indices of a cloud under a float pose (the bit-exactness probe).
+void orc_transform_cell_indices(const float* pose7, const float* pts, int n, float resolution,
+                                int* out) {
+  const Rigid3f t(Vec3f(pose7[0], pose7[1], pose7[2]),
+                  Quatf(pose7[3], pose7[4], pose7[5], pose7[6]));
+  HybridGrid tmp(resolution);
+  for (int i = 0; i < n; ++i) {
+    const Vec3i c = tmp.GetCellIndex(t * Vec3f(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+  }
+}
+
+// ---------------------------------------------------------------- CSM3D
+double orc_interpolated_probability(void* grid, double x, double y, double z) {
+  const InterpolatedGrid ig(*G(grid));
+  return ig.GetProbability(x, y, z);
+}
+// One OccupiedSpaceCostFunction3D block: residuals[n], jac_t[n*3], jac_q[n*4]
+// (ambient, as ceres::AutoDiffCostFunction fills them); jac pointers may be null.
+void orc_occupied_space_evaluate(void* grid, const float* pts, int n, double scaling,
+                                 const double* t3, const double* q4, double* residuals,
+                                 double* jac_t, double* jac_q) {
+  const PointCloud cloud = ToCloud(pts, n);
+  auto f = std::make_shared<OccupiedSpaceCostFunction3D>(scaling, cloud, *G(grid));
+  ceres_like::ResidualBlock b = ceres_like::MakeAutoDiffBlock34(f, n);
+  b.evaluate(t3, q4, residuals, jac_t, jac_q);
+}
+double orc_rotation_delta_squared_cost(const double* q4, double scaling, const double* target4) {
+  const RotationDeltaCostFunctor3D f(scaling, Quatd(target4[0], target4[1], target4[2], target4[3]));
+  double r[3];
+  f(q4, r);
+  return r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+}
+// summary_out[10] = initial_cost, final_cost, num_successful, num_unsuccessful,
+//   num_iterations, num_residual_evals, num_jacobian_evals, termination_type, 0, 0
+void orc_csm3d_match(const double* occupied_space_weights, int k, double translation_weight,
+                     double rotation_weight, int only_optimize_yaw, int use_nonmonotonic_steps,
+                     int max_num_iterations, const double* target3, const double* init7,
+                     const float* const* pts, const int* n, void* const* grids, double* out7,
+                     double* summary_out) {
+  CeresScanMatcherOptions3D o;
+  o.occupied_space_weight.assign(occupied_space_weights, occupied_space_weights + k);
+  o.translation_weight = translation_weight;
+  o.rotation_weight = rotation_weight;
+  o.only_optimize_yaw = only_optimize_yaw != 0;
+  o.use_nonmonotonic_steps = use_nonmonotonic_steps != 0;
+  o.max_num_iterations = max_num_iterations;
+  std::vector<PointCloud> clouds;
+  for (int i = 0; i < k; ++i) clouds.push_back(ToCloud(pts[i], n[i]));
+  std::vector<CeresScanMatcher3D::PointCloudAndHybridGridPointers> pairs;
+  for (int i = 0; i < k; ++i) pairs.emplace_back(&clouds[i], G(grids[i]));
+  const CeresScanMatcher3D matcher(o);
+  Rigid3d pose;
+  ceres_like::Summary s;
+  matcher.Match(Vec3d(target3[0], target3[1], target3[2]), ToRigid(init7), pairs, &pose, &s);
+  FromRigid(pose, out7);
+  if (summary_out != nullptr) {
+    summary_out[0] = s.initial_cost;
+    summary_out[1] = s.final_cost;
+    summary_out[2] = s.num_successful_steps;
+    summary_out[3] = s.num_unsuccessful_steps;
+    summary_out[4] = s.num_iterations;
+    summary_out[5] = s.num_residual_evaluations;
+    summary_out[6] = s.num_jacobian_evaluations;
+    summary_out[7] = s.termination_type;
+    summary_out[8] = 0;
+    summary_out[9] = 0;
+  }
+}
+
+// ---------------------------------------------------------------- 2D (config 1, CPU only)
+void* orc_pg_new(double resolution, double max_x, double max_y, int num_x_cells, int num_y_cells) {
+  return new ProbabilityGrid(MapLimits{resolution, max_x, max_y, num_x_cells, num_y_cells});
+}
+void orc_pg_free(void* g) { delete static_cast<ProbabilityGrid*>(g); }
+void orc_pg_set_probability(void* g, int x, int y, float p) {
+  static_cast<ProbabilityGrid*>(g)->SetProbability(x, y, p);
+}
+float orc_pg_probability(void* g, int x, int y) {
+  return static_cast<ProbabilityGrid*>(g)->GetProbability(x, y);
+}
+void orc_pg_cell_index(void* g, float px, float py, int* out2) {
+  const Cell2 c = static_cast<ProbabilityGrid*>(g)->limits().GetCellIndex(px, py);
+  out2[0] = c.x; out2[1] = c.y;
+}
+void orc_pg_cells(void* g, uint16_t* out) {
+  const std::vector<uint16>& c = static_cast<ProbabilityGrid*>(g)->cells();
+  std::memcpy(out, c.data(), c.size() * sizeof(uint16_t));
+}
+void orc_pg_insert(void* g, const float* origin3, const float* returns, int n,
+                   double hit_probability, double miss_probability, int insert_free_space) {
+  InsertRangeData2D(static_cast<ProbabilityGrid*>(g), origin3[0], origin3[1], ToCloud(returns, n),
+                    static_cast<float>(hit_probability), static_cast<float>(miss_probability),
+                    insert_free_space != 0);
+}
+// init3 = [x, y, theta]; out3 likewise.  Returns the best score.
+double orc_rtcsm2d_match(const double* opts, const double* init3, const float* pts, int n, void* g,
+                         double* out3) {
+  const RealTimeCorrelativeScanMatcher2D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  return m.Match(init3, ToCloud(pts, n), *static_cast<ProbabilityGrid*>(g), out3);
+}
+// Scores one candidate (scan_index 0 of an unrotated scan, integer offsets) --
+// what the reference's own 2D test exercises.
+float orc_rtcsm2d_score_single(const double* opts, const float* pts, int n, void* g,
+                               int x_index_offset, int y_index_offset) {
+  const RealTimeCorrelativeScanMatcher2D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  return m.ScoreSingle(ToCloud(pts, n), *static_cast<ProbabilityGrid*>(g), x_index_offset,
+                       y_index_offset);
+}
+
+// ---------------------------------------------------------------- timing helper
+double orc_now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // extern "C"

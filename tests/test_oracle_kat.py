@@ -1,0 +1,352 @@
+"""Pins the CPU oracle against every known-answer test the reference holds for
+the scan-to-submap path.  Each test names the
+reference test file it restates (paths under
+/root/reference/src/cartographer/cartographer)."""
+import numpy as np
+import pytest
+
+SEVEN_POINTS = np.array([[-3, 2, 0], [-4, 2, 0], [-5, 2, 0], [-6, 2, 0],
+                         [-6, 3, 1], [-6, 4, 2], [-7, 3, 1]], dtype=np.float32)
+
+
+def is_nearly(pose, expected, eps):
+    """transform::IsNearly = Eigen isApprox on the 4x4 affine
+    (transform/rigid_transform_test_helpers.h:42-46):
+    ||A-B||_F <= eps * min(||A||_F, ||B||_F)."""
+    def mat(p):
+        w, x, y, z = p[3:7]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        M = np.eye(4)
+        M[:3, :3] = R
+        M[:3, 3] = p[:3]
+        return M
+    a, b = mat(pose), mat(expected)
+    return np.linalg.norm(a - b) <= eps * min(np.linalg.norm(a), np.linalg.norm(b))
+
+
+# ---------------------------------------------------------------- (i) hybrid_grid_test.cc:89-110
+def test_get_cell_index_rounding(orc):
+    g = orc.HybridGrid(2.0)
+    cases = [((0, 0, 0), (0, 0, 0)), ((0, 26, 10), (0, 13, 5)), ((14, 0, 10), (7, 0, 5)),
+             ((14, 26, 0), (7, 13, 0)), ((8.5, 11.5, 0.5), (4, 6, 0)), ((7.5, 12.5, 1.5), (4, 6, 1)),
+             ((6.5, 14.5, 2.5), (3, 7, 1)), ((5.5, 13.5, 3.5), (3, 7, 2))]
+    for p, want in cases:
+        assert tuple(g.get_cell_index(p)) == want
+    # negative half-way cases round away from zero (lround)
+    assert tuple(g.get_cell_index((-1.0, -3.0, -5.0))) == (-1, -2, -3)
+
+
+# hybrid_grid_test.cc:112-121
+def test_get_center_of_cell(orc):
+    g = orc.HybridGrid(2.0)
+    c = g.get_center_of_cell((3, 2, 1))
+    assert np.allclose(c, [6, 4, 2], atol=1e-6)
+    assert tuple(g.get_cell_index(c)) == (3, 2, 1)
+
+
+# hybrid_grid_test.cc:29-70
+def test_apply_odds(orc):
+    g = orc.HybridGrid(1.0)
+    for idx in [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1)]:
+        assert not g.is_known(idx)
+    g.set_probability((1, 0, 1), 0.5)
+    g.apply_lookup_table((1, 0, 1), orc.lookup_table_to_apply_odds(orc.odds(0.9)))
+    g.finish_update()
+    assert g.get_probability((1, 0, 1)) > 0.5
+    g.set_probability((0, 1, 0), 0.5)
+    g.apply_lookup_table((0, 1, 0), orc.lookup_table_to_apply_odds(orc.odds(0.1)))
+    g.finish_update()
+    assert g.get_probability((0, 1, 0)) < 0.5
+    g.apply_lookup_table((1, 1, 1), orc.lookup_table_to_apply_odds(orc.odds(0.42)))
+    assert abs(g.get_probability((1, 1, 1)) - 0.42) < 1e-4
+    # further updates ignored until FinishUpdate
+    g.apply_lookup_table((1, 1, 1), orc.lookup_table_to_apply_odds(orc.odds(0.9)))
+    assert abs(g.get_probability((1, 1, 1)) - 0.42) < 1e-4
+    g.finish_update()
+    g.apply_lookup_table((1, 1, 1), orc.lookup_table_to_apply_odds(orc.odds(0.9)))
+    assert g.get_probability((1, 1, 1)) > 0.42
+
+
+# hybrid_grid_test.cc:72-85
+def test_get_probability_unknown_neighbours(orc):
+    g = orc.HybridGrid(1.0)
+    g.set_probability(g.get_cell_index((0, 1, 1)), 0.9)
+    assert abs(g.get_probability(g.get_cell_index((0, 1, 1))) - 0.9) < 1e-6
+    for p in [(0, 2, 1), (1, 1, 1), (1, 2, 1)]:
+        assert not g.is_known(g.get_cell_index(p))
+
+
+# hybrid_grid_test.cc:123-222 (random 10000-cell round trip through the iterator)
+def test_random_grid_iteration_round_trip(orc):
+    rng = np.random.RandomState(1285120005 % (2 ** 32))
+    g = orc.HybridGrid(2.0)
+    xyz = np.stack([rng.randint(-50, 50, 10000), rng.randint(-60, 60, 10000),
+                    rng.randint(-70, 70, 10000)], axis=1)
+    vals = {}
+    for c in xyz:
+        p = float(rng.uniform(0.1, 0.9))
+        g.set_probability(c, p)
+        vals[tuple(c)] = orc.probability_to_value(p)
+    out_xyz, out_v = g.export_cells()
+    assert len(out_v) == len(vals)
+    for c, v in zip(out_xyz, out_v):
+        assert vals[tuple(c)] == v
+    # leaf export holds the same cells
+    origins, leaves = g.export_leaves()
+    assert int((leaves != 0).sum()) == len(vals)
+    assert np.all(origins % 8 == 0)
+
+
+# ---------------------------------------------------------------- (v) probability_values_test.cc
+def test_odds_conversions(orc):
+    for p in (0.1, 0.9, 0.5):
+        assert abs(orc.probability_from_odds(orc.odds(p)) - p) < 1e-6
+
+
+def test_value_correspondence_involution(orc):
+    L = orc.lib()
+    for i in range(32768):
+        assert L.orc_probability_value_to_correspondence_cost_value(
+            L.orc_correspondence_cost_value_to_probability_value(i)) == i
+        assert L.orc_correspondence_cost_value_to_probability_value(
+            L.orc_probability_value_to_correspondence_cost_value(i)) == i
+    for i in range(1, 32768):
+        m = i + 32768
+        assert L.orc_probability_value_to_correspondence_cost_value(
+            L.orc_correspondence_cost_value_to_probability_value(m)) == m
+        assert L.orc_correspondence_cost_value_to_probability_value(
+            L.orc_probability_value_to_correspondence_cost_value(m)) == m
+
+
+def test_conversion_lookup_tables(orc):
+    p = orc.value_to_probability_table()
+    c = orc.value_to_correspondence_cost_table()
+    assert abs(p[0] - (1.0 - c[0])) < 1e-6
+    assert np.all(np.abs(p[1:32768] - c[1:32768]) < 1e-6)
+    assert np.array_equal(p[:32768], p[32768:])
+    assert p[0] == np.float32(0.1) and abs(p[32767] - 0.9) < 1e-6
+
+
+def test_cell_update_tables(orc):
+    # probability_values_test.cc:72-118 (CellUpdate)
+    pt = orc.lookup_table_to_apply_odds(orc.odds(0.9))
+    ct = orc.lookup_table_to_apply_correspondence_cost_odds(orc.odds(0.9))
+    p = orc.value_to_probability_table()
+    c = orc.value_to_correspondence_cost_table()
+    assert abs(p[pt[0]] - (1 - c[ct[0]])) < 1e-6
+    assert np.all(pt >= 32768)
+    for i in range(0, 5000, 7):
+        prob = np.float32(i) / np.float32(5000) * np.float32(0.8) + np.float32(0.1)
+        vp = orc.probability_to_value(float(prob))
+        vc = orc.correspondence_cost_to_value(float(np.float32(1) - prob))
+        assert abs(vp - (32768 - vc)) <= 1
+        assert abs(p[pt[vp]] - (1 - c[ct[vc]])) < 5e-5
+
+
+# ---------------------------------------------------------------- (iv) range_data_inserter_3d_test.cc
+def _insert_test_cloud(orc, g):
+    g.insert((0, 0, -4), [[-3, -1, 4], [-2, 0, 4], [-1, 1, 4], [0, 2, 4]], 0.7, 0.4, 1000)
+
+
+def test_range_data_inserter_insert_point_cloud(orc):
+    g = orc.HybridGrid(1.0)
+    _insert_test_cloud(orc, g)
+    P = lambda x, y, z: g.get_probability(g.get_cell_index((x, y, z)))
+    K = lambda x, y, z: g.is_known(g.get_cell_index((x, y, z)))
+    for z in (-4, -3, -2):
+        assert abs(P(0, 0, z) - 0.4) < 1e-4
+    for x in range(-4, 5):
+        for y in range(-4, 5):
+            if x < -3 or x > 0 or y != x + 2:
+                assert not K(x, y, 4)
+            else:
+                assert abs(P(x, y, 4) - 0.7) < 1e-4
+
+
+def test_range_data_inserter_probability_progression(orc):
+    g = orc.HybridGrid(1.0)
+    _insert_test_cloud(orc, g)
+    P = lambda x, y, z: g.get_probability(g.get_cell_index((x, y, z)))
+    assert abs(P(-2, 0, 4) - 0.7) < 1e-4
+    assert abs(P(-2, 0, 3) - 0.4) < 1e-4
+    assert abs(P(0, 0, -3) - 0.4) < 1e-4
+    for _ in range(1000):
+        _insert_test_cloud(orc, g)
+    assert abs(P(-2, 0, 4) - 0.9) < 1e-3
+    assert abs(P(-2, 0, 3) - 0.1) < 1e-3
+    assert abs(P(0, 0, -3) - 0.1) < 1e-3
+
+
+# ---------------------------------------------------------------- (vi) voxel_filter_test.cc
+def test_voxel_filter_first_point_per_voxel(orc):
+    pc = np.array([[0, 0, 0], [0.1, -0.1, 0.1], [0.3, -0.1, 0], [0, 0, 0.1]], dtype=np.float32)
+    assert list(orc.voxel_filter(0.3, pc)) == [0, 2]
+
+
+def test_voxel_filter_large_coordinates(orc):
+    pc = np.array([[100000, 0, 0], [100000.001, -0.0001, 0.0001], [100000.003, -0.0001, 0],
+                   [-200000, 0, 0]], dtype=np.float32)
+    assert list(orc.voxel_filter(0.01, pc)) == [0, 3]
+
+
+def test_voxel_filter_many_in_one_voxel(orc):
+    pc = np.tile(np.array([[-100, 0.3, 0.4]], dtype=np.float32), (100, 1))
+    assert list(orc.voxel_filter(0.3, pc)) == [0]
+
+
+# ---------------------------------------------------------------- (iii) interpolated_grid_test.cc
+def _interp_grid(orc):
+    g = orc.HybridGrid(0.1)
+    for p in SEVEN_POINTS:
+        g.set_probability(g.get_cell_index(p), 1.0)
+    return g
+
+
+def test_interpolates_grid_points(orc):
+    g = _interp_grid(orc)
+    res = float(np.float32(0.1))
+    z = -1.0
+    worst = 0.0
+    while z < 3.0:
+        y = 1.0
+        while y < 5.0:
+            x = -8.0
+            while x < -2.0:
+                want = g.get_probability(g.get_cell_index((x, y, z)))
+                got = g.interpolated_probability(x, y, z)
+                worst = max(worst, abs(want - got))
+                x += res
+            y += res
+        z += res * 4  # every 4th z-slab keeps the python loop short
+    assert worst < 1e-6
+
+
+def test_interpolation_monotonic_in_x(orc):
+    g = _interp_grid(orc)
+    res = float(np.float32(0.1))
+    step = res / 10.0
+    for (y, z) in [(2.0, 0.0), (3.0, 1.0), (4.0, 2.0)]:
+        x = -8.0
+        while x < -2.0:
+            p0 = np.float32(g.get_probability(g.get_cell_index((x, y, z))))
+            p1 = np.float32(g.get_probability(g.get_cell_index((x + res, y, z))))
+            d = float(p1 - p0)
+            if abs(d) >= 1e-6:
+                s = step
+                while s < res - 2 * step:
+                    a = g.interpolated_probability(x + s + step, y, z)
+                    b = g.interpolated_probability(x + s, y, z)
+                    assert d * (a - b) > 0
+                    s += step
+            x += res
+
+
+# ---------------------------------------------------------------- (ii) real_time_correlative_scan_matcher_3d_test.cc
+RTCSM_OPTS = dict(linear_search_window=0.3, angular_search_window=np.deg2rad(1.0),
+                  translation_delta_cost_weight=1e-1, rotation_delta_cost_weight=1.0)
+EXPECTED = np.array([-1.0, 0, 0, 1, 0, 0, 0])
+
+
+def _rtcsm_grid(orc, resolution):
+    g = orc.HybridGrid(resolution)
+    moved = orc.transform_points(EXPECTED.astype(np.float32), SEVEN_POINTS)
+    for p in moved:
+        g.set_probability(g.get_cell_index(p), 1.0)
+    return g
+
+
+@pytest.mark.parametrize("init", [
+    orc_pose for orc_pose in [
+        ((-1.0, 0, 0), None), ((-0.8, 0, 0), None), ((-1.0, 0, -0.2), None), ((-0.9, -0.2, 0.2), None),
+        ((-1.0, 0, 0), (0.8 / 180 * np.pi, (1, 0, 0))), ((-1.0, 0, 0), (0.8 / 180 * np.pi, (0, 1, 0))),
+        ((-1.0, 0, 0), (0.8 / 180 * np.pi, (0, 1, 1)))]])
+def test_rtcsm3d_recovers_pose(orc, init):
+    t, aa = init
+    q = (1, 0, 0, 0) if aa is None else orc.angle_axis_quat(*aa)
+    g = _rtcsm_grid(orc, 0.1)
+    r = orc.rtcsm3d_match(RTCSM_OPTS, orc.pose(t, q), SEVEN_POINTS, g)
+    assert r["score"] > 0
+    assert is_nearly(r["pose"], EXPECTED, 1e-3), r["pose"]
+
+
+def test_rtcsm3d_window_counts(orc):
+    # reference unit test window = 7^3 x 3^3 = 9261 candidates
+    w = orc.rtcsm3d_window(RTCSM_OPTS, 0.1, SEVEN_POINTS)
+    assert (w["linear_window"], w["angular_window"]) == (3, 1)
+    tr, ca = orc.rtcsm3d_candidates(RTCSM_OPTS, 0.1, SEVEN_POINTS, orc.pose())
+    assert len(tr) == 9261
+    # default config: lround(0.15 / double(0.1f)) == 1
+    d = dict(RTCSM_OPTS, linear_search_window=0.15)
+    assert orc.rtcsm3d_window(d, 0.1, SEVEN_POINTS)["linear_window"] == 1
+    # D-LIOM override: lround(0.1 / double(0.2f)) == 0
+    d = dict(RTCSM_OPTS, linear_search_window=0.1)
+    assert orc.rtcsm3d_window(d, 0.2, SEVEN_POINTS)["linear_window"] == 0
+
+
+# ---------------------------------------------------------------- (ii) ceres_scan_matcher_3d_test.cc
+CSM_OPTS = dict(occupied_space_weight=[1.0], translation_weight=0.01, rotation_weight=0.1,
+                only_optimize_yaw=False, use_nonmonotonic_steps=True, max_num_iterations=10)
+
+
+def _csm_run(orc, init, cloud=SEVEN_POINTS, expected=EXPECTED):
+    g = _rtcsm_grid(orc, 1.0)
+    r = orc.csm3d_match(CSM_OPTS, init[:3], init, [(cloud, g)])
+    assert abs(r["final_cost"]) < 1e-2, r
+    assert is_nearly(r["pose"], expected, 3e-2), r
+    return r
+
+
+@pytest.mark.parametrize("t", [(-1.0, 0, 0), (-0.8, 0, 0), (-1.0, 0, -0.2), (-0.9, -0.2, 0.2)])
+def test_csm3d_translation_cases(orc, t):
+    _csm_run(orc, orc.pose(t))
+
+
+def test_csm3d_full_pose_correction(orc):
+    # ...find the rotation around z starting with a rotation around x.
+    additional = orc.pose((0, 0, 0), orc.angle_axis_quat(0.05, (0, 0, 1)))
+    cloud = orc.transform_points(additional.astype(np.float32), SEVEN_POINTS)
+    expected = orc.rigid_multiply(EXPECTED, orc.rigid_inverse(additional))
+    init = orc.pose((-0.95, -0.05, 0.05), orc.angle_axis_quat(0.05, (1, 0, 0)))
+    _csm_run(orc, init, cloud, expected)
+
+
+# ---------------------------------------------------------------- (viii) rotation_delta_cost_functor_3d_test.cc
+def _qmul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx])
+
+
+def test_rotation_delta_cost(orc):
+    ident = np.array([1.0, 0, 0, 0])
+    assert abs(orc.rotation_delta_squared_cost(ident, 1.0, ident)) < 1e-8
+    rot = orc.angle_axis_quat(0.9, (0.2, 0.1, 0.3), True)
+    assert abs(orc.rotation_delta_squared_cost(rot, 1.0, rot)) < 1e-8
+    s, angle = 1.2, 0.8
+    rotation = orc.angle_axis_quat(angle, (0.2, 0.1, 0.8), True)
+    target = orc.angle_axis_quat(0.2, (-0.5, 0.3, 0.4), True)
+    want = (s * np.sin(angle / 2)) ** 2
+    assert abs(orc.rotation_delta_squared_cost(rotation, s, ident) - want) < 1e-8
+    assert abs(orc.rotation_delta_squared_cost(_qmul(target, rotation), s, target) - want) < 1e-8
+    assert abs(orc.rotation_delta_squared_cost(_qmul(rotation, target), s, target) - want) < 1e-8
+
+
+# ---------------------------------------------------------------- (vii) real_time_correlative_scan_matcher_2d_test.cc
+def test_rtcsm2d_scores(orc):
+    pg = orc.ProbabilityGrid(0.05, (0.05, 0.25), 6, 6)
+    pc = np.array([[0.025, 0.175, 0], [-0.025, 0.175, 0], [-0.075, 0.175, 0], [-0.125, 0.175, 0],
+                   [-0.125, 0.125, 0], [-0.125, 0.075, 0], [-0.125, 0.025, 0]], dtype=np.float32)
+    pg.insert((0, 0, 0), pc, 0.7, 0.4, True)
+    opts = dict(linear_search_window=0.6, angular_search_window=0.16,
+                translation_delta_cost_weight=0.0, rotation_delta_cost_weight=0.0)
+    perfect = orc.rtcsm2d_score_single(opts, pc, pg, 0, 0)
+    assert abs(perfect - 0.7) < 1e-2
+    partial = orc.rtcsm2d_score_single(opts, pc, pg, 0, 1)
+    assert 0.7 * 3.0 / 7.0 < partial < 0.7
+    # full Match from the true pose stays at the true pose with the perfect score
+    r = orc.rtcsm2d_match(opts, (0.0, 0.0, 0.0), pc, pg)
+    assert abs(r["score"] - 0.7) < 1e-2
+    assert np.allclose(r["pose"], 0.0, atol=1e-9)
