@@ -1,0 +1,359 @@
+// Context, scratch memory, status strings, probability-value tables and the
+// device-resident point cloud of libdliom.so.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "internal.h"
+
+namespace dliom {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const char* what, hipError_t e, const char* file, int line) {
+  char buf[512];
+  std::snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  g_last_error = buf;
+}
+
+int DevBuf::reserve(size_t bytes) {
+  if (bytes <= cap) return DLIOM_OK;
+  size_t want = std::max(bytes, cap + cap / 2);
+  want = (want + 255) & ~static_cast<size_t>(255);
+  if (p != nullptr) {
+    DLIOM_HIP_TRY(hipFree(p));
+    p = nullptr;
+    cap = 0;
+  }
+  DLIOM_HIP_TRY(hipMalloc(&p, want));
+  cap = want;
+  return DLIOM_OK;
+}
+
+void DevBuf::release() {
+  if (p != nullptr) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+// max_i ||p_i|| with Eigen's Vector3f reduction order x*x + (y*y + z*z).
+// sqrt is monotone and correctly rounded, so max of norms == sqrt of the max
+// squared norm (real_time_correlative_scan_matcher_3d.cc:62-66).
+float cloud_max_norm(const float* p, int64_t n) {
+  float best = 0.f;
+  for (int64_t i = 0; i < n; ++i) {
+    const float x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+    const float s = x * x + (y * y + z * z);
+    best = s > best ? s : best;
+  }
+  return std::sqrt(best);
+}
+
+// Smallest DynamicGrid bits (>= 1) whose index range [-32<<b, 32<<b) holds
+// [min_index, max_index]; 9 when even bits == 8 is too small.
+int needed_bits_for_cell_range(int min_index, int max_index) {
+  for (int b = 1; b <= 8; ++b) {
+    const int half = 32 << b;
+    if (min_index >= -half && max_index < half) return b;
+  }
+  return 9;
+}
+
+__global__ void aos_to_soa_kernel(const float* __restrict__ aos, int64_t n, int64_t n_padded,
+                                  float* __restrict__ x, float* __restrict__ y,
+                                  float* __restrict__ z) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_padded) return;
+  const bool in = i < n;
+  x[i] = in ? aos[3 * i] : 0.f;
+  y[i] = in ? aos[3 * i + 1] : 0.f;
+  z[i] = in ? aos[3 * i + 2] : 0.f;
+}
+
+static int64_t pad_points(int64_t n) { return ((n + 1023) / 1024) * 1024; }
+
+// Device layout of a cloud inside one allocation: [aos staging | x | y | z].
+static size_t cloud_bytes(int64_t n) {
+  return static_cast<size_t>(n) * 12 + static_cast<size_t>(pad_points(n)) * 12 + 1024;
+}
+
+static int fill_cloud(dliom_ctx* ctx, char* base, const float* points_xyz, int64_t n,
+                      dliom_cloud* out) {
+  const int64_t np = pad_points(n);
+  float* aos = reinterpret_cast<float*>(base);
+  const size_t soa_off = (static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255);
+  float* x = reinterpret_cast<float*>(base + soa_off);
+  float* y = x + np;
+  float* z = y + np;
+  if (n > 0) {
+    DLIOM_HIP_TRY(hipMemcpyAsync(aos, points_xyz, static_cast<size_t>(n) * 12,
+                                 hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (np > 0) {
+    const int threads = 256;
+    const unsigned blocks = static_cast<unsigned>((np + threads - 1) / threads);
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, aos, n, np, x,
+                       y, z);
+    DLIOM_HIP_TRY(hipGetLastError());
+  }
+  out->ctx = ctx;
+  out->n = n;
+  out->n_padded = np;
+  out->d_x = x;
+  out->d_y = y;
+  out->d_z = z;
+  out->max_norm = cloud_max_norm(points_xyz, n);
+  return DLIOM_OK;
+}
+
+int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud* out,
+                size_t scratch_offset_bytes) {
+  // All staged clouds of one call must be reserved up front by the caller
+  // through a single reserve (offsets into ctx->points); here we only fill.
+  char* base = static_cast<char*>(ctx->points.p) + scratch_offset_bytes;
+  out->owned_by_ctx_scratch = true;
+  return fill_cloud(ctx, base, points_xyz, n, out);
+}
+
+size_t staged_cloud_bytes(int64_t n) { return cloud_bytes(n); }
+
+}  // namespace dliom
+
+using namespace dliom;
+
+int dliom_ctx::begin_span(int id) {
+  if (!profiling) return -1;
+  hipEvent_t ev[2];
+  for (int k = 0; k < 2; ++k) {
+    if (!event_pool.empty()) {
+      ev[k] = event_pool.back();
+      event_pool.pop_back();
+    } else if (hipEventCreate(&ev[k]) != hipSuccess) {
+      return -1;
+    }
+  }
+  (void)hipEventRecord(ev[0], stream);
+  spans.push_back(Span{ev[0], ev[1], id});
+  return static_cast<int>(spans.size()) - 1;
+}
+
+void dliom_ctx::end_span(int span) {
+  if (span < 0) return;
+  (void)hipEventRecord(spans[span].b, stream);
+}
+
+int dliom_ctx::collect_spans() {
+  DLIOM_HIP_TRY(hipStreamSynchronize(stream));
+  for (const Span& s : spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      kernel_ms[s.id] += ms;
+      kernel_launches[s.id] += 1;
+    }
+    event_pool.push_back(s.a);
+    event_pool.push_back(s.b);
+  }
+  spans.clear();
+  return DLIOM_OK;
+}
+
+extern "C" {
+
+const char* dliom_status_string(int status) {
+  switch (status) {
+    case DLIOM_OK: return "ok";
+    case DLIOM_ERR_INVALID_ARGUMENT: return "invalid argument (null pointer or bad size)";
+    case DLIOM_ERR_HIP: return "HIP runtime error";
+    case DLIOM_ERR_NO_DEVICE: return "no HIP device";
+    case DLIOM_ERR_SCORE_NOT_POSITIVE: return "CHECK_GT(score, 0) failed";
+    case DLIOM_ERR_WEIGHTS: return "occupied_space_weight count/positivity check failed";
+    case DLIOM_ERR_GRID_EXTENT: return "grid would need more than 8 bits (CHECK_LE(new_bits, 8))";
+    case DLIOM_ERR_RAY_TOO_LONG: return "ray longer than 1<<15 cells";
+    case DLIOM_ERR_EMPTY_CLOUD: return "empty point cloud";
+    case DLIOM_ERR_CAPACITY: return "output buffer too small";
+    case DLIOM_ERR_SOLVER: return "solver failure";
+    default: return "unknown status";
+  }
+}
+
+const char* dliom_last_error(void) { return g_last_error.c_str(); }
+
+int dliom_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int ctx_create_common(int device_id, hipStream_t stream, bool owns, dliom_ctx** out) {
+  if (out == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return DLIOM_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= n) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(device_id));
+  dliom_ctx* ctx = new dliom_ctx;
+  ctx->device = device_id;
+  if (owns) {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      set_last_error("hipStreamCreateWithFlags", e, __FILE__, __LINE__);
+      delete ctx;
+      return DLIOM_ERR_HIP;
+    }
+    ctx->owns_stream = true;
+  } else {
+    ctx->stream = stream;
+  }
+  ctx->pinned_bytes = 1 << 20;
+  hipError_t e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    set_last_error("hipHostMalloc", e, __FILE__, __LINE__);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DLIOM_ERR_HIP;
+  }
+  *out = ctx;
+  return DLIOM_OK;
+}
+
+int dliom_ctx_create(int device_id, dliom_ctx** out) {
+  return ctx_create_common(device_id, nullptr, true, out);
+}
+
+int dliom_ctx_create_on_stream(int device_id, void* hip_stream, dliom_ctx** out) {
+  return ctx_create_common(device_id, static_cast<hipStream_t>(hip_stream), false, out);
+}
+
+int dliom_ctx_destroy(dliom_ctx* ctx) {
+  if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& s : ctx->spans) {
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
+  ctx->points.release();
+  ctx->cand.release();
+  ctx->sums.release();
+  ctx->bounds.release();
+  ctx->rescore.release();
+  ctx->partials.release();
+  ctx->misc.release();
+  if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
+  if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return DLIOM_OK;
+}
+
+int dliom_ctx_synchronize(dliom_ctx* ctx) {
+  if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
+int dliom_ctx_set_profiling(dliom_ctx* ctx, int enabled) {
+  if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  ctx->profiling = enabled != 0;
+  return DLIOM_OK;
+}
+
+int dliom_ctx_reset_profiling(dliom_ctx* ctx) {
+  if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_TRY(ctx->collect_spans());
+  for (int i = 0; i < DLIOM_KERNEL_COUNT; ++i) {
+    ctx->kernel_ms[i] = 0;
+    ctx->kernel_launches[i] = 0;
+  }
+  return DLIOM_OK;
+}
+
+int dliom_ctx_kernel_time(dliom_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches) {
+  if (ctx == nullptr || kernel_id < 0 || kernel_id >= DLIOM_KERNEL_COUNT)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_TRY(ctx->collect_spans());
+  if (total_ms != nullptr) *total_ms = ctx->kernel_ms[kernel_id];
+  if (launches != nullptr) *launches = ctx->kernel_launches[kernel_id];
+  return DLIOM_OK;
+}
+
+// ---- probability value tables (host, float arithmetic as in the reference) -------
+// mapping/probability_values.h:32-44,48-54 and probability_values.cc:27-36,73-83.
+static inline float clampf(float v, float lo, float hi) { return v > hi ? hi : (v < lo ? lo : v); }
+static const float kMinP = 0.1f;
+static const float kMaxP = 1.f - 0.1f;
+
+static inline uint16_t probability_to_value(float p) {
+  const int v =
+      static_cast<int>(std::lround((clampf(p, kMinP, kMaxP) - kMinP) * (32766.f / (kMaxP - kMinP)))) + 1;
+  return static_cast<uint16_t>(v);
+}
+static inline float value_to_probability(int v) {
+  if (v == 0) return kMinP;
+  const float kScale = (kMaxP - kMinP) / 32766.f;
+  return v * kScale + (kMinP - kScale);
+}
+
+float dliom_odds(float probability) { return probability / (1.f - probability); }
+
+int dliom_compute_lookup_table_to_apply_odds(float odds, uint16_t* t) {
+  if (t == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  t[0] = static_cast<uint16_t>(probability_to_value(odds / (odds + 1.f)) + 32768u);
+  for (int cell = 1; cell != 32768; ++cell) {
+    const float p = value_to_probability(cell);
+    const float o = odds * (p / (1.f - p));
+    t[cell] = static_cast<uint16_t>(probability_to_value(o / (o + 1.f)) + 32768u);
+  }
+  return DLIOM_OK;
+}
+
+int dliom_value_to_probability_table(float* t) {
+  if (t == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  for (int v = 0; v != 32768; ++v) {
+    t[v] = value_to_probability(v);
+    t[v + 32768] = t[v];
+  }
+  return DLIOM_OK;
+}
+
+// ---- device-resident cloud --------------------------------------------------------
+int dliom_cloud_create(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud** out) {
+  if (ctx == nullptr || out == nullptr || n < 0 || (n > 0 && points_xyz == nullptr))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  void* base = nullptr;
+  DLIOM_HIP_TRY(hipMalloc(&base, staged_cloud_bytes(n)));
+  dliom_cloud* c = new dliom_cloud;
+  c->owned_by_ctx_scratch = false;
+  int s = fill_cloud(ctx, static_cast<char*>(base), points_xyz, n, c);
+  if (s == DLIOM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = DLIOM_ERR_HIP;
+  if (s != DLIOM_OK) {
+    (void)hipFree(base);
+    delete c;
+    return s;
+  }
+  // the allocation base is recoverable in dliom_cloud_destroy: base = (char*)d_x - soa_off
+  *out = c;
+  return DLIOM_OK;
+}
+
+int dliom_cloud_destroy(dliom_cloud* cloud) {
+  if (cloud == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (!cloud->owned_by_ctx_scratch && cloud->d_x != nullptr) {
+    const size_t soa_off = (static_cast<size_t>(cloud->n) * 12 + 255) & ~static_cast<size_t>(255);
+    void* base = reinterpret_cast<char*>(cloud->d_x) - soa_off;
+    (void)hipFree(base);
+  }
+  delete cloud;
+  return DLIOM_OK;
+}
+
+int dliom_cloud_size(const dliom_cloud* cloud, int64_t* n) {
+  if (cloud == nullptr || n == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *n = cloud->n;
+  return DLIOM_OK;
+}
+
+}  // extern "C"

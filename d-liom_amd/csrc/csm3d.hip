@@ -1,0 +1,641 @@
+// CeresScanMatcher3D on gfx950.
+//
+// Replaces mapping/internal/3d/scan_matching/ceres_scan_matcher_3d.cc:71-123 together with the
+// residual functors it stacks:
+//   occupied_space_cost_function_3d.h:50-80, interpolated_grid.h:51-146 (device kernel below),
+//   translation_delta_cost_functor_3d.h:39-45, rotation_delta_cost_functor_3d.h:43-66 (6 scalar
+//   residuals, evaluated on the host), optimization/ceres_pose.cc:30-44 (t[3], q[4] = w,x,y,z).
+//
+// The reference hands Ceres a (N_hi+N_lo+6) x 6 Jacobian and lets DENSE_QR factor it.  Here one
+// kernel evaluates every occupied-space residual together with its ANALYTIC Jacobian row and
+// reduces straight into the 6x6 normal equations (21 unique J^T J entries + 6 J^T r + cost):
+// the Jacobian never exists in memory.  The stacked J is tall-skinny N x 6 -> 21 length-N dot
+// products; that is wave-reduction work, not an MFMA-shaped GEMM.
+// The Levenberg-Marquardt outer loop restates Ceres 1.13's trust-region minimizer
+// (jacobi scaling, radius update, tolerances) on those 6x6 systems.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "device_common.h"
+
+namespace dliom {
+
+constexpr int kCsmBlock = 256;
+constexpr int kAcc = 28;  // 21 JtJ (upper triangle, row-major) + 6 Jtr + 1 sum r^2
+
+struct CsmCloudArg {
+  GridView g;
+  const float* x;
+  const float* y;
+  const float* z;
+  int n;
+  double scale;  // occupied_space_weight / sqrt(n)
+};
+struct CsmArgs {
+  CsmCloudArg cloud[DLIOM_MAX_CLOUDS];
+  int num_clouds;
+  int total_points;
+  double t[3];
+  double q[4];      // w,x,y,z (not normalised, as in the reference's Jet evaluation)
+  double plus[12];  // d q / d local, 4 x nloc row-major (QuaternionParameterization::ComputeJacobian)
+  int nloc;         // 3, or 1 for the yaw-only parameterisation
+};
+
+__device__ __forceinline__ double lut_probability(unsigned v, float k_scale, float k_offset,
+                                                  float k_unknown) {
+  v &= 0x7FFFu;
+  const float p = v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset;
+  return static_cast<double>(p);
+}
+
+// One point: residual r = s (1 - P(T p)) and its 6 tangent-space derivatives.
+__device__ __forceinline__ void csm_point(const CsmArgs& a, const CsmCloudArg& c, int i,
+                                          float k_scale, float k_offset, float k_unknown,
+                                          double* r_out, double jrow[6]) {
+  const double vx = static_cast<double>(c.x[i]);
+  const double vy = static_cast<double>(c.y[i]);
+  const double vz = static_cast<double>(c.z[i]);
+  const double qw = a.q[0], ux = a.q[1], uy = a.q[2], uz = a.q[3];
+  // Eigen _transformVector on doubles: uv = 2 (u x v); world = (v + w uv) + u x uv, then + t
+  double uvx = uy * vz - uz * vy, uvy = uz * vx - ux * vz, uvz = ux * vy - uy * vx;
+  uvx = uvx + uvx;
+  uvy = uvy + uvy;
+  uvz = uvz + uvz;
+  const double cx = uy * uvz - uz * uvy, cy = uz * uvx - ux * uvz, cz = ux * uvy - uy * uvx;
+  const double wx = ((vx + qw * uvx) + cx) + a.t[0];
+  const double wy = ((vy + qw * uvy) + cy) + a.t[1];
+  const double wz = ((vz + qw * uvz) + cz) + a.t[2];
+
+  // interpolated_grid.h:123-139: cell of the point (double -> float), centre in float, step down
+  // where the float centre exceeds the double coordinate; x2 = x1 + resolution in float.
+  const float res = c.g.resolution;
+  const int ix0 = cell_of(static_cast<float>(wx), res);
+  const int iy0 = cell_of(static_cast<float>(wy), res);
+  const int iz0 = cell_of(static_cast<float>(wz), res);
+  float lx = static_cast<float>(ix0) * res, ly = static_cast<float>(iy0) * res,
+        lz = static_cast<float>(iz0) * res;
+  if (static_cast<double>(lx) > wx) lx -= res;
+  if (static_cast<double>(ly) > wy) ly -= res;
+  if (static_cast<double>(lz) > wz) lz -= res;
+  const double x1 = lx, y1 = ly, z1 = lz;
+  const double x2 = static_cast<double>(lx + res), y2 = static_cast<double>(ly + res),
+               z2 = static_cast<double>(lz + res);
+  const int ix = cell_of(lx, res), iy = cell_of(ly, res), iz = cell_of(lz, res);
+  const double q111 = lut_probability(grid_value(c.g, ix, iy, iz), k_scale, k_offset, k_unknown);
+  const double q112 = lut_probability(grid_value(c.g, ix, iy, iz + 1), k_scale, k_offset, k_unknown);
+  const double q121 = lut_probability(grid_value(c.g, ix, iy + 1, iz), k_scale, k_offset, k_unknown);
+  const double q122 = lut_probability(grid_value(c.g, ix, iy + 1, iz + 1), k_scale, k_offset, k_unknown);
+  const double q211 = lut_probability(grid_value(c.g, ix + 1, iy, iz), k_scale, k_offset, k_unknown);
+  const double q212 = lut_probability(grid_value(c.g, ix + 1, iy, iz + 1), k_scale, k_offset, k_unknown);
+  const double q221 = lut_probability(grid_value(c.g, ix + 1, iy + 1, iz), k_scale, k_offset, k_unknown);
+  const double q222 = lut_probability(grid_value(c.g, ix + 1, iy + 1, iz + 1), k_scale, k_offset, k_unknown);
+
+  // Jet / scalar multiplies by the reciprocal (ceres/jet.h operator/(Jet, T)).
+  const double inv_dx = 1.0 / (x2 - x1), inv_dy = 1.0 / (y2 - y1), inv_dz = 1.0 / (z2 - z1);
+  const double nx = (wx - x1) * inv_dx, ny = (wy - y1) * inv_dy, nz = (wz - z1) * inv_dz;
+  const double nxx = nx * nx, nxxx = nx * nxx;
+  const double nyy = ny * ny, nyyy = ny * nyy;
+  const double nzz = nz * nz, nzzz = nz * nzz;
+  // interpolated_grid.h:88-102, z then y then x; d(.)/dn alongside.
+  const double q11 = (q111 - q112) * nzzz * 2. + (q112 - q111) * nzz * 3. + q111;
+  const double q12 = (q121 - q122) * nzzz * 2. + (q122 - q121) * nzz * 3. + q121;
+  const double q21 = (q211 - q212) * nzzz * 2. + (q212 - q211) * nzz * 3. + q211;
+  const double q22 = (q221 - q222) * nzzz * 2. + (q222 - q221) * nzz * 3. + q221;
+  const double d11 = (q111 - q112) * nzz * 6. + (q112 - q111) * nz * 6.;
+  const double d12 = (q121 - q122) * nzz * 6. + (q122 - q121) * nz * 6.;
+  const double d21 = (q211 - q212) * nzz * 6. + (q212 - q211) * nz * 6.;
+  const double d22 = (q221 - q222) * nzz * 6. + (q222 - q221) * nz * 6.;
+  const double q1 = (q11 - q12) * nyyy * 2. + (q12 - q11) * nyy * 3. + q11;
+  const double q2 = (q21 - q22) * nyyy * 2. + (q22 - q21) * nyy * 3. + q21;
+  const double q1_z = (d11 - d12) * nyyy * 2. + (d12 - d11) * nyy * 3. + d11;
+  const double q2_z = (d21 - d22) * nyyy * 2. + (d22 - d21) * nyy * 3. + d21;
+  const double q1_y = (q11 - q12) * nyy * 6. + (q12 - q11) * ny * 6.;
+  const double q2_y = (q21 - q22) * nyy * 6. + (q22 - q21) * ny * 6.;
+  const double P = (q1 - q2) * nxxx * 2. + (q2 - q1) * nxx * 3. + q1;
+  const double P_nx = (q1 - q2) * nxx * 6. + (q2 - q1) * nx * 6.;
+  const double P_ny = (q1_y - q2_y) * nxxx * 2. + (q2_y - q1_y) * nxx * 3. + q1_y;
+  const double P_nz = (q1_z - q2_z) * nxxx * 2. + (q2_z - q1_z) * nxx * 3. + q1_z;
+  const double gx = P_nx * inv_dx, gy = P_ny * inv_dy, gz = P_nz * inv_dz;  // dP/dworld
+
+  const double s = c.scale;
+  *r_out = s * (1. - P);
+  // dr/dworld = -s * grad P ; dworld/dt = I
+  const double ax = -s * gx, ay = -s * gy, az = -s * gz;
+  jrow[0] = ax;
+  jrow[1] = ay;
+  jrow[2] = az;
+  // dworld/dq for f(w,u) = v + 2 w (u x v) + 2 u x (u x v):
+  //   d/dw   = 2 (u x v) = uv
+  //   d/du_k = 2 w (e_k x v) + 2 e_k x (u x v) + 2 u x (e_k x v)
+  const double hx = 0.5 * uvx, hy = 0.5 * uvy, hz = 0.5 * uvz;  // u x v (exact halving)
+  double dq[4];
+  dq[0] = ax * uvx + ay * uvy + az * uvz;
+  {
+    // e_x x v = (0, -vz, vy); e_x x h = (0, -hz, hy); u x (e_x x v)
+    const double ex = 0., ey = -vz, ez = vy;
+    const double fx = 0., fy = -hz, fz = hy;
+    const double gxv = uy * ez - uz * ey, gyv = uz * ex - ux * ez, gzv = ux * ey - uy * ex;
+    const double dxw = 2. * (qw * ex + fx + gxv), dyw = 2. * (qw * ey + fy + gyv),
+                 dzw = 2. * (qw * ez + fz + gzv);
+    dq[1] = ax * dxw + ay * dyw + az * dzw;
+  }
+  {
+    const double ex = vz, ey = 0., ez = -vx;
+    const double fx = hz, fy = 0., fz = -hx;
+    const double gxv = uy * ez - uz * ey, gyv = uz * ex - ux * ez, gzv = ux * ey - uy * ex;
+    const double dxw = 2. * (qw * ex + fx + gxv), dyw = 2. * (qw * ey + fy + gyv),
+                 dzw = 2. * (qw * ez + fz + gzv);
+    dq[2] = ax * dxw + ay * dyw + az * dzw;
+  }
+  {
+    const double ex = -vy, ey = vx, ez = 0.;
+    const double fx = -hy, fy = hx, fz = 0.;
+    const double gxv = uy * ez - uz * ey, gyv = uz * ex - ux * ez, gzv = ux * ey - uy * ex;
+    const double dxw = 2. * (qw * ex + fx + gxv), dyw = 2. * (qw * ey + fy + gyv),
+                 dzw = 2. * (qw * ez + fz + gzv);
+    dq[3] = ax * dxw + ay * dyw + az * dzw;
+  }
+  // tangent space: J_local = J_ambient(1x4) * plus(4 x nloc)
+  jrow[3] = jrow[4] = jrow[5] = 0.;
+  for (int c2 = 0; c2 < a.nloc; ++c2) {
+    double acc = 0.;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += dq[k] * a.plus[k * a.nloc + c2];
+    jrow[3 + c2] = acc;
+  }
+}
+
+// Every thread strides over the stacked clouds, accumulates its 28 sums in registers, then the
+// block reduces them through LDS in a FIXED order (deterministic run to run).
+__global__ __launch_bounds__(kCsmBlock) void csm_eval_kernel(CsmArgs a, float k_scale, float k_offset,
+                                                             float k_unknown,
+                                                             double* __restrict__ partials) {
+  double acc[kAcc];
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) acc[k] = 0.;
+  const int stride = gridDim.x * blockDim.x;
+  for (int ci = 0; ci < a.num_clouds; ++ci) {  // uniform: the cloud descriptor stays in SGPRs
+    const CsmCloudArg& c = a.cloud[ci];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += stride) {
+      double r, j[6];
+      csm_point(a, c, i, k_scale, k_offset, k_unknown, &r, j);
+      int idx = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = p; q < 6; ++q) acc[idx++] += j[p] * j[q];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) acc[21 + p] += j[p] * r;
+      acc[27] += r * r;
+    }
+  }
+  __shared__ double red[kCsmBlock];
+  for (int k = 0; k < kAcc; ++k) {
+    red[threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int off = kCsmBlock / 2; off > 0; off >>= 1) {
+      if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x * kAcc + k] = red[0];
+    __syncthreads();
+  }
+}
+
+__global__ void csm_final_reduce_kernel(const double* __restrict__ partials, int num_blocks,
+                                        double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= kAcc) return;
+  double s = 0.;
+  for (int b = 0; b < num_blocks; ++b) s += partials[b * kAcc + k];
+  out[k] = s;
+}
+
+// ---------------------------------------------------------------------------------- host side
+struct Normal {
+  double H[36];  // J^T J, full symmetric, row-major
+  double g[6];   // J^T r
+  double cost;   // 1/2 sum r^2
+};
+
+struct CsmProblem {
+  dliom_ctx* ctx;
+  const dliom_csm_options* o;
+  CsmArgs args;  // clouds, scales; t/q/plus filled per evaluation
+  double target_t[3];
+  double init_q[4];
+  int nloc;
+  int num_blocks;
+  double* d_partials;
+  double* d_out;
+  int evaluations;
+};
+
+static void quat_product(const double z[4], const double w[4], double zw[4]) {
+  zw[0] = z[0] * w[0] - z[1] * w[1] - z[2] * w[2] - z[3] * w[3];
+  zw[1] = z[0] * w[1] + z[1] * w[0] + z[2] * w[3] - z[3] * w[2];
+  zw[2] = z[0] * w[2] - z[1] * w[3] + z[2] * w[0] + z[3] * w[1];
+  zw[3] = z[0] * w[3] + z[1] * w[2] - z[2] * w[1] + z[3] * w[0];
+}
+
+// QuaternionParameterization / YawOnlyQuaternionPlus (rotation_parameterization.h:27-39)
+static void plus_jacobian(const double q[4], int nloc, double j[12]) {
+  if (nloc == 3) {
+    j[0] = -q[1]; j[1] = -q[2]; j[2] = -q[3];
+    j[3] = q[0];  j[4] = q[3];  j[5] = -q[2];
+    j[6] = -q[3]; j[7] = q[0];  j[8] = q[1];
+    j[9] = q[2];  j[10] = -q[1]; j[11] = q[0];
+  } else {
+    j[0] = -q[3];
+    j[1] = -q[2];
+    j[2] = q[1];
+    j[3] = q[0];
+  }
+}
+static void plus(const double x[7], const double* delta, int nloc, double out[7]) {
+  for (int i = 0; i < 3; ++i) out[i] = x[i] + delta[i];
+  const double* d = delta + 3;
+  if (nloc == 3) {
+    const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (n > 0.0) {
+      const double s = std::sin(n) / n;
+      const double qd[4] = {std::cos(n), s * d[0], s * d[1], s * d[2]};
+      quat_product(qd, x + 3, out + 3);
+    } else {
+      for (int i = 0; i < 4; ++i) out[3 + i] = x[3 + i];
+    }
+  } else {
+    double c = d[0];
+    if (c > 0.5) c = 0.5;
+    if (c < -0.5) c = -0.5;
+    const double qd[4] = {std::sqrt(1. - c * c), 0., 0., c};
+    quat_product(qd, x + 3, out + 3);
+  }
+}
+
+// One evaluation at x = [t, q]: device occupied-space sums + host prior residuals.
+static int evaluate(CsmProblem* p, const double x[7], Normal* out) {
+  dliom_ctx* ctx = p->ctx;
+  CsmArgs& a = p->args;
+  for (int i = 0; i < 3; ++i) a.t[i] = x[i];
+  for (int i = 0; i < 4; ++i) a.q[i] = x[3 + i];
+  a.nloc = p->nloc;
+  plus_jacobian(x + 3, p->nloc, a.plus);
+  const float kMin = 0.1f, kMax = 1.f - 0.1f;
+  const float k_scale = (kMax - kMin) / 32766.f;
+  const float k_offset = kMin - k_scale;
+  const int span = ctx->begin_span(DLIOM_KERNEL_CSM_EVAL);
+  hipLaunchKernelGGL(csm_eval_kernel, dim3(p->num_blocks), dim3(kCsmBlock), 0, ctx->stream, a, k_scale,
+                     k_offset, kMin, p->d_partials);
+  hipLaunchKernelGGL(csm_final_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, p->d_partials,
+                     p->num_blocks, p->d_out);
+  ctx->end_span(span);
+  DLIOM_HIP_TRY(hipGetLastError());
+  double* host = static_cast<double*>(ctx->pinned);
+  DLIOM_HIP_TRY(hipMemcpyAsync(host, p->d_out, kAcc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ++p->evaluations;
+  int idx = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) {
+      out->H[r * 6 + c] = host[idx];
+      out->H[c * 6 + r] = host[idx];
+      ++idx;
+    }
+  for (int r = 0; r < 6; ++r) out->g[r] = host[21 + r];
+  double sumsq = host[27];
+  // translation_delta_cost_functor_3d.h:39-45 (only if weight > 0: ceres_scan_matcher_3d.cc:104-110)
+  const double wt = p->o->translation_weight;
+  if (wt > 0.) {
+    for (int i = 0; i < 3; ++i) {
+      const double r = wt * (x[i] - p->target_t[i]);
+      out->H[i * 6 + i] += wt * wt;
+      out->g[i] += wt * r;
+      sumsq += r * r;
+    }
+  }
+  // rotation_delta_cost_functor_3d.h:43-54: r = w * (q_init^-1 (x) q).xyz, linear in q
+  const double wr = p->o->rotation_weight;
+  if (wr > 0.) {
+    const double z[4] = {p->init_q[0], -p->init_q[1], -p->init_q[2], -p->init_q[3]};
+    double d[4];
+    quat_product(z, x + 3, d);
+    // rows of d(delta_k)/dq for k = 1..3 (common/math.h:74-81)
+    const double D[3][4] = {{z[1], z[0], -z[3], z[2]}, {z[2], z[3], z[0], -z[1]}, {z[3], -z[2], z[1], z[0]}};
+    for (int k = 0; k < 3; ++k) {
+      const double r = wr * d[k + 1];
+      double jl[3] = {0, 0, 0};
+      for (int c = 0; c < p->nloc; ++c) {
+        double s = 0.;
+        for (int m = 0; m < 4; ++m) s += (wr * D[k][m]) * a.plus[m * p->nloc + c];
+        jl[c] = s;
+      }
+      for (int c1 = 0; c1 < p->nloc; ++c1) {
+        out->g[3 + c1] += jl[c1] * r;
+        for (int c2 = 0; c2 < p->nloc; ++c2) out->H[(3 + c1) * 6 + 3 + c2] += jl[c1] * jl[c2];
+      }
+      sumsq += r * r;
+    }
+  }
+  out->cost = 0.5 * sumsq;
+  return DLIOM_OK;
+}
+
+// (A + diag(d2)) y = b for the leading n x n block, Cholesky; false if not positive definite.
+static bool solve_spd(const double* A, const double* d2, const double* b, int n, double* y) {
+  double Lm[36];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j <= i; ++j) {
+      double s = A[i * 6 + j] + (i == j ? d2[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= Lm[i * 6 + k] * Lm[j * 6 + k];
+      if (i == j) {
+        if (!(s > 0.0)) return false;
+        Lm[i * 6 + i] = std::sqrt(s);
+      } else {
+        Lm[i * 6 + j] = s / Lm[j * 6 + j];
+      }
+    }
+  }
+  double z[6];
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= Lm[i * 6 + k] * z[k];
+    z[i] = s / Lm[i * 6 + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < n; ++k) s -= Lm[k * 6 + i] * y[k];
+    y[i] = s / Lm[i * 6 + i];
+  }
+  for (int i = 0; i < n; ++i)
+    if (!std::isfinite(y[i])) return false;
+  return true;
+}
+
+// Ceres 1.13 trust-region minimizer (LEVENBERG_MARQUARDT) on the normal equations.
+static int minimize(CsmProblem* p, double x[7], dliom_csm_summary* sum) {
+  const dliom_csm_options& o = *p->o;
+  const int ne = 3 + p->nloc;
+  const double kFunctionTol = 1e-6, kGradientTol = 1e-10, kParameterTol = 1e-8;
+  const double kMinRelDecrease = 1e-3, kMinDiag = 1e-6, kMaxDiag = 1e32;
+  const double kMaxRadius = 1e16, kMinRadius = 1e-32;
+  const int kMaxInvalid = 5;
+  double radius = 1e4, decrease_factor = 2.0;
+  auto norm7 = [](const double* v) {
+    double s = 0;
+    for (int i = 0; i < 7; ++i) s += v[i] * v[i];
+    return std::sqrt(s);
+  };
+  auto grad_max_norm = [&](const double* xx, const Normal& nrm) {
+    double neg[6] = {0, 0, 0, 0, 0, 0}, proj[7];
+    for (int i = 0; i < ne; ++i) neg[i] = -nrm.g[i];
+    plus(xx, neg, p->nloc, proj);
+    double m = 0;
+    for (int i = 0; i < 7; ++i) m = std::max(m, std::fabs(xx[i] - proj[i]));
+    return m;
+  };
+  std::memset(sum, 0, sizeof(*sum));
+  Normal cur;
+  DLIOM_TRY(evaluate(p, x, &cur));
+  double x_cost = cur.cost, minimum_cost = cur.cost;
+  double best_x[7];
+  std::memcpy(best_x, x, sizeof(best_x));
+  sum->initial_cost = x_cost;
+  double min_iter_cost = x_cost;
+  int num_iter_records = 1;
+  double scale[6] = {1, 1, 1, 1, 1, 1};
+  for (int i = 0; i < ne; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(cur.H[i * 6 + i]));
+  double x_norm = norm7(x);
+  double gmax = grad_max_norm(x, cur);
+  auto finish = [&](int type) {
+    std::memcpy(x, best_x, sizeof(best_x));
+    sum->final_cost = std::min(sum->initial_cost, min_iter_cost);
+    sum->num_iterations = num_iter_records;
+    sum->num_residual_evaluations = p->evaluations;
+    sum->num_jacobian_evaluations = p->evaluations;
+    sum->termination_type = type;
+    return type == 2 ? DLIOM_ERR_SOLVER : DLIOM_OK;
+  };
+  if (gmax <= kGradientTol) return finish(0);
+
+  // trust_region_step_evaluator.cc state
+  const int max_nonmono = o.use_nonmonotonic_steps ? 5 : 0;
+  double ev_min = x_cost, ev_cur = x_cost, ev_ref = x_cost, ev_cand = x_cost;
+  double acc_ref = 0.0, acc_cand = 0.0;
+  int nonmono = 0;
+
+  int iteration = 0, invalid = 0;
+  bool last_ok = false;
+  for (;;) {
+    if (last_ok) {
+      ++sum->num_successful_steps;
+      if (x_cost < minimum_cost) {
+        minimum_cost = x_cost;
+        std::memcpy(best_x, x, sizeof(best_x));
+      }
+    } else if (iteration > 0) {
+      ++sum->num_unsuccessful_steps;
+    }
+    if (iteration >= o.max_num_iterations) return finish(1);
+    if (last_ok && gmax <= kGradientTol) return finish(0);
+    if (radius <= kMinRadius) return finish(0);
+    ++iteration;
+    last_ok = false;
+
+    // scaled normal equations Hs = S H S, gs = S g; LM diagonal from diag(Hs)
+    double Hs[36], gs[6], d2[6], y[6], step[6];
+    for (int r = 0; r < ne; ++r) {
+      gs[r] = cur.g[r] * scale[r];
+      for (int c = 0; c < ne; ++c) Hs[r * 6 + c] = cur.H[r * 6 + c] * scale[r] * scale[c];
+    }
+    for (int r = 0; r < ne; ++r)
+      d2[r] = std::min(std::max(Hs[r * 6 + r], kMinDiag), kMaxDiag) / radius;
+    bool valid = solve_spd(Hs, d2, gs, ne, y);
+    double model_cost_change = 0.0;
+    if (valid) {
+      for (int r = 0; r < ne; ++r) step[r] = -y[r];
+      // -(J s)^T (r + J s / 2) = -s^T gs - 1/2 s^T Hs s
+      double sg = 0.0, shs = 0.0;
+      for (int r = 0; r < ne; ++r) {
+        sg += step[r] * gs[r];
+        double t = 0.0;
+        for (int c = 0; c < ne; ++c) t += Hs[r * 6 + c] * step[c];
+        shs += step[r] * t;
+      }
+      model_cost_change = -sg - 0.5 * shs;
+      valid = model_cost_change > 0.0;
+    }
+    if (!valid) {
+      if (++invalid >= kMaxInvalid) return finish(2);
+      radius *= 0.5;
+      min_iter_cost = std::min(min_iter_cost, x_cost);
+      ++num_iter_records;
+      continue;
+    }
+    invalid = 0;
+    double delta[6] = {0, 0, 0, 0, 0, 0}, cand[7];
+    for (int r = 0; r < ne; ++r) delta[r] = step[r] * scale[r];
+    plus(x, delta, p->nloc, cand);
+    Normal cn;
+    DLIOM_TRY(evaluate(p, cand, &cn));
+    const double cand_cost = cn.cost;
+    double step_norm = 0;
+    for (int i = 0; i < 7; ++i) step_norm += (x[i] - cand[i]) * (x[i] - cand[i]);
+    step_norm = std::sqrt(step_norm);
+    if (step_norm <= kParameterTol * (x_norm + kParameterTol)) return finish(0);
+    if (std::fabs(x_cost - cand_cost) <= kFunctionTol * x_cost) return finish(0);
+    const double rel = (ev_cur - cand_cost) / model_cost_change;
+    const double hist = (ev_ref - cand_cost) / (acc_ref + model_cost_change);
+    const double quality = std::max(rel, hist);
+    if (quality > kMinRelDecrease) {
+      std::memcpy(x, cand, sizeof(cand));
+      x_norm = norm7(x);
+      cur = cn;
+      x_cost = cand_cost;
+      gmax = grad_max_norm(x, cur);
+      last_ok = true;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * quality - 1.0, 3));
+      radius = std::min(kMaxRadius, radius);
+      decrease_factor = 2.0;
+      ev_cur = cand_cost;
+      acc_cand += model_cost_change;
+      acc_ref += model_cost_change;
+      if (ev_cur < ev_min) {
+        ev_min = ev_cur;
+        nonmono = 0;
+        ev_cand = ev_cur;
+        acc_cand = 0.0;
+      } else {
+        ++nonmono;
+        if (ev_cur > ev_cand) {
+          ev_cand = ev_cur;
+          acc_cand = 0.0;
+        }
+      }
+      if (nonmono == max_nonmono) {
+        ev_ref = ev_cand;
+        acc_ref = acc_cand;
+      }
+      min_iter_cost = std::min(min_iter_cost, x_cost);
+    } else {
+      radius = radius / decrease_factor;
+      decrease_factor *= 2.0;
+      min_iter_cost = std::min(min_iter_cost, cand_cost);
+    }
+    ++num_iter_records;
+  }
+}
+
+static int setup_problem(dliom_ctx* ctx, const dliom_csm_options* o, const double target_t[3],
+                         const double init7[7], int k, const dliom_cloud* const* clouds,
+                         const dliom_grid* const* grids, CsmProblem* p) {
+  if (o->num_occupied_space_weights != k || k <= 0 || k > DLIOM_MAX_CLOUDS) return DLIOM_ERR_WEIGHTS;
+  p->ctx = ctx;
+  p->o = o;
+  p->nloc = o->only_optimize_yaw ? 1 : 3;
+  p->evaluations = 0;
+  int total = 0;
+  for (int i = 0; i < k; ++i) {
+    if (!(o->occupied_space_weight[i] > 0.)) return DLIOM_ERR_WEIGHTS;
+    if (clouds[i] == nullptr || grids[i] == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+    if (clouds[i]->n <= 0) return DLIOM_ERR_EMPTY_CLOUD;
+    CsmCloudArg& c = p->args.cloud[i];
+    c.g = grids[i]->view();
+    c.x = clouds[i]->d_x;
+    c.y = clouds[i]->d_y;
+    c.z = clouds[i]->d_z;
+    c.n = static_cast<int>(clouds[i]->n);
+    c.scale = o->occupied_space_weight[i] / std::sqrt(static_cast<double>(clouds[i]->n));
+    total += c.n;
+  }
+  p->args.num_clouds = k;
+  p->args.total_points = total;
+  for (int i = 0; i < 3; ++i) p->target_t[i] = target_t[i];
+  for (int i = 0; i < 4; ++i) p->init_q[i] = init7[3 + i];
+  p->num_blocks = std::max(1, std::min(1024, (total + kCsmBlock - 1) / kCsmBlock));
+  DLIOM_TRY(ctx->partials.reserve(static_cast<size_t>(p->num_blocks + 1) * kAcc * sizeof(double)));
+  p->d_partials = ctx->partials.as<double>();
+  p->d_out = p->d_partials + static_cast<size_t>(p->num_blocks) * kAcc;
+  return DLIOM_OK;
+}
+
+static int stage_clouds(dliom_ctx* ctx, int k, const float* const* pts, const int64_t* n,
+                        std::vector<dliom_cloud>* staged, std::vector<const dliom_cloud*>* ptrs) {
+  size_t total = 0;
+  std::vector<size_t> off(k);
+  for (int i = 0; i < k; ++i) {
+    if (n[i] < 0 || (n[i] > 0 && pts[i] == nullptr)) return DLIOM_ERR_INVALID_ARGUMENT;
+    if (n[i] == 0) return DLIOM_ERR_EMPTY_CLOUD;
+    off[i] = total;
+    total += (staged_cloud_bytes(n[i]) + 255) & ~static_cast<size_t>(255);
+  }
+  DLIOM_TRY(ctx->points.reserve(total));
+  staged->resize(k);
+  ptrs->resize(k);
+  for (int i = 0; i < k; ++i) {
+    DLIOM_TRY(stage_cloud(ctx, pts[i], n[i], &(*staged)[i], off[i]));
+    (*ptrs)[i] = &(*staged)[i];
+  }
+  return DLIOM_OK;
+}
+
+}  // namespace dliom
+
+using namespace dliom;
+
+extern "C" {
+
+int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* o, const double target_t[3],
+                            const double init7[7], int k, const dliom_cloud* const* clouds,
+                            const dliom_grid* const* grids, double out7[7], dliom_csm_summary* summary) {
+  if (ctx == nullptr || o == nullptr || target_t == nullptr || init7 == nullptr || clouds == nullptr ||
+      grids == nullptr || out7 == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  CsmProblem p;
+  DLIOM_TRY(setup_problem(ctx, o, target_t, init7, k, clouds, grids, &p));
+  double x[7];
+  std::memcpy(x, init7, sizeof(x));
+  dliom_csm_summary local;
+  const int s = minimize(&p, x, summary != nullptr ? summary : &local);
+  std::memcpy(out7, x, sizeof(x));
+  return s;
+}
+
+int dliom_csm3d_match(dliom_ctx* ctx, const dliom_csm_options* o, const double target_t[3],
+                      const double init7[7], int k, const float* const* pts, const int64_t* n,
+                      const dliom_grid* const* grids, double out7[7], dliom_csm_summary* summary) {
+  if (ctx == nullptr || o == nullptr || pts == nullptr || n == nullptr || k <= 0 || k > DLIOM_MAX_CLOUDS)
+    return k <= 0 || k > DLIOM_MAX_CLOUDS ? DLIOM_ERR_WEIGHTS : DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<dliom_cloud> staged;
+  std::vector<const dliom_cloud*> ptrs;
+  DLIOM_TRY(stage_clouds(ctx, k, pts, n, &staged, &ptrs));
+  return dliom_csm3d_match_cloud(ctx, o, target_t, init7, k, ptrs.data(), grids, out7, summary);
+}
+
+int dliom_csm3d_evaluate(dliom_ctx* ctx, const dliom_csm_options* o, const double target_t[3],
+                         const double init7[7], const double pose[7], int k, const float* const* pts,
+                         const int64_t* n, const dliom_grid* const* grids, double* cost,
+                         double gradient[6], double jtj[36]) {
+  if (ctx == nullptr || o == nullptr || target_t == nullptr || init7 == nullptr || pose == nullptr ||
+      pts == nullptr || n == nullptr || grids == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  std::vector<dliom_cloud> staged;
+  std::vector<const dliom_cloud*> ptrs;
+  DLIOM_TRY(stage_clouds(ctx, k, pts, n, &staged, &ptrs));
+  CsmProblem p;
+  DLIOM_TRY(setup_problem(ctx, o, target_t, init7, k, ptrs.data(), grids, &p));
+  Normal nrm;
+  DLIOM_TRY(evaluate(&p, pose, &nrm));
+  if (cost != nullptr) *cost = nrm.cost;
+  if (gradient != nullptr) std::memcpy(gradient, nrm.g, sizeof(nrm.g));
+  if (jtj != nullptr) std::memcpy(jtj, nrm.H, sizeof(nrm.H));
+  return DLIOM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Device functions shared by the gfx950 kernels.  Everything that decides a
+// voxel index lives here so that every kernel (score volume, rescoring,
+// insertion, probes) runs the same instructions.
+//
+// Built with -ffp-contract=off and IEEE float division (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt), see d-liom_amd/Makefile: the
+// reference's x86-64 build has no FMA and uses true division
+// (mapping/3d/hybrid_grid.h:430-435, cmake/functions.cmake:91-92).
+#ifndef DLIOM_CSRC_DEVICE_COMMON_H_
+#define DLIOM_CSRC_DEVICE_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include "internal.h"
+
+namespace dliom {
+
+// std::lround semantics (common/port.h:41): round half away from zero.
+// x - trunc(x) is exact in binary floating point.
+__device__ __forceinline__ int lround_away(float x) {
+  const float t = truncf(x);
+  const float d = x - t;
+  int k = static_cast<int>(t);
+  k += (d >= 0.5f) ? 1 : 0;
+  k -= (d <= -0.5f) ? 1 : 0;
+  return k;
+}
+
+// HybridGridBase::GetCellIndex for one coordinate.
+__device__ __forceinline__ int cell_of(float p, float resolution) {
+  return lround_away(p / resolution);
+}
+
+struct Quat4 {
+  float w, x, y, z;
+};
+
+// Eigen QuaternionBase::_transformVector, scalar order kept:
+//   uv = u x v; uv += uv; return (v + w*uv) + u x uv
+__device__ __forceinline__ void rotate_point(const Quat4 q, float vx, float vy, float vz,
+                                             float& ox, float& oy, float& oz) {
+  float uvx = q.y * vz - q.z * vy;
+  float uvy = q.z * vx - q.x * vz;
+  float uvz = q.x * vy - q.y * vx;
+  uvx = uvx + uvx;
+  uvy = uvy + uvy;
+  uvz = uvz + uvz;
+  const float cx = q.y * uvz - q.z * uvy;
+  const float cy = q.z * uvx - q.x * uvz;
+  const float cz = q.x * uvy - q.y * uvx;
+  ox = (vx + q.w * uvx) + cx;
+  oy = (vy + q.w * uvy) + cy;
+  oz = (vz + q.w * uvz) + cz;
+}
+
+// DynamicGrid::value (hybrid_grid.h:263-281): shift, unsigned bounds check,
+// leaf lookup, cell lookup.  Missing leaves map to slot 0 (all zeros), so the
+// only branch-free special case is "outside the current extent".
+__device__ __forceinline__ unsigned grid_value(const GridView& g, int ix, int iy, int iz) {
+  const unsigned sx = static_cast<unsigned>(ix + g.half);
+  const unsigned sy = static_cast<unsigned>(iy + g.half);
+  const unsigned sz = static_cast<unsigned>(iz + g.half);
+  const bool inside = (sx < g.grid_size) & (sy < g.grid_size) & (sz < g.grid_size);
+  const unsigned L = static_cast<unsigned>(g.leaves_per_axis);
+  const unsigned tidx = inside ? ((sz >> 3) * L + (sy >> 3)) * L + (sx >> 3) : 0u;
+  unsigned slot = g.table[tidx];
+  slot = inside ? slot : 0u;
+  const unsigned cell = ((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u);
+  return g.pool[static_cast<size_t>(slot) * 512u + cell];
+}
+
+// Sum over the 64 lanes of a wavefront; the total lands in lane 63.
+// quad swaps, half-row mirror, row mirror, then the two row broadcasts --
+// six DPP adds, no LDS traffic.
+__device__ __forceinline__ unsigned wave_sum_lane63(unsigned v) {
+  v += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0xB1, 0xf, 0xf, false));
+  v += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x4E, 0xf, 0xf, false));
+  v += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x141, 0xf, 0xf, false));
+  v += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x140, 0xf, 0xf, false));
+  v += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
+  v += static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
+  return v;
+}
+
+}  // namespace dliom
+
+#endif  // DLIOM_CSRC_DEVICE_COMMON_H_

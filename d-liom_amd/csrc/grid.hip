@@ -1,0 +1,526 @@
+// Device-resident HybridGrid and range-data insertion for gfx950.
+//
+// Layout in HBM (DESIGN.md "grid"):
+//   table : (8<<bits)^3 uint32, z-major over LEAF coordinates shifted by 4<<bits;
+//           entry = pool slot of that 8x8x8 leaf, 0 = not allocated.
+//   pool  : slot * 1 KiB, each leaf 512 uint16 in the reference's z-major order
+//           (mapping/3d/hybrid_grid.h:40-43); slot 0 is a permanent all-zero
+//           leaf so lookups need no "missing" branch.
+// This flattens the reference's DynamicGrid -> NestedGrid pointer levels
+// (hybrid_grid.h:143-409) into one dependent load while keeping its 1 KiB
+// leaves, its index range [-32<<bits, 32<<bits) and its growth rule.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "device_common.h"
+
+namespace dliom {
+
+constexpr uint32_t kSlotLocked = 0xFFFFFFFFu;
+constexpr int kMaxFlatBits = 7;  // (8<<7)^3 entries = 2^30 fits 32-bit index math
+
+__device__ __forceinline__ bool leaf_table_index(int ix, int iy, int iz, int half, unsigned gsize,
+                                                 unsigned L, unsigned* tidx, unsigned* cell) {
+  const unsigned sx = static_cast<unsigned>(ix + half);
+  const unsigned sy = static_cast<unsigned>(iy + half);
+  const unsigned sz = static_cast<unsigned>(iz + half);
+  if (!((sx < gsize) & (sy < gsize) & (sz < gsize))) return false;
+  *tidx = ((sz >> 3) * L + (sy >> 3)) * L + (sx >> 3);
+  *cell = ((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u);
+  return true;
+}
+
+// Makes sure the leaf that holds (ix,iy,iz) exists.  Exactly one thread wins the
+// CAS and takes the next pool slot; the others need nothing from this kernel
+// (later kernels read the table after the kernel boundary).
+__device__ __forceinline__ void ensure_leaf(uint32_t* table, int32_t* slot_coord, uint32_t* count,
+                                            int ix, int iy, int iz, int half, unsigned gsize,
+                                            unsigned L) {
+  unsigned tidx, cell;
+  if (!leaf_table_index(ix, iy, iz, half, gsize, L, &tidx, &cell)) return;
+  if (table[tidx] != 0u) return;
+  if (atomicCAS(&table[tidx], 0u, kSlotLocked) == 0u) {
+    const uint32_t slot = atomicAdd(count, 1u);
+    slot_coord[3 * static_cast<size_t>(slot) + 0] = ix >> 3;  // arithmetic shift == floor(/8)
+    slot_coord[3 * static_cast<size_t>(slot) + 1] = iy >> 3;
+    slot_coord[3 * static_cast<size_t>(slot) + 2] = iz >> 3;
+    atomicExch(&table[tidx], slot);
+  }
+}
+
+// HybridGrid::ApplyLookupTable (hybrid_grid.h:509-520) on a 16-bit cell through
+// a 32-bit CAS: cells that already carry the update marker are left alone, so
+// the result does not depend on which thread gets there first.
+__device__ __forceinline__ void apply_table(uint32_t* pool32, size_t value_index,
+                                            const uint16_t* __restrict__ lut) {
+  uint32_t* word = pool32 + (value_index >> 1);
+  const unsigned shift = (value_index & 1u) ? 16u : 0u;
+  uint32_t old = *word;
+  for (;;) {
+    const uint32_t v = (old >> shift) & 0xFFFFu;
+    if (v >= 0x8000u) return;
+    const uint32_t nv = lut[v];
+    const uint32_t desired = (old & ~(0xFFFFu << shift)) | (nv << shift);
+    const uint32_t seen = atomicCAS(word, old, desired);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+
+struct InsertArgs {
+  const float* returns;  // packed xyz
+  int64_t n;
+  float ox, oy, oz;      // origin
+  float resolution;
+  int num_free;
+  int half;
+  unsigned gsize;
+  unsigned L;
+};
+
+// range_data_inserter_3d.cc:36-50: the k-th sample on the ray origin->hit in
+// Array3i arithmetic (int multiply, truncating int division).
+__device__ __forceinline__ void miss_cell(int ocx, int ocy, int ocz, int dx, int dy, int dz,
+                                          int position, int num_samples, int* mx, int* my,
+                                          int* mz) {
+  *mx = ocx + dx * position / num_samples;
+  *my = ocy + dy * position / num_samples;
+  *mz = ocz + dz * position / num_samples;
+}
+
+__device__ __forceinline__ int bits_for(int c) {
+  // smallest b >= 1 with -(32<<b) <= c < (32<<b)
+  int b = 1;
+  while (b < 9 && !(c >= -(32 << b) && c < (32 << b))) ++b;
+  return b;
+}
+
+// Pass 0: the DynamicGrid bits the reference would end up with, and the
+// CHECK_LT(num_samples, 1<<15) condition.  out[0] = max needed bits, out[1] = ray too long.
+__global__ void insert_scan_kernel(InsertArgs a, int* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int hx = cell_of(a.returns[3 * i], a.resolution);
+  const int hy = cell_of(a.returns[3 * i + 1], a.resolution);
+  const int hz = cell_of(a.returns[3 * i + 2], a.resolution);
+  int need = max(bits_for(hx), max(bits_for(hy), bits_for(hz)));
+  const int ocx = cell_of(a.ox, a.resolution), ocy = cell_of(a.oy, a.resolution),
+            ocz = cell_of(a.oz, a.resolution);
+  const int dx = hx - ocx, dy = hy - ocy, dz = hz - ocz;
+  const int num_samples = max(abs(dx), max(abs(dy), abs(dz)));
+  if (num_samples >= (1 << 15)) atomicMax(&out[1], 1);
+  for (int position = max(0, num_samples - a.num_free); position < num_samples; ++position) {
+    int mx, my, mz;
+    miss_cell(ocx, ocy, ocz, dx, dy, dz, position, num_samples, &mx, &my, &mz);
+    need = max(need, max(bits_for(mx), max(bits_for(my), bits_for(mz))));
+  }
+  atomicMax(&out[0], need);
+}
+
+// Pass 1: allocate every leaf that a hit or miss cell touches (what
+// mutable_value() does lazily, hybrid_grid.h:285-301,167-177).
+__global__ void insert_alloc_kernel(InsertArgs a, uint32_t* table, int32_t* slot_coord,
+                                    uint32_t* count) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int hx = cell_of(a.returns[3 * i], a.resolution);
+  const int hy = cell_of(a.returns[3 * i + 1], a.resolution);
+  const int hz = cell_of(a.returns[3 * i + 2], a.resolution);
+  ensure_leaf(table, slot_coord, count, hx, hy, hz, a.half, a.gsize, a.L);
+  const int ocx = cell_of(a.ox, a.resolution), ocy = cell_of(a.oy, a.resolution),
+            ocz = cell_of(a.oz, a.resolution);
+  const int dx = hx - ocx, dy = hy - ocy, dz = hz - ocz;
+  const int num_samples = max(abs(dx), max(abs(dy), abs(dz)));
+  for (int position = max(0, num_samples - a.num_free); position < num_samples; ++position) {
+    int mx, my, mz;
+    miss_cell(ocx, ocy, ocz, dx, dy, dz, position, num_samples, &mx, &my, &mz);
+    ensure_leaf(table, slot_coord, count, mx, my, mz, a.half, a.gsize, a.L);
+  }
+}
+
+// Pass 2 (MODE 0): hits.  Pass 3 (MODE 1): misses.  Pass 4 (MODE 2): FinishUpdate
+// -- clear the marker on every touched cell (hybrid_grid.h:494-500).
+template <int MODE>
+__global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ table,
+                                    uint32_t* pool32, const uint16_t* __restrict__ lut) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int hx = cell_of(a.returns[3 * i], a.resolution);
+  const int hy = cell_of(a.returns[3 * i + 1], a.resolution);
+  const int hz = cell_of(a.returns[3 * i + 2], a.resolution);
+  unsigned tidx, cell;
+  if (MODE == 0 || MODE == 2) {
+    if (leaf_table_index(hx, hy, hz, a.half, a.gsize, a.L, &tidx, &cell)) {
+      const size_t vi = static_cast<size_t>(table[tidx]) * 512u + cell;
+      if (MODE == 0) {
+        apply_table(pool32, vi, lut);
+      } else {
+        atomicAnd(pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
+      }
+    }
+  }
+  if (MODE == 1 || MODE == 2) {
+    const int ocx = cell_of(a.ox, a.resolution), ocy = cell_of(a.oy, a.resolution),
+              ocz = cell_of(a.oz, a.resolution);
+    const int dx = hx - ocx, dy = hy - ocy, dz = hz - ocz;
+    const int num_samples = max(abs(dx), max(abs(dy), abs(dz)));
+    for (int position = max(0, num_samples - a.num_free); position < num_samples; ++position) {
+      int mx, my, mz;
+      miss_cell(ocx, ocy, ocz, dx, dy, dz, position, num_samples, &mx, &my, &mz);
+      if (!leaf_table_index(mx, my, mz, a.half, a.gsize, a.L, &tidx, &cell)) continue;
+      const size_t vi = static_cast<size_t>(table[tidx]) * 512u + cell;
+      if (MODE == 1) {
+        apply_table(pool32, vi, lut);
+      } else {
+        atomicAnd(pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
+      }
+    }
+  }
+}
+
+// Rebuilds the leaf table for a new extent from the per-slot leaf coordinates
+// (the counterpart of DynamicGrid::Grow, hybrid_grid.h:387-405).
+__global__ void rebuild_table_kernel(const int32_t* __restrict__ slot_coord, uint32_t count,
+                                     uint32_t* table, int leaf_half, unsigned L) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x + 1u;  // slot 0 is the null leaf
+  if (s >= count) return;
+  const unsigned lx = static_cast<unsigned>(slot_coord[3 * static_cast<size_t>(s)] + leaf_half);
+  const unsigned ly = static_cast<unsigned>(slot_coord[3 * static_cast<size_t>(s) + 1] + leaf_half);
+  const unsigned lz = static_cast<unsigned>(slot_coord[3 * static_cast<size_t>(s) + 2] + leaf_half);
+  table[(lz * L + ly) * L + lx] = s;
+}
+
+__global__ void upload_alloc_kernel(const int32_t* __restrict__ origins, int64_t n, uint32_t* table,
+                                    int32_t* slot_coord, uint32_t* count, int half, unsigned gsize,
+                                    unsigned L) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ensure_leaf(table, slot_coord, count, origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], half,
+              gsize, L);
+}
+
+__global__ void upload_copy_kernel(const int32_t* __restrict__ origins,
+                                   const uint16_t* __restrict__ values, const uint32_t* __restrict__ table,
+                                   uint16_t* pool, int half, unsigned gsize, unsigned L) {
+  const int64_t b = blockIdx.x;
+  unsigned tidx, cell;
+  if (!leaf_table_index(origins[3 * b], origins[3 * b + 1], origins[3 * b + 2], half, gsize, L, &tidx,
+                        &cell))
+    return;
+  const size_t slot = table[tidx];
+  for (int k = threadIdx.x; k < 512; k += blockDim.x)
+    pool[slot * 512u + k] = values[static_cast<size_t>(b) * 512u + k];
+}
+
+__global__ void get_values_kernel(GridView g, const int32_t* __restrict__ cells, int64_t n,
+                                  uint16_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = static_cast<uint16_t>(grid_value(g, cells[3 * i], cells[3 * i + 1], cells[3 * i + 2]));
+}
+
+static inline unsigned blocks_for(int64_t n, int threads) {
+  return static_cast<unsigned>((n + threads - 1) / threads);
+}
+
+}  // namespace dliom
+
+using namespace dliom;
+
+GridView dliom_grid::view() const {
+  GridView v;
+  v.table = d_table;
+  v.pool = d_pool;
+  v.half = 32 << bits;
+  v.leaves_per_axis = 8 << bits;
+  v.grid_size = 64u << bits;
+  v.resolution = resolution;
+  return v;
+}
+
+static size_t table_entries(int bits) {
+  const size_t L = static_cast<size_t>(8) << bits;
+  return L * L * L;
+}
+
+int dliom_grid::refresh_count(int64_t* count) {
+  uint32_t c = 0;
+  DLIOM_HIP_TRY(hipMemcpyAsync(&c, d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  used_upper = c;
+  if (count != nullptr) *count = c;
+  return DLIOM_OK;
+}
+
+int dliom_grid::ensure_bits(int needed_bits) {
+  if (needed_bits <= bits) return DLIOM_OK;
+  if (needed_bits > 8) return DLIOM_ERR_GRID_EXTENT;
+  if (needed_bits > kMaxFlatBits) return DLIOM_ERR_GRID_EXTENT;  // flat table limit, DESIGN.md
+  uint32_t* new_table = nullptr;
+  const size_t entries = table_entries(needed_bits);
+  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&new_table), entries * sizeof(uint32_t)));
+  DLIOM_HIP_TRY(hipMemsetAsync(new_table, 0, entries * sizeof(uint32_t), ctx->stream));
+  int64_t count = 0;
+  DLIOM_TRY(refresh_count(&count));
+  if (count > 1) {
+    hipLaunchKernelGGL(rebuild_table_kernel, dim3(blocks_for(count - 1, 256)), dim3(256), 0,
+                       ctx->stream, d_slot_coord, static_cast<uint32_t>(count), new_table,
+                       4 << needed_bits, 8u << needed_bits);
+    DLIOM_HIP_TRY(hipGetLastError());
+  }
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  DLIOM_HIP_TRY(hipFree(d_table));
+  d_table = new_table;
+  bits = needed_bits;
+  return DLIOM_OK;
+}
+
+int dliom_grid::ensure_capacity(int64_t additional_slots) {
+  if (used_upper + additional_slots <= capacity) return DLIOM_OK;
+  int64_t count = 0;
+  DLIOM_TRY(refresh_count(&count));  // tighten the pessimistic bound first
+  if (count + additional_slots <= capacity) return DLIOM_OK;
+  int64_t new_cap = std::max<int64_t>(capacity * 2, count + additional_slots);
+  new_cap = std::max<int64_t>(new_cap, 4096);
+  uint16_t* new_pool = nullptr;
+  int32_t* new_coord = nullptr;
+  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&new_pool), static_cast<size_t>(new_cap) * 1024));
+  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&new_coord), static_cast<size_t>(new_cap) * 12));
+  // invariant: slots >= count are zero
+  DLIOM_HIP_TRY(hipMemsetAsync(new_pool, 0, static_cast<size_t>(new_cap) * 1024, ctx->stream));
+  if (d_pool != nullptr) {
+    DLIOM_HIP_TRY(hipMemcpyAsync(new_pool, d_pool, static_cast<size_t>(count) * 1024,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    DLIOM_HIP_TRY(hipMemcpyAsync(new_coord, d_slot_coord, static_cast<size_t>(count) * 12,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (d_pool != nullptr) {
+    DLIOM_HIP_TRY(hipFree(d_pool));
+    DLIOM_HIP_TRY(hipFree(d_slot_coord));
+  }
+  d_pool = new_pool;
+  d_slot_coord = new_coord;
+  capacity = new_cap;
+  return DLIOM_OK;
+}
+
+extern "C" {
+
+int dliom_grid_create(dliom_ctx* ctx, float resolution, dliom_grid** out) {
+  if (ctx == nullptr || out == nullptr || !(resolution > 0.f)) return DLIOM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  dliom_grid* g = new dliom_grid;
+  g->ctx = ctx;
+  g->resolution = resolution;
+  g->bits = 1;
+  int s = DLIOM_OK;
+  do {
+    if (hipMalloc(reinterpret_cast<void**>(&g->d_table), table_entries(1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&g->d_count), sizeof(uint32_t)) != hipSuccess) {
+      s = DLIOM_ERR_HIP;
+      break;
+    }
+    if (hipMemsetAsync(g->d_table, 0, table_entries(1) * sizeof(uint32_t), ctx->stream) != hipSuccess) {
+      s = DLIOM_ERR_HIP;
+      break;
+    }
+    const uint32_t one = 1;  // slot 0 is the reserved null leaf
+    if (hipMemcpyAsync(g->d_count, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+      s = DLIOM_ERR_HIP;
+      break;
+    }
+    g->used_upper = 1;
+    s = g->ensure_capacity(1024);
+  } while (false);
+  if (s != DLIOM_OK) {
+    dliom_grid_destroy(g);
+    return s;
+  }
+  *out = g;
+  return DLIOM_OK;
+}
+
+int dliom_grid_destroy(dliom_grid* g) {
+  if (g == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (g->ctx != nullptr) (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->d_table) (void)hipFree(g->d_table);
+  if (g->d_pool) (void)hipFree(g->d_pool);
+  if (g->d_slot_coord) (void)hipFree(g->d_slot_coord);
+  if (g->d_count) (void)hipFree(g->d_count);
+  delete g;
+  return DLIOM_OK;
+}
+
+int dliom_grid_resolution(const dliom_grid* g, float* resolution) {
+  if (g == nullptr || resolution == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *resolution = g->resolution;
+  return DLIOM_OK;
+}
+
+int dliom_grid_bits(const dliom_grid* g, int* bits) {
+  if (g == nullptr || bits == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *bits = g->bits;
+  return DLIOM_OK;
+}
+
+int dliom_grid_upload_blocks(dliom_grid* g, const int32_t* origins, const uint16_t* values512,
+                             int64_t n) {
+  if (g == nullptr || n < 0 || (n > 0 && (origins == nullptr || values512 == nullptr)))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_OK;
+  dliom_ctx* ctx = g->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  int lo = 0, hi = 0;
+  for (int64_t i = 0; i < 3 * n; ++i) {
+    if ((origins[i] & 7) != 0) return DLIOM_ERR_INVALID_ARGUMENT;
+    lo = std::min(lo, origins[i]);
+    hi = std::max(hi, origins[i] + 7);
+  }
+  DLIOM_TRY(g->ensure_bits(needed_bits_for_cell_range(lo, hi)));
+  DLIOM_TRY(g->ensure_capacity(n));
+  const size_t obytes = static_cast<size_t>(n) * 12, vbytes = static_cast<size_t>(n) * 1024;
+  DLIOM_TRY(ctx->misc.reserve(obytes + 256 + vbytes));
+  int32_t* d_orig = ctx->misc.as<int32_t>();
+  uint16_t* d_vals = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->misc.p) +
+                                                  ((obytes + 255) & ~static_cast<size_t>(255)));
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_orig, origins, obytes, hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_vals, values512, vbytes, hipMemcpyHostToDevice, ctx->stream));
+  const GridView v = g->view();
+  hipLaunchKernelGGL(upload_alloc_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_orig,
+                     n, g->d_table, g->d_slot_coord, g->d_count, v.half, v.grid_size,
+                     static_cast<unsigned>(v.leaves_per_axis));
+  DLIOM_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(upload_copy_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, ctx->stream,
+                     d_orig, d_vals, g->d_table, g->d_pool, v.half, v.grid_size,
+                     static_cast<unsigned>(v.leaves_per_axis));
+  DLIOM_HIP_TRY(hipGetLastError());
+  g->used_upper += n;
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // host buffers may be reused by the caller
+  return DLIOM_OK;
+}
+
+int dliom_grid_num_blocks(const dliom_grid* g, int64_t* num_blocks) {
+  if (g == nullptr || num_blocks == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  int64_t c = 0;
+  DLIOM_TRY(const_cast<dliom_grid*>(g)->refresh_count(&c));
+  *num_blocks = c - 1;
+  return DLIOM_OK;
+}
+
+int dliom_grid_download_blocks(const dliom_grid* g, int32_t* origins, uint16_t* values512,
+                               int64_t capacity, int64_t* num_blocks) {
+  if (g == nullptr || num_blocks == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  int64_t c = 0;
+  DLIOM_TRY(const_cast<dliom_grid*>(g)->refresh_count(&c));
+  const int64_t n = c - 1;
+  *num_blocks = n;
+  if (n == 0) return DLIOM_OK;
+  if (capacity < n) return DLIOM_ERR_CAPACITY;
+  if (origins == nullptr || values512 == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  dliom_ctx* ctx = g->ctx;
+  DLIOM_HIP_TRY(hipMemcpyAsync(origins, g->d_slot_coord + 3, static_cast<size_t>(n) * 12,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(values512, g->d_pool + 512, static_cast<size_t>(n) * 1024,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int64_t i = 0; i < 3 * n; ++i) origins[i] *= 8;  // leaf coordinate -> corner voxel index
+  return DLIOM_OK;
+}
+
+int dliom_grid_get_values(const dliom_grid* g, const int32_t* cells, int64_t n, uint16_t* values) {
+  if (g == nullptr || n < 0 || (n > 0 && (cells == nullptr || values == nullptr)))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_OK;
+  dliom_ctx* ctx = g->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t cbytes = static_cast<size_t>(n) * 12;
+  const size_t off = (cbytes + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->misc.reserve(off + static_cast<size_t>(n) * 2));
+  int32_t* d_cells = ctx->misc.as<int32_t>();
+  uint16_t* d_out = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->misc.p) + off);
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_cells, cells, cbytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(get_values_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, g->view(),
+                     d_cells, n, d_out);
+  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_HIP_TRY(hipMemcpyAsync(values, d_out, static_cast<size_t>(n) * 2, hipMemcpyDeviceToHost,
+                               ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
+int dliom_grid_insert(dliom_grid* g, const float origin[3], const float* returns_xyz, int64_t n,
+                      const uint16_t* hit_table, const uint16_t* miss_table,
+                      int num_free_space_voxels) {
+  if (g == nullptr || origin == nullptr || n < 0 || hit_table == nullptr || miss_table == nullptr ||
+      (n > 0 && returns_xyz == nullptr) || num_free_space_voxels < 0)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_OK;  // nothing to insert; FinishUpdate on nothing
+  dliom_ctx* ctx = g->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  // scratch: [returns | hit lut | miss lut | scan out]
+  const size_t pbytes = (static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->misc.reserve(pbytes + 65536 * 2 + 256));
+  char* base = static_cast<char*>(ctx->misc.p);
+  float* d_returns = reinterpret_cast<float*>(base);
+  uint16_t* d_hit = reinterpret_cast<uint16_t*>(base + pbytes);
+  uint16_t* d_miss = d_hit + 32768;
+  int* d_scan = reinterpret_cast<int*>(base + pbytes + 65536 * 2);
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_returns, returns_xyz, static_cast<size_t>(n) * 12,
+                               hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_hit, hit_table, 65536, hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_miss, miss_table, 65536, hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemsetAsync(d_scan, 0, 8, ctx->stream));
+
+  InsertArgs a;
+  a.returns = d_returns;
+  a.n = n;
+  a.ox = origin[0];
+  a.oy = origin[1];
+  a.oz = origin[2];
+  a.resolution = g->resolution;
+  a.num_free = num_free_space_voxels;
+  a.half = 0;
+  a.gsize = 0;
+  a.L = 0;
+  const dim3 grid(blocks_for(n, 256)), block(256);
+  const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
+  hipLaunchKernelGGL(insert_scan_kernel, grid, block, 0, ctx->stream, a, d_scan);
+  DLIOM_HIP_TRY(hipGetLastError());
+  int scan[2] = {0, 0};
+  DLIOM_HIP_TRY(hipMemcpyAsync(scan, d_scan, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (scan[1] != 0) {
+    ctx->end_span(span);
+    return DLIOM_ERR_RAY_TOO_LONG;
+  }
+  if (scan[0] > 8) {
+    ctx->end_span(span);
+    return DLIOM_ERR_GRID_EXTENT;
+  }
+  DLIOM_TRY(g->ensure_bits(scan[0]));
+  DLIOM_TRY(g->ensure_capacity(n * (1 + static_cast<int64_t>(num_free_space_voxels))));
+
+  const GridView v = g->view();
+  a.half = v.half;
+  a.gsize = v.grid_size;
+  a.L = static_cast<unsigned>(v.leaves_per_axis);
+  uint32_t* pool32 = reinterpret_cast<uint32_t*>(g->d_pool);
+  hipLaunchKernelGGL(insert_alloc_kernel, grid, block, 0, ctx->stream, a, g->d_table, g->d_slot_coord,
+                     g->d_count);
+  hipLaunchKernelGGL(insert_apply_kernel<0>, grid, block, 0, ctx->stream, a, g->d_table, pool32, d_hit);
+  if (num_free_space_voxels > 0)
+    hipLaunchKernelGGL(insert_apply_kernel<1>, grid, block, 0, ctx->stream, a, g->d_table, pool32,
+                       d_miss);
+  hipLaunchKernelGGL(insert_apply_kernel<2>, grid, block, 0, ctx->stream, a, g->d_table, pool32, d_hit);
+  DLIOM_HIP_TRY(hipGetLastError());
+  ctx->end_span(span);
+  g->used_upper += n * (1 + static_cast<int64_t>(num_free_space_voxels));
+  // ctx->misc is reused by later calls on this context: finish before returning.
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
+}  // extern "C"

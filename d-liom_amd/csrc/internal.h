@@ -1,0 +1,125 @@
+// Internal declarations shared by the libdliom.so translation units.
+#ifndef DLIOM_CSRC_INTERNAL_H_
+#define DLIOM_CSRC_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/dliom.h"
+
+namespace dliom {
+
+// ---- error plumbing -----------------------------------------------------------
+void set_last_error(const char* what, hipError_t e, const char* file, int line);
+
+#define DLIOM_HIP_TRY(expr)                                          \
+  do {                                                               \
+    hipError_t _e = (expr);                                          \
+    if (_e != hipSuccess) {                                          \
+      ::dliom::set_last_error(#expr, _e, __FILE__, __LINE__);        \
+      return DLIOM_ERR_HIP;                                          \
+    }                                                                \
+  } while (0)
+
+#define DLIOM_TRY(expr)              \
+  do {                               \
+    int _s = (expr);                 \
+    if (_s != DLIOM_OK) return _s;   \
+  } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes);  // contents are NOT preserved on growth
+  void release();
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+// Device view of a grid, passed by value to kernels.
+struct GridView {
+  const uint32_t* table;  // L^3 leaf slots, z-major; 0 = no leaf (slot 0 is all-zero)
+  const uint16_t* pool;   // slot * 512 + ((z&7)<<6 | (y&7)<<3 | (x&7))
+  int half;               // 32 << bits  (voxels): index shift, hybrid_grid.h:267
+  int leaves_per_axis;    // 8 << bits
+  unsigned grid_size;     // 64 << bits (voxels)
+  float resolution;
+};
+
+}  // namespace dliom
+
+struct dliom_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  // scratch (grow-only)
+  dliom::DevBuf points;     // temp clouds for host-pointer entry points
+  dliom::DevBuf cand;       // rotations / translations / penalties
+  dliom::DevBuf sums;       // score volume (uint64 per candidate)
+  dliom::DevBuf bounds;     // lo/hi floats, survivor list, counters
+  dliom::DevBuf rescore;    // per-survivor per-point probabilities
+  dliom::DevBuf partials;   // CSM per-block partial sums
+  dliom::DevBuf misc;       // small odds and ends (probe outputs, cell lists)
+  void* pinned = nullptr;   // small pinned host staging block
+  size_t pinned_bytes = 0;
+  // profiling
+  bool profiling = false;
+  struct Span {
+    hipEvent_t a, b;
+    int id;
+  };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> event_pool;
+  double kernel_ms[DLIOM_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  int64_t kernel_launches[DLIOM_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  dliom_rtcsm_stats last_rtcsm = {};
+
+  int begin_span(int id);  // returns span index or -1
+  void end_span(int span);
+  int collect_spans();     // synchronises the stream
+};
+
+struct dliom_grid {
+  dliom_ctx* ctx = nullptr;
+  float resolution = 0.f;
+  int bits = 1;                 // DynamicGrid::bits_ (hybrid_grid.h:255)
+  uint32_t* d_table = nullptr;  // (8<<bits)^3 entries
+  uint16_t* d_pool = nullptr;   // capacity * 512 values; slot 0 reserved (zeros)
+  int32_t* d_slot_coord = nullptr;  // capacity * 3: leaf coordinates (voxel index >> 3)
+  uint32_t* d_count = nullptr;  // number of used slots including slot 0
+  int64_t capacity = 0;         // slots
+  int64_t used_upper = 1;       // host-side upper bound of *d_count
+  dliom::GridView view() const;
+  int ensure_bits(int needed_bits);
+  int ensure_capacity(int64_t additional_slots);
+  int refresh_count(int64_t* count);
+};
+
+struct dliom_cloud {
+  dliom_ctx* ctx = nullptr;
+  int64_t n = 0;
+  int64_t n_padded = 0;    // multiple of 1024; pad lanes are flagged invalid by index
+  float* d_x = nullptr;    // SoA in HBM
+  float* d_y = nullptr;
+  float* d_z = nullptr;
+  float max_norm = 0.f;    // max_i ||p_i|| (float, Eigen order), host computed
+  bool owned_by_ctx_scratch = false;
+};
+
+namespace dliom {
+// host-pointer cloud staged in ctx->points (valid until the next staging call)
+int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud* out,
+                size_t scratch_offset_bytes = 0);
+float cloud_max_norm(const float* points_xyz, int64_t n);
+size_t staged_cloud_bytes(int64_t n);
+int needed_bits_for_cell_range(int min_index, int max_index);
+}  // namespace dliom
+
+#endif  // DLIOM_CSRC_INTERNAL_H_

@@ -1,0 +1,631 @@
+// RealTimeCorrelativeScanMatcher3D on gfx950.
+//
+// Replaces mapping/internal/3d/scan_matching/real_time_correlative_scan_matcher_3d.cc
+// (:34-53 Match, :55-95 GenerateExhaustiveSearchTransforms, :97-113 ScoreCandidate).
+//
+// Pipeline per Match (DESIGN.md "RTCSM3D"):
+//   host   window sizes, the (2A+1)^3 candidate rotations normalized(q_init * q_r) and the
+//          (2L+1)^3 candidate translations q_init * t_j + t_init, in the reference's float
+//          arithmetic (candidate c = j * R + r in generation order z,y,x,rz,ry,rx)
+//   GPU A  score volume: exact integer sum_i max(v_i & 0x7fff, 1) per candidate
+//   GPU B  rigorous float-score interval per candidate from that sum; candidates whose upper
+//          bound reaches the best lower bound survive
+//   GPU C  survivors only: per-point probabilities, then the reference's SEQUENTIAL float sum in
+//          point order (one lane per survivor) -> bit-identical scores
+//   host   score = sum / N * exp(-(|t| wt + angle wr)^2) as the reference computes it; first
+//          strictly greater score in generation order wins.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "device_common.h"
+#include "host_math.h"
+
+namespace dliom {
+
+constexpr int kBlock = 256;
+constexpr int kTC = 27;  // translations accumulated per register chunk
+
+// ---------------------------------------------------------------------------------- kernel A
+// grid = (point tiles, rotation tiles).  Each thread keeps PPT points in registers, the wave
+// walks the block's rotations (uniform -> scalar loads), and for every rotation accumulates the
+// TC translation candidates in registers before one DPP reduction + one atomic per candidate.
+template <int PPT, int TC>
+__global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
+    GridView g, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, int n, const float4* __restrict__ rot, int R,
+    const float* __restrict__ trans, int T, int rots_per_block,
+    unsigned long long* __restrict__ sums) {
+  float x[PPT], y[PPT], z[PPT];
+  unsigned valid[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i = (blockIdx.x * PPT + k) * kBlock + threadIdx.x;
+    valid[k] = i < n ? 1u : 0u;
+    x[k] = px[i];  // clouds are padded to a multiple of 1024 points
+    y[k] = py[i];
+    z[k] = pz[i];
+  }
+  const int r_begin = blockIdx.y * rots_per_block;
+  const int r_end = min(r_begin + rots_per_block, R);
+  const int lane = threadIdx.x & 63;
+  for (int r = r_begin; r < r_end; ++r) {
+    const float4 qq = rot[r];
+    const Quat4 q{qq.x, qq.y, qq.z, qq.w};  // stored (w,x,y,z)
+    float rx[PPT], ry[PPT], rz[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) rotate_point(q, x[k], y[k], z[k], rx[k], ry[k], rz[k]);
+    for (int jc = 0; jc < T; jc += TC) {
+      unsigned acc[TC];
+#pragma unroll
+      for (int jj = 0; jj < TC; ++jj) {
+        const float tx = trans[3 * (jc + jj)];
+        const float ty = trans[3 * (jc + jj) + 1];
+        const float tz = trans[3 * (jc + jj) + 2];
+        unsigned a = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const int ix = cell_of(rx[k] + tx, g.resolution);
+          const int iy = cell_of(ry[k] + ty, g.resolution);
+          const int iz = cell_of(rz[k] + tz, g.resolution);
+          unsigned v = grid_value(g, ix, iy, iz) & 0x7FFFu;
+          v = max(v, 1u);
+          a += v * valid[k];
+        }
+        acc[jj] = a;
+      }
+#pragma unroll
+      for (int jj = 0; jj < TC; ++jj) {
+        const unsigned total = wave_sum_lane63(acc[jj]);
+        if (lane == 63 && jc + jj < T) {
+          atomicAdd(&sums[static_cast<size_t>(jc + jj) * R + r],
+                    static_cast<unsigned long long>(total));
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- kernel B
+struct BoundParams {
+  double a;        // (double)kScale
+  double b;        // (double)(kMin - kScale)
+  double delta;    // max |LUT[v] - (a v + b)|, v' convention (0 -> 1)
+  double wt, wr;   // penalty weights
+  int n;           // points
+  int R, T;
+};
+
+// Upper bound of the accumulated rounding error of the reference's sequential float sum.
+// Each addition is off by at most half an ulp of its result (round to nearest) and the partial
+// sums s_m are monotone, so the error after m additions is <= m 2^-24 s_m; with every addend
+// <= 0.9000001 this gives s_m <= 0.9000001 m / (1 - m 2^-24) <= 0.93 m for m <= 2^19.  Together
+// with s_m <= U (the final sum's upper bound) the (i+1)-th result is <= min(0.93 (i+1), U).
+__device__ double seq_sum_error_bound(int n, double U) {
+  double err = 0.0;
+  long long i = 0;  // indices [0, i) are already accounted for
+  // binade k: results in [2^k, 2^(k+1)) have ulp 2^(k-23).  Index i (the (i+1)-th addition) has
+  // its result bounded by B_i = min(0.93 (i+1), U).
+  for (int k = -4; k < 64 && i < n; ++k) {
+    const double top = ldexp(1.0, k + 1);
+    long long last;  // indices [i, last) are charged this binade's ulp
+    if (U < top) {
+      last = n;  // the cap keeps every remaining result below `top`
+    } else {
+      // 0.93 (idx+1) < top  <=>  idx + 1 < top / 0.93 ; one index fewer guards the division's rounding
+      last = static_cast<long long>(floor(top / 0.93)) - 1;
+      if (last > n) last = n;
+    }
+    if (last > i) {
+      err += 0.5 * ldexp(1.0, k - 23) * static_cast<double>(last - i);
+      i = last;
+    }
+  }
+  return err;
+}
+
+__device__ __forceinline__ float next_up(float f) { return __uint_as_float(__float_as_uint(f) + 1u); }
+__device__ __forceinline__ float next_down(float f) {
+  const unsigned u = __float_as_uint(f);
+  return u == 0u ? 0.f : __uint_as_float(u - 1u);
+}
+
+__global__ void rtcsm_bounds_kernel(const unsigned long long* __restrict__ sums, long long C,
+                                    const float* __restrict__ t_norm, const float* __restrict__ r_angle,
+                                    BoundParams p, float* __restrict__ lo, float* __restrict__ hi,
+                                    unsigned* __restrict__ best_lo_bits) {
+  const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int j = static_cast<int>(c / p.R), r = static_cast<int>(c % p.R);
+  const double s = static_cast<double>(sums[c]);
+  const double mid = p.a * s + p.b * p.n;
+  const double slack = p.delta * p.n + 1e-9 * mid;
+  double sum_lo = mid - slack, sum_hi = mid + slack;
+  const double U = sum_hi * (1.0 + 1.0 / 32.0);
+  const double e = seq_sum_error_bound(p.n, U);
+  float flo, fhi;
+  if (sum_hi + e > U || p.n > (1 << 19)) {  // bound not applicable: keep the candidate
+    flo = 0.f;
+    fhi = 3.0e38f;
+  } else {
+    sum_lo -= e;
+    sum_hi += e;
+    // score = float(double(float(sum)/float(N)) * exp(-(|t| wt + angle wr)^2)); every step is
+    // monotone in sum, so outward-rounded endpoints bracket the reference's value.
+    const double arg = static_cast<double>(t_norm[j]) * p.wt + static_cast<double>(r_angle[r]) * p.wr;
+    const double pen = exp(-(arg * arg));
+    const float nf = static_cast<float>(p.n);
+    float qlo = next_down(next_down(static_cast<float>(sum_lo))) / nf;
+    float qhi = next_up(next_up(static_cast<float>(sum_hi))) / nf;
+    qlo = next_down(qlo);
+    qhi = next_up(qhi);
+    flo = next_down(next_down(static_cast<float>(static_cast<double>(qlo) * pen * (1.0 - 1e-9))));
+    fhi = next_up(next_up(static_cast<float>(static_cast<double>(qhi) * pen * (1.0 + 1e-9))));
+    if (!(flo > 0.f)) flo = 0.f;
+  }
+  lo[c] = flo;
+  hi[c] = fhi;
+  atomicMax(best_lo_bits, __float_as_uint(flo));  // non-negative floats order like their bits
+}
+
+__global__ void rtcsm_select_kernel(const float* __restrict__ hi, long long C,
+                                    const unsigned* __restrict__ best_lo_bits,
+                                    unsigned* __restrict__ count, unsigned* __restrict__ list) {
+  const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float best_lo = __uint_as_float(*best_lo_bits);
+  if (hi[c] >= best_lo) {
+    const unsigned k = atomicAdd(count, 1u);
+    list[k] = static_cast<unsigned>(c);
+  }
+}
+
+// ---------------------------------------------------------------------------------- kernel C
+// Per survivor k and point i: ValueToProbability(value) as a float, stored candidate-major so
+// that the chain kernel reads 16 contiguous bytes per lane.
+__global__ void rtcsm_rescore_values_kernel(GridView g, const float* __restrict__ px,
+                                            const float* __restrict__ py,
+                                            const float* __restrict__ pz, int n, int n_stride,
+                                            const float4* __restrict__ rot, int R,
+                                            const float* __restrict__ trans,
+                                            const unsigned* __restrict__ list, float k_scale,
+                                            float k_offset, float k_unknown,
+                                            float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned c = list[blockIdx.y];
+  if (i >= n_stride) return;
+  float prob = 0.f;  // +0.f padding leaves a float running sum unchanged
+  if (i < n) {
+    const int j = static_cast<int>(c / static_cast<unsigned>(R));
+    const int r = static_cast<int>(c % static_cast<unsigned>(R));
+    const float4 qq = rot[r];
+    const Quat4 q{qq.x, qq.y, qq.z, qq.w};
+    float rx, ry, rz;
+    rotate_point(q, px[i], py[i], pz[i], rx, ry, rz);
+    const int ix = cell_of(rx + trans[3 * j], g.resolution);
+    const int iy = cell_of(ry + trans[3 * j + 1], g.resolution);
+    const int iz = cell_of(rz + trans[3 * j + 2], g.resolution);
+    const unsigned v = grid_value(g, ix, iy, iz) & 0x7FFFu;
+    // probability_values.cc:27-36: value * kScale + (lower_bound - kScale); 0 -> kMinProbability
+    prob = v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset;
+  }
+  out[static_cast<size_t>(blockIdx.y) * n_stride + i] = prob;
+}
+
+// The reference's `score += probability` loop (rtcsm_3d.cc:101-104): strictly sequential float
+// additions in point order, one lane per surviving candidate.
+__global__ void rtcsm_chain_kernel(const float* __restrict__ probs, int n_stride, unsigned K,
+                                   float* __restrict__ sums) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const float4* row = reinterpret_cast<const float4*>(probs + static_cast<size_t>(k) * n_stride);
+  float s = 0.f;
+  const int n4 = n_stride >> 2;
+#pragma unroll 4
+  for (int i = 0; i < n4; ++i) {
+    const float4 v = row[i];
+    s += v.x;
+    s += v.y;
+    s += v.z;
+    s += v.w;
+  }
+  sums[k] = s;
+}
+
+// ---------------------------------------------------------------------------------- probes
+__global__ void probe_cells_kernel(Quat4 q, float tx, float ty, float tz, const float* __restrict__ px,
+                                   const float* __restrict__ py, const float* __restrict__ pz, int n,
+                                   float resolution, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float rx, ry, rz;
+  rotate_point(q, px[i], py[i], pz[i], rx, ry, rz);
+  out[3 * i] = cell_of(rx + tx, resolution);
+  out[3 * i + 1] = cell_of(ry + ty, resolution);
+  out[3 * i + 2] = cell_of(rz + tz, resolution);
+}
+
+// ---------------------------------------------------------------------------------- host side
+struct Candidates {
+  dliom_rtcsm_window w;
+  PoseF init;
+  std::vector<QF> rot;        // candidate rotation  normalized(init.q * q_r)
+  std::vector<QF> rot_raw;    // q_r (transform rotation)
+  std::vector<float> r_angle; // GetAngle(transform) per rotation
+  std::vector<F3> trans;      // candidate translation init.q * t_j + init.t
+  std::vector<float> t_norm;  // ||t_j||
+};
+
+// rtcsm_3d.cc:58-70
+static void compute_window(const dliom_rtcsm_options& o, float resolution, float cloud_max_norm_value,
+                           dliom_rtcsm_window* w) {
+  w->linear_window_size = static_cast<int>(std::lround(o.linear_search_window / resolution));
+  float max_scan_range = 3.f * resolution;
+  max_scan_range = std::max(cloud_max_norm_value, max_scan_range);
+  const float kSafetyMargin = 1.f - 1e-3f;
+  const float res2 = resolution * (resolution * 1.f);
+  const float range2 = max_scan_range * (max_scan_range * 1.f);
+  w->angular_step_size = kSafetyMargin * std::acos(1.f - res2 / (2.f * range2));
+  w->angular_window_size =
+      static_cast<int>(std::lround(o.angular_search_window / w->angular_step_size));
+  w->max_scan_range = max_scan_range;
+  const int64_t tl = 2 * static_cast<int64_t>(w->linear_window_size) + 1;
+  const int64_t ta = 2 * static_cast<int64_t>(w->angular_window_size) + 1;
+  w->num_translations = tl * tl * tl;
+  w->num_rotations = ta * ta * ta;
+  w->num_candidates = w->num_translations * w->num_rotations;
+}
+
+static void generate_candidates(const dliom_rtcsm_options& o, float resolution, float max_norm,
+                                const double init7[7], Candidates* c) {
+  compute_window(o, resolution, max_norm, &c->w);
+  c->init.t = F3{static_cast<float>(init7[0]), static_cast<float>(init7[1]), static_cast<float>(init7[2])};
+  c->init.q = QF{static_cast<float>(init7[3]), static_cast<float>(init7[4]),
+                 static_cast<float>(init7[5]), static_cast<float>(init7[6])};
+  const int L = c->w.linear_window_size, A = c->w.angular_window_size;
+  const float step = c->w.angular_step_size;
+  c->rot.clear();
+  c->rot_raw.clear();
+  c->r_angle.clear();
+  c->trans.clear();
+  c->t_norm.clear();
+  c->rot.reserve(c->w.num_rotations);
+  for (int rz = -A; rz <= A; ++rz)
+    for (int ry = -A; ry <= A; ++ry)
+      for (int rx = -A; rx <= A; ++rx) {
+        const QF q = angle_axis_to_quaternion(F3{rx * step, ry * step, rz * step});
+        c->rot_raw.push_back(q);
+        c->r_angle.push_back(rotation_angle(q));
+        c->rot.push_back(qnormalized(qmul(c->init.q, q)));
+      }
+  for (int z = -L; z <= L; ++z)
+    for (int y = -L; y <= L; ++y)
+      for (int x = -L; x <= L; ++x) {
+        const F3 t{x * resolution, y * resolution, z * resolution};
+        c->t_norm.push_back(norm3(t));
+        c->trans.push_back(add3(qrot(c->init.q, t), c->init.t));
+      }
+}
+
+// Device copies of the candidate tables inside ctx->cand.
+struct DeviceCandidates {
+  float4* rot;
+  float* trans;    // padded to a multiple of kTC entries
+  float* t_norm;
+  float* r_angle;
+};
+
+static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidates* d) {
+  const size_t R = c.rot.size(), T = c.trans.size();
+  const size_t Tpad = ((T + kTC - 1) / kTC) * kTC;
+  const size_t bytes_rot = (R * 16 + 255) & ~static_cast<size_t>(255);
+  const size_t bytes_trans = (Tpad * 12 + 255) & ~static_cast<size_t>(255);
+  const size_t bytes_tn = (T * 4 + 255) & ~static_cast<size_t>(255);
+  const size_t bytes_ra = (R * 4 + 255) & ~static_cast<size_t>(255);
+  const size_t total = bytes_rot + bytes_trans + bytes_tn + bytes_ra;
+  DLIOM_TRY(ctx->cand.reserve(total));
+  std::vector<char> host(total, 0);
+  float* hr = reinterpret_cast<float*>(host.data());
+  for (size_t i = 0; i < R; ++i) {
+    hr[4 * i] = c.rot[i].w;
+    hr[4 * i + 1] = c.rot[i].x;
+    hr[4 * i + 2] = c.rot[i].y;
+    hr[4 * i + 3] = c.rot[i].z;
+  }
+  float* ht = reinterpret_cast<float*>(host.data() + bytes_rot);
+  for (size_t i = 0; i < Tpad; ++i) {
+    const F3& t = c.trans[std::min(i, T - 1)];  // padding repeats the last translation (unused)
+    ht[3 * i] = t.x;
+    ht[3 * i + 1] = t.y;
+    ht[3 * i + 2] = t.z;
+  }
+  std::memcpy(host.data() + bytes_rot + bytes_trans, c.t_norm.data(), T * 4);
+  std::memcpy(host.data() + bytes_rot + bytes_trans + bytes_tn, c.r_angle.data(), R * 4);
+  char* base = static_cast<char*>(ctx->cand.p);
+  if (total <= ctx->pinned_bytes) {
+    // Pinned staging: truly asynchronous.  Every entry point that gets here synchronises the
+    // stream before it returns, so the block is free again at the next call.
+    std::memcpy(ctx->pinned, host.data(), total);
+    DLIOM_HIP_TRY(hipMemcpyAsync(base, ctx->pinned, total, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    DLIOM_HIP_TRY(hipMemcpyAsync(base, host.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `host` dies at scope exit
+  }
+  d->rot = reinterpret_cast<float4*>(base);
+  d->trans = reinterpret_cast<float*>(base + bytes_rot);
+  d->t_norm = reinterpret_cast<float*>(base + bytes_rot + bytes_trans);
+  d->r_angle = reinterpret_cast<float*>(base + bytes_rot + bytes_trans + bytes_tn);
+  return DLIOM_OK;
+}
+
+template <int PPT>
+static void launch_score(dliom_ctx* ctx, const GridView& g, const dliom_cloud& cloud,
+                         const DeviceCandidates& d, int R, int T, unsigned long long* sums) {
+  const int n = static_cast<int>(cloud.n);
+  const int tile = kBlock * PPT;
+  const int point_tiles = (n + tile - 1) / tile;
+  // aim for >= ~4096 workgroups so every CU holds several waves, without making the per-block
+  // rotation loop shorter than one rotation
+  int rot_tiles = std::max(1, std::min(R, (4096 + point_tiles - 1) / point_tiles));
+  const int rots_per_block = (R + rot_tiles - 1) / rot_tiles;
+  rot_tiles = (R + rots_per_block - 1) / rots_per_block;
+  const dim3 grid(point_tiles, rot_tiles), block(kBlock);
+  if (T == 1) {
+    hipLaunchKernelGGL((rtcsm_score_kernel<PPT, 1>), grid, block, 0, ctx->stream, g, cloud.d_x,
+                       cloud.d_y, cloud.d_z, n, d.rot, R, d.trans, T, rots_per_block, sums);
+  } else {
+    hipLaunchKernelGGL((rtcsm_score_kernel<PPT, kTC>), grid, block, 0, ctx->stream, g, cloud.d_x,
+                       cloud.d_y, cloud.d_z, n, d.rot, R, d.trans, T, rots_per_block, sums);
+  }
+}
+
+static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid,
+                            const Candidates& c, DeviceCandidates* d, unsigned long long** d_sums) {
+  DLIOM_TRY(upload_candidates(ctx, c, d));
+  const int64_t C = c.w.num_candidates;
+  DLIOM_TRY(ctx->sums.reserve(static_cast<size_t>(C) * 8));
+  *d_sums = ctx->sums.as<unsigned long long>();
+  DLIOM_HIP_TRY(hipMemsetAsync(*d_sums, 0, static_cast<size_t>(C) * 8, ctx->stream));
+  const GridView g = grid->view();
+  const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
+  const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
+  if (cloud.n >= 4 * 1024) {
+    launch_score<4>(ctx, g, cloud, *d, R, T, *d_sums);
+  } else {
+    launch_score<1>(ctx, g, cloud, *d, R, T, *d_sums);
+  }
+  ctx->end_span(span);
+  DLIOM_HIP_TRY(hipGetLastError());
+  return DLIOM_OK;
+}
+
+// LUT constants of probability_values.cc:27-36 in float, plus the affine fit used by the bounds.
+struct LutModel {
+  float k_scale, k_offset, k_unknown;
+  double a, b, delta;
+};
+static const LutModel& lut_model() {
+  static const LutModel m = [] {
+    LutModel r;
+    const float kMin = 0.1f, kMax = 1.f - 0.1f;
+    r.k_scale = (kMax - kMin) / 32766.f;
+    r.k_offset = kMin - r.k_scale;
+    r.k_unknown = kMin;
+    r.a = static_cast<double>(r.k_scale);
+    r.b = static_cast<double>(r.k_offset);
+    double d = std::fabs(static_cast<double>(kMin) - (r.a * 1.0 + r.b));  // value 0 counted as 1
+    for (int v = 1; v < 32768; ++v) {
+      const float f = v * r.k_scale + r.k_offset;
+      d = std::max(d, std::fabs(static_cast<double>(f) - (r.a * v + r.b)));
+    }
+    r.delta = d * 1.0000001 + 1e-12;
+    return r;
+  }();
+  return m;
+}
+
+static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                      const dliom_cloud& cloud, const dliom_grid* grid, double out7[7],
+                      float* out_score) {
+  if (cloud.n <= 0) return DLIOM_ERR_EMPTY_CLOUD;
+  if (cloud.n > (1 << 27)) return DLIOM_ERR_INVALID_ARGUMENT;
+  Candidates c;
+  generate_candidates(*o, grid->resolution, cloud.max_norm, init7, &c);
+  const int64_t C = c.w.num_candidates;
+  const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
+  if (C <= 0 || C > (int64_t{1} << 31)) return DLIOM_ERR_INVALID_ARGUMENT;
+
+  DeviceCandidates d;
+  unsigned long long* d_sums = nullptr;
+  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, &d, &d_sums));
+
+  // ---- bounds + selection
+  const size_t bytes_f = (static_cast<size_t>(C) * 4 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->bounds.reserve(3 * bytes_f + 256));
+  char* bb = static_cast<char*>(ctx->bounds.p);
+  float* d_lo = reinterpret_cast<float*>(bb);
+  float* d_hi = reinterpret_cast<float*>(bb + bytes_f);
+  unsigned* d_list = reinterpret_cast<unsigned*>(bb + 2 * bytes_f);
+  unsigned* d_ctrs = reinterpret_cast<unsigned*>(bb + 3 * bytes_f);  // [0] best_lo bits, [1] count
+  DLIOM_HIP_TRY(hipMemsetAsync(d_ctrs, 0, 8, ctx->stream));
+  const LutModel& lm = lut_model();
+  BoundParams bp;
+  bp.a = lm.a;
+  bp.b = lm.b;
+  bp.delta = lm.delta;
+  bp.wt = o->translation_delta_cost_weight;
+  bp.wr = o->rotation_delta_cost_weight;
+  bp.n = static_cast<int>(cloud.n);
+  bp.R = R;
+  bp.T = T;
+  const unsigned cblocks = static_cast<unsigned>((C + 255) / 256);
+  int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SELECT);
+  hipLaunchKernelGGL(rtcsm_bounds_kernel, dim3(cblocks), dim3(256), 0, ctx->stream, d_sums,
+                     static_cast<long long>(C), d.t_norm, d.r_angle, bp, d_lo, d_hi, d_ctrs);
+  hipLaunchKernelGGL(rtcsm_select_kernel, dim3(cblocks), dim3(256), 0, ctx->stream, d_hi,
+                     static_cast<long long>(C), d_ctrs, d_ctrs + 1, d_list);
+  ctx->end_span(span);
+  DLIOM_HIP_TRY(hipGetLastError());
+  unsigned ctrs[2] = {0, 0};
+  DLIOM_HIP_TRY(hipMemcpyAsync(ctrs, d_ctrs, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const unsigned K = ctrs[1];
+  if (K == 0) return DLIOM_ERR_SCORE_NOT_POSITIVE;  // cannot happen: the best-lo candidate survives
+
+  // ---- exact sequential rescoring of the survivors (batched: <= 1 GiB of probabilities and
+  //      <= 65535 rows per launch)
+  const int n = static_cast<int>(cloud.n);
+  const int n_stride = (n + 3) & ~3;
+  const size_t row_bytes = static_cast<size_t>(n_stride) * 4;
+  unsigned batch = static_cast<unsigned>(std::min<size_t>(65535, std::max<size_t>(64, (size_t{1} << 30) / row_bytes)));
+  batch = std::min(batch, K);
+  const size_t bytes_probs = static_cast<size_t>(batch) * row_bytes;
+  const size_t bytes_ks = (static_cast<size_t>(K) * 4 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->rescore.reserve(bytes_probs + bytes_ks));
+  float* d_probs = ctx->rescore.as<float>();
+  float* d_ksums = reinterpret_cast<float*>(static_cast<char*>(ctx->rescore.p) + bytes_probs);
+  span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
+  for (unsigned k0 = 0; k0 < K; k0 += batch) {
+    const unsigned kb = std::min(batch, K - k0);
+    const dim3 rgrid((n_stride + 255) / 256, kb);
+    hipLaunchKernelGGL(rtcsm_rescore_values_kernel, rgrid, dim3(256), 0, ctx->stream, grid->view(),
+                       cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, d.rot, R, d.trans, d_list + k0,
+                       lm.k_scale, lm.k_offset, lm.k_unknown, d_probs);
+    hipLaunchKernelGGL(rtcsm_chain_kernel, dim3((kb + 63) / 64), dim3(64), 0, ctx->stream, d_probs,
+                       n_stride, kb, d_ksums + k0);
+  }
+  ctx->end_span(span);
+  DLIOM_HIP_TRY(hipGetLastError());
+  std::vector<unsigned> list(K);
+  std::vector<float> ksums(K);
+  DLIOM_HIP_TRY(hipMemcpyAsync(list.data(), d_list, static_cast<size_t>(K) * 4, hipMemcpyDeviceToHost,
+                               ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(ksums.data(), d_ksums, static_cast<size_t>(K) * 4,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+  // ---- final scoring exactly as rtcsm_3d.cc:105-112, first maximum in generation order
+  float best_score = -1.f;
+  int64_t best_c = -1;
+  for (unsigned k = 0; k < K; ++k) {
+    const int64_t cc = list[k];
+    const int j = static_cast<int>(cc / R), r = static_cast<int>(cc % R);
+    float score = ksums[k];
+    score /= static_cast<float>(n);
+    const double arg = c.t_norm[j] * o->translation_delta_cost_weight +
+                       c.r_angle[r] * o->rotation_delta_cost_weight;
+    score *= std::exp(-(arg * (arg * 1.0)));
+    if (score > best_score || (score == best_score && cc < best_c)) {
+      best_score = score;
+      best_c = cc;
+    }
+  }
+  ctx->last_rtcsm.window = c.w;
+  ctx->last_rtcsm.num_points = cloud.n;
+  ctx->last_rtcsm.num_rescored = K;
+  ctx->last_rtcsm.best_index = best_c;
+  if (!(best_score > 0.f)) return DLIOM_ERR_SCORE_NOT_POSITIVE;
+  const int j = static_cast<int>(best_c / R), r = static_cast<int>(best_c % R);
+  out7[0] = c.trans[j].x;
+  out7[1] = c.trans[j].y;
+  out7[2] = c.trans[j].z;
+  out7[3] = c.rot[r].w;
+  out7[4] = c.rot[r].x;
+  out7[5] = c.rot[r].y;
+  out7[6] = c.rot[r].z;
+  *out_score = best_score;
+  return DLIOM_OK;
+}
+
+}  // namespace dliom
+
+using namespace dliom;
+
+extern "C" {
+
+int dliom_rtcsm3d_window(const dliom_rtcsm_options* o, float resolution, const float* points_xyz,
+                         int64_t n, dliom_rtcsm_window* w) {
+  if (o == nullptr || w == nullptr || n < 0 || (n > 0 && points_xyz == nullptr))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  compute_window(*o, resolution, cloud_max_norm(points_xyz, n), w);
+  return DLIOM_OK;
+}
+
+int dliom_rtcsm3d_match_cloud(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                              const dliom_cloud* cloud, const dliom_grid* grid, double out7[7],
+                              float* score) {
+  if (ctx == nullptr || o == nullptr || init7 == nullptr || cloud == nullptr || grid == nullptr ||
+      out7 == nullptr || score == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  return match_impl(ctx, o, init7, *cloud, grid, out7, score);
+}
+
+int dliom_rtcsm3d_match(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                        const float* points_xyz, int64_t n, const dliom_grid* grid, double out7[7],
+                        float* score) {
+  if (ctx == nullptr || o == nullptr || init7 == nullptr || grid == nullptr || out7 == nullptr ||
+      score == nullptr || n < 0 || (n > 0 && points_xyz == nullptr))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_ERR_EMPTY_CLOUD;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_TRY(ctx->points.reserve(staged_cloud_bytes(n)));
+  dliom_cloud cloud;
+  DLIOM_TRY(stage_cloud(ctx, points_xyz, n, &cloud));
+  return match_impl(ctx, o, init7, cloud, grid, out7, score);
+}
+
+int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats) {
+  if (ctx == nullptr || stats == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *stats = ctx->last_rtcsm;
+  return DLIOM_OK;
+}
+
+int dliom_rtcsm3d_score_volume(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                               const float* points_xyz, int64_t n, const dliom_grid* grid,
+                               uint64_t* sums, int64_t capacity, int64_t* num_candidates) {
+  if (ctx == nullptr || o == nullptr || init7 == nullptr || grid == nullptr ||
+      num_candidates == nullptr || n <= 0 || points_xyz == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_TRY(ctx->points.reserve(staged_cloud_bytes(n)));
+  dliom_cloud cloud;
+  DLIOM_TRY(stage_cloud(ctx, points_xyz, n, &cloud));
+  Candidates c;
+  generate_candidates(*o, grid->resolution, cloud.max_norm, init7, &c);
+  *num_candidates = c.w.num_candidates;
+  if (sums == nullptr) return DLIOM_OK;
+  if (capacity < c.w.num_candidates) return DLIOM_ERR_CAPACITY;
+  DeviceCandidates d;
+  unsigned long long* d_sums = nullptr;
+  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, &d, &d_sums));
+  DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_sums, static_cast<size_t>(c.w.num_candidates) * 8,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
+int dliom_probe_transform_cell_indices(dliom_ctx* ctx, const float pose[7], const float* points_xyz,
+                                       int64_t n, float resolution, int32_t* cell_xyz) {
+  if (ctx == nullptr || pose == nullptr || n < 0 || (n > 0 && (points_xyz == nullptr || cell_xyz == nullptr)))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_OK;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_TRY(ctx->points.reserve(staged_cloud_bytes(n)));
+  dliom_cloud cloud;
+  DLIOM_TRY(stage_cloud(ctx, points_xyz, n, &cloud));
+  DLIOM_TRY(ctx->misc.reserve(static_cast<size_t>(n) * 12));
+  int* d_out = ctx->misc.as<int>();
+  const Quat4 q{pose[3], pose[4], pose[5], pose[6]};
+  hipLaunchKernelGGL(probe_cells_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                     ctx->stream, q, pose[0], pose[1], pose[2], cloud.d_x, cloud.d_y, cloud.d_z,
+                     static_cast<int>(n), resolution, d_out);
+  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_HIP_TRY(hipMemcpyAsync(cell_xyz, d_out, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost,
+                               ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,450 @@
+"""Python mirror of the reference's operator surface over libdliom.so (C ABI in
+include/dliom.h).  Class and method names follow cartographer::mapping so the
+parity tests read like the reference's own tests:
+
+    HybridGrid                          mapping/3d/hybrid_grid.h:470-547
+    RangeDataInserter3D                 mapping/3d/range_data_inserter_3d.h:35-47
+    RealTimeCorrelativeScanMatcher3D    .../real_time_correlative_scan_matcher_3d.h:34-66
+    CeresScanMatcher3D                  .../ceres_scan_matcher_3d.h:37-63
+
+Everything here calls the HIP library; there is NO CPU fallback.  Importing the
+package without a built libdliom.so, or creating a Context without a GPU, fails
+loudly (DliomError).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdliom.so")
+
+
+class DliomError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = _lib.dliom_status_string(status).decode() if _lib is not None else "library not loaded"
+        detail = _lib.dliom_last_error().decode() if _lib is not None and status == -2 else ""
+        super().__init__("%s: %s (%d) %s" % (where, msg, status, detail))
+
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_HIP = -2
+ERR_NO_DEVICE = -3
+ERR_SCORE_NOT_POSITIVE = -4
+ERR_WEIGHTS = -5
+ERR_GRID_EXTENT = -6
+ERR_RAY_TOO_LONG = -7
+ERR_EMPTY_CLOUD = -8
+ERR_CAPACITY = -9
+ERR_SOLVER = -10
+
+KERNEL_RTCSM_SCORE, KERNEL_RTCSM_SELECT, KERNEL_RTCSM_RESCORE, KERNEL_CSM_EVAL, KERNEL_INSERT = range(5)
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u16p = C.POINTER(C.c_uint16)
+_u64p = C.POINTER(C.c_uint64)
+_vp = C.c_void_p
+
+
+class RtcsmOptions(C.Structure):
+    _fields_ = [("linear_search_window", C.c_double), ("angular_search_window", C.c_double),
+                ("translation_delta_cost_weight", C.c_double), ("rotation_delta_cost_weight", C.c_double)]
+
+
+class RtcsmWindow(C.Structure):
+    _fields_ = [("linear_window_size", C.c_int), ("angular_window_size", C.c_int),
+                ("angular_step_size", C.c_float), ("max_scan_range", C.c_float),
+                ("num_translations", C.c_int64), ("num_rotations", C.c_int64),
+                ("num_candidates", C.c_int64)]
+
+
+class RtcsmStats(C.Structure):
+    _fields_ = [("window", RtcsmWindow), ("num_points", C.c_int64), ("num_rescored", C.c_int64),
+                ("best_index", C.c_int64)]
+
+
+MAX_CLOUDS = 8
+
+
+class CsmOptions(C.Structure):
+    _fields_ = [("num_occupied_space_weights", C.c_int), ("occupied_space_weight", C.c_double * MAX_CLOUDS),
+                ("translation_weight", C.c_double), ("rotation_weight", C.c_double),
+                ("only_optimize_yaw", C.c_int), ("use_nonmonotonic_steps", C.c_int),
+                ("max_num_iterations", C.c_int), ("num_threads", C.c_int)]
+
+
+class CsmSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("num_successful_steps", C.c_int), ("num_unsuccessful_steps", C.c_int),
+                ("num_iterations", C.c_int), ("num_residual_evaluations", C.c_int),
+                ("num_jacobian_evaluations", C.c_int), ("termination_type", C.c_int)]
+
+
+# Every symbol include/dliom.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("dliom_status_string", C.c_char_p, [C.c_int]),
+    ("dliom_last_error", C.c_char_p, []),
+    ("dliom_device_count", C.c_int, []),
+    ("dliom_ctx_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("dliom_ctx_create_on_stream", C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    ("dliom_ctx_destroy", C.c_int, [_vp]),
+    ("dliom_ctx_synchronize", C.c_int, [_vp]),
+    ("dliom_compute_lookup_table_to_apply_odds", C.c_int, [C.c_float, _u16p]),
+    ("dliom_odds", C.c_float, [C.c_float]),
+    ("dliom_value_to_probability_table", C.c_int, [_f32p]),
+    ("dliom_grid_create", C.c_int, [_vp, C.c_float, C.POINTER(_vp)]),
+    ("dliom_grid_destroy", C.c_int, [_vp]),
+    ("dliom_grid_resolution", C.c_int, [_vp, _f32p]),
+    ("dliom_grid_bits", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("dliom_grid_upload_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64]),
+    ("dliom_grid_num_blocks", C.c_int, [_vp, _i64p]),
+    ("dliom_grid_download_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64, _i64p]),
+    ("dliom_grid_get_values", C.c_int, [_vp, _i32p, C.c_int64, _u16p]),
+    ("dliom_grid_insert", C.c_int, [_vp, _f32p, _f32p, C.c_int64, _u16p, _u16p, C.c_int]),
+    ("dliom_cloud_create", C.c_int, [_vp, _f32p, C.c_int64, C.POINTER(_vp)]),
+    ("dliom_cloud_destroy", C.c_int, [_vp]),
+    ("dliom_cloud_size", C.c_int, [_vp, _i64p]),
+    ("dliom_rtcsm3d_match", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _f64p, _f32p]),
+    ("dliom_rtcsm3d_match_cloud", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, _f64p, _f32p]),
+    ("dliom_rtcsm3d_window", C.c_int, [C.POINTER(RtcsmOptions), C.c_float, _f32p, C.c_int64, C.POINTER(RtcsmWindow)]),
+    ("dliom_rtcsm3d_last_stats", C.c_int, [_vp, C.POINTER(RtcsmStats)]),
+    ("dliom_csm3d_match", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, C.c_int, C.POINTER(_f32p), _i64p,
+                                    C.POINTER(_vp), _f64p, C.POINTER(CsmSummary)]),
+    ("dliom_csm3d_match_cloud", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, C.c_int, C.POINTER(_vp),
+                                          C.POINTER(_vp), _f64p, C.POINTER(CsmSummary)]),
+    ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
+    ("dliom_rtcsm3d_score_volume", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _u64p,
+                                             C.c_int64, _i64p]),
+    ("dliom_csm3d_evaluate", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, _f64p, C.c_int, C.POINTER(_f32p),
+                                       _i64p, C.POINTER(_vp), _f64p, _f64p, _f64p]),
+    ("dliom_ctx_set_profiling", C.c_int, [_vp, C.c_int]),
+    ("dliom_ctx_reset_profiling", C.c_int, [_vp]),
+    ("dliom_ctx_kernel_time", C.c_int, [_vp, C.c_int, _f64p, _i64p]),
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libdliom.so and binds every symbol of include/dliom.h (AttributeError if one is
+    missing).  Loading needs the HIP runtime but no GPU."""
+    global _lib
+    if _lib is None:
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise DliomError(ERR_NO_DEVICE, "libdliom.so not built at %s (run __graft_entry__.build())" % p)
+        lib = C.CDLL(p)
+        for name, res, args in SYMBOLS:
+            f = getattr(lib, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(status, where):
+    if status != OK:
+        raise DliomError(status, where)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def device_count():
+    return load_library().dliom_device_count()
+
+
+def compute_lookup_table_to_apply_odds(odds):
+    """mapping/probability_values.cc:73-83"""
+    out = np.zeros(32768, dtype=np.uint16)
+    _check(load_library().dliom_compute_lookup_table_to_apply_odds(C.c_float(odds), _p(out, _u16p)), "lookup table")
+    return out
+
+
+def odds(p):
+    return load_library().dliom_odds(C.c_float(p))
+
+
+def value_to_probability_table():
+    out = np.zeros(65536, dtype=np.float32)
+    _check(load_library().dliom_value_to_probability_table(_p(out, _f32p)), "value table")
+    return out
+
+
+class Context:
+    """One HIP stream + scratch memory (dliom_ctx)."""
+
+    def __init__(self, device_id=0, stream=None):
+        L = load_library()
+        self._L = L
+        h = _vp()
+        if stream is None:
+            _check(L.dliom_ctx_create(device_id, C.byref(h)), "dliom_ctx_create")
+        else:
+            _check(L.dliom_ctx_create_on_stream(device_id, _vp(stream), C.byref(h)), "dliom_ctx_create_on_stream")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._L.dliom_ctx_synchronize(self.h), "synchronize")
+
+    def set_profiling(self, on):
+        _check(self._L.dliom_ctx_set_profiling(self.h, int(on)), "set_profiling")
+
+    def reset_profiling(self):
+        _check(self._L.dliom_ctx_reset_profiling(self.h), "reset_profiling")
+
+    def kernel_time(self, kernel_id):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self._L.dliom_ctx_kernel_time(self.h, kernel_id, C.byref(ms), C.byref(n)), "kernel_time")
+        return ms.value, n.value
+
+    def probe_transform_cell_indices(self, pose7_f32, points, resolution):
+        pose = _f32(pose7_f32)
+        pts = _f32(points).reshape(-1, 3)
+        out = np.zeros((len(pts), 3), dtype=np.int32)
+        _check(self._L.dliom_probe_transform_cell_indices(self.h, _p(pose, _f32p), _p(pts, _f32p), len(pts),
+                                                          C.c_float(resolution), _p(out, _i32p)), "probe cells")
+        return out
+
+
+class PointCloud:
+    """sensor::PointCloud staged in HBM (dliom_cloud)."""
+
+    def __init__(self, ctx, points):
+        self._L = ctx._L
+        self.ctx = ctx
+        pts = _f32(points).reshape(-1, 3)
+        self.n = len(pts)
+        h = _vp()
+        _check(self._L.dliom_cloud_create(ctx.h, _p(pts, _f32p), len(pts), C.byref(h)), "dliom_cloud_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_cloud_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HybridGrid:
+    """Device-resident mapping::HybridGrid."""
+
+    def __init__(self, ctx, resolution):
+        self._L = ctx._L
+        self.ctx = ctx
+        self.resolution = float(np.float32(resolution))
+        h = _vp()
+        _check(self._L.dliom_grid_create(ctx.h, C.c_float(resolution), C.byref(h)), "dliom_grid_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_grid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def bits(self):
+        b = C.c_int()
+        _check(self._L.dliom_grid_bits(self.h, C.byref(b)), "grid_bits")
+        return b.value
+
+    def upload_blocks(self, origins, values512):
+        origins = np.ascontiguousarray(origins, dtype=np.int32).reshape(-1, 3)
+        values512 = np.ascontiguousarray(values512, dtype=np.uint16).reshape(-1, 512)
+        assert len(origins) == len(values512)
+        _check(self._L.dliom_grid_upload_blocks(self.h, _p(origins, _i32p), _p(values512, _u16p), len(origins)),
+               "grid_upload_blocks")
+
+    def num_blocks(self):
+        n = C.c_int64()
+        _check(self._L.dliom_grid_num_blocks(self.h, C.byref(n)), "grid_num_blocks")
+        return n.value
+
+    def download_blocks(self):
+        n = self.num_blocks()
+        origins = np.zeros((n, 3), dtype=np.int32)
+        values = np.zeros((n, 512), dtype=np.uint16)
+        got = C.c_int64()
+        _check(self._L.dliom_grid_download_blocks(self.h, _p(origins, _i32p), _p(values, _u16p), n, C.byref(got)),
+               "grid_download_blocks")
+        return origins[:got.value], values[:got.value]
+
+    def cells(self):
+        """Non-zero cells as a dict {(x,y,z): value} (what HybridGrid's iterator yields)."""
+        origins, values = self.download_blocks()
+        out = {}
+        for o, v in zip(origins, values):
+            nz = np.nonzero(v)[0]
+            for c in nz:
+                out[(int(o[0]) + (c & 7), int(o[1]) + ((c >> 3) & 7), int(o[2]) + (c >> 6))] = int(v[c])
+        return out
+
+    def values(self, cells_xyz):
+        cells = np.ascontiguousarray(cells_xyz, dtype=np.int32).reshape(-1, 3)
+        out = np.zeros(len(cells), dtype=np.uint16)
+        _check(self._L.dliom_grid_get_values(self.h, _p(cells, _i32p), len(cells), _p(out, _u16p)), "grid_get_values")
+        return out
+
+
+class RangeDataInserter3D:
+    """mapping::RangeDataInserter3D: options -> two odds tables; Insert(range_data, grid)."""
+
+    def __init__(self, hit_probability, miss_probability, num_free_space_voxels):
+        if not hit_probability > 0.5 or not miss_probability < 0.5:
+            raise ValueError("CHECK_GT(hit, 0.5) / CHECK_LT(miss, 0.5) (range_data_inserter_3d.cc:64-65)")
+        self.num_free_space_voxels = int(num_free_space_voxels)
+        # Odds(float(options.hit_probability()))
+        self.hit_table = compute_lookup_table_to_apply_odds(odds(np.float32(hit_probability)))
+        self.miss_table = compute_lookup_table_to_apply_odds(odds(np.float32(miss_probability)))
+
+    def Insert(self, origin, returns, grid):
+        origin = _f32(origin)
+        returns = _f32(returns).reshape(-1, 3)
+        _check(grid._L.dliom_grid_insert(grid.h, _p(origin, _f32p), _p(returns, _f32p), len(returns),
+                                         _p(self.hit_table, _u16p), _p(self.miss_table, _u16p),
+                                         self.num_free_space_voxels), "dliom_grid_insert")
+
+
+def _rtcsm_opts(o):
+    return RtcsmOptions(o["linear_search_window"], o["angular_search_window"],
+                        o["translation_delta_cost_weight"], o["rotation_delta_cost_weight"])
+
+
+class RealTimeCorrelativeScanMatcher3D:
+    def __init__(self, ctx, options):
+        self.ctx = ctx
+        self._L = ctx._L
+        self.options = _rtcsm_opts(options)
+
+    def Match(self, initial_pose_estimate, point_cloud, hybrid_grid):
+        """Returns (score, pose_estimate[7]).  point_cloud: ndarray or PointCloud."""
+        init = _f64(initial_pose_estimate)
+        out = np.zeros(7)
+        score = C.c_float()
+        if isinstance(point_cloud, PointCloud):
+            s = self._L.dliom_rtcsm3d_match_cloud(self.ctx.h, C.byref(self.options), _p(init, _f64p), point_cloud.h,
+                                                  hybrid_grid.h, _p(out, _f64p), C.byref(score))
+        else:
+            pts = _f32(point_cloud).reshape(-1, 3)
+            s = self._L.dliom_rtcsm3d_match(self.ctx.h, C.byref(self.options), _p(init, _f64p), _p(pts, _f32p),
+                                            len(pts), hybrid_grid.h, _p(out, _f64p), C.byref(score))
+        _check(s, "dliom_rtcsm3d_match")
+        return score.value, out
+
+    def window(self, resolution, point_cloud):
+        pts = _f32(point_cloud).reshape(-1, 3)
+        w = RtcsmWindow()
+        _check(self._L.dliom_rtcsm3d_window(C.byref(self.options), C.c_float(resolution), _p(pts, _f32p), len(pts),
+                                            C.byref(w)), "dliom_rtcsm3d_window")
+        return w
+
+    def last_stats(self):
+        st = RtcsmStats()
+        _check(self._L.dliom_rtcsm3d_last_stats(self.ctx.h, C.byref(st)), "last_stats")
+        return st
+
+    def score_volume(self, initial_pose_estimate, point_cloud, hybrid_grid):
+        init = _f64(initial_pose_estimate)
+        pts = _f32(point_cloud).reshape(-1, 3)
+        n = C.c_int64()
+        _check(self._L.dliom_rtcsm3d_score_volume(self.ctx.h, C.byref(self.options), _p(init, _f64p), _p(pts, _f32p),
+                                                  len(pts), hybrid_grid.h, None, 0, C.byref(n)), "score_volume(size)")
+        sums = np.zeros(n.value, dtype=np.uint64)
+        _check(self._L.dliom_rtcsm3d_score_volume(self.ctx.h, C.byref(self.options), _p(init, _f64p), _p(pts, _f32p),
+                                                  len(pts), hybrid_grid.h, _p(sums, _u64p), n.value, C.byref(n)),
+               "score_volume")
+        return sums
+
+
+def _csm_opts(o):
+    c = CsmOptions()
+    w = list(o["occupied_space_weight"])
+    c.num_occupied_space_weights = len(w)
+    for i, v in enumerate(w[:MAX_CLOUDS]):
+        c.occupied_space_weight[i] = v
+    c.translation_weight = o["translation_weight"]
+    c.rotation_weight = o["rotation_weight"]
+    c.only_optimize_yaw = int(o.get("only_optimize_yaw", False))
+    c.use_nonmonotonic_steps = int(o.get("use_nonmonotonic_steps", False))
+    c.max_num_iterations = int(o["max_num_iterations"])
+    c.num_threads = int(o.get("num_threads", 1))
+    return c
+
+
+class CeresScanMatcher3D:
+    def __init__(self, ctx, options):
+        self.ctx = ctx
+        self._L = ctx._L
+        self.options = _csm_opts(options)
+
+    def Match(self, target_translation, initial_pose_estimate, point_clouds_and_hybrid_grids):
+        """Returns (pose_estimate[7], summary dict)."""
+        k = len(point_clouds_and_hybrid_grids)
+        tgt = _f64(target_translation)
+        init = _f64(initial_pose_estimate)
+        out = np.zeros(7)
+        summ = CsmSummary()
+        grids = (_vp * k)(*[g.h for _, g in point_clouds_and_hybrid_grids])
+        if all(isinstance(c, PointCloud) for c, _ in point_clouds_and_hybrid_grids):
+            clouds = (_vp * k)(*[c.h for c, _ in point_clouds_and_hybrid_grids])
+            s = self._L.dliom_csm3d_match_cloud(self.ctx.h, C.byref(self.options), _p(tgt, _f64p), _p(init, _f64p), k,
+                                                clouds, grids, _p(out, _f64p), C.byref(summ))
+        else:
+            arrs = [_f32(c).reshape(-1, 3) for c, _ in point_clouds_and_hybrid_grids]
+            ptrs = (_f32p * k)(*[_p(a, _f32p) for a in arrs])
+            ns = np.array([len(a) for a in arrs], dtype=np.int64)
+            s = self._L.dliom_csm3d_match(self.ctx.h, C.byref(self.options), _p(tgt, _f64p), _p(init, _f64p), k, ptrs,
+                                          _p(ns, _i64p), grids, _p(out, _f64p), C.byref(summ))
+        _check(s, "dliom_csm3d_match")
+        return out, {f: getattr(summ, f) for f, _ in CsmSummary._fields_}
+
+    def evaluate(self, target_translation, initial_pose_estimate, pose, point_clouds_and_hybrid_grids):
+        k = len(point_clouds_and_hybrid_grids)
+        arrs = [_f32(c).reshape(-1, 3) for c, _ in point_clouds_and_hybrid_grids]
+        ptrs = (_f32p * k)(*[_p(a, _f32p) for a in arrs])
+        ns = np.array([len(a) for a in arrs], dtype=np.int64)
+        grids = (_vp * k)(*[g.h for _, g in point_clouds_and_hybrid_grids])
+        cost = C.c_double()
+        grad = np.zeros(6)
+        jtj = np.zeros((6, 6))
+        _check(self._L.dliom_csm3d_evaluate(self.ctx.h, C.byref(self.options), _p(_f64(target_translation), _f64p),
+                                            _p(_f64(initial_pose_estimate), _f64p), _p(_f64(pose), _f64p), k, ptrs,
+                                            _p(ns, _i64p), grids, C.byref(cost), _p(grad, _f64p), _p(jtj, _f64p)),
+               "dliom_csm3d_evaluate")
+        return cost.value, grad, jtj

@@ -1,0 +1,231 @@
+/* dliom.h -- C ABI of the MI355X-native scan-to-submap front end.
+ *
+ * Drop-in boundary for the hot path of peterWon/D-LIOM's
+ * cartographer::mapping::LocalTrajectoryBuilder3D.
+ * Every entry point names the reference interface it replaces; paths are
+ * relative to /root/reference/src/cartographer/cartographer.  The library is
+ * libdliom.so (d-liom_amd/csrc, hand-written HIP for gfx950); there is no CPU
+ * fallback behind these calls -- without a GPU they return DLIOM_ERR_NO_DEVICE.
+ *
+ * Conventions
+ *   pose      double[7] = [tx,ty,tz,qw,qx,qy,qz]  (order of CeresPose::Data,
+ *             mapping/internal/optimization/ceres_pose.h:47-51)
+ *   points    packed float xyz, 12-byte stride == std::vector<Eigen::Vector3f>::data()
+ *             (sensor/point_cloud.h:32)
+ *   block     one 8x8x8 uint16 leaf of the reference HybridGrid, z-major
+ *             ((z<<3)+y<<3)+x  (mapping/3d/hybrid_grid.h:40-43,66-138), addressed
+ *             by the voxel index of its (0,0,0) corner (a multiple of 8 per axis)
+ *   status    every function returns int: 0 ok, negative = the reference's
+ *             CHECK condition that would have aborted (glog CHECK -> error code,
+ *             SURVEY.md 8b "error convention"); nothing aborts or throws.
+ *   threads   a dliom_ctx owns one HIP stream and its scratch memory; calls on
+ *             different contexts are concurrency-safe (CeresScanMatcher3D::Match
+ *             is re-entered from pool threads, constraint_builder_3d.cc:320).
+ *             Grids are not thread-safe, like HybridGrid.
+ */
+#ifndef DLIOM_H_
+#define DLIOM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLIOM_OK 0
+#define DLIOM_ERR_INVALID_ARGUMENT (-1) /* CHECK_NOTNULL (rtcsm_3d.cc:38, range_data_inserter_3d.cc:80) */
+#define DLIOM_ERR_HIP (-2)              /* a HIP runtime call failed; see dliom_last_error() */
+#define DLIOM_ERR_NO_DEVICE (-3)        /* no gfx950 device visible */
+#define DLIOM_ERR_SCORE_NOT_POSITIVE (-4) /* CHECK_GT(score, 0.f) rtcsm_3d.cc:111 */
+#define DLIOM_ERR_WEIGHTS (-5)          /* CHECK_EQ / CHECK_GT ceres_scan_matcher_3d.cc:89-92 */
+#define DLIOM_ERR_GRID_EXTENT (-6)      /* CHECK_LE(new_bits, 8) hybrid_grid.h:389 */
+#define DLIOM_ERR_RAY_TOO_LONG (-7)     /* CHECK_LT(num_samples, 1 << 15) range_data_inserter_3d.cc:38 */
+#define DLIOM_ERR_EMPTY_CLOUD (-8)      /* division by size()==0 in ScoreCandidate / sqrt(N) scaling */
+#define DLIOM_ERR_CAPACITY (-9)         /* caller-provided output buffer too small */
+#define DLIOM_ERR_SOLVER (-10)          /* Ceres would report FAILURE (evaluation or invalid steps) */
+
+typedef struct dliom_ctx dliom_ctx;
+typedef struct dliom_grid dliom_grid;
+typedef struct dliom_cloud dliom_cloud;
+
+const char* dliom_status_string(int status);
+/* Text of the last HIP failure on the calling thread ("" if none). */
+const char* dliom_last_error(void);
+/* Number of visible HIP devices (0 when there is none). */
+int dliom_device_count(void);
+
+/* ---- context ------------------------------------------------------------ */
+int dliom_ctx_create(int device_id, dliom_ctx** out);
+/* Same, but work is enqueued on a caller-owned hipStream_t (e.g. torch's). */
+int dliom_ctx_create_on_stream(int device_id, void* hip_stream, dliom_ctx** out);
+int dliom_ctx_destroy(dliom_ctx* ctx);
+int dliom_ctx_synchronize(dliom_ctx* ctx);
+
+/* ---- probability value tables (host; mapping/probability_values.cc:73-83) --
+ * table[v] = ProbabilityToValue(ProbabilityFromOdds(odds * Odds(p(v)))) + 32768,
+ * what RangeDataInserter3D's constructor builds for hit and miss
+ * (mapping/3d/range_data_inserter_3d.cc:70-76 with odds = Odds(float(p))). */
+int dliom_compute_lookup_table_to_apply_odds(float odds, uint16_t* table32768);
+float dliom_odds(float probability);
+/* kValueToProbability (probability_values.cc:67-68), 65536 floats. */
+int dliom_value_to_probability_table(float* table65536);
+
+/* ---- device HybridGrid (replaces mapping/3d/hybrid_grid.h:470-547) -------- */
+int dliom_grid_create(dliom_ctx* ctx, float resolution, dliom_grid** out);
+int dliom_grid_destroy(dliom_grid* grid);
+int dliom_grid_resolution(const dliom_grid* grid, float* resolution);
+/* DynamicGrid::bits_ the reference would have after the same writes
+ * (hybrid_grid.h:255,387-405). */
+int dliom_grid_bits(const dliom_grid* grid, int* bits);
+/* Overwrites whole leaves; grows like mutable_value()/Grow(). */
+int dliom_grid_upload_blocks(dliom_grid* grid, const int32_t* block_origin_xyz,
+                             const uint16_t* values512, int64_t num_blocks);
+int dliom_grid_num_blocks(const dliom_grid* grid, int64_t* num_blocks);
+/* Allocated leaves in unspecified order; *num_blocks <= capacity. */
+int dliom_grid_download_blocks(const dliom_grid* grid, int32_t* block_origin_xyz,
+                               uint16_t* values512, int64_t capacity, int64_t* num_blocks);
+/* HybridGrid::value() for n cell indices (0 outside / unallocated). */
+int dliom_grid_get_values(const dliom_grid* grid, const int32_t* cell_xyz, int64_t n,
+                          uint16_t* values);
+/* RangeDataInserter3D::Insert(range_data{origin, returns, {}}, grid)
+ * (mapping/3d/range_data_inserter_3d.cc:78-92): hits with hit_table, then for
+ * each ray the last num_free_space_voxels cells with miss_table, each cell at
+ * most once per call, then FinishUpdate(). */
+int dliom_grid_insert(dliom_grid* grid, const float origin[3], const float* returns_xyz,
+                      int64_t num_returns, const uint16_t* hit_table32768,
+                      const uint16_t* miss_table32768, int num_free_space_voxels);
+
+/* ---- device-resident point cloud (sensor::PointCloud staged in HBM) ------- */
+int dliom_cloud_create(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud** out);
+int dliom_cloud_destroy(dliom_cloud* cloud);
+int dliom_cloud_size(const dliom_cloud* cloud, int64_t* n);
+
+/* ---- RealTimeCorrelativeScanMatcher3D -------------------------------------
+ * proto::RealTimeCorrelativeScanMatcherOptions
+ * (mapping/proto/scan_matching/real_time_correlative_scan_matcher_options.proto) */
+typedef struct dliom_rtcsm_options {
+  double linear_search_window;
+  double angular_search_window;
+  double translation_delta_cost_weight;
+  double rotation_delta_cost_weight;
+} dliom_rtcsm_options;
+
+/* float RealTimeCorrelativeScanMatcher3D::Match(initial_pose_estimate,
+ * point_cloud, hybrid_grid, pose_estimate)
+ * (mapping/internal/3d/scan_matching/real_time_correlative_scan_matcher_3d.h:47-50,
+ *  .cc:34-53).  *score receives the returned best score. */
+int dliom_rtcsm3d_match(dliom_ctx* ctx, const dliom_rtcsm_options* options,
+                        const double initial_pose_estimate[7], const float* points_xyz,
+                        int64_t n, const dliom_grid* grid, double pose_estimate[7],
+                        float* score);
+/* Same with the cloud already in HBM. */
+int dliom_rtcsm3d_match_cloud(dliom_ctx* ctx, const dliom_rtcsm_options* options,
+                              const double initial_pose_estimate[7], const dliom_cloud* cloud,
+                              const dliom_grid* grid, double pose_estimate[7], float* score);
+
+/* Search-window geometry of the last/next match (rtcsm_3d.cc:58-70). */
+typedef struct dliom_rtcsm_window {
+  int linear_window_size;
+  int angular_window_size;
+  float angular_step_size;
+  float max_scan_range;
+  int64_t num_translations; /* (2L+1)^3 */
+  int64_t num_rotations;    /* (2A+1)^3 */
+  int64_t num_candidates;
+} dliom_rtcsm_window;
+int dliom_rtcsm3d_window(const dliom_rtcsm_options* options, float resolution,
+                         const float* points_xyz, int64_t n, dliom_rtcsm_window* window);
+
+/* Statistics of the last dliom_rtcsm3d_match* on this context. */
+typedef struct dliom_rtcsm_stats {
+  dliom_rtcsm_window window;
+  int64_t num_points;
+  int64_t num_rescored;   /* candidates re-scored with the sequential float sum */
+  int64_t best_index;     /* generation order: ((z,y,x) * R + (rz,ry,rx)) */
+} dliom_rtcsm_stats;
+int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats);
+
+/* ---- CeresScanMatcher3D ------------------------------------------------------
+ * proto::CeresScanMatcherOptions3D + common.proto.CeresSolverOptions
+ * (mapping/proto/scan_matching/ceres_scan_matcher_options_3d.proto,
+ *  common/proto/ceres_solver_options.proto). */
+#define DLIOM_MAX_CLOUDS 8
+typedef struct dliom_csm_options {
+  int num_occupied_space_weights;
+  double occupied_space_weight[DLIOM_MAX_CLOUDS];
+  double translation_weight;
+  double rotation_weight;
+  int only_optimize_yaw;
+  int use_nonmonotonic_steps;
+  int max_num_iterations;
+  int num_threads; /* accepted, unused: the device evaluates all points at once */
+} dliom_csm_options;
+
+/* The fields of ceres::Solver::Summary the path reads
+ * (local_trajectory_builder_3d.cc:543) plus evaluation counts. */
+typedef struct dliom_csm_summary {
+  double initial_cost;
+  double final_cost;
+  int num_successful_steps;
+  int num_unsuccessful_steps;
+  int num_iterations;
+  int num_residual_evaluations;
+  int num_jacobian_evaluations;
+  int termination_type; /* 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE */
+} dliom_csm_summary;
+
+/* void CeresScanMatcher3D::Match(target_translation, initial_pose_estimate,
+ * point_clouds_and_hybrid_grids, pose_estimate, summary)
+ * (mapping/internal/3d/scan_matching/ceres_scan_matcher_3d.h:51-56, .cc:71-123). */
+int dliom_csm3d_match(dliom_ctx* ctx, const dliom_csm_options* options,
+                      const double target_translation[3], const double initial_pose_estimate[7],
+                      int num_clouds, const float* const* points_xyz, const int64_t* n,
+                      const dliom_grid* const* grids, double pose_estimate[7],
+                      dliom_csm_summary* summary);
+int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* options,
+                            const double target_translation[3],
+                            const double initial_pose_estimate[7], int num_clouds,
+                            const dliom_cloud* const* clouds, const dliom_grid* const* grids,
+                            double pose_estimate[7], dliom_csm_summary* summary);
+
+/* ---- diagnostics used by the parity tests and bench.py ------------------------
+ * These expose intermediate results of the same device code the matchers run. */
+/* Cell index of R(pose)*p + t per point, computed by the score kernel's own
+ * device function (bit-exactness probe for hybrid_grid.h:430-435). */
+int dliom_probe_transform_cell_indices(dliom_ctx* ctx, const float pose[7],
+                                       const float* points_xyz, int64_t n, float resolution,
+                                       int32_t* cell_xyz);
+/* Per candidate (generation order) the exact integer sum over points of
+ * max(value & 0x7fff, 1): the order-independent score volume. */
+int dliom_rtcsm3d_score_volume(dliom_ctx* ctx, const dliom_rtcsm_options* options,
+                               const double initial_pose_estimate[7], const float* points_xyz,
+                               int64_t n, const dliom_grid* grid, uint64_t* sums,
+                               int64_t capacity, int64_t* num_candidates);
+/* One evaluation of the stacked problem at `pose`: cost = 1/2 sum r^2,
+ * gradient[6] = J^T r and jtj[36] = J^T J (row-major) in the 6-dof tangent
+ * space of (translation, QuaternionParameterization). */
+int dliom_csm3d_evaluate(dliom_ctx* ctx, const dliom_csm_options* options,
+                         const double target_translation[3],
+                         const double initial_pose_estimate[7], const double pose[7],
+                         int num_clouds, const float* const* points_xyz, const int64_t* n,
+                         const dliom_grid* const* grids, double* cost, double gradient[6],
+                         double jtj[36]);
+
+/* Kernel timing (HIP events on the context's stream). */
+enum {
+  DLIOM_KERNEL_RTCSM_SCORE = 0, /* score-volume kernel (dominant) */
+  DLIOM_KERNEL_RTCSM_SELECT = 1,
+  DLIOM_KERNEL_RTCSM_RESCORE = 2,
+  DLIOM_KERNEL_CSM_EVAL = 3,
+  DLIOM_KERNEL_INSERT = 4,
+  DLIOM_KERNEL_COUNT = 5
+};
+int dliom_ctx_set_profiling(dliom_ctx* ctx, int enabled);
+int dliom_ctx_reset_profiling(dliom_ctx* ctx);
+int dliom_ctx_kernel_time(dliom_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* DLIOM_H_ */

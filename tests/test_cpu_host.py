@@ -1,0 +1,77 @@
+"""CPU-side checks (no GPU needed): the C-ABI library loads and exports every symbol that
+include/dliom.h declares, its host-only entry points agree with the oracle, and GPU entry points
+fail loudly (no silent fallback) when there is no device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dl():
+    import __graft_entry__
+    __graft_entry__.build()
+    import dliom
+    dliom.load_library()
+    return dliom
+
+
+def test_header_symbols_all_exported(dl):
+    header = open(os.path.join(ROOT, "include", "dliom.h")).read()
+    declared = set(re.findall(r"\b(dliom_[a-z0-9_]+)\s*\(", header))
+    bound = {name for name, _, _ in dl.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    lib = C.CDLL(dl.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_device_fails_loudly(dl):
+    if dl.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(dl.DliomError) as e:
+        dl.Context(0)
+    assert e.value.status == dl.ERR_NO_DEVICE
+
+
+def test_lookup_tables_equal_oracle(dl, orc):
+    for p in (0.55, 0.49, 0.7, 0.4, 0.9, 0.1, 0.51):
+        o = orc.odds(np.float32(p))
+        assert dl.odds(np.float32(p)) == o
+        assert np.array_equal(dl.compute_lookup_table_to_apply_odds(o), orc.lookup_table_to_apply_odds(o))
+    assert np.array_equal(dl.value_to_probability_table(), orc.value_to_probability_table())
+
+
+def test_window_equals_oracle(dl, orc):
+    rng = np.random.RandomState(0)
+    L = dl.load_library()
+    for trial in range(40):
+        n = int(rng.randint(1, 400))
+        scale = float(rng.choice([0.05, 1.0, 8.0, 15.0, 26.0, 60.0]))
+        pts = (rng.uniform(-1, 1, size=(n, 3)) * scale).astype(np.float32)
+        res = float(rng.choice([0.05, 0.1, 0.2, 0.45]))
+        opts = dict(linear_search_window=float(rng.choice([0.1, 0.15, 0.3])),
+                    angular_search_window=float(np.deg2rad(rng.choice([1.0, 3.0]))),
+                    translation_delta_cost_weight=0.1, rotation_delta_cost_weight=0.1)
+        w = dl.RtcsmWindow()
+        o = dl.RtcsmOptions(opts["linear_search_window"], opts["angular_search_window"], 0.1, 0.1)
+        assert L.dliom_rtcsm3d_window(C.byref(o), C.c_float(res), pts.ctypes.data_as(C.POINTER(C.c_float)), n,
+                                      C.byref(w)) == 0
+        ref = orc.rtcsm3d_window(opts, res, pts)
+        assert w.linear_window_size == ref["linear_window"]
+        assert w.angular_window_size == ref["angular_window"]
+        assert np.float32(w.angular_step_size) == np.float32(ref["angular_step"])
+        assert np.float32(w.max_scan_range) == np.float32(ref["max_scan_range"])
+        assert w.num_candidates == (2 * w.linear_window_size + 1) ** 3 * (2 * w.angular_window_size + 1) ** 3
+
+
+def test_argument_checks_without_gpu(dl):
+    L = dl.load_library()
+    assert L.dliom_ctx_destroy(None) == dl.ERR_INVALID_ARGUMENT
+    assert L.dliom_grid_destroy(None) == dl.ERR_INVALID_ARGUMENT
+    assert L.dliom_compute_lookup_table_to_apply_odds(C.c_float(1.0), None) == dl.ERR_INVALID_ARGUMENT
+    assert L.dliom_status_string(dl.ERR_RAY_TOO_LONG) != b"unknown status"

@@ -1,0 +1,394 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/dliom.h) against the CPU oracle
+on the same seeded inputs.  Integer / index work must be bit-exact; floating point poses have
+their tolerance written in the test.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from helpers import (DEFAULT_CSM, DEFAULT_RTCSM, FREE, HIT_P, MISS_P, build_oracle_submap,
+                     oracle_cells_dict, pose_distance, to_device_grid)
+
+pytestmark = pytest.mark.gpu
+
+SEVEN_POINTS = np.array([[-3, 2, 0], [-4, 2, 0], [-5, 2, 0], [-6, 2, 0],
+                         [-6, 3, 1], [-6, 4, 2], [-7, 3, 1]], dtype=np.float32)
+
+
+@pytest.fixture(scope="module")
+def dl():
+    import dliom
+    dliom.load_library()
+    assert dliom.device_count() > 0, "no HIP device: the GPU tests must not pass on a fallback"
+    return dliom
+
+
+@pytest.fixture(scope="module")
+def ctx(dl):
+    c = dl.Context(0)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------------------ voxel indices
+def test_transform_cell_indices_bit_exact(dl, ctx, orc):
+    rng = np.random.RandomState(1)
+    for trial in range(8):
+        n = 20000
+        pts = rng.uniform(-40, 40, size=(n, 3)).astype(np.float32)
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        pose = np.concatenate([rng.uniform(-2, 2, 3), q]).astype(np.float32)
+        res = [0.05, 0.1, 0.2, 0.45][trial % 4]
+        if trial >= 4:
+            # force exact half-way cases: identity pose, points on .5 cell boundaries
+            pose = np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float32)
+            k = rng.randint(-300, 300, size=(n, 3)).astype(np.float32)
+            pts = ((k + np.float32(0.5)) * np.float32(res)).astype(np.float32)
+        want = orc.transform_cell_indices(pose, pts, res)
+        got = ctx.probe_transform_cell_indices(pose, pts, res)
+        assert np.array_equal(want, got)
+
+
+# ------------------------------------------------------------------------------ grid storage
+def test_grid_upload_download_round_trip(dl, ctx, orc):
+    rng = np.random.RandomState(2)
+    og = orc.HybridGrid(0.1)
+    xyz = rng.randint(-400, 400, size=(30000, 3))
+    vals = rng.randint(1, 32768, size=30000).astype(np.uint16)
+    og.set_values(xyz, vals)
+    dg = to_device_grid(dl, ctx, og)
+    assert dg.bits == og.bits
+    assert dg.cells() == oracle_cells_dict(og)
+    probe = np.concatenate([xyz[:5000], rng.randint(-600, 600, size=(5000, 3))]).astype(np.int32)
+    assert np.array_equal(dg.values(probe), og.values(probe))
+    # far outside the extent -> 0, like DynamicGrid::value
+    far = np.array([[100000, 0, 0], [0, -100000, 0], [0, 0, 2 ** 30]], dtype=np.int32)
+    assert np.array_equal(dg.values(far), np.zeros(3, dtype=np.uint16))
+    dg.close()
+
+
+# ------------------------------------------------------------------------------ insertion
+def test_range_data_inserter_reference_kat(dl, ctx):
+    """range_data_inserter_3d_test.cc:68-103 through the HIP inserter."""
+    g = dl.HybridGrid(ctx, 1.0)
+    ins = dl.RangeDataInserter3D(0.7, 0.4, 1000)
+    returns = [[-3, -1, 4], [-2, 0, 4], [-1, 1, 4], [0, 2, 4]]
+    ins.Insert((0, 0, -4), returns, g)
+    table = dl.value_to_probability_table()
+    cells = g.cells()
+    P = lambda x, y, z: table[cells.get((x, y, z), 0)]
+    for z in (-4, -3, -2):
+        assert abs(P(0, 0, z) - 0.4) < 1e-4
+    for x in range(-4, 5):
+        for y in range(-4, 5):
+            if x < -3 or x > 0 or y != x + 2:
+                assert (x, y, 4) not in cells
+            else:
+                assert abs(P(x, y, 4) - 0.7) < 1e-4
+    for _ in range(1000):
+        ins.Insert((0, 0, -4), returns, g)
+    cells = g.cells()
+    assert abs(P(-2, 0, 4) - 0.9) < 1e-3
+    assert abs(P(-2, 0, 3) - 0.1) < 1e-3
+    assert abs(P(0, 0, -3) - 0.1) < 1e-3
+    assert all(v < 32768 for v in cells.values())  # FinishUpdate cleared every marker
+    g.close()
+
+
+@pytest.mark.parametrize("resolution,free", [(0.1, 2), (0.45, 2), (0.2, 0), (0.1, 5)])
+def test_insert_matches_oracle_bit_exact(dl, ctx, orc, resolution, free):
+    from dliom import synth
+    og = orc.HybridGrid(resolution)
+    dg = dl.HybridGrid(ctx, resolution)
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, free)
+    hit = orc.lookup_table_to_apply_odds(orc.odds(HIT_P))
+    miss = orc.lookup_table_to_apply_odds(orc.odds(MISS_P))
+    assert np.array_equal(hit, ins.hit_table) and np.array_equal(miss, ins.miss_table)
+    for s in range(4):
+        pose = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(pose, 32, 512)
+        world = synth.transform_points(pose, pts)
+        origin = pose[:3].astype(np.float32)
+        og.insert_tables(origin, world, hit, miss, free)
+        ins.Insert(origin, world, dg)
+        assert dg.bits == og.bits
+    assert dg.cells() == oracle_cells_dict(og)
+    dg.close()
+
+
+def test_insert_empty_and_ragged(dl, ctx, orc):
+    g = dl.HybridGrid(ctx, 0.1)
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE)
+    ins.Insert((0, 0, 0), np.zeros((0, 3), dtype=np.float32), g)  # empty range data: no-op
+    assert g.num_blocks() == 0
+    # a single return on top of the origin: num_samples == 0 -> hit only
+    ins.Insert((0, 0, 0), [[0.01, 0.0, 0.0]], g)
+    og = orc.HybridGrid(0.1)
+    og.insert((0, 0, 0), [[0.01, 0.0, 0.0]], HIT_P, MISS_P, FREE)
+    assert g.cells() == oracle_cells_dict(og)
+    # ray longer than 1<<15 cells -> the reference CHECK-fails
+    with pytest.raises(dl.DliomError) as e:
+        ins.Insert((0, 0, 0), [[4000.0, 0.0, 0.0]], g)
+    assert e.value.status == dl.ERR_RAY_TOO_LONG
+    g.close()
+
+
+# ------------------------------------------------------------------------------ RTCSM3D
+RTCSM_TEST_OPTS = dict(linear_search_window=0.3, angular_search_window=np.deg2rad(1.0),
+                       translation_delta_cost_weight=1e-1, rotation_delta_cost_weight=1.0)
+EXPECTED = np.array([-1.0, 0, 0, 1, 0, 0, 0])
+
+
+def _kat_grids(dl, ctx, orc, resolution):
+    og = orc.HybridGrid(resolution)
+    for p in orc.transform_points(EXPECTED.astype(np.float32), SEVEN_POINTS):
+        og.set_probability(og.get_cell_index(p), 1.0)
+    return og, to_device_grid(dl, ctx, og)
+
+
+@pytest.mark.parametrize("t,aa", [((-1.0, 0, 0), None), ((-0.8, 0, 0), None), ((-1.0, 0, -0.2), None),
+                                  ((-0.9, -0.2, 0.2), None), ((-1.0, 0, 0), (0.8 / 180 * np.pi, (1, 0, 0))),
+                                  ((-1.0, 0, 0), (0.8 / 180 * np.pi, (0, 1, 0))),
+                                  ((-1.0, 0, 0), (0.8 / 180 * np.pi, (0, 1, 1)))])
+def test_rtcsm3d_reference_kat(dl, ctx, orc, t, aa):
+    """real_time_correlative_scan_matcher_3d_test.cc:36-117 through the HIP matcher, and equality
+    with the oracle's result down to the bit."""
+    from test_oracle_kat import is_nearly
+    q = (1, 0, 0, 0) if aa is None else orc.angle_axis_quat(*aa)
+    init = orc.pose(t, q)
+    og, dg = _kat_grids(dl, ctx, orc, 0.1)
+    m = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_TEST_OPTS)
+    score, pose = m.Match(init, SEVEN_POINTS, dg)
+    assert is_nearly(pose, EXPECTED, 1e-3)
+    ref = orc.rtcsm3d_match(RTCSM_TEST_OPTS, init, SEVEN_POINTS, og)
+    assert np.float32(score) == np.float32(ref["score"])
+    assert np.array_equal(pose, ref["pose"])
+    assert m.last_stats().best_index == ref["best_index"]
+    assert m.last_stats().window.num_candidates == 9261
+    dg.close()
+
+
+def _synthetic_case(orc, beams, azimuths, resolution=0.1, scan_index=6, max_range=None, seed=13):
+    from dliom import synth
+    og = build_oracle_submap(orc, resolution, num_scans=6, beams=16, azimuths=256)
+    truth = synth.trajectory_pose(0.1 * scan_index)
+    pts, _ = synth.scan(truth, beams, azimuths)
+    if max_range is not None:
+        pts = synth.range_filter(pts, max_range)
+    init = synth.perturb_pose(truth, 0.1, 0.5, seed=seed)
+    return og, pts, init, truth
+
+
+def test_rtcsm3d_score_volume_matches_oracle(dl, ctx, orc):
+    og, pts, init, _ = _synthetic_case(orc, 8, 64, max_range=15.0)
+    dg = to_device_grid(dl, ctx, og)
+    m = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    got = m.score_volume(init, pts, dg)
+    want = orc.rtcsm3d_value_sums(DEFAULT_RTCSM, init, pts, og)
+    assert len(got) == len(want) == m.window(0.1, pts).num_candidates
+    assert np.array_equal(got, want)
+    dg.close()
+
+
+@pytest.mark.parametrize("beams,azimuths,max_range,opts", [
+    (8, 40, 15.0, DEFAULT_RTCSM),                     # W-ref sized cloud (~300 points)
+    (16, 256, 15.0, DEFAULT_RTCSM),                   # 4096-ray scan
+    (16, 128, None, dict(DEFAULT_RTCSM, linear_search_window=0.1, angular_search_window=np.deg2rad(3.0),
+                         rotation_delta_cost_weight=0.3)),  # D-LIOM override: 1 translation x many rotations
+])
+def test_rtcsm3d_match_equals_oracle(dl, ctx, orc, beams, azimuths, max_range, opts):
+    og, pts, init, _ = _synthetic_case(orc, beams, azimuths, max_range=max_range)
+    dg = to_device_grid(dl, ctx, og)
+    m = dl.RealTimeCorrelativeScanMatcher3D(ctx, opts)
+    score, pose = m.Match(init, pts, dg)
+    ref = orc.rtcsm3d_match(opts, init, pts, og)
+    st = m.last_stats()
+    assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"], st.num_rescored)
+    assert np.float32(score) == np.float32(ref["score"])
+    assert np.array_equal(pose, ref["pose"])
+    assert 1 <= st.num_rescored <= st.window.num_candidates
+    # the device-resident cloud entry point gives the same answer
+    cloud = dl.PointCloud(ctx, pts)
+    score2, pose2 = m.Match(init, cloud, dg)
+    assert score2 == score and np.array_equal(pose2, pose)
+    cloud.close()
+    dg.close()
+
+
+def test_rtcsm3d_full_size_properties(dl, ctx, orc):
+    """64 x 1024 cloud (BASELINE config 2): integer score volume is additive over a split of the
+    cloud, agrees with the oracle on sampled candidates, and the match is deterministic."""
+    og, pts, init, _ = _synthetic_case(orc, 64, 1024, max_range=15.0)
+    dg = to_device_grid(dl, ctx, og)
+    m = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    far = int(np.argmax(np.linalg.norm(pts.astype(np.float64), axis=1)))
+    rest = np.delete(pts, far, axis=0)
+    half = len(rest) // 2
+    a = np.concatenate([pts[far:far + 1], rest[:half]])
+    b = np.concatenate([pts[far:far + 1], rest[half:]])
+    full = np.concatenate([a, b])
+    sa, sb, sf = m.score_volume(init, a, dg), m.score_volume(init, b, dg), m.score_volume(init, full, dg)
+    assert np.array_equal(sa + sb, sf)
+    rng = np.random.RandomState(3)
+    for c in rng.randint(0, len(sf), size=12):
+        want = orc.rtcsm3d_value_sums(DEFAULT_RTCSM, init, full, og, first=int(c), count=1)[0]
+        assert sf[c] == want
+    s1, p1 = m.Match(init, full, dg)
+    s2, p2 = m.Match(init, full, dg)
+    assert s1 == s2 and np.array_equal(p1, p2)
+    dg.close()
+
+
+def test_rtcsm3d_error_codes(dl, ctx, orc):
+    og, dg = _kat_grids(dl, ctx, orc, 0.1)
+    m = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_TEST_OPTS)
+    with pytest.raises(dl.DliomError) as e:
+        m.Match(EXPECTED, np.zeros((0, 3), dtype=np.float32), dg)
+    assert e.value.status == dl.ERR_EMPTY_CLOUD
+    dg.close()
+
+
+# ------------------------------------------------------------------------------ CSM3D
+CSM_TEST_OPTS = dict(occupied_space_weight=[1.0], translation_weight=0.01, rotation_weight=0.1,
+                     only_optimize_yaw=False, use_nonmonotonic_steps=True, max_num_iterations=10)
+
+
+def _oracle_normal_equations(orc, opts, target_t, init, pose, clouds_and_grids):
+    """cost, J^T r and J^T J of the stacked problem from the oracle's per-residual Jacobians."""
+    q = np.asarray(pose[3:7], dtype=np.float64)
+    Pq = np.array([[-q[1], -q[2], -q[3]], [q[0], q[3], -q[2]], [-q[3], q[0], q[1]], [q[2], -q[1], q[0]]])
+    rows, res = [], []
+    for (pts, g), w in zip(clouds_and_grids, opts["occupied_space_weight"]):
+        r, jt, jq = orc.occupied_space_evaluate(g, pts, w / np.sqrt(len(pts)), pose[:3], q)
+        rows.append(np.hstack([jt, jq @ Pq]))
+        res.append(r)
+    if opts["translation_weight"] > 0:
+        w = opts["translation_weight"]
+        rows.append(np.hstack([w * np.eye(3), np.zeros((3, 3))]))
+        res.append(w * (np.asarray(pose[:3]) - np.asarray(target_t)))
+    if opts["rotation_weight"] > 0:
+        w = opts["rotation_weight"]
+        z = np.array([init[3], -init[4], -init[5], -init[6]])
+        D = np.array([[z[1], z[0], -z[3], z[2]], [z[2], z[3], z[0], -z[1]], [z[3], -z[2], z[1], z[0]]])
+        rows.append(np.hstack([np.zeros((3, 3)), w * D @ Pq]))
+        res.append(w * (D @ q))
+    J = np.vstack(rows)
+    r = np.concatenate(res)
+    return 0.5 * float(r @ r), J.T @ r, J.T @ J
+
+
+def test_csm3d_evaluate_matches_oracle_jets(dl, ctx, orc):
+    """Residuals and analytic Jacobians of the kernel vs the oracle's forward-mode Jets."""
+    og_hi, pts, init, truth = _synthetic_case(orc, 16, 128, resolution=0.1, max_range=20.0)
+    og_lo = build_oracle_submap(orc, 0.45, num_scans=6, beams=16, azimuths=256)
+    dg_hi, dg_lo = to_device_grid(dl, ctx, og_hi), to_device_grid(dl, ctx, og_lo)
+    m = dl.CeresScanMatcher3D(ctx, DEFAULT_CSM)
+    pairs_o = [(pts, og_hi), (pts[::2], og_lo)]
+    pairs_d = [(pts, dg_hi), (pts[::2], dg_lo)]
+    for pose in (init, truth, 0.5 * (init + truth)):
+        cost, grad, jtj = m.evaluate(init[:3], init, pose, pairs_d)
+        c0, g0, h0 = _oracle_normal_equations(orc, DEFAULT_CSM, init[:3], init, pose, pairs_o)
+        assert abs(cost - c0) <= 1e-11 * max(1.0, abs(c0))
+        assert np.allclose(grad, g0, rtol=1e-9, atol=1e-9 * np.abs(g0).max())
+        assert np.allclose(jtj, h0, rtol=1e-9, atol=1e-9 * np.abs(h0).max())
+    dg_hi.close()
+    dg_lo.close()
+
+
+@pytest.mark.parametrize("t", [(-1.0, 0, 0), (-0.8, 0, 0), (-1.0, 0, -0.2), (-0.9, -0.2, 0.2)])
+def test_csm3d_reference_kat(dl, ctx, orc, t):
+    """ceres_scan_matcher_3d_test.cc:34-100 through the HIP matcher."""
+    from test_oracle_kat import is_nearly
+    og, dg = _kat_grids(dl, ctx, orc, 1.0)
+    init = orc.pose(t)
+    m = dl.CeresScanMatcher3D(ctx, CSM_TEST_OPTS)
+    pose, summary = m.Match(init[:3], init, [(SEVEN_POINTS, dg)])
+    assert abs(summary["final_cost"]) < 1e-2
+    assert is_nearly(pose, EXPECTED, 3e-2)
+    ref = orc.csm3d_match(CSM_TEST_OPTS, init[:3], init, [(SEVEN_POINTS, og)])
+    dt, da = pose_distance(pose, ref["pose"])
+    assert dt <= 1e-6 and da <= 1e-6, (pose, ref["pose"])  # north_star: <= 1e-4 m vs reference path
+    dg.close()
+
+
+def test_csm3d_reference_kat_full_pose(dl, ctx, orc):
+    from test_oracle_kat import is_nearly
+    og, dg = _kat_grids(dl, ctx, orc, 1.0)
+    additional = orc.pose((0, 0, 0), orc.angle_axis_quat(0.05, (0, 0, 1)))
+    cloud = orc.transform_points(additional.astype(np.float32), SEVEN_POINTS)
+    expected = orc.rigid_multiply(EXPECTED, orc.rigid_inverse(additional))
+    init = orc.pose((-0.95, -0.05, 0.05), orc.angle_axis_quat(0.05, (1, 0, 0)))
+    m = dl.CeresScanMatcher3D(ctx, CSM_TEST_OPTS)
+    pose, summary = m.Match(init[:3], init, [(cloud, dg)])
+    assert abs(summary["final_cost"]) < 1e-2
+    assert is_nearly(pose, expected, 3e-2)
+    dg.close()
+
+
+@pytest.mark.parametrize("beams,azimuths,yaw_only", [(8, 40, False), (16, 256, False), (16, 256, True)])
+def test_csm3d_match_close_to_oracle(dl, ctx, orc, beams, azimuths, yaw_only):
+    """Same inputs, same LM restatement: final pose within 1e-6 m / 1e-6 rad of the oracle
+    (north_star tolerance: 1e-4 m).  Normal equations vs the oracle's QR and analytic vs Jet
+    derivatives differ in rounding only."""
+    og_hi, pts, init, truth = _synthetic_case(orc, beams, azimuths, resolution=0.1, max_range=20.0)
+    og_lo = build_oracle_submap(orc, 0.45, num_scans=6, beams=16, azimuths=256)
+    dg_hi, dg_lo = to_device_grid(dl, ctx, og_hi), to_device_grid(dl, ctx, og_lo)
+    opts = dict(DEFAULT_CSM, only_optimize_yaw=yaw_only)
+    m = dl.CeresScanMatcher3D(ctx, opts)
+    pose, summary = m.Match(init[:3], init, [(pts, dg_hi), (pts, dg_lo)])
+    ref = orc.csm3d_match(opts, init[:3], init, [(pts, og_hi), (pts, og_lo)])
+    dt, da = pose_distance(pose, ref["pose"])
+    assert dt <= 1e-6 and da <= 1e-6, (dt, da, summary, ref)
+    assert abs(summary["final_cost"] - ref["final_cost"]) <= 1e-9 * max(1.0, ref["final_cost"])
+    assert summary["num_iterations"] == ref["num_iterations"]
+    dg_hi.close()
+    dg_lo.close()
+
+
+def test_csm3d_error_codes(dl, ctx, orc):
+    og, dg = _kat_grids(dl, ctx, orc, 1.0)
+    bad = dict(CSM_TEST_OPTS, occupied_space_weight=[1.0, 2.0])  # CHECK_EQ(weights, clouds)
+    with pytest.raises(dl.DliomError) as e:
+        dl.CeresScanMatcher3D(ctx, bad).Match(EXPECTED[:3], EXPECTED, [(SEVEN_POINTS, dg)])
+    assert e.value.status == dl.ERR_WEIGHTS
+    zero = dict(CSM_TEST_OPTS, occupied_space_weight=[0.0])  # CHECK_GT(weight, 0)
+    with pytest.raises(dl.DliomError) as e:
+        dl.CeresScanMatcher3D(ctx, zero).Match(EXPECTED[:3], EXPECTED, [(SEVEN_POINTS, dg)])
+    assert e.value.status == dl.ERR_WEIGHTS
+    dg.close()
+
+
+# ------------------------------------------------------------------------------ end to end
+def test_front_end_slice_equals_oracle(dl, ctx, orc):
+    """Insert -> RTCSM -> Ceres -> insert on the device vs the same chain on the oracle."""
+    from dliom import synth
+    res_hi, res_lo = 0.1, 0.45
+    og_hi, og_lo = orc.HybridGrid(res_hi), orc.HybridGrid(res_lo)
+    dg_hi, dg_lo = dl.HybridGrid(ctx, res_hi), dl.HybridGrid(ctx, res_lo)
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE)
+    hit, miss = ins.hit_table, ins.miss_table
+    for s in range(4):
+        pose = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(pose, 16, 256)
+        world = synth.transform_points(pose, pts)
+        origin = pose[:3].astype(np.float32)
+        near = world[np.linalg.norm((world - origin).astype(np.float64), axis=1) <= 20.0]
+        og_hi.insert_tables(origin, near, hit, miss, FREE)
+        og_lo.insert_tables(origin, world, hit, miss, FREE)
+        ins.Insert(origin, near, dg_hi)
+        ins.Insert(origin, world, dg_lo)
+    truth = synth.trajectory_pose(0.4)
+    pts, _ = synth.scan(truth, 16, 256)
+    init = synth.perturb_pose(truth, 0.1, 0.5, seed=5)
+    hi_pts = orc.adaptive_voxel_filter(2.0, 150, 15.0, pts)
+    lo_pts = orc.adaptive_voxel_filter(4.0, 200, 60.0, pts)
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    cs = dl.CeresScanMatcher3D(ctx, DEFAULT_CSM)
+    _, p1 = rt.Match(init, hi_pts, dg_hi)
+    p2, _ = cs.Match(init[:3], p1, [(hi_pts, dg_hi), (lo_pts, dg_lo)])
+    r1 = orc.rtcsm3d_match(DEFAULT_RTCSM, init, hi_pts, og_hi)
+    r2 = orc.csm3d_match(DEFAULT_CSM, init[:3], r1["pose"], [(hi_pts, og_hi), (lo_pts, og_lo)])
+    assert np.array_equal(p1, r1["pose"])
+    dt, da = pose_distance(p2, r2["pose"])
+    assert dt <= 1e-6 and da <= 1e-6
+    for g in (dg_hi, dg_lo):
+        g.close()
