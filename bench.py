@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/sec of the scan-to-submap front end on MI355X.
+
+One "step" = one pass of the hot path over one synthetic scan (BASELINE.json config 2, the
+north-star workload "W-dense"): a 64-beam x 1024-azimuth cloud (all returns, nothing filtered)
+is matched against a 10 cm HybridGrid submap by RealTimeCorrelativeScanMatcher3D, refined by
+CeresScanMatcher3D against the high (0.10 m) and low (0.45 m) resolution grids, and inserted into
+both grids -- LocalTrajectoryBuilder3D::AddAccumulatedRangeData minus the GTSAM window
+(local_trajectory_builder_3d.cc:493-572).  Clouds and grids are resident in HBM when the timed
+region starts.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, every rank runs its own independent scan stream against its own
+submap (weak scaling, no data-path collective; SURVEY.md 8e "replicas").  Rank 0 prints ONE JSON
+line.  The CPU oracle is used ONLY for the `cpu_baseline` leg (rank 0, N == 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "d-liom_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); 6.29 TB/s measured copy
+
+RTCSM_OPTS = dict(linear_search_window=0.15, angular_search_window=float(np.deg2rad(1.0)),
+                  translation_delta_cost_weight=1e-1, rotation_delta_cost_weight=1e-1)
+CSM_OPTS = dict(occupied_space_weight=[1.0, 6.0], translation_weight=5.0, rotation_weight=4e2,
+                only_optimize_yaw=False, use_nonmonotonic_steps=False, max_num_iterations=12)
+HIT_P, MISS_P, FREE = 0.55, 0.49, 2
+HIGH_RES_MAX_RANGE = 20.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--beams", type=int, default=64)
+    ap.add_argument("--azimuths", type=int, default=1024)
+    ap.add_argument("--high-resolution", type=float, default=0.10)
+    ap.add_argument("--low-resolution", type=float, default=0.45)
+    ap.add_argument("--map-scans", type=int, default=20, help="scans inserted at ground truth before matching")
+    ap.add_argument("--distinct-scans", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libdliom has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    import dliom as dl
+    from dliom import synth
+    dl.load_library()
+    ctx = dl.Context(local_rank)
+
+    # ---------------------------------------------------------------- scene (per rank: own time offset)
+    t0 = 0.05 * rank  # every rank flies its own stretch of the corkscrew
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
+    g_hi = dl.HybridGrid(ctx, args.high_resolution)
+    g_lo = dl.HybridGrid(ctx, args.low_resolution)
+    centers = synth.bubbles()
+    for s in range(args.map_scans):
+        pose = synth.trajectory_pose(t0 + 0.1 * s)
+        pts, _ = synth.scan(pose, args.beams, args.azimuths, centers=centers)
+        cloud = dl.PointCloud(ctx, pts)
+        pf = pose.astype(np.float32)
+        ins.InsertCloud(g_hi, cloud, poses=[pf], max_range=HIGH_RES_MAX_RANGE)
+        ins.InsertCloud(g_lo, cloud, poses=[pf])
+        cloud.close()
+    scans = []
+    for k in range(args.distinct_scans):
+        truth = synth.trajectory_pose(t0 + 0.1 * (args.map_scans + k))
+        pts, _ = synth.scan(truth, args.beams, args.azimuths, centers=centers)
+        init = synth.perturb_pose(truth, 0.1, 0.5, seed=13 + k)
+        scans.append(dict(truth=truth, pts=pts, init=init, cloud=dl.PointCloud(ctx, pts)))
+
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_OPTS)
+    cs = dl.CeresScanMatcher3D(ctx, CSM_OPTS)
+    stage = {"rtcsm": 0.0, "ceres": 0.0, "insert": 0.0}
+    evals = []
+
+    def step(i, timed):
+        sc = scans[i % len(scans)]
+        a = time.perf_counter()
+        _, p1 = rt.Match(sc["init"], sc["cloud"], g_hi)
+        b = time.perf_counter()
+        p2, summ = cs.Match(sc["init"][:3], p1, [(sc["cloud"], g_hi), (sc["cloud"], g_lo)])
+        c = time.perf_counter()
+        pf = p2.astype(np.float32)
+        ins.InsertCloud(g_hi, sc["cloud"], poses=[pf], max_range=HIGH_RES_MAX_RANGE)
+        ins.InsertCloud(g_lo, sc["cloud"], poses=[pf])
+        d = time.perf_counter()
+        if timed:
+            stage["rtcsm"] += b - a
+            stage["ceres"] += c - b
+            stage["insert"] += d - c
+            evals.append(summ["num_residual_evaluations"])
+        return p2
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    ctx.set_profiling(True)
+    ctx.reset_profiling()
+    fence()
+    lat = []
+    t_begin = time.perf_counter()
+    for i in range(args.steps):
+        s0 = time.perf_counter()
+        step(args.warmup + i, True)
+        lat.append(time.perf_counter() - s0)
+    fence()
+    elapsed = time.perf_counter() - t_begin
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    score_ms, score_n = ctx.kernel_time(dl.KERNEL_RTCSM_SCORE)
+    select_ms, _ = ctx.kernel_time(dl.KERNEL_RTCSM_SELECT)
+    rescore_ms, _ = ctx.kernel_time(dl.KERNEL_RTCSM_RESCORE)
+    csm_ms, csm_n = ctx.kernel_time(dl.KERNEL_CSM_EVAL)
+    insert_ms, insert_n = ctx.kernel_time(dl.KERNEL_INSERT)
+    ctx.set_profiling(False)
+    st = rt.last_stats()
+    n_pts = int(st.num_points)
+    C = int(st.window.num_candidates)
+
+    out = None
+    if rank == 0:
+        total_scans = args.steps * world
+        value = total_scans / elapsed
+        alg_bytes = 14.0 * C * n_pts  # 12 B point + 2 B voxel per candidate-point pair
+        k_ms = score_ms / max(score_n, 1)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("num_points") == n_pts and tj.get("num_candidates") == C:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "scans/sec (64-beam x 1024 pts -> 10 cm 3D submap)",
+            "value": value,
+            "unit": "scans/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "p50_latency_ms": 1e3 * float(np.median(lat)),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 transforms + u16 voxels/u64 sums (rtcsm), f64 (ceres)",
+            "data": "synthetic",
+            "config": {
+                "workload": "config2 W-dense: %dx%d scan, all returns matched (adaptive voxel filters "
+                            "neutralised), RTCSM3D + CeresScanMatcher3D(hi+lo) + insertion(hi+lo)" %
+                            (args.beams, args.azimuths),
+                "high_resolution": args.high_resolution, "low_resolution": args.low_resolution,
+                "N_hi": n_pts, "N_lo": n_pts, "C": C,
+                "linear_window": int(st.window.linear_window_size),
+                "angular_window": int(st.window.angular_window_size),
+                "max_scan_range": float(st.window.max_scan_range),
+                "E_mean": float(np.mean(evals)) if evals else 0.0,
+                "rescored_candidates_last": int(st.num_rescored),
+                "map_scans": args.map_scans, "parallelism": "replicas x%d" % world,
+            },
+            "stage_ms_per_scan": {k: 1e3 * v / args.steps for k, v in stage.items()},
+            "kernel_ms_per_scan": {
+                "rtcsm_score": score_ms / args.steps, "rtcsm_select": select_ms / args.steps,
+                "rtcsm_rescore": rescore_ms / args.steps, "csm_eval": csm_ms / args.steps,
+                "insert": insert_ms / args.steps},
+            "roofline": {
+                "kernel": "rtcsm_score_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_ms, "launches": int(score_n),
+                "note": "algorithmic bytes = 14 B x C x N; points are reused from registers and the "
+                        "grid from L2/MALL, so frac > 1 is possible -- see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, dl, scans[0], g_hi, g_lo, ins, C, n_pts)
+    if out is not None:
+        print(json.dumps(out))
+    for sc in scans:
+        sc["cloud"].close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, dl, sc, g_hi, g_lo, ins, C, n_pts):
+    """Times the CPU oracle (reference-layout pointer-tree HybridGrid, per-candidate
+    TransformPointCloud allocation, Jet autodiff + dense QR) on the same scan and the same grids.
+    The RTCSM3D candidate loop is timed on an evenly spread sample of candidates and scaled to C;
+    Ceres and insertion are timed in full.  One thread, like the reference runs this path."""
+    from oracle import oracle as orc
+
+    def to_oracle(dg):
+        og = orc.HybridGrid(dg.resolution)
+        origins, values = dg.download_blocks()
+        for o, v in zip(origins, values):
+            nz = np.nonzero(v)[0]
+            if len(nz) == 0:
+                continue
+            xyz = np.stack([o[0] + (nz & 7), o[1] + ((nz >> 3) & 7), o[2] + (nz >> 6)], axis=1)
+            og.set_values(xyz, v[nz])
+        return og
+
+    og_hi, og_lo = to_oracle(g_hi), to_oracle(g_lo)
+    pts, init = sc["pts"], sc["init"]
+    # calibrate on a few candidates, then spend ~cpu_seconds on evenly spread chunks
+    t = time.perf_counter()
+    orc.rtcsm3d_match_range(RTCSM_OPTS, init, pts, og_hi, 0, 8)
+    per_cand = (time.perf_counter() - t) / 8
+    budget = max(2.0, args.cpu_seconds * 0.7)
+    n_sample = int(max(16, min(C, budget / max(per_cand, 1e-9))))
+    chunks = 16
+    per_chunk = max(1, n_sample // chunks)
+    t = time.perf_counter()
+    done = 0
+    for k in range(chunks):
+        first = (C // chunks) * k
+        cnt = min(per_chunk, C - first)
+        orc.rtcsm3d_match_range(RTCSM_OPTS, init, pts, og_hi, first, cnt)
+        done += cnt
+    t_rtcsm_sample = time.perf_counter() - t
+    t_rtcsm = t_rtcsm_sample / done * C
+    t = time.perf_counter()
+    r = orc.csm3d_match(CSM_OPTS, init[:3], init, [(pts, og_hi), (pts, og_lo)])
+    t_csm = time.perf_counter() - t
+    from dliom import synth
+    world_pts = synth.transform_points(sc["truth"], pts)
+    origin = sc["truth"][:3].astype(np.float32)
+    near = world_pts[np.linalg.norm((world_pts - origin).astype(np.float64), axis=1) <= HIGH_RES_MAX_RANGE]
+    t = time.perf_counter()
+    og_hi.insert_tables(origin, near, ins.hit_table, ins.miss_table, FREE)
+    og_lo.insert_tables(origin, world_pts, ins.hit_table, ins.miss_table, FREE)
+    t_ins = time.perf_counter() - t
+    per_scan = t_rtcsm + t_csm + t_ins
+    return {
+        "value": 1.0 / per_scan, "unit": "scans/s", "cores": 1, "kind": "port",
+        "host_cores_available": os.cpu_count(),
+        "seconds_per_scan": per_scan,
+        "stage_seconds": {"rtcsm": t_rtcsm, "ceres": t_csm, "insert": t_ins},
+        "sample": "oracle (C++ restatement of the reference, g++ -O3, 1 thread) on the same %d-point scan and "
+                  "grids: RTCSM3D candidate loop timed on %d of %d candidates in %d evenly spread chunks "
+                  "(%.1f s) and scaled to C; CeresScanMatcher3D (%d evaluations) and both insertions timed "
+                  "in full" % (n_pts, done, C, chunks, t_rtcsm_sample, r["num_residual_evaluations"]),
+    }
+
+
+if __name__ == "__main__":
+    main()

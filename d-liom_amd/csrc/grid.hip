@@ -70,7 +70,8 @@ __device__ __forceinline__ void apply_table(uint32_t* pool32, size_t value_index
 
 struct InsertArgs {
   const float* returns;  // packed xyz
-  int64_t n;
+  int64_t n;             // upper bound of the number of returns
+  const unsigned* n_dev; // if non-null the actual number (<= n) lives on the device
   float ox, oy, oz;      // origin
   float resolution;
   int num_free;
@@ -100,7 +101,7 @@ __device__ __forceinline__ int bits_for(int c) {
 // CHECK_LT(num_samples, 1<<15) condition.  out[0] = max needed bits, out[1] = ray too long.
 __global__ void insert_scan_kernel(InsertArgs a, int* __restrict__ out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  if (i >= (a.n_dev != nullptr ? static_cast<int64_t>(*a.n_dev) : a.n)) return;
   const int hx = cell_of(a.returns[3 * i], a.resolution);
   const int hy = cell_of(a.returns[3 * i + 1], a.resolution);
   const int hz = cell_of(a.returns[3 * i + 2], a.resolution);
@@ -123,7 +124,7 @@ __global__ void insert_scan_kernel(InsertArgs a, int* __restrict__ out) {
 __global__ void insert_alloc_kernel(InsertArgs a, uint32_t* table, int32_t* slot_coord,
                                     uint32_t* count) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  if (i >= (a.n_dev != nullptr ? static_cast<int64_t>(*a.n_dev) : a.n)) return;
   const int hx = cell_of(a.returns[3 * i], a.resolution);
   const int hy = cell_of(a.returns[3 * i + 1], a.resolution);
   const int hz = cell_of(a.returns[3 * i + 2], a.resolution);
@@ -145,7 +146,7 @@ template <int MODE>
 __global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ table,
                                     uint32_t* pool32, const uint16_t* __restrict__ lut) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  if (i >= (a.n_dev != nullptr ? static_cast<int64_t>(*a.n_dev) : a.n)) return;
   const int hx = cell_of(a.returns[3 * i], a.resolution);
   const int hy = cell_of(a.returns[3 * i + 1], a.resolution);
   const int hz = cell_of(a.returns[3 * i + 2], a.resolution);
@@ -218,6 +219,41 @@ __global__ void get_values_kernel(GridView g, const int32_t* __restrict__ cells,
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   out[i] = static_cast<uint16_t>(grid_value(g, cells[3 * i], cells[3 * i + 1], cells[3 * i + 2]));
+}
+
+// sensor::TransformRangeData (sensor/range_data.cc:25-33) through up to two float poses applied
+// in sequence, then FilterRangeDataByMaxRange (mapping/3d/submap_3d.cc:42-51): keeps returns
+// with ||hit - origin|| <= max_range (Eigen norm order x*x + (y*y + z*z)).  Survivors are
+// compacted in arbitrary order -- insertion is order independent.
+struct TransformArgs {
+  Quat4 q[2];
+  float t[2][3];
+  int num_poses;
+  float ox, oy, oz;   // origin AFTER the transforms
+  float max_range;    // <= 0: keep everything
+};
+__global__ void transform_filter_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                                        const float* __restrict__ pz, int64_t n, TransformArgs a,
+                                        float* __restrict__ out, unsigned* __restrict__ count) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = px[i], y = py[i], z = pz[i];
+  for (int k = 0; k < a.num_poses; ++k) {
+    float rx, ry, rz;
+    rotate_point(a.q[k], x, y, z, rx, ry, rz);
+    x = rx + a.t[k][0];
+    y = ry + a.t[k][1];
+    z = rz + a.t[k][2];
+  }
+  if (a.max_range > 0.f) {
+    const float dx = x - a.ox, dy = y - a.oy, dz = z - a.oz;
+    const float norm = sqrtf(dx * dx + (dy * dy + dz * dz));
+    if (!(norm <= a.max_range)) return;
+  }
+  const unsigned k = atomicAdd(count, 1u);
+  out[3 * static_cast<size_t>(k)] = x;
+  out[3 * static_cast<size_t>(k) + 1] = y;
+  out[3 * static_cast<size_t>(k) + 2] = z;
 }
 
 static inline unsigned blocks_for(int64_t n, int threads) {
@@ -451,6 +487,54 @@ int dliom_grid_get_values(const dliom_grid* g, const int32_t* cells, int64_t n, 
   return DLIOM_OK;
 }
 
+// Shared tail of the insertion entry points.  d_returns: packed xyz on the device (n upper
+// bound, n_dev optional exact count), d_hit/d_miss: 32768-entry tables on the device,
+// d_scan: 2 ints of scratch.
+static int insert_device(dliom_grid* g, const float origin[3], const float* d_returns, int64_t n,
+                         const unsigned* n_dev, const uint16_t* d_hit, const uint16_t* d_miss,
+                         int* d_scan, int num_free_space_voxels) {
+  dliom_ctx* ctx = g->ctx;
+  DLIOM_HIP_TRY(hipMemsetAsync(d_scan, 0, 8, ctx->stream));
+  InsertArgs a;
+  a.returns = d_returns;
+  a.n = n;
+  a.n_dev = n_dev;
+  a.ox = origin[0];
+  a.oy = origin[1];
+  a.oz = origin[2];
+  a.resolution = g->resolution;
+  a.num_free = num_free_space_voxels;
+  a.half = 0;
+  a.gsize = 0;
+  a.L = 0;
+  const dim3 grid(blocks_for(n, 256)), block(256);
+  hipLaunchKernelGGL(insert_scan_kernel, grid, block, 0, ctx->stream, a, d_scan);
+  DLIOM_HIP_TRY(hipGetLastError());
+  int scan[2] = {0, 0};
+  DLIOM_HIP_TRY(hipMemcpyAsync(scan, d_scan, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (scan[1] != 0) return DLIOM_ERR_RAY_TOO_LONG;
+  if (scan[0] > 8) return DLIOM_ERR_GRID_EXTENT;
+  DLIOM_TRY(g->ensure_bits(scan[0]));
+  DLIOM_TRY(g->ensure_capacity(n * (1 + static_cast<int64_t>(num_free_space_voxels))));
+
+  const GridView v = g->view();
+  a.half = v.half;
+  a.gsize = v.grid_size;
+  a.L = static_cast<unsigned>(v.leaves_per_axis);
+  uint32_t* pool32 = reinterpret_cast<uint32_t*>(g->d_pool);
+  hipLaunchKernelGGL(insert_alloc_kernel, grid, block, 0, ctx->stream, a, g->d_table, g->d_slot_coord,
+                     g->d_count);
+  hipLaunchKernelGGL(insert_apply_kernel<0>, grid, block, 0, ctx->stream, a, g->d_table, pool32, d_hit);
+  if (num_free_space_voxels > 0)
+    hipLaunchKernelGGL(insert_apply_kernel<1>, grid, block, 0, ctx->stream, a, g->d_table, pool32,
+                       d_miss);
+  hipLaunchKernelGGL(insert_apply_kernel<2>, grid, block, 0, ctx->stream, a, g->d_table, pool32, d_hit);
+  DLIOM_HIP_TRY(hipGetLastError());
+  g->used_upper += n * (1 + static_cast<int64_t>(num_free_space_voxels));
+  return DLIOM_OK;
+}
+
 int dliom_grid_insert(dliom_grid* g, const float origin[3], const float* returns_xyz, int64_t n,
                       const uint16_t* hit_table, const uint16_t* miss_table,
                       int num_free_space_voxels) {
@@ -472,55 +556,135 @@ int dliom_grid_insert(dliom_grid* g, const float origin[3], const float* returns
                                hipMemcpyHostToDevice, ctx->stream));
   DLIOM_HIP_TRY(hipMemcpyAsync(d_hit, hit_table, 65536, hipMemcpyHostToDevice, ctx->stream));
   DLIOM_HIP_TRY(hipMemcpyAsync(d_miss, miss_table, 65536, hipMemcpyHostToDevice, ctx->stream));
-  DLIOM_HIP_TRY(hipMemsetAsync(d_scan, 0, 8, ctx->stream));
-
-  InsertArgs a;
-  a.returns = d_returns;
-  a.n = n;
-  a.ox = origin[0];
-  a.oy = origin[1];
-  a.oz = origin[2];
-  a.resolution = g->resolution;
-  a.num_free = num_free_space_voxels;
-  a.half = 0;
-  a.gsize = 0;
-  a.L = 0;
-  const dim3 grid(blocks_for(n, 256)), block(256);
   const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
-  hipLaunchKernelGGL(insert_scan_kernel, grid, block, 0, ctx->stream, a, d_scan);
-  DLIOM_HIP_TRY(hipGetLastError());
-  int scan[2] = {0, 0};
-  DLIOM_HIP_TRY(hipMemcpyAsync(scan, d_scan, 8, hipMemcpyDeviceToHost, ctx->stream));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (scan[1] != 0) {
-    ctx->end_span(span);
-    return DLIOM_ERR_RAY_TOO_LONG;
-  }
-  if (scan[0] > 8) {
-    ctx->end_span(span);
-    return DLIOM_ERR_GRID_EXTENT;
-  }
-  DLIOM_TRY(g->ensure_bits(scan[0]));
-  DLIOM_TRY(g->ensure_capacity(n * (1 + static_cast<int64_t>(num_free_space_voxels))));
-
-  const GridView v = g->view();
-  a.half = v.half;
-  a.gsize = v.grid_size;
-  a.L = static_cast<unsigned>(v.leaves_per_axis);
-  uint32_t* pool32 = reinterpret_cast<uint32_t*>(g->d_pool);
-  hipLaunchKernelGGL(insert_alloc_kernel, grid, block, 0, ctx->stream, a, g->d_table, g->d_slot_coord,
-                     g->d_count);
-  hipLaunchKernelGGL(insert_apply_kernel<0>, grid, block, 0, ctx->stream, a, g->d_table, pool32, d_hit);
-  if (num_free_space_voxels > 0)
-    hipLaunchKernelGGL(insert_apply_kernel<1>, grid, block, 0, ctx->stream, a, g->d_table, pool32,
-                       d_miss);
-  hipLaunchKernelGGL(insert_apply_kernel<2>, grid, block, 0, ctx->stream, a, g->d_table, pool32, d_hit);
-  DLIOM_HIP_TRY(hipGetLastError());
+  const int s = insert_device(g, origin, d_returns, n, nullptr, d_hit, d_miss, d_scan,
+                              num_free_space_voxels);
   ctx->end_span(span);
-  g->used_upper += n * (1 + static_cast<int64_t>(num_free_space_voxels));
   // ctx->misc is reused by later calls on this context: finish before returning.
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return s;
+}
+
+int dliom_inserter_create(dliom_ctx* ctx, double hit_probability, double miss_probability,
+                          int num_free_space_voxels, dliom_inserter** out) {
+  if (ctx == nullptr || out == nullptr || num_free_space_voxels < 0) return DLIOM_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  // CHECK_GT(hit, 0.5), CHECK_LT(miss, 0.5): range_data_inserter_3d.cc:64-65
+  if (!(hit_probability > 0.5) || !(miss_probability < 0.5)) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  dliom_inserter* ins = new dliom_inserter;
+  ins->ctx = ctx;
+  ins->num_free_space_voxels = num_free_space_voxels;
+  ins->hit_table.resize(32768);
+  ins->miss_table.resize(32768);
+  // RangeDataInserter3D ctor: ComputeLookupTableToApplyOdds(Odds(float(p)))
+  dliom_compute_lookup_table_to_apply_odds(dliom_odds(static_cast<float>(hit_probability)),
+                                           ins->hit_table.data());
+  dliom_compute_lookup_table_to_apply_odds(dliom_odds(static_cast<float>(miss_probability)),
+                                           ins->miss_table.data());
+  if (hipMalloc(reinterpret_cast<void**>(&ins->d_tables), 2 * 65536 + 256) != hipSuccess) {
+    delete ins;
+    return DLIOM_ERR_HIP;
+  }
+  if (hipMemcpy(ins->d_tables, ins->hit_table.data(), 65536, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ins->d_tables + 32768, ins->miss_table.data(), 65536, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(ins->d_tables);
+    delete ins;
+    return DLIOM_ERR_HIP;
+  }
+  *out = ins;
   return DLIOM_OK;
+}
+
+int dliom_inserter_destroy(dliom_inserter* ins) {
+  if (ins == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (ins->d_tables != nullptr) (void)hipFree(ins->d_tables);
+  delete ins;
+  return DLIOM_OK;
+}
+
+int dliom_inserter_tables(const dliom_inserter* ins, uint16_t* hit_table, uint16_t* miss_table) {
+  if (ins == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (hit_table != nullptr) std::memcpy(hit_table, ins->hit_table.data(), 65536);
+  if (miss_table != nullptr) std::memcpy(miss_table, ins->miss_table.data(), 65536);
+  return DLIOM_OK;
+}
+
+int dliom_inserter_insert(const dliom_inserter* ins, dliom_grid* g, const float origin[3],
+                          const float* returns_xyz, int64_t n) {
+  if (ins == nullptr || g == nullptr || origin == nullptr || n < 0 || (n > 0 && returns_xyz == nullptr))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_OK;
+  dliom_ctx* ctx = g->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t pbytes = (static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->misc.reserve(pbytes + 256));
+  char* base = static_cast<char*>(ctx->misc.p);
+  float* d_returns = reinterpret_cast<float*>(base);
+  int* d_scan = reinterpret_cast<int*>(base + pbytes);
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_returns, returns_xyz, static_cast<size_t>(n) * 12,
+                               hipMemcpyHostToDevice, ctx->stream));
+  const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
+  const int s = insert_device(g, origin, d_returns, n, nullptr, ins->d_tables, ins->d_tables + 32768,
+                              d_scan, ins->num_free_space_voxels);
+  ctx->end_span(span);
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return s;
+}
+
+int dliom_inserter_insert_cloud(const dliom_inserter* ins, dliom_grid* g, const float* poses7,
+                                int num_poses, const float origin[3], const dliom_cloud* cloud,
+                                float max_range) {
+  if (ins == nullptr || g == nullptr || origin == nullptr || cloud == nullptr || num_poses < 0 ||
+      num_poses > 2 || (num_poses > 0 && poses7 == nullptr))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  const int64_t n = cloud->n;
+  if (n == 0) return DLIOM_OK;
+  dliom_ctx* ctx = g->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t pbytes = (static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->misc.reserve(pbytes + 512));
+  char* base = static_cast<char*>(ctx->misc.p);
+  float* d_returns = reinterpret_cast<float*>(base);
+  int* d_scan = reinterpret_cast<int*>(base + pbytes);
+  unsigned* d_n = reinterpret_cast<unsigned*>(base + pbytes + 256);
+  DLIOM_HIP_TRY(hipMemsetAsync(d_n, 0, 4, ctx->stream));
+  TransformArgs t;
+  t.num_poses = num_poses;
+  float o[3] = {origin[0], origin[1], origin[2]};
+  for (int k = 0; k < num_poses; ++k) {
+    const float* p = poses7 + 7 * k;
+    t.q[k] = Quat4{p[3], p[4], p[5], p[6]};
+    t.t[k][0] = p[0];
+    t.t[k][1] = p[1];
+    t.t[k][2] = p[2];
+    // the origin rides through the same float transforms (host, same operation order)
+    const Quat4 q = t.q[k];
+    float uvx = q.y * o[2] - q.z * o[1], uvy = q.z * o[0] - q.x * o[2], uvz = q.x * o[1] - q.y * o[0];
+    uvx = uvx + uvx;
+    uvy = uvy + uvy;
+    uvz = uvz + uvz;
+    const float cx = q.y * uvz - q.z * uvy, cy = q.z * uvx - q.x * uvz, cz = q.x * uvy - q.y * uvx;
+    const float nx = ((o[0] + q.w * uvx) + cx) + p[0];
+    const float ny = ((o[1] + q.w * uvy) + cy) + p[1];
+    const float nz = ((o[2] + q.w * uvz) + cz) + p[2];
+    o[0] = nx;
+    o[1] = ny;
+    o[2] = nz;
+  }
+  t.ox = o[0];
+  t.oy = o[1];
+  t.oz = o[2];
+  t.max_range = max_range;
+  const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
+  hipLaunchKernelGGL(transform_filter_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream,
+                     cloud->d_x, cloud->d_y, cloud->d_z, n, t, d_returns, d_n);
+  DLIOM_HIP_TRY(hipGetLastError());
+  const int s = insert_device(g, o, d_returns, n, d_n, ins->d_tables, ins->d_tables + 32768, d_scan,
+                              ins->num_free_space_voxels);
+  ctx->end_span(span);
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return s;
 }
 
 }  // extern "C"

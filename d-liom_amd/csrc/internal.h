@@ -113,6 +113,13 @@ struct dliom_cloud {
   bool owned_by_ctx_scratch = false;
 };
 
+struct dliom_inserter {
+  dliom_ctx* ctx = nullptr;
+  int num_free_space_voxels = 0;
+  std::vector<uint16_t> hit_table, miss_table;  // host copies
+  uint16_t* d_tables = nullptr;                 // [hit 32768 | miss 32768] in HBM
+};
+
 namespace dliom {
 // host-pointer cloud staged in ctx->points (valid until the next staging call)
 int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud* out,

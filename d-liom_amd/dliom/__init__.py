@@ -106,6 +106,11 @@ SYMBOLS = [
     ("dliom_grid_download_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64, _i64p]),
     ("dliom_grid_get_values", C.c_int, [_vp, _i32p, C.c_int64, _u16p]),
     ("dliom_grid_insert", C.c_int, [_vp, _f32p, _f32p, C.c_int64, _u16p, _u16p, C.c_int]),
+    ("dliom_inserter_create", C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.POINTER(_vp)]),
+    ("dliom_inserter_destroy", C.c_int, [_vp]),
+    ("dliom_inserter_tables", C.c_int, [_vp, _u16p, _u16p]),
+    ("dliom_inserter_insert", C.c_int, [_vp, _vp, _f32p, _f32p, C.c_int64]),
+    ("dliom_inserter_insert_cloud", C.c_int, [_vp, _vp, _f32p, C.c_int, _f32p, _vp, C.c_float]),
     ("dliom_cloud_create", C.c_int, [_vp, _f32p, C.c_int64, C.POINTER(_vp)]),
     ("dliom_cloud_destroy", C.c_int, [_vp]),
     ("dliom_cloud_size", C.c_int, [_vp, _i64p]),
@@ -323,22 +328,61 @@ class HybridGrid:
 
 
 class RangeDataInserter3D:
-    """mapping::RangeDataInserter3D: options -> two odds tables; Insert(range_data, grid)."""
+    """mapping::RangeDataInserter3D: options -> two odds tables; Insert(range_data, grid).
 
-    def __init__(self, hit_probability, miss_probability, num_free_space_voxels):
+    With a Context the tables live in HBM (dliom_inserter); without one the host tables are
+    passed on every Insert (dliom_grid_insert)."""
+
+    def __init__(self, hit_probability, miss_probability, num_free_space_voxels, ctx=None):
         if not hit_probability > 0.5 or not miss_probability < 0.5:
             raise ValueError("CHECK_GT(hit, 0.5) / CHECK_LT(miss, 0.5) (range_data_inserter_3d.cc:64-65)")
         self.num_free_space_voxels = int(num_free_space_voxels)
-        # Odds(float(options.hit_probability()))
-        self.hit_table = compute_lookup_table_to_apply_odds(odds(np.float32(hit_probability)))
-        self.miss_table = compute_lookup_table_to_apply_odds(odds(np.float32(miss_probability)))
+        self.h = None
+        if ctx is not None:
+            self._L = ctx._L
+            h = _vp()
+            _check(self._L.dliom_inserter_create(ctx.h, hit_probability, miss_probability,
+                                                 self.num_free_space_voxels, C.byref(h)), "dliom_inserter_create")
+            self.h = h
+            self.hit_table = np.zeros(32768, dtype=np.uint16)
+            self.miss_table = np.zeros(32768, dtype=np.uint16)
+            _check(self._L.dliom_inserter_tables(h, _p(self.hit_table, _u16p), _p(self.miss_table, _u16p)),
+                   "dliom_inserter_tables")
+        else:
+            # Odds(float(options.hit_probability()))
+            self.hit_table = compute_lookup_table_to_apply_odds(odds(np.float32(hit_probability)))
+            self.miss_table = compute_lookup_table_to_apply_odds(odds(np.float32(miss_probability)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_inserter_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def Insert(self, origin, returns, grid):
         origin = _f32(origin)
         returns = _f32(returns).reshape(-1, 3)
-        _check(grid._L.dliom_grid_insert(grid.h, _p(origin, _f32p), _p(returns, _f32p), len(returns),
-                                         _p(self.hit_table, _u16p), _p(self.miss_table, _u16p),
-                                         self.num_free_space_voxels), "dliom_grid_insert")
+        if self.h is not None:
+            _check(grid._L.dliom_inserter_insert(self.h, grid.h, _p(origin, _f32p), _p(returns, _f32p), len(returns)),
+                   "dliom_inserter_insert")
+        else:
+            _check(grid._L.dliom_grid_insert(grid.h, _p(origin, _f32p), _p(returns, _f32p), len(returns),
+                                             _p(self.hit_table, _u16p), _p(self.miss_table, _u16p),
+                                             self.num_free_space_voxels), "dliom_grid_insert")
+
+    def InsertCloud(self, grid, cloud, poses=(), origin=(0.0, 0.0, 0.0), max_range=0.0):
+        """Submap3D::InsertRangeData's data path on the device: transform the HBM-resident cloud
+        through `poses` (0..2 float poses, applied in order), range-filter, insert."""
+        assert self.h is not None, "InsertCloud needs an inserter created with a Context"
+        poses = _f32(np.asarray(poses, dtype=np.float32).reshape(-1, 7)) if len(poses) else np.zeros((0, 7), np.float32)
+        origin = _f32(origin)
+        _check(grid._L.dliom_inserter_insert_cloud(self.h, grid.h, _p(poses, _f32p), len(poses), _p(origin, _f32p),
+                                                   cloud.h, C.c_float(max_range)), "dliom_inserter_insert_cloud")
 
 
 def _rtcsm_opts(o):

@@ -47,6 +47,7 @@ extern "C" {
 typedef struct dliom_ctx dliom_ctx;
 typedef struct dliom_grid dliom_grid;
 typedef struct dliom_cloud dliom_cloud;
+typedef struct dliom_inserter dliom_inserter;
 
 const char* dliom_status_string(int status);
 /* Text of the last HIP failure on the calling thread ("" if none). */
@@ -94,6 +95,27 @@ int dliom_grid_get_values(const dliom_grid* grid, const int32_t* cell_xyz, int64
 int dliom_grid_insert(dliom_grid* grid, const float origin[3], const float* returns_xyz,
                       int64_t num_returns, const uint16_t* hit_table32768,
                       const uint16_t* miss_table32768, int num_free_space_voxels);
+
+/* ---- RangeDataInserter3D object (mapping/3d/range_data_inserter_3d.h:35-47) ---
+ * The constructor builds the hit and miss odds tables once
+ * (range_data_inserter_3d.cc:70-76) and keeps them in HBM. */
+int dliom_inserter_create(dliom_ctx* ctx, double hit_probability, double miss_probability,
+                          int num_free_space_voxels, dliom_inserter** out);
+int dliom_inserter_destroy(dliom_inserter* inserter);
+/* Host copies of hit_table_ / miss_table_ (32768 entries each; either may be NULL). */
+int dliom_inserter_tables(const dliom_inserter* inserter, uint16_t* hit_table32768,
+                          uint16_t* miss_table32768);
+/* RangeDataInserter3D::Insert(RangeData{origin, returns, {}}, grid). */
+int dliom_inserter_insert(const dliom_inserter* inserter, dliom_grid* grid, const float origin[3],
+                          const float* returns_xyz, int64_t num_returns);
+/* Submap3D::InsertRangeData's data path on the device (mapping/3d/submap_3d.cc:264-279):
+ * sensor::TransformRangeData through num_poses (0..2) float poses applied in sequence
+ * (poses7[k] = [tx,ty,tz,qw,qx,qy,qz]; e.g. tracking->local then local->submap), then
+ * FilterRangeDataByMaxRange(max_range) when max_range > 0 (submap_3d.cc:42-51), then Insert.
+ * `origin` is given in the cloud's own frame and is transformed the same way. */
+int dliom_inserter_insert_cloud(const dliom_inserter* inserter, dliom_grid* grid,
+                                const float* poses7, int num_poses, const float origin[3],
+                                const dliom_cloud* cloud, float max_range);
 
 /* ---- device-resident point cloud (sensor::PointCloud staged in HBM) ------- */
 int dliom_cloud_create(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud** out);

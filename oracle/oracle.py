@@ -89,6 +89,8 @@ def _declare(L):
     sig("orc_rtcsm3d_window", None, _f64p, C.c_float, _f32p, C.c_int, _i32p, _i32p, _f32p, _f32p)
     sig("orc_rtcsm3d_candidates", C.c_int64, _f64p, C.c_float, _f32p, C.c_int, _f64p, _f32p, _f32p)
     sig("orc_rtcsm3d_match", C.c_float, _f64p, _f64p, _f32p, C.c_int, vp, _f64p, _f32p, _i32p)
+    sig("orc_rtcsm3d_match_range", C.c_float, _f64p, _f64p, _f32p, C.c_int, vp, C.c_int64, C.c_int64,
+        C.POINTER(C.c_int64))
     sig("orc_rtcsm3d_value_sums", None, _f64p, _f64p, _f32p, C.c_int, vp, C.c_int64, C.c_int64, _u64p)
     sig("orc_transform_cell_indices", None, _f32p, _f32p, C.c_int, C.c_float, _i32p)
     sig("orc_interpolated_probability", C.c_double, vp, C.c_double, C.c_double, C.c_double)
@@ -374,6 +376,15 @@ def rtcsm3d_match(opts, init7, pts, grid, want_scores=False):
     s = lib().orc_rtcsm3d_match(_p(o, _f64p), _p(init7, _f64p), _p(pts, _f32p), len(pts), grid.h,
                                 _p(out, _f64p), sp, C.byref(best))
     return dict(score=s, pose=out, best_index=best.value, scores=scores)
+
+
+def rtcsm3d_match_range(opts, init7, pts, grid, first, count):
+    """The reference's candidate loop over [first, first+count) only (cpu_baseline sampling)."""
+    pts = _f32(pts).reshape(-1, 3)
+    best = C.c_int64(-1)
+    s = lib().orc_rtcsm3d_match_range(_p(_opts4(opts), _f64p), _p(_f64(init7), _f64p), _p(pts, _f32p), len(pts),
+                                      grid.h, first, count, C.byref(best))
+    return s, best.value
 
 
 def rtcsm3d_value_sums(opts, init7, pts, grid, first=0, count=-1):

@@ -255,6 +255,33 @@ float orc_rtcsm3d_match(const double* opts, const double* init7, const float* pt
   if (best_index != nullptr) *best_index = best;
   return s;
 }
+// The reference's Match loop (rtcsm_3d.cc:40-51) restricted to candidates
+// [first, first+count): per candidate a fresh TransformPointCloud allocation
+// and the sequential float score, exactly as the reference pays for them.
+// Used by bench.py's cpu_baseline leg to time a bounded sample.  Returns the
+// best score of the range and its index.
+float orc_rtcsm3d_match_range(const double* opts, const double* init7, const float* pts, int n,
+                              void* grid, int64_t first, int64_t count, int64_t* best_index) {
+  const RealTimeCorrelativeScanMatcher3D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  const PointCloud cloud = ToCloud(pts, n);
+  const HybridGrid& g = *G(grid);
+  const std::vector<Rigid3f> ts = m.GenerateExhaustiveSearchTransforms(g.resolution(), cloud);
+  const Rigid3f init = ToRigid(init7).cast<float>();
+  const int64_t end = std::min<int64_t>(first + count, static_cast<int64_t>(ts.size()));
+  float best = -1.f;
+  int64_t best_c = -1;
+  for (int64_t c = first; c < end; ++c) {
+    const Rigid3f candidate = init * ts[c];
+    const float score = m.ScoreCandidate(g, TransformPointCloud(cloud, candidate), ts[c]);
+    if (score > best) {
+      best = score;
+      best_c = c;
+    }
+  }
+  if (best_index != nullptr) *best_index = best_c;
+  return best;
+}
 // Per candidate: sum over points of max(value & 0x7fff, 1) (exact integers),
 // the order-independent quantity the HIP score-volume kernel accumulates.
 // Candidates [first, first+count) only (count<0: all).

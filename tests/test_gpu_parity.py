@@ -392,3 +392,37 @@ def test_front_end_slice_equals_oracle(dl, ctx, orc):
     assert dt <= 1e-6 and da <= 1e-6
     for g in (dg_hi, dg_lo):
         g.close()
+
+
+def test_inserter_object_and_device_cloud_path(dl, ctx, orc):
+    """dliom_inserter_* (tables resident in HBM) and the transform+filter+insert device path of
+    Submap3D::InsertRangeData against the oracle's TransformRangeData / FilterRangeDataByMaxRange
+    / Insert chain."""
+    from dliom import synth
+    res, free, max_range = 0.1, 2, 20.0
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, free, ctx=ctx)
+    assert np.array_equal(ins.hit_table, orc.lookup_table_to_apply_odds(orc.odds(HIT_P)))
+    og, dg, dg2 = orc.HybridGrid(res), dl.HybridGrid(ctx, res), dl.HybridGrid(ctx, res)
+    for s in range(3):
+        truth = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(truth, 32, 256)
+        pose_f = truth.astype(np.float32)
+        submap_inv = synth.pose_inverse(synth.trajectory_pose(0.0)).astype(np.float32)
+        # oracle: two sequential float transforms, then the range filter, then Insert
+        local = orc.transform_points(pose_f, pts)
+        sub = orc.transform_points(submap_inv, local)
+        origin = orc.transform_points(submap_inv, orc.transform_points(pose_f, np.zeros((1, 3), np.float32)))[0]
+        d = (sub - origin).astype(np.float32)
+        nrm = np.sqrt(d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]), dtype=np.float32)
+        kept = sub[nrm <= np.float32(max_range)]
+        og.insert_tables(origin, kept, ins.hit_table, ins.miss_table, free)
+        ins.Insert(origin, kept, dg)
+        cloud = dl.PointCloud(ctx, pts)
+        ins.InsertCloud(dg2, cloud, poses=[pose_f, submap_inv], origin=(0, 0, 0), max_range=max_range)
+        cloud.close()
+    want = oracle_cells_dict(og)
+    assert dg.cells() == want
+    assert dg2.cells() == want
+    for g in (dg, dg2):
+        g.close()
+    ins.close()
