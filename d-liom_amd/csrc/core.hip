@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <hipcub/hipcub.hpp>
+
 #include "internal.h"
 
 namespace dliom {
@@ -71,11 +73,54 @@ __global__ void aos_to_soa_kernel(const float* __restrict__ aos, int64_t n, int6
   z[i] = in ? aos[3 * i + 2] : 0.f;
 }
 
-static int64_t pad_points(int64_t n) { return ((n + 1023) / 1024) * 1024; }
+static int64_t pad_points(int64_t n) { return ((n + 4095) / 4096) * 4096; }
 
-// Device layout of a cloud inside one allocation: [aos staging | x | y | z].
+// 30-bit Morton code of the point quantised to 1/8 m (exact power of two), clamped to +-64 m.
+// Only used to ORDER points so that neighbouring lanes of a wave look up neighbouring voxels;
+// results never depend on it.
+__device__ __forceinline__ unsigned spread3(unsigned v) {
+  v &= 0x3FFu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ void morton_keys_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                   const float* __restrict__ z, int64_t n, unsigned* __restrict__ keys,
+                                   unsigned* __restrict__ idx) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto q = [](float v) {
+    const float c = fminf(fmaxf(v * 8.f + 512.f, 0.f), 1023.f);
+    return static_cast<unsigned>(c);
+  };
+  keys[i] = spread3(q(x[i])) | (spread3(q(y[i])) << 1) | (spread3(q(z[i])) << 2);
+  idx[i] = static_cast<unsigned>(i);
+}
+__global__ void gather_sorted_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                     const float* __restrict__ z, const unsigned* __restrict__ idx,
+                                     int64_t n, int64_t n_padded, float* __restrict__ xs,
+                                     float* __restrict__ ys, float* __restrict__ zs) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_padded) return;
+  if (i < n) {
+    const unsigned j = idx[i];
+    xs[i] = x[j];
+    ys[i] = y[j];
+    zs[i] = z[j];
+  } else {
+    xs[i] = kPadCoordinate;  // outside every grid: reads value 0 (score kernel contract)
+    ys[i] = kPadCoordinate;
+    zs[i] = kPadCoordinate;
+  }
+}
+
+// Device layout of a cloud inside one allocation:
+//   [aos staging | x y z (input order) | xs ys zs (Morton order) | keys, idx (in/out) ]
 static size_t cloud_bytes(int64_t n) {
-  return static_cast<size_t>(n) * 12 + static_cast<size_t>(pad_points(n)) * 12 + 1024;
+  const size_t np = static_cast<size_t>(pad_points(n));
+  return static_cast<size_t>(n) * 12 + 256 + np * 12 * 2 + np * 4 * 4 + 1024;
 }
 
 static int fill_cloud(dliom_ctx* ctx, char* base, const float* points_xyz, int64_t n,
@@ -86,6 +131,13 @@ static int fill_cloud(dliom_ctx* ctx, char* base, const float* points_xyz, int64
   float* x = reinterpret_cast<float*>(base + soa_off);
   float* y = x + np;
   float* z = y + np;
+  float* xs = z + np;
+  float* ys = xs + np;
+  float* zs = ys + np;
+  unsigned* keys_in = reinterpret_cast<unsigned*>(zs + np);
+  unsigned* keys_out = keys_in + np;
+  unsigned* idx_in = keys_out + np;
+  unsigned* idx_out = idx_in + np;
   if (n > 0) {
     DLIOM_HIP_TRY(hipMemcpyAsync(aos, points_xyz, static_cast<size_t>(n) * 12,
                                  hipMemcpyHostToDevice, ctx->stream));
@@ -95,6 +147,18 @@ static int fill_cloud(dliom_ctx* ctx, char* base, const float* points_xyz, int64
     const unsigned blocks = static_cast<unsigned>((np + threads - 1) / threads);
     hipLaunchKernelGGL(aos_to_soa_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, aos, n, np, x,
                        y, z);
+    hipLaunchKernelGGL(morton_keys_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, x, y, z, n,
+                       keys_in, idx_in);
+    DLIOM_HIP_TRY(hipGetLastError());
+    size_t temp_bytes = 0;
+    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, idx_in,
+                                                     idx_out, static_cast<int>(n), 0, 30, ctx->stream));
+    DLIOM_TRY(ctx->sort_tmp.reserve(temp_bytes));
+    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, temp_bytes, keys_in, keys_out,
+                                                     idx_in, idx_out, static_cast<int>(n), 0, 30,
+                                                     ctx->stream));
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, x, y, z,
+                       idx_out, n, np, xs, ys, zs);
     DLIOM_HIP_TRY(hipGetLastError());
   }
   out->ctx = ctx;
@@ -103,6 +167,9 @@ static int fill_cloud(dliom_ctx* ctx, char* base, const float* points_xyz, int64
   out->d_x = x;
   out->d_y = y;
   out->d_z = z;
+  out->d_xs = xs;
+  out->d_ys = ys;
+  out->d_zs = zs;
   out->max_norm = cloud_max_norm(points_xyz, n);
   return DLIOM_OK;
 }
@@ -241,6 +308,7 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   ctx->rescore.release();
   ctx->partials.release();
   ctx->misc.release();
+  ctx->sort_tmp.release();
   if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -192,26 +192,32 @@ __global__ __launch_bounds__(kCsmBlock) void csm_eval_kernel(CsmArgs a, float k_
       acc[27] += r * r;
     }
   }
-  __shared__ double red[kCsmBlock];
-  for (int k = 0; k < kAcc; ++k) {
-    red[threadIdx.x] = acc[k];
-    __syncthreads();
-    for (int off = kCsmBlock / 2; off > 0; off >>= 1) {
-      if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) partials[blockIdx.x * kAcc + k] = red[0];
-    __syncthreads();
+  // Block reduction in a fixed order: all 28 x 256 partials go to LDS once, then wave w folds
+  // values w, w+4, ... (4 LDS reads per lane + a 6-step butterfly), lane 0 writes the result.
+  __shared__ double red[kAcc][kCsmBlock];
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < kAcc; k += kCsmBlock / 64) {
+    double v = (red[k][lane] + red[k][lane + 64]) + (red[k][lane + 128] + red[k][lane + 192]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) partials[blockIdx.x * kAcc + k] = v;
   }
 }
 
+// One wave per accumulated quantity: lane l sums blocks l, l+64, ... then a fixed butterfly --
+// the summation order never changes from run to run.
 __global__ void csm_final_reduce_kernel(const double* __restrict__ partials, int num_blocks,
                                         double* __restrict__ out) {
-  const int k = threadIdx.x;
-  if (k >= kAcc) return;
+  const int k = blockIdx.x;
+  const int lane = threadIdx.x;
   double s = 0.;
-  for (int b = 0; b < num_blocks; ++b) s += partials[b * kAcc + k];
-  out[k] = s;
+  for (int b = lane; b < num_blocks; b += 64) s += partials[b * kAcc + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) out[k] = s;
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -290,7 +296,7 @@ static int evaluate(CsmProblem* p, const double x[7], Normal* out) {
   const int span = ctx->begin_span(DLIOM_KERNEL_CSM_EVAL);
   hipLaunchKernelGGL(csm_eval_kernel, dim3(p->num_blocks), dim3(kCsmBlock), 0, ctx->stream, a, k_scale,
                      k_offset, kMin, p->d_partials);
-  hipLaunchKernelGGL(csm_final_reduce_kernel, dim3(1), dim3(64), 0, ctx->stream, p->d_partials,
+  hipLaunchKernelGGL(csm_final_reduce_kernel, dim3(kAcc), dim3(64), 0, ctx->stream, p->d_partials,
                      p->num_blocks, p->d_out);
   ctx->end_span(span);
   DLIOM_HIP_TRY(hipGetLastError());
@@ -544,9 +550,9 @@ static int setup_problem(dliom_ctx* ctx, const dliom_csm_options* o, const doubl
     if (clouds[i]->n <= 0) return DLIOM_ERR_EMPTY_CLOUD;
     CsmCloudArg& c = p->args.cloud[i];
     c.g = grids[i]->view();
-    c.x = clouds[i]->d_x;
-    c.y = clouds[i]->d_y;
-    c.z = clouds[i]->d_z;
+    c.x = clouds[i]->d_xs;  // Morton order: neighbouring lanes read neighbouring voxels; the
+    c.y = clouds[i]->d_ys;  // reduction order is still fixed, so results stay reproducible
+    c.z = clouds[i]->d_zs;
     c.n = static_cast<int>(clouds[i]->n);
     c.scale = o->occupied_space_weight[i] / std::sqrt(static_cast<double>(clouds[i]->n));
     total += c.n;
@@ -555,7 +561,7 @@ static int setup_problem(dliom_ctx* ctx, const dliom_csm_options* o, const doubl
   p->args.total_points = total;
   for (int i = 0; i < 3; ++i) p->target_t[i] = target_t[i];
   for (int i = 0; i < 4; ++i) p->init_q[i] = init7[3 + i];
-  p->num_blocks = std::max(1, std::min(1024, (total + kCsmBlock - 1) / kCsmBlock));
+  p->num_blocks = std::max(1, std::min(512, (total + 2 * kCsmBlock - 1) / (2 * kCsmBlock)));
   DLIOM_TRY(ctx->partials.reserve(static_cast<size_t>(p->num_blocks + 1) * kAcc * sizeof(double)));
   p->d_partials = ctx->partials.as<double>();
   p->d_out = p->d_partials + static_cast<size_t>(p->num_blocks) * kAcc;

@@ -69,6 +69,35 @@ __device__ __forceinline__ unsigned grid_value(const GridView& g, int ix, int iy
   return g.pool[static_cast<size_t>(slot) * 512u + cell];
 }
 
+// Fast voxel index for the score-volume kernel: k = rint(p * (1/res)) whenever that provably
+// equals lround(p / res), else *near is set and the caller recomputes with cell_of().
+//   y = fl(p * fl(1/res)) differs from the real quotient q by <= |q| 2^-23; the reference's
+//   decision lround(fl(q)) can flip only when q is within |q| 2^-24 of a half-integer.  So if y is
+//   farther than 2.5e-7 |y| (> 1.5 * 2^-23 |y|) from every half-integer, y and q round to the same
+//   integer -- and then round-half-even (v_rndne) and round-half-away agree as well.
+__device__ __forceinline__ int cell_fast(float p, float inv_resolution, bool* near) {
+  const float y = p * inv_resolution;
+  const float fr = __builtin_amdgcn_fractf(y);
+  *near |= fabsf(fr - 0.5f) <= fabsf(y) * 2.5e-7f;
+  return __float2int_rn(y);
+}
+
+// grid_value() with shift/or index math and 32-bit byte offsets (pool <= 4 GiB, table <= 4 GiB).
+__device__ __forceinline__ unsigned grid_value_fast(const GridView& g, int ix, int iy, int iz) {
+  const unsigned sx = static_cast<unsigned>(ix + g.half);
+  const unsigned sy = static_cast<unsigned>(iy + g.half);
+  const unsigned sz = static_cast<unsigned>(iz + g.half);
+  const bool inside = (sx | sy | sz) < g.grid_size;  // grid_size is a power of two
+  const unsigned lb = static_cast<unsigned>(g.log2_leaves);
+  unsigned tidx = (((sz >> 3) << lb | (sy >> 3)) << lb) | (sx >> 3);
+  tidx = inside ? tidx : 0u;
+  unsigned slot = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(g.table) + (tidx << 2));
+  slot = inside ? slot : 0u;
+  const unsigned cell = ((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u);
+  const unsigned off = (slot << 10) | (cell << 1);
+  return *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.pool) + off);
+}
+
 // Sum over the 64 lanes of a wavefront; the total lands in lane 63.
 // quad swaps, half-row mirror, row mirror, then the two row broadcasts --
 // six DPP adds, no LDS traffic.

@@ -272,12 +272,16 @@ GridView dliom_grid::view() const {
   v.leaves_per_axis = 8 << bits;
   v.grid_size = 64u << bits;
   v.resolution = resolution;
+  v.inv_resolution = 1.f / resolution;
+  v.log2_leaves = bits + 3;
   return v;
 }
 
+// L^3 leaf slots plus one trailing sentinel entry that is always 0: kernels send out-of-extent
+// lookups there and read the null leaf without a second select.
 static size_t table_entries(int bits) {
   const size_t L = static_cast<size_t>(8) << bits;
-  return L * L * L;
+  return L * L * L + 1;
 }
 
 int dliom_grid::refresh_count(int64_t* count) {
@@ -319,6 +323,9 @@ int dliom_grid::ensure_capacity(int64_t additional_slots) {
   if (count + additional_slots <= capacity) return DLIOM_OK;
   int64_t new_cap = std::max<int64_t>(capacity * 2, count + additional_slots);
   new_cap = std::max<int64_t>(new_cap, 4096);
+  // the score kernel addresses the pool with 32-bit byte offsets: <= 4 Mi leaves (4 GiB)
+  new_cap = std::min<int64_t>(new_cap, int64_t{1} << 22);
+  if (count + additional_slots > new_cap) return DLIOM_ERR_GRID_EXTENT;
   uint16_t* new_pool = nullptr;
   int32_t* new_coord = nullptr;
   DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&new_pool), static_cast<size_t>(new_cap) * 1024));
@@ -381,7 +388,8 @@ int dliom_grid_create(dliom_ctx* ctx, float resolution, dliom_grid** out) {
 
 int dliom_grid_destroy(dliom_grid* g) {
   if (g == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
-  if (g->ctx != nullptr) (void)hipStreamSynchronize(g->ctx->stream);
+  // Objects may be torn down in any order (e.g. at interpreter exit): do not touch g->ctx.
+  (void)hipDeviceSynchronize();
   if (g->d_table) (void)hipFree(g->d_table);
   if (g->d_pool) (void)hipFree(g->d_pool);
   if (g->d_slot_coord) (void)hipFree(g->d_slot_coord);

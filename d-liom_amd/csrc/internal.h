@@ -51,6 +51,8 @@ struct GridView {
   int leaves_per_axis;    // 8 << bits
   unsigned grid_size;     // 64 << bits (voxels)
   float resolution;
+  float inv_resolution;   // fl(1 / resolution): fast path of the score kernel only
+  int log2_leaves;        // log2(leaves_per_axis) = bits + 3
 };
 
 }  // namespace dliom
@@ -67,6 +69,7 @@ struct dliom_ctx {
   dliom::DevBuf rescore;    // per-survivor per-point probabilities
   dliom::DevBuf partials;   // CSM per-block partial sums
   dliom::DevBuf misc;       // small odds and ends (probe outputs, cell lists)
+  dliom::DevBuf sort_tmp;   // radix-sort temporary storage (cloud staging)
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
   // profiling
@@ -105,10 +108,13 @@ struct dliom_grid {
 struct dliom_cloud {
   dliom_ctx* ctx = nullptr;
   int64_t n = 0;
-  int64_t n_padded = 0;    // multiple of 1024; pad lanes are flagged invalid by index
+  int64_t n_padded = 0;    // multiple of 4096
   float* d_x = nullptr;    // SoA in HBM
   float* d_y = nullptr;
   float* d_z = nullptr;
+  float* d_xs = nullptr;   // the same points in Morton order (order-independent kernels only)
+  float* d_ys = nullptr;
+  float* d_zs = nullptr;
   float max_norm = 0.f;    // max_i ||p_i|| (float, Eigen order), host computed
   bool owned_by_ctx_scratch = false;
 };
@@ -121,6 +127,8 @@ struct dliom_inserter {
 };
 
 namespace dliom {
+// Coordinate of the padding points of the Morton-ordered arrays: far outside any grid extent.
+constexpr float kPadCoordinate = 1.0e7f;  // cell index ~1e7/res: no int overflow for res >= 0.005 m
 // host-pointer cloud staged in ctx->points (valid until the next staging call)
 int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud* out,
                 size_t scratch_offset_bytes = 0);

@@ -16,6 +16,7 @@
 //          strictly greater score in generation order wins.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -25,64 +26,84 @@
 namespace dliom {
 
 constexpr int kBlock = 256;
-constexpr int kTC = 27;  // translations accumulated per register chunk
 
 // ---------------------------------------------------------------------------------- kernel A
-// grid = (point tiles, rotation tiles).  Each thread keeps PPT points in registers, the wave
-// walks the block's rotations (uniform -> scalar loads), and for every rotation accumulates the
-// TC translation candidates in registers before one DPP reduction + one atomic per candidate.
-template <int PPT, int TC>
+// grid = (point tiles, rotation tiles), 256 threads.  Every thread keeps PPT points of its tile
+// in registers (Morton order: the 64 lanes of a wave sit in one small patch of space).  A block
+// walks its rotations; for each one it rotates its points once, then walks the T translations
+// (uniform -> three scalar loads per translation) and looks up PPT voxels per lane in two
+// batches of independent gathers (PPT leaf-table loads, then PPT voxel loads).  The per-lane
+// integer sum is reduced across the wave with six DPP adds, combined across the block's four
+// waves in LDS, and leaves the block as ONE atomic per candidate per rotation.
+template <int PPT>
 __global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
     GridView g, const float* __restrict__ px, const float* __restrict__ py,
-    const float* __restrict__ pz, int n, const float4* __restrict__ rot, int R,
+    const float* __restrict__ pz, const float4* __restrict__ rot, int R,
     const float* __restrict__ trans, int T, int rots_per_block,
-    unsigned long long* __restrict__ sums) {
+    unsigned long long* __restrict__ sums, int debug_no_atomic) {
+  // Clouds are padded to a multiple of 4096 points with far-away points (kPadCoordinate): those
+  // fall outside every grid, read 0 and add exactly 1 each -- the host subtracts the pad count.
+  extern __shared__ unsigned block_sum[];  // T entries
   float x[PPT], y[PPT], z[PPT];
-  unsigned valid[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int i = (blockIdx.x * PPT + k) * kBlock + threadIdx.x;
-    valid[k] = i < n ? 1u : 0u;
-    x[k] = px[i];  // clouds are padded to a multiple of 1024 points
+    x[k] = px[i];
     y[k] = py[i];
     z[k] = pz[i];
   }
   const int r_begin = blockIdx.y * rots_per_block;
   const int r_end = min(r_begin + rots_per_block, R);
   const int lane = threadIdx.x & 63;
+  const float inv = g.inv_resolution;
+  const unsigned sentinel = 1u << (3 * g.log2_leaves);  // table[L^3] is always 0 (null leaf)
+  const unsigned lb = static_cast<unsigned>(g.log2_leaves);
   for (int r = r_begin; r < r_end; ++r) {
+    for (int j = threadIdx.x; j < T; j += kBlock) block_sum[j] = 0u;
+    __syncthreads();
     const float4 qq = rot[r];
     const Quat4 q{qq.x, qq.y, qq.z, qq.w};  // stored (w,x,y,z)
     float rx[PPT], ry[PPT], rz[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) rotate_point(q, x[k], y[k], z[k], rx[k], ry[k], rz[k]);
-    for (int jc = 0; jc < T; jc += TC) {
-      unsigned acc[TC];
+#pragma unroll 1
+    for (int j = 0; j < T; ++j) {
+      const float tx = trans[3 * j], ty = trans[3 * j + 1], tz = trans[3 * j + 2];
+      unsigned tix[PPT], cel[PPT];
 #pragma unroll
-      for (int jj = 0; jj < TC; ++jj) {
-        const float tx = trans[3 * (jc + jj)];
-        const float ty = trans[3 * (jc + jj) + 1];
-        const float tz = trans[3 * (jc + jj) + 2];
-        unsigned a = 0;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          const int ix = cell_of(rx[k] + tx, g.resolution);
-          const int iy = cell_of(ry[k] + ty, g.resolution);
-          const int iz = cell_of(rz[k] + tz, g.resolution);
-          unsigned v = grid_value(g, ix, iy, iz) & 0x7FFFu;
-          v = max(v, 1u);
-          a += v * valid[k];
+      for (int k = 0; k < PPT; ++k) {
+        const float cx = rx[k] + tx, cy = ry[k] + ty, cz = rz[k] + tz;
+        bool near = false;
+        int ix = cell_fast(cx, inv, &near);
+        int iy = cell_fast(cy, inv, &near);
+        int iz = cell_fast(cz, inv, &near);
+        if (__builtin_expect(near, 0)) {  // within rounding reach of a cell boundary: exact path
+          ix = cell_of(cx, g.resolution);
+          iy = cell_of(cy, g.resolution);
+          iz = cell_of(cz, g.resolution);
         }
-        acc[jj] = a;
+        const unsigned sx = static_cast<unsigned>(ix + g.half);
+        const unsigned sy = static_cast<unsigned>(iy + g.half);
+        const unsigned sz = static_cast<unsigned>(iz + g.half);
+        const bool inside = (sx | sy | sz) < g.grid_size;  // grid_size is a power of two
+        const unsigned t = (((sz >> 3) << lb | (sy >> 3)) << lb) | (sx >> 3);
+        tix[k] = inside ? t : sentinel;
+        cel[k] = ((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u);
       }
 #pragma unroll
-      for (int jj = 0; jj < TC; ++jj) {
-        const unsigned total = wave_sum_lane63(acc[jj]);
-        if (lane == 63 && jc + jj < T) {
-          atomicAdd(&sums[static_cast<size_t>(jc + jj) * R + r],
-                    static_cast<unsigned long long>(total));
-        }
-      }
+      for (int k = 0; k < PPT; ++k) tix[k] = g.table[tix[k]];
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) cel[k] = g.pool[(tix[k] << 9) | cel[k]];
+      unsigned a = 0;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) a += max(cel[k] & 0x7FFFu, 1u);
+      const unsigned total = wave_sum_lane63(a);
+      if (lane == 63) atomicAdd(&block_sum[j], total);
+    }
+    __syncthreads();
+    if (!debug_no_atomic) {
+      for (int j = threadIdx.x; j < T; j += kBlock)
+        atomicAdd(&sums[static_cast<size_t>(j) * R + r], static_cast<unsigned long long>(block_sum[j]));
     }
   }
 }
@@ -94,6 +115,7 @@ struct BoundParams {
   double delta;    // max |LUT[v] - (a v + b)|, v' convention (0 -> 1)
   double wt, wr;   // penalty weights
   int n;           // points
+  int n_pad;       // padding points, each of which added exactly 1 to every sum
   int R, T;
 };
 
@@ -138,7 +160,7 @@ __global__ void rtcsm_bounds_kernel(const unsigned long long* __restrict__ sums,
   const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const int j = static_cast<int>(c / p.R), r = static_cast<int>(c % p.R);
-  const double s = static_cast<double>(sums[c]);
+  const double s = static_cast<double>(sums[c] - static_cast<unsigned long long>(p.n_pad));
   const double mid = p.a * s + p.b * p.n;
   const double slack = p.delta * p.n + 1e-9 * mid;
   double sum_lo = mid - slack, sum_hi = mid + slack;
@@ -182,55 +204,61 @@ __global__ void rtcsm_select_kernel(const float* __restrict__ hi, long long C,
 }
 
 // ---------------------------------------------------------------------------------- kernel C
-// Per survivor k and point i: ValueToProbability(value) as a float, stored candidate-major so
-// that the chain kernel reads 16 contiguous bytes per lane.
-__global__ void rtcsm_rescore_values_kernel(GridView g, const float* __restrict__ px,
-                                            const float* __restrict__ py,
-                                            const float* __restrict__ pz, int n, int n_stride,
-                                            const float4* __restrict__ rot, int R,
-                                            const float* __restrict__ trans,
-                                            const unsigned* __restrict__ list, float k_scale,
-                                            float k_offset, float k_unknown,
-                                            float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned c = list[blockIdx.y];
-  if (i >= n_stride) return;
-  float prob = 0.f;  // +0.f padding leaves a float running sum unchanged
-  if (i < n) {
-    const int j = static_cast<int>(c / static_cast<unsigned>(R));
-    const int r = static_cast<int>(c % static_cast<unsigned>(R));
-    const float4 qq = rot[r];
-    const Quat4 q{qq.x, qq.y, qq.z, qq.w};
-    float rx, ry, rz;
-    rotate_point(q, px[i], py[i], pz[i], rx, ry, rz);
-    const int ix = cell_of(rx + trans[3 * j], g.resolution);
-    const int iy = cell_of(ry + trans[3 * j + 1], g.resolution);
-    const int iz = cell_of(rz + trans[3 * j + 2], g.resolution);
-    const unsigned v = grid_value(g, ix, iy, iz) & 0x7FFFu;
-    // probability_values.cc:27-36: value * kScale + (lower_bound - kScale); 0 -> kMinProbability
-    prob = v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset;
-  }
-  out[static_cast<size_t>(blockIdx.y) * n_stride + i] = prob;
-}
-
-// The reference's `score += probability` loop (rtcsm_3d.cc:101-104): strictly sequential float
-// additions in point order, one lane per surviving candidate.
-__global__ void rtcsm_chain_kernel(const float* __restrict__ probs, int n_stride, unsigned K,
-                                   float* __restrict__ sums) {
-  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  const float4* row = reinterpret_cast<const float4*>(probs + static_cast<size_t>(k) * n_stride);
+// One workgroup per surviving candidate.  Waves 1-3 turn tiles of points (INPUT order) into
+// probabilities in LDS -- ValueToProbability(value) as probability_values.cc:27-36 computes it:
+// value * kScale + (kMin - kScale), 0 -> kMin -- while lane 0 of wave 0 replays the reference's
+// `score += probability` loop (rtcsm_3d.cc:101-104) over the previous tile: strictly sequential
+// float additions in point order, so the sum is bit-identical to the reference's.
+constexpr int kChainTile = 2048;
+__global__ __launch_bounds__(256) void rtcsm_rescore_kernel(
+    GridView g, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, int n, const float4* __restrict__ rot, int R,
+    const float* __restrict__ trans, const unsigned* __restrict__ list, float k_scale, float k_offset,
+    float k_unknown, float* __restrict__ sums) {
+  __shared__ float4 tile[2][kChainTile / 4];
+  const unsigned c = list[blockIdx.x];
+  const int j = static_cast<int>(c / static_cast<unsigned>(R));
+  const int r = static_cast<int>(c % static_cast<unsigned>(R));
+  const float4 qq = rot[r];
+  const Quat4 q{qq.x, qq.y, qq.z, qq.w};
+  const float tx = trans[3 * j], ty = trans[3 * j + 1], tz = trans[3 * j + 2];
+  const int num_tiles = (n + kChainTile - 1) / kChainTile;
+  const int producer = static_cast<int>(threadIdx.x) - 64;  // waves 1..3
+  auto produce = [&](int t) {
+    if (producer < 0) return;
+    float* dst = reinterpret_cast<float*>(tile[t & 1]);
+    for (int k = producer; k < kChainTile; k += 192) {
+      const int i = t * kChainTile + k;
+      float prob = 0.f;  // +0.f padding leaves a float running sum unchanged
+      if (i < n) {
+        float rx, ry, rz;
+        rotate_point(q, px[i], py[i], pz[i], rx, ry, rz);
+        const unsigned v = grid_value(g, cell_of(rx + tx, g.resolution), cell_of(ry + ty, g.resolution),
+                                      cell_of(rz + tz, g.resolution)) & 0x7FFFu;
+        prob = v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset;
+      }
+      dst[k] = prob;
+    }
+  };
   float s = 0.f;
-  const int n4 = n_stride >> 2;
-#pragma unroll 4
-  for (int i = 0; i < n4; ++i) {
-    const float4 v = row[i];
-    s += v.x;
-    s += v.y;
-    s += v.z;
-    s += v.w;
+  produce(0);
+  __syncthreads();
+  for (int t = 0; t < num_tiles; ++t) {
+    if (t + 1 < num_tiles) produce(t + 1);
+    if (threadIdx.x == 0) {
+      const float4* src = tile[t & 1];
+#pragma unroll 8
+      for (int k = 0; k < kChainTile / 4; ++k) {
+        const float4 v = src[k];
+        s += v.x;
+        s += v.y;
+        s += v.z;
+        s += v.w;
+      }
+    }
+    __syncthreads();
   }
-  sums[k] = s;
+  if (threadIdx.x == 0) sums[blockIdx.x] = s;
 }
 
 // ---------------------------------------------------------------------------------- probes
@@ -311,14 +339,14 @@ static void generate_candidates(const dliom_rtcsm_options& o, float resolution, 
 // Device copies of the candidate tables inside ctx->cand.
 struct DeviceCandidates {
   float4* rot;
-  float* trans;    // padded to a multiple of kTC entries
+  float* trans;    // T x 3
   float* t_norm;
   float* r_angle;
 };
 
 static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidates* d) {
   const size_t R = c.rot.size(), T = c.trans.size();
-  const size_t Tpad = ((T + kTC - 1) / kTC) * kTC;
+  const size_t Tpad = T;
   const size_t bytes_rot = (R * 16 + 255) & ~static_cast<size_t>(255);
   const size_t bytes_trans = (Tpad * 12 + 255) & ~static_cast<size_t>(255);
   const size_t bytes_tn = (T * 4 + 255) & ~static_cast<size_t>(255);
@@ -359,29 +387,16 @@ static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidat
   return DLIOM_OK;
 }
 
-template <int PPT>
-static void launch_score(dliom_ctx* ctx, const GridView& g, const dliom_cloud& cloud,
-                         const DeviceCandidates& d, int R, int T, unsigned long long* sums) {
-  const int n = static_cast<int>(cloud.n);
-  const int tile = kBlock * PPT;
-  const int point_tiles = (n + tile - 1) / tile;
-  // aim for >= ~4096 workgroups so every CU holds several waves, without making the per-block
-  // rotation loop shorter than one rotation
-  int rot_tiles = std::max(1, std::min(R, (4096 + point_tiles - 1) / point_tiles));
-  const int rots_per_block = (R + rot_tiles - 1) / rot_tiles;
-  rot_tiles = (R + rots_per_block - 1) / rots_per_block;
-  const dim3 grid(point_tiles, rot_tiles), block(kBlock);
-  if (T == 1) {
-    hipLaunchKernelGGL((rtcsm_score_kernel<PPT, 1>), grid, block, 0, ctx->stream, g, cloud.d_x,
-                       cloud.d_y, cloud.d_z, n, d.rot, R, d.trans, T, rots_per_block, sums);
-  } else {
-    hipLaunchKernelGGL((rtcsm_score_kernel<PPT, kTC>), grid, block, 0, ctx->stream, g, cloud.d_x,
-                       cloud.d_y, cloud.d_z, n, d.rot, R, d.trans, T, rots_per_block, sums);
-  }
+static int env_int(const char* name, int fallback) {
+  const char* e = std::getenv(name);
+  return e != nullptr ? std::atoi(e) : fallback;
 }
 
+// Launches the score-volume kernel; *pad_processed = padding points visited (each adds 1 to
+// every sum).
 static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid,
-                            const Candidates& c, DeviceCandidates* d, unsigned long long** d_sums) {
+                            const Candidates& c, DeviceCandidates* d, unsigned long long** d_sums,
+                            int64_t* pad_processed) {
   DLIOM_TRY(upload_candidates(ctx, c, d));
   const int64_t C = c.w.num_candidates;
   DLIOM_TRY(ctx->sums.reserve(static_cast<size_t>(C) * 8));
@@ -389,14 +404,37 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   DLIOM_HIP_TRY(hipMemsetAsync(*d_sums, 0, static_cast<size_t>(C) * 8, ctx->stream));
   const GridView g = grid->view();
   const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
+  const int n = static_cast<int>(cloud.n);
+  // points per thread (registers) x rotation tiles: keep a few thousand workgroups in flight
+  static const int forced_ppt = env_int("DLIOM_SCORE_PPT", 0);  // tuning knobs
+  static const int target_blocks = env_int("DLIOM_SCORE_BLOCKS", 4096);
+  static const int debug_no_atomic = env_int("DLIOM_DEBUG_NO_ATOMIC", 0);
+  int ppt = forced_ppt > 0 ? forced_ppt : (n >= 32 * 1024 ? 8 : (n >= 8 * 1024 ? 4 : (n >= 2048 ? 2 : 1)));
+  while (ppt > 1 && (cloud.n_padded % (static_cast<int64_t>(kBlock) * ppt)) != 0) ppt >>= 1;
+  const int tile = kBlock * ppt;
+  const int point_tiles = (n + tile - 1) / tile;
+  int rot_tiles = std::max(1, std::min(R, (target_blocks + point_tiles - 1) / point_tiles));
+  const int rots_per_block = (R + rot_tiles - 1) / rot_tiles;
+  rot_tiles = (R + rots_per_block - 1) / rots_per_block;
+  const dim3 grid_dim(point_tiles, rot_tiles), block(kBlock);
+  const size_t lds = static_cast<size_t>(T) * sizeof(unsigned);
+  if (lds > 150 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;  // (2L+1)^3 translations must fit LDS
   const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
-  if (cloud.n >= 4 * 1024) {
-    launch_score<4>(ctx, g, cloud, *d, R, T, *d_sums);
-  } else {
-    launch_score<1>(ctx, g, cloud, *d, R, T, *d_sums);
+#define DLIOM_LAUNCH_SCORE(P)                                                                    \
+  hipLaunchKernelGGL((rtcsm_score_kernel<P>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,  \
+                     cloud.d_ys, cloud.d_zs, d->rot, R, d->trans, T, rots_per_block, *d_sums,    \
+                     debug_no_atomic)
+  switch (ppt) {
+    case 16: DLIOM_LAUNCH_SCORE(16); break;
+    case 8: DLIOM_LAUNCH_SCORE(8); break;
+    case 4: DLIOM_LAUNCH_SCORE(4); break;
+    case 2: DLIOM_LAUNCH_SCORE(2); break;
+    default: DLIOM_LAUNCH_SCORE(1); break;
   }
+#undef DLIOM_LAUNCH_SCORE
   ctx->end_span(span);
   DLIOM_HIP_TRY(hipGetLastError());
+  *pad_processed = static_cast<int64_t>(point_tiles) * tile - n;
   return DLIOM_OK;
 }
 
@@ -438,7 +476,8 @@ static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double
 
   DeviceCandidates d;
   unsigned long long* d_sums = nullptr;
-  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, &d, &d_sums));
+  int64_t pad_processed = 0;
+  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, &d, &d_sums, &pad_processed));
 
   // ---- bounds + selection
   const size_t bytes_f = (static_cast<size_t>(C) * 4 + 255) & ~static_cast<size_t>(255);
@@ -457,6 +496,7 @@ static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double
   bp.wt = o->translation_delta_cost_weight;
   bp.wr = o->rotation_delta_cost_weight;
   bp.n = static_cast<int>(cloud.n);
+  bp.n_pad = static_cast<int>(pad_processed);
   bp.R = R;
   bp.T = T;
   const unsigned cblocks = static_cast<unsigned>((C + 255) / 256);
@@ -473,28 +513,14 @@ static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double
   const unsigned K = ctrs[1];
   if (K == 0) return DLIOM_ERR_SCORE_NOT_POSITIVE;  // cannot happen: the best-lo candidate survives
 
-  // ---- exact sequential rescoring of the survivors (batched: <= 1 GiB of probabilities and
-  //      <= 65535 rows per launch)
+  // ---- exact sequential rescoring of the survivors: one workgroup each
   const int n = static_cast<int>(cloud.n);
-  const int n_stride = (n + 3) & ~3;
-  const size_t row_bytes = static_cast<size_t>(n_stride) * 4;
-  unsigned batch = static_cast<unsigned>(std::min<size_t>(65535, std::max<size_t>(64, (size_t{1} << 30) / row_bytes)));
-  batch = std::min(batch, K);
-  const size_t bytes_probs = static_cast<size_t>(batch) * row_bytes;
-  const size_t bytes_ks = (static_cast<size_t>(K) * 4 + 255) & ~static_cast<size_t>(255);
-  DLIOM_TRY(ctx->rescore.reserve(bytes_probs + bytes_ks));
-  float* d_probs = ctx->rescore.as<float>();
-  float* d_ksums = reinterpret_cast<float*>(static_cast<char*>(ctx->rescore.p) + bytes_probs);
+  DLIOM_TRY(ctx->rescore.reserve(static_cast<size_t>(K) * 4));
+  float* d_ksums = ctx->rescore.as<float>();
   span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
-  for (unsigned k0 = 0; k0 < K; k0 += batch) {
-    const unsigned kb = std::min(batch, K - k0);
-    const dim3 rgrid((n_stride + 255) / 256, kb);
-    hipLaunchKernelGGL(rtcsm_rescore_values_kernel, rgrid, dim3(256), 0, ctx->stream, grid->view(),
-                       cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, d.rot, R, d.trans, d_list + k0,
-                       lm.k_scale, lm.k_offset, lm.k_unknown, d_probs);
-    hipLaunchKernelGGL(rtcsm_chain_kernel, dim3((kb + 63) / 64), dim3(64), 0, ctx->stream, d_probs,
-                       n_stride, kb, d_ksums + k0);
-  }
+  hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(K), dim3(256), 0, ctx->stream, grid->view(), cloud.d_x,
+                     cloud.d_y, cloud.d_z, n, d.rot, R, d.trans, d_list, lm.k_scale, lm.k_offset,
+                     lm.k_unknown, d_ksums);
   ctx->end_span(span);
   DLIOM_HIP_TRY(hipGetLastError());
   std::vector<unsigned> list(K);
@@ -599,10 +625,13 @@ int dliom_rtcsm3d_score_volume(dliom_ctx* ctx, const dliom_rtcsm_options* o, con
   if (capacity < c.w.num_candidates) return DLIOM_ERR_CAPACITY;
   DeviceCandidates d;
   unsigned long long* d_sums = nullptr;
-  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, &d, &d_sums));
+  int64_t pad_processed = 0;
+  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, &d, &d_sums, &pad_processed));
   DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_sums, static_cast<size_t>(c.w.num_candidates) * 8,
                                hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const uint64_t n_pad = static_cast<uint64_t>(pad_processed);
+  for (int64_t i = 0; i < c.w.num_candidates; ++i) sums[i] -= n_pad;
   return DLIOM_OK;
 }
 
