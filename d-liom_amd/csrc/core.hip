@@ -365,6 +365,8 @@ static inline float value_to_probability(int v) {
 
 float dliom_odds(float probability) { return probability / (1.f - probability); }
 
+uint16_t dliom_probability_to_value(float probability) { return probability_to_value(probability); }
+
 int dliom_compute_lookup_table_to_apply_odds(float odds, uint16_t* t) {
   if (t == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   t[0] = static_cast<uint16_t>(probability_to_value(odds / (odds + 1.f)) + 32768u);

@@ -214,6 +214,24 @@ __global__ void upload_copy_kernel(const int32_t* __restrict__ origins,
     pool[slot * 512u + k] = values[static_cast<size_t>(b) * 512u + k];
 }
 
+__global__ void set_alloc_kernel(const int32_t* __restrict__ cells, int64_t n, uint32_t* table,
+                                 int32_t* slot_coord, uint32_t* count, int half, unsigned gsize,
+                                 unsigned L) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ensure_leaf(table, slot_coord, count, cells[3 * i], cells[3 * i + 1], cells[3 * i + 2], half, gsize, L);
+}
+
+__global__ void set_values_kernel(const int32_t* __restrict__ cells, const uint16_t* __restrict__ values,
+                                  int64_t n, const uint32_t* __restrict__ table, uint16_t* pool, int half,
+                                  unsigned gsize, unsigned L) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned tidx, cell;
+  if (!leaf_table_index(cells[3 * i], cells[3 * i + 1], cells[3 * i + 2], half, gsize, L, &tidx, &cell)) return;
+  pool[static_cast<size_t>(table[tidx]) * 512u + cell] = values[i];
+}
+
 __global__ void get_values_kernel(GridView g, const int32_t* __restrict__ cells, int64_t n,
                                   uint16_t* __restrict__ out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -471,6 +489,37 @@ int dliom_grid_download_blocks(const dliom_grid* g, int32_t* origins, uint16_t* 
                                hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   for (int64_t i = 0; i < 3 * n; ++i) origins[i] *= 8;  // leaf coordinate -> corner voxel index
+  return DLIOM_OK;
+}
+
+int dliom_grid_set_values(dliom_grid* g, const int32_t* cells, const uint16_t* values, int64_t n) {
+  if (g == nullptr || n < 0 || (n > 0 && (cells == nullptr || values == nullptr)))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_OK;
+  dliom_ctx* ctx = g->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  int lo = 0, hi = 0;
+  for (int64_t i = 0; i < 3 * n; ++i) {
+    lo = std::min(lo, cells[i]);
+    hi = std::max(hi, cells[i]);
+  }
+  DLIOM_TRY(g->ensure_bits(needed_bits_for_cell_range(lo, hi)));
+  DLIOM_TRY(g->ensure_capacity(n));
+  const size_t cbytes = (static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->misc.reserve(cbytes + static_cast<size_t>(n) * 2));
+  int32_t* d_cells = ctx->misc.as<int32_t>();
+  uint16_t* d_vals = reinterpret_cast<uint16_t*>(static_cast<char*>(ctx->misc.p) + cbytes);
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_cells, cells, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_vals, values, static_cast<size_t>(n) * 2, hipMemcpyHostToDevice, ctx->stream));
+  const GridView v = g->view();
+  hipLaunchKernelGGL(set_alloc_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_cells, n,
+                     g->d_table, g->d_slot_coord, g->d_count, v.half, v.grid_size,
+                     static_cast<unsigned>(v.leaves_per_axis));
+  hipLaunchKernelGGL(set_values_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream, d_cells, d_vals,
+                     n, g->d_table, g->d_pool, v.half, v.grid_size, static_cast<unsigned>(v.leaves_per_axis));
+  DLIOM_HIP_TRY(hipGetLastError());
+  g->used_upper += n;
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   return DLIOM_OK;
 }
 

@@ -96,6 +96,8 @@ SYMBOLS = [
     ("dliom_ctx_synchronize", C.c_int, [_vp]),
     ("dliom_compute_lookup_table_to_apply_odds", C.c_int, [C.c_float, _u16p]),
     ("dliom_odds", C.c_float, [C.c_float]),
+    ("dliom_probability_to_value", C.c_uint16, [C.c_float]),
+    ("dliom_grid_set_values", C.c_int, [_vp, _i32p, _u16p, C.c_int64]),
     ("dliom_value_to_probability_table", C.c_int, [_f32p]),
     ("dliom_grid_create", C.c_int, [_vp, C.c_float, C.POINTER(_vp)]),
     ("dliom_grid_destroy", C.c_int, [_vp]),
@@ -319,6 +321,15 @@ class HybridGrid:
             for c in nz:
                 out[(int(o[0]) + (c & 7), int(o[1]) + ((c >> 3) & 7), int(o[2]) + (c >> 6))] = int(v[c])
         return out
+
+    def set_values(self, cells_xyz, values):
+        cells = np.ascontiguousarray(cells_xyz, dtype=np.int32).reshape(-1, 3)
+        vals = np.ascontiguousarray(values, dtype=np.uint16)
+        _check(self._L.dliom_grid_set_values(self.h, _p(cells, _i32p), _p(vals, _u16p), len(vals)), "grid_set_values")
+
+    def SetProbability(self, index, probability):
+        """hybrid_grid.h:489-491"""
+        self.set_values([index], [self._L.dliom_probability_to_value(C.c_float(probability))])
 
     def values(self, cells_xyz):
         cells = np.ascontiguousarray(cells_xyz, dtype=np.int32).reshape(-1, 3)

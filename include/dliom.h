@@ -68,6 +68,8 @@ int dliom_ctx_synchronize(dliom_ctx* ctx);
  * (mapping/3d/range_data_inserter_3d.cc:70-76 with odds = Odds(float(p))). */
 int dliom_compute_lookup_table_to_apply_odds(float odds, uint16_t* table32768);
 float dliom_odds(float probability);
+/* ProbabilityToValue (mapping/probability_values.h:91-93). */
+uint16_t dliom_probability_to_value(float probability);
 /* kValueToProbability (probability_values.cc:67-68), 65536 floats. */
 int dliom_value_to_probability_table(float* table65536);
 
@@ -85,6 +87,10 @@ int dliom_grid_num_blocks(const dliom_grid* grid, int64_t* num_blocks);
 /* Allocated leaves in unspecified order; *num_blocks <= capacity. */
 int dliom_grid_download_blocks(const dliom_grid* grid, int32_t* block_origin_xyz,
                                uint16_t* values512, int64_t capacity, int64_t* num_blocks);
+/* *mutable_value(cell) = value for n cells (HybridGrid::SetProbability with
+ * value = ProbabilityToValue(p), hybrid_grid.h:489-491; also how HybridGrid(proto) loads cells,
+ * hybrid_grid.h:475-486).  Grows / allocates like the reference. */
+int dliom_grid_set_values(dliom_grid* grid, const int32_t* cell_xyz, const uint16_t* values, int64_t n);
 /* HybridGrid::value() for n cell indices (0 outside / unallocated). */
 int dliom_grid_get_values(const dliom_grid* grid, const int32_t* cell_xyz, int64_t n,
                           uint16_t* values);

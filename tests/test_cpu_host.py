@@ -75,3 +75,13 @@ def test_argument_checks_without_gpu(dl):
     assert L.dliom_grid_destroy(None) == dl.ERR_INVALID_ARGUMENT
     assert L.dliom_compute_lookup_table_to_apply_odds(C.c_float(1.0), None) == dl.ERR_INVALID_ARGUMENT
     assert L.dliom_status_string(dl.ERR_RAY_TOO_LONG) != b"unknown status"
+
+
+def test_cpp_adapter_header_compiles(dl, tmp_path):
+    """The header-only adapters and their KAT program build with plain g++ against the C ABI."""
+    import subprocess
+    exe = str(tmp_path / "adapter_kat")
+    libdir = os.path.join(ROOT, "d-liom_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "adapter_kat.cc"), "-L", libdir, "-ldliom",
+                           "-Wl,-rpath," + libdir])

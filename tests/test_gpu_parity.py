@@ -426,3 +426,33 @@ def test_inserter_object_and_device_cloud_path(dl, ctx, orc):
     for g in (dg, dg2):
         g.close()
     ins.close()
+
+
+def test_cpp_adapters(dl, ctx, tmp_path):
+    """tests/cpp/adapter_kat.cc: the reference's KATs written against the C++ adapter classes
+    (cartographer names and signatures) linked to libdliom.so with plain g++."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "adapter_kat")
+    libdir = os.path.join(root, "d-liom_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(root, "tests", "cpp", "adapter_kat.cc"),
+                           "-L", libdir, "-ldliom", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL ADAPTER TESTS PASSED" in out.stdout
+
+
+def test_set_values_and_set_probability(dl, ctx, orc):
+    rng = np.random.RandomState(4)
+    og, dg = orc.HybridGrid(0.2), dl.HybridGrid(ctx, 0.2)
+    xyz = rng.randint(-700, 700, size=(5000, 3))
+    vals = rng.randint(1, 32768, size=5000).astype(np.uint16)
+    og.set_values(xyz, vals)
+    dg.set_values(xyz, og.values(xyz))  # last write wins on duplicates: take the oracle's view
+    assert dg.bits == og.bits
+    assert dg.cells() == oracle_cells_dict(og)
+    og.set_probability((3, -2, 900), 0.63)
+    dg.SetProbability((3, -2, 900), 0.63)
+    assert dg.bits == og.bits and dg.cells() == oracle_cells_dict(og)
+    dg.close()

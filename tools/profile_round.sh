@@ -1,0 +1,24 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun).  Produces, under gpurun_out/prof_<tag>/:
+#   kernel-trace + stats CSVs of `bench.py` (same command as the bench line, fewer steps)
+#   PMC passes (FETCH_SIZE / WRITE_SIZE / TCC hit-miss / SQ / TA) over the score kernel
+# Copy the summaries you want judged into profiles/ afterwards (tools/collect_profiles.py).
+set -u
+TAG=${1:-r1}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
+echo "trace rc=$?"
+grep '^{' $OUT/trace.log > $OUT/bench_under_trace.json
+i=0
+for P in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
+         "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+         "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
+  timeout 300 rocprofv3 --pmc $P --kernel-include-regex "rtcsm_score" --output-format csv -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1
+  echo "pmc pass $i rc=$?"
+  i=$((i+1))
+done
+find $OUT -name "*.csv" | head -20
