@@ -71,6 +71,70 @@ inline float rotation_angle(const QF& q) {
   return 2.f * std::atan2(norm3(v), std::abs(q.w));
 }
 
+// ---- double precision rigid transforms (pose bookkeeping around the matchers) ----------------
+// transform/rigid_transform.h:125-219 on Eigen::Quaterniond, SSE2 evaluation order of
+// Eigen/src/Geometry/arch/Geometry_SSE.h (two Packet2d halves), see SURVEY.md App. A.1.
+struct PoseD {
+  double t[3];
+  double q[4];  // w, x, y, z
+};
+inline void qmul_d(const double* a, const double* b, double* r) {  // (w,x,y,z)
+  const double aw = a[0], ax = a[1], ay = a[2], az = a[3];
+  const double bw = b[0], bx = b[1], by = b[2], bz = b[3];
+  const double t1x = aw * bx + ay * bz, t1y = aw * by + ay * bw;
+  const double t2x = az * bx - ax * bz, t2y = az * by - ax * bw;
+  const double u1z = aw * bz - ay * bx, u1w = aw * bw - ay * by;
+  const double u2z = az * bz + ax * bx, u2w = az * bw + ax * by;
+  r[1] = t1x - t2y;
+  r[2] = t1y + t2x;
+  r[3] = u1z + u2w;
+  r[0] = u1w - u2z;
+}
+inline void qnormalize_d(double* q) {
+  const double z2 = (q[1] * q[1] + q[3] * q[3]) + (q[2] * q[2] + q[0] * q[0]);
+  if (z2 > 0.0) {
+    const double n = std::sqrt(z2);
+    q[0] /= n;
+    q[1] /= n;
+    q[2] /= n;
+    q[3] /= n;
+  }
+}
+inline void qrot_d(const double* q, const double* v, double* out) {
+  double uv[3] = {q[2] * v[2] - q[3] * v[1], q[3] * v[0] - q[1] * v[2], q[1] * v[1] - q[2] * v[0]};
+  uv[0] += uv[0];
+  uv[1] += uv[1];
+  uv[2] += uv[2];
+  const double c[3] = {q[2] * uv[2] - q[3] * uv[1], q[3] * uv[0] - q[1] * uv[2], q[1] * uv[1] - q[2] * uv[0]};
+  out[0] = (v[0] + q[0] * uv[0]) + c[0];
+  out[1] = (v[1] + q[0] * uv[1]) + c[1];
+  out[2] = (v[2] + q[0] * uv[2]) + c[2];
+}
+inline PoseD pose_mul(const PoseD& a, const PoseD& b) {  // rigid_transform.h:206-212
+  PoseD r;
+  double rt[3];
+  qrot_d(a.q, b.t, rt);
+  for (int i = 0; i < 3; ++i) r.t[i] = rt[i] + a.t[i];
+  qmul_d(a.q, b.q, r.q);
+  qnormalize_d(r.q);
+  return r;
+}
+inline PoseD pose_inverse(const PoseD& a) {  // rigid_transform.h:167-171
+  PoseD r;
+  r.q[0] = a.q[0];
+  r.q[1] = -a.q[1];
+  r.q[2] = -a.q[2];
+  r.q[3] = -a.q[3];
+  double rt[3];
+  qrot_d(r.q, a.t, rt);
+  for (int i = 0; i < 3; ++i) r.t[i] = -rt[i];
+  return r;
+}
+inline void pose_to_float7(const PoseD& p, float* out) {  // Rigid3d::cast<float>()
+  for (int i = 0; i < 3; ++i) out[i] = static_cast<float>(p.t[i]);
+  for (int i = 0; i < 4; ++i) out[3 + i] = static_cast<float>(p.q[i]);
+}
+
 }  // namespace dliom
 
 #endif  // DLIOM_CSRC_HOST_MATH_H_

@@ -85,6 +85,38 @@ class CsmSummary(C.Structure):
                 ("num_jacobian_evaluations", C.c_int), ("termination_type", C.c_int)]
 
 
+class AdaptiveVoxelFilterOptions(C.Structure):
+    _fields_ = [("max_length", C.c_float), ("min_num_points", C.c_float), ("max_range", C.c_float)]
+
+
+class FrontEndOptions(C.Structure):
+    _fields_ = [("high_resolution_adaptive_voxel_filter", AdaptiveVoxelFilterOptions),
+                ("low_resolution_adaptive_voxel_filter", AdaptiveVoxelFilterOptions),
+                ("use_online_correlative_scan_matching", C.c_int),
+                ("real_time_correlative_scan_matcher", RtcsmOptions),
+                ("ceres_scan_matcher", CsmOptions),
+                ("motion_filter_max_time_seconds", C.c_double),
+                ("motion_filter_max_distance_meters", C.c_double),
+                ("motion_filter_max_angle_radians", C.c_double),
+                ("high_resolution", C.c_double), ("high_resolution_max_range", C.c_double),
+                ("low_resolution", C.c_double), ("num_range_data", C.c_int),
+                ("hit_probability", C.c_double), ("miss_probability", C.c_double),
+                ("num_free_space_voxels", C.c_int)]
+
+
+class MatchResult(C.Structure):
+    _fields_ = [("dropped", C.c_int), ("pose_estimate", C.c_double * 7),
+                ("pose_observation_in_submap", C.c_double * 7), ("initial_ceres_pose", C.c_double * 7),
+                ("rtcsm_score", C.c_float), ("summary", CsmSummary), ("residual_distance", C.c_double),
+                ("residual_angle", C.c_double), ("num_high_resolution_points", C.c_int64),
+                ("num_low_resolution_points", C.c_int64), ("matching_submap_index", C.c_int)]
+
+
+class InsertionResult(C.Structure):
+    _fields_ = [("inserted", C.c_int), ("num_insertion_submaps", C.c_int), ("insertion_submap_index", C.c_int * 2),
+                ("submap_added", C.c_int), ("submap_finished", C.c_int)]
+
+
 # Every symbol include/dliom.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("dliom_status_string", C.c_char_p, [C.c_int]),
@@ -124,6 +156,16 @@ SYMBOLS = [
                                     C.POINTER(_vp), _f64p, C.POINTER(CsmSummary)]),
     ("dliom_csm3d_match_cloud", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, C.c_int, C.POINTER(_vp),
                                           C.POINTER(_vp), _f64p, C.POINTER(CsmSummary)]),
+    ("dliom_front_end_create", C.c_int, [_vp, C.POINTER(FrontEndOptions), C.POINTER(_vp)]),
+    ("dliom_front_end_destroy", C.c_int, [_vp]),
+    ("dliom_front_end_match", C.c_int, [_vp, _f64p, _f32p, _f32p, C.c_int64, C.POINTER(MatchResult)]),
+    ("dliom_front_end_insert", C.c_int, [_vp, C.c_int64, _f64p, _f64p, C.POINTER(InsertionResult)]),
+    ("dliom_front_end_num_active_submaps", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("dliom_front_end_matching_index", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("dliom_front_end_active_submap", C.c_int, [_vp, C.c_int, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                C.POINTER(_vp), C.POINTER(_vp)]),
+    ("dliom_voxel_filter", C.c_int, [C.c_float, _f32p, C.c_int64, _f32p, _i64p]),
+    ("dliom_adaptive_voxel_filter", C.c_int, [C.POINTER(AdaptiveVoxelFilterOptions), _f32p, C.c_int64, _f32p, _i64p]),
     ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
     ("dliom_rtcsm3d_score_volume", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _u64p,
                                              C.c_int64, _i64p]),
@@ -503,3 +545,119 @@ class CeresScanMatcher3D:
                                             _p(ns, _i64p), grids, C.byref(cost), _p(grad, _f64p), _p(jtj, _f64p)),
                "dliom_csm3d_evaluate")
         return cost.value, grad, jtj
+
+
+def voxel_filter(size, points):
+    """sensor::VoxelFilter(size).Filter(points) (host)."""
+    pts = _f32(points).reshape(-1, 3)
+    out = np.zeros_like(pts)
+    n = C.c_int64()
+    _check(load_library().dliom_voxel_filter(C.c_float(size), _p(pts, _f32p), len(pts), _p(out, _f32p), C.byref(n)),
+           "dliom_voxel_filter")
+    return out[:n.value].copy()
+
+
+def adaptive_voxel_filter(max_length, min_num_points, max_range, points):
+    """sensor::AdaptiveVoxelFilter(options).Filter(points) (host)."""
+    pts = _f32(points).reshape(-1, 3)
+    out = np.zeros_like(pts)
+    n = C.c_int64()
+    o = AdaptiveVoxelFilterOptions(max_length, min_num_points, max_range)
+    _check(load_library().dliom_adaptive_voxel_filter(C.byref(o), _p(pts, _f32p), len(pts), _p(out, _f32p), C.byref(n)),
+           "dliom_adaptive_voxel_filter")
+    return out[:n.value].copy()
+
+
+class _BorrowedGrid(HybridGrid):
+    """A grid owned by a front end (never destroyed from Python)."""
+
+    def __init__(self, ctx, handle, resolution):
+        self._L = ctx._L
+        self.ctx = ctx
+        self.resolution = float(np.float32(resolution))
+        self.h = handle
+
+    def close(self):
+        self.h = None
+
+
+class LocalTrajectoryBuilder3D:
+    """AddAccumulatedRangeData + InsertIntoSubmap of the reference's LocalTrajectoryBuilder3D
+    (local_trajectory_builder_3d.cc:493-622) minus the GTSAM window, over ActiveSubmaps3D."""
+
+    def __init__(self, ctx, options):
+        self.ctx = ctx
+        self._L = ctx._L
+        o = FrontEndOptions()
+        hi, lo = options["high_resolution_adaptive_voxel_filter"], options["low_resolution_adaptive_voxel_filter"]
+        o.high_resolution_adaptive_voxel_filter = AdaptiveVoxelFilterOptions(hi["max_length"], hi["min_num_points"], hi["max_range"])
+        o.low_resolution_adaptive_voxel_filter = AdaptiveVoxelFilterOptions(lo["max_length"], lo["min_num_points"], lo["max_range"])
+        o.use_online_correlative_scan_matching = int(options["use_online_correlative_scan_matching"])
+        o.real_time_correlative_scan_matcher = _rtcsm_opts(options["real_time_correlative_scan_matcher"])
+        o.ceres_scan_matcher = _csm_opts(options["ceres_scan_matcher"])
+        m, s = options["motion_filter"], options["submaps"]
+        o.motion_filter_max_time_seconds = m["max_time_seconds"]
+        o.motion_filter_max_distance_meters = m["max_distance_meters"]
+        o.motion_filter_max_angle_radians = m["max_angle_radians"]
+        o.high_resolution = s["high_resolution"]
+        o.high_resolution_max_range = s["high_resolution_max_range"]
+        o.low_resolution = s["low_resolution"]
+        o.num_range_data = s["num_range_data"]
+        o.hit_probability = s["hit_probability"]
+        o.miss_probability = s["miss_probability"]
+        o.num_free_space_voxels = s["num_free_space_voxels"]
+        self.resolutions = (s["high_resolution"], s["low_resolution"])
+        h = _vp()
+        _check(self._L.dliom_front_end_create(ctx.h, C.byref(o), C.byref(h)), "dliom_front_end_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_front_end_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def match(self, pose_prediction, origin, returns):
+        returns = _f32(returns).reshape(-1, 3)
+        r = MatchResult()
+        _check(self._L.dliom_front_end_match(self.h, _p(_f64(pose_prediction), _f64p), _p(_f32(origin), _f32p),
+                                             _p(returns, _f32p), len(returns), C.byref(r)), "dliom_front_end_match")
+        return dict(dropped=bool(r.dropped), pose_estimate=np.array(r.pose_estimate),
+                    pose_observation_in_submap=np.array(r.pose_observation_in_submap),
+                    initial_ceres_pose=np.array(r.initial_ceres_pose), rtcsm_score=r.rtcsm_score,
+                    final_cost=r.summary.final_cost, num_iterations=r.summary.num_iterations,
+                    num_high=r.num_high_resolution_points, num_low=r.num_low_resolution_points,
+                    residual_distance=r.residual_distance, residual_angle=r.residual_angle,
+                    matching_submap_index=r.matching_submap_index)
+
+    def insert(self, time_ticks, pose_estimate, gravity_alignment):
+        r = InsertionResult()
+        _check(self._L.dliom_front_end_insert(self.h, int(time_ticks), _p(_f64(pose_estimate), _f64p),
+                                              _p(_f64(gravity_alignment), _f64p), C.byref(r)), "dliom_front_end_insert")
+        return dict(inserted=bool(r.inserted), num_insertion_submaps=r.num_insertion_submaps,
+                    insertion_submap_index=list(r.insertion_submap_index)[:r.num_insertion_submaps],
+                    submap_added=bool(r.submap_added), submap_finished=bool(r.submap_finished))
+
+    def num_active_submaps(self):
+        n = C.c_int()
+        _check(self._L.dliom_front_end_num_active_submaps(self.h, C.byref(n)), "num_active_submaps")
+        return n.value
+
+    def matching_index(self):
+        n = C.c_int()
+        _check(self._L.dliom_front_end_matching_index(self.h, C.byref(n)), "matching_index")
+        return n.value
+
+    def active_submap(self, i):
+        pose = np.zeros(7)
+        n, fin = C.c_int(), C.c_int()
+        hi, lo = _vp(), _vp()
+        _check(self._L.dliom_front_end_active_submap(self.h, i, _p(pose, _f64p), C.byref(n), C.byref(fin),
+                                                     C.byref(hi), C.byref(lo)), "active_submap")
+        return dict(local_pose=pose, num_range_data=n.value, finished=bool(fin.value),
+                    hi=_BorrowedGrid(self.ctx, hi, self.resolutions[0]), lo=_BorrowedGrid(self.ctx, lo, self.resolutions[1]))

@@ -216,6 +216,84 @@ int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* options,
                             const dliom_cloud* const* clouds, const dliom_grid* const* grids,
                             double pose_estimate[7], dliom_csm_summary* summary);
 
+/* ---- scan-to-submap front end --------------------------------------------------------------
+ * LocalTrajectoryBuilder3D::AddAccumulatedRangeData + InsertIntoSubmap
+ * (mapping/internal/3d/local_trajectory_builder_3d.cc:493-622) around ActiveSubmaps3D
+ * (mapping/3d/submap_3d.cc:281-326), WITHOUT the GTSAM window: the caller runs WindowOptimize
+ * between dliom_front_end_match() and dliom_front_end_insert(), exactly where the reference does
+ * (:555-557), and passes the optimised pose to insert. */
+typedef struct dliom_front_end dliom_front_end;
+
+typedef struct dliom_adaptive_voxel_filter_options { /* sensor/proto/adaptive_voxel_filter_options.proto */
+  float max_length;
+  float min_num_points;
+  float max_range;
+} dliom_adaptive_voxel_filter_options;
+
+typedef struct dliom_front_end_options { /* proto/3d/local_trajectory_builder_options_3d.proto (subset) */
+  dliom_adaptive_voxel_filter_options high_resolution_adaptive_voxel_filter;
+  dliom_adaptive_voxel_filter_options low_resolution_adaptive_voxel_filter;
+  int use_online_correlative_scan_matching;
+  dliom_rtcsm_options real_time_correlative_scan_matcher;
+  dliom_csm_options ceres_scan_matcher;
+  /* proto/motion_filter_options.proto */
+  double motion_filter_max_time_seconds;
+  double motion_filter_max_distance_meters;
+  double motion_filter_max_angle_radians;
+  /* proto/3d/submaps_options_3d.proto */
+  double high_resolution;
+  double high_resolution_max_range;
+  double low_resolution;
+  int num_range_data;
+  double hit_probability;
+  double miss_probability;
+  int num_free_space_voxels;
+} dliom_front_end_options;
+
+typedef struct dliom_match_result {
+  int dropped;                        /* 1: the reference returns nullptr (:497-500,510-513,531-534) */
+  double pose_estimate[7];            /* local frame: submap.local_pose * observation (:552-553) */
+  double pose_observation_in_submap[7];
+  double initial_ceres_pose[7];       /* after the optional RTCSM (:504-521) */
+  float rtcsm_score;                  /* 0 when the online matcher is off */
+  dliom_csm_summary summary;
+  double residual_distance;           /* :544-547 */
+  double residual_angle;              /* :548-551 */
+  int64_t num_high_resolution_points; /* after the adaptive voxel filters (:506-509,526-530) */
+  int64_t num_low_resolution_points;
+  int matching_submap_index;
+} dliom_match_result;
+
+typedef struct dliom_insertion_result {
+  int inserted;                 /* 0: MotionFilter::IsSimilar said "similar" (:593-595) */
+  int num_insertion_submaps;    /* submaps the range data went into (1 or 2) */
+  int insertion_submap_index[2];/* trajectory-wide submap indices */
+  int submap_added;             /* a new submap was started after this insertion */
+  int submap_finished;          /* the oldest active submap was finished and dropped */
+} dliom_insertion_result;
+
+int dliom_front_end_create(dliom_ctx* ctx, const dliom_front_end_options* options, dliom_front_end** out);
+int dliom_front_end_destroy(dliom_front_end* fe);
+/* filtered_range_data_in_tracking = {origin, returns} (misses are not used by the 3D path).
+ * pose_prediction: tracking frame -> local frame. */
+int dliom_front_end_match(dliom_front_end* fe, const double pose_prediction[7], const float origin[3],
+                          const float* returns_xyz, int64_t num_returns, dliom_match_result* result);
+/* InsertIntoSubmap with the range data of the preceding match.  time_ticks: cartographer
+ * common::Time ticks (100 ns).  gravity_alignment: quaternion (w,x,y,z) used for new submaps. */
+int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double pose_estimate[7],
+                           const double gravity_alignment[4], dliom_insertion_result* result);
+/* ActiveSubmaps3D::submaps() / matching_index(). */
+int dliom_front_end_num_active_submaps(const dliom_front_end* fe, int* n);
+int dliom_front_end_matching_index(const dliom_front_end* fe, int* index);
+int dliom_front_end_active_submap(const dliom_front_end* fe, int i, double local_pose[7], int* num_range_data,
+                                  int* finished, dliom_grid** high_resolution_grid,
+                                  dliom_grid** low_resolution_grid);
+/* sensor::VoxelFilter / AdaptiveVoxelFilter (sensor/internal/voxel_filter.cc:39-90,147-150) on the
+ * host: out_xyz has room for n points; *num_out receives the survivors (first point per voxel). */
+int dliom_voxel_filter(float size, const float* points_xyz, int64_t n, float* out_xyz, int64_t* num_out);
+int dliom_adaptive_voxel_filter(const dliom_adaptive_voxel_filter_options* options, const float* points_xyz,
+                                int64_t n, float* out_xyz, int64_t* num_out);
+
 /* ---- diagnostics used by the parity tests and bench.py ------------------------
  * These expose intermediate results of the same device code the matchers run. */
 /* Cell index of R(pose)*p + t per point, computed by the score kernel's own

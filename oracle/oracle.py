@@ -98,6 +98,13 @@ def _declare(L):
     sig("orc_rotation_delta_squared_cost", C.c_double, _f64p, C.c_double, _f64p)
     sig("orc_csm3d_match", None, _f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
         _f64p, _f64p, C.POINTER(_f32p), _i32p, C.POINTER(vp), _f64p, _f64p)
+    sig("orc_front_end_new", vp, _f64p)
+    sig("orc_front_end_free", None, vp)
+    sig("orc_front_end_match", None, vp, _f64p, _f32p, _f32p, C.c_int, _f64p)
+    sig("orc_front_end_insert", C.c_int, vp, C.c_int64, _f64p, _f64p)
+    sig("orc_front_end_num_active_submaps", C.c_int, vp)
+    sig("orc_front_end_matching_index", C.c_int, vp)
+    sig("orc_front_end_active_submap", None, vp, C.c_int, _f64p, _i32p, C.POINTER(vp), C.POINTER(vp))
     sig("orc_pg_new", vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int)
     sig("orc_pg_free", None, vp)
     sig("orc_pg_set_probability", None, vp, C.c_int, C.c_int, C.c_float)
@@ -203,13 +210,15 @@ def cell_indices(resolution, pts):
 
 # ------------------------------------------------------------------ HybridGrid
 class HybridGrid:
-    def __init__(self, resolution):
+    def __init__(self, resolution, borrowed_handle=None):
         self._L = lib()
-        self.h = C.c_void_p(self._L.orc_grid_new(C.c_float(resolution)))
+        self._owned = borrowed_handle is None
+        self.h = C.c_void_p(self._L.orc_grid_new(C.c_float(resolution))) if self._owned else borrowed_handle
 
     def __del__(self):
         try:
-            self._L.orc_grid_free(self.h)
+            if self._owned:
+                self._L.orc_grid_free(self.h)
         except Exception:
             pass
 
@@ -488,3 +497,59 @@ def rtcsm2d_score_single(opts, pts, pg, x_index_offset, y_index_offset):
     pts = _f32(pts).reshape(-1, 3)
     return lib().orc_rtcsm2d_score_single(_p(_opts4(opts), _f64p), _p(pts, _f32p), len(pts), pg.h,
                                           x_index_offset, y_index_offset)
+
+
+# ------------------------------------------------------------------ front end
+def front_end_options_vector(o):
+    """Flattens the dict used by both the oracle and the product front end (see tests)."""
+    hi, lo = o["high_resolution_adaptive_voxel_filter"], o["low_resolution_adaptive_voxel_filter"]
+    r, c, m, s = o["real_time_correlative_scan_matcher"], o["ceres_scan_matcher"], o["motion_filter"], o["submaps"]
+    return _f64([hi["max_length"], hi["min_num_points"], hi["max_range"], lo["max_length"], lo["min_num_points"],
+                 lo["max_range"], float(o["use_online_correlative_scan_matching"]), r["linear_search_window"],
+                 r["angular_search_window"], r["translation_delta_cost_weight"], r["rotation_delta_cost_weight"],
+                 c["occupied_space_weight"][0], c["occupied_space_weight"][1], c["translation_weight"],
+                 c["rotation_weight"], float(c.get("only_optimize_yaw", False)),
+                 float(c.get("use_nonmonotonic_steps", False)), c["max_num_iterations"], m["max_time_seconds"],
+                 m["max_distance_meters"], m["max_angle_radians"], s["high_resolution"],
+                 s["high_resolution_max_range"], s["low_resolution"], s["num_range_data"], s["hit_probability"],
+                 s["miss_probability"], s["num_free_space_voxels"]])
+
+
+class FrontEnd:
+    def __init__(self, options):
+        self._L = lib()
+        v = front_end_options_vector(options)
+        self.h = C.c_void_p(self._L.orc_front_end_new(_p(v, _f64p)))
+
+    def __del__(self):
+        try:
+            self._L.orc_front_end_free(self.h)
+        except Exception:
+            pass
+
+    def match(self, pose_prediction, origin, returns):
+        returns = _f32(returns).reshape(-1, 3)
+        out = np.zeros(27)
+        self._L.orc_front_end_match(self.h, _p(_f64(pose_prediction), _f64p), _p(_f32(origin), _f32p),
+                                    _p(returns, _f32p), len(returns), _p(out, _f64p))
+        return dict(dropped=bool(out[0]), pose_estimate=out[1:8].copy(), pose_observation_in_submap=out[8:15].copy(),
+                    initial_ceres_pose=out[15:22].copy(), rtcsm_score=float(out[22]), final_cost=float(out[23]),
+                    num_iterations=int(out[24]), num_high=int(out[25]), num_low=int(out[26]))
+
+    def insert(self, time_ticks, pose, gravity_alignment):
+        return self._L.orc_front_end_insert(self.h, int(time_ticks), _p(_f64(pose), _f64p),
+                                            _p(_f64(gravity_alignment), _f64p))
+
+    def num_active_submaps(self):
+        return self._L.orc_front_end_num_active_submaps(self.h)
+
+    def matching_index(self):
+        return self._L.orc_front_end_matching_index(self.h)
+
+    def active_submap(self, i, resolutions):
+        pose = np.zeros(7)
+        n = C.c_int()
+        hi, lo = C.c_void_p(), C.c_void_p()
+        self._L.orc_front_end_active_submap(self.h, i, _p(pose, _f64p), C.byref(n), C.byref(hi), C.byref(lo))
+        return dict(local_pose=pose, num_range_data=n.value, hi=HybridGrid(resolutions[0], borrowed_handle=hi),
+                    lo=HybridGrid(resolutions[1], borrowed_handle=lo), _keepalive=self)

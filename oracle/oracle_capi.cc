@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "src/om_csm3d.h"
+#include "src/om_front_end.h"
 #include "src/om_grid2d.h"
 #include "src/om_rtcsm3d.h"
 
@@ -372,6 +373,63 @@ void orc_csm3d_match(const double* occupied_space_weights, int k, double transla
     summary_out[8] = 0;
     summary_out[9] = 0;
   }
+}
+
+// ---------------------------------------------------------------- front end
+// opts (doubles): [0..2] hi adaptive filter (max_length, min_num_points, max_range), [3..5] lo,
+// [6] use_online_csm, [7..10] rtcsm options, [11] occupied_space_weight_0, [12] weight_1,
+// [13] translation_weight, [14] rotation_weight, [15] only_optimize_yaw, [16] nonmonotonic,
+// [17] max_num_iterations, [18..20] motion filter (time, distance, angle),
+// [21] high_resolution, [22] high_resolution_max_range, [23] low_resolution, [24] num_range_data,
+// [25] hit_probability, [26] miss_probability, [27] num_free_space_voxels
+void* orc_front_end_new(const double* o) {
+  FrontEndOptions f;
+  f.high_resolution_adaptive_voxel_filter = {static_cast<float>(o[0]), static_cast<float>(o[1]), static_cast<float>(o[2])};
+  f.low_resolution_adaptive_voxel_filter = {static_cast<float>(o[3]), static_cast<float>(o[4]), static_cast<float>(o[5])};
+  f.use_online_correlative_scan_matching = o[6] != 0;
+  f.real_time_correlative_scan_matcher = {o[7], o[8], o[9], o[10]};
+  f.ceres_scan_matcher.occupied_space_weight = {o[11], o[12]};
+  f.ceres_scan_matcher.translation_weight = o[13];
+  f.ceres_scan_matcher.rotation_weight = o[14];
+  f.ceres_scan_matcher.only_optimize_yaw = o[15] != 0;
+  f.ceres_scan_matcher.use_nonmonotonic_steps = o[16] != 0;
+  f.ceres_scan_matcher.max_num_iterations = static_cast<int>(o[17]);
+  f.motion_filter = {o[18], o[19], o[20]};
+  f.submaps = {o[21], o[22], o[23], static_cast<int>(o[24]), o[25], o[26], static_cast<int>(o[27])};
+  return new FrontEnd(f);
+}
+void orc_front_end_free(void* fe) { delete static_cast<FrontEnd*>(fe); }
+// out[0] dropped, out[1..7] pose_estimate, out[8..14] observation, out[15..21] initial ceres pose,
+// out[22] rtcsm score, out[23] final cost, out[24] iterations, out[25] n_hi, out[26] n_lo
+void orc_front_end_match(void* fe, const double* pose_prediction7, const float* origin3, const float* returns,
+                         int n, double* out) {
+  RangeData rd{Vec3f(origin3[0], origin3[1], origin3[2]), ToCloud(returns, n), {}};
+  const MatchResult r = static_cast<FrontEnd*>(fe)->Match(ToRigid(pose_prediction7), rd);
+  out[0] = r.dropped ? 1 : 0;
+  FromRigid(r.pose_estimate, out + 1);
+  FromRigid(r.pose_observation_in_submap, out + 8);
+  FromRigid(r.initial_ceres_pose, out + 15);
+  out[22] = r.rtcsm_score;
+  out[23] = r.summary.final_cost;
+  out[24] = r.summary.num_iterations;
+  out[25] = static_cast<double>(r.num_high);
+  out[26] = static_cast<double>(r.num_low);
+}
+int orc_front_end_insert(void* fe, int64_t time_ticks, const double* pose7, const double* gravity4) {
+  return static_cast<FrontEnd*>(fe)->Insert(time_ticks, ToRigid(pose7),
+                                            Quatd(gravity4[0], gravity4[1], gravity4[2], gravity4[3]));
+}
+int orc_front_end_num_active_submaps(void* fe) {
+  return static_cast<int>(static_cast<FrontEnd*>(fe)->active_submaps().submaps().size());
+}
+int orc_front_end_matching_index(void* fe) { return static_cast<FrontEnd*>(fe)->active_submaps().matching_index(); }
+// Borrowed pointers to the active submap's grids (owned by the front end).
+void orc_front_end_active_submap(void* fe, int i, double* local_pose7, int* num_range_data, void** hi, void** lo) {
+  const auto& s = static_cast<FrontEnd*>(fe)->active_submaps().submaps()[i];
+  FromRigid(s->local_pose(), local_pose7);
+  *num_range_data = s->num_range_data();
+  *hi = &s->high_resolution_hybrid_grid();
+  *lo = &s->low_resolution_hybrid_grid();
 }
 
 // ---------------------------------------------------------------- 2D (config 1, CPU only)

@@ -85,3 +85,19 @@ def test_cpp_adapter_header_compiles(dl, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "adapter_kat.cc"), "-L", libdir, "-ldliom",
                            "-Wl,-rpath," + libdir])
+
+
+def test_voxel_filters_equal_oracle(dl, orc):
+    """sensor::VoxelFilter / AdaptiveVoxelFilter: product host code vs oracle, incl. the reference's
+    own cases (voxel_filter_test.cc:29-55) and the empty / already-sparse edge cases."""
+    pc = np.array([[0, 0, 0], [0.1, -0.1, 0.1], [0.3, -0.1, 0], [0, 0, 0.1]], dtype=np.float32)
+    assert np.array_equal(dl.voxel_filter(0.3, pc), pc[[0, 2]])
+    big = np.array([[100000, 0, 0], [100000.001, -0.0001, 0.0001], [100000.003, -0.0001, 0], [-200000, 0, 0]], np.float32)
+    assert np.array_equal(dl.voxel_filter(0.01, big), big[[0, 3]])
+    assert len(dl.voxel_filter(0.3, np.zeros((0, 3), np.float32))) == 0
+    from dliom import synth
+    pts, _ = synth.scan(synth.trajectory_pose(0.3), 32, 256)
+    for size in (0.075, 0.15, 0.3):
+        assert np.array_equal(dl.voxel_filter(size, pts), pts[orc.voxel_filter(size, pts)])
+    for (ml, mn, mr) in ((2.0, 150, 15.0), (4.0, 200, 60.0), (0.5, 5000, 60.0), (2.0, 1e9, 60.0), (2.0, 150, 0.5)):
+        assert np.array_equal(dl.adaptive_voxel_filter(ml, mn, mr, pts), orc.adaptive_voxel_filter(ml, mn, mr, pts))

@@ -456,3 +456,74 @@ def test_set_values_and_set_probability(dl, ctx, orc):
     dg.SetProbability((3, -2, 900), 0.63)
     assert dg.bits == og.bits and dg.cells() == oracle_cells_dict(og)
     dg.close()
+
+
+FRONT_END_OPTS = dict(
+    high_resolution_adaptive_voxel_filter=dict(max_length=2.0, min_num_points=150, max_range=15.0),
+    low_resolution_adaptive_voxel_filter=dict(max_length=4.0, min_num_points=200, max_range=60.0),
+    use_online_correlative_scan_matching=True,
+    real_time_correlative_scan_matcher=DEFAULT_RTCSM,
+    ceres_scan_matcher=DEFAULT_CSM,
+    motion_filter=dict(max_time_seconds=0.5, max_distance_meters=0.1, max_angle_radians=0.004),
+    submaps=dict(high_resolution=0.10, high_resolution_max_range=20.0, low_resolution=0.45, num_range_data=4,
+                 hit_probability=HIT_P, miss_probability=MISS_P, num_free_space_voxels=FREE))
+
+
+@pytest.mark.parametrize("online", [True, False])
+def test_front_end_sequence_equals_oracle(dl, ctx, orc, online):
+    """A 12-scan trajectory through LocalTrajectoryBuilder3D's AddAccumulatedRangeData /
+    InsertIntoSubmap chain (two active submaps, submap roll-over every 4 insertions, motion
+    filter) on the device vs the oracle: RTCSM poses bit-equal, Ceres poses within 1e-6, every
+    active grid bit-equal after every scan."""
+    from dliom import synth
+    opts = dict(FRONT_END_OPTS, use_online_correlative_scan_matching=online)
+    ofe = orc.FrontEnd(opts)
+    dfe = dl.LocalTrajectoryBuilder3D(ctx, opts)
+    gravity = np.array([1.0, 0, 0, 0])
+    for s in range(12):
+        truth = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(truth, 16, 256)
+        pts = pts[orc.voxel_filter(0.15, pts)]  # AddRangeData's fixed-size voxel filter (:479-484)
+        prediction = synth.perturb_pose(truth, 0.03, 0.2, seed=100 + s)
+        origin = np.zeros(3, np.float32)
+        ro = ofe.match(prediction, origin, pts)
+        rd = dfe.match(prediction, origin, pts)
+        assert rd["dropped"] == ro["dropped"] is False
+        assert rd["num_high"] == ro["num_high"] and rd["num_low"] == ro["num_low"]
+        if online:
+            assert np.float32(rd["rtcsm_score"]) == np.float32(ro["rtcsm_score"])
+        assert np.array_equal(rd["initial_ceres_pose"], ro["initial_ceres_pose"])
+        dt, da = pose_distance(rd["pose_estimate"], ro["pose_estimate"])
+        assert dt <= 1e-6 and da <= 1e-6, (s, dt, da)
+        # both sides insert at the ORACLE's estimate so that the grids stay comparable bit for bit
+        t = int(s * 1e6)  # 0.1 s steps in 100 ns ticks
+        io = ofe.insert(t, ro["pose_estimate"], gravity)
+        idv = dfe.insert(t, ro["pose_estimate"], gravity)
+        assert idv["inserted"] == (io > 0)
+        assert idv["submap_added"] == (io == 2)
+        assert dfe.num_active_submaps() == ofe.num_active_submaps()
+        assert dfe.matching_index() == ofe.matching_index()
+        for i in range(dfe.num_active_submaps()):
+            so, sd = ofe.active_submap(i, (0.1, 0.45)), dfe.active_submap(i)
+            assert sd["num_range_data"] == so["num_range_data"]
+            assert np.array_equal(sd["local_pose"], so["local_pose"])
+            assert sd["hi"].cells() == oracle_cells_dict(so["hi"])
+            assert sd["lo"].cells() == oracle_cells_dict(so["lo"])
+    assert dfe.matching_index() >= 1  # the roll-over was exercised
+    dfe.close()
+
+
+def test_front_end_drops_and_motion_filter(dl, ctx, orc):
+    from dliom import synth
+    dfe = dl.LocalTrajectoryBuilder3D(ctx, FRONT_END_OPTS)
+    r = dfe.match(np.array([0, 0, 0, 1.0, 0, 0, 0]), np.zeros(3, np.float32), np.zeros((0, 3), np.float32))
+    assert r["dropped"]  # "Dropped empty range data."
+    pts, _ = synth.scan(synth.trajectory_pose(0.0), 8, 64)
+    pose = synth.trajectory_pose(0.0)
+    r = dfe.match(pose, np.zeros(3, np.float32), pts)
+    assert not r["dropped"]
+    g = np.array([1.0, 0, 0, 0])
+    assert dfe.insert(0, pose, g)["inserted"]
+    assert not dfe.insert(1000, pose, g)["inserted"]        # same pose, 0.1 ms later: similar
+    assert dfe.insert(int(0.6e7), pose, g)["inserted"]      # max_time_seconds exceeded
+    dfe.close()
