@@ -301,6 +301,7 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
     (void)hipEventDestroy(s.b);
   }
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->rtcsm_state != nullptr && ctx->rtcsm_state_free != nullptr) ctx->rtcsm_state_free(ctx->rtcsm_state);
   ctx->points.release();
   ctx->cand.release();
   ctx->sums.release();

@@ -83,6 +83,8 @@ struct dliom_ctx {
   double kernel_ms[DLIOM_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   int64_t kernel_launches[DLIOM_KERNEL_COUNT] = {0, 0, 0, 0, 0};
   dliom_rtcsm_stats last_rtcsm = {};
+  void* rtcsm_state = nullptr;              // state between the phases of a match (rtcsm3d.hip)
+  void (*rtcsm_state_free)(void*) = nullptr;
 
   int begin_span(int id);  // returns span index or -1
   void end_span(int span);

@@ -38,7 +38,7 @@ constexpr int kBlock = 256;
 template <int PPT>
 __global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
     GridView g, const float* __restrict__ px, const float* __restrict__ py,
-    const float* __restrict__ pz, const float4* __restrict__ rot, int R,
+    const float* __restrict__ pz, const float4* __restrict__ rot, int R, int r_first, int r_last,
     const float* __restrict__ trans, int T, int rots_per_block,
     unsigned long long* __restrict__ sums, int debug_no_atomic) {
   // Clouds are padded to a multiple of 4096 points with far-away points (kPadCoordinate): those
@@ -52,8 +52,8 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
     y[k] = py[i];
     z[k] = pz[i];
   }
-  const int r_begin = blockIdx.y * rots_per_block;
-  const int r_end = min(r_begin + rots_per_block, R);
+  const int r_begin = r_first + blockIdx.y * rots_per_block;  // this shard's rotations only
+  const int r_end = min(r_begin + rots_per_block, r_last);
   const int lane = threadIdx.x & 63;
   const float inv = g.inv_resolution;
   const unsigned sentinel = 1u << (3 * g.log2_leaves);  // table[L^3] is always 0 (null leaf)
@@ -117,6 +117,7 @@ struct BoundParams {
   int n;           // points
   int n_pad;       // padding points, each of which added exactly 1 to every sum
   int R, T;
+  int r_first, r_last;  // rotations owned by this shard
 };
 
 // Upper bound of the accumulated rounding error of the reference's sequential float sum.
@@ -160,6 +161,11 @@ __global__ void rtcsm_bounds_kernel(const unsigned long long* __restrict__ sums,
   const long long c = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const int j = static_cast<int>(c / p.R), r = static_cast<int>(c % p.R);
+  if (r < p.r_first || r >= p.r_last) {  // another shard's candidate
+    lo[c] = 0.f;
+    hi[c] = -1.f;
+    return;
+  }
   const double s = static_cast<double>(sums[c] - static_cast<unsigned long long>(p.n_pad));
   const double mid = p.a * s + p.b * p.n;
   const double slack = p.delta * p.n + 1e-9 * mid;
@@ -395,8 +401,8 @@ static int env_int(const char* name, int fallback) {
 // Launches the score-volume kernel; *pad_processed = padding points visited (each adds 1 to
 // every sum).
 static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid,
-                            const Candidates& c, DeviceCandidates* d, unsigned long long** d_sums,
-                            int64_t* pad_processed) {
+                            const Candidates& c, int r_first, int r_last, DeviceCandidates* d,
+                            unsigned long long** d_sums, int64_t* pad_processed) {
   DLIOM_TRY(upload_candidates(ctx, c, d));
   const int64_t C = c.w.num_candidates;
   DLIOM_TRY(ctx->sums.reserve(static_cast<size_t>(C) * 8));
@@ -413,17 +419,18 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   while (ppt > 1 && (cloud.n_padded % (static_cast<int64_t>(kBlock) * ppt)) != 0) ppt >>= 1;
   const int tile = kBlock * ppt;
   const int point_tiles = (n + tile - 1) / tile;
-  int rot_tiles = std::max(1, std::min(R, (target_blocks + point_tiles - 1) / point_tiles));
-  const int rots_per_block = (R + rot_tiles - 1) / rot_tiles;
-  rot_tiles = (R + rots_per_block - 1) / rots_per_block;
+  const int Rs = r_last - r_first;  // rotations of this shard
+  int rot_tiles = std::max(1, std::min(Rs, (target_blocks + point_tiles - 1) / point_tiles));
+  const int rots_per_block = (Rs + rot_tiles - 1) / rot_tiles;
+  rot_tiles = (Rs + rots_per_block - 1) / rots_per_block;
   const dim3 grid_dim(point_tiles, rot_tiles), block(kBlock);
   const size_t lds = static_cast<size_t>(T) * sizeof(unsigned);
   if (lds > 150 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;  // (2L+1)^3 translations must fit LDS
   const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
 #define DLIOM_LAUNCH_SCORE(P)                                                                    \
   hipLaunchKernelGGL((rtcsm_score_kernel<P>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,  \
-                     cloud.d_ys, cloud.d_zs, d->rot, R, d->trans, T, rots_per_block, *d_sums,    \
-                     debug_no_atomic)
+                     cloud.d_ys, cloud.d_zs, d->rot, R, r_first, r_last, d->trans, T,             \
+                     rots_per_block, *d_sums, debug_no_atomic)
   switch (ppt) {
     case 16: DLIOM_LAUNCH_SCORE(16); break;
     case 8: DLIOM_LAUNCH_SCORE(8); break;
@@ -463,95 +470,185 @@ static const LutModel& lut_model() {
   return m;
 }
 
-static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
-                      const dliom_cloud& cloud, const dliom_grid* grid, double out7[7],
-                      float* out_score) {
-  if (cloud.n <= 0) return DLIOM_ERR_EMPTY_CLOUD;
-  if (cloud.n > (1 << 27)) return DLIOM_ERR_INVALID_ARGUMENT;
+// State of a (possibly sharded) match between its phases; lives in dliom_ctx::rtcsm_state.
+struct RtcsmState {
+  dliom_rtcsm_options o;
   Candidates c;
+  DeviceCandidates d;
+  dliom_cloud cloud;
+  const dliom_grid* grid = nullptr;
+  int r_first = 0, r_last = 0;
+  unsigned long long* d_sums = nullptr;
+  float* d_hi = nullptr;
+  unsigned* d_list = nullptr;
+  unsigned* d_ctrs = nullptr;
+  float best_score = -1.f;
+  int64_t best_c = -1;
+  bool active = false;
+};
+
+static RtcsmState* state_of(dliom_ctx* ctx) {
+  if (ctx->rtcsm_state == nullptr) {
+    ctx->rtcsm_state = new RtcsmState;
+    ctx->rtcsm_state_free = [](void* p) { delete static_cast<RtcsmState*>(p); };
+  }
+  return static_cast<RtcsmState*>(ctx->rtcsm_state);
+}
+
+// Phase 1: score volume + score bounds for the rotations [shard * R / num_shards, ...).
+// local_best_lo_bits (optional) receives this shard's best lower bound (float bits) -- the
+// quantity that is max-all-reduced when the window is sharded across GPUs.
+static int match_begin(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                       const dliom_cloud& cloud, const dliom_grid* grid, int shard, int num_shards,
+                       unsigned* local_best_lo_bits) {
+  if (cloud.n <= 0) return DLIOM_ERR_EMPTY_CLOUD;
+  if (cloud.n > (1 << 27) || num_shards < 1 || shard < 0 || shard >= num_shards)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  RtcsmState* st = state_of(ctx);
+  st->active = false;
+  st->o = *o;
+  st->cloud = cloud;
+  st->grid = grid;
+  Candidates& c = st->c;
   generate_candidates(*o, grid->resolution, cloud.max_norm, init7, &c);
   const int64_t C = c.w.num_candidates;
   const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
   if (C <= 0 || C > (int64_t{1} << 31)) return DLIOM_ERR_INVALID_ARGUMENT;
+  st->r_first = static_cast<int>(static_cast<int64_t>(R) * shard / num_shards);
+  st->r_last = static_cast<int>(static_cast<int64_t>(R) * (shard + 1) / num_shards);
 
-  DeviceCandidates d;
-  unsigned long long* d_sums = nullptr;
-  int64_t pad_processed = 0;
-  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, &d, &d_sums, &pad_processed));
-
-  // ---- bounds + selection
   const size_t bytes_f = (static_cast<size_t>(C) * 4 + 255) & ~static_cast<size_t>(255);
   DLIOM_TRY(ctx->bounds.reserve(3 * bytes_f + 256));
   char* bb = static_cast<char*>(ctx->bounds.p);
   float* d_lo = reinterpret_cast<float*>(bb);
-  float* d_hi = reinterpret_cast<float*>(bb + bytes_f);
-  unsigned* d_list = reinterpret_cast<unsigned*>(bb + 2 * bytes_f);
-  unsigned* d_ctrs = reinterpret_cast<unsigned*>(bb + 3 * bytes_f);  // [0] best_lo bits, [1] count
-  DLIOM_HIP_TRY(hipMemsetAsync(d_ctrs, 0, 8, ctx->stream));
-  const LutModel& lm = lut_model();
-  BoundParams bp;
-  bp.a = lm.a;
-  bp.b = lm.b;
-  bp.delta = lm.delta;
-  bp.wt = o->translation_delta_cost_weight;
-  bp.wr = o->rotation_delta_cost_weight;
-  bp.n = static_cast<int>(cloud.n);
-  bp.n_pad = static_cast<int>(pad_processed);
-  bp.R = R;
-  bp.T = T;
-  const unsigned cblocks = static_cast<unsigned>((C + 255) / 256);
-  int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SELECT);
-  hipLaunchKernelGGL(rtcsm_bounds_kernel, dim3(cblocks), dim3(256), 0, ctx->stream, d_sums,
-                     static_cast<long long>(C), d.t_norm, d.r_angle, bp, d_lo, d_hi, d_ctrs);
-  hipLaunchKernelGGL(rtcsm_select_kernel, dim3(cblocks), dim3(256), 0, ctx->stream, d_hi,
-                     static_cast<long long>(C), d_ctrs, d_ctrs + 1, d_list);
-  ctx->end_span(span);
-  DLIOM_HIP_TRY(hipGetLastError());
-  unsigned ctrs[2] = {0, 0};
-  DLIOM_HIP_TRY(hipMemcpyAsync(ctrs, d_ctrs, 8, hipMemcpyDeviceToHost, ctx->stream));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  const unsigned K = ctrs[1];
-  if (K == 0) return DLIOM_ERR_SCORE_NOT_POSITIVE;  // cannot happen: the best-lo candidate survives
+  st->d_hi = reinterpret_cast<float*>(bb + bytes_f);
+  st->d_list = reinterpret_cast<unsigned*>(bb + 2 * bytes_f);
+  st->d_ctrs = reinterpret_cast<unsigned*>(bb + 3 * bytes_f);  // [0] best_lo bits, [1] count
+  DLIOM_HIP_TRY(hipMemsetAsync(st->d_ctrs, 0, 8, ctx->stream));
+  if (st->r_last > st->r_first) {
+    int64_t pad_processed = 0;
+    DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, st->r_first, st->r_last, &st->d, &st->d_sums,
+                               &pad_processed));
+    const LutModel& lm = lut_model();
+    BoundParams bp;
+    bp.a = lm.a;
+    bp.b = lm.b;
+    bp.delta = lm.delta;
+    bp.wt = o->translation_delta_cost_weight;
+    bp.wr = o->rotation_delta_cost_weight;
+    bp.n = static_cast<int>(cloud.n);
+    bp.n_pad = static_cast<int>(pad_processed);
+    bp.R = R;
+    bp.T = T;
+    bp.r_first = st->r_first;
+    bp.r_last = st->r_last;
+    const unsigned cblocks = static_cast<unsigned>((C + 255) / 256);
+    const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SELECT);
+    hipLaunchKernelGGL(rtcsm_bounds_kernel, dim3(cblocks), dim3(256), 0, ctx->stream, st->d_sums,
+                       static_cast<long long>(C), st->d.t_norm, st->d.r_angle, bp, d_lo, st->d_hi,
+                       st->d_ctrs);
+    ctx->end_span(span);
+    DLIOM_HIP_TRY(hipGetLastError());
+  }
+  if (local_best_lo_bits != nullptr) {
+    DLIOM_HIP_TRY(hipMemcpyAsync(local_best_lo_bits, st->d_ctrs, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  st->active = true;
+  return DLIOM_OK;
+}
 
-  // ---- exact sequential rescoring of the survivors: one workgroup each
-  const int n = static_cast<int>(cloud.n);
-  DLIOM_TRY(ctx->rescore.reserve(static_cast<size_t>(K) * 4));
-  float* d_ksums = ctx->rescore.as<float>();
-  span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
-  hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(K), dim3(256), 0, ctx->stream, grid->view(), cloud.d_x,
-                     cloud.d_y, cloud.d_z, n, d.rot, R, d.trans, d_list, lm.k_scale, lm.k_offset,
-                     lm.k_unknown, d_ksums);
-  ctx->end_span(span);
-  DLIOM_HIP_TRY(hipGetLastError());
-  std::vector<unsigned> list(K);
-  std::vector<float> ksums(K);
-  DLIOM_HIP_TRY(hipMemcpyAsync(list.data(), d_list, static_cast<size_t>(K) * 4, hipMemcpyDeviceToHost,
-                               ctx->stream));
-  DLIOM_HIP_TRY(hipMemcpyAsync(ksums.data(), d_ksums, static_cast<size_t>(K) * 4,
-                               hipMemcpyDeviceToHost, ctx->stream));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-
-  // ---- final scoring exactly as rtcsm_3d.cc:105-112, first maximum in generation order
-  float best_score = -1.f;
-  int64_t best_c = -1;
-  for (unsigned k = 0; k < K; ++k) {
-    const int64_t cc = list[k];
-    const int j = static_cast<int>(cc / R), r = static_cast<int>(cc % R);
-    float score = ksums[k];
-    score /= static_cast<float>(n);
-    const double arg = c.t_norm[j] * o->translation_delta_cost_weight +
-                       c.r_angle[r] * o->rotation_delta_cost_weight;
-    score *= std::exp(-(arg * (arg * 1.0)));
-    if (score > best_score || (score == best_score && cc < best_c)) {
-      best_score = score;
-      best_c = cc;
+// Phase 2: survivors against the (global) best lower bound, exact sequential rescoring, and this
+// shard's winner packed as (score_bits << 32) | (0xFFFFFFFF - index): the max over shards of that
+// word is the reference's first-maximum-in-generation-order winner.
+static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uint64_t* local_best_packed) {
+  RtcsmState* st = state_of(ctx);
+  if (!st->active) return DLIOM_ERR_INVALID_ARGUMENT;
+  const dliom_rtcsm_options* o = &st->o;
+  const Candidates& c = st->c;
+  const int64_t C = c.w.num_candidates;
+  const int R = static_cast<int>(c.w.num_rotations);
+  const dliom_cloud& cloud = st->cloud;
+  st->best_score = -1.f;
+  st->best_c = -1;
+  unsigned K = 0;
+  if (st->r_last > st->r_first) {
+    if (global_best_lo_bits != nullptr) {
+      DLIOM_HIP_TRY(hipMemcpyAsync(st->d_ctrs, global_best_lo_bits, 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const unsigned cblocks = static_cast<unsigned>((C + 255) / 256);
+    int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SELECT);
+    hipLaunchKernelGGL(rtcsm_select_kernel, dim3(cblocks), dim3(256), 0, ctx->stream, st->d_hi,
+                       static_cast<long long>(C), st->d_ctrs, st->d_ctrs + 1, st->d_list);
+    ctx->end_span(span);
+    DLIOM_HIP_TRY(hipGetLastError());
+    unsigned ctrs[2] = {0, 0};
+    DLIOM_HIP_TRY(hipMemcpyAsync(ctrs, st->d_ctrs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    K = ctrs[1];
+  }
+  if (K > 0) {
+    // exact sequential rescoring of the survivors: one workgroup each
+    const LutModel& lm = lut_model();
+    const int n = static_cast<int>(cloud.n);
+    DLIOM_TRY(ctx->rescore.reserve(static_cast<size_t>(K) * 4));
+    float* d_ksums = ctx->rescore.as<float>();
+    const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
+    hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(K), dim3(256), 0, ctx->stream, st->grid->view(), cloud.d_x,
+                       cloud.d_y, cloud.d_z, n, st->d.rot, R, st->d.trans, st->d_list, lm.k_scale, lm.k_offset,
+                       lm.k_unknown, d_ksums);
+    ctx->end_span(span);
+    DLIOM_HIP_TRY(hipGetLastError());
+    std::vector<unsigned> list(K);
+    std::vector<float> ksums(K);
+    DLIOM_HIP_TRY(hipMemcpyAsync(list.data(), st->d_list, static_cast<size_t>(K) * 4, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    DLIOM_HIP_TRY(hipMemcpyAsync(ksums.data(), d_ksums, static_cast<size_t>(K) * 4, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // final scoring exactly as rtcsm_3d.cc:105-112, first maximum in generation order
+    for (unsigned k = 0; k < K; ++k) {
+      const int64_t cc = list[k];
+      const int j = static_cast<int>(cc / R), r = static_cast<int>(cc % R);
+      float score = ksums[k];
+      score /= static_cast<float>(n);
+      const double arg = c.t_norm[j] * o->translation_delta_cost_weight +
+                         c.r_angle[r] * o->rotation_delta_cost_weight;
+      score *= std::exp(-(arg * (arg * 1.0)));
+      if (score > st->best_score || (score == st->best_score && cc < st->best_c)) {
+        st->best_score = score;
+        st->best_c = cc;
+      }
     }
   }
   ctx->last_rtcsm.window = c.w;
   ctx->last_rtcsm.num_points = cloud.n;
   ctx->last_rtcsm.num_rescored = K;
-  ctx->last_rtcsm.best_index = best_c;
-  if (!(best_score > 0.f)) return DLIOM_ERR_SCORE_NOT_POSITIVE;
+  ctx->last_rtcsm.best_index = st->best_c;
+  if (local_best_packed != nullptr) {
+    uint64_t packed = 0;  // a shard without a positive-score survivor contributes nothing
+    if (st->best_c >= 0 && st->best_score > 0.f) {
+      uint32_t bits;
+      std::memcpy(&bits, &st->best_score, 4);
+      packed = (static_cast<uint64_t>(bits) << 32) | (0xFFFFFFFFull - static_cast<uint64_t>(st->best_c));
+    }
+    *local_best_packed = packed;
+  }
+  return DLIOM_OK;
+}
+
+// Phase 3: pose of the winning candidate (every shard can decode it: candidates are replicated).
+static int match_decode(dliom_ctx* ctx, uint64_t best_packed, double out7[7], float* out_score) {
+  RtcsmState* st = state_of(ctx);
+  if (!st->active) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (best_packed == 0) return DLIOM_ERR_SCORE_NOT_POSITIVE;  // CHECK_GT(score, 0.f)
+  const Candidates& c = st->c;
+  const int R = static_cast<int>(c.w.num_rotations);
+  const uint32_t bits = static_cast<uint32_t>(best_packed >> 32);
+  const int64_t best_c = static_cast<int64_t>(0xFFFFFFFFull - (best_packed & 0xFFFFFFFFull));
+  if (best_c < 0 || best_c >= c.w.num_candidates) return DLIOM_ERR_INVALID_ARGUMENT;
+  float score;
+  std::memcpy(&score, &bits, 4);
   const int j = static_cast<int>(best_c / R), r = static_cast<int>(best_c % R);
   out7[0] = c.trans[j].x;
   out7[1] = c.trans[j].y;
@@ -560,8 +657,18 @@ static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double
   out7[4] = c.rot[r].x;
   out7[5] = c.rot[r].y;
   out7[6] = c.rot[r].z;
-  *out_score = best_score;
+  *out_score = score;
+  ctx->last_rtcsm.best_index = best_c;
   return DLIOM_OK;
+}
+
+static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                      const dliom_cloud& cloud, const dliom_grid* grid, double out7[7],
+                      float* out_score) {
+  DLIOM_TRY(match_begin(ctx, o, init7, cloud, grid, 0, 1, nullptr));
+  uint64_t packed = 0;
+  DLIOM_TRY(match_finish(ctx, nullptr, &packed));
+  return match_decode(ctx, packed, out7, out_score);
 }
 
 }  // namespace dliom
@@ -602,6 +709,29 @@ int dliom_rtcsm3d_match(dliom_ctx* ctx, const dliom_rtcsm_options* o, const doub
   return match_impl(ctx, o, init7, cloud, grid, out7, score);
 }
 
+int dliom_rtcsm3d_shard_begin(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                              const dliom_cloud* cloud, const dliom_grid* grid, int shard, int num_shards,
+                              uint32_t* local_best_lower_bound_bits) {
+  if (ctx == nullptr || o == nullptr || init7 == nullptr || cloud == nullptr || grid == nullptr ||
+      local_best_lower_bound_bits == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  return match_begin(ctx, o, init7, *cloud, grid, shard, num_shards, local_best_lower_bound_bits);
+}
+
+int dliom_rtcsm3d_shard_finish(dliom_ctx* ctx, uint32_t global_best_lower_bound_bits,
+                               uint64_t* local_best_packed) {
+  if (ctx == nullptr || local_best_packed == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  return match_finish(ctx, &global_best_lower_bound_bits, local_best_packed);
+}
+
+int dliom_rtcsm3d_shard_decode(dliom_ctx* ctx, uint64_t global_best_packed, double pose_estimate[7],
+                               float* score) {
+  if (ctx == nullptr || pose_estimate == nullptr || score == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  return match_decode(ctx, global_best_packed, pose_estimate, score);
+}
+
 int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats) {
   if (ctx == nullptr || stats == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   *stats = ctx->last_rtcsm;
@@ -626,7 +756,8 @@ int dliom_rtcsm3d_score_volume(dliom_ctx* ctx, const dliom_rtcsm_options* o, con
   DeviceCandidates d;
   unsigned long long* d_sums = nullptr;
   int64_t pad_processed = 0;
-  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, &d, &d_sums, &pad_processed));
+  DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, 0, static_cast<int>(c.w.num_rotations), &d, &d_sums,
+                             &pad_processed));
   DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_sums, static_cast<size_t>(c.w.num_candidates) * 8,
                                hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));

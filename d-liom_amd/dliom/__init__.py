@@ -150,6 +150,10 @@ SYMBOLS = [
     ("dliom_cloud_size", C.c_int, [_vp, _i64p]),
     ("dliom_rtcsm3d_match", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _f64p, _f32p]),
     ("dliom_rtcsm3d_match_cloud", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, _f64p, _f32p]),
+    ("dliom_rtcsm3d_shard_begin", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, C.c_int, C.c_int,
+                                            C.POINTER(C.c_uint32)]),
+    ("dliom_rtcsm3d_shard_finish", C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("dliom_rtcsm3d_shard_decode", C.c_int, [_vp, C.c_uint64, _f64p, _f32p]),
     ("dliom_rtcsm3d_window", C.c_int, [C.POINTER(RtcsmOptions), C.c_float, _f32p, C.c_int64, C.POINTER(RtcsmWindow)]),
     ("dliom_rtcsm3d_last_stats", C.c_int, [_vp, C.POINTER(RtcsmStats)]),
     ("dliom_csm3d_match", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, C.c_int, C.POINTER(_f32p), _i64p,
@@ -487,6 +491,37 @@ class RealTimeCorrelativeScanMatcher3D:
                                                   len(pts), hybrid_grid.h, _p(sums, _u64p), n.value, C.byref(n)),
                "score_volume")
         return sums
+
+
+class RtcsmShard:
+    """One rank's share of a sharded RealTimeCorrelativeScanMatcher3D::Match (BASELINE config 4):
+    the three local phases of include/dliom.h; the two all-reduces live in dliom.sharded."""
+
+    def __init__(self, ctx, options, shard, num_shards):
+        self.ctx = ctx
+        self._L = ctx._L
+        self.options = _rtcsm_opts(options)
+        self.shard, self.num_shards = int(shard), int(num_shards)
+
+    def begin(self, initial_pose_estimate, cloud, hybrid_grid):
+        bits = C.c_uint32()
+        _check(self._L.dliom_rtcsm3d_shard_begin(self.ctx.h, C.byref(self.options), _p(_f64(initial_pose_estimate), _f64p),
+                                                 cloud.h, hybrid_grid.h, self.shard, self.num_shards, C.byref(bits)),
+               "dliom_rtcsm3d_shard_begin")
+        return bits.value
+
+    def finish(self, global_best_lower_bound_bits):
+        packed = C.c_uint64()
+        _check(self._L.dliom_rtcsm3d_shard_finish(self.ctx.h, int(global_best_lower_bound_bits), C.byref(packed)),
+               "dliom_rtcsm3d_shard_finish")
+        return packed.value
+
+    def decode(self, global_best_packed):
+        out = np.zeros(7)
+        score = C.c_float()
+        _check(self._L.dliom_rtcsm3d_shard_decode(self.ctx.h, int(global_best_packed), _p(out, _f64p), C.byref(score)),
+               "dliom_rtcsm3d_shard_decode")
+        return score.value, out
 
 
 def _csm_opts(o):

@@ -151,6 +151,25 @@ int dliom_rtcsm3d_match_cloud(dliom_ctx* ctx, const dliom_rtcsm_options* options
                               const double initial_pose_estimate[7], const dliom_cloud* cloud,
                               const dliom_grid* grid, double pose_estimate[7], float* score);
 
+/* The same match with the search window sharded across GPUs (BASELINE config 4): every rank
+ * holds the cloud and the grid, owns the rotations [shard*R/num_shards, (shard+1)*R/num_shards)
+ * (all translations of each), and the ranks exchange two words:
+ *   begin  -> local best score LOWER BOUND (float bits, non-negative: orders like an integer)
+ *             ... all-reduce MAX over ranks ...
+ *   finish <- that global bound; -> local winner packed as (score_bits << 32) | (0xFFFFFFFF - index)
+ *             ... all-reduce MAX over ranks (the lower index wins ties, like the reference's
+ *             first strictly greater score in generation order, rtcsm_3d.cc:46-51) ...
+ *   decode <- the global word; -> pose_estimate and score, identical on every rank.
+ * With num_shards == 1 the three calls equal dliom_rtcsm3d_match_cloud. */
+int dliom_rtcsm3d_shard_begin(dliom_ctx* ctx, const dliom_rtcsm_options* options,
+                              const double initial_pose_estimate[7], const dliom_cloud* cloud,
+                              const dliom_grid* grid, int shard, int num_shards,
+                              uint32_t* local_best_lower_bound_bits);
+int dliom_rtcsm3d_shard_finish(dliom_ctx* ctx, uint32_t global_best_lower_bound_bits,
+                               uint64_t* local_best_packed);
+int dliom_rtcsm3d_shard_decode(dliom_ctx* ctx, uint64_t global_best_packed, double pose_estimate[7],
+                               float* score);
+
 /* Search-window geometry of the last/next match (rtcsm_3d.cc:58-70). */
 typedef struct dliom_rtcsm_window {
   int linear_window_size;

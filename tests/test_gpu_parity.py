@@ -527,3 +527,28 @@ def test_front_end_drops_and_motion_filter(dl, ctx, orc):
     assert not dfe.insert(1000, pose, g)["inserted"]        # same pose, 0.1 ms later: similar
     assert dfe.insert(int(0.6e7), pose, g)["inserted"]      # max_time_seconds exceeded
     dfe.close()
+
+
+@pytest.mark.parametrize("num_shards", [1, 2, 8])
+def test_sharded_match_single_process(dl, ctx, orc, num_shards):
+    """The three shard phases of the C ABI driven for every shard in one process: merging the
+    shards' words with max() reproduces the unsharded match bit for bit (what the two RCCL
+    all-reduces do across GPUs; the collective itself is covered by tests/test_sharded_gloo.py)."""
+    og, pts, init, _ = _synthetic_case(orc, 16, 256, max_range=15.0)
+    dg = to_device_grid(dl, ctx, og)
+    cloud = dl.PointCloud(ctx, pts)
+    ref_score, ref_pose = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM).Match(init, cloud, dg)
+    ctxs = [dl.Context(0) for _ in range(num_shards)]  # one context per "rank" (state lives in the ctx)
+    clouds = [dl.PointCloud(c, pts) for c in ctxs]
+    shards = [dl.RtcsmShard(c, DEFAULT_RTCSM, s, num_shards) for s, c in enumerate(ctxs)]
+    glo = max(sh.begin(init, cl, dg) for sh, cl in zip(shards, clouds))
+    gbest = max(sh.finish(glo) for sh in shards)
+    for sh in shards:
+        score, pose = sh.decode(gbest)
+        assert score == ref_score and np.array_equal(pose, ref_pose)
+    ref = orc.rtcsm3d_match(DEFAULT_RTCSM, init, pts, og)
+    assert np.array_equal(ref_pose, ref["pose"])
+    for c in clouds:
+        c.close()
+    cloud.close()
+    dg.close()
