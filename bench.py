@@ -170,7 +170,8 @@ def main():
     if rank == 0:
         total_scans = args.steps if sharded_mode else args.steps * world
         value = total_scans / elapsed
-        alg_bytes = 14.0 * C * n_pts  # 12 B point + 2 B voxel per candidate-point pair
+        # 12 B point + 2 B voxel per candidate-point pair (a shard scores C/world of them)
+        alg_bytes = 14.0 * C * n_pts / (world if sharded_mode else 1)
         k_ms = score_ms / max(score_n, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None

@@ -19,6 +19,7 @@ namespace dliom {
 
 constexpr uint32_t kSlotLocked = 0xFFFFFFFFu;
 constexpr int kMaxFlatBits = 7;  // (8<<7)^3 entries = 2^30 fits 32-bit index math
+constexpr int kMaxDenseBits = 4; // dense mirror: (64<<4 + 2)^3 * 2 B = 2.0 GiB
 
 __device__ __forceinline__ bool leaf_table_index(int ix, int iy, int iz, int half, unsigned gsize,
                                                  unsigned L, unsigned* tidx, unsigned* cell) {
@@ -52,18 +53,19 @@ __device__ __forceinline__ void ensure_leaf(uint32_t* table, int32_t* slot_coord
 // HybridGrid::ApplyLookupTable (hybrid_grid.h:509-520) on a 16-bit cell through
 // a 32-bit CAS: cells that already carry the update marker are left alone, so
 // the result does not depend on which thread gets there first.
-__device__ __forceinline__ void apply_table(uint32_t* pool32, size_t value_index,
-                                            const uint16_t* __restrict__ lut) {
+// Returns the value written (with the marker bit) or 0 when the cell was already updated.
+__device__ __forceinline__ uint32_t apply_table(uint32_t* pool32, size_t value_index,
+                                                const uint16_t* __restrict__ lut) {
   uint32_t* word = pool32 + (value_index >> 1);
   const unsigned shift = (value_index & 1u) ? 16u : 0u;
   uint32_t old = *word;
   for (;;) {
     const uint32_t v = (old >> shift) & 0xFFFFu;
-    if (v >= 0x8000u) return;
+    if (v >= 0x8000u) return 0u;
     const uint32_t nv = lut[v];
     const uint32_t desired = (old & ~(0xFFFFu << shift)) | (nv << shift);
     const uint32_t seen = atomicCAS(word, old, desired);
-    if (seen == old) return;
+    if (seen == old) return nv;
     old = seen;
   }
 }
@@ -78,7 +80,15 @@ struct InsertArgs {
   int half;
   unsigned gsize;
   unsigned L;
+  uint16_t* dense;  // write-through dense mirror of the grid (may be null), see ensure_dense()
+  int dense_stride; // cells per axis of the mirror = grid_size + 2 (one guard cell each side)
 };
+
+// Index into the dense mirror: every axis shifted by half + 1 (guard cell).
+__device__ __forceinline__ size_t dense_index(int ix, int iy, int iz, int half, int stride) {
+  return (static_cast<size_t>(iz + half + 1) * stride + static_cast<size_t>(iy + half + 1)) * stride +
+         static_cast<size_t>(ix + half + 1);
+}
 
 // range_data_inserter_3d.cc:36-50: the k-th sample on the ray origin->hit in
 // Array3i arithmetic (int multiply, truncating int division).
@@ -155,7 +165,10 @@ __global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ t
     if (leaf_table_index(hx, hy, hz, a.half, a.gsize, a.L, &tidx, &cell)) {
       const size_t vi = static_cast<size_t>(table[tidx]) * 512u + cell;
       if (MODE == 0) {
-        apply_table(pool32, vi, lut);
+        const uint32_t nv = apply_table(pool32, vi, lut);
+        // each cell is written at most once per Insert: the mirror takes the final value
+        if (nv != 0u && a.dense != nullptr)
+          a.dense[dense_index(hx, hy, hz, a.half, a.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
       } else {
         atomicAnd(pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
       }
@@ -172,7 +185,9 @@ __global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ t
       if (!leaf_table_index(mx, my, mz, a.half, a.gsize, a.L, &tidx, &cell)) continue;
       const size_t vi = static_cast<size_t>(table[tidx]) * 512u + cell;
       if (MODE == 1) {
-        apply_table(pool32, vi, lut);
+        const uint32_t nv = apply_table(pool32, vi, lut);
+        if (nv != 0u && a.dense != nullptr)
+          a.dense[dense_index(mx, my, mz, a.half, a.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
       } else {
         atomicAnd(pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
       }
@@ -190,6 +205,17 @@ __global__ void rebuild_table_kernel(const int32_t* __restrict__ slot_coord, uin
   const unsigned ly = static_cast<unsigned>(slot_coord[3 * static_cast<size_t>(s) + 1] + leaf_half);
   const unsigned lz = static_cast<unsigned>(slot_coord[3 * static_cast<size_t>(s) + 2] + leaf_half);
   table[(lz * L + ly) * L + lx] = s;
+}
+
+// Dense mirror (re)build: one workgroup per allocated leaf copies its 512 cells.
+__global__ void dense_fill_kernel(const int32_t* __restrict__ slot_coord, const uint16_t* __restrict__ pool,
+                                  uint16_t* __restrict__ dense, int half, int stride) {
+  const size_t s = static_cast<size_t>(blockIdx.x) + 1;  // slot 0 is the null leaf
+  const int bx = slot_coord[3 * s] * 8, by = slot_coord[3 * s + 1] * 8, bz = slot_coord[3 * s + 2] * 8;
+  for (int c = threadIdx.x; c < 512; c += blockDim.x) {
+    const uint16_t v = pool[s * 512 + c] & 0x7FFFu;
+    dense[dense_index(bx + (c & 7), by + ((c >> 3) & 7), bz + (c >> 6), half, stride)] = v;
+  }
 }
 
 __global__ void upload_alloc_kernel(const int32_t* __restrict__ origins, int64_t n, uint32_t* table,
@@ -292,6 +318,8 @@ GridView dliom_grid::view() const {
   v.resolution = resolution;
   v.inv_resolution = 1.f / resolution;
   v.log2_leaves = bits + 3;
+  v.dense = d_dense;
+  v.dense_stride = dense_stride;
   return v;
 }
 
@@ -331,6 +359,36 @@ int dliom_grid::ensure_bits(int needed_bits) {
   DLIOM_HIP_TRY(hipFree(d_table));
   d_table = new_table;
   bits = needed_bits;
+  drop_dense();  // wrong extent now; rebuilt lazily by the next match
+  return DLIOM_OK;
+}
+
+void dliom_grid::drop_dense() {
+  if (d_dense != nullptr) (void)hipFree(d_dense);
+  d_dense = nullptr;
+  dense_stride = 0;
+}
+
+// Dense mirror of the grid for the correlative matcher: (grid_size + 2)^3 uint16, linear z-major,
+// one guard cell per side (always 0), marker bit stripped.  Spends HBM capacity (258 MiB at
+// bits = 3, 2.0 GiB at bits = 4) to make a voxel lookup ONE load at a linear address instead of
+// leaf-table load + leaf load; kept in sync by the insertion kernels (write-through) and rebuilt
+// from the leaf pool after uploads or growth.  Grids beyond bits = 4 stay on the leaf path.
+int dliom_grid::ensure_dense() {
+  if (d_dense != nullptr) return DLIOM_OK;
+  if (bits > kMaxDenseBits) return DLIOM_ERR_GRID_EXTENT;
+  const int stride = (64 << bits) + 2;
+  const size_t cells = static_cast<size_t>(stride) * stride * stride;
+  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_dense), cells * sizeof(uint16_t)));
+  DLIOM_HIP_TRY(hipMemsetAsync(d_dense, 0, cells * sizeof(uint16_t), ctx->stream));
+  int64_t count = 0;
+  DLIOM_TRY(refresh_count(&count));
+  if (count > 1) {
+    hipLaunchKernelGGL(dense_fill_kernel, dim3(static_cast<unsigned>(count - 1)), dim3(256), 0, ctx->stream,
+                       d_slot_coord, d_pool, d_dense, 32 << bits, stride);
+    DLIOM_HIP_TRY(hipGetLastError());
+  }
+  dense_stride = stride;
   return DLIOM_OK;
 }
 
@@ -412,6 +470,7 @@ int dliom_grid_destroy(dliom_grid* g) {
   if (g->d_pool) (void)hipFree(g->d_pool);
   if (g->d_slot_coord) (void)hipFree(g->d_slot_coord);
   if (g->d_count) (void)hipFree(g->d_count);
+  if (g->d_dense) (void)hipFree(g->d_dense);
   delete g;
   return DLIOM_OK;
 }
@@ -461,6 +520,7 @@ int dliom_grid_upload_blocks(dliom_grid* g, const int32_t* origins, const uint16
   DLIOM_HIP_TRY(hipGetLastError());
   g->used_upper += n;
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // host buffers may be reused by the caller
+  g->drop_dense();
   return DLIOM_OK;
 }
 
@@ -520,6 +580,7 @@ int dliom_grid_set_values(dliom_grid* g, const int32_t* cells, const uint16_t* v
   DLIOM_HIP_TRY(hipGetLastError());
   g->used_upper += n;
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  g->drop_dense();
   return DLIOM_OK;
 }
 
@@ -564,6 +625,8 @@ static int insert_device(dliom_grid* g, const float origin[3], const float* d_re
   a.half = 0;
   a.gsize = 0;
   a.L = 0;
+  a.dense = nullptr;
+  a.dense_stride = 0;
   const dim3 grid(blocks_for(n, 256)), block(256);
   hipLaunchKernelGGL(insert_scan_kernel, grid, block, 0, ctx->stream, a, d_scan);
   DLIOM_HIP_TRY(hipGetLastError());
@@ -579,6 +642,8 @@ static int insert_device(dliom_grid* g, const float origin[3], const float* d_re
   a.half = v.half;
   a.gsize = v.grid_size;
   a.L = static_cast<unsigned>(v.leaves_per_axis);
+  a.dense = g->d_dense;  // write-through when the mirror exists
+  a.dense_stride = g->dense_stride;
   uint32_t* pool32 = reinterpret_cast<uint32_t*>(g->d_pool);
   hipLaunchKernelGGL(insert_alloc_kernel, grid, block, 0, ctx->stream, a, g->d_table, g->d_slot_coord,
                      g->d_count);

@@ -53,6 +53,8 @@ struct GridView {
   float resolution;
   float inv_resolution;   // fl(1 / resolution): fast path of the score kernel only
   int log2_leaves;        // log2(leaves_per_axis) = bits + 3
+  const uint16_t* dense;  // dense mirror (grid_size + 2)^3, null when absent
+  int dense_stride;       // grid_size + 2
 };
 
 }  // namespace dliom
@@ -101,6 +103,10 @@ struct dliom_grid {
   uint32_t* d_count = nullptr;  // number of used slots including slot 0
   int64_t capacity = 0;         // slots
   int64_t used_upper = 1;       // host-side upper bound of *d_count
+  uint16_t* d_dense = nullptr;  // optional dense mirror for the correlative matcher (grid.hip)
+  int dense_stride = 0;
+  int ensure_dense();
+  void drop_dense();
   dliom::GridView view() const;
   int ensure_bits(int needed_bits);
   int ensure_capacity(int64_t additional_slots);

@@ -108,6 +108,174 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------- kernel A'
+// Lanes = candidate ROTATIONS, points are wave-uniform.  grid = (rotation groups of 256, point
+// chunks).  Each lane owns one rotation (its quaternion stays in 4 VGPRs) and TC integer
+// accumulators, one per translation; the block streams its chunk of points through scalar
+// registers (P at a time), rotates each point per lane and looks up the TC translated positions.
+// Why: the 64 lanes of a gather now differ only by a few milliradians of rotation of the SAME
+// point, so they fall into a handful of neighbouring voxels -- a gather touches ~4 cache lines
+// instead of ~40, which removes the texture-addresser bound of the points-per-lane mapping
+// (profiles/).  There is no cross-lane reduction at all: a lane's accumulators ARE its
+// candidates' partial sums, added to the score volume with 64-lane contiguous atomics.
+template <int TC, int P>
+__global__ __launch_bounds__(kBlock) void rtcsm_score_rot_kernel(
+    GridView g, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, int points_per_chunk, const float4* __restrict__ rot, int R,
+    int r_first, int r_last, const float4* __restrict__ trans4, int T,
+    unsigned long long* __restrict__ sums) {
+  // LDS: the T translations (read as wave-wide broadcasts) and one accumulator column per lane
+  // (TC rows): `lds_acc[jj][lane]` is touched by that lane only -- no conflicts, no barriers.
+  extern __shared__ float4 lds_trans[];
+  __shared__ unsigned lds_acc[TC][kBlock];
+  for (int j = threadIdx.x; j < T; j += kBlock) lds_trans[j] = trans4[j];
+  __syncthreads();
+  const int r = r_first + blockIdx.x * kBlock + threadIdx.x;
+  const bool active = r < r_last;
+  const float4 qq = rot[active ? r : r_first];
+  const Quat4 q{qq.x, qq.y, qq.z, qq.w};  // stored (w,x,y,z)
+  const float inv = g.inv_resolution;
+  const unsigned sentinel = 1u << (3 * g.log2_leaves);  // table[L^3] is always 0 (null leaf)
+  const unsigned lb = static_cast<unsigned>(g.log2_leaves);
+  const int p_begin = blockIdx.y * points_per_chunk;
+  const int p_end = p_begin + points_per_chunk;  // the cloud is padded: no tail handling
+  for (int jc = 0; jc < T; jc += TC) {
+    const int tc = min(TC, T - jc);
+    for (int jj = 0; jj < tc; ++jj) lds_acc[jj][threadIdx.x] = 0u;
+#pragma unroll 1
+    for (int i = p_begin; i < p_end; i += P) {
+      float rx[P], ry[P], rz[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k) rotate_point(q, px[i + k], py[i + k], pz[i + k], rx[k], ry[k], rz[k]);
+#pragma unroll 1
+      for (int jj = 0; jj < tc; ++jj) {
+        const float4 t = lds_trans[jc + jj];  // same address in every lane: LDS broadcast
+        unsigned tix[P], cel[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          const float cx = rx[k] + t.x, cy = ry[k] + t.y, cz = rz[k] + t.z;
+          bool near = false;
+          int ix = cell_fast(cx, inv, &near);
+          int iy = cell_fast(cy, inv, &near);
+          int iz = cell_fast(cz, inv, &near);
+          if (__builtin_expect(near, 0)) {  // within rounding reach of a cell boundary: exact path
+            ix = cell_of(cx, g.resolution);
+            iy = cell_of(cy, g.resolution);
+            iz = cell_of(cz, g.resolution);
+          }
+          const unsigned sx = static_cast<unsigned>(ix + g.half);
+          const unsigned sy = static_cast<unsigned>(iy + g.half);
+          const unsigned sz = static_cast<unsigned>(iz + g.half);
+          const bool inside = (sx | sy | sz) < g.grid_size;  // grid_size is a power of two
+          const unsigned tt = (((sz >> 3) << lb | (sy >> 3)) << lb) | (sx >> 3);
+          tix[k] = inside ? tt : sentinel;
+          cel[k] = ((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u);
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) tix[k] = g.table[tix[k]];
+#pragma unroll
+        for (int k = 0; k < P; ++k) cel[k] = g.pool[(tix[k] << 9) | cel[k]];
+        unsigned a = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) a += max(cel[k] & 0x7FFFu, 1u);
+        atomicAdd(&lds_acc[jj][threadIdx.x], a);  // ds_add_u32, own column
+      }
+    }
+    if (active) {
+      for (int jj = 0; jj < tc; ++jj)
+        atomicAdd(&sums[static_cast<size_t>(jc + jj) * R + r],
+                  static_cast<unsigned long long>(lds_acc[jj][threadIdx.x]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- kernel A''
+// The same rotation-per-lane walk over the DENSE MIRROR of the grid (grid.hip::ensure_dense):
+// one load per lookup at a linear address, no leaf table, no leaf/cell bit surgery.
+//   y' = fma(c, 1/res, K)   K = half + 1 shifts the index into the mirror's [0, S) range for free
+//   near <=> min_c |frac(y'_c) - 1/2| <= 4 S 2^-24      (then: exact lround(c / res) path)
+//   i'  = v_cvt_rpi_i32_f32(y')  (floor(y' + 1/2): equals lround away from the near band)
+//   clamp to [0, S-1] (guard cells are 0 = "outside / unknown"), address = (iz' S + iy') S + ix'.
+// Error budget: fl(1/res) and the fma rounding put y' - K within (|q| + |y'|) 2^-24 of the real
+// quotient q = c/res, and the reference's lround(fl(q)) can only flip when q is within |q| 2^-24
+// of a half-integer; all three terms are < S, so 4 S 2^-24 is a safe band (~1e-4: the exact path
+// runs for ~3 % of the wave-rows).
+__device__ __forceinline__ int cvt_rpi(float y) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(y));
+  return r;
+}
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void rtcsm_score_dense_kernel(
+    GridView g, const float* __restrict__ px, const float* __restrict__ py,
+    const float* __restrict__ pz, int points_per_chunk, const float4* __restrict__ rot, int R,
+    int r_first, int r_last, const float4* __restrict__ trans4, int T, int t_chunk,
+    unsigned long long* __restrict__ sums) {
+  extern __shared__ float4 lds_dyn[];  // [T translations | t_chunk x 256 accumulators]
+  float4* lds_trans = lds_dyn;
+  unsigned* lds_acc = reinterpret_cast<unsigned*>(lds_dyn + T);
+  for (int j = threadIdx.x; j < T; j += kBlock) lds_trans[j] = trans4[j];
+  __syncthreads();
+  const int r = r_first + blockIdx.x * kBlock + threadIdx.x;
+  const bool active = r < r_last;
+  const float4 qq = rot[active ? r : r_first];
+  const Quat4 q{qq.x, qq.y, qq.z, qq.w};  // stored (w,x,y,z)
+  const float inv = g.inv_resolution;
+  const int S = g.dense_stride;
+  const float K = static_cast<float>(g.half + 1);
+  const float band = 4.f * static_cast<float>(S) * 5.9604645e-8f;
+  const int p_begin = blockIdx.y * points_per_chunk;
+  const int p_end = p_begin + points_per_chunk;  // the cloud is padded: no tail handling
+  for (int jc = 0; jc < T; jc += t_chunk) {
+    const int tc = min(t_chunk, T - jc);
+    for (int jj = 0; jj < tc; ++jj) lds_acc[jj * kBlock + threadIdx.x] = 0u;
+#pragma unroll 1
+    for (int i = p_begin; i < p_end; i += P) {
+      float rx[P], ry[P], rz[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k) rotate_point(q, px[i + k], py[i + k], pz[i + k], rx[k], ry[k], rz[k]);
+#pragma unroll 1
+      for (int jj = 0; jj < tc; ++jj) {
+        const float4 t = lds_trans[jc + jj];  // same address in every lane: LDS broadcast
+        unsigned off[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          const float cx = rx[k] + t.x, cy = ry[k] + t.y, cz = rz[k] + t.z;
+          const float yx = __builtin_fmaf(cx, inv, K), yy = __builtin_fmaf(cy, inv, K),
+                      yz = __builtin_fmaf(cz, inv, K);
+          const float dx = __builtin_amdgcn_fractf(yx) - 0.5f, dy = __builtin_amdgcn_fractf(yy) - 0.5f,
+                      dz = __builtin_amdgcn_fractf(yz) - 0.5f;
+          const float m = fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz));
+          int ix = cvt_rpi(yx), iy = cvt_rpi(yy), iz = cvt_rpi(yz);
+          if (__builtin_expect(m <= band, 0)) {  // within rounding reach of a cell boundary: exact path
+            ix = cell_of(cx, g.resolution) + g.half + 1;
+            iy = cell_of(cy, g.resolution) + g.half + 1;
+            iz = cell_of(cz, g.resolution) + g.half + 1;
+          }
+          ix = min(max(ix, 0), S - 1);
+          iy = min(max(iy, 0), S - 1);
+          iz = min(max(iz, 0), S - 1);
+          off[k] = (static_cast<unsigned>(iz) * static_cast<unsigned>(S) + static_cast<unsigned>(iy)) *
+                       static_cast<unsigned>(S) + static_cast<unsigned>(ix);
+        }
+        unsigned v[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) v[k] = g.dense[off[k]];
+        unsigned a = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) a += max(v[k], 1u);  // the mirror stores marker-free values
+        atomicAdd(&lds_acc[jj * kBlock + threadIdx.x], a);  // ds_add_u32, own column
+      }
+    }
+    if (active) {
+      for (int jj = 0; jj < tc; ++jj)
+        atomicAdd(&sums[static_cast<size_t>(jc + jj) * R + r],
+                  static_cast<unsigned long long>(lds_acc[jj * kBlock + threadIdx.x]));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- kernel B
 struct BoundParams {
   double a;        // (double)kScale
@@ -346,6 +514,7 @@ static void generate_candidates(const dliom_rtcsm_options& o, float resolution, 
 struct DeviceCandidates {
   float4* rot;
   float* trans;    // T x 3
+  float4* trans4;  // T x (x,y,z,0): 16-byte rows for the rotation-per-lane kernel
   float* t_norm;
   float* r_angle;
 };
@@ -357,7 +526,8 @@ static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidat
   const size_t bytes_trans = (Tpad * 12 + 255) & ~static_cast<size_t>(255);
   const size_t bytes_tn = (T * 4 + 255) & ~static_cast<size_t>(255);
   const size_t bytes_ra = (R * 4 + 255) & ~static_cast<size_t>(255);
-  const size_t total = bytes_rot + bytes_trans + bytes_tn + bytes_ra;
+  const size_t bytes_t4 = (T * 16 + 255) & ~static_cast<size_t>(255);
+  const size_t total = bytes_rot + bytes_trans + bytes_tn + bytes_ra + bytes_t4;
   DLIOM_TRY(ctx->cand.reserve(total));
   std::vector<char> host(total, 0);
   float* hr = reinterpret_cast<float*>(host.data());
@@ -376,6 +546,13 @@ static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidat
   }
   std::memcpy(host.data() + bytes_rot + bytes_trans, c.t_norm.data(), T * 4);
   std::memcpy(host.data() + bytes_rot + bytes_trans + bytes_tn, c.r_angle.data(), R * 4);
+  float* h4 = reinterpret_cast<float*>(host.data() + bytes_rot + bytes_trans + bytes_tn + bytes_ra);
+  for (size_t i = 0; i < T; ++i) {
+    h4[4 * i] = c.trans[i].x;
+    h4[4 * i + 1] = c.trans[i].y;
+    h4[4 * i + 2] = c.trans[i].z;
+    h4[4 * i + 3] = 0.f;
+  }
   char* base = static_cast<char*>(ctx->cand.p);
   if (total <= ctx->pinned_bytes) {
     // Pinned staging: truly asynchronous.  Every entry point that gets here synchronises the
@@ -390,6 +567,7 @@ static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidat
   d->trans = reinterpret_cast<float*>(base + bytes_rot);
   d->t_norm = reinterpret_cast<float*>(base + bytes_rot + bytes_trans);
   d->r_angle = reinterpret_cast<float*>(base + bytes_rot + bytes_trans + bytes_tn);
+  d->trans4 = reinterpret_cast<float4*>(base + bytes_rot + bytes_trans + bytes_tn + bytes_ra);
   return DLIOM_OK;
 }
 
@@ -408,40 +586,95 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   DLIOM_TRY(ctx->sums.reserve(static_cast<size_t>(C) * 8));
   *d_sums = ctx->sums.as<unsigned long long>();
   DLIOM_HIP_TRY(hipMemsetAsync(*d_sums, 0, static_cast<size_t>(C) * 8, ctx->stream));
-  const GridView g = grid->view();
   const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
   const int n = static_cast<int>(cloud.n);
-  // points per thread (registers) x rotation tiles: keep a few thousand workgroups in flight
-  static const int forced_ppt = env_int("DLIOM_SCORE_PPT", 0);  // tuning knobs
+  // 2: rotation per lane over the dense mirror (default when the grid allows it),
+  // 1: rotation per lane over the leaf table, 0: point per lane over the leaf table
+  static const int wanted_mapping = env_int("DLIOM_SCORE_MAPPING", 2);
+  int mapping = wanted_mapping;
+  if (mapping == 2) {
+    // the mirror is a cache of the grid's contents: building it does not change the grid
+    if (const_cast<dliom_grid*>(grid)->ensure_dense() != DLIOM_OK) mapping = 1;  // too large: leaf path
+  }
+  const GridView g = grid->view();
+  static const int forced_ppt = env_int("DLIOM_SCORE_PPT", 0);   // tuning knobs
   static const int target_blocks = env_int("DLIOM_SCORE_BLOCKS", 4096);
-  static const int debug_no_atomic = env_int("DLIOM_DEBUG_NO_ATOMIC", 0);
-  int ppt = forced_ppt > 0 ? forced_ppt : (n >= 32 * 1024 ? 8 : (n >= 8 * 1024 ? 4 : (n >= 2048 ? 2 : 1)));
-  while (ppt > 1 && (cloud.n_padded % (static_cast<int64_t>(kBlock) * ppt)) != 0) ppt >>= 1;
-  const int tile = kBlock * ppt;
-  const int point_tiles = (n + tile - 1) / tile;
   const int Rs = r_last - r_first;  // rotations of this shard
-  int rot_tiles = std::max(1, std::min(Rs, (target_blocks + point_tiles - 1) / point_tiles));
-  const int rots_per_block = (Rs + rot_tiles - 1) / rot_tiles;
-  rot_tiles = (Rs + rots_per_block - 1) / rots_per_block;
-  const dim3 grid_dim(point_tiles, rot_tiles), block(kBlock);
-  const size_t lds = static_cast<size_t>(T) * sizeof(unsigned);
-  if (lds > 150 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;  // (2L+1)^3 translations must fit LDS
-  const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
-#define DLIOM_LAUNCH_SCORE(P)                                                                    \
-  hipLaunchKernelGGL((rtcsm_score_kernel<P>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,  \
+  int span = -1;
+  int64_t processed = 0;
+  if (mapping >= 1) {
+    static const int forced_chunk = env_int("DLIOM_SCORE_CHUNK", 0);
+    const int rot_groups = (Rs + kBlock - 1) / kBlock;
+    // points per chunk: a multiple of 4 dividing the 4096-point padding; aim at >= target blocks
+    int chunk = 4096;
+    while (chunk > 64 && static_cast<int64_t>(rot_groups) * ((n + chunk - 1) / chunk) < target_blocks) chunk >>= 1;
+    if (forced_chunk > 0) chunk = forced_chunk;
+    const int point_chunks = (n + chunk - 1) / chunk;
+    processed = static_cast<int64_t>(point_chunks) * chunk;
+    const dim3 grid_dim(rot_groups, point_chunks), block(kBlock);
+    span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
+    static const int pts_per_iter = env_int("DLIOM_SCORE_P", 4);
+    const size_t lds = static_cast<size_t>(T) * 16;
+    if (lds > 100 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;
+    if (mapping == 2) {
+      const int t_chunk = std::min(T, 27);
+      const size_t lds2 = lds + static_cast<size_t>(t_chunk) * kBlock * 4;
+      if (pts_per_iter == 8) {
+        hipLaunchKernelGGL((rtcsm_score_dense_kernel<8>), grid_dim, block, lds2, ctx->stream, g, cloud.d_xs,
+                           cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
+                           *d_sums);
+      } else if (pts_per_iter == 2) {
+        hipLaunchKernelGGL((rtcsm_score_dense_kernel<2>), grid_dim, block, lds2, ctx->stream, g, cloud.d_xs,
+                           cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
+                           *d_sums);
+      } else {
+        hipLaunchKernelGGL((rtcsm_score_dense_kernel<4>), grid_dim, block, lds2, ctx->stream, g, cloud.d_xs,
+                           cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
+                           *d_sums);
+      }
+    } else if (T == 1) {
+      hipLaunchKernelGGL((rtcsm_score_rot_kernel<1, 4>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,
+                         cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, *d_sums);
+    } else if (pts_per_iter == 2) {
+      hipLaunchKernelGGL((rtcsm_score_rot_kernel<27, 2>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,
+                         cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, *d_sums);
+    } else if (pts_per_iter == 8) {
+      hipLaunchKernelGGL((rtcsm_score_rot_kernel<27, 8>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,
+                         cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, *d_sums);
+    } else {
+      hipLaunchKernelGGL((rtcsm_score_rot_kernel<27, 4>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,
+                         cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, *d_sums);
+    }
+  } else {
+    static const int debug_no_atomic = env_int("DLIOM_DEBUG_NO_ATOMIC", 0);
+    int ppt = forced_ppt > 0 ? forced_ppt : (n >= 32 * 1024 ? 8 : (n >= 8 * 1024 ? 4 : (n >= 2048 ? 2 : 1)));
+    while (ppt > 1 && (cloud.n_padded % (static_cast<int64_t>(kBlock) * ppt)) != 0) ppt >>= 1;
+    const int tile = kBlock * ppt;
+    const int point_tiles = (n + tile - 1) / tile;
+    processed = static_cast<int64_t>(point_tiles) * tile;
+    int rot_tiles = std::max(1, std::min(Rs, (target_blocks + point_tiles - 1) / point_tiles));
+    const int rots_per_block = (Rs + rot_tiles - 1) / rot_tiles;
+    rot_tiles = (Rs + rots_per_block - 1) / rots_per_block;
+    const dim3 grid_dim(point_tiles, rot_tiles), block(kBlock);
+    const size_t lds = static_cast<size_t>(T) * sizeof(unsigned);
+    if (lds > 150 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;  // (2L+1)^3 translations must fit LDS
+    span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
+#define DLIOM_LAUNCH_SCORE(PP)                                                                    \
+  hipLaunchKernelGGL((rtcsm_score_kernel<PP>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,  \
                      cloud.d_ys, cloud.d_zs, d->rot, R, r_first, r_last, d->trans, T,             \
                      rots_per_block, *d_sums, debug_no_atomic)
-  switch (ppt) {
-    case 16: DLIOM_LAUNCH_SCORE(16); break;
-    case 8: DLIOM_LAUNCH_SCORE(8); break;
-    case 4: DLIOM_LAUNCH_SCORE(4); break;
-    case 2: DLIOM_LAUNCH_SCORE(2); break;
-    default: DLIOM_LAUNCH_SCORE(1); break;
-  }
+    switch (ppt) {
+      case 16: DLIOM_LAUNCH_SCORE(16); break;
+      case 8: DLIOM_LAUNCH_SCORE(8); break;
+      case 4: DLIOM_LAUNCH_SCORE(4); break;
+      case 2: DLIOM_LAUNCH_SCORE(2); break;
+      default: DLIOM_LAUNCH_SCORE(1); break;
+    }
 #undef DLIOM_LAUNCH_SCORE
+  }
   ctx->end_span(span);
   DLIOM_HIP_TRY(hipGetLastError());
-  *pad_processed = static_cast<int64_t>(point_tiles) * tile - n;
+  *pad_processed = processed - n;
   return DLIOM_OK;
 }
 
