@@ -170,6 +170,8 @@ SYMBOLS = [
                                                 C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_voxel_filter", C.c_int, [C.c_float, _f32p, C.c_int64, _f32p, _i64p]),
     ("dliom_adaptive_voxel_filter", C.c_int, [C.POINTER(AdaptiveVoxelFilterOptions), _f32p, C.c_int64, _f32p, _i64p]),
+    ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
+                                      C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
     ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
     ("dliom_rtcsm3d_score_volume", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _u64p,
                                              C.c_int64, _i64p]),
@@ -696,3 +698,23 @@ class LocalTrajectoryBuilder3D:
                                                      C.byref(hi), C.byref(lo)), "active_submap")
         return dict(local_pose=pose, num_range_data=n.value, finished=bool(fin.value),
                     hi=_BorrowedGrid(self.ctx, hi, self.resolutions[0]), lo=_BorrowedGrid(self.ctx, lo, self.resolutions[1]))
+
+
+class RealTimeCorrelativeScanMatcher2D:
+    """BASELINE config 1: the 2D matcher over a dense ProbabilityGrid, host only by contract."""
+
+    def __init__(self, options):
+        self._L = load_library()
+        self.options = _rtcsm_opts(options)
+
+    def Match(self, initial_pose_estimate, point_cloud, cells, resolution, max_xy):
+        """cells: uint16 [num_y_cells, num_x_cells] correspondence-cost values.  Returns (score, pose[3])."""
+        pts = _f32(point_cloud).reshape(-1, 3)
+        cells = np.ascontiguousarray(cells, dtype=np.uint16)
+        out = np.zeros(3)
+        score = C.c_double()
+        _check(self._L.dliom_rtcsm2d_match(C.byref(self.options), _p(_f64(initial_pose_estimate), _f64p),
+                                           _p(pts, _f32p), len(pts), _p(cells, _u16p), cells.shape[1], cells.shape[0],
+                                           resolution, max_xy[0], max_xy[1], _p(out, _f64p), C.byref(score)),
+               "dliom_rtcsm2d_match")
+        return score.value, out

@@ -313,6 +313,17 @@ int dliom_voxel_filter(float size, const float* points_xyz, int64_t n, float* ou
 int dliom_adaptive_voxel_filter(const dliom_adaptive_voxel_filter_options* options, const float* points_xyz,
                                 int64_t n, float* out_xyz, int64_t* num_out);
 
+/* ---- RealTimeCorrelativeScanMatcher2D (BASELINE config 1: host only, by contract) -------------
+ * double Match(initial_pose_estimate, point_cloud, probability_grid, pose_estimate)
+ * (mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h:66-69, .cc:74-108).
+ * Poses are [x, y, theta].  The ProbabilityGrid is passed as what it stores: num_x_cells *
+ * num_y_cells uint16 correspondence-cost cells, row-major num_x_cells * y + x
+ * (mapping/2d/grid_2d.cc:168-171), with MapLimits{resolution, max} (mapping/2d/map_limits.h). */
+int dliom_rtcsm2d_match(const dliom_rtcsm_options* options, const double initial_pose_estimate[3],
+                        const float* points_xyz, int64_t n, const uint16_t* correspondence_cost_cells,
+                        int num_x_cells, int num_y_cells, double resolution, double max_x, double max_y,
+                        double pose_estimate[3], double* score);
+
 /* ---- diagnostics used by the parity tests and bench.py ------------------------
  * These expose intermediate results of the same device code the matchers run. */
 /* Cell index of R(pose)*p + t per point, computed by the score kernel's own

@@ -111,6 +111,7 @@ def _declare(L):
     sig("orc_pg_probability", C.c_float, vp, C.c_int, C.c_int)
     sig("orc_pg_cell_index", None, vp, C.c_float, C.c_float, _i32p)
     sig("orc_pg_cells", None, vp, _u16p)
+    sig("orc_pg_limits", None, vp, _f64p)
     sig("orc_pg_insert", None, vp, _f32p, _f32p, C.c_int, C.c_double, C.c_double, C.c_int)
     sig("orc_rtcsm2d_match", C.c_double, _f64p, _f64p, _f32p, C.c_int, vp, _f64p)
     sig("orc_rtcsm2d_score_single", C.c_float, _f64p, _f32p, C.c_int, vp, C.c_int, C.c_int)
@@ -476,6 +477,16 @@ class ProbabilityGrid:
     def cell_index(self, px, py):
         out = np.zeros(2, dtype=np.int32)
         self._L.orc_pg_cell_index(self.h, C.c_float(px), C.c_float(py), _p(out, _i32p))
+        return out
+
+    def cells(self):
+        """uint16 correspondence-cost cells [num_y_cells, num_x_cells] (the grid may have grown)."""
+        lim = np.zeros(5)
+        self._L.orc_pg_limits(self.h, _p(lim, _f64p))
+        self.resolution, self.max_xy = lim[0], (lim[1], lim[2])
+        self.num_x_cells, self.num_y_cells = int(lim[3]), int(lim[4])
+        out = np.zeros((self.num_y_cells, self.num_x_cells), dtype=np.uint16)
+        self._L.orc_pg_cells(self.h, _p(out, _u16p))
         return out
 
     def insert(self, origin, returns, hit_probability, miss_probability, insert_free_space=True):

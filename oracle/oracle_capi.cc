@@ -447,6 +447,10 @@ void orc_pg_cell_index(void* g, float px, float py, int* out2) {
   const Cell2 c = static_cast<ProbabilityGrid*>(g)->limits().GetCellIndex(px, py);
   out2[0] = c.x; out2[1] = c.y;
 }
+void orc_pg_limits(void* g, double* out5) {
+  const MapLimits& l = static_cast<ProbabilityGrid*>(g)->limits();
+  out5[0] = l.resolution; out5[1] = l.max_x; out5[2] = l.max_y; out5[3] = l.num_x_cells; out5[4] = l.num_y_cells;
+}
 void orc_pg_cells(void* g, uint16_t* out) {
   const std::vector<uint16>& c = static_cast<ProbabilityGrid*>(g)->cells();
   std::memcpy(out, c.data(), c.size() * sizeof(uint16_t));

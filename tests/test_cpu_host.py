@@ -101,3 +101,40 @@ def test_voxel_filters_equal_oracle(dl, orc):
         assert np.array_equal(dl.voxel_filter(size, pts), pts[orc.voxel_filter(size, pts)])
     for (ml, mn, mr) in ((2.0, 150, 15.0), (4.0, 200, 60.0), (0.5, 5000, 60.0), (2.0, 1e9, 60.0), (2.0, 150, 0.5)):
         assert np.array_equal(dl.adaptive_voxel_filter(ml, mn, mr, pts), orc.adaptive_voxel_filter(ml, mn, mr, pts))
+
+
+def test_rtcsm2d_config1_equals_oracle(dl, orc):
+    """BASELINE config 1: a 16-beam x 512 scan projected to z = 0 against one 2D ProbabilityGrid
+    submap; the product's host RealTimeCorrelativeScanMatcher2D vs the oracle (bit-equal pose and
+    score), plus the reference's own KAT (rtcsm_2d_test.cc:37-122) through the product."""
+    from dliom import synth
+    opts = dict(linear_search_window=0.1, angular_search_window=float(np.deg2rad(2.0)),
+                translation_delta_cost_weight=1e-1, rotation_delta_cost_weight=1e-1)
+    pg = orc.ProbabilityGrid(0.05, (1.0, 1.0), 40, 40)  # grows as scans are inserted
+    for s in range(3):
+        pose = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(pose, 16, 512)
+        world = synth.transform_points(pose, pts)
+        world[:, 2] = 0.0
+        pg.insert((pose[0], pose[1], 0.0), world, 0.55, 0.49, True)
+    cells = pg.cells()
+    truth = synth.trajectory_pose(0.3)
+    pts, _ = synth.scan(truth, 16, 512)
+    flat = pts.copy()
+    flat[:, 2] = 0.0
+    yaw = 2.0 * np.arctan2(truth[6], truth[3])
+    init = np.array([truth[0] + 0.04, truth[1] - 0.03, yaw + 0.01])
+    ref = orc.rtcsm2d_match(opts, init, flat, pg)
+    score, pose = dl.RealTimeCorrelativeScanMatcher2D(opts).Match(init, flat, cells, pg.resolution, pg.max_xy)
+    assert np.float32(score) == np.float32(ref["score"])
+    assert np.array_equal(pose, ref["pose"])
+    # reference KAT
+    kat = orc.ProbabilityGrid(0.05, (0.05, 0.25), 6, 6)
+    pc = np.array([[0.025, 0.175, 0], [-0.025, 0.175, 0], [-0.075, 0.175, 0], [-0.125, 0.175, 0],
+                   [-0.125, 0.125, 0], [-0.125, 0.075, 0], [-0.125, 0.025, 0]], dtype=np.float32)
+    kat.insert((0, 0, 0), pc, 0.7, 0.4, True)
+    k = dict(linear_search_window=0.6, angular_search_window=0.16, translation_delta_cost_weight=0.0,
+             rotation_delta_cost_weight=0.0)
+    score, pose = dl.RealTimeCorrelativeScanMatcher2D(k).Match((0.0, 0.0, 0.0), pc, kat.cells(), kat.resolution,
+                                                               kat.max_xy)
+    assert abs(score - 0.7) < 1e-2 and np.allclose(pose, 0.0, atol=1e-9)
