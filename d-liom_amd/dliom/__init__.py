@@ -170,6 +170,8 @@ SYMBOLS = [
                                                 C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_voxel_filter", C.c_int, [C.c_float, _f32p, C.c_int64, _f32p, _i64p]),
     ("dliom_adaptive_voxel_filter", C.c_int, [C.POINTER(AdaptiveVoxelFilterOptions), _f32p, C.c_int64, _f32p, _i64p]),
+    ("dliom_deskew", C.c_int, [_vp, _f64p, _f64p, C.c_double, _f32p, C.c_int64, _f32p, C.c_float, C.c_float, _f32p,
+                               C.POINTER(C.c_uint8), _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
     ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
@@ -718,3 +720,73 @@ class RealTimeCorrelativeScanMatcher2D:
                                            resolution, max_xy[0], max_xy[1], _p(out, _f64p), C.byref(score)),
                "dliom_rtcsm2d_match")
         return score.value, out
+
+
+def deskew(ctx, prev_pose, predicted_pose, scan_period, hits_xyzt, origin, min_range, max_range):
+    """local_trajectory_builder_3d.cc:421-472 on the device.  Returns (xyz[n,3], kind[n], current_pose[7] float32)."""
+    h = _f32(hits_xyzt).reshape(-1, 4)
+    n = len(h)
+    out = np.zeros((n, 3), dtype=np.float32)
+    kind = np.zeros(n, dtype=np.uint8)
+    cur = np.zeros(7, dtype=np.float32)
+    _check(ctx._L.dliom_deskew(ctx.h, _p(_f64(prev_pose), _f64p), _p(_f64(predicted_pose), _f64p), scan_period,
+                               _p(h, _f32p), n, _p(_f32(origin), _f32p), C.c_float(min_range), C.c_float(max_range),
+                               _p(out, _f32p), kind.ctypes.data_as(C.POINTER(C.c_uint8)), _p(cur, _f32p)), "dliom_deskew")
+    return out, kind, cur
+
+
+def add_range_data_preprocess(ctx, prev_pose, predicted_pose, scan_period, ranges_xyzt, origin, min_range, max_range,
+                              voxel_filter_size):
+    """AddRangeData's pre-processing chain (:393-487): VoxelFilter(0.5 vfs) [host] -> de-skew + range gate
+    [device] -> VoxelFilter(vfs) [host] -> back to the tracking frame by current_pose.inverse() [host,
+    float].  Returns (returns_in_tracking, origin_in_tracking, current_pose)."""
+    r = _f32(ranges_xyzt).reshape(-1, 4)
+    keep = voxel_filter_indices(0.5 * np.float32(voxel_filter_size), r[:, :3])
+    hits = r[keep]
+    xyz, kind, cur = deskew(ctx, prev_pose, predicted_pose, scan_period, hits, origin, min_range, max_range)
+    returns = voxel_filter(voxel_filter_size, xyz[kind == 1])
+    inv = _pose_inverse_f32(cur)
+    return _transform_f32(inv, returns), _transform_f32(inv, cur[:3].reshape(1, 3))[0], cur
+
+
+def voxel_filter_indices(size, points):
+    """Indices kept by sensor::VoxelFilter (first point per voxel), via the host filter."""
+    pts = _f32(points).reshape(-1, 3)
+    kept = voxel_filter(size, pts)
+    # the filter preserves order and keeps exact copies: recover the indices by a single sweep
+    idx = np.zeros(len(kept), dtype=np.int64)
+    j = 0
+    for i in range(len(pts)):
+        if j < len(kept) and pts[i, 0] == kept[j, 0] and pts[i, 1] == kept[j, 1] and pts[i, 2] == kept[j, 2]:
+            idx[j] = i
+            j += 1
+    assert j == len(kept)
+    return idx
+
+
+def _pose_inverse_f32(p):
+    """Rigid3f::inverse() in float32 with Eigen's operation order (transform/rigid_transform.h:167-171)."""
+    f = np.float32
+    w, x, y, z = f(p[3]), f(-p[4]), f(-p[5]), f(-p[6])
+    t = _transform_f32(np.array([0, 0, 0, w, x, y, z], dtype=np.float32), np.asarray(p[:3], dtype=np.float32).reshape(1, 3))[0]
+    return np.array([-t[0], -t[1], -t[2], w, x, y, z], dtype=np.float32)
+
+
+def _transform_f32(pose, pts):
+    """rigid * point in float32: uv = 2 (u x v); (v + w uv) + u x uv, then + t."""
+    f = np.float32
+    pts = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
+    w, ux, uy, uz = f(pose[3]), f(pose[4]), f(pose[5]), f(pose[6])
+    vx, vy, vz = pts[:, 0], pts[:, 1], pts[:, 2]
+    uvx = uy * vz - uz * vy
+    uvy = uz * vx - ux * vz
+    uvz = ux * vy - uy * vx
+    uvx = uvx + uvx
+    uvy = uvy + uvy
+    uvz = uvz + uvz
+    cx = uy * uvz - uz * uvy
+    cy = uz * uvx - ux * uvz
+    cz = ux * uvy - uy * uvx
+    out = np.stack([((vx + w * uvx) + cx) + f(pose[0]), ((vy + w * uvy) + cy) + f(pose[1]),
+                    ((vz + w * uvz) + cz) + f(pose[2])], axis=1)
+    return out.astype(np.float32)

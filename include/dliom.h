@@ -313,6 +313,21 @@ int dliom_voxel_filter(float size, const float* points_xyz, int64_t n, float* ou
 int dliom_adaptive_voxel_filter(const dliom_adaptive_voxel_filter_options* options, const float* points_xyz,
                                 int64_t n, float* out_xyz, int64_t* num_out);
 
+/* ---- per-hit de-skew of LocalTrajectoryBuilder3D::AddRangeData -------------------------------
+ * (mapping/internal/3d/local_trajectory_builder_3d.cc:421-472, InterpolatePose :869-877).
+ * hits_xyzt: n x (x, y, z, t) in the tracking frame, t <= 0 seconds relative to the scan end (the
+ * hits that survived VoxelFilter(0.5 * voxel_filter_size), :393-395).  For every hit: s = (T + t)/T,
+ * pose_i = (prev_pose * [s t_rel, slerp(I, q_rel, s)]).cast<float>() with rel = prev^-1 * predicted,
+ * hit and origin moved into the local frame, then the range gate: out_kind 0 = dropped
+ * (range < min_range), 1 = return (out_xyz = hit_in_local), 2 = miss (out_xyz = ray cropped at
+ * max_range).  If |t_0| < 1e-3 every hit takes the predicted pose ("not de-skewing", :429-433).
+ * current_pose (float, [t,q]) = the last hit's pose (:477).  Slerp coefficients use the device's
+ * double-precision sin/acos: results agree with the host path to float rounding (tolerance in
+ * tests/test_gpu_parity.py), not bit for bit. */
+int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7], double scan_period,
+                 const float* hits_xyzt, int64_t n, const float origin[3], float min_range, float max_range,
+                 float* out_xyz, uint8_t* out_kind, float current_pose[7]);
+
 /* ---- RealTimeCorrelativeScanMatcher2D (BASELINE config 1: host only, by contract) -------------
  * double Match(initial_pose_estimate, point_cloud, probability_grid, pose_estimate)
  * (mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h:66-69, .cc:74-108).

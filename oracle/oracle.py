@@ -105,6 +105,8 @@ def _declare(L):
     sig("orc_front_end_num_active_submaps", C.c_int, vp)
     sig("orc_front_end_matching_index", C.c_int, vp)
     sig("orc_front_end_active_submap", None, vp, C.c_int, _f64p, _i32p, C.POINTER(vp), C.POINTER(vp))
+    sig("orc_deskew_and_filter", None, _f64p, _f64p, _f64p, _f32p, C.c_int, _f32p, _f32p, _i32p, _i32p, _f32p,
+        _f32p, _f32p, _f32p)
     sig("orc_pg_new", vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int)
     sig("orc_pg_free", None, vp)
     sig("orc_pg_set_probability", None, vp, C.c_int, C.c_int, C.c_float)
@@ -564,3 +566,26 @@ class FrontEnd:
         self._L.orc_front_end_active_submap(self.h, i, _p(pose, _f64p), C.byref(n), C.byref(hi), C.byref(lo))
         return dict(local_pose=pose, num_range_data=n.value, hi=HybridGrid(resolutions[0], borrowed_handle=hi),
                     lo=HybridGrid(resolutions[1], borrowed_handle=lo), _keepalive=self)
+
+
+# ------------------------------------------------------------------ AddRangeData pre-processing
+def deskew_and_filter(scan_period, min_range, max_range, voxel_filter_size, prev_pose, cur_pose, ranges_xyzt,
+                      origin=(0.0, 0.0, 0.0)):
+    """local_trajectory_builder_3d.cc:393-487.  Returns a dict with the per-hit local points and
+    gate decisions and the filtered range data in the tracking frame."""
+    r = _f32(ranges_xyzt).reshape(-1, 4)
+    n = len(r)
+    hits = np.zeros((n, 3), dtype=np.float32)
+    kind = np.zeros(n, dtype=np.int32)
+    counts = np.zeros(3, dtype=np.int32)
+    ret = np.zeros((n, 3), dtype=np.float32)
+    mis = np.zeros((n, 3), dtype=np.float32)
+    cur = np.zeros(7, dtype=np.float32)
+    org = np.zeros(3, dtype=np.float32)
+    lib().orc_deskew_and_filter(_p(_f64([scan_period, min_range, max_range, voxel_filter_size]), _f64p),
+                                _p(_f64(prev_pose), _f64p), _p(_f64(cur_pose), _f64p), _p(r, _f32p), n,
+                                _p(_f32(origin), _f32p), _p(hits, _f32p), _p(kind, _i32p), _p(counts, _i32p),
+                                _p(ret, _f32p), _p(mis, _f32p), _p(cur, _f32p), _p(org, _f32p))
+    return dict(hits_in_local=hits[:counts[0]].copy(), kind=kind[:counts[0]].copy(),
+                returns_in_tracking=ret[:counts[1]].copy(), misses_in_tracking=mis[:counts[2]].copy(),
+                current_pose=cur, origin_in_tracking=org)

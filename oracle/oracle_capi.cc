@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "src/om_csm3d.h"
+#include "src/om_deskew.h"
 #include "src/om_front_end.h"
 #include "src/om_grid2d.h"
 #include "src/om_rtcsm3d.h"
@@ -430,6 +431,41 @@ void orc_front_end_active_submap(void* fe, int i, double* local_pose7, int* num_
   *num_range_data = s->num_range_data();
   *hi = &s->high_resolution_hybrid_grid();
   *lo = &s->low_resolution_hybrid_grid();
+}
+
+// ---------------------------------------------------------------- AddRangeData pre-processing
+// opts = [scan_period, min_range, max_range, voxel_filter_size].  ranges: n x (x,y,z,t).
+// Outputs: hits_in_local (capacity n x 3), kind (capacity n), counts[0] = hits after the first
+// voxel filter, counts[1] = returns in tracking, counts[2] = misses in tracking;
+// returns_tracking / misses_tracking (capacity n x 3 each), current_pose7 (float), origin3 (tracking).
+void orc_deskew_and_filter(const double* opts, const double* prev7, const double* cur7, const float* ranges, int n,
+                           const float* origin3, float* hits_in_local, int* kind, int* counts,
+                           float* returns_tracking, float* misses_tracking, float* current_pose7,
+                           float* origin_tracking3) {
+  std::vector<TimedPoint> r(n);
+  for (int i = 0; i < n; ++i) r[i] = TimedPoint{ranges[4 * i], ranges[4 * i + 1], ranges[4 * i + 2], ranges[4 * i + 3]};
+  const DeskewOptions o{opts[0], static_cast<float>(opts[1]), static_cast<float>(opts[2]), static_cast<float>(opts[3])};
+  const DeskewResult d = DeskewAndFilter(o, ToRigid(prev7), ToRigid(cur7), r, Vec3f(origin3[0], origin3[1], origin3[2]));
+  counts[0] = static_cast<int>(d.hits_in_local.size());
+  for (size_t i = 0; i < d.hits_in_local.size(); ++i) {
+    hits_in_local[3 * i] = d.hits_in_local[i].x; hits_in_local[3 * i + 1] = d.hits_in_local[i].y;
+    hits_in_local[3 * i + 2] = d.hits_in_local[i].z;
+    kind[i] = d.kind[i];
+  }
+  counts[1] = static_cast<int>(d.filtered_in_tracking.returns.size());
+  counts[2] = static_cast<int>(d.filtered_in_tracking.misses.size());
+  for (size_t i = 0; i < d.filtered_in_tracking.returns.size(); ++i) {
+    const Vec3f& p = d.filtered_in_tracking.returns[i];
+    returns_tracking[3 * i] = p.x; returns_tracking[3 * i + 1] = p.y; returns_tracking[3 * i + 2] = p.z;
+  }
+  for (size_t i = 0; i < d.filtered_in_tracking.misses.size(); ++i) {
+    const Vec3f& p = d.filtered_in_tracking.misses[i];
+    misses_tracking[3 * i] = p.x; misses_tracking[3 * i + 1] = p.y; misses_tracking[3 * i + 2] = p.z;
+  }
+  FromRigidF(d.current_pose, current_pose7);
+  origin_tracking3[0] = d.filtered_in_tracking.origin.x;
+  origin_tracking3[1] = d.filtered_in_tracking.origin.y;
+  origin_tracking3[2] = d.filtered_in_tracking.origin.z;
 }
 
 // ---------------------------------------------------------------- 2D (config 1, CPU only)

@@ -552,3 +552,53 @@ def test_sharded_match_single_process(dl, ctx, orc, num_shards):
         c.close()
     cloud.close()
     dg.close()
+
+
+def _timed_scan(beams=32, azimuths=256, k=5):
+    from dliom import synth
+    prev = synth.trajectory_pose(0.1 * (k - 1))
+    cur = synth.trajectory_pose(0.1 * k)
+    pts, rel_t = synth.scan(cur, beams, azimuths)
+    return prev, cur, np.concatenate([pts, rel_t.reshape(-1, 1)], axis=1).astype(np.float32)
+
+
+def test_deskew_matches_oracle(dl, ctx, orc):
+    """AddRangeData's per-hit de-skew + range gate on the device vs the oracle.  Float tolerance:
+    the slerp coefficients come from the device's double sin/acos, so a point may differ from the
+    host path by float rounding of its pose (<= 4e-6 m at these ranges); gate decisions must agree
+    except for hits within that tolerance of the min/max range."""
+    prev, cur, ranges = _timed_scan()
+    vfs, min_r, max_r, T = 0.15, 1.0, 20.0, 0.1
+    ref = orc.deskew_and_filter(T, min_r, max_r, vfs, prev, cur, ranges)
+    keep = orc.voxel_filter(0.5 * np.float32(vfs), ranges[:, :3])
+    hits = ranges[keep]
+    assert len(hits) == len(ref["hits_in_local"])
+    xyz, kind, cur_f = dl.deskew(ctx, prev, cur, T, hits, (0, 0, 0), min_r, max_r)
+    ret = kind == 1
+    assert np.abs(xyz[ret] - ref["hits_in_local"][ret]).max() <= 4e-6
+    assert np.abs(cur_f - ref["current_pose"]).max() <= 1e-6
+    rng = np.linalg.norm(ref["hits_in_local"].astype(np.float64) - cur[:3], axis=1)  # ~range (origin = sensor)
+    borderline = (np.abs(rng - min_r) < 1e-4) | (np.abs(rng - max_r) < 1e-4)
+    assert np.array_equal(kind[~borderline], ref["kind"][~borderline].astype(np.uint8))
+    assert (kind == 2).sum() > 0 and (kind == 1).sum() > 0
+    # "not de-skewing" branch: no per-point stamps -> every hit takes the predicted pose, bit-exact
+    flat = hits.copy()
+    flat[:, 3] = 0.0
+    xyz0, kind0, cur0 = dl.deskew(ctx, prev, cur, T, flat, (0, 0, 0), min_r, max_r)
+    want = orc.transform_points(cur.astype(np.float32), flat[:, :3])
+    assert np.array_equal(cur0, cur.astype(np.float32))
+    assert np.array_equal(xyz0[kind0 == 1], want[kind0 == 1])
+
+
+def test_add_range_data_preprocess_chain(dl, ctx, orc):
+    """VoxelFilter(0.5 vfs) -> de-skew -> gate -> VoxelFilter(vfs) -> tracking frame: the product
+    chain (host filters + device de-skew) against the oracle's AddRangeData restatement."""
+    prev, cur, ranges = _timed_scan(16, 256, k=7)
+    vfs, min_r, max_r, T = 0.15, 1.0, 100.0, 0.1
+    ref = orc.deskew_and_filter(T, min_r, max_r, vfs, prev, cur, ranges)
+    returns, origin, cur_f = dl.add_range_data_preprocess(ctx, prev, cur, T, ranges, (0, 0, 0), min_r, max_r, vfs)
+    # same voxels survive (a 1e-6 m wobble can move a point across a voxel face only in rare cases)
+    assert abs(len(returns) - len(ref["returns_in_tracking"])) <= 2
+    if len(returns) == len(ref["returns_in_tracking"]):
+        assert np.abs(returns - ref["returns_in_tracking"]).max() <= 1e-5
+    assert np.abs(origin - ref["origin_in_tracking"]).max() <= 1e-5
