@@ -121,8 +121,8 @@ def main():
         p2, summ = cs.Match(sc["init"][:3], p1, [(sc["cloud"], g_hi), (sc["cloud"], g_lo)])
         c = time.perf_counter()
         pf = p2.astype(np.float32)
-        ins.InsertCloud(g_hi, sc["cloud"], poses=[pf], max_range=HIGH_RES_MAX_RANGE)
-        ins.InsertCloud(g_lo, sc["cloud"], poses=[pf])
+        # Submap3D::InsertRangeData: high-resolution grid (range filtered) + low-resolution grid, fused
+        dl.insert_cloud_multi(ins, sc["cloud"], [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)])
         d = time.perf_counter()
         if timed:
             stage["rtcsm"] += b - a

@@ -312,16 +312,29 @@ int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double
   r->inserted = 1;
   r->num_insertion_submaps = static_cast<int>(fe->submaps.size());
   float origin_local[3] = {0, 0, 0};
+  // all active grids (hi + lo of each submap) in one fused insertion: up to 4 targets
+  dliom_grid* targets[4];
+  float target_poses[4 * 14];
+  int target_num_poses[4];
+  float target_max_range[4];
+  int nt = 0;
+  // Submap3D::InsertRangeData takes high_resolution_max_range as an int (submap_3d.h:79-81)
+  const float hi_max_range = static_cast<float>(static_cast<int>(o.high_resolution_max_range));
   for (size_t i = 0; i < fe->submaps.size(); ++i) {
     dliom_front_end::Submap& s = *fe->submaps[i];
     r->insertion_submap_index[i] = fe->matching_submap_index + static_cast<int>(i);
     pose_to_float7(pose_inverse(s.local_pose), poses + 7);
-    // Submap3D::InsertRangeData takes high_resolution_max_range as an int (submap_3d.h:79-81)
-    const float max_range = static_cast<float>(static_cast<int>(o.high_resolution_max_range));
-    DLIOM_TRY(dliom_inserter_insert_cloud(fe->inserter, s.hi, poses, 2, fe->origin, fe->returns_cloud, max_range));
-    DLIOM_TRY(dliom_inserter_insert_cloud(fe->inserter, s.lo, poses, 2, fe->origin, fe->returns_cloud, 0.f));
+    for (int hl = 0; hl < 2; ++hl) {
+      targets[nt] = hl == 0 ? s.hi : s.lo;
+      std::memcpy(target_poses + 14 * nt, poses, sizeof(poses));
+      target_num_poses[nt] = 2;
+      target_max_range[nt] = hl == 0 ? hi_max_range : 0.f;
+      ++nt;
+    }
     ++s.num_range_data;
   }
+  DLIOM_TRY(dliom_inserter_insert_cloud_multi(fe->inserter, nt, targets, target_poses, target_num_poses, fe->origin,
+                                              fe->returns_cloud, target_max_range));
   if (fe->submaps.back()->num_range_data == o.num_range_data) {  // submap_3d.cc:310-313
     // new submap at (range_data.origin in the local frame, gravity_alignment)
     const QF qf{poses[3], poses[4], poses[5], poses[6]};

@@ -300,6 +300,143 @@ __global__ void transform_filter_kernel(const float* __restrict__ px, const floa
   out[3 * static_cast<size_t>(k) + 2] = z;
 }
 
+// ---- fused insertion of one HBM-resident cloud into up to 4 grids ---------------------------------
+// (Submap3D::InsertRangeData for both grids of both active submaps, mapping/3d/submap_3d.cc:264-279,
+// 303-309.)  Every kernel recomputes a target's transform chain and range filter per point instead of
+// materialising transformed copies; blockIdx.y selects the target.  The host launches all five passes
+// back to back and synchronises ONCE: passes 1-4 skip a target whose pass-0 status says it needs the
+// host first (extent growth or CHECK failure); the host then grows and re-runs just that target.
+constexpr int kMaxInsertTargets = 4;
+struct InsertTarget {
+  Quat4 q[2];
+  float t[2][3];
+  int num_poses;
+  float ox, oy, oz;   // range_data.origin after the transforms
+  float max_range;    // <= 0: no range filter
+  float resolution;
+  int num_free;
+  int bits;
+  int half;
+  unsigned gsize, L;
+  uint32_t* table;
+  int32_t* slot_coord;
+  uint32_t* count;
+  uint32_t* pool32;
+  uint16_t* dense;
+  int dense_stride;
+};
+struct MultiInsertArgs {
+  InsertTarget tg[kMaxInsertTargets];
+  unsigned run_mask;  // bit k: process target k in this launch
+  const float* px;
+  const float* py;
+  const float* pz;
+  int n;
+  const uint16_t* hit;
+  const uint16_t* miss;
+  int* status;  // per target: [needed bits, ray too long]
+};
+
+// Transformed + range-filtered hit of point i for target tg; false if filtered out.
+__device__ __forceinline__ bool target_hit(const MultiInsertArgs& a, const InsertTarget& tg, int i, int* hx,
+                                           int* hy, int* hz) {
+  float x = a.px[i], y = a.py[i], z = a.pz[i];
+  for (int k = 0; k < tg.num_poses; ++k) {
+    float rx, ry, rz;
+    rotate_point(tg.q[k], x, y, z, rx, ry, rz);
+    x = rx + tg.t[k][0];
+    y = ry + tg.t[k][1];
+    z = rz + tg.t[k][2];
+  }
+  if (tg.max_range > 0.f) {
+    const float dx = x - tg.ox, dy = y - tg.oy, dz = z - tg.oz;
+    if (!(sqrtf(dx * dx + (dy * dy + dz * dz)) <= tg.max_range)) return false;
+  }
+  *hx = cell_of(x, tg.resolution);
+  *hy = cell_of(y, tg.resolution);
+  *hz = cell_of(z, tg.resolution);
+  return true;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <int PASS>  // 0 scan, 1 alloc, 2 hits, 3 misses, 4 finish
+__global__ void multi_insert_kernel(MultiInsertArgs a) {
+  const int tgi = blockIdx.y;
+  if (!((a.run_mask >> tgi) & 1u)) return;
+  const InsertTarget& tg = a.tg[tgi];
+  if (PASS > 0 && (a.status[2 * tgi] > tg.bits || a.status[2 * tgi + 1] != 0)) return;  // host first
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int hx = 0, hy = 0, hz = 0;
+  const bool valid = i < a.n && target_hit(a, tg, i, &hx, &hy, &hz);
+  const int ocx = cell_of(tg.ox, tg.resolution), ocy = cell_of(tg.oy, tg.resolution),
+            ocz = cell_of(tg.oz, tg.resolution);
+  const int dx = hx - ocx, dy = hy - ocy, dz = hz - ocz;
+  const int num_samples = max(abs(dx), max(abs(dy), abs(dz)));
+  const int first = max(0, num_samples - tg.num_free);
+  if (PASS == 0) {
+    int need = 0, too_long = 0;
+    if (valid) {
+      need = max(bits_for(hx), max(bits_for(hy), bits_for(hz)));
+      too_long = num_samples >= (1 << 15) ? 1 : 0;
+      for (int position = first; position < num_samples; ++position) {
+        int mx, my, mz;
+        miss_cell(ocx, ocy, ocz, dx, dy, dz, position, num_samples, &mx, &my, &mz);
+        need = max(need, max(bits_for(mx), max(bits_for(my), bits_for(mz))));
+      }
+    }
+    need = wave_max_i32(need);
+    too_long = wave_max_i32(too_long);
+    if ((threadIdx.x & 63) == 0) {
+      if (need > 0) atomicMax(&a.status[2 * tgi], need);
+      if (too_long) atomicMax(&a.status[2 * tgi + 1], 1);
+    }
+    return;
+  }
+  if (!valid) return;
+  unsigned tidx, cell;
+  if (PASS == 1) {
+    ensure_leaf(tg.table, tg.slot_coord, tg.count, hx, hy, hz, tg.half, tg.gsize, tg.L);
+    for (int position = first; position < num_samples; ++position) {
+      int mx, my, mz;
+      miss_cell(ocx, ocy, ocz, dx, dy, dz, position, num_samples, &mx, &my, &mz);
+      ensure_leaf(tg.table, tg.slot_coord, tg.count, mx, my, mz, tg.half, tg.gsize, tg.L);
+    }
+    return;
+  }
+  if (PASS == 2 || PASS == 4) {
+    if (leaf_table_index(hx, hy, hz, tg.half, tg.gsize, tg.L, &tidx, &cell)) {
+      const size_t vi = static_cast<size_t>(tg.table[tidx]) * 512u + cell;
+      if (PASS == 2) {
+        const uint32_t nv = apply_table(tg.pool32, vi, a.hit);
+        if (nv != 0u && tg.dense != nullptr)
+          tg.dense[dense_index(hx, hy, hz, tg.half, tg.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
+      } else {
+        atomicAnd(tg.pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
+      }
+    }
+  }
+  if (PASS == 3 || PASS == 4) {
+    for (int position = first; position < num_samples; ++position) {
+      int mx, my, mz;
+      miss_cell(ocx, ocy, ocz, dx, dy, dz, position, num_samples, &mx, &my, &mz);
+      if (!leaf_table_index(mx, my, mz, tg.half, tg.gsize, tg.L, &tidx, &cell)) continue;
+      const size_t vi = static_cast<size_t>(tg.table[tidx]) * 512u + cell;
+      if (PASS == 3) {
+        const uint32_t nv = apply_table(tg.pool32, vi, a.miss);
+        if (nv != 0u && tg.dense != nullptr)
+          tg.dense[dense_index(mx, my, mz, tg.half, tg.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
+      } else {
+        atomicAnd(tg.pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
+      }
+    }
+  }
+}
+
 static inline unsigned blocks_for(int64_t n, int threads) {
   return static_cast<unsigned>((n + threads - 1) / threads);
 }
@@ -754,59 +891,138 @@ int dliom_inserter_insert(const dliom_inserter* ins, dliom_grid* g, const float 
   return s;
 }
 
-int dliom_inserter_insert_cloud(const dliom_inserter* ins, dliom_grid* g, const float* poses7,
-                                int num_poses, const float origin[3], const dliom_cloud* cloud,
-                                float max_range) {
-  if (ins == nullptr || g == nullptr || origin == nullptr || cloud == nullptr || num_poses < 0 ||
-      num_poses > 2 || (num_poses > 0 && poses7 == nullptr))
-    return DLIOM_ERR_INVALID_ARGUMENT;
-  const int64_t n = cloud->n;
-  if (n == 0) return DLIOM_OK;
-  dliom_ctx* ctx = g->ctx;
-  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  const size_t pbytes = (static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255);
-  DLIOM_TRY(ctx->misc.reserve(pbytes + 512));
-  char* base = static_cast<char*>(ctx->misc.p);
-  float* d_returns = reinterpret_cast<float*>(base);
-  int* d_scan = reinterpret_cast<int*>(base + pbytes);
-  unsigned* d_n = reinterpret_cast<unsigned*>(base + pbytes + 256);
-  DLIOM_HIP_TRY(hipMemsetAsync(d_n, 0, 4, ctx->stream));
-  TransformArgs t;
-  t.num_poses = num_poses;
+// Applies a pose chain to the origin on the host with the device's float operation order.
+static void transform_origin(const float* poses7, int num_poses, const float origin[3], float out[3]) {
   float o[3] = {origin[0], origin[1], origin[2]};
   for (int k = 0; k < num_poses; ++k) {
     const float* p = poses7 + 7 * k;
-    t.q[k] = Quat4{p[3], p[4], p[5], p[6]};
-    t.t[k][0] = p[0];
-    t.t[k][1] = p[1];
-    t.t[k][2] = p[2];
-    // the origin rides through the same float transforms (host, same operation order)
-    const Quat4 q = t.q[k];
-    float uvx = q.y * o[2] - q.z * o[1], uvy = q.z * o[0] - q.x * o[2], uvz = q.x * o[1] - q.y * o[0];
+    const float qw = p[3], qx = p[4], qy = p[5], qz = p[6];
+    float uvx = qy * o[2] - qz * o[1], uvy = qz * o[0] - qx * o[2], uvz = qx * o[1] - qy * o[0];
     uvx = uvx + uvx;
     uvy = uvy + uvy;
     uvz = uvz + uvz;
-    const float cx = q.y * uvz - q.z * uvy, cy = q.z * uvx - q.x * uvz, cz = q.x * uvy - q.y * uvx;
-    const float nx = ((o[0] + q.w * uvx) + cx) + p[0];
-    const float ny = ((o[1] + q.w * uvy) + cy) + p[1];
-    const float nz = ((o[2] + q.w * uvz) + cz) + p[2];
+    const float cx = qy * uvz - qz * uvy, cy = qz * uvx - qx * uvz, cz = qx * uvy - qy * uvx;
+    const float nx = ((o[0] + qw * uvx) + cx) + p[0];
+    const float ny = ((o[1] + qw * uvy) + cy) + p[1];
+    const float nz = ((o[2] + qw * uvz) + cz) + p[2];
     o[0] = nx;
     o[1] = ny;
     o[2] = nz;
   }
-  t.ox = o[0];
-  t.oy = o[1];
-  t.oz = o[2];
-  t.max_range = max_range;
+  out[0] = o[0];
+  out[1] = o[1];
+  out[2] = o[2];
+}
+
+static void refresh_target(InsertTarget* tg, dliom_grid* g) {
+  const GridView v = g->view();
+  tg->bits = g->bits;
+  tg->half = v.half;
+  tg->gsize = v.grid_size;
+  tg->L = static_cast<unsigned>(v.leaves_per_axis);
+  tg->table = g->d_table;
+  tg->slot_coord = g->d_slot_coord;
+  tg->count = g->d_count;
+  tg->pool32 = reinterpret_cast<uint32_t*>(g->d_pool);
+  tg->dense = g->d_dense;
+  tg->dense_stride = g->dense_stride;
+}
+
+int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets, dliom_grid* const* grids,
+                                      const float* poses7, const int* num_poses, const float origin[3],
+                                      const dliom_cloud* cloud, const float* max_range) {
+  if (ins == nullptr || grids == nullptr || origin == nullptr || cloud == nullptr || num_poses == nullptr ||
+      max_range == nullptr || num_targets < 1 || num_targets > kMaxInsertTargets)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  const int64_t n = cloud->n;
+  if (n == 0) return DLIOM_OK;
+  if (n > (int64_t{1} << 30)) return DLIOM_ERR_INVALID_ARGUMENT;
+  dliom_ctx* ctx = grids[0]->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  MultiInsertArgs a;
+  std::memset(&a, 0, sizeof(a));
+  const int F = ins->num_free_space_voxels;
+  for (int k = 0; k < num_targets; ++k) {
+    if (grids[k] == nullptr || num_poses[k] < 0 || num_poses[k] > 2 || (num_poses[k] > 0 && poses7 == nullptr))
+      return DLIOM_ERR_INVALID_ARGUMENT;
+    InsertTarget& tg = a.tg[k];
+    const float* p = poses7 + 14 * k;  // two pose slots per target
+    tg.num_poses = num_poses[k];
+    for (int j = 0; j < num_poses[k]; ++j) {
+      tg.q[j] = Quat4{p[7 * j + 3], p[7 * j + 4], p[7 * j + 5], p[7 * j + 6]};
+      tg.t[j][0] = p[7 * j];
+      tg.t[j][1] = p[7 * j + 1];
+      tg.t[j][2] = p[7 * j + 2];
+    }
+    float o[3];
+    transform_origin(p, num_poses[k], origin, o);
+    tg.ox = o[0];
+    tg.oy = o[1];
+    tg.oz = o[2];
+    tg.max_range = max_range[k];
+    tg.resolution = grids[k]->resolution;
+    tg.num_free = F;
+    DLIOM_TRY(grids[k]->ensure_capacity(n * (1 + static_cast<int64_t>(F))));
+    refresh_target(&tg, grids[k]);
+  }
+  DLIOM_TRY(ctx->misc.reserve(256));
+  a.status = ctx->misc.as<int>();
+  a.px = cloud->d_x;
+  a.py = cloud->d_y;
+  a.pz = cloud->d_z;
+  a.n = static_cast<int>(n);
+  a.hit = ins->d_tables;
+  a.miss = ins->d_tables + 32768;
+  a.run_mask = (1u << num_targets) - 1u;
+  DLIOM_HIP_TRY(hipMemsetAsync(a.status, 0, 8 * kMaxInsertTargets, ctx->stream));
+  const dim3 grid_dim(blocks_for(n, 256), num_targets), block(256);
   const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
-  hipLaunchKernelGGL(transform_filter_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, ctx->stream,
-                     cloud->d_x, cloud->d_y, cloud->d_z, n, t, d_returns, d_n);
-  DLIOM_HIP_TRY(hipGetLastError());
-  const int s = insert_device(g, o, d_returns, n, d_n, ins->d_tables, ins->d_tables + 32768, d_scan,
-                              ins->num_free_space_voxels);
+  hipLaunchKernelGGL(multi_insert_kernel<0>, grid_dim, block, 0, ctx->stream, a);
+  int status[2 * kMaxInsertTargets];
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    hipLaunchKernelGGL(multi_insert_kernel<1>, grid_dim, block, 0, ctx->stream, a);
+    hipLaunchKernelGGL(multi_insert_kernel<2>, grid_dim, block, 0, ctx->stream, a);
+    if (F > 0) hipLaunchKernelGGL(multi_insert_kernel<3>, grid_dim, block, 0, ctx->stream, a);
+    hipLaunchKernelGGL(multi_insert_kernel<4>, grid_dim, block, 0, ctx->stream, a);
+    DLIOM_HIP_TRY(hipGetLastError());
+    if (attempt == 0) {
+      DLIOM_HIP_TRY(hipMemcpyAsync(status, a.status, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+      DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      unsigned redo = 0;
+      for (int k = 0; k < num_targets; ++k) {
+        if (status[2 * k + 1] != 0) {
+          ctx->end_span(span);
+          return DLIOM_ERR_RAY_TOO_LONG;  // NB: targets before k may already be updated, like a CHECK mid-way
+        }
+        if (status[2 * k] > 8) {
+          ctx->end_span(span);
+          return DLIOM_ERR_GRID_EXTENT;
+        }
+        if (status[2 * k] > grids[k]->bits) {  // skipped on the device: grow, then run it alone
+          DLIOM_TRY(grids[k]->ensure_bits(status[2 * k]));
+          refresh_target(&a.tg[k], grids[k]);
+          redo |= 1u << k;
+        }
+      }
+      if (redo == 0) break;
+      a.run_mask = redo;
+    } else {
+      DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+  }
   ctx->end_span(span);
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return s;
+  for (int k = 0; k < num_targets; ++k) grids[k]->used_upper += n * (1 + static_cast<int64_t>(F));
+  return DLIOM_OK;
+}
+
+int dliom_inserter_insert_cloud(const dliom_inserter* ins, dliom_grid* g, const float* poses7,
+                                int num_poses, const float origin[3], const dliom_cloud* cloud,
+                                float max_range) {
+  if (g == nullptr || num_poses < 0 || num_poses > 2) return DLIOM_ERR_INVALID_ARGUMENT;
+  float slots[14] = {0};
+  if (num_poses > 0 && poses7 == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < 7 * num_poses; ++i) slots[i] = poses7[i];
+  return dliom_inserter_insert_cloud_multi(ins, 1, &g, slots, &num_poses, origin, cloud, &max_range);
 }
 
 }  // extern "C"

@@ -145,6 +145,7 @@ SYMBOLS = [
     ("dliom_inserter_tables", C.c_int, [_vp, _u16p, _u16p]),
     ("dliom_inserter_insert", C.c_int, [_vp, _vp, _f32p, _f32p, C.c_int64]),
     ("dliom_inserter_insert_cloud", C.c_int, [_vp, _vp, _f32p, C.c_int, _f32p, _vp, C.c_float]),
+    ("dliom_inserter_insert_cloud_multi", C.c_int, [_vp, C.c_int, C.POINTER(_vp), _f32p, C.POINTER(C.c_int), _f32p, _vp, _f32p]),
     ("dliom_cloud_create", C.c_int, [_vp, _f32p, C.c_int64, C.POINTER(_vp)]),
     ("dliom_cloud_destroy", C.c_int, [_vp]),
     ("dliom_cloud_size", C.c_int, [_vp, _i64p]),
@@ -444,6 +445,23 @@ class RangeDataInserter3D:
         origin = _f32(origin)
         _check(grid._L.dliom_inserter_insert_cloud(self.h, grid.h, _p(poses, _f32p), len(poses), _p(origin, _f32p),
                                                    cloud.h, C.c_float(max_range)), "dliom_inserter_insert_cloud")
+
+
+def insert_cloud_multi(inserter, cloud, targets, origin=(0.0, 0.0, 0.0)):
+    """targets: list of (grid, poses (0..2 float poses), max_range).  One set of launches, one sync."""
+    k = len(targets)
+    grids = (_vp * k)(*[g.h for g, _, _ in targets])
+    poses = np.zeros((k, 14), dtype=np.float32)
+    nposes = (C.c_int * k)()
+    ranges = np.zeros(k, dtype=np.float32)
+    for i, (_, ps, mr) in enumerate(targets):
+        ps = np.asarray(ps, dtype=np.float32).reshape(-1, 7) if len(ps) else np.zeros((0, 7), np.float32)
+        nposes[i] = len(ps)
+        poses[i, :7 * len(ps)] = ps.reshape(-1)
+        ranges[i] = mr
+    _check(inserter._L.dliom_inserter_insert_cloud_multi(inserter.h, k, grids, _p(poses, _f32p), nposes,
+                                                         _p(_f32(origin), _f32p), cloud.h, _p(ranges, _f32p)),
+           "dliom_inserter_insert_cloud_multi")
 
 
 def _rtcsm_opts(o):

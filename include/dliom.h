@@ -123,6 +123,14 @@ int dliom_inserter_insert_cloud(const dliom_inserter* inserter, dliom_grid* grid
                                 const float* poses7, int num_poses, const float origin[3],
                                 const dliom_cloud* cloud, float max_range);
 
+/* The same for up to 4 grids in one set of launches and one synchronisation -- the four
+ * insertions of ActiveSubmaps3D::InsertRangeData (both grids of both active submaps,
+ * submap_3d.cc:303-309).  Target k uses poses7[14*k .. 14*k + 7*num_poses[k]) and max_range[k]. */
+int dliom_inserter_insert_cloud_multi(const dliom_inserter* inserter, int num_targets,
+                                      dliom_grid* const* grids, const float* poses7, const int* num_poses,
+                                      const float origin[3], const dliom_cloud* cloud,
+                                      const float* max_range);
+
 /* ---- device-resident point cloud (sensor::PointCloud staged in HBM) ------- */
 int dliom_cloud_create(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud** out);
 int dliom_cloud_destroy(dliom_cloud* cloud);

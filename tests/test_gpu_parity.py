@@ -602,3 +602,37 @@ def test_add_range_data_preprocess_chain(dl, ctx, orc):
     if len(returns) == len(ref["returns_in_tracking"]):
         assert np.abs(returns - ref["returns_in_tracking"]).max() <= 1e-5
     assert np.abs(origin - ref["origin_in_tracking"]).max() <= 1e-5
+
+
+def test_fused_multi_grid_insertion(dl, ctx, orc):
+    """dliom_inserter_insert_cloud_multi: four targets (two resolutions x two submap frames, one with
+    a range filter) in one set of launches vs four oracle insertions; extent growth mid-sequence."""
+    from dliom import synth
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
+    frames = [synth.pose_inverse(synth.trajectory_pose(0.0)).astype(np.float32),
+              synth.pose_inverse(synth.trajectory_pose(0.25)).astype(np.float32)]
+    specs = [(0.1, frames[0], 20.0), (0.45, frames[0], 0.0), (0.1, frames[1], 20.0), (0.45, frames[1], 0.0)]
+    ogs = [orc.HybridGrid(r) for r, _, _ in specs]
+    dgs = [dl.HybridGrid(ctx, r) for r, _, _ in specs]
+    for s in range(3):
+        truth = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(truth, 32, 256)
+        pf = truth.astype(np.float32)
+        cloud = dl.PointCloud(ctx, pts)
+        dl.insert_cloud_multi(ins, cloud, [(g, [pf, fr], mr) for g, (_, fr, mr) in zip(dgs, specs)])
+        cloud.close()
+        local = orc.transform_points(pf, pts)
+        for og, (_, fr, mr) in zip(ogs, specs):
+            sub = orc.transform_points(fr, local)
+            origin = orc.transform_points(fr, orc.transform_points(pf, np.zeros((1, 3), np.float32)))[0]
+            if mr > 0:
+                d = (sub - origin).astype(np.float32)
+                nrm = np.sqrt(d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]), dtype=np.float32)
+                sub = sub[nrm <= np.float32(mr)]
+            og.insert_tables(origin, sub, ins.hit_table, ins.miss_table, FREE)
+        for og, dg in zip(ogs, dgs):
+            assert dg.bits == og.bits
+    for og, dg in zip(ogs, dgs):
+        assert dg.cells() == oracle_cells_dict(og)
+        dg.close()
+    ins.close()
