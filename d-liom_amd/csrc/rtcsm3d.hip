@@ -435,6 +435,194 @@ __global__ __launch_bounds__(256) void rtcsm_rescore_kernel(
   if (threadIdx.x == 0) sums[blockIdx.x] = s;
 }
 
+// Parallel, bit-exact evaluation of the SAME sequential float sum (one workgroup of 1024 threads
+// per surviving candidate).  Float addition is not associative, but inside one binade it is
+// integer arithmetic: with the running sum s = m * U (U = ulp of the binade, m a 24-bit mantissa)
+// and every addend an exact multiple of 2^-27,
+//     fl(s + a) = (m + c) * U,   c = floor(a/U) + [frac(a/U) > 1/2]   (+ ties-to-even),
+// so a stretch of additions that stays in one binade is an exact integer prefix sum.  Ties
+// (frac == 1/2) depend on the parity of m, which a tie itself resets to even; that makes every
+// segment of addends a function {parity in} -> {increment, parity out}, and functions compose
+// associatively -> a block-wide scan.  The sum is therefore computed binade by binade: each pass
+// scans a window that must contain the next binade crossing, finds the first addition whose
+// result reaches 2^24 U, rounds that one exact sum to the new ulp 2U, and continues behind it.
+// The first 256 additions are simply replayed in float by one lane.
+struct ParityFn {
+  unsigned s0, s1;  // total increment for parity-in 0 / 1
+  unsigned p0, p1;  // parity out
+};
+__device__ __forceinline__ ParityFn compose(const ParityFn& a, const ParityFn& b) {  // a first, then b
+  ParityFn r;
+  r.s0 = a.s0 + (a.p0 ? b.s1 : b.s0);
+  r.p0 = a.p0 ? b.p1 : b.p0;
+  r.s1 = a.s1 + (a.p1 ? b.s1 : b.s0);
+  r.p1 = a.p1 ? b.p1 : b.p0;
+  return r;
+}
+__device__ __forceinline__ ParityFn shfl_up_fn(const ParityFn& f, int off) {
+  ParityFn r;
+  r.s0 = __shfl_up(f.s0, off, 64);
+  r.s1 = __shfl_up(f.s1, off, 64);
+  r.p0 = __shfl_up(f.p0, off, 64);
+  r.p1 = __shfl_up(f.p1, off, 64);
+  return r;
+}
+
+constexpr int kScanThreads = 1024;
+constexpr int kSerialPrefix = 256;
+
+// Per survivor k and point i (input order): the 15-bit grid value, for the scan kernel below.
+__global__ void rtcsm_rescore_values_kernel(GridView g, const float* __restrict__ px,
+                                            const float* __restrict__ py, const float* __restrict__ pz,
+                                            int n, int n_stride, const float4* __restrict__ rot, int R,
+                                            const float* __restrict__ trans, const unsigned* __restrict__ list,
+                                            unsigned short* __restrict__ values) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_stride) return;
+  unsigned short v = 0;
+  if (i < n) {
+    const unsigned c = list[blockIdx.y];
+    const int j = static_cast<int>(c / static_cast<unsigned>(R));
+    const int r = static_cast<int>(c % static_cast<unsigned>(R));
+    const float4 qq = rot[r];
+    const Quat4 q{qq.x, qq.y, qq.z, qq.w};
+    float rx, ry, rz;
+    rotate_point(q, px[i], py[i], pz[i], rx, ry, rz);
+    v = static_cast<unsigned short>(grid_value(g, cell_of(rx + trans[3 * j], g.resolution),
+                                               cell_of(ry + trans[3 * j + 1], g.resolution),
+                                               cell_of(rz + trans[3 * j + 2], g.resolution)) & 0x7FFFu);
+  }
+  values[static_cast<size_t>(blockIdx.y) * n_stride + i] = v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_scan_kernel(
+    const unsigned short* __restrict__ values, int n, int n_stride, float k_scale, float k_offset,
+    float k_unknown, float* __restrict__ sums) {
+  extern __shared__ unsigned short lds_value[];  // n_stride grid values (15 bit), input order
+  __shared__ ParityFn wave_total[kScanThreads / 64];
+  __shared__ unsigned sh_m, sh_e, sh_i0, sh_cross, sh_m_before, sh_total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    // coalesced 16-byte loads of this survivor's row (n_stride is a multiple of 8)
+    const uint4* src = reinterpret_cast<const uint4*>(values + static_cast<size_t>(blockIdx.x) * n_stride);
+    uint4* dst = reinterpret_cast<uint4*>(lds_value);
+    for (int i = tid; i < n_stride / 8; i += kScanThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  // probability of point i as the reference's float (probability_values.cc:27-36) ...
+  auto prob = [&](int i) -> float {
+    const unsigned v = lds_value[i];
+    return v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset;
+  };
+  // ... and as an exact integer in units of 2^-27 (every probability is in [2^-4, 1))
+  auto fixed = [&](int i) -> unsigned {
+    const unsigned b = __float_as_uint(prob(i));
+    return ((b & 0x7FFFFFu) | 0x800000u) << ((b >> 23) - 123u);
+  };
+  if (tid == 0) {
+    float s = 0.f;
+    const int n0 = min(n, kSerialPrefix);
+    for (int i = 0; i < n0; ++i) s += prob(i);
+    const unsigned b = __float_as_uint(s);
+    sh_m = (b & 0x7FFFFFu) | 0x800000u;  // s = m * 2^(e - 27), e = biased exponent - 123
+    sh_e = (b >> 23) - 123u;
+    sh_i0 = static_cast<unsigned>(n0);
+  }
+  __syncthreads();
+  while (sh_i0 < static_cast<unsigned>(n)) {  // uniform: one pass per binade
+    const unsigned m = sh_m, e = sh_e, i0 = sh_i0;
+    const unsigned U = 1u << e, half = U >> 1, fmask = U - 1u;
+    // window that must contain the crossing: every addend is >= 0.1 > 13421772 * 2^-27
+    const unsigned c_min = max(13421772u >> e, 1u);
+    const unsigned remaining = static_cast<unsigned>(n) - i0;
+    const unsigned window = min(remaining, ((1u << 24) - m) / c_min + 2u);
+    const unsigned seg = ((window + kScanThreads - 1) / kScanThreads) | 1u;  // odd: LDS banks
+    const unsigned begin = i0 + static_cast<unsigned>(tid) * seg;
+    const unsigned end = min(i0 + window, begin + seg);
+    // phase A: this segment as a function of the incoming parity
+    ParityFn f{0u, 0u, 0u, 1u};
+    for (unsigned i = begin; i < end; ++i) {
+      const unsigned a = fixed(static_cast<int>(i));
+      const unsigned q = a >> e, fr = a & fmask;
+      if (e != 0u && fr == half) {  // tie: round to even mantissa
+        f.s0 += q + ((f.p0 + q) & 1u);
+        f.s1 += q + ((f.p1 + q) & 1u);
+        f.p0 = 0u;
+        f.p1 = 0u;
+      } else {
+        const unsigned c = q + (fr > half ? 1u : 0u);
+        f.s0 += c;
+        f.s1 += c;
+        f.p0 = (f.p0 + c) & 1u;
+        f.p1 = (f.p1 + c) & 1u;
+      }
+    }
+    // block-wide inclusive scan of the composition
+    ParityFn inc = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const ParityFn o = shfl_up_fn(inc, off);
+      if (lane >= off) inc = compose(o, inc);
+    }
+    if (lane == 63) wave_total[wave] = inc;
+    if (tid == 0) {
+      sh_cross = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    ParityFn before{0u, 0u, 0u, 1u};  // composition of all earlier waves
+    for (int w = 0; w < wave; ++w) before = compose(before, wave_total[w]);
+    ParityFn excl = shfl_up_fn(inc, 1);  // earlier lanes of this wave
+    if (lane == 0) excl = ParityFn{0u, 0u, 0u, 1u};
+    excl = compose(before, excl);
+    const unsigned p_start = m & 1u;
+    unsigned mt = m + (p_start ? excl.s1 : excl.s0);
+    if (tid == kScanThreads - 1) {
+      const ParityFn all = compose(before, inc);
+      sh_total = p_start ? all.s1 : all.s0;
+    }
+    // phase B: replay the segment with the real mantissa, look for the first result >= 2^24
+    unsigned my_cross = 0xFFFFFFFFu, my_before = 0u;
+    for (unsigned i = begin; i < end; ++i) {
+      const unsigned a = fixed(static_cast<int>(i));
+      const unsigned q = a >> e, fr = a & fmask;
+      unsigned c;
+      if (e != 0u && fr == half) {
+        c = q + ((mt + q) & 1u);
+      } else {
+        c = q + (fr > half ? 1u : 0u);
+      }
+      if (mt + c >= (1u << 24)) {
+        my_cross = i;
+        my_before = mt;
+        break;
+      }
+      mt += c;
+    }
+    if (my_cross != 0xFFFFFFFFu) atomicMin(&sh_cross, my_cross);
+    __syncthreads();
+    if (my_cross != 0xFFFFFFFFu && my_cross == sh_cross) sh_m_before = my_before;
+    __syncthreads();
+    if (tid == 0) {
+      if (sh_cross == 0xFFFFFFFFu) {  // the window ended inside this binade
+        sh_m = m + sh_total;
+        sh_i0 = i0 + window;
+      } else {
+        // exact sum of the crossing addition, rounded once to the next binade's ulp (2U)
+        const unsigned long long X =
+            (static_cast<unsigned long long>(sh_m_before) << e) + fixed(static_cast<int>(sh_cross));
+        const unsigned e2 = e + 1u;
+        const unsigned long long q2 = X >> e2, f2 = X & ((1ull << e2) - 1ull), h2 = 1ull << e;
+        const unsigned long long up = (f2 > h2 || (f2 == h2 && (q2 & 1ull))) ? 1ull : 0ull;
+        sh_m = static_cast<unsigned>(q2 + up);
+        sh_e = e2;
+        sh_i0 = sh_cross + 1u;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) sums[blockIdx.x] = __uint_as_float(((sh_e + 123u) << 23) | (sh_m & 0x7FFFFFu));
+}
+
 // ---------------------------------------------------------------------------------- probes
 __global__ void probe_cells_kernel(Quat4 q, float tx, float ty, float tz, const float* __restrict__ px,
                                    const float* __restrict__ py, const float* __restrict__ pz, int n,
@@ -827,9 +1015,24 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
     DLIOM_TRY(ctx->rescore.reserve(static_cast<size_t>(K) * 4));
     float* d_ksums = ctx->rescore.as<float>();
     const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
-    hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(K), dim3(256), 0, ctx->stream, st->grid->view(), cloud.d_x,
-                       cloud.d_y, cloud.d_z, n, st->d.rot, R, st->d.trans, st->d_list, lm.k_scale, lm.k_offset,
-                       lm.k_unknown, d_ksums);
+    static const int rescore_method = env_int("DLIOM_RESCORE", 1);  // 1: binade-wise scan, 0: serial chain
+    const int n_stride = (n + 7) & ~7;
+    const size_t scan_lds = static_cast<size_t>(n_stride) * 2;
+    if (rescore_method == 1 && scan_lds <= 128 * 1024 && K <= 65535) {
+      const size_t ks_bytes = (static_cast<size_t>(K) * 4 + 255) & ~static_cast<size_t>(255);
+      DLIOM_TRY(ctx->rescore.reserve(ks_bytes + static_cast<size_t>(K) * n_stride * 2));
+      d_ksums = ctx->rescore.as<float>();
+      unsigned short* d_values = reinterpret_cast<unsigned short*>(static_cast<char*>(ctx->rescore.p) + ks_bytes);
+      hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, K), dim3(256), 0, ctx->stream,
+                         st->grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, st->d.rot, R, st->d.trans,
+                         st->d_list, d_values);
+      hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(K), dim3(kScanThreads), scan_lds, ctx->stream, d_values,
+                         n, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
+    } else {
+      hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(K), dim3(256), 0, ctx->stream, st->grid->view(), cloud.d_x,
+                         cloud.d_y, cloud.d_z, n, st->d.rot, R, st->d.trans, st->d_list, lm.k_scale, lm.k_offset,
+                         lm.k_unknown, d_ksums);
+    }
     ctx->end_span(span);
     DLIOM_HIP_TRY(hipGetLastError());
     std::vector<unsigned> list(K);
@@ -996,6 +1199,55 @@ int dliom_rtcsm3d_score_volume(dliom_ctx* ctx, const dliom_rtcsm_options* o, con
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   const uint64_t n_pad = static_cast<uint64_t>(pad_processed);
   for (int64_t i = 0; i < c.w.num_candidates; ++i) sums[i] -= n_pad;
+  return DLIOM_OK;
+}
+
+int dliom_rtcsm3d_sequential_sums(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                                  const float* points_xyz, int64_t n, const dliom_grid* grid,
+                                  const int64_t* candidate_indices, int64_t k, int method, float* sums) {
+  if (ctx == nullptr || o == nullptr || init7 == nullptr || grid == nullptr || candidate_indices == nullptr ||
+      sums == nullptr || n <= 0 || points_xyz == nullptr || k <= 0)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_TRY(ctx->points.reserve(staged_cloud_bytes(n)));
+  dliom_cloud cloud;
+  DLIOM_TRY(stage_cloud(ctx, points_xyz, n, &cloud));
+  Candidates c;
+  generate_candidates(*o, grid->resolution, cloud.max_norm, init7, &c);
+  DeviceCandidates d;
+  DLIOM_TRY(upload_candidates(ctx, c, &d));
+  std::vector<unsigned> list(static_cast<size_t>(k));
+  for (int64_t i = 0; i < k; ++i) {
+    if (candidate_indices[i] < 0 || candidate_indices[i] >= c.w.num_candidates) return DLIOM_ERR_INVALID_ARGUMENT;
+    list[i] = static_cast<unsigned>(candidate_indices[i]);
+  }
+  const size_t lbytes = (static_cast<size_t>(k) * 4 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->rescore.reserve(2 * lbytes));
+  unsigned* d_list = ctx->rescore.as<unsigned>();
+  float* d_ksums = reinterpret_cast<float*>(static_cast<char*>(ctx->rescore.p) + lbytes);
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_list, list.data(), static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, ctx->stream));
+  const LutModel& lm = lut_model();
+  const int R = static_cast<int>(c.w.num_rotations);
+  const int ni = static_cast<int>(n);
+  if (method == 1) {
+    const int n_stride = (ni + 7) & ~7;
+    const size_t scan_lds = static_cast<size_t>(n_stride) * 2;
+    if (scan_lds > 128 * 1024 || k > 65535) return DLIOM_ERR_INVALID_ARGUMENT;
+    DLIOM_TRY(ctx->misc.reserve(static_cast<size_t>(k) * n_stride * 2));
+    unsigned short* d_values = ctx->misc.as<unsigned short>();
+    hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, static_cast<unsigned>(k)), dim3(256),
+                       0, ctx->stream, grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, ni, n_stride, d.rot, R, d.trans,
+                       d_list, d_values);
+    hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(static_cast<unsigned>(k)), dim3(kScanThreads), scan_lds,
+                       ctx->stream, d_values, ni, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
+  } else {
+    hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(static_cast<unsigned>(k)), dim3(256), 0, ctx->stream,
+                       grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, ni, d.rot, R, d.trans, d_list, lm.k_scale,
+                       lm.k_offset, lm.k_unknown, d_ksums);
+  }
+  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_ksums, static_cast<size_t>(k) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   return DLIOM_OK;
 }
 

@@ -178,6 +178,8 @@ SYMBOLS = [
     ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
     ("dliom_rtcsm3d_score_volume", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _u64p,
                                              C.c_int64, _i64p]),
+    ("dliom_rtcsm3d_sequential_sums", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _i64p,
+                                                C.c_int64, C.c_int, _f32p]),
     ("dliom_csm3d_evaluate", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, _f64p, C.c_int, C.POINTER(_f32p),
                                        _i64p, C.POINTER(_vp), _f64p, _f64p, _f64p]),
     ("dliom_ctx_set_profiling", C.c_int, [_vp, C.c_int]),
@@ -501,6 +503,16 @@ class RealTimeCorrelativeScanMatcher3D:
         st = RtcsmStats()
         _check(self._L.dliom_rtcsm3d_last_stats(self.ctx.h, C.byref(st)), "last_stats")
         return st
+
+    def sequential_sums(self, initial_pose_estimate, point_cloud, hybrid_grid, candidate_indices, method):
+        pts = _f32(point_cloud).reshape(-1, 3)
+        idx = np.ascontiguousarray(candidate_indices, dtype=np.int64)
+        out = np.zeros(len(idx), dtype=np.float32)
+        _check(self._L.dliom_rtcsm3d_sequential_sums(self.ctx.h, C.byref(self.options),
+                                                     _p(_f64(initial_pose_estimate), _f64p), _p(pts, _f32p), len(pts),
+                                                     hybrid_grid.h, _p(idx, _i64p), len(idx), int(method),
+                                                     _p(out, _f32p)), "dliom_rtcsm3d_sequential_sums")
+        return out
 
     def score_volume(self, initial_pose_estimate, point_cloud, hybrid_grid):
         init = _f64(initial_pose_estimate)

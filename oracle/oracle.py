@@ -91,6 +91,7 @@ def _declare(L):
     sig("orc_rtcsm3d_match", C.c_float, _f64p, _f64p, _f32p, C.c_int, vp, _f64p, _f32p, _i32p)
     sig("orc_rtcsm3d_match_range", C.c_float, _f64p, _f64p, _f32p, C.c_int, vp, C.c_int64, C.c_int64,
         C.POINTER(C.c_int64))
+    sig("orc_rtcsm3d_float_sums", None, _f64p, _f64p, _f32p, C.c_int, vp, C.POINTER(C.c_int64), C.c_int64, _f32p)
     sig("orc_rtcsm3d_value_sums", None, _f64p, _f64p, _f32p, C.c_int, vp, C.c_int64, C.c_int64, _u64p)
     sig("orc_transform_cell_indices", None, _f32p, _f32p, C.c_int, C.c_float, _i32p)
     sig("orc_interpolated_probability", C.c_double, vp, C.c_double, C.c_double, C.c_double)
@@ -397,6 +398,16 @@ def rtcsm3d_match_range(opts, init7, pts, grid, first, count):
     s = lib().orc_rtcsm3d_match_range(_p(_opts4(opts), _f64p), _p(_f64(init7), _f64p), _p(pts, _f32p), len(pts),
                                       grid.h, first, count, C.byref(best))
     return s, best.value
+
+
+def rtcsm3d_float_sums(opts, init7, pts, grid, indices):
+    """Sequential float sums (before the division by N) of the given candidates."""
+    pts = _f32(pts).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, dtype=np.int64)
+    out = np.zeros(len(idx), dtype=np.float32)
+    lib().orc_rtcsm3d_float_sums(_p(_opts4(opts), _f64p), _p(_f64(init7), _f64p), _p(pts, _f32p), len(pts), grid.h,
+                                 idx.ctypes.data_as(C.POINTER(C.c_int64)), len(idx), _p(out, _f32p))
+    return out
 
 
 def rtcsm3d_value_sums(opts, init7, pts, grid, first=0, count=-1):

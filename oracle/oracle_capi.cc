@@ -306,6 +306,23 @@ void orc_rtcsm3d_value_sums(const double* opts, const double* init7, const float
     sums[c - first] = s;
   }
 }
+// The sequential float sum of probabilities (rtcsm_3d.cc:101-104, before `score /= N`) for k
+// candidates given by index.
+void orc_rtcsm3d_float_sums(const double* opts, const double* init7, const float* pts, int n, void* grid,
+                            const int64_t* indices, int64_t k, float* sums) {
+  const RealTimeCorrelativeScanMatcher3D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  const PointCloud cloud = ToCloud(pts, n);
+  const HybridGrid& g = *G(grid);
+  const std::vector<Rigid3f> ts = m.GenerateExhaustiveSearchTransforms(g.resolution(), cloud);
+  const Rigid3f init = ToRigid(init7).cast<float>();
+  for (int64_t i = 0; i < k; ++i) {
+    const Rigid3f cand = init * ts[indices[i]];
+    float score = 0.f;
+    for (const Vec3f& p : TransformPointCloud(cloud, cand)) score += g.GetProbability(g.GetCellIndex(p));
+    sums[i] = score;
+  }
+}
 // Cell indices of a cloud under a float pose (the bit-exactness probe).
 void orc_transform_cell_indices(const float* pose7, const float* pts, int n, float resolution,
                                 int* out) {

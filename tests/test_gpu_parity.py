@@ -636,3 +636,41 @@ def test_fused_multi_grid_insertion(dl, ctx, orc):
         assert dg.cells() == oracle_cells_dict(og)
         dg.close()
     ins.close()
+
+
+@pytest.mark.parametrize("beams,azimuths,max_range", [(4, 16, None), (8, 40, 15.0), (32, 512, None), (64, 1024, None)])
+def test_sequential_sum_kernels_bit_exact(dl, ctx, orc, beams, azimuths, max_range):
+    """The reference's sequential float sum per candidate: the single-lane replay and the
+    binade-wise parallel scan both equal the oracle's loop bit for bit (N = 64 ... 65536: the sum
+    crosses up to ~13 binades)."""
+    og, pts, init, _ = _synthetic_case(orc, beams, azimuths, max_range=max_range)
+    dg = to_device_grid(dl, ctx, og)
+    m = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    C_ = m.window(0.1, pts).num_candidates
+    rng = np.random.RandomState(7)
+    idx = np.unique(np.concatenate([[0, C_ - 1, C_ // 2], rng.randint(0, C_, size=60)])).astype(np.int64)
+    want = orc.rtcsm3d_float_sums(DEFAULT_RTCSM, init, pts, og, idx)
+    serial = m.sequential_sums(init, pts, dg, idx, 0)
+    scan = m.sequential_sums(init, pts, dg, idx, 1)
+    assert np.array_equal(serial.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(scan.view(np.uint32), want.view(np.uint32))
+    dg.close()
+
+
+def test_sequential_sum_scan_handles_ties_and_saturated_values(dl, ctx, orc):
+    """Adversarial addends for the parallel scan: a grid whose cells hold only a few distinct values
+    (kMax, kMin, 0.5 -> many exact round-to-even ties in the float additions)."""
+    rng = np.random.RandomState(11)
+    og = orc.HybridGrid(0.1)
+    xyz = rng.randint(-60, 60, size=(60000, 3))
+    vals = rng.choice(np.array([1, 16384, 32767, 8192, 24576], dtype=np.uint16), size=60000)
+    og.set_values(xyz, vals)
+    pts = (rng.uniform(-5.5, 5.5, size=(30000, 3))).astype(np.float32)
+    init = orc.pose((0.01, -0.02, 0.03))
+    dg = to_device_grid(dl, ctx, og)
+    m = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    idx = np.arange(0, m.window(0.1, pts).num_candidates, 97).astype(np.int64)
+    want = orc.rtcsm3d_float_sums(DEFAULT_RTCSM, init, pts, og, idx)
+    assert np.array_equal(m.sequential_sums(init, pts, dg, idx, 1).view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(m.sequential_sums(init, pts, dg, idx, 0).view(np.uint32), want.view(np.uint32))
+    dg.close()
