@@ -193,13 +193,16 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_rot_kernel(
 // The same rotation-per-lane walk over the DENSE MIRROR of the grid (grid.hip::ensure_dense):
 // one load per lookup at a linear address, no leaf table, no leaf/cell bit surgery.
 //   y' = fma(c, 1/res, K)   K = half + 1 shifts the index into the mirror's [0, S) range for free
-//   near <=> min_c |frac(y'_c) - 1/2| <= 4 S 2^-24      (then: exact lround(c / res) path)
+//   near <=> min_c |frac(y'_c) - 1/2| <= 2.2 S 2^-24     (then: exact lround(c / res) path)
 //   i'  = v_cvt_rpi_i32_f32(y')  (floor(y' + 1/2): equals lround away from the near band)
 //   clamp to [0, S-1] (guard cells are 0 = "outside / unknown"), address = (iz' S + iy') S + ix'.
-// Error budget: fl(1/res) and the fma rounding put y' - K within (|q| + |y'|) 2^-24 of the real
-// quotient q = c/res, and the reference's lround(fl(q)) can only flip when q is within |q| 2^-24
-// of a half-integer; all three terms are < S, so 4 S 2^-24 is a safe band (~1e-4: the exact path
-// runs for ~3 % of the wave-rows).
+// Error budget, in cells, with q = c/res the real quotient (|q| <= S/2 inside the grid, y' <= S):
+//   fl(1/res) relative error 2^-24        -> |c fl(1/res) - q| <= |q| 2^-24     <= (S/2) 2^-24
+//   one rounding of the fma               -> <= ulp(y')/2 <= y' 2^-24            <=  S    2^-24
+//   the reference's lround(fl(q)) can only flip when q is within |q| 2^-24 of a half-integer
+//                                                                                <= (S/2) 2^-24
+// so outside a band of 2 S 2^-24 around the half-integers both agree; 2.2 S 2^-24 is used
+// (~6.7e-5 cells at S = 514: the exact path runs for ~2.5 % of the wave-rows).
 __device__ __forceinline__ int cvt_rpi(float y) {
   int r;
   asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(y));
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_dense_kernel(
   const float inv = g.inv_resolution;
   const int S = g.dense_stride;
   const float K = static_cast<float>(g.half + 1);
-  const float band = 4.f * static_cast<float>(S) * 5.9604645e-8f;
+  const float band = 2.2f * static_cast<float>(S) * 5.9604645e-8f;
   const int p_begin = blockIdx.y * points_per_chunk;
   const int p_end = p_begin + points_per_chunk;  // the cloud is padded: no tail handling
   for (int jc = 0; jc < T; jc += t_chunk) {
@@ -238,30 +241,34 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_dense_kernel(
 #pragma unroll 1
       for (int jj = 0; jj < tc; ++jj) {
         const float4 t = lds_trans[jc + jj];  // same address in every lane: LDS broadcast
-        unsigned off[P];
+        int ix[P], iy[P], iz[P];
+        float m = 1.f;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-          const float cx = rx[k] + t.x, cy = ry[k] + t.y, cz = rz[k] + t.z;
-          const float yx = __builtin_fmaf(cx, inv, K), yy = __builtin_fmaf(cy, inv, K),
-                      yz = __builtin_fmaf(cz, inv, K);
+          const float yx = __builtin_fmaf(rx[k] + t.x, inv, K), yy = __builtin_fmaf(ry[k] + t.y, inv, K),
+                      yz = __builtin_fmaf(rz[k] + t.z, inv, K);
           const float dx = __builtin_amdgcn_fractf(yx) - 0.5f, dy = __builtin_amdgcn_fractf(yy) - 0.5f,
                       dz = __builtin_amdgcn_fractf(yz) - 0.5f;
-          const float m = fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz));
-          int ix = cvt_rpi(yx), iy = cvt_rpi(yy), iz = cvt_rpi(yz);
-          if (__builtin_expect(m <= band, 0)) {  // within rounding reach of a cell boundary: exact path
-            ix = cell_of(cx, g.resolution) + g.half + 1;
-            iy = cell_of(cy, g.resolution) + g.half + 1;
-            iz = cell_of(cz, g.resolution) + g.half + 1;
+          m = fminf(m, fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)));
+          ix[k] = cvt_rpi(yx);
+          iy[k] = cvt_rpi(yy);
+          iz[k] = cvt_rpi(yz);
+        }
+        if (__builtin_expect(m <= band, 0)) {  // some lookup of this lane is within rounding reach of a
+#pragma unroll                                 // cell boundary: exact path for the lane's P lookups
+          for (int k = 0; k < P; ++k) {
+            ix[k] = cell_of(rx[k] + t.x, g.resolution) + g.half + 1;
+            iy[k] = cell_of(ry[k] + t.y, g.resolution) + g.half + 1;
+            iz[k] = cell_of(rz[k] + t.z, g.resolution) + g.half + 1;
           }
-          ix = min(max(ix, 0), S - 1);
-          iy = min(max(iy, 0), S - 1);
-          iz = min(max(iz, 0), S - 1);
-          off[k] = (static_cast<unsigned>(iz) * static_cast<unsigned>(S) + static_cast<unsigned>(iy)) *
-                       static_cast<unsigned>(S) + static_cast<unsigned>(ix);
         }
         unsigned v[P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) v[k] = g.dense[off[k]];
+        for (int k = 0; k < P; ++k) {
+          const int cx = min(max(ix[k], 0), S - 1), cy = min(max(iy[k], 0), S - 1), cz = min(max(iz[k], 0), S - 1);
+          v[k] = g.dense[(static_cast<unsigned>(cz) * static_cast<unsigned>(S) + static_cast<unsigned>(cy)) *
+                             static_cast<unsigned>(S) + static_cast<unsigned>(cx)];
+        }
         unsigned a = 0;
 #pragma unroll
         for (int k = 0; k < P; ++k) a += max(v[k], 1u);  // the mirror stores marker-free values

@@ -33,7 +33,7 @@ if os.path.exists(bj) and os.path.getsize(bj) > 0:
     b = json.load(open(bj))
     meta = {"num_points": b["config"]["N_hi"], "num_candidates": b["config"]["C"],
             "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"]}
-json.dump({"kernel": "rtcsm_score_kernel", "workload": meta, "counters": summary,
+json.dump({"kernel": "rtcsm_score_dense_kernel", "workload": meta, "counters": summary,
            "notes": "rocprofv3 --pmc, one pass per counter group, values are per-dispatch means. FETCH_SIZE / "
                     "WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced streams by 2x "
                     "(MI355X_MICROARCH.md HBM section): the x2 correction is applied in pmc_traffic.json "
