@@ -209,18 +209,37 @@ __device__ __forceinline__ int cvt_rpi(float y) {
   return r;
 }
 
+constexpr int kDenseMaxBlock = 256;
+
+// a * b + c on the low 24 bits of a and b: full rate (32-bit integer multiplies are quarter rate).
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b_uniform, unsigned c) {
+  unsigned r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+
 template <int P>
-__global__ __launch_bounds__(kBlock) void rtcsm_score_dense_kernel(
+__global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
     GridView g, const float* __restrict__ px, const float* __restrict__ py,
-    const float* __restrict__ pz, int points_per_chunk, const float4* __restrict__ rot, int R,
-    int r_first, int r_last, const float4* __restrict__ trans4, int T, int t_chunk,
-    unsigned long long* __restrict__ sums) {
-  extern __shared__ float4 lds_dyn[];  // [T translations | t_chunk x 256 accumulators]
+    const float* __restrict__ pz, int points_per_chunk, int point_chunks,
+    int rot_groups, const float4* __restrict__ rot, int R, int r_first, int r_last,
+    const float4* __restrict__ trans4, int T, int t_chunk, unsigned long long* __restrict__ sums) {
+  // XCD-aware block -> (point chunk, rotation group) map.  Workgroup b lands on XCD b % 8 (observed,
+  // used for speed only): the rotation groups of one point chunk run back to back on ONE XCD and
+  // share its L2 lines; chunks are dealt to the XCDs round-robin -- giving every XCD one contiguous
+  // Morton range of the cloud instead measured 8 % slower (all CUs of an XCD then hammer the few L2
+  // channels that hold one compact region of the mirror).
+  const int bs = blockDim.x;  // 64..256, picked by the host to waste the fewest lanes on R % bs
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rot_group = slot % rot_groups;
+  const int chunk_id = (slot / rot_groups) * 8 + xcd;
+  if (chunk_id >= point_chunks) return;
+  extern __shared__ float4 lds_dyn[];  // [T translations | t_chunk x blockDim accumulators]
   float4* lds_trans = lds_dyn;
   unsigned* lds_acc = reinterpret_cast<unsigned*>(lds_dyn + T);
-  for (int j = threadIdx.x; j < T; j += kBlock) lds_trans[j] = trans4[j];
+  for (int j = threadIdx.x; j < T; j += bs) lds_trans[j] = trans4[j];
   __syncthreads();
-  const int r = r_first + blockIdx.x * kBlock + threadIdx.x;
+  const int r = r_first + rot_group * bs + threadIdx.x;
   const bool active = r < r_last;
   const float4 qq = rot[active ? r : r_first];
   const Quat4 q{qq.x, qq.y, qq.z, qq.w};  // stored (w,x,y,z)
@@ -228,11 +247,12 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_dense_kernel(
   const int S = g.dense_stride;
   const float K = static_cast<float>(g.half + 1);
   const float band = 2.2f * static_cast<float>(S) * 5.9604645e-8f;
-  const int p_begin = blockIdx.y * points_per_chunk;
+  const float lim = static_cast<float>(S - 1);
+  const int p_begin = chunk_id * points_per_chunk;
   const int p_end = p_begin + points_per_chunk;  // the cloud is padded: no tail handling
   for (int jc = 0; jc < T; jc += t_chunk) {
     const int tc = min(t_chunk, T - jc);
-    for (int jj = 0; jj < tc; ++jj) lds_acc[jj * kBlock + threadIdx.x] = 0u;
+    for (int jj = 0; jj < tc; ++jj) lds_acc[jj * bs + threadIdx.x] = 0u;
 #pragma unroll 1
     for (int i = p_begin; i < p_end; i += P) {
       float rx[P], ry[P], rz[P];
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_dense_kernel(
 #pragma unroll 1
       for (int jj = 0; jj < tc; ++jj) {
         const float4 t = lds_trans[jc + jj];  // same address in every lane: LDS broadcast
-        int ix[P], iy[P], iz[P];
+        int ix[P], iy[P], iz[P];  // clamped mirror coordinates
         float m = 1.f;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -250,35 +270,38 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_dense_kernel(
           const float dx = __builtin_amdgcn_fractf(yx) - 0.5f, dy = __builtin_amdgcn_fractf(yy) - 0.5f,
                       dz = __builtin_amdgcn_fractf(yz) - 0.5f;
           m = fminf(m, fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)));
-          ix[k] = cvt_rpi(yx);
-          iy[k] = cvt_rpi(yy);
-          iz[k] = cvt_rpi(yz);
+          // clamp in float (one v_med3_f32): floor(clamp(y, 0, S-1) + 1/2) == clamp(floor(y + 1/2), 0, S-1)
+          ix[k] = cvt_rpi(__builtin_amdgcn_fmed3f(yx, 0.f, lim));
+          iy[k] = cvt_rpi(__builtin_amdgcn_fmed3f(yy, 0.f, lim));
+          iz[k] = cvt_rpi(__builtin_amdgcn_fmed3f(yz, 0.f, lim));
         }
         if (__builtin_expect(m <= band, 0)) {  // some lookup of this lane is within rounding reach of a
 #pragma unroll                                 // cell boundary: exact path for the lane's P lookups
           for (int k = 0; k < P; ++k) {
-            ix[k] = cell_of(rx[k] + t.x, g.resolution) + g.half + 1;
-            iy[k] = cell_of(ry[k] + t.y, g.resolution) + g.half + 1;
-            iz[k] = cell_of(rz[k] + t.z, g.resolution) + g.half + 1;
+            ix[k] = min(max(cell_of(rx[k] + t.x, g.resolution) + g.half + 1, 0), S - 1);
+            iy[k] = min(max(cell_of(ry[k] + t.y, g.resolution) + g.half + 1, 0), S - 1);
+            iz[k] = min(max(cell_of(rz[k] + t.z, g.resolution) + g.half + 1, 0), S - 1);
           }
         }
         unsigned v[P];
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-          const int cx = min(max(ix[k], 0), S - 1), cy = min(max(iy[k], 0), S - 1), cz = min(max(iz[k], 0), S - 1);
-          v[k] = g.dense[(static_cast<unsigned>(cz) * static_cast<unsigned>(S) + static_cast<unsigned>(cy)) *
-                             static_cast<unsigned>(S) + static_cast<unsigned>(cx)];
+          // full-rate 24-bit multiplies (S <= 1026, (z S + y) < 2^21) and a 32-bit byte offset
+          const unsigned zy = mad24(static_cast<unsigned>(iz[k]), static_cast<unsigned>(S),
+                                    static_cast<unsigned>(iy[k]));
+          const unsigned off = mad24(zy, static_cast<unsigned>(2 * S), static_cast<unsigned>(ix[k]) << 1) ;
+          v[k] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.dense) + off);
         }
         unsigned a = 0;
 #pragma unroll
         for (int k = 0; k < P; ++k) a += max(v[k], 1u);  // the mirror stores marker-free values
-        atomicAdd(&lds_acc[jj * kBlock + threadIdx.x], a);  // ds_add_u32, own column
+        atomicAdd(&lds_acc[jj * bs + threadIdx.x], a);  // ds_add_u32, own column
       }
     }
     if (active) {
       for (int jj = 0; jj < tc; ++jj)
         atomicAdd(&sums[static_cast<size_t>(jc + jj) * R + r],
-                  static_cast<unsigned long long>(lds_acc[jj * kBlock + threadIdx.x]));
+                  static_cast<unsigned long long>(lds_acc[jj * bs + threadIdx.x]));
     }
   }
 }
@@ -813,18 +836,29 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
     if (lds > 100 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;
     if (mapping == 2) {
       const int t_chunk = std::min(T, 27);
-      const size_t lds2 = lds + static_cast<size_t>(t_chunk) * kBlock * 4;
+      // block size: whole wavefronts, the fewest idle lanes in the last rotation group
+      static const int forced_bs = env_int("DLIOM_SCORE_BLOCK", 0);
+      static const int max_bs = env_int("DLIOM_SCORE_MAX_BLOCK", kDenseMaxBlock);
+      int bs = max_bs;
+      for (int cand = max_bs; cand >= 64; cand -= 64)
+        if ((Rs + cand - 1) / cand * cand < (Rs + bs - 1) / bs * bs) bs = cand;
+      if (forced_bs >= 64 && forced_bs <= kDenseMaxBlock && forced_bs % 64 == 0) bs = forced_bs;
+      const int rot_groups = (Rs + bs - 1) / bs;
+      const dim3 block(bs);
+      const size_t lds2 = lds + static_cast<size_t>(t_chunk) * bs * 4;
+      const int chunks_per_xcd = (point_chunks + 7) / 8;
+      const dim3 dense_grid(8 * chunks_per_xcd * rot_groups);
       if (pts_per_iter == 8) {
-        hipLaunchKernelGGL((rtcsm_score_dense_kernel<8>), grid_dim, block, lds2, ctx->stream, g, cloud.d_xs,
-                           cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
+        hipLaunchKernelGGL((rtcsm_score_dense_kernel<8>), dense_grid, block, lds2, ctx->stream, g, cloud.d_xs,
+                           cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
                            *d_sums);
       } else if (pts_per_iter == 2) {
-        hipLaunchKernelGGL((rtcsm_score_dense_kernel<2>), grid_dim, block, lds2, ctx->stream, g, cloud.d_xs,
-                           cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
+        hipLaunchKernelGGL((rtcsm_score_dense_kernel<2>), dense_grid, block, lds2, ctx->stream, g, cloud.d_xs,
+                           cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
                            *d_sums);
       } else {
-        hipLaunchKernelGGL((rtcsm_score_dense_kernel<4>), grid_dim, block, lds2, ctx->stream, g, cloud.d_xs,
-                           cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
+        hipLaunchKernelGGL((rtcsm_score_dense_kernel<4>), dense_grid, block, lds2, ctx->stream, g, cloud.d_xs,
+                           cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
                            *d_sums);
       }
     } else if (T == 1) {
