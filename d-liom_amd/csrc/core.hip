@@ -123,53 +123,101 @@ static size_t cloud_bytes(int64_t n) {
   return static_cast<size_t>(n) * 12 + 256 + np * 12 * 2 + np * 4 * 4 + 1024;
 }
 
-static int fill_cloud(dliom_ctx* ctx, char* base, const float* points_xyz, int64_t n,
-                      dliom_cloud* out) {
+struct CloudLayout {
+  float* aos;
+  float *x, *y, *z, *xs, *ys, *zs;
+  unsigned *keys_in, *keys_out, *idx_in, *idx_out;
+};
+
+static CloudLayout layout_cloud(char* base, int64_t n) {
   const int64_t np = pad_points(n);
-  float* aos = reinterpret_cast<float*>(base);
+  CloudLayout l;
+  l.aos = reinterpret_cast<float*>(base);
   const size_t soa_off = (static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255);
-  float* x = reinterpret_cast<float*>(base + soa_off);
-  float* y = x + np;
-  float* z = y + np;
-  float* xs = z + np;
-  float* ys = xs + np;
-  float* zs = ys + np;
-  unsigned* keys_in = reinterpret_cast<unsigned*>(zs + np);
-  unsigned* keys_out = keys_in + np;
-  unsigned* idx_in = keys_out + np;
-  unsigned* idx_out = idx_in + np;
-  if (n > 0) {
-    DLIOM_HIP_TRY(hipMemcpyAsync(aos, points_xyz, static_cast<size_t>(n) * 12,
-                                 hipMemcpyHostToDevice, ctx->stream));
+  l.x = reinterpret_cast<float*>(base + soa_off);
+  l.y = l.x + np;
+  l.z = l.y + np;
+  l.xs = l.z + np;
+  l.ys = l.xs + np;
+  l.zs = l.ys + np;
+  l.keys_in = reinterpret_cast<unsigned*>(l.zs + np);
+  l.keys_out = l.keys_in + np;
+  l.idx_in = l.keys_out + np;
+  l.idx_out = l.idx_in + np;
+  return l;
+}
+
+// Tail [n, n_padded) of the input-order arrays := 0; with `unsorted` the "Morton" arrays become a
+// padded copy of the input order (small clouds: a sort costs more than it saves).
+__global__ void pad_copy_kernel(float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
+                                int64_t n, int64_t n_padded, int unsorted, float* __restrict__ xs,
+                                float* __restrict__ ys, float* __restrict__ zs) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_padded) return;
+  if (i >= n) x[i] = y[i] = z[i] = 0.f;
+  if (unsorted) {
+    xs[i] = i < n ? x[i] : kPadCoordinate;
+    ys[i] = i < n ? y[i] : kPadCoordinate;
+    zs[i] = i < n ? z[i] : kPadCoordinate;
   }
+}
+
+// Clouds below this size keep their input order in the "Morton" arrays.
+constexpr int64_t kMortonSortMinPoints = 4096;
+
+// x, y, z [0, n) are in place on the device: pad them and build the Morton-ordered copies.
+static int finish_cloud(dliom_ctx* ctx, const CloudLayout& l, int64_t n, dliom_cloud* out) {
+  const int64_t np = pad_points(n);
   if (np > 0) {
     const int threads = 256;
     const unsigned blocks = static_cast<unsigned>((np + threads - 1) / threads);
-    hipLaunchKernelGGL(aos_to_soa_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, aos, n, np, x,
-                       y, z);
-    hipLaunchKernelGGL(morton_keys_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, x, y, z, n,
-                       keys_in, idx_in);
-    DLIOM_HIP_TRY(hipGetLastError());
-    size_t temp_bytes = 0;
-    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, idx_in,
-                                                     idx_out, static_cast<int>(n), 0, 30, ctx->stream));
-    DLIOM_TRY(ctx->sort_tmp.reserve(temp_bytes));
-    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, temp_bytes, keys_in, keys_out,
-                                                     idx_in, idx_out, static_cast<int>(n), 0, 30,
-                                                     ctx->stream));
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, x, y, z,
-                       idx_out, n, np, xs, ys, zs);
+    const bool sorted = n >= kMortonSortMinPoints;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.x, l.y, l.z, n, np,
+                       sorted ? 0 : 1, l.xs, l.ys, l.zs);
+    if (sorted) {
+      hipLaunchKernelGGL(morton_keys_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.x, l.y, l.z, n,
+                         l.keys_in, l.idx_in);
+      DLIOM_HIP_TRY(hipGetLastError());
+      size_t temp_bytes = 0;
+      DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, l.keys_in, l.keys_out, l.idx_in,
+                                                       l.idx_out, static_cast<int>(n), 0, 30, ctx->stream));
+      DLIOM_TRY(ctx->sort_tmp.reserve(temp_bytes));
+      DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, temp_bytes, l.keys_in, l.keys_out,
+                                                       l.idx_in, l.idx_out, static_cast<int>(n), 0, 30,
+                                                       ctx->stream));
+      hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.x, l.y, l.z,
+                         l.idx_out, n, np, l.xs, l.ys, l.zs);
+    }
     DLIOM_HIP_TRY(hipGetLastError());
   }
   out->ctx = ctx;
   out->n = n;
   out->n_padded = np;
-  out->d_x = x;
-  out->d_y = y;
-  out->d_z = z;
-  out->d_xs = xs;
-  out->d_ys = ys;
-  out->d_zs = zs;
+  out->d_x = l.x;
+  out->d_y = l.y;
+  out->d_z = l.z;
+  out->d_xs = l.xs;
+  out->d_ys = l.ys;
+  out->d_zs = l.zs;
+  return DLIOM_OK;
+}
+
+static int fill_cloud(dliom_ctx* ctx, char* base, const float* points_xyz, int64_t n,
+                      dliom_cloud* out) {
+  const int64_t np = pad_points(n);
+  const CloudLayout l = layout_cloud(base, n);
+  if (n > 0) {
+    DLIOM_HIP_TRY(hipMemcpyAsync(l.aos, points_xyz, static_cast<size_t>(n) * 12,
+                                 hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (np > 0) {
+    const int threads = 256;
+    const unsigned blocks = static_cast<unsigned>((np + threads - 1) / threads);
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.aos, n, np, l.x,
+                       l.y, l.z);
+  }
+  DLIOM_TRY(finish_cloud(ctx, l, n, out));
+  out->base = base;
   out->max_norm = cloud_max_norm(points_xyz, n);
   return DLIOM_OK;
 }
@@ -181,6 +229,33 @@ int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud*
   char* base = static_cast<char*>(ctx->points.p) + scratch_offset_bytes;
   out->owned_by_ctx_scratch = true;
   return fill_cloud(ctx, base, points_xyz, n, out);
+}
+
+// A cloud whose points a kernel is about to write: allocates for `n` points and hands back the
+// input-order arrays; finish_device_cloud() completes it once x, y, z [0, n) are written on
+// ctx->stream.
+int alloc_device_cloud(dliom_ctx* ctx, int64_t n, dliom_cloud** out, float** x, float** y, float** z) {
+  *out = nullptr;
+  void* base = nullptr;
+  DLIOM_HIP_TRY(hipMalloc(&base, cloud_bytes(n)));
+  dliom_cloud* c = new dliom_cloud;
+  c->owned_by_ctx_scratch = false;
+  c->base = base;
+  c->ctx = ctx;
+  c->n = n;
+  const CloudLayout l = layout_cloud(static_cast<char*>(base), n);
+  *x = l.x;
+  *y = l.y;
+  *z = l.z;
+  *out = c;
+  return DLIOM_OK;
+}
+
+int finish_device_cloud(dliom_ctx* ctx, dliom_cloud* c, float max_norm) {
+  const CloudLayout l = layout_cloud(static_cast<char*>(c->base), c->n);
+  DLIOM_TRY(finish_cloud(ctx, l, c->n, c));
+  c->max_norm = max_norm;
+  return DLIOM_OK;
 }
 
 size_t staged_cloud_bytes(int64_t n) { return cloud_bytes(n); }
@@ -405,18 +480,13 @@ int dliom_cloud_create(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom
     delete c;
     return s;
   }
-  // the allocation base is recoverable in dliom_cloud_destroy: base = (char*)d_x - soa_off
   *out = c;
   return DLIOM_OK;
 }
 
 int dliom_cloud_destroy(dliom_cloud* cloud) {
   if (cloud == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
-  if (!cloud->owned_by_ctx_scratch && cloud->d_x != nullptr) {
-    const size_t soa_off = (static_cast<size_t>(cloud->n) * 12 + 255) & ~static_cast<size_t>(255);
-    void* base = reinterpret_cast<char*>(cloud->d_x) - soa_off;
-    (void)hipFree(base);
-  }
+  if (!cloud->owned_by_ctx_scratch && cloud->base != nullptr) (void)hipFree(cloud->base);
   delete cloud;
   return DLIOM_OK;
 }

@@ -106,9 +106,9 @@ struct dliom_front_end {
   int64_t last_time = 0;
   PoseD last_pose;
   // range data of the last match (tracking frame)
-  std::vector<float> returns;
   float origin[3] = {0, 0, 0};
   dliom_cloud* returns_cloud = nullptr;
+  bool owns_returns_cloud = false;
 
   int add_submap(const PoseD& local_pose, int* finished_flag) {
     // submap_3d.cc:316-326
@@ -127,6 +127,9 @@ struct dliom_front_end {
     return DLIOM_OK;
   }
 };
+
+static int front_end_match_cloud(dliom_front_end* fe, const double pose_prediction7[7], const float origin[3],
+                                 dliom_cloud* cloud, bool take_ownership, dliom_match_result* r);
 
 static PoseD pose_from(const double* a) {
   PoseD p;
@@ -198,7 +201,7 @@ int dliom_front_end_destroy(dliom_front_end* fe) {
       if (s->hi) dliom_grid_destroy(s->hi);
       if (s->lo) dliom_grid_destroy(s->lo);
     }
-  if (fe->returns_cloud) dliom_cloud_destroy(fe->returns_cloud);
+  if (fe->returns_cloud && fe->owns_returns_cloud) dliom_cloud_destroy(fe->returns_cloud);
   if (fe->inserter) dliom_inserter_destroy(fe->inserter);
   delete fe;
   return DLIOM_OK;
@@ -209,54 +212,75 @@ int dliom_front_end_match(dliom_front_end* fe, const double pose_prediction7[7],
   if (fe == nullptr || pose_prediction7 == nullptr || origin == nullptr || r == nullptr || n < 0 ||
       (n > 0 && returns_xyz == nullptr))
     return DLIOM_ERR_INVALID_ARGUMENT;
+  // the range data moves to the device once; filters, matchers and insertion all read it there
+  dliom_cloud* cloud = nullptr;
+  DLIOM_TRY(dliom_cloud_create(fe->ctx, returns_xyz, n, &cloud));
+  const int s = front_end_match_cloud(fe, pose_prediction7, origin, cloud, true, r);
+  if (s != DLIOM_OK && fe->returns_cloud != cloud) dliom_cloud_destroy(cloud);
+  return s;
+}
+
+int dliom_front_end_match_cloud(dliom_front_end* fe, const double pose_prediction7[7], const float origin[3],
+                                const dliom_cloud* returns, dliom_match_result* r) {
+  if (fe == nullptr || pose_prediction7 == nullptr || origin == nullptr || r == nullptr || returns == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  return front_end_match_cloud(fe, pose_prediction7, origin, const_cast<dliom_cloud*>(returns), false, r);
+}
+
+}  // extern "C"
+
+// AddAccumulatedRangeData (local_trajectory_builder_3d.cc:493-553) on a device-resident cloud.
+// take_ownership: the front end destroys `cloud` when the next match replaces it.
+static int front_end_match_cloud(dliom_front_end* fe, const double pose_prediction7[7], const float origin[3],
+                                 dliom_cloud* cloud, bool take_ownership, dliom_match_result* r) {
   std::memset(r, 0, sizeof(*r));
   const dliom_front_end_options& o = fe->options;
-  // keep the range data for insert()
-  fe->returns.assign(returns_xyz, returns_xyz + 3 * n);
   std::memcpy(fe->origin, origin, sizeof(fe->origin));
-  if (fe->returns_cloud != nullptr) {
-    dliom_cloud_destroy(fe->returns_cloud);
-    fe->returns_cloud = nullptr;
-  }
-  if (n == 0) {  // "Dropped empty range data." (:497-500)
+  if (fe->returns_cloud != nullptr && fe->owns_returns_cloud) dliom_cloud_destroy(fe->returns_cloud);
+  fe->returns_cloud = cloud;
+  fe->owns_returns_cloud = take_ownership;
+  if (cloud->n == 0) {  // "Dropped empty range data." (:497-500)
     r->dropped = 1;
     return DLIOM_OK;
   }
-  DLIOM_TRY(dliom_cloud_create(fe->ctx, returns_xyz, n, &fe->returns_cloud));
+  struct CloudGuard {  // the filtered clouds live for this call only
+    dliom_cloud* c = nullptr;
+    ~CloudGuard() {
+      if (c != nullptr) dliom_cloud_destroy(c);
+    }
+  } hi, lo;
 
   const dliom_front_end::Submap& matching = *fe->submaps.front();
   const PoseD pose_prediction = pose_from(pose_prediction7);
   const PoseD prediction_in_submap = pose_mul(pose_inverse(matching.local_pose), pose_prediction);  // :504-505
   PoseD initial_ceres_pose = prediction_in_submap;
-  const std::vector<F3> returns = to_f3(returns_xyz, n);
-  const std::vector<F3> hi = adaptive_voxel_filter(o.high_resolution_adaptive_voxel_filter, returns);
-  if (hi.empty()) {
+  DLIOM_TRY(dliom_cloud_adaptive_voxel_filter(fe->ctx, cloud, &o.high_resolution_adaptive_voxel_filter, &hi.c));
+  if (hi.c->n == 0) {
     r->dropped = 1;
     return DLIOM_OK;
   }
-  r->num_high_resolution_points = static_cast<int64_t>(hi.size());
+  r->num_high_resolution_points = hi.c->n;
   r->matching_submap_index = fe->matching_submap_index;
   double init7[7];
   pose_to(initial_ceres_pose, init7);
   if (o.use_online_correlative_scan_matching) {  // :514-521
     double out7[7];
-    DLIOM_TRY(dliom_rtcsm3d_match(fe->ctx, &o.real_time_correlative_scan_matcher, init7, &hi[0].x,
-                                  static_cast<int64_t>(hi.size()), matching.hi, out7, &r->rtcsm_score));
+    DLIOM_TRY(dliom_rtcsm3d_match_cloud(fe->ctx, &o.real_time_correlative_scan_matcher, init7, hi.c, matching.hi,
+                                        out7, &r->rtcsm_score));
     initial_ceres_pose = pose_from(out7);
     pose_to(initial_ceres_pose, init7);
   }
-  const std::vector<F3> lo = adaptive_voxel_filter(o.low_resolution_adaptive_voxel_filter, returns);
-  if (lo.empty()) {
+  DLIOM_TRY(dliom_cloud_adaptive_voxel_filter(fe->ctx, cloud, &o.low_resolution_adaptive_voxel_filter, &lo.c));
+  if (lo.c->n == 0) {
     r->dropped = 1;
     return DLIOM_OK;
   }
-  r->num_low_resolution_points = static_cast<int64_t>(lo.size());
-  const float* pts[2] = {&hi[0].x, &lo[0].x};
-  const int64_t ns[2] = {static_cast<int64_t>(hi.size()), static_cast<int64_t>(lo.size())};
+  r->num_low_resolution_points = lo.c->n;
+  const dliom_cloud* clouds[2] = {hi.c, lo.c};
   const dliom_grid* grids[2] = {matching.hi, matching.lo};
   double obs7[7];
-  DLIOM_TRY(dliom_csm3d_match(fe->ctx, &o.ceres_scan_matcher, prediction_in_submap.t, init7, 2, pts, ns, grids,
-                              obs7, &r->summary));  // :535-542
+  DLIOM_TRY(dliom_csm3d_match_cloud(fe->ctx, &o.ceres_scan_matcher, prediction_in_submap.t, init7, 2, clouds, grids,
+                                    obs7, &r->summary));  // :535-542
   const PoseD observation = pose_from(obs7);
   std::memcpy(r->initial_ceres_pose, init7, sizeof(init7));
   std::memcpy(r->pose_observation_in_submap, obs7, sizeof(obs7));
@@ -277,6 +301,8 @@ int dliom_front_end_match(dliom_front_end* fe, const double pose_prediction7[7],
   pose_to(pose_mul(matching.local_pose, observation), r->pose_estimate);  // :552-553
   return DLIOM_OK;
 }
+
+extern "C" {
 
 int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double pose_estimate7[7],
                            const double gravity_alignment[4], dliom_insertion_result* r) {

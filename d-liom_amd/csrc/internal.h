@@ -72,6 +72,7 @@ struct dliom_ctx {
   dliom::DevBuf partials;   // CSM per-block partial sums
   dliom::DevBuf misc;       // small odds and ends (probe outputs, cell lists)
   dliom::DevBuf sort_tmp;   // radix-sort temporary storage (cloud staging)
+  dliom::DevBuf voxel;      // voxel-filter hash tables, slots, flags, counters (voxel_filter.hip)
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
   // profiling
@@ -125,6 +126,7 @@ struct dliom_cloud {
   float* d_zs = nullptr;
   float max_norm = 0.f;    // max_i ||p_i|| (float, Eigen order), host computed
   bool owned_by_ctx_scratch = false;
+  void* base = nullptr;    // the allocation everything above lives in
 };
 
 struct dliom_inserter {
@@ -142,6 +144,10 @@ int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud*
                 size_t scratch_offset_bytes = 0);
 float cloud_max_norm(const float* points_xyz, int64_t n);
 size_t staged_cloud_bytes(int64_t n);
+// device-built clouds (voxel_filter.hip, preprocess.hip): allocate, let a kernel write x/y/z [0, n)
+// on ctx->stream, finish (padding + Morton copies)
+int alloc_device_cloud(dliom_ctx* ctx, int64_t n, dliom_cloud** out, float** x, float** y, float** z);
+int finish_device_cloud(dliom_ctx* ctx, dliom_cloud* cloud, float max_norm);
 int needed_bits_for_cell_range(int min_index, int max_index);
 }  // namespace dliom
 

@@ -149,6 +149,9 @@ SYMBOLS = [
     ("dliom_cloud_create", C.c_int, [_vp, _f32p, C.c_int64, C.POINTER(_vp)]),
     ("dliom_cloud_destroy", C.c_int, [_vp]),
     ("dliom_cloud_size", C.c_int, [_vp, _i64p]),
+    ("dliom_cloud_voxel_filter", C.c_int, [_vp, _vp, C.c_float, C.POINTER(_vp)]),
+    ("dliom_cloud_adaptive_voxel_filter", C.c_int, [_vp, _vp, C.POINTER(AdaptiveVoxelFilterOptions), C.POINTER(_vp)]),
+    ("dliom_cloud_download", C.c_int, [_vp, _f32p]),
     ("dliom_rtcsm3d_match", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _f64p, _f32p]),
     ("dliom_rtcsm3d_match_cloud", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, _f64p, _f32p]),
     ("dliom_rtcsm3d_shard_begin", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, C.c_int, C.c_int,
@@ -164,6 +167,7 @@ SYMBOLS = [
     ("dliom_front_end_create", C.c_int, [_vp, C.POINTER(FrontEndOptions), C.POINTER(_vp)]),
     ("dliom_front_end_destroy", C.c_int, [_vp]),
     ("dliom_front_end_match", C.c_int, [_vp, _f64p, _f32p, _f32p, C.c_int64, C.POINTER(MatchResult)]),
+    ("dliom_front_end_match_cloud", C.c_int, [_vp, _f64p, _f32p, _vp, C.POINTER(MatchResult)]),
     ("dliom_front_end_insert", C.c_int, [_vp, C.c_int64, _f64p, _f64p, C.POINTER(InsertionResult)]),
     ("dliom_front_end_num_active_submaps", C.c_int, [_vp, C.POINTER(C.c_int)]),
     ("dliom_front_end_matching_index", C.c_int, [_vp, C.POINTER(C.c_int)]),
@@ -295,14 +299,42 @@ class Context:
 class PointCloud:
     """sensor::PointCloud staged in HBM (dliom_cloud)."""
 
-    def __init__(self, ctx, points):
+    def __init__(self, ctx, points=None, _handle=None):
         self._L = ctx._L
         self.ctx = ctx
+        if _handle is not None:  # a cloud built on the device (filters)
+            self.h = _handle
+            n = C.c_int64()
+            _check(self._L.dliom_cloud_size(self.h, C.byref(n)), "dliom_cloud_size")
+            self.n = n.value
+            return
         pts = _f32(points).reshape(-1, 3)
         self.n = len(pts)
         h = _vp()
         _check(self._L.dliom_cloud_create(ctx.h, _p(pts, _f32p), len(pts), C.byref(h)), "dliom_cloud_create")
         self.h = h
+
+    def __len__(self):
+        return self.n
+
+    def voxel_filter(self, size):
+        """sensor::VoxelFilter(size).Filter(cloud) on the device -> new PointCloud."""
+        h = _vp()
+        _check(self._L.dliom_cloud_voxel_filter(self.ctx.h, self.h, C.c_float(size), C.byref(h)), "dliom_cloud_voxel_filter")
+        return PointCloud(self.ctx, _handle=h)
+
+    def adaptive_voxel_filter(self, max_length, min_num_points, max_range):
+        """sensor::AdaptiveVoxelFilter(options).Filter(cloud) on the device -> new PointCloud."""
+        o = AdaptiveVoxelFilterOptions(max_length, min_num_points, max_range)
+        h = _vp()
+        _check(self._L.dliom_cloud_adaptive_voxel_filter(self.ctx.h, self.h, C.byref(o), C.byref(h)),
+               "dliom_cloud_adaptive_voxel_filter")
+        return PointCloud(self.ctx, _handle=h)
+
+    def download(self):
+        out = np.zeros((self.n, 3), dtype=np.float32)
+        _check(self._L.dliom_cloud_download(self.h, _p(out, _f32p)), "dliom_cloud_download")
+        return out
 
     def close(self):
         if getattr(self, "h", None):
@@ -696,6 +728,10 @@ class LocalTrajectoryBuilder3D:
         r = MatchResult()
         _check(self._L.dliom_front_end_match(self.h, _p(_f64(pose_prediction), _f64p), _p(_f32(origin), _f32p),
                                              _p(returns, _f32p), len(returns), C.byref(r)), "dliom_front_end_match")
+        return self._result(r)
+
+    @staticmethod
+    def _result(r):
         return dict(dropped=bool(r.dropped), pose_estimate=np.array(r.pose_estimate),
                     pose_observation_in_submap=np.array(r.pose_observation_in_submap),
                     initial_ceres_pose=np.array(r.initial_ceres_pose), rtcsm_score=r.rtcsm_score,
@@ -703,6 +739,13 @@ class LocalTrajectoryBuilder3D:
                     num_high=r.num_high_resolution_points, num_low=r.num_low_resolution_points,
                     residual_distance=r.residual_distance, residual_angle=r.residual_angle,
                     matching_submap_index=r.matching_submap_index)
+
+    def match_cloud(self, pose_prediction, origin, cloud):
+        """match() on range data that already lives on the device (keep `cloud` alive until insert())."""
+        r = MatchResult()
+        _check(self._L.dliom_front_end_match_cloud(self.h, _p(_f64(pose_prediction), _f64p), _p(_f32(origin), _f32p),
+                                                   cloud.h, C.byref(r)), "dliom_front_end_match_cloud")
+        return self._result(r)
 
     def insert(self, time_ticks, pose_estimate, gravity_alignment):
         r = InsertionResult()

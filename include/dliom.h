@@ -305,6 +305,10 @@ int dliom_front_end_destroy(dliom_front_end* fe);
  * pose_prediction: tracking frame -> local frame. */
 int dliom_front_end_match(dliom_front_end* fe, const double pose_prediction[7], const float origin[3],
                           const float* returns_xyz, int64_t num_returns, dliom_match_result* result);
+/* The same with the range data already resident on the device (e.g. the output of
+ * dliom_cloud_voxel_filter); `returns` must stay alive until the following dliom_front_end_insert. */
+int dliom_front_end_match_cloud(dliom_front_end* fe, const double pose_prediction[7], const float origin[3],
+                                const dliom_cloud* returns, dliom_match_result* result);
 /* InsertIntoSubmap with the range data of the preceding match.  time_ticks: cartographer
  * common::Time ticks (100 ns).  gravity_alignment: quaternion (w,x,y,z) used for new submaps. */
 int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double pose_estimate[7],
@@ -315,8 +319,17 @@ int dliom_front_end_matching_index(const dliom_front_end* fe, int* index);
 int dliom_front_end_active_submap(const dliom_front_end* fe, int i, double local_pose[7], int* num_range_data,
                                   int* finished, dliom_grid** high_resolution_grid,
                                   dliom_grid** low_resolution_grid);
-/* sensor::VoxelFilter / AdaptiveVoxelFilter (sensor/internal/voxel_filter.cc:39-90,147-150) on the
- * host: out_xyz has room for n points; *num_out receives the survivors (first point per voxel). */
+/* sensor::VoxelFilter::Filter / AdaptiveVoxelFilter::Filter (sensor/internal/voxel_filter.cc:81-90,
+ * 28-77,147-150) on device-resident clouds: *out is a new cloud (dliom_cloud_destroy) holding the
+ * survivors in input order -- the first point of every voxel lround(p / size).  Bit-identical to
+ * the host filters below for |p / size| < 2^20 per axis, DLIOM_ERR_INVALID_ARGUMENT beyond. */
+int dliom_cloud_voxel_filter(dliom_ctx* ctx, const dliom_cloud* in, float size, dliom_cloud** out);
+int dliom_cloud_adaptive_voxel_filter(dliom_ctx* ctx, const dliom_cloud* in,
+                                      const dliom_adaptive_voxel_filter_options* options, dliom_cloud** out);
+/* The points of a cloud in input order, packed xyz (room for dliom_cloud_size points). */
+int dliom_cloud_download(const dliom_cloud* cloud, float* points_xyz);
+/* The same filters on host buffers (the reference's own placement): out_xyz has room for n points;
+ * *num_out receives the survivors (first point per voxel). */
 int dliom_voxel_filter(float size, const float* points_xyz, int64_t n, float* out_xyz, int64_t* num_out);
 int dliom_adaptive_voxel_filter(const dliom_adaptive_voxel_filter_options* options, const float* points_xyz,
                                 int64_t n, float* out_xyz, int64_t* num_out);

@@ -674,3 +674,104 @@ def test_sequential_sum_scan_handles_ties_and_saturated_values(dl, ctx, orc):
     assert np.array_equal(m.sequential_sums(init, pts, dg, idx, 1).view(np.uint32), want.view(np.uint32))
     assert np.array_equal(m.sequential_sums(init, pts, dg, idx, 0).view(np.uint32), want.view(np.uint32))
     dg.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# device voxel filters (sensor/internal/voxel_filter.cc) vs the oracle's host restatement
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,size", [(1, 0.15), (7, 0.5), (1000, 0.05), (5000, 0.15), (65536, 0.15), (65536, 2.0)])
+def test_device_voxel_filter_equals_oracle(dl, ctx, orc, n, size):
+    """First point of every voxel, in input order: bit-identical coordinates and count.  The
+    clouds have many points per voxel AND points exactly on voxel boundaries (k + 0.5) * size."""
+    rng = np.random.RandomState(n + int(size * 100))
+    pts = rng.uniform(-20, 20, size=(n, 3)).astype(np.float32)
+    pts[::5] = pts[::5].round(1)                       # duplicates and lattice points
+    pts[1::7] = (np.floor(pts[1::7] / size) + 0.5) * np.float32(size)  # half-way cases of lround
+    want = pts[orc.voxel_filter(size, pts)]
+    cloud = dl.PointCloud(ctx, pts)
+    out = cloud.voxel_filter(size)
+    got = out.download()
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got, dl.voxel_filter(size, pts))  # and the host ABI function
+    out.close()
+    cloud.close()
+
+
+@pytest.mark.gpu
+def test_device_voxel_filter_order_semantics_kat(dl, ctx):
+    """voxel_filter_test.cc:29-41: {(0,0,0), (0.1,-0.1,0.1), (0.3,-0.1,0), (0,0,0.1)} @0.3 ->
+    the first and the third point, in that order."""
+    pts = np.array([[0, 0, 0], [0.1, -0.1, 0.1], [0.3, -0.1, 0], [0, 0, 0.1]], np.float32)
+    cloud = dl.PointCloud(ctx, pts)
+    out = cloud.voxel_filter(0.3)
+    assert np.array_equal(out.download(), pts[[0, 2]])
+    out.close()
+    empty = dl.PointCloud(ctx, np.zeros((0, 3), np.float32))
+    e2 = empty.voxel_filter(0.3)
+    assert len(e2) == 0 and e2.download().shape == (0, 3)
+    e2.close()
+    empty.close()
+    cloud.close()
+
+
+@pytest.mark.gpu
+def test_device_voxel_filter_rejects_out_of_range_indices(dl, ctx):
+    pts = np.array([[0, 0, 0], [1e7, 0, 0]], np.float32)
+    cloud = dl.PointCloud(ctx, pts)
+    with pytest.raises(dl.DliomError):
+        cloud.voxel_filter(0.001)  # 1e10 cells: outside the 21-bit key
+    cloud.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [(2.0, 150, 15.0), (4.0, 200, 60.0), (0.5, 20000, 30.0), (2.0, 1e9, 50.0),
+                                  (2.0, 10, 1.0), (0.05, 5, 60.0)])
+def test_device_adaptive_voxel_filter_equals_oracle(dl, ctx, orc, opts):
+    """AdaptiveVoxelFilter: range crop, halving search, bisection (all branches: sparse-enough early
+    return, max_length dense enough, bisection reached, nothing dense enough) on a 64x1024 scan."""
+    from dliom import synth
+    truth = synth.trajectory_pose(0.3)
+    pts, _ = synth.scan(truth, 64, 1024)
+    pts = pts[orc.voxel_filter(0.15, pts)]
+    want = orc.adaptive_voxel_filter(opts[0], opts[1], opts[2], pts)
+    cloud = dl.PointCloud(ctx, pts)
+    out = cloud.adaptive_voxel_filter(*opts)
+    got = out.download()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got, dl.adaptive_voxel_filter(opts[0], opts[1], opts[2], pts))
+    out.close()
+    cloud.close()
+
+
+@pytest.mark.gpu
+def test_front_end_match_cloud_equals_match(dl, ctx, orc):
+    """The device-resident entry point (voxel filter -> match_cloud -> insert) against the host
+    entry point on the same scans: identical results and grids."""
+    from dliom import synth
+    a = dl.LocalTrajectoryBuilder3D(ctx, FRONT_END_OPTS)
+    b = dl.LocalTrajectoryBuilder3D(ctx, FRONT_END_OPTS)
+    gravity = np.array([1.0, 0, 0, 0])
+    origin = np.zeros(3, np.float32)
+    for s in range(5):
+        truth = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(truth, 16, 512)
+        pred = synth.perturb_pose(truth, 0.03, 0.2, seed=40 + s)
+        ra = a.match(pred, origin, pts[orc.voxel_filter(0.15, pts)])
+        raw = dl.PointCloud(ctx, pts)
+        filtered = raw.voxel_filter(0.15)
+        rb = b.match_cloud(pred, origin, filtered)
+        assert ra["num_high"] == rb["num_high"] and ra["num_low"] == rb["num_low"]
+        assert np.array_equal(ra["pose_estimate"], rb["pose_estimate"])
+        a.insert(int(s * 1e6), ra["pose_estimate"], gravity)
+        b.insert(int(s * 1e6), rb["pose_estimate"], gravity)
+        filtered.close()
+        raw.close()
+    for i in range(a.num_active_submaps()):
+        sa, sb = a.active_submap(i), b.active_submap(i)
+        assert sa["hi"].cells() == sb["hi"].cells() and sa["lo"].cells() == sb["lo"].cells()
+    a.close()
+    b.close()

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""W-ref workload of SURVEY.md 8(d): the reference-faithful chain on 64x1024 scans with the
+default options of trajectory_builder_3d.lua -- fixed voxel filter 0.15 m, adaptive filters
+(2 m / 150 pts / 15 m and 4 m / 200 pts / 60 m), RTCSM3D (0.15 m / 1 deg), CeresScanMatcher3D,
+insertion into the active submaps -- through LocalTrajectoryBuilder3D on the device, and the same
+chain on the CPU oracle.  Prints per-stage wall times (p50 over the measured scans) as one JSON
+line.  Not the headline metric (bench.py measures W-dense); this is the latency the reference's
+own configuration sees."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "d-liom_amd"))
+sys.path.insert(0, ROOT)
+
+OPTS = dict(
+    high_resolution_adaptive_voxel_filter=dict(max_length=2.0, min_num_points=150, max_range=15.0),
+    low_resolution_adaptive_voxel_filter=dict(max_length=4.0, min_num_points=200, max_range=60.0),
+    use_online_correlative_scan_matching=True,
+    real_time_correlative_scan_matcher=dict(linear_search_window=0.15, angular_search_window=np.deg2rad(1.0),
+                                            translation_delta_cost_weight=1e-1, rotation_delta_cost_weight=1e-1),
+    ceres_scan_matcher=dict(occupied_space_weight=[1.0, 6.0], translation_weight=5.0, rotation_weight=4e2,
+                            only_optimize_yaw=False, use_nonmonotonic_steps=False, max_num_iterations=12,
+                            num_threads=1),
+    motion_filter=dict(max_time_seconds=0.5, max_distance_meters=0.1, max_angle_radians=0.004),
+    submaps=dict(high_resolution=0.10, high_resolution_max_range=20.0, low_resolution=0.45, num_range_data=160,
+                 hit_probability=0.55, miss_probability=0.49, num_free_space_voxels=2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scans", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--beams", type=int, default=64)
+    ap.add_argument("--azimuths", type=int, default=1024)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-scans", type=int, default=6)
+    args = ap.parse_args()
+    import dliom as dl
+    from dliom import synth
+
+    ctx = dl.Context(0)
+    fe = dl.LocalTrajectoryBuilder3D(ctx, OPTS)
+    gravity = np.array([1.0, 0, 0, 0])
+    origin = np.zeros(3, np.float32)
+    scans = []
+    for s in range(args.scans):
+        truth = synth.trajectory_pose(0.025 * s)
+        pts, _ = synth.scan(truth, args.beams, args.azimuths)
+        scans.append((truth, pts, synth.perturb_pose(truth, 0.03, 0.2, seed=100 + s)))
+
+    def run(front_end, voxel_filter, sync, n_scans):
+        rows = []
+        for s in range(n_scans):
+            truth, pts, pred = scans[s]
+            t0 = time.perf_counter()
+            filtered = voxel_filter(pts)
+            t1 = time.perf_counter()
+            r = front_end.match(pred, origin, filtered)
+            sync()
+            t2 = time.perf_counter()
+            front_end.insert(int(s * 250000), r["pose_estimate"], gravity)
+            sync()
+            t3 = time.perf_counter()
+            rows.append((t1 - t0, t2 - t1, t3 - t2, len(filtered), r["num_high"], r["num_low"]))
+        return np.array(rows)
+
+    class DeviceChain:  # raw scan -> device cloud -> device voxel filter -> match_cloud
+        def __init__(self):
+            self.keep = []
+
+        def voxel_filter(self, p):
+            for c in self.keep:
+                c.close()
+            raw = dl.PointCloud(ctx, p)
+            f = raw.voxel_filter(0.15)
+            self.keep = [raw, f]
+            return f
+
+        def match(self, pred, origin, cloud):
+            return fe.match_cloud(pred, origin, cloud)
+
+        def insert(self, *a):
+            return fe.insert(*a)
+
+    chain = DeviceChain()
+    rows = run(chain, chain.voxel_filter, ctx.synchronize, args.scans)[args.warmup:]
+    st = None
+    out = {
+        "workload": "W-ref config2: %dx%d scans, voxel filter 0.15 -> adaptive filters -> RTCSM3D -> Ceres -> insert" %
+                    (args.beams, args.azimuths),
+        "device": {"scans_per_s": 1.0 / float(np.mean(rows[:, :3].sum(axis=1))),
+                   "p50_ms": {"voxel_filter": 1e3 * float(np.median(rows[:, 0])),
+                              "match": 1e3 * float(np.median(rows[:, 1])),
+                              "insert": 1e3 * float(np.median(rows[:, 2])),
+                              "total": 1e3 * float(np.median(rows[:, :3].sum(axis=1)))},
+                   "N_filtered": int(np.median(rows[:, 3])), "N_hi": int(np.median(rows[:, 4])),
+                   "N_lo": int(np.median(rows[:, 5]))},
+    }
+    if not args.no_cpu:
+        from oracle import oracle as orc
+        ofe = orc.FrontEnd(OPTS)
+        n = min(args.cpu_scans + 1, args.scans)
+        rows_c = run(ofe, lambda p: p[orc.voxel_filter(0.15, p)], lambda: None, n)[1:]
+        out["cpu_oracle_1_thread"] = {
+            "scans_per_s": 1.0 / float(np.mean(rows_c[:, :3].sum(axis=1))),
+            "p50_ms": {"voxel_filter": 1e3 * float(np.median(rows_c[:, 0])),
+                       "match": 1e3 * float(np.median(rows_c[:, 1])),
+                       "insert": 1e3 * float(np.median(rows_c[:, 2])),
+                       "total": 1e3 * float(np.median(rows_c[:, :3].sum(axis=1)))}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
