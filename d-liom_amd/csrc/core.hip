@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 
@@ -147,34 +149,63 @@ static CloudLayout layout_cloud(char* base, int64_t n) {
   return l;
 }
 
-// Tail [n, n_padded) of the input-order arrays := 0; with `unsorted` the "Morton" arrays become a
-// padded copy of the input order (small clouds: a sort costs more than it saves).
-__global__ void pad_copy_kernel(float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
-                                int64_t n, int64_t n_padded, int unsorted, float* __restrict__ xs,
-                                float* __restrict__ ys, float* __restrict__ zs) {
+// Tail [n, n_padded) of the input-order arrays := 0.
+__global__ void pad_tail_kernel(float* __restrict__ x, float* __restrict__ y, float* __restrict__ z, int64_t n,
+                                int64_t n_padded) {
+  const int64_t i = n + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n_padded) x[i] = y[i] = z[i] = 0.f;
+}
+// Small clouds: the "Morton" arrays are a padded copy of the input order (a sort costs more than
+// it saves).
+__global__ void pad_copy_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                const float* __restrict__ z, int64_t n, int64_t n_padded,
+                                float* __restrict__ xs, float* __restrict__ ys, float* __restrict__ zs) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_padded) return;
-  if (i >= n) x[i] = y[i] = z[i] = 0.f;
-  if (unsorted) {
-    xs[i] = i < n ? x[i] : kPadCoordinate;
-    ys[i] = i < n ? y[i] : kPadCoordinate;
-    zs[i] = i < n ? z[i] : kPadCoordinate;
-  }
+  xs[i] = i < n ? x[i] : kPadCoordinate;
+  ys[i] = i < n ? y[i] : kPadCoordinate;
+  zs[i] = i < n ? z[i] : kPadCoordinate;
 }
 
 // Clouds below this size keep their input order in the "Morton" arrays.
 constexpr int64_t kMortonSortMinPoints = 4096;
 
-// x, y, z [0, n) are in place on the device: pad them and build the Morton-ordered copies.
+// x, y, z [0, n) are in place on the device: pad them.  The Morton-ordered copies are built when a
+// kernel that wants them first sees the cloud (ensure_morton).
 static int finish_cloud(dliom_ctx* ctx, const CloudLayout& l, int64_t n, dliom_cloud* out) {
   const int64_t np = pad_points(n);
+  if (np > n) {
+    const int threads = 256;
+    const unsigned blocks = static_cast<unsigned>((np - n + threads - 1) / threads);
+    hipLaunchKernelGGL(pad_tail_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.x, l.y, l.z, n, np);
+    DLIOM_HIP_TRY(hipGetLastError());
+  }
+  out->ctx = ctx;
+  out->device = ctx->device;
+  out->n = n;
+  out->n_padded = np;
+  out->d_x = l.x;
+  out->d_y = l.y;
+  out->d_z = l.z;
+  out->d_xs = l.xs;
+  out->d_ys = l.ys;
+  out->d_zs = l.zs;
+  out->morton_ready = false;
+  return DLIOM_OK;
+}
+
+int ensure_morton(dliom_ctx* ctx, const dliom_cloud* cloud) {
+  dliom_cloud* c = const_cast<dliom_cloud*>(cloud);
+  if (c->morton_ready) return DLIOM_OK;
+  const int64_t n = c->n, np = c->n_padded;
   if (np > 0) {
+    const CloudLayout l = layout_cloud(static_cast<char*>(c->base), n);
     const int threads = 256;
     const unsigned blocks = static_cast<unsigned>((np + threads - 1) / threads);
-    const bool sorted = n >= kMortonSortMinPoints;
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.x, l.y, l.z, n, np,
-                       sorted ? 0 : 1, l.xs, l.ys, l.zs);
-    if (sorted) {
+    if (n < kMortonSortMinPoints) {
+      hipLaunchKernelGGL(pad_copy_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.x, l.y, l.z, n, np, l.xs,
+                         l.ys, l.zs);
+    } else {
       hipLaunchKernelGGL(morton_keys_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.x, l.y, l.z, n,
                          l.keys_in, l.idx_in);
       DLIOM_HIP_TRY(hipGetLastError());
@@ -190,15 +221,7 @@ static int finish_cloud(dliom_ctx* ctx, const CloudLayout& l, int64_t n, dliom_c
     }
     DLIOM_HIP_TRY(hipGetLastError());
   }
-  out->ctx = ctx;
-  out->n = n;
-  out->n_padded = np;
-  out->d_x = l.x;
-  out->d_y = l.y;
-  out->d_z = l.z;
-  out->d_xs = l.xs;
-  out->d_ys = l.ys;
-  out->d_zs = l.zs;
+  c->morton_ready = true;
   return DLIOM_OK;
 }
 
@@ -231,16 +254,63 @@ int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud*
   return fill_cloud(ctx, base, points_xyz, n, out);
 }
 
+// Cloud allocations are pooled per device: a scan makes four clouds (raw, filtered, high, low) and
+// hipMalloc/hipFree cost more than the kernels that fill them.  Blocks are power-of-two sized and
+// handed back by dliom_cloud_destroy after a device synchronise (what hipFree would have done).
+namespace {
+struct PoolBlock {
+  int device;
+  size_t bytes;
+  void* p;
+};
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> g_pool;
+constexpr size_t kPoolMaxBlocks = 64;
+}  // namespace
+
+static int pool_alloc(int device, size_t need, void** p, size_t* bytes) {
+  size_t cls = 64 * 1024;
+  while (cls < need) cls <<= 1;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t i = 0; i < g_pool.size(); ++i)
+      if (g_pool[i].device == device && g_pool[i].bytes == cls) {
+        *p = g_pool[i].p;
+        *bytes = cls;
+        g_pool.erase(g_pool.begin() + i);
+        return DLIOM_OK;
+      }
+  }
+  DLIOM_HIP_TRY(hipMalloc(p, cls));
+  *bytes = cls;
+  return DLIOM_OK;
+}
+
+static void pool_free(int device, void* p, size_t bytes) {
+  (void)hipDeviceSynchronize();  // nothing in flight may still read the block
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_pool.size() < kPoolMaxBlocks) {
+      g_pool.push_back(PoolBlock{device, bytes, p});
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
 // A cloud whose points a kernel is about to write: allocates for `n` points and hands back the
 // input-order arrays; finish_device_cloud() completes it once x, y, z [0, n) are written on
 // ctx->stream.
 int alloc_device_cloud(dliom_ctx* ctx, int64_t n, dliom_cloud** out, float** x, float** y, float** z) {
   *out = nullptr;
   void* base = nullptr;
-  DLIOM_HIP_TRY(hipMalloc(&base, cloud_bytes(n)));
+  size_t bytes = 0;
+  DLIOM_TRY(pool_alloc(ctx->device, cloud_bytes(n), &base, &bytes));
   dliom_cloud* c = new dliom_cloud;
   c->owned_by_ctx_scratch = false;
   c->base = base;
+  c->base_bytes = bytes;
+  c->device = ctx->device;
   c->ctx = ctx;
   c->n = n;
   const CloudLayout l = layout_cloud(static_cast<char*>(base), n);
@@ -470,13 +540,16 @@ int dliom_cloud_create(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom
   *out = nullptr;
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   void* base = nullptr;
-  DLIOM_HIP_TRY(hipMalloc(&base, staged_cloud_bytes(n)));
+  size_t bytes = 0;
+  DLIOM_TRY(pool_alloc(ctx->device, staged_cloud_bytes(n), &base, &bytes));
   dliom_cloud* c = new dliom_cloud;
   c->owned_by_ctx_scratch = false;
   int s = fill_cloud(ctx, static_cast<char*>(base), points_xyz, n, c);
+  c->base_bytes = bytes;
+  // the host buffer may be reused by the caller as soon as we return
   if (s == DLIOM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) s = DLIOM_ERR_HIP;
   if (s != DLIOM_OK) {
-    (void)hipFree(base);
+    pool_free(ctx->device, base, bytes);
     delete c;
     return s;
   }
@@ -486,7 +559,7 @@ int dliom_cloud_create(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom
 
 int dliom_cloud_destroy(dliom_cloud* cloud) {
   if (cloud == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
-  if (!cloud->owned_by_ctx_scratch && cloud->base != nullptr) (void)hipFree(cloud->base);
+  if (!cloud->owned_by_ctx_scratch && cloud->base != nullptr) pool_free(cloud->device, cloud->base, cloud->base_bytes);
   delete cloud;
   return DLIOM_OK;
 }

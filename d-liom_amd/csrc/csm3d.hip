@@ -550,6 +550,7 @@ static int setup_problem(dliom_ctx* ctx, const dliom_csm_options* o, const doubl
     if (clouds[i]->n <= 0) return DLIOM_ERR_EMPTY_CLOUD;
     CsmCloudArg& c = p->args.cloud[i];
     c.g = grids[i]->view();
+    DLIOM_TRY(ensure_morton(ctx, clouds[i]));
     c.x = clouds[i]->d_xs;  // Morton order: neighbouring lanes read neighbouring voxels; the
     c.y = clouds[i]->d_ys;  // reduction order is still fixed, so results stay reproducible
     c.z = clouds[i]->d_zs;

@@ -127,6 +127,9 @@ struct dliom_cloud {
   float max_norm = 0.f;    // max_i ||p_i|| (float, Eigen order), host computed
   bool owned_by_ctx_scratch = false;
   void* base = nullptr;    // the allocation everything above lives in
+  size_t base_bytes = 0;   // its size class (cloud allocations are pooled per device)
+  int device = 0;
+  bool morton_ready = false;  // d_xs/d_ys/d_zs are built on first use (ensure_morton)
 };
 
 struct dliom_inserter {
@@ -148,6 +151,20 @@ size_t staged_cloud_bytes(int64_t n);
 // on ctx->stream, finish (padding + Morton copies)
 int alloc_device_cloud(dliom_ctx* ctx, int64_t n, dliom_cloud** out, float** x, float** y, float** z);
 int finish_device_cloud(dliom_ctx* ctx, dliom_cloud* cloud, float max_norm);
+// builds the Morton-ordered copies of a cloud on ctx->stream if they are not there yet (a cache of
+// the cloud's contents, hence callable on const clouds)
+int ensure_morton(dliom_ctx* ctx, const dliom_cloud* cloud);
+// voxel_filter.hip on bare device arrays (w: optional 4th channel carried along, e.g. point times)
+struct Soa {
+  const float *x, *y, *z, *w;
+  int64_t n;
+};
+// VoxelFilter(size): survivors into ox..ow (room for n), count in *n_out; synchronises once.
+int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, float* oy, float* oz, float* ow,
+                        int64_t* n_out);
+// Order-preserving compaction of the points with kinds[i] == want; synchronises once.
+int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
+                         float* oy, float* oz, int64_t* n_out);
 int needed_bits_for_cell_range(int min_index, int max_index);
 }  // namespace dliom
 

@@ -1,8 +1,12 @@
 // Per-scan pre-processing of LocalTrajectoryBuilder3D::AddRangeData
-// (mapping/internal/3d/local_trajectory_builder_3d.cc:393-487): the per-hit de-skew -- one
-// double-precision slerp + rigid composition per point, the part the reference pays ~1 us per
-// point for -- runs on the device; the order-dependent "first point per voxel" filters around it
-// stay on the host (front_end.hip) until the device voxel filter lands.
+// (mapping/internal/3d/local_trajectory_builder_3d.cc:393-487) on the device:
+//   VoxelFilter(0.5 * voxel_filter_size) on the timed hits (:393-395)      voxel_filter.hip
+//   per-hit de-skew: double slerp + rigid composition, range gate (:421-472)   deskew_kernel
+//   returns = hits with min_range <= range <= max_range (order kept)        compaction
+//   VoxelFilter(voxel_filter_size) on the returns (:479-484)                  voxel_filter.hip
+//   TransformRangeData(., current_pose.inverse()) (:485-487)                  transform_kernel
+// dliom_add_range_data() chains them without leaving HBM; dliom_deskew() is the de-skew alone on
+// host buffers.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -39,12 +43,17 @@ __device__ __forceinline__ void quat_mul_sse_d(const double* a, const double* b,
 // One hit: pose_i = (prev * [s t_rel, slerp(I, q_rel, s)]).cast<float>() (:437-445,869-877), then
 // hit/origin into the local frame and the range gate (:454-472).
 // out_kind: 0 dropped (range < min_range), 1 return, 2 miss (beyond max_range: cropped ray end).
-__global__ void deskew_kernel(DeskewArgs a, const float4* __restrict__ hits, int n,
-                              float* __restrict__ out_xyz, unsigned char* __restrict__ out_kind,
+// Inputs / outputs are strided so that packed host layouts (xyzt stride 4, xyz stride 3) and the
+// device SoA layout (stride 1) run the same code.
+__global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, const float* __restrict__ in_y,
+                              const float* __restrict__ in_z, const float* __restrict__ in_t, int in_stride, int n,
+                              float* __restrict__ out_x, float* __restrict__ out_y, float* __restrict__ out_z,
+                              int out_stride, unsigned char* __restrict__ out_kind,
                               float* __restrict__ last_pose7) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float4 h = hits[i];
+  const size_t ii = static_cast<size_t>(i) * in_stride;
+  const float4 h = make_float4(in_x[ii], in_y[ii], in_z[ii], in_t[ii]);
   Quat4 q;
   float tx, ty, tz;
   if (a.use_stamps) {
@@ -118,9 +127,10 @@ __global__ void deskew_kernel(DeskewArgs a, const float4* __restrict__ hits, int
       hz = oz + f * dz;
     }
   }
-  out_xyz[3 * i] = hx;
-  out_xyz[3 * i + 1] = hy;
-  out_xyz[3 * i + 2] = hz;
+  const size_t oi = static_cast<size_t>(i) * out_stride;
+  out_x[oi] = hx;
+  out_y[oi] = hy;
+  out_z[oi] = hz;
   out_kind[i] = kind;
   if (i == n - 1) {  // current_pose = hits_poses.back() (:477)
     last_pose7[0] = tx;
@@ -133,9 +143,155 @@ __global__ void deskew_kernel(DeskewArgs a, const float4* __restrict__ hits, int
   }
 }
 
+__global__ void split_xyzt_kernel(const float4* __restrict__ aos, int n, float* __restrict__ x,
+                                  float* __restrict__ y, float* __restrict__ z, float* __restrict__ t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = aos[i];
+  x[i] = p.x;
+  y[i] = p.y;
+  z[i] = p.z;
+  t[i] = p.w;
+}
+
+// sensor::TransformPointCloud in float (sensor/point_cloud.cc:25-33): rotation * p + translation.
+__global__ void transform_kernel(Quat4 q, float tx, float ty, float tz, const float* __restrict__ x,
+                                 const float* __restrict__ y, const float* __restrict__ z, int n,
+                                 float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
+                                 unsigned* __restrict__ max_sq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float rx, ry, rz;
+  rotate_point(q, x[i], y[i], z[i], rx, ry, rz);
+  rx += tx;
+  ry += ty;
+  rz += tz;
+  ox[i] = rx;
+  oy[i] = ry;
+  oz[i] = rz;
+  atomicMax(max_sq, __float_as_uint(rx * rx + (ry * ry + rz * rz)));
+}
+
+static int make_deskew_args(const double prev_pose[7], const double predicted_pose[7], double scan_period,
+                            const float origin[3], float min_range, float max_range, float first_time,
+                            DeskewArgs* a) {
+  PoseD prev, cur;
+  for (int i = 0; i < 3; ++i) {
+    prev.t[i] = prev_pose[i];
+    cur.t[i] = predicted_pose[i];
+  }
+  for (int i = 0; i < 4; ++i) {
+    prev.q[i] = prev_pose[3 + i];
+    cur.q[i] = predicted_pose[3 + i];
+  }
+  const PoseD rel = pose_mul(pose_inverse(prev), cur);  // :427
+  std::memcpy(a->prev_t, prev.t, sizeof(a->prev_t));
+  std::memcpy(a->prev_q, prev.q, sizeof(a->prev_q));
+  std::memcpy(a->rel_t, rel.t, sizeof(a->rel_t));
+  std::memcpy(a->rel_q, rel.q, sizeof(a->rel_q));
+  float cf[7];
+  pose_to_float7(cur, cf);
+  std::memcpy(a->cur_t, cf, 12);
+  std::memcpy(a->cur_q, cf + 3, 16);
+  a->scan_period = scan_period;
+  a->ox = origin[0];
+  a->oy = origin[1];
+  a->oz = origin[2];
+  a->min_range = min_range;
+  a->max_range = max_range;
+  a->use_stamps = std::abs(first_time) < 1e-3 ? 0 : 1;  // hits.front().point_time[3] (:429)
+  return DLIOM_OK;
+}
+
 }  // namespace dliom
 
 using namespace dliom;
+
+extern "C" int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7],
+                                    double scan_period, const float* ranges_xyzt, int64_t n, const float origin[3],
+                                    float min_range, float max_range, float voxel_filter_size,
+                                    dliom_cloud** returns_in_tracking, float origin_in_tracking[3],
+                                    float current_pose[7]) {
+  if (ctx == nullptr || prev_pose == nullptr || predicted_pose == nullptr || origin == nullptr || n < 0 ||
+      returns_in_tracking == nullptr || origin_in_tracking == nullptr || current_pose == nullptr ||
+      (n > 0 && ranges_xyzt == nullptr) || !(scan_period > 0.) || !(voxel_filter_size > 0.f))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  *returns_in_tracking = nullptr;
+  if (n == 0) return DLIOM_ERR_EMPTY_CLOUD;  // CHECK(!synchronized_data.ranges.empty()) (:383)
+  if (n > (1 << 30)) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t nn = static_cast<size_t>(n);
+  auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  // scratch: raw AoS | raw SoA (4) | filtered hits SoA (4) | de-skewed SoA (3) + kind | returns (3) |
+  // filtered returns (3) | pose
+  const size_t off_raw = 0, off_b = al(16 * nn), off_c = off_b + al(16 * nn), off_d = off_c + al(16 * nn),
+               off_kind = off_d + al(12 * nn), off_e = off_kind + al(nn), off_f = off_e + al(12 * nn),
+               off_pose = off_f + al(12 * nn), total = off_pose + 256;
+  DLIOM_TRY(ctx->misc.reserve(total));
+  char* base = static_cast<char*>(ctx->misc.p);
+  float* b = reinterpret_cast<float*>(base + off_b);
+  float* c = reinterpret_cast<float*>(base + off_c);
+  float* d = reinterpret_cast<float*>(base + off_d);
+  unsigned char* kind = reinterpret_cast<unsigned char*>(base + off_kind);
+  float* e = reinterpret_cast<float*>(base + off_e);
+  float* f = reinterpret_cast<float*>(base + off_f);
+  float* d_pose = reinterpret_cast<float*>(base + off_pose);
+  unsigned* d_max_sq = reinterpret_cast<unsigned*>(d_pose + 8);
+  const int threads = 256;
+  DLIOM_HIP_TRY(hipMemcpyAsync(base + off_raw, ranges_xyzt, 16 * nn, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(split_xyzt_kernel, dim3(static_cast<unsigned>((n + threads - 1) / threads)), dim3(threads), 0,
+                     ctx->stream, reinterpret_cast<const float4*>(base + off_raw), static_cast<int>(n), b, b + nn,
+                     b + 2 * nn, b + 3 * nn);
+  // hits = VoxelFilter(0.5f * voxel_filter_size).Filter(ranges): the time rides along
+  int64_t n1 = 0;
+  DLIOM_TRY(voxel_filter_arrays(ctx, Soa{b, b + nn, b + 2 * nn, b + 3 * nn, n}, 0.5f * voxel_filter_size, c, c + nn,
+                                c + 2 * nn, c + 3 * nn, &n1));
+  DeskewArgs a;
+  // the first range always survives the filter, so hits.front() is ranges.front()
+  DLIOM_TRY(make_deskew_args(prev_pose, predicted_pose, scan_period, origin, min_range, max_range, ranges_xyzt[3], &a));
+  hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n1 + threads - 1) / threads)), dim3(threads), 0,
+                     ctx->stream, a, c, c + nn, c + 2 * nn, c + 3 * nn, 1, static_cast<int>(n1), d, d + nn, d + 2 * nn,
+                     1, kind, d_pose);
+  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_HIP_TRY(hipMemcpyAsync(current_pose, d_pose, 28, hipMemcpyDeviceToHost, ctx->stream));
+  // returns (kind 1), in hit order; misses (kind 2) are not used by the 3D path
+  int64_t n2 = 0;
+  DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, &n2));
+  int64_t n3 = 0;
+  DLIOM_TRY(voxel_filter_arrays(ctx, Soa{e, e + nn, e + 2 * nn, nullptr, n2}, voxel_filter_size, f, f + nn, f + 2 * nn,
+                                nullptr, &n3));
+  // current_pose.inverse() in float (rigid_transform.h:167-171); current_pose arrived with the sync above
+  const QF qc{current_pose[3], -current_pose[4], -current_pose[5], -current_pose[6]};
+  const F3 rt = qrot(qc, F3{current_pose[0], current_pose[1], current_pose[2]});
+  const F3 ti{-rt.x, -rt.y, -rt.z};
+  const F3 o = add3(qrot(qc, F3{current_pose[0], current_pose[1], current_pose[2]}), ti);  // inverse * origin
+  origin_in_tracking[0] = o.x;
+  origin_in_tracking[1] = o.y;
+  origin_in_tracking[2] = o.z;
+  float *ox, *oy, *oz;
+  DLIOM_TRY(alloc_device_cloud(ctx, n3, returns_in_tracking, &ox, &oy, &oz));
+  float max_norm = 0.f;
+  int st = DLIOM_OK;
+  if (n3 > 0) {
+    if (hipMemsetAsync(d_max_sq, 0, 4, ctx->stream) != hipSuccess) st = DLIOM_ERR_HIP;
+    hipLaunchKernelGGL(transform_kernel, dim3(static_cast<unsigned>((n3 + threads - 1) / threads)), dim3(threads), 0,
+                       ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y, ti.z, f, f + nn, f + 2 * nn,
+                       static_cast<int>(n3), ox, oy, oz, d_max_sq);
+    unsigned* host = static_cast<unsigned*>(ctx->pinned);
+    if (st == DLIOM_OK && (hipMemcpyAsync(host, d_max_sq, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                           hipStreamSynchronize(ctx->stream) != hipSuccess))
+      st = DLIOM_ERR_HIP;
+    float sq;
+    std::memcpy(&sq, host, 4);
+    max_norm = std::sqrt(sq);
+  }
+  if (st == DLIOM_OK) st = finish_device_cloud(ctx, *returns_in_tracking, max_norm);
+  if (st != DLIOM_OK) {
+    dliom_cloud_destroy(*returns_in_tracking);
+    *returns_in_tracking = nullptr;
+  }
+  return st;
+}
 
 extern "C" int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7],
                             double scan_period, const float* hits_xyzt, int64_t n, const float origin[3],
@@ -147,32 +303,8 @@ extern "C" int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const dou
     return DLIOM_ERR_INVALID_ARGUMENT;
   if (n == 0) return DLIOM_ERR_EMPTY_CLOUD;  // CHECK(!synchronized_data.ranges.empty()) (:383)
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  PoseD prev, cur;
-  for (int i = 0; i < 3; ++i) {
-    prev.t[i] = prev_pose[i];
-    cur.t[i] = predicted_pose[i];
-  }
-  for (int i = 0; i < 4; ++i) {
-    prev.q[i] = prev_pose[3 + i];
-    cur.q[i] = predicted_pose[3 + i];
-  }
-  const PoseD rel = pose_mul(pose_inverse(prev), cur);  // :427
   DeskewArgs a;
-  std::memcpy(a.prev_t, prev.t, sizeof(a.prev_t));
-  std::memcpy(a.prev_q, prev.q, sizeof(a.prev_q));
-  std::memcpy(a.rel_t, rel.t, sizeof(a.rel_t));
-  std::memcpy(a.rel_q, rel.q, sizeof(a.rel_q));
-  float cf[7];
-  pose_to_float7(cur, cf);
-  std::memcpy(a.cur_t, cf, 12);
-  std::memcpy(a.cur_q, cf + 3, 16);
-  a.scan_period = scan_period;
-  a.ox = origin[0];
-  a.oy = origin[1];
-  a.oz = origin[2];
-  a.min_range = min_range;
-  a.max_range = max_range;
-  a.use_stamps = std::abs(hits_xyzt[3]) < 1e-3 ? 0 : 1;  // hits.front().point_time[3] (:429)
+  DLIOM_TRY(make_deskew_args(prev_pose, predicted_pose, scan_period, origin, min_range, max_range, hits_xyzt[3], &a));
   const size_t in_bytes = static_cast<size_t>(n) * 16;
   const size_t xyz_off = (in_bytes + 255) & ~static_cast<size_t>(255);
   const size_t kind_off = xyz_off + ((static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255));
@@ -181,9 +313,11 @@ extern "C" int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const dou
   char* base = static_cast<char*>(ctx->misc.p);
   DLIOM_HIP_TRY(hipMemcpyAsync(base, hits_xyzt, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, a,
-                     reinterpret_cast<const float4*>(base), static_cast<int>(n),
-                     reinterpret_cast<float*>(base + xyz_off), reinterpret_cast<unsigned char*>(base + kind_off),
-                     reinterpret_cast<float*>(base + pose_off));
+                     reinterpret_cast<const float*>(base), reinterpret_cast<const float*>(base) + 1,
+                     reinterpret_cast<const float*>(base) + 2, reinterpret_cast<const float*>(base) + 3, 4,
+                     static_cast<int>(n), reinterpret_cast<float*>(base + xyz_off),
+                     reinterpret_cast<float*>(base + xyz_off) + 1, reinterpret_cast<float*>(base + xyz_off) + 2, 3,
+                     reinterpret_cast<unsigned char*>(base + kind_off), reinterpret_cast<float*>(base + pose_off));
   DLIOM_HIP_TRY(hipGetLastError());
   DLIOM_HIP_TRY(hipMemcpyAsync(out_xyz, base + xyz_off, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipMemcpyAsync(out_kind, base + kind_off, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));

@@ -28,6 +28,8 @@
 
 namespace dliom {
 
+int read_max_norm(dliom_ctx* ctx, const unsigned* d_max_sq, float* max_norm);
+
 constexpr int kVfBlock = 256;
 constexpr int kMaxLengths = 24;
 constexpr unsigned long long kEmptyKey = ~0ull;
@@ -215,7 +217,7 @@ static int carve_scratch(dliom_ctx* ctx, int64_t n, VfScratch* s) {
 
 // Insert launch for `sizes`; counts[k] = survivors of VoxelFilter(sizes[k]); *in_range = points
 // passing the crop.  Synchronises the stream (8..100-byte readback through pinned memory).
-static int run_insert(dliom_ctx* ctx, const dliom_cloud& in, bool crop, float max_range,
+static int run_insert(dliom_ctx* ctx, const Soa& in, bool crop, float max_range,
                       const std::vector<float>& sizes, VfTables* t, std::vector<unsigned>* counts,
                       unsigned* in_range) {
   const int num = static_cast<int>(sizes.size());
@@ -230,7 +232,7 @@ static int run_insert(dliom_ctx* ctx, const dliom_cloud& in, bool crop, float ma
   DLIOM_HIP_TRY(hipMemsetAsync(t->counters, 0, (num + 2) * 4, ctx->stream));
   const unsigned n = static_cast<unsigned>(in.n);
   const dim3 grid((n + kVfBlock - 1) / kVfBlock, num);
-  hipLaunchKernelGGL(voxel_insert_kernel, grid, dim3(kVfBlock), 0, ctx->stream, in.d_x, in.d_y, in.d_z, n,
+  hipLaunchKernelGGL(voxel_insert_kernel, grid, dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z, n,
                      crop ? 1 : 0, max_range, lengths, *t);
   DLIOM_HIP_TRY(hipGetLastError());
   unsigned* host = static_cast<unsigned*>(ctx->pinned);
@@ -242,35 +244,101 @@ static int run_insert(dliom_ctx* ctx, const dliom_cloud& in, bool crop, float ma
   return DLIOM_OK;
 }
 
-// flag + compact of table (t, l) into a new cloud of `n_out` points.
-static int emit_cloud(dliom_ctx* ctx, const dliom_cloud& in, const VfScratch& s, const VfTables& t, int l, int mode,
+// flag + compact of table (t, l) into caller-provided arrays (room for the survivor count the
+// insert launch reported).  max_sq != nullptr: device word receiving the survivors' largest
+// squared norm (zeroed here).  No synchronisation.
+static int emit_arrays(dliom_ctx* ctx, const Soa& in, const VfScratch& s, const VfTables& t, int l, int mode,
+                       float* ox, float* oy, float* oz, float* ow, unsigned* max_sq) {
+  const unsigned n = static_cast<unsigned>(in.n);
+  const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
+  if (max_sq != nullptr) DLIOM_HIP_TRY(hipMemsetAsync(max_sq, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(voxel_flag_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, n, t, l, mode, s.flags,
+                     s.block_counts);
+  hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z, in.w, n,
+                     s.flags, s.block_counts, ox, oy, oz, ow, static_cast<unsigned*>(nullptr), max_sq);
+  DLIOM_HIP_TRY(hipGetLastError());
+  return DLIOM_OK;
+}
+
+// ... into a new cloud of `n_out` points.
+static int emit_cloud(dliom_ctx* ctx, const Soa& in, const VfScratch& s, const VfTables& t, int l, int mode,
                       int64_t n_out, dliom_cloud** out) {
   float *ox, *oy, *oz;
   DLIOM_TRY(alloc_device_cloud(ctx, n_out, out, &ox, &oy, &oz));
   float max_norm = 0.f;
+  int st = DLIOM_OK;
   if (n_out > 0) {
-    const unsigned n = static_cast<unsigned>(in.n);
-    const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
-    DLIOM_HIP_TRY(hipMemsetAsync(s.max_sq, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(voxel_flag_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, n, t, l, mode, s.flags,
-                       s.block_counts);
-    hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.d_x, in.d_y, in.d_z,
-                       static_cast<const float*>(nullptr), n, s.flags, s.block_counts, ox, oy, oz,
-                       static_cast<float*>(nullptr), static_cast<unsigned*>(nullptr), s.max_sq);
-    DLIOM_HIP_TRY(hipGetLastError());
-    unsigned* host = static_cast<unsigned*>(ctx->pinned);
-    DLIOM_HIP_TRY(hipMemcpyAsync(host, s.max_sq, 4, hipMemcpyDeviceToHost, ctx->stream));
-    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    float sq;
-    std::memcpy(&sq, host, 4);
-    max_norm = std::sqrt(sq);  // sqrt is monotone and correctly rounded: == max of the norms
+    st = emit_arrays(ctx, Soa{in.x, in.y, in.z, nullptr, in.n}, s, t, l, mode, ox, oy, oz, nullptr, s.max_sq);
+    if (st == DLIOM_OK) st = read_max_norm(ctx, s.max_sq, &max_norm);
   }
-  const int st = finish_device_cloud(ctx, *out, max_norm);
+  if (st == DLIOM_OK) st = finish_device_cloud(ctx, *out, max_norm);
   if (st != DLIOM_OK) {
     dliom_cloud_destroy(*out);
     *out = nullptr;
   }
   return st;
+}
+
+// Compacts the points with flags[i] != 0 (order kept).  block_counts: scratch for n/256+1 words.
+__global__ __launch_bounds__(kVfBlock) void count_flags_kernel(const unsigned char* __restrict__ flags, unsigned n,
+                                                               unsigned char want,
+                                                               unsigned char* __restrict__ out_flags,
+                                                               unsigned* __restrict__ block_counts,
+                                                               unsigned* __restrict__ total) {
+  const unsigned i = blockIdx.x * kVfBlock + threadIdx.x;
+  const bool keep = i < n && flags[i] == want;
+  if (i < n) out_flags[i] = keep ? 1 : 0;
+  const int c = __syncthreads_count(keep ? 1 : 0);
+  if (threadIdx.x == 0) {
+    block_counts[blockIdx.x] = static_cast<unsigned>(c);
+    atomicAdd(total, static_cast<unsigned>(c));
+  }
+}
+
+int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, float* oy, float* oz, float* ow,
+                        int64_t* n_out) {
+  *n_out = 0;
+  if (!(size > 0.f)) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (in.n == 0) return DLIOM_OK;
+  VfScratch s;
+  DLIOM_TRY(carve_scratch(ctx, in.n, &s));
+  std::vector<unsigned> counts;
+  unsigned in_range = 0;
+  DLIOM_TRY(run_insert(ctx, in, false, 0.f, {size}, &s.tables[0], &counts, &in_range));
+  *n_out = counts[0];
+  return emit_arrays(ctx, in, s, s.tables[0], 0, 0, ox, oy, oz, ow, nullptr);
+}
+
+int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
+                         float* oy, float* oz, int64_t* n_out) {
+  *n_out = 0;
+  if (in.n == 0) return DLIOM_OK;
+  VfScratch s;
+  DLIOM_TRY(carve_scratch(ctx, in.n, &s));
+  const unsigned n = static_cast<unsigned>(in.n);
+  const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
+  DLIOM_HIP_TRY(hipMemsetAsync(s.max_sq, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, kinds, n, want, s.flags,
+                     s.block_counts, s.max_sq);
+  hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z,
+                     static_cast<const float*>(nullptr), n, s.flags, s.block_counts, ox, oy, oz,
+                     static_cast<float*>(nullptr), static_cast<unsigned*>(nullptr), static_cast<unsigned*>(nullptr));
+  DLIOM_HIP_TRY(hipGetLastError());
+  unsigned* host = static_cast<unsigned*>(ctx->pinned);
+  DLIOM_HIP_TRY(hipMemcpyAsync(host, s.max_sq, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *n_out = host[0];
+  return DLIOM_OK;
+}
+
+int read_max_norm(dliom_ctx* ctx, const unsigned* d_max_sq, float* max_norm) {
+  unsigned* host = static_cast<unsigned*>(ctx->pinned);
+  DLIOM_HIP_TRY(hipMemcpyAsync(host, d_max_sq, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  float sq;
+  std::memcpy(&sq, host, 4);
+  *max_norm = std::sqrt(sq);  // sqrt is monotone and correctly rounded: == max of the norms
+  return DLIOM_OK;
 }
 
 int voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, float size, dliom_cloud** out) {
@@ -285,8 +353,9 @@ int voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, float size, dliom_
   DLIOM_TRY(carve_scratch(ctx, in.n, &s));
   std::vector<unsigned> counts;
   unsigned in_range = 0;
-  DLIOM_TRY(run_insert(ctx, in, false, 0.f, {size}, &s.tables[0], &counts, &in_range));
-  return emit_cloud(ctx, in, s, s.tables[0], 0, 0, counts[0], out);
+  const Soa soa{in.d_x, in.d_y, in.d_z, nullptr, in.n};
+  DLIOM_TRY(run_insert(ctx, soa, false, 0.f, {size}, &s.tables[0], &counts, &in_range));
+  return emit_cloud(ctx, soa, s, s.tables[0], 0, 0, counts[0], out);
 }
 
 int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dliom_adaptive_voxel_filter_options& o,
@@ -300,6 +369,7 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
   }
   VfScratch s;
   DLIOM_TRY(carve_scratch(ctx, in.n, &s));
+  const Soa soa{in.d_x, in.d_y, in.d_z, nullptr, in.n};
   // launch 1: max_length and every low_length of the halving loop (voxel_filter.cc:55-58)
   std::vector<float> sizes{o.max_length};
   std::vector<float> highs;
@@ -310,12 +380,12 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
   }
   std::vector<unsigned> counts;
   unsigned in_range = 0;
-  DLIOM_TRY(run_insert(ctx, in, true, o.max_range, sizes, &s.tables[0], &counts, &in_range));
+  DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, sizes, &s.tables[0], &counts, &in_range));
   const float min_points = o.min_num_points;
   if (static_cast<float>(in_range) <= min_points)  // "already sparse enough" (:42-45)
-    return emit_cloud(ctx, in, s, s.tables[0], 0, 1, in_range, out);
+    return emit_cloud(ctx, soa, s, s.tables[0], 0, 1, in_range, out);
   if (static_cast<float>(counts[0]) >= min_points)  // max_length is dense enough (:46-50)
-    return emit_cloud(ctx, in, s, s.tables[0], 0, 0, counts[0], out);
+    return emit_cloud(ctx, soa, s, s.tables[0], 0, 0, counts[0], out);
   for (size_t k = 0; k < highs.size(); ++k) {
     if (!(static_cast<float>(counts[k + 1]) >= min_points)) continue;
     // launch 2: every mid_length the bisection (:63-73) can reach from (low, high)
@@ -350,7 +420,7 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
       for (const Node& nd : nodes) mids.push_back(nd.mid);
       std::vector<unsigned> mid_counts;
       unsigned dummy = 0;
-      DLIOM_TRY(run_insert(ctx, in, true, o.max_range, mids, &s.tables[1], &mid_counts, &dummy));
+      DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, mids, &s.tables[1], &mid_counts, &dummy));
       for (int id = 0; id >= 0;) {
         if (static_cast<float>(mid_counts[id]) >= min_points) {
           chosen_table = 1;
@@ -362,11 +432,11 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
         }
       }
     }
-    return emit_cloud(ctx, in, s, s.tables[chosen_table], chosen_l, 0, chosen_count, out);
+    return emit_cloud(ctx, soa, s, s.tables[chosen_table], chosen_l, 0, chosen_count, out);
   }
   // no edge length was dense enough: the last low_length's result stands (:56-57,76)
   const int last = static_cast<int>(sizes.size()) - 1;
-  return emit_cloud(ctx, in, s, s.tables[0], last, 0, counts[last], out);
+  return emit_cloud(ctx, soa, s, s.tables[0], last, 0, counts[last], out);
 }
 
 }  // namespace dliom

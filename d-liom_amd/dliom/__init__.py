@@ -177,6 +177,8 @@ SYMBOLS = [
     ("dliom_adaptive_voxel_filter", C.c_int, [C.POINTER(AdaptiveVoxelFilterOptions), _f32p, C.c_int64, _f32p, _i64p]),
     ("dliom_deskew", C.c_int, [_vp, _f64p, _f64p, C.c_double, _f32p, C.c_int64, _f32p, C.c_float, C.c_float, _f32p,
                                C.POINTER(C.c_uint8), _f32p]),
+    ("dliom_add_range_data", C.c_int, [_vp, _f64p, _f64p, C.c_double, _f32p, C.c_int64, _f32p, C.c_float, C.c_float,
+                                       C.c_float, C.POINTER(_vp), _f32p, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
     ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
@@ -820,6 +822,21 @@ def add_range_data_preprocess(ctx, prev_pose, predicted_pose, scan_period, range
     returns = voxel_filter(voxel_filter_size, xyz[kind == 1])
     inv = _pose_inverse_f32(cur)
     return _transform_f32(inv, returns), _transform_f32(inv, cur[:3].reshape(1, 3))[0], cur
+
+
+def add_range_data(ctx, prev_pose, predicted_pose, scan_period, ranges_xyzt, origin, min_range, max_range,
+                   voxel_filter_size):
+    """The same chain entirely on the device (dliom_add_range_data).
+    Returns (PointCloud returns_in_tracking, origin_in_tracking, current_pose)."""
+    r = _f32(ranges_xyzt).reshape(-1, 4)
+    h = _vp()
+    o = np.zeros(3, dtype=np.float32)
+    cur = np.zeros(7, dtype=np.float32)
+    _check(ctx._L.dliom_add_range_data(ctx.h, _p(_f64(prev_pose), _f64p), _p(_f64(predicted_pose), _f64p), scan_period,
+                                       _p(r, _f32p), len(r), _p(_f32(origin), _f32p), C.c_float(min_range),
+                                       C.c_float(max_range), C.c_float(voxel_filter_size), C.byref(h), _p(o, _f32p),
+                                       _p(cur, _f32p)), "dliom_add_range_data")
+    return PointCloud(ctx, _handle=h), o, cur
 
 
 def voxel_filter_indices(size, points):

@@ -349,6 +349,17 @@ int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const double predict
                  const float* hits_xyzt, int64_t n, const float origin[3], float min_range, float max_range,
                  float* out_xyz, uint8_t* out_kind, float current_pose[7]);
 
+/* The whole pre-processing chain of AddRangeData on the device (:393-487), one scan per call
+ * (num_accumulated_range_data = 1): ranges_xyzt (host, n x (x,y,z,t)) -> VoxelFilter(0.5 *
+ * voxel_filter_size) -> de-skew + range gate as in dliom_deskew -> returns only (the 3D inserter
+ * never reads RangeData::misses) -> VoxelFilter(voxel_filter_size) -> TransformRangeData by
+ * current_pose.inverse().  *returns_in_tracking is a new device cloud (dliom_cloud_destroy), ready
+ * for dliom_front_end_match_cloud; origin_in_tracking / current_pose as the reference computes them. */
+int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7],
+                         double scan_period, const float* ranges_xyzt, int64_t n, const float origin[3],
+                         float min_range, float max_range, float voxel_filter_size,
+                         dliom_cloud** returns_in_tracking, float origin_in_tracking[3], float current_pose[7]);
+
 /* ---- RealTimeCorrelativeScanMatcher2D (BASELINE config 1: host only, by contract) -------------
  * double Match(initial_pose_estimate, point_cloud, probability_grid, pose_estimate)
  * (mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h:66-69, .cc:74-108).

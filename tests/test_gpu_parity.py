@@ -604,6 +604,30 @@ def test_add_range_data_preprocess_chain(dl, ctx, orc):
     assert np.abs(origin - ref["origin_in_tracking"]).max() <= 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("beams,azimuths,k", [(16, 256, 7), (64, 1024, 11)])
+def test_add_range_data_device_chain(dl, ctx, orc, beams, azimuths, k):
+    """dliom_add_range_data (every stage in HBM) is bit-identical to the staged chain (host voxel
+    filters + device de-skew + host transform), whose filters are pinned to the oracle elsewhere;
+    and within float rounding of the oracle's whole AddRangeData restatement."""
+    prev, cur, ranges = _timed_scan(beams, azimuths, k=k)
+    vfs, min_r, max_r, T = 0.15, 1.0, 100.0, 0.1
+    returns, origin, cur_f = dl.add_range_data_preprocess(ctx, prev, cur, T, ranges, (0, 0, 0), min_r, max_r, vfs)
+    cloud, origin_d, cur_d = dl.add_range_data(ctx, prev, cur, T, ranges, (0, 0, 0), min_r, max_r, vfs)
+    got = cloud.download()
+    assert got.shape == returns.shape
+    assert np.array_equal(got.view(np.uint32), returns.view(np.uint32))
+    assert np.array_equal(origin_d, origin) and np.array_equal(cur_d, cur_f)
+    ref = orc.deskew_and_filter(T, min_r, max_r, vfs, prev, cur, ranges)
+    assert abs(len(got) - len(ref["returns_in_tracking"])) <= 2 + len(got) // 20000
+    # a gated scan: min_range above some returns, max_range below others
+    r2, o2, c2 = dl.add_range_data_preprocess(ctx, prev, cur, T, ranges, (0, 0, 0), 12.0, 16.0, vfs)
+    cl2, od2, cd2 = dl.add_range_data(ctx, prev, cur, T, ranges, (0, 0, 0), 12.0, 16.0, vfs)
+    assert np.array_equal(cl2.download().view(np.uint32), r2.view(np.uint32)) and 0 < len(r2) < len(returns)
+    cl2.close()
+    cloud.close()
+
+
 def test_fused_multi_grid_insertion(dl, ctx, orc):
     """dliom_inserter_insert_cloud_multi: four targets (two resolutions x two submap frames, one with
     a range filter) in one set of launches vs four oracle insertions; extent growth mid-sequence."""

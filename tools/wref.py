@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--azimuths", type=int, default=1024)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-scans", type=int, default=6)
+    ap.add_argument("--stages", action="store_true", help="time the individual device calls of one scan")
     args = ap.parse_args()
     import dliom as dl
     from dliom import synth
@@ -88,6 +89,9 @@ def main():
         def insert(self, *a):
             return fe.insert(*a)
 
+    if args.stages:
+        stages(args, dl, synth, ctx)
+        return
     chain = DeviceChain()
     rows = run(chain, chain.voxel_filter, ctx.synchronize, args.scans)[args.warmup:]
     st = None
@@ -114,6 +118,48 @@ def main():
                        "insert": 1e3 * float(np.median(rows_c[:, 2])),
                        "total": 1e3 * float(np.median(rows_c[:, :3].sum(axis=1)))}}
     print(json.dumps(out))
+
+
+def stages(args, dl, synth, ctx):
+    """Wall time of every device call of the W-ref chain on one scan (median of 20)."""
+    truth = synth.trajectory_pose(0.3)
+    ins = dl.RangeDataInserter3D(0.55, 0.49, 2, ctx=ctx)
+    g_hi, g_lo = dl.HybridGrid(ctx, 0.1), dl.HybridGrid(ctx, 0.45)
+    for s in range(6):
+        pose = synth.trajectory_pose(0.025 * s)
+        pts, _ = synth.scan(pose, args.beams, args.azimuths)
+        c = dl.PointCloud(ctx, pts)
+        dl.insert_cloud_multi(ins, c, [(g_hi, [pose.astype(np.float32)], 20.0), (g_lo, [pose.astype(np.float32)], 0.0)])
+        c.close()
+    pts, _ = synth.scan(truth, args.beams, args.azimuths)
+    init = synth.perturb_pose(truth, 0.03, 0.2, seed=3)
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, OPTS["real_time_correlative_scan_matcher"])
+    cs = dl.CeresScanMatcher3D(ctx, OPTS["ceres_scan_matcher"])
+    t = {k: [] for k in ("upload", "voxel_filter", "adaptive_hi", "adaptive_lo", "rtcsm", "ceres", "insert", "free")}
+    for rep in range(24):
+        a = time.perf_counter()
+        raw = dl.PointCloud(ctx, pts)
+        b = time.perf_counter()
+        f = raw.voxel_filter(0.15)
+        c0 = time.perf_counter()
+        hi = f.adaptive_voxel_filter(2.0, 150, 15.0)
+        d = time.perf_counter()
+        lo = f.adaptive_voxel_filter(4.0, 200, 60.0)
+        e = time.perf_counter()
+        _, p1 = rt.Match(init, hi, g_hi)
+        g = time.perf_counter()
+        cs.Match(init[:3], p1, [(hi, g_hi), (lo, g_lo)])
+        h = time.perf_counter()
+        dl.insert_cloud_multi(ins, f, [(g_hi, [truth.astype(np.float32)], 20.0), (g_lo, [truth.astype(np.float32)], 0.0)])
+        ctx.synchronize()
+        i = time.perf_counter()
+        for cl in (raw, f, hi, lo):
+            cl.close()
+        j = time.perf_counter()
+        for k, v in zip(t, (b - a, c0 - b, d - c0, e - d, g - e, h - g, i - h, j - i)):
+            t[k].append(v)
+    print(json.dumps({"stage_p50_us": {k: 1e6 * float(np.median(v[4:])) for k, v in t.items()},
+                      "N_filtered": len(f), "N_hi": len(hi), "N_lo": len(lo)}))
 
 
 if __name__ == "__main__":
