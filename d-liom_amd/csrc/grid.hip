@@ -84,10 +84,13 @@ struct InsertArgs {
   int dense_stride; // cells per axis of the mirror = grid_size + 2 (one guard cell each side)
 };
 
-// Index into the dense mirror: every axis shifted by half + 1 (guard cell).
+// Index into the dense mirror: every axis shifted by half + 1 (guard cell); 4 x 4 x 4 bricks of
+// 64 cells (one 128-byte cache line), bricks z-major with B = ceil(stride / 4) per axis.
 __device__ __forceinline__ size_t dense_index(int ix, int iy, int iz, int half, int stride) {
-  return (static_cast<size_t>(iz + half + 1) * stride + static_cast<size_t>(iy + half + 1)) * stride +
-         static_cast<size_t>(ix + half + 1);
+  const unsigned x = static_cast<unsigned>(ix + half + 1), y = static_cast<unsigned>(iy + half + 1),
+                 z = static_cast<unsigned>(iz + half + 1);
+  const size_t B = static_cast<size_t>((stride + 3) >> 2);
+  return (((z >> 2) * B + (y >> 2)) * B + (x >> 2)) * 64 + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
 }
 
 // range_data_inserter_3d.cc:36-50: the k-th sample on the ray origin->hit in
@@ -214,7 +217,7 @@ __global__ void dense_fill_kernel(const int32_t* __restrict__ slot_coord, const 
   const int bx = slot_coord[3 * s] * 8, by = slot_coord[3 * s + 1] * 8, bz = slot_coord[3 * s + 2] * 8;
   for (int c = threadIdx.x; c < 512; c += blockDim.x) {
     const uint16_t v = pool[s * 512 + c] & 0x7FFFu;
-    dense[dense_index(bx + (c & 7), by + ((c >> 3) & 7), bz + (c >> 6), half, stride)] = v;
+    dense[dense_index(bx + (c & 7), by + ((c >> 3) & 7), bz + (c >> 6), half, stride)] = v > 0 ? v : 1;
   }
 }
 
@@ -457,6 +460,7 @@ GridView dliom_grid::view() const {
   v.log2_leaves = bits + 3;
   v.dense = d_dense;
   v.dense_stride = dense_stride;
+  v.dense_bricks = dense_bricks;
   return v;
 }
 
@@ -504,10 +508,13 @@ void dliom_grid::drop_dense() {
   if (d_dense != nullptr) (void)hipFree(d_dense);
   d_dense = nullptr;
   dense_stride = 0;
+  dense_bricks = 0;
 }
 
-// Dense mirror of the grid for the correlative matcher: (grid_size + 2)^3 uint16, linear z-major,
-// one guard cell per side (always 0), marker bit stripped.  Spends HBM capacity (258 MiB at
+// Dense mirror of the grid for the correlative matcher: (grid_size + 2)^3 uint16 in 4x4x4 bricks
+// (dense_index), one guard cell per side, holding what the matcher SUMS: max(value & 0x7fff, 1) -- unknown cells,
+// guard cells and everything outside read 1 (= kMinProbability's value, rtcsm3d.hip), known cells
+// their marker-free value (always >= 1 once a lookup table was applied).  Spends HBM capacity (258 MiB at
 // bits = 3, 2.0 GiB at bits = 4) to make a voxel lookup ONE load at a linear address instead of
 // leaf-table load + leaf load; kept in sync by the insertion kernels (write-through) and rebuilt
 // from the leaf pool after uploads or growth.  Grids beyond bits = 4 stay on the leaf path.
@@ -515,9 +522,10 @@ int dliom_grid::ensure_dense() {
   if (d_dense != nullptr) return DLIOM_OK;
   if (bits > kMaxDenseBits) return DLIOM_ERR_GRID_EXTENT;
   const int stride = (64 << bits) + 2;
-  const size_t cells = static_cast<size_t>(stride) * stride * stride;
+  const size_t bricks = static_cast<size_t>((stride + 3) >> 2);
+  const size_t cells = bricks * bricks * bricks * 64;
   DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_dense), cells * sizeof(uint16_t)));
-  DLIOM_HIP_TRY(hipMemsetAsync(d_dense, 0, cells * sizeof(uint16_t), ctx->stream));
+  DLIOM_HIP_TRY(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(d_dense), 1, cells, ctx->stream));
   int64_t count = 0;
   DLIOM_TRY(refresh_count(&count));
   if (count > 1) {
@@ -526,6 +534,7 @@ int dliom_grid::ensure_dense() {
     DLIOM_HIP_TRY(hipGetLastError());
   }
   dense_stride = stride;
+  dense_bricks = static_cast<int>(bricks);
   return DLIOM_OK;
 }
 

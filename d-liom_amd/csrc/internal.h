@@ -54,7 +54,8 @@ struct GridView {
   float inv_resolution;   // fl(1 / resolution): fast path of the score kernel only
   int log2_leaves;        // log2(leaves_per_axis) = bits + 3
   const uint16_t* dense;  // dense mirror (grid_size + 2)^3, null when absent
-  int dense_stride;       // grid_size + 2
+  int dense_stride;       // S = grid_size + 2 cells per axis
+  int dense_bricks;       // B = ceil(S / 4): the mirror is B^3 bricks of 4x4x4 cells (128 B)
 };
 
 }  // namespace dliom
@@ -106,6 +107,7 @@ struct dliom_grid {
   int64_t used_upper = 1;       // host-side upper bound of *d_count
   uint16_t* d_dense = nullptr;  // optional dense mirror for the correlative matcher (grid.hip)
   int dense_stride = 0;
+  int dense_bricks = 0;
   int ensure_dense();
   void drop_dense();
   dliom::GridView view() const;

@@ -191,21 +191,26 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_rot_kernel(
 
 // ---------------------------------------------------------------------------------- kernel A''
 // The same rotation-per-lane walk over the DENSE MIRROR of the grid (grid.hip::ensure_dense):
-// one load per lookup at a linear address, no leaf table, no leaf/cell bit surgery.
-//   y' = fma(c, 1/res, K)   K = half + 1 shifts the index into the mirror's [0, S) range for free
-//   near <=> min_c |frac(y'_c) - 1/2| <= 2.2 S 2^-24     (then: exact lround(c / res) path)
-//   i'  = v_cvt_rpi_i32_f32(y')  (floor(y' + 1/2): equals lround away from the near band)
-//   clamp to [0, S-1] (guard cells are 0 = "outside / unknown"), address = (iz' S + iy') S + ix'.
-// Error budget, in cells, with q = c/res the real quotient (|q| <= S/2 inside the grid, y' <= S):
+// one load per lookup, no leaf table, no leaf/cell bit surgery, and the mirror already holds
+// max(value, 1), the quantity that is summed.
+//   z  = fma(c, 1/res, K)    K = half + 1 + 1/2: shift into the mirror's [0, S) range AND the
+//                            half of "floor(x + 1/2)" in the fma's single rounding
+//   i' = v_cvt_flr_i32_f32(clamp(z, 0, S - 1/2))   guard cells 0 and S-1 read 1 = "outside/unknown"
+//   near <=> some frac(z_c) <= band or >= 1 - band, band = 2.2 S 2^-24 (then: exact path)
+//   byte offset = X[ix'] + Y[iy'] + Z[iz']  (LDS tables of the bricked layout, see the kernel)
+// Error budget, in cells, with q = c/res the real quotient (|q| <= S/2 inside the grid, z <= S):
 //   fl(1/res) relative error 2^-24        -> |c fl(1/res) - q| <= |q| 2^-24     <= (S/2) 2^-24
-//   one rounding of the fma               -> <= ulp(y')/2 <= y' 2^-24            <=  S    2^-24
-//   the reference's lround(fl(q)) can only flip when q is within |q| 2^-24 of a half-integer
+//   one rounding of the fma               -> <= ulp(z)/2 <= z 2^-24              <=  S    2^-24
+//   the reference's lround(fl(q)) can only differ from floor(q + 1/2) when q is within |q| 2^-24
+//   of a half-integer (its own rounding of the quotient, and the half-away tie rule)
 //                                                                                <= (S/2) 2^-24
-// so outside a band of 2 S 2^-24 around the half-integers both agree; 2.2 S 2^-24 is used
-// (~6.7e-5 cells at S = 514: the exact path runs for ~2.5 % of the wave-rows).
-__device__ __forceinline__ int cvt_rpi(float y) {
+// so when z is farther than (2 S + 1) 2^-24 from every integer, floor(z) and the reference agree;
+// 2.2 S 2^-24 is used (~6.7e-5 cells at S = 514).  Points far outside the grid break the bounds
+// but land in a guard cell on both paths.  The exact path is taken per point (a wave-level branch):
+// ~10 % of the 4-point iterations have a near lookup in some lane, usually in one point only.
+__device__ __forceinline__ int cvt_flr(float y) {  // floor to int in one instruction
   int r;
-  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(y));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(y));
   return r;
 }
 
@@ -234,20 +239,35 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
   const int rot_group = slot % rot_groups;
   const int chunk_id = (slot / rot_groups) * 8 + xcd;
   if (chunk_id >= point_chunks) return;
-  extern __shared__ float4 lds_dyn[];  // [T translations | t_chunk x blockDim accumulators]
+  extern __shared__ float4 lds_dyn[];  // [T translations | 3 S byte offsets | t_chunk x blockDim accumulators]
   float4* lds_trans = lds_dyn;
-  unsigned* lds_acc = reinterpret_cast<unsigned*>(lds_dyn + T);
+  unsigned* lds_off = reinterpret_cast<unsigned*>(lds_dyn + T);
+  const int S = g.dense_stride;
+  unsigned* lds_acc = lds_off + 3 * S;
   for (int j = threadIdx.x; j < T; j += bs) lds_trans[j] = trans4[j];
+  // The mirror is stored in 4 x 4 x 4 bricks of 128 B (one cache line): lanes of a wave look up
+  // cells a few voxels apart in EVERY direction, and the texture addresser works per distinct line.
+  // Per-axis byte offsets come from LDS tables, so the brick swizzle costs no VALU:
+  //   offset(x, y, z) = X[x] + Y[y] + Z[z],  X[x] = (x>>2) 128 + (x&3) 2,
+  //   Y[y] = (y>>2) B 128 + (y&3) 8,  Z[z] = (z>>2) B^2 128 + (z&3) 32,  B = bricks per axis
+  {
+    const unsigned B = static_cast<unsigned>(g.dense_bricks);
+    for (int c = threadIdx.x; c < S; c += bs) {
+      const unsigned h = static_cast<unsigned>(c) >> 2, l = static_cast<unsigned>(c) & 3u;
+      lds_off[c] = h * 128u + l * 2u;
+      lds_off[S + c] = h * B * 128u + l * 8u;
+      lds_off[2 * S + c] = h * B * B * 128u + l * 32u;
+    }
+  }
   __syncthreads();
   const int r = r_first + rot_group * bs + threadIdx.x;
   const bool active = r < r_last;
   const float4 qq = rot[active ? r : r_first];
   const Quat4 q{qq.x, qq.y, qq.z, qq.w};  // stored (w,x,y,z)
   const float inv = g.inv_resolution;
-  const int S = g.dense_stride;
-  const float K = static_cast<float>(g.half + 1);
+  const float K = static_cast<float>(g.half + 1) + 0.5f;
   const float band = 2.2f * static_cast<float>(S) * 5.9604645e-8f;
-  const float lim = static_cast<float>(S - 1);
+  const float lim = static_cast<float>(S - 1) + 0.5f;
   const int p_begin = chunk_id * points_per_chunk;
   const int p_end = p_begin + points_per_chunk;  // the cloud is padded: no tail handling
   for (int jc = 0; jc < T; jc += t_chunk) {
@@ -261,40 +281,48 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
 #pragma unroll 1
       for (int jj = 0; jj < tc; ++jj) {
         const float4 t = lds_trans[jc + jj];  // same address in every lane: LDS broadcast
-        int ix[P], iy[P], iz[P];  // clamped mirror coordinates
-        float m = 1.f;
+        unsigned ox[P], oy[P], oz[P];  // byte offsets of the three clamped mirror coordinates
+        float lo[P], hi[P];            // per point: min / max over the axes of frac(z)
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-          const float yx = __builtin_fmaf(rx[k] + t.x, inv, K), yy = __builtin_fmaf(ry[k] + t.y, inv, K),
-                      yz = __builtin_fmaf(rz[k] + t.z, inv, K);
-          const float dx = __builtin_amdgcn_fractf(yx) - 0.5f, dy = __builtin_amdgcn_fractf(yy) - 0.5f,
-                      dz = __builtin_amdgcn_fractf(yz) - 0.5f;
-          m = fminf(m, fminf(fminf(fabsf(dx), fabsf(dy)), fabsf(dz)));
-          // clamp in float (one v_med3_f32): floor(clamp(y, 0, S-1) + 1/2) == clamp(floor(y + 1/2), 0, S-1)
-          ix[k] = cvt_rpi(__builtin_amdgcn_fmed3f(yx, 0.f, lim));
-          iy[k] = cvt_rpi(__builtin_amdgcn_fmed3f(yy, 0.f, lim));
-          iz[k] = cvt_rpi(__builtin_amdgcn_fmed3f(yz, 0.f, lim));
+          // z = c / res + (half + 1) + 1/2 in ONE rounding; floor(z) is the mirror coordinate
+          const float zx = __builtin_fmaf(rx[k] + t.x, inv, K), zy = __builtin_fmaf(ry[k] + t.y, inv, K),
+                      zz = __builtin_fmaf(rz[k] + t.z, inv, K);
+          const float fx = __builtin_amdgcn_fractf(zx), fy = __builtin_amdgcn_fractf(zy),
+                      fz = __builtin_amdgcn_fractf(zz);
+          lo[k] = fminf(fminf(fx, fy), fz);
+          hi[k] = fmaxf(fmaxf(fx, fy), fz);
+          // clamp in float (one v_med3_f32): floor(clamp(z, 0, S - 1/2)) == clamp(floor(z), 0, S - 1)
+          ox[k] = lds_off[cvt_flr(__builtin_amdgcn_fmed3f(zx, 0.f, lim))];
+          oy[k] = lds_off[S + cvt_flr(__builtin_amdgcn_fmed3f(zy, 0.f, lim))];
+          oz[k] = lds_off[2 * S + cvt_flr(__builtin_amdgcn_fmed3f(zz, 0.f, lim))];
         }
-        if (__builtin_expect(m <= band, 0)) {  // some lookup of this lane is within rounding reach of a
-#pragma unroll                                 // cell boundary: exact path for the lane's P lookups
+        float m = lo[0], M = hi[0];
+#pragma unroll
+        for (int k = 1; k < P; ++k) {
+          m = fminf(m, lo[k]);
+          M = fmaxf(M, hi[k]);
+        }
+        if (__builtin_expect(m <= band || M >= 1.f - band, 0)) {
+          // some lookup of this lane sits within rounding reach of a cell boundary: the exact
+          // division path, but only for the points that need it (one wave-level branch per point)
+#pragma unroll
           for (int k = 0; k < P; ++k) {
-            ix[k] = min(max(cell_of(rx[k] + t.x, g.resolution) + g.half + 1, 0), S - 1);
-            iy[k] = min(max(cell_of(ry[k] + t.y, g.resolution) + g.half + 1, 0), S - 1);
-            iz[k] = min(max(cell_of(rz[k] + t.z, g.resolution) + g.half + 1, 0), S - 1);
+            if (lo[k] <= band || hi[k] >= 1.f - band) {
+              ox[k] = lds_off[min(max(cell_of(rx[k] + t.x, g.resolution) + g.half + 1, 0), S - 1)];
+              oy[k] = lds_off[S + min(max(cell_of(ry[k] + t.y, g.resolution) + g.half + 1, 0), S - 1)];
+              oz[k] = lds_off[2 * S + min(max(cell_of(rz[k] + t.z, g.resolution) + g.half + 1, 0), S - 1)];
+            }
           }
         }
         unsigned v[P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-          // full-rate 24-bit multiplies (S <= 1026, (z S + y) < 2^21) and a 32-bit byte offset
-          const unsigned zy = mad24(static_cast<unsigned>(iz[k]), static_cast<unsigned>(S),
-                                    static_cast<unsigned>(iy[k]));
-          const unsigned off = mad24(zy, static_cast<unsigned>(2 * S), static_cast<unsigned>(ix[k]) << 1) ;
-          v[k] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.dense) + off);
-        }
+        for (int k = 0; k < P; ++k)
+          v[k] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.dense) +
+                                                          (ox[k] + oy[k] + oz[k]));
         unsigned a = 0;
 #pragma unroll
-        for (int k = 0; k < P; ++k) a += max(v[k], 1u);  // the mirror stores marker-free values
+        for (int k = 0; k < P; ++k) a += v[k];  // the mirror stores max(value, 1) already
         atomicAdd(&lds_acc[jj * bs + threadIdx.x], a);  // ds_add_u32, own column
       }
     }
@@ -846,7 +874,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
       if (forced_bs >= 64 && forced_bs <= kDenseMaxBlock && forced_bs % 64 == 0) bs = forced_bs;
       const int rot_groups = (Rs + bs - 1) / bs;
       const dim3 block(bs);
-      const size_t lds2 = lds + static_cast<size_t>(t_chunk) * bs * 4;
+      const size_t lds2 = lds + static_cast<size_t>(g.dense_stride) * 12 + static_cast<size_t>(t_chunk) * bs * 4;
       const int chunks_per_xcd = (point_chunks + 7) / 8;
       const dim3 dense_grid(8 * chunks_per_xcd * rot_groups);
       if (pts_per_iter == 8) {

@@ -48,4 +48,11 @@ if "FETCH_SIZE" in summary and meta:
                "source": "profiles/%s_pmc_score_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, x2 gfx950 "
                          "read correction)" % tag},
               open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+for name, out in (("bench_full.json", "%s_bench.json"), ("wref.json", "%s_wref.json"),
+                  ("wref_stages.json", "%s_wref_stages.json")):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, out % tag), "w").write(lines[-1] + "\n")
 print(sorted(os.listdir(dst)))

@@ -21,4 +21,8 @@ for P in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
   echo "pmc pass $i rc=$?"
   i=$((i+1))
 done
+timeout 300 python $R/bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
+echo "bench rc=$?"
+timeout 200 python $R/tools/wref.py > $OUT/wref.json 2> $OUT/wref.err
+timeout 100 python $R/tools/wref.py --stages > $OUT/wref_stages.json 2>> $OUT/wref.err
 find $OUT -name "*.csv" | head -20
