@@ -860,7 +860,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
     processed = static_cast<int64_t>(point_chunks) * chunk;
     const dim3 grid_dim(rot_groups, point_chunks), block(kBlock);
     span = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
-    static const int pts_per_iter = env_int("DLIOM_SCORE_P", 4);
+    static const int pts_per_iter = env_int("DLIOM_SCORE_P", 8);
     const size_t lds = static_cast<size_t>(T) * 16;
     if (lds > 100 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;
     if (mapping == 2) {
