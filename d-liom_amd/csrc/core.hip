@@ -335,7 +335,7 @@ size_t staged_cloud_bytes(int64_t n) { return cloud_bytes(n); }
 using namespace dliom;
 
 int dliom_ctx::begin_span(int id) {
-  if (!profiling) return -1;
+  if (!profiling || ((profiling_mask >> id) & 1u) == 0u) return -1;
   hipEvent_t ev[2];
   for (int k = 0; k < 2; ++k) {
     if (!event_pool.empty()) {
@@ -470,6 +470,8 @@ int dliom_ctx_synchronize(dliom_ctx* ctx) {
 int dliom_ctx_set_profiling(dliom_ctx* ctx, int enabled) {
   if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   ctx->profiling = enabled != 0;
+  // enabled > 1: bit (k + 1) selects kernel id k, e.g. 2 = DLIOM_KERNEL_RTCSM_SCORE only
+  ctx->profiling_mask = enabled > 1 ? static_cast<unsigned>(enabled) >> 1 : ~0u;
   return DLIOM_OK;
 }
 

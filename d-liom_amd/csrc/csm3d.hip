@@ -296,12 +296,12 @@ static int evaluate(CsmProblem* p, const double x[7], Normal* out) {
   const int span = ctx->begin_span(DLIOM_KERNEL_CSM_EVAL);
   hipLaunchKernelGGL(csm_eval_kernel, dim3(p->num_blocks), dim3(kCsmBlock), 0, ctx->stream, a, k_scale,
                      k_offset, kMin, p->d_partials);
+  // the 28 results go straight into pinned host memory (device-visible): no copy command
+  double* host = static_cast<double*>(ctx->pinned);
   hipLaunchKernelGGL(csm_final_reduce_kernel, dim3(kAcc), dim3(64), 0, ctx->stream, p->d_partials,
-                     p->num_blocks, p->d_out);
+                     p->num_blocks, host);
   ctx->end_span(span);
   DLIOM_HIP_TRY(hipGetLastError());
-  double* host = static_cast<double*>(ctx->pinned);
-  DLIOM_HIP_TRY(hipMemcpyAsync(host, p->d_out, kAcc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   ++p->evaluations;
   int idx = 0;

@@ -78,6 +78,7 @@ struct dliom_ctx {
   size_t pinned_bytes = 0;
   // profiling
   bool profiling = false;
+  unsigned profiling_mask = ~0u;  // kernel ids whose launches are timed
   struct Span {
     hipEvent_t a, b;
     int id;

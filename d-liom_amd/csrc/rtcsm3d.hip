@@ -733,20 +733,36 @@ static void generate_candidates(const dliom_rtcsm_options& o, float resolution, 
                  static_cast<float>(init7[5]), static_cast<float>(init7[6])};
   const int L = c->w.linear_window_size, A = c->w.angular_window_size;
   const float step = c->w.angular_step_size;
-  c->rot.clear();
-  c->rot_raw.clear();
-  c->r_angle.clear();
+  // The transform rotations q_r and their angles depend on the window only: cached per thread
+  // across matches (sin/cos/atan2 per rotation are the expensive part of this function).
+  struct RotCache {
+    int A = -1;
+    float step = 0.f;
+    std::vector<QF> rot_raw;
+    std::vector<float> r_angle;
+  };
+  static thread_local RotCache cache;
+  if (cache.A != A || cache.step != step) {
+    cache.A = A;
+    cache.step = step;
+    cache.rot_raw.clear();
+    cache.r_angle.clear();
+    cache.rot_raw.reserve(c->w.num_rotations);
+    cache.r_angle.reserve(c->w.num_rotations);
+    for (int rz = -A; rz <= A; ++rz)
+      for (int ry = -A; ry <= A; ++ry)
+        for (int rx = -A; rx <= A; ++rx) {
+          const QF q = angle_axis_to_quaternion(F3{rx * step, ry * step, rz * step});
+          cache.rot_raw.push_back(q);
+          cache.r_angle.push_back(rotation_angle(q));
+        }
+  }
+  c->rot_raw = cache.rot_raw;
+  c->r_angle = cache.r_angle;
+  c->rot.resize(cache.rot_raw.size());
+  for (size_t i = 0; i < cache.rot_raw.size(); ++i) c->rot[i] = qnormalized(qmul(c->init.q, cache.rot_raw[i]));
   c->trans.clear();
   c->t_norm.clear();
-  c->rot.reserve(c->w.num_rotations);
-  for (int rz = -A; rz <= A; ++rz)
-    for (int ry = -A; ry <= A; ++ry)
-      for (int rx = -A; rx <= A; ++rx) {
-        const QF q = angle_axis_to_quaternion(F3{rx * step, ry * step, rz * step});
-        c->rot_raw.push_back(q);
-        c->r_angle.push_back(rotation_angle(q));
-        c->rot.push_back(qnormalized(qmul(c->init.q, q)));
-      }
   for (int z = -L; z <= L; ++z)
     for (int y = -L; y <= L; ++y)
       for (int x = -L; x <= L; ++x) {

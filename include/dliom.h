@@ -410,6 +410,8 @@ enum {
   DLIOM_KERNEL_INSERT = 4,
   DLIOM_KERNEL_COUNT = 5
 };
+/* enabled: 0 off, 1 every kernel id, otherwise a mask with bit (id + 1) per timed kernel id
+ * (2 = the score kernel only: what bench.py's timed region uses). */
 int dliom_ctx_set_profiling(dliom_ctx* ctx, int enabled);
 int dliom_ctx_reset_profiling(dliom_ctx* ctx);
 int dliom_ctx_kernel_time(dliom_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
