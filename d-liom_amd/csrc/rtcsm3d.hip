@@ -445,9 +445,10 @@ constexpr int kChainTile = 2048;
 __global__ __launch_bounds__(256) void rtcsm_rescore_kernel(
     GridView g, const float* __restrict__ px, const float* __restrict__ py,
     const float* __restrict__ pz, int n, const float4* __restrict__ rot, int R,
-    const float* __restrict__ trans, const unsigned* __restrict__ list, float k_scale, float k_offset,
-    float k_unknown, float* __restrict__ sums) {
+    const float* __restrict__ trans, const unsigned* __restrict__ list, const unsigned* __restrict__ count,
+    float k_scale, float k_offset, float k_unknown, float* __restrict__ sums) {
   __shared__ float4 tile[2][kChainTile / 4];
+  if (count != nullptr && blockIdx.x >= *count) return;
   const unsigned c = list[blockIdx.x];
   const int j = static_cast<int>(c / static_cast<unsigned>(R));
   const int r = static_cast<int>(c % static_cast<unsigned>(R));
@@ -534,7 +535,10 @@ __global__ void rtcsm_rescore_values_kernel(GridView g, const float* __restrict_
                                             const float* __restrict__ py, const float* __restrict__ pz,
                                             int n, int n_stride, const float4* __restrict__ rot, int R,
                                             const float* __restrict__ trans, const unsigned* __restrict__ list,
+                                            const unsigned* __restrict__ count,
                                             unsigned short* __restrict__ values) {
+  // launched for an upper bound of survivors when the host has not read the count yet
+  if (count != nullptr && blockIdx.y >= *count) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_stride) return;
   unsigned short v = 0;
@@ -555,8 +559,9 @@ __global__ void rtcsm_rescore_values_kernel(GridView g, const float* __restrict_
 
 __global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_scan_kernel(
     const unsigned short* __restrict__ values, int n, int n_stride, float k_scale, float k_offset,
-    float k_unknown, float* __restrict__ sums) {
+    float k_unknown, const unsigned* __restrict__ count, float* __restrict__ sums) {
   extern __shared__ unsigned short lds_value[];  // n_stride grid values (15 bit), input order
+  if (count != nullptr && blockIdx.x >= *count) return;
   __shared__ ParityFn wave_total[kScanThreads / 64];
   __shared__ unsigned sh_m, sh_e, sh_i0, sh_cross, sh_m_before, sh_total;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1089,45 +1094,70 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
                        static_cast<long long>(C), st->d_ctrs, st->d_ctrs + 1, st->d_list);
     ctx->end_span(span);
     DLIOM_HIP_TRY(hipGetLastError());
-    unsigned ctrs[2] = {0, 0};
-    DLIOM_HIP_TRY(hipMemcpyAsync(ctrs, st->d_ctrs, 8, hipMemcpyDeviceToHost, ctx->stream));
-    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    K = ctrs[1];
   }
-  if (K > 0) {
-    // exact sequential rescoring of the survivors: one workgroup each
+  // Exact sequential rescoring of the survivors, one workgroup each.  Usually a handful survive, so
+  // the first kSpecK are rescored SPECULATIVELY in the same stream segment (the kernels read the
+  // count on the device and idle blocks exit): one synchronisation for the whole match.  Only if
+  // more survived does a second, exactly sized round run.
+  constexpr unsigned kSpecK = 8;
+  std::vector<unsigned> list;
+  std::vector<float> ksums;
+  if (st->r_last > st->r_first) {
     const LutModel& lm = lut_model();
     const int n = static_cast<int>(cloud.n);
-    DLIOM_TRY(ctx->rescore.reserve(static_cast<size_t>(K) * 4));
-    float* d_ksums = ctx->rescore.as<float>();
-    const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
     static const int rescore_method = env_int("DLIOM_RESCORE", 1);  // 1: binade-wise scan, 0: serial chain
     const int n_stride = (n + 7) & ~7;
     const size_t scan_lds = static_cast<size_t>(n_stride) * 2;
-    if (rescore_method == 1 && scan_lds <= 128 * 1024 && K <= 65535) {
-      const size_t ks_bytes = (static_cast<size_t>(K) * 4 + 255) & ~static_cast<size_t>(255);
-      DLIOM_TRY(ctx->rescore.reserve(ks_bytes + static_cast<size_t>(K) * n_stride * 2));
-      d_ksums = ctx->rescore.as<float>();
-      unsigned short* d_values = reinterpret_cast<unsigned short*>(static_cast<char*>(ctx->rescore.p) + ks_bytes);
-      hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, K), dim3(256), 0, ctx->stream,
-                         st->grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, st->d.rot, R, st->d.trans,
-                         st->d_list, d_values);
-      hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(K), dim3(kScanThreads), scan_lds, ctx->stream, d_values,
-                         n, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
-    } else {
-      hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(K), dim3(256), 0, ctx->stream, st->grid->view(), cloud.d_x,
-                         cloud.d_y, cloud.d_z, n, st->d.rot, R, st->d.trans, st->d_list, lm.k_scale, lm.k_offset,
-                         lm.k_unknown, d_ksums);
-    }
-    ctx->end_span(span);
-    DLIOM_HIP_TRY(hipGetLastError());
-    std::vector<unsigned> list(K);
-    std::vector<float> ksums(K);
-    DLIOM_HIP_TRY(hipMemcpyAsync(list.data(), st->d_list, static_cast<size_t>(K) * 4, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    DLIOM_HIP_TRY(hipMemcpyAsync(ksums.data(), d_ksums, static_cast<size_t>(K) * 4, hipMemcpyDeviceToHost,
-                                 ctx->stream));
+    const bool scan_ok = rescore_method == 1 && scan_lds <= 128 * 1024;
+    // readback block at the end of the pinned staging area: [count pair | list | sums]
+    unsigned* h_ctrs = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 4096);
+    unsigned* h_list = h_ctrs + 2;
+    float* h_sums = reinterpret_cast<float*>(h_ctrs + 2 + kSpecK);
+    auto rescore = [&](unsigned count, const unsigned* d_count, size_t list_offset) -> int {
+      const size_t ks_bytes = (static_cast<size_t>(count) * 4 + 255) & ~static_cast<size_t>(255);
+      const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
+      if (scan_ok && count <= 65535) {
+        DLIOM_TRY(ctx->rescore.reserve(ks_bytes + static_cast<size_t>(count) * n_stride * 2));
+        float* d_ksums = ctx->rescore.as<float>();
+        unsigned short* d_values = reinterpret_cast<unsigned short*>(static_cast<char*>(ctx->rescore.p) + ks_bytes);
+        hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, count), dim3(256), 0, ctx->stream,
+                           st->grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, st->d.rot, R, st->d.trans,
+                           st->d_list + list_offset, d_count, d_values);
+        hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(count), dim3(kScanThreads), scan_lds, ctx->stream, d_values,
+                           n, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, d_count, d_ksums);
+      } else {
+        DLIOM_TRY(ctx->rescore.reserve(ks_bytes));
+        hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(count), dim3(256), 0, ctx->stream, st->grid->view(), cloud.d_x,
+                           cloud.d_y, cloud.d_z, n, st->d.rot, R, st->d.trans, st->d_list + list_offset, d_count,
+                           lm.k_scale, lm.k_offset, lm.k_unknown, ctx->rescore.as<float>());
+      }
+      ctx->end_span(span);
+      DLIOM_HIP_TRY(hipGetLastError());
+      return DLIOM_OK;
+    };
+    DLIOM_TRY(rescore(kSpecK, st->d_ctrs + 1, 0));
+    DLIOM_HIP_TRY(hipMemcpyAsync(h_ctrs, st->d_ctrs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DLIOM_HIP_TRY(hipMemcpyAsync(h_list, st->d_list, kSpecK * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DLIOM_HIP_TRY(hipMemcpyAsync(h_sums, ctx->rescore.p, kSpecK * 4, hipMemcpyDeviceToHost, ctx->stream));
     DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    K = h_ctrs[1];
+    const unsigned first = std::min(K, kSpecK);
+    list.assign(h_list, h_list + first);
+    ksums.assign(h_sums, h_sums + first);
+    if (K > kSpecK) {  // the rest, exactly sized
+      const unsigned rest = K - kSpecK;
+      DLIOM_TRY(rescore(rest, nullptr, kSpecK));
+      list.resize(K);
+      ksums.resize(K);
+      DLIOM_HIP_TRY(hipMemcpyAsync(list.data() + kSpecK, st->d_list + kSpecK, static_cast<size_t>(rest) * 4,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+      DLIOM_HIP_TRY(hipMemcpyAsync(ksums.data() + kSpecK, ctx->rescore.p, static_cast<size_t>(rest) * 4,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+      DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  if (K > 0) {
+    const int n = static_cast<int>(cloud.n);
     // final scoring exactly as rtcsm_3d.cc:105-112, first maximum in generation order
     for (unsigned k = 0; k < K; ++k) {
       const int64_t cc = list[k];
@@ -1323,13 +1353,14 @@ int dliom_rtcsm3d_sequential_sums(dliom_ctx* ctx, const dliom_rtcsm_options* o, 
     unsigned short* d_values = ctx->misc.as<unsigned short>();
     hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, static_cast<unsigned>(k)), dim3(256),
                        0, ctx->stream, grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, ni, n_stride, d.rot, R, d.trans,
-                       d_list, d_values);
+                       d_list, static_cast<const unsigned*>(nullptr), d_values);
     hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(static_cast<unsigned>(k)), dim3(kScanThreads), scan_lds,
-                       ctx->stream, d_values, ni, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
+                       ctx->stream, d_values, ni, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown,
+                       static_cast<const unsigned*>(nullptr), d_ksums);
   } else {
     hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(static_cast<unsigned>(k)), dim3(256), 0, ctx->stream,
-                       grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, ni, d.rot, R, d.trans, d_list, lm.k_scale,
-                       lm.k_offset, lm.k_unknown, d_ksums);
+                       grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, ni, d.rot, R, d.trans, d_list,
+                       static_cast<const unsigned*>(nullptr), lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
   }
   DLIOM_HIP_TRY(hipGetLastError());
   DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_ksums, static_cast<size_t>(k) * 4, hipMemcpyDeviceToHost, ctx->stream));
