@@ -192,7 +192,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "scans/sec (64-beam x 1024 pts -> 10 cm 3D submap)",
+            "metric": "scans/sec (%d-beam x %d pts -> %g cm 3D submap)" % (args.beams, args.azimuths, 100 * args.high_resolution),
             "value": value,
             "unit": "scans/s",
             "n_gpus": world,
@@ -206,9 +206,11 @@ def main():
             "dtype": "f32 transforms + u16 voxels/u64 sums (rtcsm), f64 (ceres)",
             "data": "synthetic",
             "config": {
-                "workload": "config2 W-dense: %dx%d scan, all returns matched (adaptive voxel filters "
+                "workload": "%s W-dense: %dx%d scan, all returns matched (adaptive voxel filters "
                             "neutralised), RTCSM3D + CeresScanMatcher3D(hi+lo) + insertion(hi+lo)" %
-                            (args.beams, args.azimuths),
+                            ({(64, 1024, 0.1): "config2", (128, 2048, 0.05): "config5"}.get(
+                                (args.beams, args.azimuths, args.high_resolution), "custom"),
+                             args.beams, args.azimuths),
                 "high_resolution": args.high_resolution, "low_resolution": args.low_resolution,
                 "N_hi": n_pts, "N_lo": n_pts, "C": C,
                 "linear_window": int(st.window.linear_window_size),
