@@ -799,3 +799,71 @@ def test_front_end_match_cloud_equals_match(dl, ctx, orc):
         assert sa["hi"].cells() == sb["hi"].cells() and sa["lo"].cells() == sb["lo"].cells()
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_matchers_are_reentrant_across_contexts(dl, orc):
+    """The back end calls CeresScanMatcher3D::Match from pool threads (constraint_builder_3d.cc:320):
+    one dliom_ctx per thread, shared const grids.  Four threads x (RTCSM3D + Ceres) on the same two
+    grids give the results of the serial run."""
+    import threading
+    from dliom import synth
+    main = dl.Context(0)
+    og_hi = build_oracle_submap(orc, 0.1, num_scans=5, max_range=20.0)
+    og_lo = build_oracle_submap(orc, 0.45, num_scans=5)
+    g_hi, g_lo = to_device_grid(dl, main, og_hi), to_device_grid(dl, main, og_lo)
+    jobs = []
+    for k in range(4):
+        truth = synth.trajectory_pose(0.5 + 0.02 * k)
+        pts, _ = synth.scan(truth, 16, 256)
+        jobs.append((pts, synth.perturb_pose(truth, 0.08, 0.4, seed=70 + k)))
+
+    def run(ctx, pts, init):
+        rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+        cs = dl.CeresScanMatcher3D(ctx, DEFAULT_CSM)
+        score, p1 = rt.Match(init, pts, g_hi)
+        p2, _ = cs.Match(init[:3], p1, [(pts, g_hi), (pts, g_lo)])
+        return score, p1, p2
+
+    serial = [run(main, pts, init) for pts, init in jobs]
+    out = [None] * len(jobs)
+    ctxs = [dl.Context(0) for _ in jobs]
+
+    def worker(i):
+        for _ in range(3):
+            out[i] = run(ctxs[i], *jobs[i])
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for got, want in zip(out, serial):
+        assert got is not None
+        assert np.float32(got[0]) == np.float32(want[0])
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    for c in ctxs:
+        c.close()
+    g_hi.close()
+    g_lo.close()
+    main.close()
+
+
+@pytest.mark.gpu
+def test_error_statuses_instead_of_aborts(dl, ctx):
+    """The reference's CHECKs come back as negative statuses."""
+    g = dl.HybridGrid(ctx, 0.1)
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    ident = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    with pytest.raises(dl.DliomError):  # empty cloud
+        rt.Match(ident, np.zeros((0, 3), np.float32), g)
+    cs = dl.CeresScanMatcher3D(ctx, dict(DEFAULT_CSM, occupied_space_weight=[1.0]))
+    pts = np.ones((4, 3), np.float32)
+    with pytest.raises(dl.DliomError):  # CHECK_EQ(weights.size(), clouds.size()) (ceres_scan_matcher_3d.cc:89-92)
+        cs.Match(ident[:3], ident, [(pts, g), (pts, g)])
+    with pytest.raises((dl.DliomError, ValueError)):  # CHECK_GT(hit_probability, 0.5) (range_data_inserter_3d.cc:38)
+        dl.RangeDataInserter3D(0.4, 0.49, 2, ctx=ctx)
+    ins = dl.RangeDataInserter3D(0.55, 0.49, 2)
+    with pytest.raises(dl.DliomError):  # a return farther than the 8-bit DynamicGrid can hold (hybrid_grid.h:389)
+        ins.Insert(np.zeros(3, np.float32), np.array([[1e4, 0, 0]], np.float32), g)
+    g.close()
