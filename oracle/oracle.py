@@ -118,6 +118,22 @@ def _declare(L):
     sig("orc_pg_insert", None, vp, _f32p, _f32p, C.c_int, C.c_double, C.c_double, C.c_int)
     sig("orc_rtcsm2d_match", C.c_double, _f64p, _f64p, _f32p, C.c_int, vp, _f64p)
     sig("orc_rtcsm2d_score_single", C.c_float, _f64p, _f32p, C.c_int, vp, C.c_int, C.c_int)
+    u8p = C.POINTER(C.c_uint8)
+    sig("orc_fast_csm_new", vp, vp, vp, _f32p, _f32p, C.c_int, C.c_int, _f64p)
+    sig("orc_fast_csm_free", None, vp)
+    sig("orc_fast_csm_max_depth", C.c_int, vp)
+    sig("orc_fast_csm_stack_num_cells", C.c_int64, vp, C.c_int)
+    sig("orc_fast_csm_stack_cells", None, vp, C.c_int, _i32p, u8p)
+    sig("orc_fast_csm_match", None, vp, _f64p, _f64p, _f64p, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int,
+        C.c_float, _f64p, _f64p)
+    sig("orc_fast_csm_match_full_submap", None, vp, _f64p, _f64p, _f64p, _f32p, C.c_int, _f32p, C.c_int, _f32p,
+        C.c_int, C.c_float, _f64p, _f64p)
+    sig("orc_fast_csm_match_3dof", None, vp, _f64p, _f64p, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_float,
+        _f64p, _f64p)
+    sig("orc_compute_histogram", None, _f32p, C.c_int, C.c_int, _f32p)
+    sig("orc_rotational_match", None, _f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p)
+    sig("orc_kat_precomputation_grid", C.c_double)
+    sig("orc_kat_fast_csm", C.c_int, C.c_int, _f64p)
     sig("orc_now_seconds", C.c_double)
 
 
@@ -600,3 +616,94 @@ def deskew_and_filter(scan_period, min_range, max_range, voxel_filter_size, prev
     return dict(hits_in_local=hits[:counts[0]].copy(), kind=kind[:counts[0]].copy(),
                 returns_in_tracking=ret[:counts[1]].copy(), misses_in_tracking=mis[:counts[2]].copy(),
                 current_pose=cur, origin_in_tracking=org)
+
+
+# ------------------------------------------------------------------ fast correlative scan matcher 3D
+def fast_options(o):
+    """dict(branch_and_bound_depth, full_resolution_depth, min_rotational_score, min_low_resolution_score,
+    linear_xy_search_window, linear_z_search_window, angular_search_window) -> float64[7]."""
+    return _f64([o["branch_and_bound_depth"], o["full_resolution_depth"], o["min_rotational_score"],
+                 o["min_low_resolution_score"], o["linear_xy_search_window"], o["linear_z_search_window"],
+                 o["angular_search_window"]])
+
+
+def compute_histogram(pts, histogram_size):
+    pts = _f32(pts).reshape(-1, 3)
+    out = np.zeros(histogram_size, dtype=np.float32)
+    lib().orc_compute_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p))
+    return out
+
+
+def rotational_match(node_histograms, node_angles, scan_histogram, initial_angle, angles):
+    h = _f32(node_histograms).reshape(len(node_angles), -1)
+    a = _f32(angles)
+    out = np.zeros(len(a), dtype=np.float32)
+    lib().orc_rotational_match(_p(h, _f32p), _p(_f32(node_angles), _f32p), h.shape[0], h.shape[1],
+                               _p(_f32(scan_histogram), _f32p), C.c_float(initial_angle), _p(a, _f32p), len(a),
+                               _p(out, _f32p))
+    return out
+
+
+class FastCorrelativeScanMatcher3D:
+    """FastCorrelativeScanMatcher3D(hybrid_grid, low_resolution_hybrid_grid, nodes, options) with the nodes
+    given as (histogram, yaw) pairs (HistogramsAtAnglesFromNodes, fast_correlative_scan_matcher_3d.cc:114-127)."""
+
+    def __init__(self, hi_grid, lo_grid, node_histograms, node_angles, options):
+        h = _f32(node_histograms).reshape(len(node_angles), -1)
+        self.hist_size = h.shape[1]
+        self.grids = (hi_grid, lo_grid)  # keep alive
+        self.h = lib().orc_fast_csm_new(hi_grid.h, lo_grid.h, _p(h, _f32p), _p(_f32(node_angles), _f32p), h.shape[0],
+                                        h.shape[1], _p(fast_options(options), _f64p))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_fast_csm_free(self.h)
+            self.h = None
+
+    def max_depth(self):
+        return lib().orc_fast_csm_max_depth(self.h)
+
+    def stack_cells(self, depth):
+        n = lib().orc_fast_csm_stack_num_cells(self.h, depth)
+        xyz = np.zeros((n, 3), dtype=np.int32)
+        v = np.zeros(n, dtype=np.uint8)
+        lib().orc_fast_csm_stack_cells(self.h, depth, _p(xyz, _i32p), v.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return xyz, v
+
+    @staticmethod
+    def _result(pose, out):
+        return dict(found=bool(out[0]), score=np.float32(out[1]), rotational_score=np.float32(out[2]),
+                    low_resolution_score=np.float32(out[3]), num_scored_candidates=int(out[4]),
+                    num_discrete_scans=int(out[5]), pose=pose if out[0] else None)
+
+    def _data(self, data):
+        hi = _f32(data["high_resolution_point_cloud"]).reshape(-1, 3)
+        lo = _f32(data["low_resolution_point_cloud"]).reshape(-1, 3)
+        hist = _f32(data["rotational_scan_matcher_histogram"])
+        assert len(hist) == self.hist_size
+        return _f64(data["gravity_alignment"]), hi, lo, hist
+
+    def Match(self, global_node_pose, global_submap_pose, data, min_score):
+        g, hi, lo, hist = self._data(data)
+        pose, out = np.zeros(7), np.zeros(6)
+        lib().orc_fast_csm_match(self.h, _p(_f64(global_node_pose), _f64p), _p(_f64(global_submap_pose), _f64p),
+                                 _p(g, _f64p), _p(hi, _f32p), len(hi), _p(lo, _f32p), len(lo), _p(hist, _f32p), len(hist),
+                                 C.c_float(min_score), _p(pose, _f64p), _p(out, _f64p))
+        return self._result(pose, out)
+
+    def MatchFullSubmap(self, global_node_rotation, global_submap_rotation, data, min_score):
+        g, hi, lo, hist = self._data(data)
+        pose, out = np.zeros(7), np.zeros(6)
+        lib().orc_fast_csm_match_full_submap(self.h, _p(_f64(global_node_rotation), _f64p),
+                                             _p(_f64(global_submap_rotation), _f64p), _p(g, _f64p), _p(hi, _f32p), len(hi),
+                                             _p(lo, _f32p), len(lo), _p(hist, _f32p), len(hist), C.c_float(min_score),
+                                             _p(pose, _f64p), _p(out, _f64p))
+        return self._result(pose, out)
+
+    def MatchWith3DofInitial(self, pose_in_submap_guess, data, min_score):
+        g, hi, lo, hist = self._data(data)
+        pose, out = np.zeros(7), np.zeros(6)
+        lib().orc_fast_csm_match_3dof(self.h, _p(_f64(pose_in_submap_guess), _f64p), _p(g, _f64p), _p(hi, _f32p), len(hi),
+                                      _p(lo, _f32p), len(lo), _p(hist, _f32p), len(hist), C.c_float(min_score),
+                                      _p(pose, _f64p), _p(out, _f64p))
+        return self._result(pose, out)

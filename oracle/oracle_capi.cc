@@ -9,10 +9,12 @@
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "src/om_csm3d.h"
 #include "src/om_deskew.h"
+#include "src/om_fast_csm3d.h"
 #include "src/om_front_end.h"
 #include "src/om_grid2d.h"
 #include "src/om_rtcsm3d.h"
@@ -532,6 +534,205 @@ float orc_rtcsm2d_score_single(const double* opts, const float* pts, int n, void
 }
 
 // ---------------------------------------------------------------- timing helper
+// ---------------------------------------------------------------- fast correlative scan matcher 3D
+// options: [branch_and_bound_depth, full_resolution_depth, min_rotational_score,
+//           min_low_resolution_score, linear_xy_search_window, linear_z_search_window,
+//           angular_search_window]
+static FastCorrelativeScanMatcherOptions3D FastOptions(const double* o) {
+  return FastCorrelativeScanMatcherOptions3D{static_cast<int>(o[0]), static_cast<int>(o[1]), o[2], o[3], o[4], o[5], o[6]};
+}
+static std::vector<std::pair<Histogram, float>> HistogramsAtAngles(const float* histograms, const float* angles,
+                                                                 int num_nodes, int histogram_size) {
+  std::vector<std::pair<Histogram, float>> v;
+  for (int i = 0; i < num_nodes; ++i)
+    v.emplace_back(Histogram(histograms + static_cast<size_t>(i) * histogram_size,
+                             histograms + static_cast<size_t>(i + 1) * histogram_size),
+                   angles[i]);
+  return v;
+}
+static NodeData MakeNodeData(const double* gravity4, const float* hi, int n_hi, const float* lo, int n_lo,
+                             const float* histogram, int histogram_size) {
+  NodeData d;
+  d.gravity_alignment = Quatd(gravity4[0], gravity4[1], gravity4[2], gravity4[3]);
+  d.high_resolution_point_cloud = ToCloud(hi, n_hi);
+  d.low_resolution_point_cloud = ToCloud(lo, n_lo);
+  d.rotational_scan_matcher_histogram.assign(histogram, histogram + histogram_size);
+  return d;
+}
+// out9: found, score, rotational_score, low_resolution_score, num_scored_candidates, num_discrete_scans
+static void StoreFastResult(const FastMatchResult& r, double* pose7, double* out6) {
+  out6[0] = r.found ? 1. : 0.;
+  out6[1] = r.score;
+  out6[2] = r.rotational_score;
+  out6[3] = r.low_resolution_score;
+  out6[4] = static_cast<double>(r.num_scored_candidates);
+  out6[5] = r.num_discrete_scans;
+  if (r.found) FromRigid(r.pose_estimate, pose7);
+}
+
+void* orc_fast_csm_new(void* hi_grid, void* lo_grid, const float* histograms, const float* angles, int num_nodes,
+                       int histogram_size, const double* options7) {
+  return new FastCorrelativeScanMatcher3D(*G(hi_grid), G(lo_grid),
+                                          HistogramsAtAngles(histograms, angles, num_nodes, histogram_size),
+                                          FastOptions(options7));
+}
+void orc_fast_csm_free(void* m) { delete static_cast<FastCorrelativeScanMatcher3D*>(m); }
+int orc_fast_csm_max_depth(void* m) { return static_cast<FastCorrelativeScanMatcher3D*>(m)->stack().max_depth(); }
+int64_t orc_fast_csm_stack_num_cells(void* m, int depth) {
+  int64_t n = 0;
+  static_cast<FastCorrelativeScanMatcher3D*>(m)->stack().Get(depth).ForEachCell([&](const Vec3i&, uint8) { ++n; });
+  return n;
+}
+void orc_fast_csm_stack_cells(void* m, int depth, int* xyz, uint8_t* values) {
+  int64_t i = 0;
+  static_cast<FastCorrelativeScanMatcher3D*>(m)->stack().Get(depth).ForEachCell([&](const Vec3i& c, uint8 v) {
+    xyz[3 * i] = c.x; xyz[3 * i + 1] = c.y; xyz[3 * i + 2] = c.z;
+    values[i] = v;
+    ++i;
+  });
+}
+void orc_fast_csm_match(void* m, const double* node_pose7, const double* submap_pose7, const double* gravity4,
+                        const float* hi, int n_hi, const float* lo, int n_lo, const float* histogram, int histogram_size,
+                        float min_score, double* pose7, double* out6) {
+  const NodeData d = MakeNodeData(gravity4, hi, n_hi, lo, n_lo, histogram, histogram_size);
+  StoreFastResult(static_cast<FastCorrelativeScanMatcher3D*>(m)->Match(ToRigid(node_pose7), ToRigid(submap_pose7), d,
+                                                                         min_score), pose7, out6);
+}
+void orc_fast_csm_match_full_submap(void* m, const double* node_rotation4, const double* submap_rotation4,
+                                    const double* gravity4, const float* hi, int n_hi, const float* lo, int n_lo,
+                                    const float* histogram, int histogram_size, float min_score, double* pose7,
+                                    double* out6) {
+  const NodeData d = MakeNodeData(gravity4, hi, n_hi, lo, n_lo, histogram, histogram_size);
+  StoreFastResult(static_cast<FastCorrelativeScanMatcher3D*>(m)->MatchFullSubmap(
+                      Quatd(node_rotation4[0], node_rotation4[1], node_rotation4[2], node_rotation4[3]),
+                      Quatd(submap_rotation4[0], submap_rotation4[1], submap_rotation4[2], submap_rotation4[3]), d,
+                      min_score), pose7, out6);
+}
+void orc_fast_csm_match_3dof(void* m, const double* pose_in_submap7, const double* gravity4, const float* hi, int n_hi,
+                             const float* lo, int n_lo, const float* histogram, int histogram_size, float min_score,
+                             double* pose7, double* out6) {
+  const NodeData d = MakeNodeData(gravity4, hi, n_hi, lo, n_lo, histogram, histogram_size);
+  StoreFastResult(static_cast<FastCorrelativeScanMatcher3D*>(m)->MatchWith3DofInitial(ToRigid(pose_in_submap7), d, min_score),
+                  pose7, out6);
+}
+void orc_compute_histogram(const float* pts, int n, int histogram_size, float* out) {
+  const Histogram h = ComputeHistogram(ToCloud(pts, n), histogram_size);
+  std::memcpy(out, h.data(), sizeof(float) * histogram_size);
+}
+void orc_rotational_match(const float* histograms, const float* node_angles, int num_nodes, int histogram_size,
+                          const float* scan_histogram, float initial_angle, const float* angles, int num_angles,
+                          float* scores) {
+  const RotationalScanMatcher rsm(HistogramsAtAngles(histograms, node_angles, num_nodes, histogram_size));
+  const std::vector<float> s = rsm.Match(Histogram(scan_histogram, scan_histogram + histogram_size), initial_angle,
+                                         std::vector<float>(angles, angles + num_angles));
+  std::memcpy(scores, s.data(), sizeof(float) * num_angles);
+}
+
+// precomputation_grid_3d_test.cc:30-77 run natively (it interleaves std::mt19937 draws of two
+// distributions): returns the largest |naive max - precomputed| over the 4 x 100 probes.
+double orc_kat_precomputation_grid(void) {
+  HybridGrid hybrid_grid(2.f);
+  std::mt19937 rng(23847);
+  std::uniform_int_distribution<int> coordinate_distribution(-50, 49);
+  std::uniform_real_distribution<float> value_distribution(kMinProbability, kMaxProbability);
+  for (int i = 0; i < 1000; ++i) {
+    const auto x = coordinate_distribution(rng);
+    const auto y = coordinate_distribution(rng);
+    const auto z = coordinate_distribution(rng);
+    hybrid_grid.SetProbability(Vec3i(x, y, z), value_distribution(rng));
+  }
+  std::vector<PrecomputationGrid3D> grids;
+  double worst = 0.;
+  for (int depth = 0; depth <= 3; ++depth) {
+    if (depth == 0) {
+      grids.push_back(ConvertToPrecomputationGrid(hybrid_grid));
+    } else {
+      const int s = 1 << (depth - 1);
+      grids.push_back(PrecomputeGrid(grids.back(), false, Vec3i(s, s, s)));
+    }
+    const int width = 1 << depth;
+    for (int i = 0; i < 100; ++i) {
+      const auto x = coordinate_distribution(rng);
+      const auto y = coordinate_distribution(rng);
+      const auto z = coordinate_distribution(rng);
+      float max_probability = 0.;
+      for (int dx = 0; dx < width; ++dx)
+        for (int dy = 0; dy < width; ++dy)
+          for (int dz = 0; dz < width; ++dz)
+            max_probability = std::max(max_probability, hybrid_grid.GetProbability(Vec3i(x + dx, y + dy, z + dz)));
+      worst = std::max(worst, static_cast<double>(std::abs(
+                                  max_probability - PrecomputationGrid3D::ToProbability(grids.back().value(Vec3i(x, y, z))))));
+    }
+  }
+  return worst;
+}
+
+// fast_correlative_scan_matcher_3d_test.cc:35-190.  mode 0: CorrectPoseForMatch (20 random poses),
+// mode 1: CorrectPoseForMatchFullSubmap (1 pose).  Returns the number of failed expectations;
+// worst3 = {max translation error, max rotation angle error, min score}.
+int orc_kat_fast_csm(int mode, double* worst3) {
+  const PointCloud point_cloud = {Vec3f(4.f, 0.f, 0.f), Vec3f(4.5f, 0.f, 0.f), Vec3f(5.f, 0.f, 0.f), Vec3f(5.5f, 0.f, 0.f),
+                                  Vec3f(0.f, 4.f, 0.f), Vec3f(0.f, 4.5f, 0.f), Vec3f(0.f, 5.f, 0.f), Vec3f(0.f, 5.5f, 0.f),
+                                  Vec3f(0.f, 0.f, 4.f), Vec3f(0.f, 0.f, 4.5f), Vec3f(0.f, 0.f, 5.f), Vec3f(0.f, 0.f, 5.5f)};
+  std::mt19937 prng(42);
+  std::uniform_real_distribution<float> distribution(-1.f, 1.f);
+  const FastCorrelativeScanMatcherOptions3D options{6, 6, 0.1, 0.15, 0.8, 0.8, 0.3};
+  const RangeDataInserter3D inserter(0.7, 0.4, 5);
+  const float kMinScore = 0.1f;
+  int failures = 0;
+  worst3[0] = worst3[1] = 0.;
+  worst3[2] = 1e9;
+  const int rounds = mode == 0 ? 20 : 1;
+  for (int i = 0; i != rounds; ++i) {
+    const float x = 0.7f * distribution(prng);
+    const float y = 0.7f * distribution(prng);
+    const float z = 0.7f * distribution(prng);
+    const float theta = 0.2f * distribution(prng);
+    // Eigen::AngleAxisf(theta, UnitZ) -> Quaternionf: w = cos(theta/2), vec = sin(theta/2) * axis (float)
+    const Rigid3f expected = Rigid3f::Translation(Vec3f(x, y, z)) *
+                             Rigid3f::Rotation(Quatf(std::cos(0.5f * theta), 0.f, 0.f, std::sin(0.5f * theta)));
+    HybridGrid grid(0.05f);
+    PointCloud transformed;
+    for (const Vec3f& p : point_cloud) transformed.push_back(expected * p);
+    inserter.Insert(RangeData{expected.translation, transformed, {}}, &grid);
+    grid.FinishUpdate();
+    // HistogramsAtAnglesFromNodes (:114-127): one node at `expected`, identity gravity alignment
+    const Rigid3d node_pose = expected.cast<double>() * Rigid3d::Rotation(QuatInverse(Quatd()));
+    const std::vector<std::pair<Histogram, float>> nodes = {
+        {Histogram(10, 0.f), static_cast<float>(GetYaw(node_pose.rotation))}};
+    const FastCorrelativeScanMatcher3D matcher(grid, &grid, nodes, options);
+    NodeData data;
+    data.gravity_alignment = Quatd();
+    data.high_resolution_point_cloud = point_cloud;
+    data.low_resolution_point_cloud = point_cloud;
+    data.rotational_scan_matcher_histogram = Histogram(10, 0.f);
+    const FastMatchResult r = mode == 0 ? matcher.Match(Rigid3d(), Rigid3d(), data, kMinScore)
+                                        : matcher.MatchFullSubmap(Quatd(), Quatd(), data, kMinScore);
+    if (!r.found) {
+      ++failures;
+      continue;
+    }
+    if (!(kMinScore < r.score)) ++failures;
+    if (!(0.09f < r.rotational_score)) ++failures;
+    if (!(0.14f < r.low_resolution_score)) ++failures;
+    // transform::IsNearly(expected, actual, 0.05f): |t| and rotation angle of the difference
+    const Rigid3f actual = r.pose_estimate.cast<float>();
+    const Rigid3f diff = expected.inverse() * actual;
+    const double dt = diff.translation.norm();
+    const double da = GetAngle(diff);
+    worst3[0] = std::max(worst3[0], dt);
+    worst3[1] = std::max(worst3[1], da);
+    worst3[2] = std::min(worst3[2], static_cast<double>(r.score));
+    if (!(dt < 0.05) || !(da < 0.05)) ++failures;
+    NodeData far = data;
+    far.low_resolution_point_cloud = {Vec3f(42.f, 42.f, 42.f)};
+    const FastMatchResult r2 = mode == 0 ? matcher.Match(Rigid3d(), Rigid3d(), far, kMinScore)
+                                         : matcher.MatchFullSubmap(Quatd(), Quatd(), far, kMinScore);
+    if (r2.found) ++failures;
+  }
+  return failures;
+}
+
 double orc_now_seconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }

@@ -350,3 +350,31 @@ def test_rtcsm2d_scores(orc):
     r = orc.rtcsm2d_match(opts, (0.0, 0.0, 0.0), pc, pg)
     assert abs(r["score"] - 0.7) < 1e-2
     assert np.allclose(r["pose"], 0.0, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# FastCorrelativeScanMatcher3D / PrecomputationGrid3D known-answer tests of the reference, run
+# natively inside the oracle because they interleave std::mt19937 draws of two distributions.
+
+
+def test_precomputation_grid_against_naive_algorithm(orc):
+    """precomputation_grid_3d_test.cc:30-77: EXPECT_NEAR(naive max, precomputed, 1e-2) at depths 0..3."""
+    assert orc.lib().orc_kat_precomputation_grid() <= 1e-2
+
+
+def test_fast_correlative_scan_matcher_correct_pose_for_match(orc):
+    """fast_correlative_scan_matcher_3d_test.cc:134-163: 20 random poses found within 0.05, scores above
+    the thresholds, and no match for a far low-resolution cloud."""
+    worst = np.zeros(3)
+    import ctypes as C
+    failures = orc.lib().orc_kat_fast_csm(0, worst.ctypes.data_as(C.POINTER(C.c_double)))
+    assert failures == 0, worst
+    assert worst[0] < 0.05 and worst[1] < 0.05 and worst[2] > 0.1
+
+
+def test_fast_correlative_scan_matcher_correct_pose_for_match_full_submap(orc):
+    """fast_correlative_scan_matcher_3d_test.cc:165-190."""
+    worst = np.zeros(3)
+    import ctypes as C
+    failures = orc.lib().orc_kat_fast_csm(1, worst.ctypes.data_as(C.POINTER(C.c_double)))
+    assert failures == 0, worst
