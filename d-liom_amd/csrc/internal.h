@@ -169,6 +169,9 @@ int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, fl
 int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
                          float* oy, float* oz, int64_t* n_out);
 int needed_bits_for_cell_range(int min_index, int max_index);
+// rtcsm3d.hip: exact sequential float sums of LUT probabilities under explicit float poses
+int sequential_probability_sums(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid, const float* poses7,
+                                int k, float* sums);
 }  // namespace dliom
 
 #endif  // DLIOM_CSRC_INTERNAL_H_

@@ -1227,6 +1227,66 @@ static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double
 
 using namespace dliom;
 
+// Sequential float sums, in point order, of the LUT probabilities of `cloud` under k explicit float
+// poses: sums[i] = sum_p P(value(cell(q_i * p + t_i))) accumulated like `score += p`
+// (low_resolution_matcher.cc:27-34; the same loop as rtcsm_3d.cc:101-104).  Uses ctx->bounds,
+// ctx->rescore and ctx->misc as scratch; synchronises the stream.
+namespace dliom {
+int sequential_probability_sums(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid, const float* poses7,
+                                int k, float* sums) {
+  if (k <= 0 || k > 65535 || cloud.n <= 0) return DLIOM_ERR_INVALID_ARGUMENT;
+  const size_t K = static_cast<size_t>(k);
+  const size_t rot_bytes = (K * 16 + 255) & ~static_cast<size_t>(255);
+  const size_t trans_bytes = (K * 12 + 255) & ~static_cast<size_t>(255);
+  const size_t list_bytes = (K * 4 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->bounds.reserve(rot_bytes + trans_bytes + list_bytes));
+  std::vector<char> host(rot_bytes + trans_bytes + list_bytes, 0);
+  float* hr = reinterpret_cast<float*>(host.data());
+  float* ht = reinterpret_cast<float*>(host.data() + rot_bytes);
+  unsigned* hl = reinterpret_cast<unsigned*>(host.data() + rot_bytes + trans_bytes);
+  for (size_t i = 0; i < K; ++i) {
+    const float* p = poses7 + 7 * i;
+    hr[4 * i] = p[3];
+    hr[4 * i + 1] = p[4];
+    hr[4 * i + 2] = p[5];
+    hr[4 * i + 3] = p[6];
+    ht[3 * i] = p[0];
+    ht[3 * i + 1] = p[1];
+    ht[3 * i + 2] = p[2];
+    hl[i] = static_cast<unsigned>(i * K + i);  // the kernels decode c -> (translation c / R, rotation c % R), R = k
+  }
+  char* base = static_cast<char*>(ctx->bounds.p);
+  DLIOM_HIP_TRY(hipMemcpyAsync(base, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+  const float4* d_rot = reinterpret_cast<const float4*>(base);
+  const float* d_trans = reinterpret_cast<const float*>(base + rot_bytes);
+  const unsigned* d_list = reinterpret_cast<const unsigned*>(base + rot_bytes + trans_bytes);
+  const LutModel& lm = lut_model();
+  const int n = static_cast<int>(cloud.n);
+  const int n_stride = (n + 7) & ~7;
+  const size_t scan_lds = static_cast<size_t>(n_stride) * 2;
+  DLIOM_TRY(ctx->rescore.reserve(list_bytes));
+  float* d_ksums = ctx->rescore.as<float>();
+  if (scan_lds <= 128 * 1024) {
+    DLIOM_TRY(ctx->misc.reserve(K * n_stride * 2));
+    unsigned short* d_values = ctx->misc.as<unsigned short>();
+    hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, static_cast<unsigned>(k)), dim3(256), 0,
+                       ctx->stream, grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, d_rot, k, d_trans, d_list,
+                       static_cast<const unsigned*>(nullptr), d_values);
+    hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(static_cast<unsigned>(k)), dim3(kScanThreads), scan_lds, ctx->stream,
+                       d_values, n, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, static_cast<const unsigned*>(nullptr),
+                       d_ksums);
+  } else {
+    hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(static_cast<unsigned>(k)), dim3(256), 0, ctx->stream, grid->view(),
+                       cloud.d_x, cloud.d_y, cloud.d_z, n, d_rot, k, d_trans, d_list, static_cast<const unsigned*>(nullptr),
+                       lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
+  }
+  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_ksums, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `host` alive long enough
+  return DLIOM_OK;
+}
+}  // namespace dliom
+
 extern "C" {
 
 int dliom_rtcsm3d_window(const dliom_rtcsm_options* o, float resolution, const float* points_xyz,

@@ -104,6 +104,26 @@ class FrontEndOptions(C.Structure):
                 ("num_free_space_voxels", C.c_int)]
 
 
+class FastCsmOptions(C.Structure):
+    _fields_ = [("branch_and_bound_depth", C.c_int), ("full_resolution_depth", C.c_int),
+                ("min_rotational_score", C.c_double), ("min_low_resolution_score", C.c_double),
+                ("linear_xy_search_window", C.c_double), ("linear_z_search_window", C.c_double),
+                ("angular_search_window", C.c_double)]
+
+
+class FastCsmNodeData(C.Structure):
+    _fields_ = [("gravity_alignment", C.c_double * 4), ("high_resolution_points", C.POINTER(C.c_float)),
+                ("num_high_resolution_points", C.c_int64), ("low_resolution_points", C.POINTER(C.c_float)),
+                ("num_low_resolution_points", C.c_int64),
+                ("rotational_scan_matcher_histogram", C.POINTER(C.c_float))]
+
+
+class FastCsmResult(C.Structure):
+    _fields_ = [("found", C.c_int), ("score", C.c_float), ("pose_estimate", C.c_double * 7),
+                ("rotational_score", C.c_float), ("low_resolution_score", C.c_float), ("num_discrete_scans", C.c_int),
+                ("num_scored_candidates", C.c_int64), ("num_score_launches", C.c_int64)]
+
+
 class MatchResult(C.Structure):
     _fields_ = [("dropped", C.c_int), ("pose_estimate", C.c_double * 7),
                 ("pose_observation_in_submap", C.c_double * 7), ("initial_ceres_pose", C.c_double * 7),
@@ -179,6 +199,16 @@ SYMBOLS = [
                                C.POINTER(C.c_uint8), _f32p]),
     ("dliom_add_range_data", C.c_int, [_vp, _f64p, _f64p, C.c_double, _f32p, C.c_int64, _f32p, C.c_float, C.c_float,
                                        C.c_float, C.POINTER(_vp), _f32p, _f32p]),
+    ("dliom_fast_csm_create", C.c_int, [_vp, _vp, _vp, _f32p, _f32p, C.c_int, C.c_int, C.POINTER(FastCsmOptions),
+                                        C.POINTER(_vp)]),
+    ("dliom_fast_csm_destroy", C.c_int, [_vp]),
+    ("dliom_fast_csm_match", C.c_int, [_vp, _f64p, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
+                                       C.POINTER(FastCsmResult)]),
+    ("dliom_fast_csm_match_full_submap", C.c_int, [_vp, _f64p, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
+                                                   C.POINTER(FastCsmResult)]),
+    ("dliom_fast_csm_match_with_3dof_initial", C.c_int, [_vp, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
+                                                         C.POINTER(FastCsmResult)]),
+    ("dliom_fast_csm_level", C.c_int, [_vp, C.c_int, _i32p, _i32p, C.POINTER(C.c_uint8), C.c_int64]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
     ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
@@ -880,3 +910,89 @@ def _transform_f32(pose, pts):
     out = np.stack([((vx + w * uvx) + cx) + f(pose[0]), ((vy + w * uvy) + cy) + f(pose[1]),
                     ((vz + w * uvz) + cz) + f(pose[2])], axis=1)
     return out.astype(np.float32)
+
+
+class FastCorrelativeScanMatcher3D:
+    """mapping::scan_matching::FastCorrelativeScanMatcher3D on the device (dliom_fast_csm_*); `nodes` are given
+    as the (histogram, yaw) pairs HistogramsAtAnglesFromNodes extracts."""
+
+    def __init__(self, ctx, hybrid_grid, low_resolution_hybrid_grid, node_histograms, node_angles, options):
+        self.ctx = ctx
+        self._L = ctx._L
+        h = _f32(node_histograms).reshape(len(node_angles), -1)
+        self.hist_size = h.shape[1]
+        self.grids = (hybrid_grid, low_resolution_hybrid_grid)
+        o = FastCsmOptions(options["branch_and_bound_depth"], options["full_resolution_depth"],
+                           options["min_rotational_score"], options["min_low_resolution_score"],
+                           options["linear_xy_search_window"], options["linear_z_search_window"],
+                           options["angular_search_window"])
+        hnd = _vp()
+        _check(self._L.dliom_fast_csm_create(ctx.h, hybrid_grid.h, low_resolution_hybrid_grid.h, _p(h, _f32p),
+                                             _p(_f32(node_angles), _f32p), h.shape[0], h.shape[1], C.byref(o),
+                                             C.byref(hnd)), "dliom_fast_csm_create")
+        self.h = hnd
+        self.depth = options["branch_and_bound_depth"]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_fast_csm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level(self, depth):
+        """(lo[3], values[nz, ny, nx] uint8) of one pyramid level."""
+        lo = np.zeros(3, dtype=np.int32)
+        dims = np.zeros(3, dtype=np.int32)
+        _check(self._L.dliom_fast_csm_level(self.h, depth, _p(lo, _i32p), _p(dims, _i32p), None, 0), "level")
+        v = np.zeros((int(dims[2]), int(dims[1]), int(dims[0])), dtype=np.uint8)
+        if v.size:
+            _check(self._L.dliom_fast_csm_level(self.h, depth, _p(lo, _i32p), _p(dims, _i32p),
+                                                v.ctypes.data_as(C.POINTER(C.c_uint8)), v.size), "level")
+        return lo, v
+
+    def _data(self, data):
+        self._hi = _f32(data["high_resolution_point_cloud"]).reshape(-1, 3)
+        self._lo = _f32(data["low_resolution_point_cloud"]).reshape(-1, 3)
+        self._hist = _f32(data["rotational_scan_matcher_histogram"])
+        assert len(self._hist) == self.hist_size
+        d = FastCsmNodeData()
+        for i in range(4):
+            d.gravity_alignment[i] = float(data["gravity_alignment"][i])
+        d.high_resolution_points = _p(self._hi, _f32p)
+        d.num_high_resolution_points = len(self._hi)
+        d.low_resolution_points = _p(self._lo, _f32p)
+        d.num_low_resolution_points = len(self._lo)
+        d.rotational_scan_matcher_histogram = _p(self._hist, _f32p)
+        return d
+
+    @staticmethod
+    def _result(r):
+        return dict(found=bool(r.found), score=np.float32(r.score), rotational_score=np.float32(r.rotational_score),
+                    low_resolution_score=np.float32(r.low_resolution_score), num_discrete_scans=r.num_discrete_scans,
+                    num_scored_candidates=r.num_scored_candidates, num_score_launches=r.num_score_launches,
+                    pose=np.array(r.pose_estimate) if r.found else None)
+
+    def Match(self, global_node_pose, global_submap_pose, data, min_score):
+        d, r = self._data(data), FastCsmResult()
+        _check(self._L.dliom_fast_csm_match(self.h, _p(_f64(global_node_pose), _f64p), _p(_f64(global_submap_pose), _f64p),
+                                            C.byref(d), C.c_float(min_score), C.byref(r)), "dliom_fast_csm_match")
+        return self._result(r)
+
+    def MatchFullSubmap(self, global_node_rotation, global_submap_rotation, data, min_score):
+        d, r = self._data(data), FastCsmResult()
+        _check(self._L.dliom_fast_csm_match_full_submap(self.h, _p(_f64(global_node_rotation), _f64p),
+                                                        _p(_f64(global_submap_rotation), _f64p), C.byref(d),
+                                                        C.c_float(min_score), C.byref(r)), "dliom_fast_csm_match_full_submap")
+        return self._result(r)
+
+    def MatchWith3DofInitial(self, pose_in_submap_guess, data, min_score):
+        d, r = self._data(data), FastCsmResult()
+        _check(self._L.dliom_fast_csm_match_with_3dof_initial(self.h, _p(_f64(pose_in_submap_guess), _f64p), C.byref(d),
+                                                              C.c_float(min_score), C.byref(r)),
+               "dliom_fast_csm_match_with_3dof_initial")
+        return self._result(r)

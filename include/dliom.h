@@ -360,6 +360,60 @@ int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], const double
                          float min_range, float max_range, float voxel_filter_size,
                          dliom_cloud** returns_in_tracking, float origin_in_tracking[3], float current_pose[7]);
 
+/* ---- FastCorrelativeScanMatcher3D (loop closure) --------------------------------
+ * mapping/internal/3d/scan_matching/fast_correlative_scan_matcher_3d.h:100-132.  The constructor's
+ * `nodes` arrive as what HistogramsAtAnglesFromNodes (:114-127) extracts from them: one rotational
+ * histogram and one yaw per node.  The uint8 max-pool pyramid (PrecomputationGridStack3D, :57-77) is
+ * built on the device at creation from `high_resolution_grid`; both grids must outlive the matcher
+ * and stay unchanged (finished submaps).  Results equal the reference's: same candidate scores
+ * (integer sums), same traversal order and tie handling (host recursion with the reference's
+ * std::sort calls), low-resolution score by the exact sequential float sum. */
+typedef struct dliom_fast_csm dliom_fast_csm;
+typedef struct dliom_fast_csm_options { /* proto/scan_matching/fast_correlative_scan_matcher_options_3d.proto */
+  int branch_and_bound_depth;
+  int full_resolution_depth;
+  double min_rotational_score;
+  double min_low_resolution_score;
+  double linear_xy_search_window;
+  double linear_z_search_window;
+  double angular_search_window;
+} dliom_fast_csm_options;
+typedef struct dliom_fast_csm_node_data { /* the fields of TrajectoryNode::Data the matcher reads */
+  double gravity_alignment[4];                     /* w, x, y, z */
+  const float* high_resolution_points;             /* packed xyz */
+  int64_t num_high_resolution_points;
+  const float* low_resolution_points;
+  int64_t num_low_resolution_points;
+  const float* rotational_scan_matcher_histogram;  /* histogram_size floats */
+} dliom_fast_csm_node_data;
+typedef struct dliom_fast_csm_result { /* FastCorrelativeScanMatcher3D::Result; found == 0 <=> nullptr */
+  int found;
+  float score;
+  double pose_estimate[7];
+  float rotational_score;
+  float low_resolution_score;
+  int num_discrete_scans;
+  int64_t num_scored_candidates; /* candidates the device scored (incl. prefetched ones) */
+  int64_t num_score_launches;
+} dliom_fast_csm_result;
+int dliom_fast_csm_create(dliom_ctx* ctx, const dliom_grid* high_resolution_grid, const dliom_grid* low_resolution_grid,
+                          const float* node_histograms, const float* node_angles, int num_nodes, int histogram_size,
+                          const dliom_fast_csm_options* options, dliom_fast_csm** out);
+int dliom_fast_csm_destroy(dliom_fast_csm* matcher);
+/* Match (:147-165), MatchFullSubmap (:204-232), MatchWith3DofInitial (:168-201). */
+int dliom_fast_csm_match(dliom_fast_csm* matcher, const double global_node_pose[7], const double global_submap_pose[7],
+                         const dliom_fast_csm_node_data* constant_data, float min_score, dliom_fast_csm_result* result);
+int dliom_fast_csm_match_full_submap(dliom_fast_csm* matcher, const double global_node_rotation[4],
+                                     const double global_submap_rotation[4], const dliom_fast_csm_node_data* constant_data,
+                                     float min_score, dliom_fast_csm_result* result);
+int dliom_fast_csm_match_with_3dof_initial(dliom_fast_csm* matcher, const double pose_in_submap_guess[7],
+                                           const dliom_fast_csm_node_data* constant_data, float min_score,
+                                           dliom_fast_csm_result* result);
+/* One level of the pyramid: a dense box of dims[0]*dims[1]*dims[2] uint8 (x fastest) whose element
+ * (0,0,0) is cell lo[]; everything outside is 0.  values may be NULL to query the box only. */
+int dliom_fast_csm_level(const dliom_fast_csm* matcher, int depth, int32_t lo[3], int32_t dims[3], uint8_t* values,
+                         int64_t capacity);
+
 /* ---- RealTimeCorrelativeScanMatcher2D (BASELINE config 1: host only, by contract) -------------
  * double Match(initial_pose_estimate, point_cloud, probability_grid, pose_estimate)
  * (mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h:66-69, .cc:74-108).
