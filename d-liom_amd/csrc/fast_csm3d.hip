@@ -119,18 +119,20 @@ struct ScoreArgs {
   int start[3];             // search_window_start (negative window sizes)
 };
 
-// ScoreCandidates: one wavefront per candidate (scan, full-resolution offset), lanes over points.
+// ScoreCandidates: blockIdx.x = candidate (scan, full-resolution offset), blockIdx.y = chunk of
+// kScoreChunk points; lanes over points, block reduction, one atomicAdd per (candidate, chunk).
+constexpr int kScoreChunk = 2048;
 __global__ __launch_bounds__(256) void score_candidates_kernel(ScoreArgs a, const int4* __restrict__ candidates,
                                                                int num_candidates, int* __restrict__ sums) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= num_candidates) return;
-  const int lane = threadIdx.x & 63;
+  __shared__ unsigned wave_sums[4];
+  const int c = blockIdx.x;
   const int4 cand = candidates[c];
   const int ox = cand.y >> a.e, oy = cand.z >> a.e, oz = cand.w >> a.e;
   const int lsx = a.start[0] >> a.e, lsy = a.start[1] >> a.e, lsz = a.start[2] >> a.e;
   const size_t base = static_cast<size_t>(cand.x) * a.n;
+  const int p_begin = blockIdx.y * kScoreChunk, p_end = min(a.n, p_begin + kScoreChunk);
   unsigned sum = 0;
-  for (int p = lane; p < a.n; p += 64) {
+  for (int p = p_begin + threadIdx.x; p < p_end; p += 256) {
     int x = a.cx[base + p], y = a.cy[base + p], z = a.cz[base + p];
     if (a.e > 0) {  // low-resolution cells (:285-301)
       x = ((x + a.start[0]) >> a.e) - lsx;
@@ -140,7 +142,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(ScoreArgs a, cons
     sum += level_value(a.level, x + ox, y + oy, z + oz);
   }
   sum = wave_sum_lane63(sum);
-  if (lane == 63) sums[c] = static_cast<int>(sum);
+  if ((threadIdx.x & 63) == 63) wave_sums[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&sums[c], static_cast<int>(wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3]));
 }
 
 // ---- host side: rotational scan matcher (rotational_scan_matcher.cc) -----------------------------
@@ -264,6 +268,9 @@ struct Search {
   float min_low_resolution_score_f = 0.f;
   long long scored = 0;
   long long launches = 0;
+  const std::vector<Candidate>* top = nullptr;  // the sorted lowest-resolution candidates
+  float initial_min_score = 0.f;
+  float frontier_threshold = std::numeric_limits<float>::infinity();  // last wavefront prefetch ran with this
   // score cache: (depth, scan, offset) -> integer sum
   std::unordered_map<uint64_t, int> cache;
   static uint64_t key(int depth, int scan, const int* o) {
@@ -283,7 +290,14 @@ int device_sums(Search& s, int depth, const std::vector<Candidate>& list, std::v
   if (k == 0) return DLIOM_OK;
   const size_t cbytes = (k * 16 + 255) & ~static_cast<size_t>(255);
   DLIOM_TRY(ctx->cand.reserve(cbytes + k * 4));
-  std::vector<int> host(4 * k);
+  // candidate list and sums travel through the pinned block when they fit (no staging copies)
+  const bool pinned = cbytes + k * 4 <= ctx->pinned_bytes - 8192;
+  std::vector<int> pageable;
+  int* host = static_cast<int*>(ctx->pinned);
+  if (!pinned) {
+    pageable.resize(4 * k + k);
+    host = pageable.data();
+  }
   for (size_t i = 0; i < k; ++i) {
     host[4 * i] = list[i].scan_index;
     host[4 * i + 1] = list[i].offset[0];
@@ -292,7 +306,8 @@ int device_sums(Search& s, int depth, const std::vector<Candidate>& list, std::v
   }
   int4* d_cand = ctx->cand.as<int4>();
   int* d_sums = reinterpret_cast<int*>(static_cast<char*>(ctx->cand.p) + cbytes);
-  DLIOM_HIP_TRY(hipMemcpyAsync(d_cand, host.data(), k * 16, hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_cand, host, k * 16, hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemsetAsync(d_sums, 0, k * 4, ctx->stream));
   ScoreArgs a;
   a.level = m->levels[depth].view();
   a.cx = s.d_cx;
@@ -303,11 +318,14 @@ int device_sums(Search& s, int depth, const std::vector<Candidate>& list, std::v
   a.start[0] = -s.linear_xy;
   a.start[1] = -s.linear_xy;
   a.start[2] = -s.linear_z;
-  hipLaunchKernelGGL(score_candidates_kernel, dim3(static_cast<unsigned>((k + 3) / 4)), dim3(256), 0, ctx->stream, a,
-                     d_cand, static_cast<int>(k), d_sums);
+  const unsigned chunks = static_cast<unsigned>((s.n_hi + kScoreChunk - 1) / kScoreChunk);
+  hipLaunchKernelGGL(score_candidates_kernel, dim3(static_cast<unsigned>(k), chunks), dim3(256), 0, ctx->stream, a, d_cand,
+                     static_cast<int>(k), d_sums);
   DLIOM_HIP_TRY(hipGetLastError());
-  DLIOM_HIP_TRY(hipMemcpyAsync(sums->data(), d_sums, k * 4, hipMemcpyDeviceToHost, ctx->stream));
+  int* host_sums = host + 4 * k;
+  DLIOM_HIP_TRY(hipMemcpyAsync(host_sums, d_sums, k * 4, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  std::memcpy(sums->data(), host_sums, k * 4);
   s.scored += static_cast<long long>(k);
   ++s.launches;
   return DLIOM_OK;
@@ -374,6 +392,37 @@ int prefetch_children(Search& s, const std::vector<Candidate>& siblings, size_t 
   return DLIOM_OK;
 }
 
+// Wavefront prefetch: once a first match has raised the bound, every node the recursion can still
+// expand has a score above `threshold` -- score the children of ALL such nodes level by level
+// (one launch per level) instead of one launch per sibling group.
+int prefetch_frontier(Search& s, float threshold) {
+  const int top_depth = s.m->max_depth();
+  std::vector<Candidate> frontier;
+  for (const Candidate& c : *s.top)
+    if (c.score > threshold) frontier.push_back(c);
+  for (int depth = top_depth; depth >= 1 && !frontier.empty(); --depth) {
+    std::vector<Candidate> children;
+    for (const Candidate& c : frontier) children_of(s, c, depth, &children);
+    if (children.size() > (1u << 18)) break;  // a flat score landscape: stay with on-demand batches
+    std::vector<Candidate> missing;
+    for (const Candidate& c : children)
+      if (s.cache.find(Search::key(depth - 1, c.scan_index, c.offset)) == s.cache.end()) missing.push_back(c);
+    if (!missing.empty()) {
+      std::vector<int> sums;
+      DLIOM_TRY(device_sums(s, depth - 1, missing, &sums));
+      for (size_t i = 0; i < missing.size(); ++i)
+        s.cache[Search::key(depth - 1, missing[i].scan_index, missing[i].offset)] = sums[i];
+    }
+    frontier.clear();
+    for (Candidate& c : children) {
+      c.score = to_probability(s.cache[Search::key(depth - 1, c.scan_index, c.offset)] / static_cast<float>(s.n_hi));
+      if (c.score > threshold) frontier.push_back(c);
+    }
+  }
+  s.frontier_threshold = threshold;
+  return DLIOM_OK;
+}
+
 PoseF pose_from_candidate(const Search& s, const Candidate& c) {  // :431-437
   const float r = s.m->resolution;
   const PoseF t{F3{r * static_cast<float>(c.offset[0]), r * static_cast<float>(c.offset[1]), r * static_cast<float>(c.offset[2])},
@@ -418,8 +467,14 @@ Candidate branch_and_bound(Search& s, const std::vector<Candidate>& candidates, 
     std::vector<Candidate> higher;
     children_of(s, c, candidate_depth, &higher);
     if (!higher.empty() && s.cache.find(Search::key(candidate_depth - 1, higher[0].scan_index, higher[0].offset)) == s.cache.end()) {
-      *status = prefetch_children(s, candidates, i, candidate_depth, std::max(min_score, best.score));
-      if (*status != DLIOM_OK) return unsuccessful;
+      if (best.score > s.initial_min_score && best.score < s.frontier_threshold) {
+        *status = prefetch_frontier(s, best.score);  // a match exists: everything still reachable, per level
+        if (*status != DLIOM_OK) return unsuccessful;
+      }
+      if (s.cache.find(Search::key(candidate_depth - 1, higher[0].scan_index, higher[0].offset)) == s.cache.end()) {
+        *status = prefetch_children(s, candidates, i, candidate_depth, best.score);
+        if (*status != DLIOM_OK) return unsuccessful;
+      }
     }
     *status = score_candidates(s, candidate_depth - 1, &higher);
     if (*status != DLIOM_OK) return unsuccessful;
@@ -472,6 +527,8 @@ int run_search(Search& s, const dliom_cloud& hi_cloud, float min_score, dliom_fa
           lowest.push_back(c);
         }
   DLIOM_TRY(score_candidates(s, m->max_depth(), &lowest));
+  s.top = &lowest;
+  s.initial_min_score = min_score;
   int status = DLIOM_OK;
   const Candidate best = branch_and_bound(s, lowest, m->max_depth(), min_score, &status);
   DLIOM_TRY(status);
