@@ -7,6 +7,8 @@
 //   dliom::mapping::scan_matching::RealTimeCorrelativeScanMatcher3D
 //                                  .../scan_matching/real_time_correlative_scan_matcher_3d.h:34-66
 //   dliom::mapping::scan_matching::CeresScanMatcher3D         .../scan_matching/ceres_scan_matcher_3d.h:37-63
+//   dliom::mapping::scan_matching::FastCorrelativeScanMatcher3D
+//                                  .../scan_matching/fast_correlative_scan_matcher_3d.h:100-132
 //
 // The value types below are layout-compatible stand-ins for Eigen::Vector3f / transform::Rigid3d
 // so that this header builds without Eigen; inside cartographer the same adapters are
@@ -244,6 +246,103 @@ class CeresScanMatcher3D {
  private:
   Context* context_;
   dliom_csm_options options_ = {};
+};
+
+// proto/scan_matching/fast_correlative_scan_matcher_options_3d.proto
+using FastCorrelativeScanMatcherOptions3D = dliom_fast_csm_options;
+
+// The fields of mapping::TrajectoryNode::Data the loop-closure matcher reads
+// (mapping/trajectory_node.h:45-69).
+struct TrajectoryNodeData {
+  transform::Quaterniond gravity_alignment{{1, 0, 0, 0}};
+  sensor::PointCloud high_resolution_point_cloud;
+  sensor::PointCloud low_resolution_point_cloud;
+  std::vector<float> rotational_scan_matcher_histogram;
+};
+
+// fast_correlative_scan_matcher_3d.h:100-132.  `nodes` are passed as the (histogram, yaw) pairs the
+// reference's HistogramsAtAnglesFromNodes (fast_correlative_scan_matcher_3d.cc:114-127) extracts.
+class FastCorrelativeScanMatcher3D {
+ public:
+  struct Result {
+    float score;
+    transform::Rigid3d pose_estimate;
+    float rotational_score;
+    float low_resolution_score;
+  };
+
+  FastCorrelativeScanMatcher3D(Context* context, const HybridGrid& hybrid_grid,
+                               const HybridGrid* low_resolution_hybrid_grid,
+                               const std::vector<std::pair<std::vector<float>, float>>& histograms_at_angles,
+                               const FastCorrelativeScanMatcherOptions3D& options) {
+    if (low_resolution_hybrid_grid == nullptr || histograms_at_angles.empty())
+      Check(DLIOM_ERR_INVALID_ARGUMENT, "FastCorrelativeScanMatcher3D: nodes.at(0) / low resolution grid");
+    histogram_size_ = static_cast<int>(histograms_at_angles[0].first.size());
+    std::vector<float> h, a;
+    for (const auto& ha : histograms_at_angles) {
+      h.insert(h.end(), ha.first.begin(), ha.first.end());
+      a.push_back(ha.second);
+    }
+    Check(dliom_fast_csm_create(context->get(), hybrid_grid.get(), low_resolution_hybrid_grid->get(), h.data(), a.data(),
+                                static_cast<int>(a.size()), histogram_size_, &options, &matcher_),
+          "dliom_fast_csm_create (CHECK_GE(branch_and_bound_depth, 1), CHECK_GE(full_resolution_depth, 1))");
+  }
+  ~FastCorrelativeScanMatcher3D() { dliom_fast_csm_destroy(matcher_); }
+  FastCorrelativeScanMatcher3D(const FastCorrelativeScanMatcher3D&) = delete;
+  FastCorrelativeScanMatcher3D& operator=(const FastCorrelativeScanMatcher3D&) = delete;
+
+  // Returns false where the reference returns nullptr.
+  bool Match(const transform::Rigid3d& global_node_pose, const transform::Rigid3d& global_submap_pose,
+             const TrajectoryNodeData& constant_data, float min_score, Result* result) const {
+    const dliom_fast_csm_node_data d = Data(constant_data);
+    dliom_fast_csm_result r;
+    Check(dliom_fast_csm_match(matcher_, global_node_pose.ToArray().data(), global_submap_pose.ToArray().data(), &d,
+                               min_score, &r),
+          "FastCorrelativeScanMatcher3D::Match");
+    return Store(r, result);
+  }
+  bool MatchFullSubmap(const transform::Quaterniond& global_node_rotation,
+                       const transform::Quaterniond& global_submap_rotation, const TrajectoryNodeData& constant_data,
+                       float min_score, Result* result) const {
+    const dliom_fast_csm_node_data d = Data(constant_data);
+    dliom_fast_csm_result r;
+    Check(dliom_fast_csm_match_full_submap(matcher_, global_node_rotation.wxyz, global_submap_rotation.wxyz, &d,
+                                           min_score, &r),
+          "FastCorrelativeScanMatcher3D::MatchFullSubmap");
+    return Store(r, result);
+  }
+  bool MatchWith3DofInitial(const transform::Rigid3d& pose_in_submap_guess, const TrajectoryNodeData& constant_data,
+                            float min_score, Result* result) const {
+    const dliom_fast_csm_node_data d = Data(constant_data);
+    dliom_fast_csm_result r;
+    Check(dliom_fast_csm_match_with_3dof_initial(matcher_, pose_in_submap_guess.ToArray().data(), &d, min_score, &r),
+          "FastCorrelativeScanMatcher3D::MatchWith3DofInitial");
+    return Store(r, result);
+  }
+
+ private:
+  dliom_fast_csm_node_data Data(const TrajectoryNodeData& c) const {
+    if (static_cast<int>(c.rotational_scan_matcher_histogram.size()) != histogram_size_)
+      Check(DLIOM_ERR_INVALID_ARGUMENT, "rotational_scan_matcher_histogram size");
+    dliom_fast_csm_node_data d;
+    for (int i = 0; i < 4; ++i) d.gravity_alignment[i] = c.gravity_alignment.wxyz[i];
+    d.high_resolution_points = c.high_resolution_point_cloud.empty() ? nullptr : &c.high_resolution_point_cloud[0].x;
+    d.num_high_resolution_points = static_cast<int64_t>(c.high_resolution_point_cloud.size());
+    d.low_resolution_points = c.low_resolution_point_cloud.empty() ? nullptr : &c.low_resolution_point_cloud[0].x;
+    d.num_low_resolution_points = static_cast<int64_t>(c.low_resolution_point_cloud.size());
+    d.rotational_scan_matcher_histogram = c.rotational_scan_matcher_histogram.data();
+    return d;
+  }
+  static bool Store(const dliom_fast_csm_result& r, Result* result) {
+    if (!r.found) return false;
+    result->score = r.score;
+    result->pose_estimate = transform::Rigid3d::FromArray(r.pose_estimate);
+    result->rotational_score = r.rotational_score;
+    result->low_resolution_score = r.low_resolution_score;
+    return true;
+  }
+  dliom_fast_csm* matcher_ = nullptr;
+  int histogram_size_ = 0;
 };
 
 }  // namespace scan_matching

@@ -209,6 +209,7 @@ SYMBOLS = [
     ("dliom_fast_csm_match_with_3dof_initial", C.c_int, [_vp, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
                                                          C.POINTER(FastCsmResult)]),
     ("dliom_fast_csm_level", C.c_int, [_vp, C.c_int, _i32p, _i32p, C.POINTER(C.c_uint8), C.c_int64]),
+    ("dliom_rotational_histogram", C.c_int, [_f32p, C.c_int64, C.c_int, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
     ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
@@ -996,3 +997,12 @@ class FastCorrelativeScanMatcher3D:
                                                               C.c_float(min_score), C.byref(r)),
                "dliom_fast_csm_match_with_3dof_initial")
         return self._result(r)
+
+
+def rotational_histogram(points, histogram_size):
+    """RotationalScanMatcher::ComputeHistogram (host)."""
+    pts = _f32(points).reshape(-1, 3)
+    out = np.zeros(histogram_size, dtype=np.float32)
+    _check(load_library().dliom_rotational_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p)),
+           "dliom_rotational_histogram")
+    return out

@@ -414,6 +414,10 @@ int dliom_fast_csm_match_with_3dof_initial(dliom_fast_csm* matcher, const double
 int dliom_fast_csm_level(const dliom_fast_csm* matcher, int depth, int32_t lo[3], int32_t dims[3], uint8_t* values,
                          int64_t capacity);
 
+/* RotationalScanMatcher::ComputeHistogram (rotational_scan_matcher.cc:159-170; called per inserted
+ * scan, local_trajectory_builder_3d.cc:605-610) on the host: histogram_size floats. */
+int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram);
+
 /* ---- RealTimeCorrelativeScanMatcher2D (BASELINE config 1: host only, by contract) -------------
  * double Match(initial_pose_estimate, point_cloud, probability_grid, pose_estimate)
  * (mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h:66-69, .cc:74-108).

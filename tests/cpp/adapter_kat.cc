@@ -91,6 +91,34 @@ int main() {
     EXPECT(std::abs(int(v[2]) - int(hit)) <= 4 && std::abs(int(v[3]) - int(hit)) <= 4);
     EXPECT(v[4] == 0);
   }
+  {  // FastCorrelativeScanMatcher3DTest.CorrectPoseForMatch (fast_correlative_scan_matcher_3d_test.cc:134-163)
+    const sensor::PointCloud cloud = {{4.f, 0.f, 0.f}, {4.5f, 0.f, 0.f}, {5.f, 0.f, 0.f}, {5.5f, 0.f, 0.f},
+                                      {0.f, 4.f, 0.f}, {0.f, 4.5f, 0.f}, {0.f, 5.f, 0.f}, {0.f, 5.5f, 0.f},
+                                      {0.f, 0.f, 4.f}, {0.f, 0.f, 4.5f}, {0.f, 0.f, 5.f}, {0.f, 0.f, 5.5f}};
+    const float poses[][4] = {{0.3f, -0.5f, 0.2f, 0.f}, {-0.6f, 0.1f, -0.4f, 0.f}, {0.f, 0.65f, 0.35f, 0.f}};
+    for (const auto& e : poses) {
+      HybridGrid grid(&context, 0.05f);
+      const mapping::RangeDataInserter3D inserter(&context, {0.7, 0.4, 5});
+      const float c = std::cos(0.5f * e[3]), s = std::sin(0.5f * e[3]);
+      sensor::PointCloud moved;
+      for (const auto& p : cloud)  // Rz(theta) p + t
+        moved.push_back({(1.f - 2.f * s * s) * p.x - 2.f * c * s * p.y + e[0], 2.f * c * s * p.x + (1.f - 2.f * s * s) * p.y + e[1],
+                         p.z + e[2]});
+      inserter.Insert(sensor::RangeData{{e[0], e[1], e[2]}, moved, {}}, &grid);
+      const mapping::scan_matching::FastCorrelativeScanMatcher3D matcher(
+          &context, grid, &grid, {{std::vector<float>(10, 0.f), e[3]}}, {6, 6, 0.1, 0.15, 0.8, 0.8, 0.3});
+      mapping::scan_matching::TrajectoryNodeData data;
+      data.high_resolution_point_cloud = cloud;
+      data.low_resolution_point_cloud = cloud;
+      data.rotational_scan_matcher_histogram.assign(10, 0.f);
+      mapping::scan_matching::FastCorrelativeScanMatcher3D::Result result;
+      EXPECT(matcher.Match(Rigid3d(), Rigid3d(), data, 0.1f, &result));
+      EXPECT(result.score > 0.1f && result.rotational_score > 0.09f && result.low_resolution_score > 0.14f);
+      EXPECT(IsNearly(result.pose_estimate, e[0], e[1], e[2], 0.05));
+      data.low_resolution_point_cloud = {{42.f, 42.f, 42.f}};
+      EXPECT(!matcher.Match(Rigid3d(), Rigid3d(), data, 0.1f, &result));
+    }
+  }
   std::printf(g_failures == 0 ? "ALL ADAPTER TESTS PASSED\n" : "%d FAILURES\n", g_failures);
   return g_failures == 0 ? 0 : 1;
 }

@@ -138,3 +138,16 @@ def test_rtcsm2d_config1_equals_oracle(dl, orc):
     score, pose = dl.RealTimeCorrelativeScanMatcher2D(k).Match((0.0, 0.0, 0.0), pc, kat.cells(), kat.resolution,
                                                                kat.max_xy)
     assert abs(score - 0.7) < 1e-2 and np.allclose(pose, 0.0, atol=1e-9)
+
+
+def test_rotational_histogram_equals_oracle(orc):
+    """RotationalScanMatcher::ComputeHistogram (host code on both sides): bit-identical."""
+    import dliom as dl
+    from dliom import synth
+    for k, size in ((0, 120), (3, 30), (5, 10)):
+        pts, _ = synth.scan(synth.trajectory_pose(0.1 * k), 16, 256)
+        got = dl.rotational_histogram(pts, size)
+        want = orc.compute_histogram(pts, size)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert got.sum() > 0
+    assert np.array_equal(dl.rotational_histogram(np.zeros((0, 3), np.float32), 8), np.zeros(8, np.float32))
