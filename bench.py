@@ -80,8 +80,10 @@ def main():
 
     # ---------------------------------------------------------------- scene (per rank: own time offset)
     sharded_mode = args.shard_candidates and world > 1
-    # replicas: every rank flies its own stretch of the corkscrew; sharded: all ranks share one
-    t0 = 0.0 if sharded_mode else 0.05 * rank
+    # replicas: every rank runs the SAME scan stream on its own submap copy, so that the per-GPU work
+    # (N, C, evaluations) is identical and the max-over-ranks time measures scaling, not scene
+    # differences; sharded: all ranks share one stream by construction
+    t0 = 0.0
     ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
     g_hi = dl.HybridGrid(ctx, args.high_resolution)
     g_lo = dl.HybridGrid(ctx, args.low_resolution)
