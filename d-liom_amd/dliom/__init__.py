@@ -159,6 +159,8 @@ SYMBOLS = [
     ("dliom_grid_num_blocks", C.c_int, [_vp, _i64p]),
     ("dliom_grid_download_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64, _i64p]),
     ("dliom_grid_get_values", C.c_int, [_vp, _i32p, C.c_int64, _u16p]),
+    ("dliom_grid_to_proto", C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int64, _i64p]),
+    ("dliom_grid_from_proto", C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int64, C.POINTER(_vp)]),
     ("dliom_grid_insert", C.c_int, [_vp, _f32p, _f32p, C.c_int64, _u16p, _u16p, C.c_int]),
     ("dliom_inserter_create", C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.POINTER(_vp)]),
     ("dliom_inserter_destroy", C.c_int, [_vp]),
@@ -439,6 +441,28 @@ class HybridGrid:
             for c in nz:
                 out[(int(o[0]) + (c & 7), int(o[1]) + ((c >> 3) & 7), int(o[2]) + (c >> 6))] = int(v[c])
         return out
+
+    def to_proto(self):
+        """Serialized mapping::proto::HybridGrid (bytes)."""
+        n = C.c_int64()
+        _check(self._L.dliom_grid_to_proto(self.h, None, 0, C.byref(n)), "dliom_grid_to_proto")
+        buf = (C.c_uint8 * max(n.value, 1))()
+        _check(self._L.dliom_grid_to_proto(self.h, buf, n.value, C.byref(n)), "dliom_grid_to_proto")
+        return bytes(buf[:n.value])
+
+    @classmethod
+    def from_proto(cls, ctx, data):
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if len(data) else b"\0")
+        h = _vp()
+        _check(ctx._L.dliom_grid_from_proto(ctx.h, buf, len(data), C.byref(h)), "dliom_grid_from_proto")
+        g = cls.__new__(cls)
+        g._L = ctx._L
+        g.ctx = ctx
+        g.h = h
+        res = C.c_float()
+        _check(ctx._L.dliom_grid_resolution(h, C.byref(res)), "dliom_grid_resolution")
+        g.resolution = res.value
+        return g
 
     def set_values(self, cells_xyz, values):
         cells = np.ascontiguousarray(cells_xyz, dtype=np.int32).reshape(-1, 3)

@@ -91,6 +91,13 @@ int dliom_grid_download_blocks(const dliom_grid* grid, int32_t* block_origin_xyz
  * value = ProbabilityToValue(p), hybrid_grid.h:489-491; also how HybridGrid(proto) loads cells,
  * hybrid_grid.h:475-486).  Grows / allocates like the reference. */
 int dliom_grid_set_values(dliom_grid* grid, const int32_t* cell_xyz, const uint16_t* values, int64_t n);
+/* mapping::proto::HybridGrid wire bytes (mapping/proto/3d/hybrid_grid.proto) of the grid -- what
+ * HybridGrid::ToProto().SerializeAsString() yields (hybrid_grid.h:530-542: cells in iterator order) --
+ * and back (the proto constructor, hybrid_grid.h:475-486: SetProbability(ValueToProbability(v)) per
+ * entry).  buffer == NULL queries *size.  This is how finished submaps leave / enter the device for
+ * pbstream files and Submap3D::ToProto / UpdateFromProto (submap_3d.cc:217-250). */
+int dliom_grid_to_proto(const dliom_grid* grid, uint8_t* buffer, int64_t capacity, int64_t* size);
+int dliom_grid_from_proto(dliom_ctx* ctx, const uint8_t* buffer, int64_t size, dliom_grid** out);
 /* HybridGrid::value() for n cell indices (0 outside / unallocated). */
 int dliom_grid_get_values(const dliom_grid* grid, const int32_t* cell_xyz, int64_t n,
                           uint16_t* values);
