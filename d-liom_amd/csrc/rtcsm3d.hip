@@ -893,7 +893,15 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
       for (int cand = max_bs; cand >= 64; cand -= 64)
         if ((Rs + cand - 1) / cand * cand < (Rs + bs - 1) / bs * bs) bs = cand;
       if (forced_bs >= 64 && forced_bs <= kDenseMaxBlock && forced_bs % 64 == 0) bs = forced_bs;
+      // small searches (a few hundred points after the adaptive voxel filter) would fill a handful
+      // of workgroups: go down to one wavefront per group and 8-point chunks to spread them
+      if (forced_bs == 0 && static_cast<int64_t>((Rs + bs - 1) / bs) * ((n + 63) / 64) < 256) bs = 64;
       const int rot_groups = (Rs + bs - 1) / bs;
+      int chunk = 4096;
+      while (chunk > 8 && static_cast<int64_t>(rot_groups) * ((n + chunk - 1) / chunk) < target_blocks) chunk >>= 1;
+      if (forced_chunk > 0) chunk = forced_chunk;
+      const int point_chunks = (n + chunk - 1) / chunk;
+      processed = static_cast<int64_t>(point_chunks) * chunk;
       const dim3 block(bs);
       const size_t lds2 = lds + static_cast<size_t>(g.dense_stride) * 12 + static_cast<size_t>(t_chunk) * bs * 4;
       const int chunks_per_xcd = (point_chunks + 7) / 8;

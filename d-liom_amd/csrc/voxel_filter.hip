@@ -31,7 +31,7 @@ namespace dliom {
 int read_max_norm(dliom_ctx* ctx, const unsigned* d_max_sq, float* max_norm);
 
 constexpr int kVfBlock = 256;
-constexpr int kMaxLengths = 24;
+constexpr int kMaxLengths = 16;
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr unsigned kNoSlot = 0xFFFFFFFFu;
 
@@ -88,10 +88,13 @@ __global__ __launch_bounds__(kVfBlock) void voxel_insert_kernel(const float* __r
         const unsigned mask = t.capacity - 1;
         unsigned h = static_cast<unsigned>(mix64(key)) & mask;
         for (;;) {
-          const unsigned long long prev = atomicCAS(&keys[h], kEmptyKey, key);
+          // look before locking: with large voxels thousands of points share a slot, and all but
+          // the first few find their key in place and a smaller index already recorded
+          unsigned long long prev = __builtin_nontemporal_load(&keys[h]);
+          if (prev == kEmptyKey) prev = atomicCAS(&keys[h], kEmptyKey, key);
           if (prev == kEmptyKey || prev == key) {
             claimed = prev == kEmptyKey;
-            atomicMin(&min_index[h], i);
+            if (__builtin_nontemporal_load(&min_index[h]) > i) atomicMin(&min_index[h], i);
             my_slot = h;
             break;
           }
@@ -177,7 +180,7 @@ static unsigned table_capacity(int64_t n) {
 }
 
 struct VfScratch {
-  VfTables tables[2];      // two insert launches can be alive (halvings, bisection tree)
+  VfTables tables[3];      // insert launches that can be alive together: first halvings, remaining halvings, bisection tree
   unsigned char* flags;
   unsigned* block_counts;
   unsigned* max_sq;
@@ -191,10 +194,10 @@ static int carve_scratch(dliom_ctx* ctx, int64_t n, VfScratch* s) {
                             align256(static_cast<size_t>(kMaxLengths) * cap * 4) +
                             align256(static_cast<size_t>(kMaxLengths) * n * 4) + align256((kMaxLengths + 2) * 4);
   const unsigned blocks = static_cast<unsigned>((n + kVfBlock - 1) / kVfBlock);
-  const size_t total = 2 * per_launch + align256(static_cast<size_t>(n)) + align256(static_cast<size_t>(blocks) * 4) + 256;
+  const size_t total = 3 * per_launch + align256(static_cast<size_t>(n)) + align256(static_cast<size_t>(blocks) * 4) + 256;
   DLIOM_TRY(ctx->voxel.reserve(total));
   char* p = static_cast<char*>(ctx->voxel.p);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     VfTables& t = s->tables[k];
     t.capacity = cap;
     t.num = 0;
@@ -376,17 +379,33 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
   for (float high = o.max_length; high > 1e-2f * o.max_length; high /= 2.f) {
     highs.push_back(high);
     sizes.push_back(high / 2.f);
-    if (static_cast<int>(sizes.size()) == kMaxLengths) break;
   }
+  // The halving search almost always ends within its first two steps, and the small edge lengths
+  // are the expensive ones (most distinct voxels): count max_length and the first two halvings
+  // first, the rest only if none of them is dense enough.
+  const size_t first_batch = std::min<size_t>(3, sizes.size());
   std::vector<unsigned> counts;
   unsigned in_range = 0;
-  DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, sizes, &s.tables[0], &counts, &in_range));
+  DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, std::vector<float>(sizes.begin(), sizes.begin() + first_batch),
+                       &s.tables[0], &counts, &in_range));
   const float min_points = o.min_num_points;
   if (static_cast<float>(in_range) <= min_points)  // "already sparse enough" (:42-45)
     return emit_cloud(ctx, soa, s, s.tables[0], 0, 1, in_range, out);
   if (static_cast<float>(counts[0]) >= min_points)  // max_length is dense enough (:46-50)
     return emit_cloud(ctx, soa, s, s.tables[0], 0, 0, counts[0], out);
-  for (size_t k = 0; k < highs.size(); ++k) {
+  bool decided = false;
+  for (size_t k = 1; k < first_batch; ++k) decided = decided || static_cast<float>(counts[k]) >= min_points;
+  if (!decided && sizes.size() > first_batch) {
+    std::vector<unsigned> more;
+    unsigned dummy = 0;
+    DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, std::vector<float>(sizes.begin() + first_batch, sizes.end()),
+                         &s.tables[2], &more, &dummy));
+    counts.insert(counts.end(), more.begin(), more.end());
+  }
+  // table / slot of sizes[i]
+  auto table_of = [&](size_t i) -> const VfTables& { return i < first_batch ? s.tables[0] : s.tables[2]; };
+  auto slot_of = [&](size_t i) { return static_cast<int>(i < first_batch ? i : i - first_batch); };
+  for (size_t k = 0; k < highs.size() && k + 1 < counts.size(); ++k) {
     if (!(static_cast<float>(counts[k + 1]) >= min_points)) continue;
     // launch 2: every mid_length the bisection (:63-73) can reach from (low, high)
     struct Node {
@@ -413,7 +432,8 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
       todo.push_back({low, nd.mid});   // else: high = mid
       origin.push_back({id, 1});
     }
-    int chosen_table = 0, chosen_l = static_cast<int>(k) + 1;
+    const VfTables* chosen_table = &table_of(k + 1);
+    int chosen_l = slot_of(k + 1);
     unsigned chosen_count = counts[k + 1];
     if (!nodes.empty()) {
       std::vector<float> mids;
@@ -423,7 +443,7 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
       DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, mids, &s.tables[1], &mid_counts, &dummy));
       for (int id = 0; id >= 0;) {
         if (static_cast<float>(mid_counts[id]) >= min_points) {
-          chosen_table = 1;
+          chosen_table = &s.tables[1];
           chosen_l = id;
           chosen_count = mid_counts[id];
           id = nodes[id].ok_child;
@@ -432,11 +452,11 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
         }
       }
     }
-    return emit_cloud(ctx, soa, s, s.tables[chosen_table], chosen_l, 0, chosen_count, out);
+    return emit_cloud(ctx, soa, s, *chosen_table, chosen_l, 0, chosen_count, out);
   }
   // no edge length was dense enough: the last low_length's result stands (:56-57,76)
-  const int last = static_cast<int>(sizes.size()) - 1;
-  return emit_cloud(ctx, soa, s, s.tables[0], last, 0, counts[last], out);
+  const size_t last = sizes.size() - 1;
+  return emit_cloud(ctx, soa, s, table_of(last), slot_of(last), 0, counts[last], out);
 }
 
 }  // namespace dliom
