@@ -216,13 +216,6 @@ __device__ __forceinline__ int cvt_flr(float y) {  // floor to int in one instru
 
 constexpr int kDenseMaxBlock = 256;
 
-// a * b + c on the low 24 bits of a and b: full rate (32-bit integer multiplies are quarter rate).
-__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b_uniform, unsigned c) {
-  unsigned r;
-  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
-  return r;
-}
-
 template <int P>
 __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
     GridView g, const float* __restrict__ px, const float* __restrict__ py,

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kVfBlock) void voxel_compact_kernel(
   for (unsigned b = threadIdx.x; b < blockIdx.x; b += kVfBlock) part += block_counts[b];
   sh_part[threadIdx.x] = part;
   __syncthreads();
-  for (int s = kVfBlock / 2; s > 0; s >>= 1) {
+  for (unsigned s = kVfBlock / 2; s > 0; s >>= 1) {
     if (threadIdx.x < s) sh_part[threadIdx.x] += sh_part[threadIdx.x + s];
     __syncthreads();
   }
