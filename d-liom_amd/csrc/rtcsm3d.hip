@@ -216,9 +216,21 @@ __device__ __forceinline__ int cvt_flr(float y) {  // floor to int in one instru
 
 constexpr int kDenseMaxBlock = 256;
 
-template <int P>
+// Domain of the per-axis offset tables.  CLAMP = true: [0, S), every lookup is clamped into it
+// (v_med3_f32).  CLAMP = false: the host proved that every lookup of this launch -- real points
+// within max ||p|| + max |t| of the origin, padding replaced by `pad`, a point that stays beyond the
+// grid's edge under every candidate -- lands in [lo, lo + size); entries outside [0, S) alias the
+// guard cells, so the three clamps per lookup disappear.
+struct DenseDomain {
+  int lo;     // mirror coordinate of table entry 0 (<= 0)
+  int size;   // entries per axis
+  int n_real; // points below this index are real, the rest of the padded arrays is replaced by pad
+  float pad[3];
+};
+
+template <int P, bool CLAMP>
 __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
-    GridView g, const float* __restrict__ px, const float* __restrict__ py,
+    GridView g, DenseDomain dom, const float* __restrict__ px, const float* __restrict__ py,
     const float* __restrict__ pz, int points_per_chunk, int point_chunks,
     int rot_groups, const float4* __restrict__ rot, int R, int r_first, int r_last,
     const float4* __restrict__ trans4, int T, int t_chunk, unsigned long long* __restrict__ sums) {
@@ -232,11 +244,12 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
   const int rot_group = slot % rot_groups;
   const int chunk_id = (slot / rot_groups) * 8 + xcd;
   if (chunk_id >= point_chunks) return;
-  extern __shared__ float4 lds_dyn[];  // [T translations | 3 S byte offsets | t_chunk x blockDim accumulators]
+  extern __shared__ float4 lds_dyn[];  // [T translations | 3 TS byte offsets | t_chunk x blockDim accumulators]
   float4* lds_trans = lds_dyn;
   unsigned* lds_off = reinterpret_cast<unsigned*>(lds_dyn + T);
   const int S = g.dense_stride;
-  unsigned* lds_acc = lds_off + 3 * S;
+  const int TS = dom.size;  // table entries per axis (S when clamping)
+  unsigned* lds_acc = lds_off + 3 * TS;
   for (int j = threadIdx.x; j < T; j += bs) lds_trans[j] = trans4[j];
   // The mirror is stored in 4 x 4 x 4 bricks of 128 B (one cache line): lanes of a wave look up
   // cells a few voxels apart in EVERY direction, and the texture addresser works per distinct line.
@@ -245,11 +258,12 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
   //   Y[y] = (y>>2) B 128 + (y&3) 8,  Z[z] = (z>>2) B^2 128 + (z&3) 32,  B = bricks per axis
   {
     const unsigned B = static_cast<unsigned>(g.dense_bricks);
-    for (int c = threadIdx.x; c < S; c += bs) {
-      const unsigned h = static_cast<unsigned>(c) >> 2, l = static_cast<unsigned>(c) & 3u;
+    for (int c = threadIdx.x; c < TS; c += bs) {
+      const unsigned m = static_cast<unsigned>(min(max(c + dom.lo, 0), S - 1));  // outside -> guard cell
+      const unsigned h = m >> 2, l = m & 3u;
       lds_off[c] = h * 128u + l * 2u;
-      lds_off[S + c] = h * B * 128u + l * 8u;
-      lds_off[2 * S + c] = h * B * B * 128u + l * 32u;
+      lds_off[TS + c] = h * B * 128u + l * 8u;
+      lds_off[2 * TS + c] = h * B * B * 128u + l * 32u;
     }
   }
   __syncthreads();
@@ -258,9 +272,10 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
   const float4 qq = rot[active ? r : r_first];
   const Quat4 q{qq.x, qq.y, qq.z, qq.w};  // stored (w,x,y,z)
   const float inv = g.inv_resolution;
-  const float K = static_cast<float>(g.half + 1) + 0.5f;
-  const float band = 2.2f * static_cast<float>(S) * 5.9604645e-8f;
-  const float lim = static_cast<float>(S - 1) + 0.5f;
+  const float K = static_cast<float>(g.half + 1 - dom.lo) + 0.5f;  // exact: a small integer + 1/2
+  const float band = 2.2f * static_cast<float>(TS) * 5.9604645e-8f;
+  const float lim = static_cast<float>(TS - 1) + 0.5f;
+  const int to_table = g.half + 1 - dom.lo;
   const int p_begin = chunk_id * points_per_chunk;
   const int p_end = p_begin + points_per_chunk;  // the cloud is padded: no tail handling
   for (int jc = 0; jc < T; jc += t_chunk) {
@@ -270,7 +285,12 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
     for (int i = p_begin; i < p_end; i += P) {
       float rx[P], ry[P], rz[P];
 #pragma unroll
-      for (int k = 0; k < P; ++k) rotate_point(q, px[i + k], py[i + k], pz[i + k], rx[k], ry[k], rz[k]);
+      for (int k = 0; k < P; ++k) {
+        // wave-uniform point (scalar loads); without clamps the padding is swapped for dom.pad
+        const bool real = CLAMP || i + k < dom.n_real;
+        rotate_point(q, real ? px[i + k] : dom.pad[0], real ? py[i + k] : dom.pad[1], real ? pz[i + k] : dom.pad[2],
+                     rx[k], ry[k], rz[k]);
+      }
 #pragma unroll 1
       for (int jj = 0; jj < tc; ++jj) {
         const float4 t = lds_trans[jc + jj];  // same address in every lane: LDS broadcast
@@ -285,10 +305,16 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
                       fz = __builtin_amdgcn_fractf(zz);
           lo[k] = fminf(fminf(fx, fy), fz);
           hi[k] = fmaxf(fmaxf(fx, fy), fz);
-          // clamp in float (one v_med3_f32): floor(clamp(z, 0, S - 1/2)) == clamp(floor(z), 0, S - 1)
-          ox[k] = lds_off[cvt_flr(__builtin_amdgcn_fmed3f(zx, 0.f, lim))];
-          oy[k] = lds_off[S + cvt_flr(__builtin_amdgcn_fmed3f(zy, 0.f, lim))];
-          oz[k] = lds_off[2 * S + cvt_flr(__builtin_amdgcn_fmed3f(zz, 0.f, lim))];
+          if (CLAMP) {
+            // clamp in float (one v_med3_f32): floor(clamp(z, 0, TS - 1/2)) == clamp(floor(z), 0, TS - 1)
+            ox[k] = lds_off[cvt_flr(__builtin_amdgcn_fmed3f(zx, 0.f, lim))];
+            oy[k] = lds_off[TS + cvt_flr(__builtin_amdgcn_fmed3f(zy, 0.f, lim))];
+            oz[k] = lds_off[2 * TS + cvt_flr(__builtin_amdgcn_fmed3f(zz, 0.f, lim))];
+          } else {
+            ox[k] = lds_off[cvt_flr(zx)];
+            oy[k] = lds_off[TS + cvt_flr(zy)];
+            oz[k] = lds_off[2 * TS + cvt_flr(zz)];
+          }
         }
         float m = lo[0], M = hi[0];
 #pragma unroll
@@ -302,9 +328,9 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
 #pragma unroll
           for (int k = 0; k < P; ++k) {
             if (lo[k] <= band || hi[k] >= 1.f - band) {
-              ox[k] = lds_off[min(max(cell_of(rx[k] + t.x, g.resolution) + g.half + 1, 0), S - 1)];
-              oy[k] = lds_off[S + min(max(cell_of(ry[k] + t.y, g.resolution) + g.half + 1, 0), S - 1)];
-              oz[k] = lds_off[2 * S + min(max(cell_of(rz[k] + t.z, g.resolution) + g.half + 1, 0), S - 1)];
+              ox[k] = lds_off[min(max(cell_of(rx[k] + t.x, g.resolution) + to_table, 0), TS - 1)];
+              oy[k] = lds_off[TS + min(max(cell_of(ry[k] + t.y, g.resolution) + to_table, 0), TS - 1)];
+              oz[k] = lds_off[2 * TS + min(max(cell_of(rz[k] + t.z, g.resolution) + to_table, 0), TS - 1)];
             }
           }
         }
@@ -896,22 +922,54 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
       const int point_chunks = (n + chunk - 1) / chunk;
       processed = static_cast<int64_t>(point_chunks) * chunk;
       const dim3 block(bs);
-      const size_t lds2 = lds + static_cast<size_t>(g.dense_stride) * 12 + static_cast<size_t>(t_chunk) * bs * 4;
+      // Table domain: all real lookups lie within max ||p|| + max |translation component| of the origin.
+      DenseDomain dom;
+      dom.lo = 0;
+      dom.size = g.dense_stride;
+      dom.n_real = n;
+      dom.pad[0] = dom.pad[1] = dom.pad[2] = kPadCoordinate;
+      bool clamp = true;
+      {
+        float tmax = 0.f, t_init = norm3(c.init.t);
+        for (const F3& t : c.trans) tmax = std::max(tmax, std::max(std::fabs(t.x), std::max(std::fabs(t.y), std::fabs(t.z))));
+        const float res = g.resolution;
+        const double reach = (static_cast<double>(cloud.max_norm) + tmax) / res + 3.0;  // cells from the origin
+        // padding point: W = ((half + m) res, 0, 0) in the grid frame, mapped back through the initial
+        // pose; under a candidate it moves by at most theta_max |W - t_init| + (L + 1) res sqrt(3)
+        const double theta_max = 1.7321 * (c.w.angular_window_size + 1) * c.w.angular_step_size * 1.01 + 1e-4;
+        const double rho = (g.half + 64) * static_cast<double>(res) + t_init;
+        const double m_cells = 8.0 + std::ceil((theta_max * rho + (c.w.linear_window_size + 1) * res * 1.7321) / res);
+        const double hi_cell = std::max(reach, g.half + m_cells + 4.0);
+        const int lo_i = std::min(0, g.half + 1 - static_cast<int>(std::ceil(hi_cell)));
+        const int hi_i = std::max(g.dense_stride, g.half + 1 + static_cast<int>(std::ceil(hi_cell)) + 1);
+        static const int no_clamp = env_int("DLIOM_SCORE_NO_CLAMP", 1);
+        if (no_clamp && m_cells <= 64.0 && hi_i - lo_i <= 1024 && std::isfinite(reach)) {
+          clamp = false;
+          dom.lo = lo_i;
+          dom.size = hi_i - lo_i;
+          const F3 w{static_cast<float>((g.half + m_cells) * res) - c.init.t.x, -c.init.t.y, -c.init.t.z};
+          const QF qi{c.init.q.w, -c.init.q.x, -c.init.q.y, -c.init.q.z};
+          const F3 p = qrot(qi, w);
+          dom.pad[0] = p.x;
+          dom.pad[1] = p.y;
+          dom.pad[2] = p.z;
+        }
+      }
+      const size_t lds2 = lds + static_cast<size_t>(dom.size) * 12 + static_cast<size_t>(t_chunk) * bs * 4;
       const int chunks_per_xcd = (point_chunks + 7) / 8;
       const dim3 dense_grid(8 * chunks_per_xcd * rot_groups);
-      if (pts_per_iter == 8) {
-        hipLaunchKernelGGL((rtcsm_score_dense_kernel<8>), dense_grid, block, lds2, ctx->stream, g, cloud.d_xs,
-                           cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
-                           *d_sums);
-      } else if (pts_per_iter == 2) {
-        hipLaunchKernelGGL((rtcsm_score_dense_kernel<2>), dense_grid, block, lds2, ctx->stream, g, cloud.d_xs,
-                           cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
-                           *d_sums);
+#define DLIOM_LAUNCH_DENSE(PP, CL)                                                                                    \
+  hipLaunchKernelGGL((rtcsm_score_dense_kernel<PP, CL>), dense_grid, block, lds2, ctx->stream, g, dom, cloud.d_xs,     \
+                     cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, \
+                     t_chunk, *d_sums)
+      if (pts_per_iter == 2) {
+        if (clamp) DLIOM_LAUNCH_DENSE(2, true); else DLIOM_LAUNCH_DENSE(2, false);
+      } else if (pts_per_iter == 4) {
+        if (clamp) DLIOM_LAUNCH_DENSE(4, true); else DLIOM_LAUNCH_DENSE(4, false);
       } else {
-        hipLaunchKernelGGL((rtcsm_score_dense_kernel<4>), dense_grid, block, lds2, ctx->stream, g, cloud.d_xs,
-                           cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, t_chunk,
-                           *d_sums);
+        if (clamp) DLIOM_LAUNCH_DENSE(8, true); else DLIOM_LAUNCH_DENSE(8, false);
       }
+#undef DLIOM_LAUNCH_DENSE
     } else if (T == 1) {
       hipLaunchKernelGGL((rtcsm_score_rot_kernel<1, 4>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,
                          cloud.d_ys, cloud.d_zs, chunk, d->rot, R, r_first, r_last, d->trans4, T, *d_sums);
