@@ -939,7 +939,8 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
         const double theta_max = 1.7321 * (c.w.angular_window_size + 1) * c.w.angular_step_size * 1.01 + 1e-4;
         const double rho = (g.half + 64) * static_cast<double>(res) + t_init;
         const double m_cells = 8.0 + std::ceil((theta_max * rho + (c.w.linear_window_size + 1) * res * 1.7321) / res);
-        const double hi_cell = std::max(reach, g.half + m_cells + 4.0);
+        // the padding point itself may be carried up to (m - 8) cells outward as well
+        const double hi_cell = std::max(reach, g.half + 2.0 * m_cells);
         const int lo_i = std::min(0, g.half + 1 - static_cast<int>(std::ceil(hi_cell)));
         const int hi_i = std::max(g.dense_stride, g.half + 1 + static_cast<int>(std::ceil(hi_cell)) + 1);
         static const int no_clamp = env_int("DLIOM_SCORE_NO_CLAMP", 1);

@@ -867,3 +867,24 @@ def test_error_statuses_instead_of_aborts(dl, ctx):
     with pytest.raises(dl.DliomError):  # a return farther than the 8-bit DynamicGrid can hold (hybrid_grid.h:389)
         ins.Insert(np.zeros(3, np.float32), np.array([[1e4, 0, 0]], np.float32), g)
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed", [(1, 1), (9, 2), (63, 3), (130, 4), (1001, 5)])
+def test_rtcsm3d_score_volume_ragged_clouds_and_far_poses(dl, ctx, orc, n, seed):
+    """Score volumes for cloud sizes that leave padding in the last point group, under initial
+    poses with large rotations / translations and with points that fall outside the grid (the
+    clamp-free lookup tables and the padding point must reproduce 'outside reads 1' exactly)."""
+    from dliom import synth
+    rng = np.random.RandomState(seed)
+    og = build_oracle_submap(orc, 0.1, num_scans=3, beams=16, azimuths=128, max_range=20.0)
+    dg = to_device_grid(dl, ctx, og)
+    pts = rng.uniform(-22, 22, size=(n, 3)).astype(np.float32)
+    pts[::3] *= 1.6  # some points beyond the +-25.6 m extent once transformed
+    axis = rng.normal(size=3)
+    init = np.concatenate([rng.uniform(-12, 12, 3), synth.quat_from_axis_angle(axis, rng.uniform(0.5, 3.0))])
+    m = dl.RealTimeCorrelativeScanMatcher3D(ctx, dict(DEFAULT_RTCSM, angular_search_window=np.deg2rad(0.6)))
+    got = m.score_volume(init, pts, dg)
+    want = orc.rtcsm3d_value_sums(dict(DEFAULT_RTCSM, angular_search_window=np.deg2rad(0.6)), init, pts, og)
+    assert np.array_equal(got, want)
+    dg.close()
