@@ -288,6 +288,19 @@ def cpu_baseline(args, dl, sc, g_hi, g_lo, ins, C, n_pts):
         done += cnt
     t_rtcsm_sample = time.perf_counter() - t
     t_rtcsm = t_rtcsm_sample / done * C
+    # the same sample with the candidate loop spread over 8 host threads (what an OpenMP-over-candidates
+    # build of the reference could reach; the reference itself runs this loop on one thread)
+    threads = min(8, os.cpu_count() or 1)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(k):
+        first = (C // chunks) * k
+        orc.rtcsm3d_match_range(RTCSM_OPTS, init, pts, og_hi, first, min(per_chunk, C - first))
+
+    t = time.perf_counter()
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(one, range(chunks)))
+    t_rtcsm_mt = (time.perf_counter() - t) / done * C
     t = time.perf_counter()
     r = orc.csm3d_match(CSM_OPTS, init[:3], init, [(pts, og_hi), (pts, og_lo)])
     t_csm = time.perf_counter() - t
@@ -305,6 +318,8 @@ def cpu_baseline(args, dl, sc, g_hi, g_lo, ins, C, n_pts):
         "host_cores_available": os.cpu_count(),
         "seconds_per_scan": per_scan,
         "stage_seconds": {"rtcsm": t_rtcsm, "ceres": t_csm, "insert": t_ins},
+        "rtcsm_candidate_loop_on_%d_threads" % threads: {"seconds_per_scan": t_rtcsm_mt + t_csm + t_ins,
+                                                         "value": 1.0 / (t_rtcsm_mt + t_csm + t_ins)},
         "sample": "oracle (C++ restatement of the reference, g++ -O3, 1 thread) on the same %d-point scan and "
                   "grids: RTCSM3D candidate loop timed on %d of %d candidates in %d evenly spread chunks "
                   "(%.1f s) and scaled to C; CeresScanMatcher3D (%d evaluations) and both insertions timed "
