@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--xy", type=float, default=15.0)
     ap.add_argument("--z", type=float, default=8.0)
     ap.add_argument("--angle", type=float, default=45.0)
+    ap.add_argument("--full", action="store_true", help="MatchFullSubmap (window = whole submap, 360 deg)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
@@ -58,9 +59,10 @@ def main():
     times = []
     for _ in range(args.reps):
         t0 = time.perf_counter()
-        rd = dm.Match(node_pose, ident, data, 0.55)
+        rd = dm.MatchFullSubmap(node_pose[3:], ident[3:], data, 0.55) if args.full else dm.Match(node_pose, ident, data, 0.55)
         times.append(time.perf_counter() - t0)
-    out = {"workload": "FastCorrelativeScanMatcher3D::Match, 0.2 m submap of 10 scans, window %.0f m x %.0f m x %.0f deg, "
+    out = {"mode": "MatchFullSubmap" if args.full else "Match",
+           "workload": "FastCorrelativeScanMatcher3D::Match, 0.2 m submap of 10 scans, window %.0f m x %.0f m x %.0f deg, "
                        "depth 8 / full-resolution depth 3" % (args.xy, args.z, args.angle),
            "N_hi": len(hi_pts), "N_lo": len(lo_pts), "pyramid_build_ms": 1e3 * t_build,
            "device": {"match_ms_p50": 1e3 * float(np.median(times)), "found": rd["found"], "score": float(rd["score"]),
@@ -71,7 +73,7 @@ def main():
         om = orc.FastCorrelativeScanMatcher3D(og_hi, og_lo, np.array(hists), yaws, opts)
         t_build_cpu = time.perf_counter() - t0
         t0 = time.perf_counter()
-        ro = om.Match(node_pose, ident, data, 0.55)
+        ro = om.MatchFullSubmap(node_pose[3:], ident[3:], data, 0.55) if args.full else om.Match(node_pose, ident, data, 0.55)
         t_cpu = time.perf_counter() - t0
         same = ro["found"] == rd["found"] and (not ro["found"] or (np.float32(ro["score"]) == np.float32(rd["score"]) and
                                                                   np.array_equal(ro["pose"], rd["pose"])))
