@@ -233,12 +233,12 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_ms, "launches": int(score_n),
                 "note": "algorithmic bytes = 14 B x C x N; points are reused from registers and the "
                         "grid from L2/MALL, so frac > 1 is possible -- see DESIGN.md",
-                # what actually limits the kernel: one gather + ~25 VALU instructions per
+                # what actually limits the kernel: one gather + ~22.4 VALU instructions (PMC: SQ_INSTS_VALU / pair-rows) per
                 # (candidate, point) pair; VALU peak = 256 CU x 64 lanes x 2.4 GHz lane-instr/s
                 "issue_bound": {"bound": "valu", "unit": "pairs/s",
                                 "achieved": C * n_pts / (world if sharded_mode else 1) / (k_ms * 1e-3) if k_ms > 0 else 0.0,
-                                "peak": 256 * 64 * 2.4e9 / 25.0,
-                                "frac": (C * n_pts / (world if sharded_mode else 1) / (k_ms * 1e-3)) / (256 * 64 * 2.4e9 / 25.0) if k_ms > 0 else 0.0}},
+                                "peak": 256 * 64 * 2.4e9 / 22.4,
+                                "frac": (C * n_pts / (world if sharded_mode else 1) / (k_ms * 1e-3)) / (256 * 64 * 2.4e9 / 22.4) if k_ms > 0 else 0.0}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, dl, scans[0], g_hi, g_lo, ins, C, n_pts)
