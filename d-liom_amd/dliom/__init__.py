@@ -124,6 +124,16 @@ class FastCsmResult(C.Structure):
                 ("num_scored_candidates", C.c_int64), ("num_score_launches", C.c_int64)]
 
 
+class ImuNoise(C.Structure):
+    _fields_ = [("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double)]
+
+
+class ImuPreintegration(C.Structure):
+    _fields_ = [("sum_dt", C.c_double), ("delta_p", C.c_double * 3), ("delta_q", C.c_double * 4),
+                ("delta_v", C.c_double * 3), ("linearized_ba", C.c_double * 3), ("linearized_bg", C.c_double * 3),
+                ("jacobian", C.c_double * 225), ("covariance", C.c_double * 225)]
+
+
 class MatchResult(C.Structure):
     _fields_ = [("dropped", C.c_int), ("pose_estimate", C.c_double * 7),
                 ("pose_observation_in_submap", C.c_double * 7), ("initial_ceres_pose", C.c_double * 7),
@@ -211,6 +221,14 @@ SYMBOLS = [
     ("dliom_fast_csm_match_with_3dof_initial", C.c_int, [_vp, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
                                                          C.POINTER(FastCsmResult)]),
     ("dliom_fast_csm_level", C.c_int, [_vp, C.c_int, _i32p, _i32p, C.POINTER(C.c_uint8), C.c_int64]),
+    ("dliom_imu_integrator_create", C.c_int, [_f64p, _f64p, C.POINTER(ImuNoise), C.POINTER(_vp)]),
+    ("dliom_imu_integrator_destroy", C.c_int, [_vp]),
+    ("dliom_imu_integrator_reset", C.c_int, [_vp, _f64p, _f64p, C.POINTER(ImuNoise)]),
+    ("dliom_imu_integrator_push_back", C.c_int, [_vp, C.c_double, _f64p, _f64p]),
+    ("dliom_imu_integrator_repropagate", C.c_int, [_vp, _f64p, _f64p]),
+    ("dliom_imu_integrator_get", C.c_int, [_vp, C.POINTER(ImuPreintegration)]),
+    ("dliom_imu_integrator_evaluate", C.c_int, [_vp, _f64p, _f64p, _f64p, _f64p]),
+    ("dliom_imu_integrator_predict", C.c_int, [_vp, _f64p, _f64p, _f64p]),
     ("dliom_rotational_histogram", C.c_int, [_f32p, C.c_int64, C.c_int, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
@@ -1030,3 +1048,57 @@ def rotational_histogram(points, histogram_size):
     _check(load_library().dliom_rotational_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p)),
            "dliom_rotational_histogram")
     return out
+
+
+class ImuIntegrator:
+    """IMU preintegration between two scans (dliom_imu_integrator_*; host)."""
+
+    def __init__(self, ba, bg, noise):
+        self._L = load_library()
+        self._noise = ImuNoise(*[float(x) for x in noise])
+        h = _vp()
+        _check(self._L.dliom_imu_integrator_create(_p(_f64(ba), _f64p), _p(_f64(bg), _f64p), C.byref(self._noise),
+                                                   C.byref(h)), "dliom_imu_integrator_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_imu_integrator_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, ba, bg):
+        _check(self._L.dliom_imu_integrator_reset(self.h, _p(_f64(ba), _f64p), _p(_f64(bg), _f64p), C.byref(self._noise)),
+               "dliom_imu_integrator_reset")
+
+    def push_back(self, dt, acc, gyr):
+        _check(self._L.dliom_imu_integrator_push_back(self.h, float(dt), _p(_f64(acc), _f64p), _p(_f64(gyr), _f64p)),
+               "dliom_imu_integrator_push_back")
+
+    def repropagate(self, ba, bg):
+        _check(self._L.dliom_imu_integrator_repropagate(self.h, _p(_f64(ba), _f64p), _p(_f64(bg), _f64p)),
+               "dliom_imu_integrator_repropagate")
+
+    def get(self):
+        o = ImuPreintegration()
+        _check(self._L.dliom_imu_integrator_get(self.h, C.byref(o)), "dliom_imu_integrator_get")
+        return dict(sum_dt=o.sum_dt, delta_p=np.array(o.delta_p), delta_q=np.array(o.delta_q),
+                    delta_v=np.array(o.delta_v), jacobian=np.array(o.jacobian).reshape(15, 15),
+                    covariance=np.array(o.covariance).reshape(15, 15))
+
+    def evaluate(self, state_i, state_j, gravity):
+        r = np.zeros(15)
+        _check(self._L.dliom_imu_integrator_evaluate(self.h, _p(_f64(state_i), _f64p), _p(_f64(state_j), _f64p),
+                                                     _p(_f64(gravity), _f64p), _p(r, _f64p)), "dliom_imu_integrator_evaluate")
+        return r
+
+    def predict(self, state_i, gravity):
+        sj = np.zeros(16)
+        _check(self._L.dliom_imu_integrator_predict(self.h, _p(_f64(state_i), _f64p), _p(_f64(gravity), _f64p),
+                                                    _p(sj, _f64p)), "dliom_imu_integrator_predict")
+        return sj

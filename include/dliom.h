@@ -425,6 +425,40 @@ int dliom_fast_csm_level(const dliom_fast_csm* matcher, int depth, int32_t lo[3]
  * scan, local_trajectory_builder_3d.cc:605-610) on the host: histogram_size floats. */
 int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram);
 
+/* ---- IMU preintegration between scans (host; SURVEY 8f rank 4, PARITY UNPINNED) ------------------
+ * Mid-point preintegration with bias Jacobians and covariance as the reference's in-tree
+ * IntegrationBase (mapping/internal/3d/initialization/integration_base.h:106-278), plus the VINS-Mono
+ * residual it keeps commented out (:280-316) and the matching state prediction -- a self-contained
+ * stand-in for the gtsam::PreintegratedImuMeasurements calls of the steady-state path
+ * (local_trajectory_builder_3d.cc:179-199).  Blocks of jacobian / covariance (row-major 15 x 15):
+ * P 0, R 3, V 6, BA 9, BG 12.  States are [P(3), Q(w,x,y,z), V(3), Ba(3), Bg(3)]; gravity is the
+ * world-frame vector G of the residual (e.g. {0, 0, 9.80511}). */
+typedef struct dliom_imu_integrator dliom_imu_integrator;
+typedef struct dliom_imu_noise { double acc_n, gyr_n, acc_w, gyr_w; } dliom_imu_noise;
+typedef struct dliom_imu_preintegration {
+  double sum_dt;
+  double delta_p[3];
+  double delta_q[4];
+  double delta_v[3];
+  double linearized_ba[3];
+  double linearized_bg[3];
+  double jacobian[225];
+  double covariance[225];
+} dliom_imu_preintegration;
+int dliom_imu_integrator_create(const double ba[3], const double bg[3], const dliom_imu_noise* noise,
+                                dliom_imu_integrator** out);
+int dliom_imu_integrator_destroy(dliom_imu_integrator* integrator);
+int dliom_imu_integrator_reset(dliom_imu_integrator* integrator, const double ba[3], const double bg[3],
+                               const dliom_imu_noise* noise);
+int dliom_imu_integrator_push_back(dliom_imu_integrator* integrator, double dt, const double acc[3],
+                                   const double gyr[3]);
+int dliom_imu_integrator_repropagate(dliom_imu_integrator* integrator, const double ba[3], const double bg[3]);
+int dliom_imu_integrator_get(const dliom_imu_integrator* integrator, dliom_imu_preintegration* out);
+int dliom_imu_integrator_evaluate(const dliom_imu_integrator* integrator, const double state_i[16],
+                                  const double state_j[16], const double gravity[3], double residuals[15]);
+int dliom_imu_integrator_predict(const dliom_imu_integrator* integrator, const double state_i[16],
+                                 const double gravity[3], double state_j[16]);
+
 /* ---- RealTimeCorrelativeScanMatcher2D (BASELINE config 1: host only, by contract) -------------
  * double Match(initial_pose_estimate, point_cloud, probability_grid, pose_estimate)
  * (mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h:66-69, .cc:74-108).

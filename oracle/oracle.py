@@ -134,6 +134,12 @@ def _declare(L):
     sig("orc_rotational_match", None, _f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p)
     sig("orc_kat_precomputation_grid", C.c_double)
     sig("orc_kat_fast_csm", C.c_int, C.c_int, _f64p)
+    sig("orc_imu_new", vp, _f64p, _f64p, _f64p)
+    sig("orc_imu_free", None, vp)
+    sig("orc_imu_push_back", None, vp, C.c_double, _f64p, _f64p)
+    sig("orc_imu_repropagate", None, vp, _f64p, _f64p)
+    sig("orc_imu_get", None, vp, _f64p)
+    sig("orc_imu_evaluate", None, vp, _f64p, _f64p, _f64p, _f64p)
     sig("orc_now_seconds", C.c_double)
 
 
@@ -707,3 +713,34 @@ class FastCorrelativeScanMatcher3D:
                                       _p(lo, _f32p), len(lo), _p(hist, _f32p), len(hist), C.c_float(min_score),
                                       _p(pose, _f64p), _p(out, _f64p))
         return self._result(pose, out)
+
+
+# ------------------------------------------------------------------ IMU preintegration
+class IntegrationBase:
+    """mapping/internal/3d/initialization/integration_base.h restated (oracle/src/om_imu.h)."""
+
+    def __init__(self, ba, bg, noise):
+        self.h = lib().orc_imu_new(_p(_f64(ba), _f64p), _p(_f64(bg), _f64p), _p(_f64(noise), _f64p))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_imu_free(self.h)
+            self.h = None
+
+    def push_back(self, dt, acc, gyr):
+        lib().orc_imu_push_back(self.h, float(dt), _p(_f64(acc), _f64p), _p(_f64(gyr), _f64p))
+
+    def repropagate(self, ba, bg):
+        lib().orc_imu_repropagate(self.h, _p(_f64(ba), _f64p), _p(_f64(bg), _f64p))
+
+    def get(self):
+        o = np.zeros(461)
+        lib().orc_imu_get(self.h, _p(o, _f64p))
+        return dict(sum_dt=o[0], delta_p=o[1:4].copy(), delta_q=o[4:8].copy(), delta_v=o[8:11].copy(),
+                    jacobian=o[11:236].reshape(15, 15).copy(), covariance=o[236:461].reshape(15, 15).copy())
+
+    def evaluate(self, state_i, state_j, gravity):
+        r = np.zeros(15)
+        lib().orc_imu_evaluate(self.h, _p(_f64(state_i), _f64p), _p(_f64(state_j), _f64p), _p(_f64(gravity), _f64p),
+                               _p(r, _f64p))
+        return r

@@ -17,6 +17,7 @@
 #include "src/om_fast_csm3d.h"
 #include "src/om_front_end.h"
 #include "src/om_grid2d.h"
+#include "src/om_imu.h"
 #include "src/om_rtcsm3d.h"
 
 using namespace oracle;
@@ -731,6 +732,37 @@ int orc_kat_fast_csm(int mode, double* worst3) {
     if (r2.found) ++failures;
   }
   return failures;
+}
+
+// ---------------------------------------------------------------- IMU preintegration (integration_base.h)
+void* orc_imu_new(const double* ba3, const double* bg3, const double* noise4) {
+  return new IntegrationBase(Vec3d(ba3[0], ba3[1], ba3[2]), Vec3d(bg3[0], bg3[1], bg3[2]),
+                             ImuNoise{noise4[0], noise4[1], noise4[2], noise4[3]});
+}
+void orc_imu_free(void* m) { delete static_cast<IntegrationBase*>(m); }
+void orc_imu_push_back(void* m, double dt, const double* acc3, const double* gyr3) {
+  static_cast<IntegrationBase*>(m)->push_back(dt, Vec3d(acc3[0], acc3[1], acc3[2]), Vec3d(gyr3[0], gyr3[1], gyr3[2]));
+}
+void orc_imu_repropagate(void* m, const double* ba3, const double* bg3) {
+  static_cast<IntegrationBase*>(m)->repropagate(Vec3d(ba3[0], ba3[1], ba3[2]), Vec3d(bg3[0], bg3[1], bg3[2]));
+}
+// out: sum_dt, delta_p[3], delta_q[4] (w,x,y,z), delta_v[3], jacobian[225], covariance[225]
+void orc_imu_get(void* m, double* out461) {
+  const IntegrationBase& b = *static_cast<IntegrationBase*>(m);
+  double* o = out461;
+  *o++ = b.sum_dt;
+  *o++ = b.delta_p.x; *o++ = b.delta_p.y; *o++ = b.delta_p.z;
+  *o++ = b.delta_q.w; *o++ = b.delta_q.x; *o++ = b.delta_q.y; *o++ = b.delta_q.z;
+  *o++ = b.delta_v.x; *o++ = b.delta_v.y; *o++ = b.delta_v.z;
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) *o++ = b.jacobian[i][j];
+  for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) *o++ = b.covariance[i][j];
+}
+void orc_imu_evaluate(void* m, const double* si16, const double* sj16, const double* g3, double* residuals15) {
+  auto v = [](const double* p) { return Vec3d(p[0], p[1], p[2]); };
+  const std::array<double, 15> r = static_cast<IntegrationBase*>(m)->evaluate(
+      v(si16), Quatd(si16[3], si16[4], si16[5], si16[6]), v(si16 + 7), v(si16 + 10), v(si16 + 13), v(sj16),
+      Quatd(sj16[3], sj16[4], sj16[5], sj16[6]), v(sj16 + 7), v(sj16 + 10), v(sj16 + 13), v(g3));
+  std::memcpy(residuals15, r.data(), sizeof(double) * 15);
 }
 
 double orc_now_seconds() {

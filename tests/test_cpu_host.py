@@ -151,3 +151,65 @@ def test_rotational_histogram_equals_oracle(orc):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert got.sum() > 0
     assert np.array_equal(dl.rotational_histogram(np.zeros((0, 3), np.float32), 8), np.zeros(8, np.float32))
+
+
+def _imu_stream(seed, n=40, dt=0.005):
+    rng = np.random.RandomState(seed)
+    acc = np.array([0.3, -0.2, 9.7]) + 0.5 * rng.normal(size=(n, 3))
+    gyr = np.array([0.05, -0.1, 0.3]) + 0.2 * rng.normal(size=(n, 3))
+    return dt, acc, gyr
+
+
+def test_imu_preintegration_equals_oracle(orc):
+    """IntegrationBase (integration_base.h) in the product vs the oracle's independent restatement:
+    deltas, bias Jacobian, covariance, repropagation and the residual, bit for bit."""
+    import dliom as dl
+    noise = [0.08, 0.004, 4e-5, 2e-6]
+    ba, bg = [0.02, -0.01, 0.03], [1e-3, -2e-3, 5e-4]
+    dt, acc, gyr = _imu_stream(1)
+    a, b = dl.ImuIntegrator(ba, bg, noise), orc.IntegrationBase(ba, bg, noise)
+    for k in range(len(acc)):
+        a.push_back(dt, acc[k], gyr[k])
+        b.push_back(dt, acc[k], gyr[k])
+    for stage in range(2):
+        ga, gb = a.get(), b.get()
+        assert ga["sum_dt"] == gb["sum_dt"] and abs(ga["sum_dt"] - dt * (len(acc) - 1)) < 1e-12
+        for key in ("delta_p", "delta_q", "delta_v", "jacobian", "covariance"):
+            assert np.array_equal(ga[key], gb[key]), key
+        ba2, bg2 = [0.025, -0.012, 0.028], [1.5e-3, -1e-3, 7e-4]
+        a.repropagate(ba2, bg2)
+        b.repropagate(ba2, bg2)
+    si = np.concatenate([[1, 2, 3], [0.9, 0.1, -0.2, 0.3] / np.linalg.norm([0.9, 0.1, -0.2, 0.3]), [0.5, -0.4, 0.1], ba, bg])
+    sj = np.concatenate([[1.1, 1.9, 3.05], [0.88, 0.12, -0.22, 0.32] / np.linalg.norm([0.88, 0.12, -0.22, 0.32]),
+                         [0.45, -0.35, 0.12], ba, bg])
+    g = [0, 0, 9.80511]
+    assert np.array_equal(a.evaluate(si, sj, g), b.evaluate(si, sj, g))
+    a.close()
+
+
+def test_imu_preintegration_against_closed_form_motion():
+    """Constant body-frame rate about z and constant world acceleration: the predicted state matches the
+    analytic one (mid-point rule, 200 Hz), and the residual of (state_i, predicted state_j) vanishes."""
+    import dliom as dl
+    g = np.array([0, 0, 9.80511])
+    w = np.array([0.0, 0.0, 0.4])
+    a_world = np.array([0.3, -0.1, 0.05])
+    dt, n = 0.005, 21  # 0.1 s
+    integ = dl.ImuIntegrator([0, 0, 0], [0, 0, 0], [0.08, 0.004, 4e-5, 2e-6])
+    for k in range(n):
+        yaw = w[2] * k * dt
+        R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+        integ.push_back(dt, R.T @ (a_world + g), w)  # specific force in the body frame
+    T = dt * (n - 1)
+    si = np.concatenate([[1, -2, 0.5], [1, 0, 0, 0], [0.7, 0.2, -0.1], np.zeros(6)])
+    sj = integ.predict(si, g)
+    p_true = si[:3] + si[7:10] * T + 0.5 * a_world * T * T
+    v_true = si[7:10] + a_world * T
+    assert np.abs(sj[:3] - p_true).max() < 2e-6
+    assert np.abs(sj[7:10] - v_true).max() < 5e-5
+    assert abs(2 * np.arctan2(sj[6], sj[3]) - w[2] * T) < 1e-7  # first-order quaternion increments
+    r = integ.evaluate(si, sj, g)
+    assert np.abs(r).max() < 1e-12
+    cov = integ.get()["covariance"]
+    assert np.allclose(cov, cov.T, atol=1e-18) and (np.diag(cov)[:9] > 0).all()
+    integ.close()
