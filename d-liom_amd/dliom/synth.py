@@ -133,3 +133,70 @@ def perturb_pose(pose, max_translation, max_angle_deg, seed=13):
 def range_filter(pts, max_range):
     r = np.linalg.norm(pts.astype(np.float64), axis=1)
     return pts[r <= max_range]
+
+
+# ---------------------------------------------------------------- motion-distorted scans + IMU (config 3)
+AXIS = np.array([1.0, -1.0, 2.0]) / np.sqrt(6.0)
+GRAVITY = np.array([0.0, 0.0, 9.80511])  # trajectory_builder_3d.lua:92; the IMU measures R^T (a + G)
+
+
+def trajectory_velocity(t):
+    return np.array([4.0 * np.cos(4.0 * t), 4.0 * np.sin(4.0 * t), 1.0])
+
+
+def trajectory_state(t):
+    """[P(3), Q(4), V(3), Ba(3), Bg(3)] of the corkscrew at time t."""
+    pose = trajectory_pose(t)
+    return np.concatenate([pose, trajectory_velocity(t), np.zeros(6)])
+
+
+def imu_samples(t0, t1, rate=200.0, noise=None, seed=11):
+    """Specific force R^T (a + G) and body rate at t0, t0 + 1/rate, ..., t1 (inclusive)."""
+    n = int(round((t1 - t0) * rate)) + 1
+    ts = t0 + np.arange(n) / rate
+    acc_w = np.stack([-16.0 * np.sin(4.0 * ts), 16.0 * np.cos(4.0 * ts), np.zeros(n)], axis=1) + GRAVITY
+    acc = np.stack([quat_to_matrix(quat_from_axis_angle(AXIS, 0.3 * t)).T @ a for t, a in zip(ts, acc_w)])
+    gyr = np.tile(0.3 * AXIS, (n, 1))  # rotation about a fixed axis: body rate == world rate
+    if noise is not None:
+        rng = np.random.RandomState(seed)
+        acc = acc + noise[0] * rng.normal(size=acc.shape)
+        gyr = gyr + noise[1] * rng.normal(size=gyr.shape)
+    return 1.0 / rate, acc, gyr
+
+
+def cast_many(origins, dirs, centers=None):
+    """cast() with one origin per ray."""
+    if centers is None:
+        centers = bubbles()
+    o = np.asarray(origins, dtype=np.float64)
+    d = np.asarray(dirs, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_pos = (CUBE_HALF - o) / d
+        t_neg = (-CUBE_HALF - o) / d
+    best = np.where(d > 0, t_pos, np.where(d < 0, t_neg, np.inf)).min(axis=1)
+    for c in centers:
+        oc = o - c
+        bq = (d * oc).sum(axis=1)
+        cq = (oc * oc).sum(axis=1) - BUBBLE_RADIUS ** 2
+        disc = bq * bq - cq
+        hit = disc > 0
+        t = np.where(hit, -bq - np.sqrt(np.where(hit, disc, 0.0)), np.inf)
+        t = np.where(t > 1e-9, t, np.inf)
+        best = np.minimum(best, t)
+    return best
+
+
+def moving_scan(t_end, num_beams=64, num_azimuths=1024, centers=None):
+    """A scan swept while the sensor flies the corkscrew: point k is measured at t_end + rel_t[k] in the
+    sensor frame OF THAT INSTANT.  Returns float32 [x, y, z, rel_t] rows."""
+    dirs_s, rel_t = beam_directions(num_beams, num_azimuths)
+    ts = t_end + rel_t
+    pos = np.stack([np.sin(4.0 * ts), 1.0 - np.cos(4.0 * ts), ts], axis=1)
+    ang = 0.3 * ts
+    K = np.array([[0, -AXIS[2], AXIS[1]], [AXIS[2], 0, -AXIS[0]], [-AXIS[1], AXIS[0], 0]])
+    # Rodrigues: R d = d + sin(a) K d + (1 - cos a) K K d
+    Kd = dirs_s @ K.T
+    KKd = Kd @ K.T
+    dirs_w = dirs_s + np.sin(ang)[:, None] * Kd + (1.0 - np.cos(ang))[:, None] * KKd
+    rng_ = cast_many(pos, dirs_w, centers)
+    return np.concatenate([dirs_s * rng_[:, None], rel_t[:, None]], axis=1).astype(np.float32)
