@@ -455,6 +455,7 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   ctx->partials.release();
   ctx->misc.release();
   ctx->sort_tmp.release();
+  ctx->voxel.release();
   if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
