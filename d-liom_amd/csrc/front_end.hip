@@ -114,6 +114,9 @@ struct dliom_front_end {
     // submap_3d.cc:316-326
     if (submaps.size() > 1) {
       submaps.front()->finished = true;
+      // a finished submap is never matched by the online matcher again: give its dense mirror back
+      // (272 MB at 10 cm / +-25.6 m); the leaf pool stays for the back end
+      if (submaps.front()->hi != nullptr) submaps.front()->hi->drop_dense();
       ++matching_submap_index;
       retired.push_back(std::move(submaps.front()));
       submaps.erase(submaps.begin());
