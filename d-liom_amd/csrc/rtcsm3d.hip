@@ -904,7 +904,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
     const size_t lds = static_cast<size_t>(T) * 16;
     if (lds > 100 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;
     if (mapping == 2) {
-      const int t_chunk = std::min(T, 27);
+
       // block size: whole wavefronts, the fewest idle lanes in the last rotation group
       static const int forced_bs = env_int("DLIOM_SCORE_BLOCK", 0);
       static const int max_bs = env_int("DLIOM_SCORE_MAX_BLOCK", kDenseMaxBlock);
@@ -956,7 +956,13 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
           dom.pad[2] = p.z;
         }
       }
-      const size_t lds2 = lds + static_cast<size_t>(dom.size) * 12 + static_cast<size_t>(t_chunk) * bs * 4;
+      // translations per pass over the points: as many as keep >= 4 workgroups per CU in LDS (160 KB);
+      // large windows / big grids trade a few extra point rotations for occupancy
+      static const int t_chunk_max = env_int("DLIOM_SCORE_TCHUNK", 27);
+      const size_t fixed_lds = lds + static_cast<size_t>(dom.size) * 12;
+      const size_t acc_budget = fixed_lds < 34 * 1024 ? 36 * 1024 - fixed_lds : 2 * 1024;
+      const int t_chunk = std::max(4, std::min(std::min(T, t_chunk_max), static_cast<int>(acc_budget / (static_cast<size_t>(bs) * 4))));
+      const size_t lds2 = fixed_lds + static_cast<size_t>(t_chunk) * bs * 4;
       const int chunks_per_xcd = (point_chunks + 7) / 8;
       const dim3 dense_grid(8 * chunks_per_xcd * rot_groups);
 #define DLIOM_LAUNCH_DENSE(PP, CL)                                                                                    \
