@@ -30,6 +30,7 @@
 #include "device_common.h"
 #include "host_math.h"
 #include "internal.h"
+#include "rotational.h"
 
 namespace dliom {
 
@@ -147,58 +148,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(ScoreArgs a, cons
   if (threadIdx.x == 0) atomicAdd(&sums[c], static_cast<int>(wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3]));
 }
 
-// ---- host side: rotational scan matcher (rotational_scan_matcher.cc) -----------------------------
+// ---- host side ---------------------------------------------------------------------------------
+// rotate_histogram / match_histograms live in rotational_histogram.cc (host-only, CPU-testable).
 using Histogram = std::vector<float>;
-
-// Eigen 3.3 vectorised redux over an aligned dynamic float vector (SSE2 packets of 4, two
-// accumulators, (a0+a2)+(a1+a3), scalar tail): VectorXf::squaredNorm() / dot().
-template <typename Term>
-static float eigen_dyn_redux(int size, Term term) {
-  const int ps = 4;
-  const int end2 = (size / (2 * ps)) * (2 * ps), end1 = (size / ps) * ps;
-  if (end1 == 0) {
-    float r = term(0);
-    for (int i = 1; i < size; ++i) r = r + term(i);
-    return r;
-  }
-  float a[4], b[4];
-  for (int l = 0; l < 4; ++l) a[l] = term(l);
-  if (end1 > ps) {
-    for (int l = 0; l < 4; ++l) b[l] = term(ps + l);
-    for (int i = 2 * ps; i < end2; i += 2 * ps)
-      for (int l = 0; l < 4; ++l) {
-        a[l] = a[l] + term(i + l);
-        b[l] = b[l] + term(i + ps + l);
-      }
-    for (int l = 0; l < 4; ++l) a[l] = a[l] + b[l];
-    if (end1 > end2)
-      for (int l = 0; l < 4; ++l) a[l] = a[l] + term(end2 + l);
-  }
-  float r = (a[0] + a[2]) + (a[1] + a[3]);
-  for (int i = end1; i < size; ++i) r = r + term(i);
-  return r;
-}
-
-static Histogram rotate_histogram(const Histogram& h, float angle) {  // :125-144
-  const int n = static_cast<int>(h.size());
-  const float rotate_by_buckets = static_cast<float>(-angle * static_cast<float>(n) / M_PI);
-  int full_buckets = static_cast<int>(std::lround(rotate_by_buckets - 0.5f));
-  const float fraction = rotate_by_buckets - static_cast<float>(full_buckets);
-  while (full_buckets < 0) full_buckets += n;
-  Histogram out(n);
-  for (int i = 0; i != n; ++i)
-    out[i] = fraction * h[(i + 1 + full_buckets) % n] + (1.f - fraction) * h[(i + full_buckets) % n];
-  return out;
-}
-
-static float match_histograms(const Histogram& submap, const Histogram& scan) {  // :146-157
-  const int n = static_cast<int>(scan.size());
-  const float scan_norm = std::sqrt(eigen_dyn_redux(n, [&](int i) { return scan[i] * scan[i]; }));
-  const float submap_norm = std::sqrt(eigen_dyn_redux(n, [&](int i) { return submap[i] * submap[i]; }));
-  const float normalization = scan_norm * submap_norm;
-  if (normalization < 1e-3f) return 1.f;
-  return eigen_dyn_redux(n, [&](int i) { return submap[i] * scan[i]; }) / normalization;
-}
 
 static QF quat_inverse(const QF& q) {  // Eigen QuaternionBase::inverse()
   const float n2 = (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w);

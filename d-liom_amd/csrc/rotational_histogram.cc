@@ -9,6 +9,63 @@
 #include <vector>
 
 #include "../../include/dliom.h"
+#include "rotational.h"
+
+namespace dliom {
+
+
+// Eigen 3.3 vectorised redux over an aligned dynamic float vector (SSE2 packets of 4, two
+// accumulators, (a0+a2)+(a1+a3), scalar tail): VectorXf::squaredNorm() / dot().
+template <typename Term>
+static float eigen_dyn_redux(int size, Term term) {
+  const int ps = 4;
+  const int end2 = (size / (2 * ps)) * (2 * ps), end1 = (size / ps) * ps;
+  if (end1 == 0) {
+    float r = term(0);
+    for (int i = 1; i < size; ++i) r = r + term(i);
+    return r;
+  }
+  float a[4], b[4];
+  for (int l = 0; l < 4; ++l) a[l] = term(l);
+  if (end1 > ps) {
+    for (int l = 0; l < 4; ++l) b[l] = term(ps + l);
+    for (int i = 2 * ps; i < end2; i += 2 * ps)
+      for (int l = 0; l < 4; ++l) {
+        a[l] = a[l] + term(i + l);
+        b[l] = b[l] + term(i + ps + l);
+      }
+    for (int l = 0; l < 4; ++l) a[l] = a[l] + b[l];
+    if (end1 > end2)
+      for (int l = 0; l < 4; ++l) a[l] = a[l] + term(end2 + l);
+  }
+  float r = (a[0] + a[2]) + (a[1] + a[3]);
+  for (int i = end1; i < size; ++i) r = r + term(i);
+  return r;
+}
+
+std::vector<float> rotate_histogram(const std::vector<float>& h, float angle) {  // :125-144
+  const int n = static_cast<int>(h.size());
+  const float rotate_by_buckets = static_cast<float>(-angle * static_cast<float>(n) / M_PI);
+  int full_buckets = static_cast<int>(std::lround(rotate_by_buckets - 0.5f));
+  const float fraction = rotate_by_buckets - static_cast<float>(full_buckets);
+  while (full_buckets < 0) full_buckets += n;
+  std::vector<float> out(n);
+  for (int i = 0; i != n; ++i)
+    out[i] = fraction * h[(i + 1 + full_buckets) % n] + (1.f - fraction) * h[(i + full_buckets) % n];
+  return out;
+}
+
+float match_histograms(const std::vector<float>& submap, const std::vector<float>& scan) {  // :146-157
+  const int n = static_cast<int>(scan.size());
+  const float scan_norm = std::sqrt(eigen_dyn_redux(n, [&](int i) { return scan[i] * scan[i]; }));
+  const float submap_norm = std::sqrt(eigen_dyn_redux(n, [&](int i) { return submap[i] * submap[i]; }));
+  const float normalization = scan_norm * submap_norm;
+  if (normalization < 1e-3f) return 1.f;
+  return eigen_dyn_redux(n, [&](int i) { return submap[i] * scan[i]; }) / normalization;
+}
+
+
+}  // namespace dliom
 
 namespace {
 
@@ -94,5 +151,27 @@ extern "C" int dliom_rotational_histogram(const float* points_xyz, int64_t n, in
     slices[static_cast<int>(std::lround(p.z / kSliceHeight))].push_back(p);
   }
   for (const auto& s : slices) add_slice(sort_slice(s.second), histogram, histogram_size);
+  return DLIOM_OK;
+}
+
+// RotationalScanMatcher(histograms_at_angles).Match(histogram, initial_angle, angles)
+// (rotational_scan_matcher.cc:174-194): the submap histogram is the sum of the node histograms
+// rotated by their yaws; one score per angle.
+extern "C" int dliom_rotational_scan_match(const float* node_histograms, const float* node_angles, int num_nodes,
+                                           int histogram_size, const float* scan_histogram, float initial_angle,
+                                           const float* angles, int num_angles, float* scores) {
+  if (node_histograms == nullptr || node_angles == nullptr || num_nodes <= 0 || histogram_size <= 0 ||
+      scan_histogram == nullptr || num_angles < 0 || (num_angles > 0 && (angles == nullptr || scores == nullptr)))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  std::vector<float> submap(histogram_size, 0.f);
+  for (int k = 0; k < num_nodes; ++k) {
+    const std::vector<float> h(node_histograms + static_cast<size_t>(k) * histogram_size,
+                               node_histograms + static_cast<size_t>(k + 1) * histogram_size);
+    const std::vector<float> r = dliom::rotate_histogram(h, node_angles[k]);
+    for (int i = 0; i < histogram_size; ++i) submap[i] += r[i];
+  }
+  const std::vector<float> scan(scan_histogram, scan_histogram + histogram_size);
+  for (int i = 0; i < num_angles; ++i)
+    scores[i] = dliom::match_histograms(submap, dliom::rotate_histogram(scan, initial_angle + angles[i]));
   return DLIOM_OK;
 }

@@ -230,6 +230,7 @@ SYMBOLS = [
     ("dliom_imu_integrator_evaluate", C.c_int, [_vp, _f64p, _f64p, _f64p, _f64p]),
     ("dliom_imu_integrator_predict", C.c_int, [_vp, _f64p, _f64p, _f64p]),
     ("dliom_rotational_histogram", C.c_int, [_f32p, C.c_int64, C.c_int, _f32p]),
+    ("dliom_rotational_scan_match", C.c_int, [_f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
     ("dliom_probe_transform_cell_indices", C.c_int, [_vp, _f32p, _f32p, C.c_int64, C.c_float, _i32p]),
@@ -1102,3 +1103,14 @@ class ImuIntegrator:
         _check(self._L.dliom_imu_integrator_predict(self.h, _p(_f64(state_i), _f64p), _p(_f64(gravity), _f64p),
                                                     _p(sj, _f64p)), "dliom_imu_integrator_predict")
         return sj
+
+
+def rotational_scan_match(node_histograms, node_angles, scan_histogram, initial_angle, angles):
+    """RotationalScanMatcher(nodes).Match(histogram, initial_angle, angles) (host)."""
+    h = _f32(node_histograms).reshape(len(node_angles), -1)
+    a = _f32(angles)
+    out = np.zeros(len(a), dtype=np.float32)
+    _check(load_library().dliom_rotational_scan_match(_p(h, _f32p), _p(_f32(node_angles), _f32p), h.shape[0], h.shape[1],
+                                                      _p(_f32(scan_histogram), _f32p), C.c_float(initial_angle),
+                                                      _p(a, _f32p), len(a), _p(out, _f32p)), "dliom_rotational_scan_match")
+    return out

@@ -424,6 +424,12 @@ int dliom_fast_csm_level(const dliom_fast_csm* matcher, int depth, int32_t lo[3]
 /* RotationalScanMatcher::ComputeHistogram (rotational_scan_matcher.cc:159-170; called per inserted
  * scan, local_trajectory_builder_3d.cc:605-610) on the host: histogram_size floats. */
 int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram);
+/* RotationalScanMatcher(histograms_at_angles).Match(histogram, initial_angle, angles)
+ * (rotational_scan_matcher.cc:174-194), host: one score per angle.  The loop-closure matcher calls
+ * the same code to pick the yaw candidates worth discretising. */
+int dliom_rotational_scan_match(const float* node_histograms, const float* node_angles, int num_nodes,
+                                int histogram_size, const float* scan_histogram, float initial_angle,
+                                const float* angles, int num_angles, float* scores);
 
 /* ---- IMU preintegration between scans (host; SURVEY 8f rank 4, PARITY UNPINNED) ------------------
  * Mid-point preintegration with bias Jacobians and covariance as the reference's in-tree

@@ -213,3 +213,27 @@ def test_imu_preintegration_against_closed_form_motion():
     cov = integ.get()["covariance"]
     assert np.allclose(cov, cov.T, atol=1e-18) and (np.diag(cov)[:9] > 0).all()
     integ.close()
+
+
+def test_rotational_scan_match_equals_oracle(orc):
+    """RotationalScanMatcher ctor + Match (histogram rotation, normalised dot product with Eigen's
+    packet reduction order) -- host code on both sides, bit-identical scores."""
+    import dliom as dl
+    from dliom import synth
+    for size in (10, 30, 120, 7):
+        hists, yaws = [], []
+        for k in range(4):
+            pose = synth.trajectory_pose(0.1 * k)
+            pts, _ = synth.scan(pose, 16, 256)
+            hists.append(orc.compute_histogram(pts, size))
+            yaws.append(0.05 * k - 0.1)
+        scan_pts, _ = synth.scan(synth.trajectory_pose(0.45), 16, 256)
+        scan_hist = orc.compute_histogram(scan_pts, size)
+        angles = np.linspace(-0.8, 0.8, 41).astype(np.float32)
+        got = dl.rotational_scan_match(np.array(hists), yaws, scan_hist, 0.123, angles)
+        want = orc.rotational_match(np.array(hists), yaws, scan_hist, 0.123, angles)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), size
+        assert got.max() <= 1.0 + 1e-6 and got.max() > 0.5
+    # all-zero histograms: MatchHistograms returns 1 (normalisation < 1e-3)
+    z = np.zeros((1, 10), np.float32)
+    assert np.array_equal(dl.rotational_scan_match(z, [0.0], z[0], 0.0, [0.0, 0.1]), np.ones(2, np.float32))
