@@ -885,7 +885,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   const GridView g = grid->view();
   DLIOM_TRY(ensure_morton(ctx, &cloud));
   static const int forced_ppt = env_int("DLIOM_SCORE_PPT", 0);   // tuning knobs
-  static const int target_blocks = env_int("DLIOM_SCORE_BLOCKS", 4096);
+  static const int target_blocks = env_int("DLIOM_SCORE_BLOCKS", 8192);
   const int Rs = r_last - r_first;  // rotations of this shard
   int span = -1;
   int64_t processed = 0;
