@@ -555,11 +555,11 @@ __global__ void rtcsm_rescore_values_kernel(GridView g, const float* __restrict_
                                             int n, int n_stride, const float4* __restrict__ rot, int R,
                                             const float* __restrict__ trans, const unsigned* __restrict__ list,
                                             const unsigned* __restrict__ count,
-                                            unsigned short* __restrict__ values) {
+                                            unsigned short* __restrict__ values, float k_scale, float k_offset,
+                                            float k_unknown, double* __restrict__ chunk_sums, int num_chunks) {
   // launched for an upper bound of survivors when the host has not read the count yet
   if (count != nullptr && blockIdx.y >= *count) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_stride) return;
   unsigned short v = 0;
   if (i < n) {
     const unsigned c = list[blockIdx.y];
@@ -573,7 +573,18 @@ __global__ void rtcsm_rescore_values_kernel(GridView g, const float* __restrict_
                                                cell_of(ry + trans[3 * j + 1], g.resolution),
                                                cell_of(rz + trans[3 * j + 2], g.resolution)) & 0x7FFFu);
   }
-  values[static_cast<size_t>(blockIdx.y) * n_stride + i] = v;
+  if (i < n_stride) values[static_cast<size_t>(blockIdx.y) * n_stride + i] = v;
+  if (chunk_sums != nullptr) {
+    // real (double) sum of the probabilities of this wavefront's 64-point chunk: locates the binade
+    // of the running sum for rtcsm_rescore_chunk_fns_kernel
+    double p = 0.;
+    if (i < n) p = v == 0 ? static_cast<double>(k_unknown)
+                          : static_cast<double>(static_cast<float>(static_cast<int>(v)) * k_scale + k_offset);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+    const int chunk = i >> 6;
+    if ((threadIdx.x & 63) == 0 && chunk < num_chunks) chunk_sums[static_cast<size_t>(blockIdx.y) * num_chunks + chunk] = p;
+  }
 }
 
 __global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_scan_kernel(
@@ -698,6 +709,223 @@ __global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_scan_kernel(
         sh_m = static_cast<unsigned>(q2 + up);
         sh_e = e2;
         sh_i0 = sh_cross + 1u;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) sums[blockIdx.x] = __uint_as_float(((sh_e + 123u) << 23) | (sh_m & 0x7FFFFFu));
+}
+
+// ---- chunked variant of the exact scan (method 2) -----------------------------------------------
+// The element scan above spends its time in one CU walking 64 elements per thread twice per
+// binade.  Here the composition of every aligned 64-point chunk is computed ONCE, in parallel over
+// the whole chip: the real (double) prefix sum tells, within a proven error bound, which binade(s)
+// the reference's running float sum can be in while it crosses the chunk -- at most two -- and the
+// chunk's ParityFn is stored for each.  The scan then works on chunk functions (one per thread) and
+// only opens the two chunks that matter per binade: the one it resumes in and the one the sum
+// leaves the binade in (both handled by a wavefront, lane per element).
+constexpr int kChunk = 64;
+struct ChunkFns {  // the chunk's ParityFn for up to two binades; e == 0xFFFFFFFF: absent
+  unsigned e0, s00, s01, pp0;  // pp = p0 | p1 << 1
+  unsigned e1, s10, s11, pp1;
+};
+
+__device__ __forceinline__ ParityFn element_fn(unsigned a, unsigned e) {
+  const unsigned U = 1u << e, half = U >> 1, fmask = U - 1u;
+  const unsigned q = a >> e, fr = a & fmask;
+  if (e != 0u && fr == half) return ParityFn{q + (q & 1u), q + ((1u + q) & 1u), 0u, 0u};  // tie -> even
+  const unsigned c = q + (fr > half ? 1u : 0u);
+  return ParityFn{c, c, c & 1u, (1u + c) & 1u};
+}
+__device__ __forceinline__ ParityFn wave_inclusive_scan(ParityFn f, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const ParityFn o = shfl_up_fn(f, off);
+    if (lane >= off) f = compose(o, f);
+  }
+  return f;
+}
+__device__ __forceinline__ unsigned fixed_of_value(unsigned v, float k_scale, float k_offset, float k_unknown) {
+  const float p = v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset;
+  const unsigned b = __float_as_uint(p);
+  return ((b & 0x7FFFFFu) | 0x800000u) << ((b >> 23) - 123u);
+}
+// binade index e (ulp = 2^(e-27)) of a positive real sum: floor(log2 x) + 4, never below 0
+__device__ __forceinline__ int binade_of(double x) { return max(ilogb(fmax(x, 0.0625)) + 4, 0); }
+
+__global__ __launch_bounds__(256) void rtcsm_rescore_chunk_fns_kernel(
+    const unsigned short* __restrict__ values, int n, int n_stride, float k_scale, float k_offset, float k_unknown,
+    const unsigned* __restrict__ count, const double* __restrict__ chunk_sums, int num_chunks,
+    ChunkFns* __restrict__ fns) {
+  if (count != nullptr && blockIdx.y >= *count) return;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= num_chunks) return;
+  const double* sums = chunk_sums + static_cast<size_t>(blockIdx.y) * num_chunks;
+  double before = 0.;
+  for (int k = lane; k < c; k += 64) before += sums[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+  const double after = before + sums[c];
+  const int i = c * kChunk + lane;
+  const int i_end = min(n, (c + 1) * kChunk);
+  // |sequential float sum - real sum| <= sum_i 2^-24 s_i <= i 2^-24 s_i (partial sums are monotone)
+  const double delta = 1.05 * static_cast<double>(i_end) * 5.9604644775390625e-8 * after + 1e-6;
+  const int e_lo = binade_of(before - delta), e_hi = binade_of(after + delta);
+  ChunkFns out{0xFFFFFFFFu, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u};
+  if (e_hi - e_lo <= 1) {
+    const unsigned a = i < n ? fixed_of_value(values[static_cast<size_t>(blockIdx.y) * n_stride + i], k_scale, k_offset, k_unknown) : 0u;
+    const ParityFn id{0u, 0u, 0u, 1u};
+    const ParityFn t0 = wave_inclusive_scan(i < n ? element_fn(a, static_cast<unsigned>(e_lo)) : id, lane);
+    out.e0 = static_cast<unsigned>(e_lo);
+    out.s00 = t0.s0;
+    out.s01 = t0.s1;
+    out.pp0 = t0.p0 | (t0.p1 << 1);
+    if (e_hi != e_lo) {
+      const ParityFn t1 = wave_inclusive_scan(i < n ? element_fn(a, static_cast<unsigned>(e_hi)) : id, lane);
+      out.e1 = static_cast<unsigned>(e_hi);
+      out.s10 = t1.s0;
+      out.s11 = t1.s1;
+      out.pp1 = t1.p0 | (t1.p1 << 1);
+    }
+  }
+  if (lane == 63) fns[static_cast<size_t>(blockIdx.y) * num_chunks + c] = out;
+}
+
+__global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_chunk_scan_kernel(
+    const unsigned short* __restrict__ values, int n, int n_stride, float k_scale, float k_offset, float k_unknown,
+    const unsigned* __restrict__ count, const ChunkFns* __restrict__ fns, int num_chunks, float* __restrict__ sums) {
+  extern __shared__ unsigned short lds_value[];  // n_stride grid values (15 bit), input order
+  if (count != nullptr && blockIdx.x >= *count) return;
+  __shared__ ParityFn wave_total[kScanThreads / 64];
+  __shared__ unsigned sh_m, sh_e, sh_i0, sh_cross_t, sh_cross_begin, sh_cross_end, sh_cross_m, sh_total, sh_cross_i, sh_cross_before,
+      sh_mismatch_t, sh_force_serial;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(values + static_cast<size_t>(blockIdx.x) * n_stride);
+    uint4* dst = reinterpret_cast<uint4*>(lds_value);
+    for (int i = tid; i < n_stride / 8; i += kScanThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  auto fixed = [&](unsigned i) { return fixed_of_value(lds_value[i], k_scale, k_offset, k_unknown); };
+  if (tid == 0) {
+    float s = 0.f;
+    const int n0 = min(n, kSerialPrefix);
+    for (int i = 0; i < n0; ++i) {
+      const unsigned v = lds_value[i];
+      s += v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset;
+    }
+    const unsigned b = __float_as_uint(s);
+    sh_m = (b & 0x7FFFFFu) | 0x800000u;
+    sh_e = (b >> 23) - 123u;
+    sh_i0 = static_cast<unsigned>(n0);
+    sh_force_serial = 0u;
+  }
+  __syncthreads();
+  const ChunkFns* my_fns = fns + static_cast<size_t>(blockIdx.x) * num_chunks;
+  const ParityFn id{0u, 0u, 0u, 1u};
+  while (sh_i0 < static_cast<unsigned>(n)) {  // uniform: one pass per binade
+    const unsigned m = sh_m, e = sh_e, i0 = sh_i0;
+    // window that must contain the crossing (every addend >= 0.1 > 13421772 * 2^-27), rounded up to
+    // a chunk boundary: elements behind the crossing are never looked at
+    const unsigned c_min = max(13421772u >> e, 1u);
+    const unsigned remaining = static_cast<unsigned>(n) - i0;
+    const unsigned window = min(remaining, ((1u << 24) - m) / c_min + 2u);
+    const unsigned c0 = i0 / kChunk;
+    const unsigned i_lim = min(static_cast<unsigned>(n), ((i0 + window + kChunk - 1u) / kChunk) * kChunk);
+    // thread t <-> chunk c0 + t, clipped to [i0, i_lim)
+    const unsigned c = c0 + static_cast<unsigned>(tid);
+    const unsigned begin = max(i0, c * kChunk), end = min(i_lim, (c + 1u) * kChunk);
+    ParityFn f = id;
+    bool mismatch = false;
+    if (tid != 0 && begin < end) {
+      const ChunkFns cf = my_fns[c];
+      if (cf.e0 == e) f = ParityFn{cf.s00, cf.s01, cf.pp0 & 1u, cf.pp0 >> 1};
+      else if (cf.e1 == e) f = ParityFn{cf.s10, cf.s11, cf.pp1 & 1u, cf.pp1 >> 1};
+      else mismatch = true;
+    }
+    // A chunk without a function for this binade lies BEHIND the crossing (the window bound is loose
+    // by up to 9x, and the real prefix proves the sum has left the binade by then): it stays the
+    // identity and is never selected.  Should one ever sit before the crossing -- a violated bound --
+    // the pass is repeated with such chunks opened element by element (sh_force_serial).
+    if (mismatch && sh_force_serial) {
+      for (unsigned i = begin; i < end; ++i) f = compose(f, element_fn(fixed(i), e));
+      mismatch = false;
+    }
+    if (wave == 0) {  // the chunk the walk resumes in is partial: lane per element
+      const unsigned hb = i0, he = min(i_lim, (c0 + 1u) * kChunk);
+      const unsigned i = hb + static_cast<unsigned>(lane);
+      ParityFn h = wave_inclusive_scan(i < he ? element_fn(fixed(i), e) : id, lane);
+      h.s0 = __shfl(h.s0, 63, 64);
+      h.s1 = __shfl(h.s1, 63, 64);
+      h.p0 = __shfl(h.p0, 63, 64);
+      h.p1 = __shfl(h.p1, 63, 64);
+      if (lane == 0) f = h;
+    }
+    // block-wide inclusive scan over the chunk functions
+    ParityFn inc = wave_inclusive_scan(f, lane);
+    if (lane == 63) wave_total[wave] = inc;
+    if (tid == 0) {
+      sh_cross_t = 0xFFFFFFFFu;
+      sh_mismatch_t = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if (mismatch) atomicMin(&sh_mismatch_t, static_cast<unsigned>(tid));
+    ParityFn before = id;
+    for (int w = 0; w < wave; ++w) before = compose(before, wave_total[w]);
+    ParityFn excl = shfl_up_fn(inc, 1);
+    if (lane == 0) excl = id;
+    excl = compose(before, excl);
+    const ParityFn incl = compose(before, inc);
+    const unsigned p_start = m & 1u;
+    const unsigned mt_start = m + (p_start ? excl.s1 : excl.s0);
+    const unsigned mt_end = m + (p_start ? incl.s1 : incl.s0);
+    if (tid == kScanThreads - 1) sh_total = mt_end - m;
+    if (begin < end && mt_end >= (1u << 24) && mt_start < (1u << 24)) atomicMin(&sh_cross_t, static_cast<unsigned>(tid));
+    __syncthreads();
+    if (sh_mismatch_t < sh_cross_t || (sh_cross_t == 0xFFFFFFFFu && sh_mismatch_t != 0xFFFFFFFFu)) {
+      __syncthreads();  // everyone has read the verdict
+      if (tid == 0) sh_force_serial = 1u;
+      __syncthreads();
+      continue;  // same (m, e, i0), chunks without a function opened serially
+    }
+    if (static_cast<unsigned>(tid) == sh_cross_t) {
+      sh_cross_begin = begin;
+      sh_cross_end = end;
+      sh_cross_m = mt_start;
+    }
+    __syncthreads();
+    if (sh_cross_t != 0xFFFFFFFFu && wave == 0) {  // open the crossing chunk: lane per element
+      const unsigned cb = sh_cross_begin, ce = sh_cross_end, ms = sh_cross_m;
+      const unsigned i = cb + static_cast<unsigned>(lane);
+      const ParityFn ef = i < ce ? element_fn(fixed(i), e) : id;
+      const ParityFn sc = wave_inclusive_scan(ef, lane);
+      ParityFn ex = shfl_up_fn(sc, 1);
+      if (lane == 0) ex = id;
+      const unsigned ps = ms & 1u;
+      const unsigned m_before = ms + (ps ? ex.s1 : ex.s0);
+      const unsigned m_after = ms + (ps ? sc.s1 : sc.s0);
+      const unsigned long long crossed = __ballot(i < ce && m_after >= (1u << 24));
+      const int first = __ffsll(static_cast<long long>(crossed)) - 1;
+      if (lane == first) {
+        sh_cross_i = i;
+        sh_cross_before = m_before;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (sh_cross_t == 0xFFFFFFFFu) {  // the cloud ended inside this binade
+        sh_m = m + sh_total;
+        sh_i0 = i_lim;
+      } else {
+        // exact sum of the crossing addition, rounded once to the next binade's ulp (2U)
+        const unsigned long long X = (static_cast<unsigned long long>(sh_cross_before) << e) + fixed(sh_cross_i);
+        const unsigned e2 = e + 1u;
+        const unsigned long long q2 = X >> e2, f2 = X & ((1ull << e2) - 1ull), h2 = 1ull << e;
+        const unsigned long long up = (f2 > h2 || (f2 == h2 && (q2 & 1ull))) ? 1ull : 0ull;
+        sh_m = static_cast<unsigned>(q2 + up);
+        sh_e = e2;
+        sh_i0 = sh_cross_i + 1u;
       }
     }
     __syncthreads();
@@ -1049,6 +1277,53 @@ static const LutModel& lut_model() {
 }
 
 // State of a (possibly sharded) match between its phases; lives in dliom_ctx::rtcsm_state.
+// Launches the exact sequential-sum kernels for `count` candidates whose indices are in d_list
+// (c -> translation c / R, rotation c % R): method 0 = one lane replays the loop, 1 = element scan,
+// 2 = chunk scan (default).  Methods 1 and 2 need the 15-bit values of a candidate in LDS
+// (n <= 65536) and fall back to method 0 beyond.  `scratch` receives values / chunk sums / chunk
+// functions; d_count != nullptr: the kernels read the live candidate count on the device.
+static int rescore_method_default() {
+  static const int m = env_int("DLIOM_RESCORE", 2);
+  return m;
+}
+static int launch_sequential_sums(dliom_ctx* ctx, int method, const GridView& gv, const dliom_cloud& cloud,
+                                  const float4* d_rot, int R, const float* d_trans, const unsigned* d_list,
+                                  const unsigned* d_count, unsigned count, DevBuf* scratch, float* d_ksums) {
+  const LutModel& lm = lut_model();
+  const int n = static_cast<int>(cloud.n);
+  const int n_stride = (n + 7) & ~7;
+  const size_t scan_lds = static_cast<size_t>(n_stride) * 2;
+  if (method == 0 || scan_lds > 128 * 1024 || count > 65535) {
+    hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(count), dim3(256), 0, ctx->stream, gv, cloud.d_x, cloud.d_y, cloud.d_z, n,
+                       d_rot, R, d_trans, d_list, d_count, lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
+    DLIOM_HIP_TRY(hipGetLastError());
+    return DLIOM_OK;
+  }
+  const int num_chunks = (n + kChunk - 1) / kChunk;
+  const size_t values_bytes = (static_cast<size_t>(count) * n_stride * 2 + 255) & ~static_cast<size_t>(255);
+  const size_t sums_bytes = (static_cast<size_t>(count) * num_chunks * 8 + 255) & ~static_cast<size_t>(255);
+  const size_t fns_bytes = static_cast<size_t>(count) * num_chunks * sizeof(ChunkFns);
+  DLIOM_TRY(scratch->reserve(values_bytes + sums_bytes + fns_bytes));
+  char* base = static_cast<char*>(scratch->p);
+  unsigned short* d_values = reinterpret_cast<unsigned short*>(base);
+  double* d_chunk_sums = method == 2 ? reinterpret_cast<double*>(base + values_bytes) : nullptr;
+  ChunkFns* d_fns = reinterpret_cast<ChunkFns*>(base + values_bytes + sums_bytes);
+  hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, count), dim3(256), 0, ctx->stream, gv,
+                     cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, d_rot, R, d_trans, d_list, d_count, d_values, lm.k_scale,
+                     lm.k_offset, lm.k_unknown, d_chunk_sums, num_chunks);
+  if (method == 2) {
+    hipLaunchKernelGGL(rtcsm_rescore_chunk_fns_kernel, dim3((num_chunks + 3) / 4, count), dim3(256), 0, ctx->stream, d_values,
+                       n, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, d_count, d_chunk_sums, num_chunks, d_fns);
+    hipLaunchKernelGGL(rtcsm_rescore_chunk_scan_kernel, dim3(count), dim3(kScanThreads), scan_lds, ctx->stream, d_values, n,
+                       n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, d_count, d_fns, num_chunks, d_ksums);
+  } else {
+    hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(count), dim3(kScanThreads), scan_lds, ctx->stream, d_values, n, n_stride,
+                       lm.k_scale, lm.k_offset, lm.k_unknown, d_count, d_ksums);
+  }
+  DLIOM_HIP_TRY(hipGetLastError());
+  return DLIOM_OK;
+}
+
 struct RtcsmState {
   dliom_rtcsm_options o;
   Candidates c;
@@ -1169,37 +1444,17 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
   std::vector<unsigned> list;
   std::vector<float> ksums;
   if (st->r_last > st->r_first) {
-    const LutModel& lm = lut_model();
-    const int n = static_cast<int>(cloud.n);
-    static const int rescore_method = env_int("DLIOM_RESCORE", 1);  // 1: binade-wise scan, 0: serial chain
-    const int n_stride = (n + 7) & ~7;
-    const size_t scan_lds = static_cast<size_t>(n_stride) * 2;
-    const bool scan_ok = rescore_method == 1 && scan_lds <= 128 * 1024;
     // readback block at the end of the pinned staging area: [count pair | list | sums]
     unsigned* h_ctrs = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 4096);
     unsigned* h_list = h_ctrs + 2;
     float* h_sums = reinterpret_cast<float*>(h_ctrs + 2 + kSpecK);
     auto rescore = [&](unsigned count, const unsigned* d_count, size_t list_offset) -> int {
-      const size_t ks_bytes = (static_cast<size_t>(count) * 4 + 255) & ~static_cast<size_t>(255);
+      DLIOM_TRY(ctx->rescore.reserve((static_cast<size_t>(count) * 4 + 255) & ~static_cast<size_t>(255)));
       const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
-      if (scan_ok && count <= 65535) {
-        DLIOM_TRY(ctx->rescore.reserve(ks_bytes + static_cast<size_t>(count) * n_stride * 2));
-        float* d_ksums = ctx->rescore.as<float>();
-        unsigned short* d_values = reinterpret_cast<unsigned short*>(static_cast<char*>(ctx->rescore.p) + ks_bytes);
-        hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, count), dim3(256), 0, ctx->stream,
-                           st->grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, st->d.rot, R, st->d.trans,
-                           st->d_list + list_offset, d_count, d_values);
-        hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(count), dim3(kScanThreads), scan_lds, ctx->stream, d_values,
-                           n, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, d_count, d_ksums);
-      } else {
-        DLIOM_TRY(ctx->rescore.reserve(ks_bytes));
-        hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(count), dim3(256), 0, ctx->stream, st->grid->view(), cloud.d_x,
-                           cloud.d_y, cloud.d_z, n, st->d.rot, R, st->d.trans, st->d_list + list_offset, d_count,
-                           lm.k_scale, lm.k_offset, lm.k_unknown, ctx->rescore.as<float>());
-      }
+      const int s = launch_sequential_sums(ctx, rescore_method_default(), st->grid->view(), cloud, st->d.rot, R, st->d.trans,
+                                           st->d_list + list_offset, d_count, count, &ctx->misc, ctx->rescore.as<float>());
       ctx->end_span(span);
-      DLIOM_HIP_TRY(hipGetLastError());
-      return DLIOM_OK;
+      return s;
     };
     DLIOM_TRY(rescore(kSpecK, st->d_ctrs + 1, 0));
     DLIOM_HIP_TRY(hipMemcpyAsync(h_ctrs, st->d_ctrs, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1326,27 +1581,10 @@ int sequential_probability_sums(dliom_ctx* ctx, const dliom_cloud& cloud, const 
   const float4* d_rot = reinterpret_cast<const float4*>(base);
   const float* d_trans = reinterpret_cast<const float*>(base + rot_bytes);
   const unsigned* d_list = reinterpret_cast<const unsigned*>(base + rot_bytes + trans_bytes);
-  const LutModel& lm = lut_model();
-  const int n = static_cast<int>(cloud.n);
-  const int n_stride = (n + 7) & ~7;
-  const size_t scan_lds = static_cast<size_t>(n_stride) * 2;
   DLIOM_TRY(ctx->rescore.reserve(list_bytes));
   float* d_ksums = ctx->rescore.as<float>();
-  if (scan_lds <= 128 * 1024) {
-    DLIOM_TRY(ctx->misc.reserve(K * n_stride * 2));
-    unsigned short* d_values = ctx->misc.as<unsigned short>();
-    hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, static_cast<unsigned>(k)), dim3(256), 0,
-                       ctx->stream, grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, n, n_stride, d_rot, k, d_trans, d_list,
-                       static_cast<const unsigned*>(nullptr), d_values);
-    hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(static_cast<unsigned>(k)), dim3(kScanThreads), scan_lds, ctx->stream,
-                       d_values, n, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown, static_cast<const unsigned*>(nullptr),
-                       d_ksums);
-  } else {
-    hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(static_cast<unsigned>(k)), dim3(256), 0, ctx->stream, grid->view(),
-                       cloud.d_x, cloud.d_y, cloud.d_z, n, d_rot, k, d_trans, d_list, static_cast<const unsigned*>(nullptr),
-                       lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
-  }
-  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_TRY(launch_sequential_sums(ctx, rescore_method_default(), grid->view(), cloud, d_rot, k, d_trans, d_list, nullptr,
+                                   static_cast<unsigned>(k), &ctx->misc, d_ksums));
   DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_ksums, K * 4, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `host` alive long enough
   return DLIOM_OK;
@@ -1468,27 +1706,11 @@ int dliom_rtcsm3d_sequential_sums(dliom_ctx* ctx, const dliom_rtcsm_options* o, 
   unsigned* d_list = ctx->rescore.as<unsigned>();
   float* d_ksums = reinterpret_cast<float*>(static_cast<char*>(ctx->rescore.p) + lbytes);
   DLIOM_HIP_TRY(hipMemcpyAsync(d_list, list.data(), static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, ctx->stream));
-  const LutModel& lm = lut_model();
   const int R = static_cast<int>(c.w.num_rotations);
-  const int ni = static_cast<int>(n);
-  if (method == 1) {
-    const int n_stride = (ni + 7) & ~7;
-    const size_t scan_lds = static_cast<size_t>(n_stride) * 2;
-    if (scan_lds > 128 * 1024 || k > 65535) return DLIOM_ERR_INVALID_ARGUMENT;
-    DLIOM_TRY(ctx->misc.reserve(static_cast<size_t>(k) * n_stride * 2));
-    unsigned short* d_values = ctx->misc.as<unsigned short>();
-    hipLaunchKernelGGL(rtcsm_rescore_values_kernel, dim3((n_stride + 255) / 256, static_cast<unsigned>(k)), dim3(256),
-                       0, ctx->stream, grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, ni, n_stride, d.rot, R, d.trans,
-                       d_list, static_cast<const unsigned*>(nullptr), d_values);
-    hipLaunchKernelGGL(rtcsm_rescore_scan_kernel, dim3(static_cast<unsigned>(k)), dim3(kScanThreads), scan_lds,
-                       ctx->stream, d_values, ni, n_stride, lm.k_scale, lm.k_offset, lm.k_unknown,
-                       static_cast<const unsigned*>(nullptr), d_ksums);
-  } else {
-    hipLaunchKernelGGL(rtcsm_rescore_kernel, dim3(static_cast<unsigned>(k)), dim3(256), 0, ctx->stream,
-                       grid->view(), cloud.d_x, cloud.d_y, cloud.d_z, ni, d.rot, R, d.trans, d_list,
-                       static_cast<const unsigned*>(nullptr), lm.k_scale, lm.k_offset, lm.k_unknown, d_ksums);
-  }
-  DLIOM_HIP_TRY(hipGetLastError());
+  if (method < 0 || method > 2 || k > 65535) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (method != 0 && ((static_cast<size_t>(n) + 7) & ~static_cast<size_t>(7)) * 2 > 128 * 1024) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_TRY(launch_sequential_sums(ctx, method, grid->view(), cloud, d.rot, R, d.trans, d_list, nullptr,
+                                   static_cast<unsigned>(k), &ctx->misc, d_ksums));
   DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_ksums, static_cast<size_t>(k) * 4, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   return DLIOM_OK;

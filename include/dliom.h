@@ -491,7 +491,8 @@ int dliom_rtcsm3d_score_volume(dliom_ctx* ctx, const dliom_rtcsm_options* option
                                int64_t capacity, int64_t* num_candidates);
 /* For k given candidates: the reference's SEQUENTIAL float sum of probabilities in point order
  * (rtcsm_3d.cc:101-104, before the division by N), method 0 = one lane replays the loop,
- * method 1 = the binade-wise exact parallel scan (n <= 65536).  Both must be bit-identical. */
+ * method 1 = the binade-wise exact parallel scan over elements, method 2 = the same scan over
+ * precomputed 64-point chunk functions (both n <= 65536).  All three must be bit-identical. */
 int dliom_rtcsm3d_sequential_sums(dliom_ctx* ctx, const dliom_rtcsm_options* options,
                                   const double initial_pose_estimate[7], const float* points_xyz, int64_t n,
                                   const dliom_grid* grid, const int64_t* candidate_indices, int64_t k,

@@ -676,8 +676,10 @@ def test_sequential_sum_kernels_bit_exact(dl, ctx, orc, beams, azimuths, max_ran
     want = orc.rtcsm3d_float_sums(DEFAULT_RTCSM, init, pts, og, idx)
     serial = m.sequential_sums(init, pts, dg, idx, 0)
     scan = m.sequential_sums(init, pts, dg, idx, 1)
+    chunked = m.sequential_sums(init, pts, dg, idx, 2)
     assert np.array_equal(serial.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(scan.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(chunked.view(np.uint32), want.view(np.uint32))
     dg.close()
 
 
@@ -697,6 +699,7 @@ def test_sequential_sum_scan_handles_ties_and_saturated_values(dl, ctx, orc):
     want = orc.rtcsm3d_float_sums(DEFAULT_RTCSM, init, pts, og, idx)
     assert np.array_equal(m.sequential_sums(init, pts, dg, idx, 1).view(np.uint32), want.view(np.uint32))
     assert np.array_equal(m.sequential_sums(init, pts, dg, idx, 0).view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(m.sequential_sums(init, pts, dg, idx, 2).view(np.uint32), want.view(np.uint32))
     dg.close()
 
 
