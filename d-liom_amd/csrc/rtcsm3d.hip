@@ -8,10 +8,13 @@
 //          (2L+1)^3 candidate translations q_init * t_j + t_init, in the reference's float
 //          arithmetic (candidate c = j * R + r in generation order z,y,x,rz,ry,rx)
 //   GPU A  score volume: exact integer sum_i max(v_i & 0x7fff, 1) per candidate
+//          (rtcsm_score_dense_kernel over the grid's bricked dense mirror; the two leaf-table
+//          kernels above it are the fallbacks for grids whose mirror would not fit)
 //   GPU B  rigorous float-score interval per candidate from that sum; candidates whose upper
 //          bound reaches the best lower bound survive
-//   GPU C  survivors only: per-point probabilities, then the reference's SEQUENTIAL float sum in
-//          point order (one lane per survivor) -> bit-identical scores
+//   GPU C  survivors only: the reference's SEQUENTIAL float sum in point order, bit-identical,
+//          evaluated in parallel (chunk functions + binade-wise scan; element scan and serial
+//          replay kept as cross-checks)
 //   host   score = sum / N * exp(-(|t| wt + angle wr)^2) as the reference computes it; first
 //          strictly greater score in generation order wins.
 #include <algorithm>
