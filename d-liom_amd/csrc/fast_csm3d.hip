@@ -466,6 +466,12 @@ int run_search(Search& s, const dliom_cloud& hi_cloud, float min_score, dliom_fa
 
   // lowest-resolution candidates (:358-392, 419-429)
   const int step = 1 << m->max_depth();
+  {
+    // the reference would allocate them all as well; refuse searches that cannot fit instead of
+    // exhausting host memory (a whole-submap window with a shallow pyramid is ~1e8 per scan)
+    const double per_axis_xy = std::floor((2.0 * s.linear_xy + step) / step), per_axis_z = std::floor((2.0 * s.linear_z + step) / step);
+    if (per_axis_xy * per_axis_xy * per_axis_z * num_scans > 3.0e7) return DLIOM_ERR_CAPACITY;
+  }
   std::vector<Candidate> lowest;
   for (int scan = 0; scan != num_scans; ++scan)
     for (int z = -s.linear_z; z <= s.linear_z; z += step)
