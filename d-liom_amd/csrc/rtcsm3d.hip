@@ -231,7 +231,11 @@ struct DenseDomain {
   float pad[3];
 };
 
-template <int P, bool CLAMP>
+// DEBUG != 0 are TIMING-ONLY variants (wrong sums) that isolate one pipe each (DLIOM_SCORE_DEBUG,
+// profiles/r2_score_pipe_experiment.json): 1 = all index math and LDS table reads, the gather replaced
+// by a register value; 2 = the gather with the index math done once per point instead of once per
+// (point, translation); 3 = index math only (no LDS table reads, no gather).
+template <int P, bool CLAMP, int DEBUG = 0>
 __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
     GridView g, DenseDomain dom, const float* __restrict__ px, const float* __restrict__ py,
     const float* __restrict__ pz, int points_per_chunk, int point_chunks,
@@ -294,6 +298,26 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
         rotate_point(q, real ? px[i + k] : dom.pad[0], real ? py[i + k] : dom.pad[1], real ? pz[i + k] : dom.pad[2],
                      rx[k], ry[k], rz[k]);
       }
+      if (DEBUG == 2) {
+        unsigned o[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          const float4 t = lds_trans[jc];
+          o[k] = lds_off[cvt_flr(__builtin_fmaf(rx[k] + t.x, inv, K))] +
+                 lds_off[TS + cvt_flr(__builtin_fmaf(ry[k] + t.y, inv, K))] +
+                 lds_off[2 * TS + cvt_flr(__builtin_fmaf(rz[k] + t.z, inv, K))];
+        }
+#pragma unroll 1
+        for (int jj = 0; jj < tc; ++jj) {
+          const unsigned d = (jj % 3) * 2u + ((jj / 3) % 3) * 8u + ((jj / 9) % 3) * 32u;  // uniform, stays inside a brick or the next
+          unsigned a = 0;
+#pragma unroll
+          for (int k = 0; k < P; ++k)
+            a += *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.dense) + (o[k] + d));
+          atomicAdd(&lds_acc[jj * bs + threadIdx.x], a);
+        }
+        continue;
+      }
 #pragma unroll 1
       for (int jj = 0; jj < tc; ++jj) {
         const float4 t = lds_trans[jc + jj];  // same address in every lane: LDS broadcast
@@ -313,6 +337,10 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
             ox[k] = lds_off[cvt_flr(__builtin_amdgcn_fmed3f(zx, 0.f, lim))];
             oy[k] = lds_off[TS + cvt_flr(__builtin_amdgcn_fmed3f(zy, 0.f, lim))];
             oz[k] = lds_off[2 * TS + cvt_flr(__builtin_amdgcn_fmed3f(zz, 0.f, lim))];
+          } else if (DEBUG == 3) {
+            ox[k] = cvt_flr(zx);
+            oy[k] = cvt_flr(zy) << 3;
+            oz[k] = cvt_flr(zz) << 6;
           } else {
             ox[k] = lds_off[cvt_flr(zx)];
             oy[k] = lds_off[TS + cvt_flr(zy)];
@@ -340,8 +368,10 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
         unsigned v[P];
 #pragma unroll
         for (int k = 0; k < P; ++k)
-          v[k] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.dense) +
-                                                          (ox[k] + oy[k] + oz[k]));
+          v[k] = DEBUG == 1 || DEBUG == 3
+                     ? ((ox[k] + oy[k] + oz[k]) & 0x7fffu)
+                     : *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.dense) +
+                                                                (ox[k] + oy[k] + oz[k]));
         unsigned a = 0;
 #pragma unroll
         for (int k = 0; k < P; ++k) a += v[k];  // the mirror stores max(value, 1) already
@@ -1200,7 +1230,17 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   hipLaunchKernelGGL((rtcsm_score_dense_kernel<PP, CL>), dense_grid, block, lds2, ctx->stream, g, dom, cloud.d_xs,     \
                      cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, \
                      t_chunk, *d_sums)
-      if (pts_per_iter == 2) {
+      static const int score_debug = env_int("DLIOM_SCORE_DEBUG", 0);  // timing-only pipe isolation
+      if (score_debug >= 1 && score_debug <= 3 && !clamp) {
+#define DLIOM_LAUNCH_DEBUG(DBG)                                                                                       \
+  hipLaunchKernelGGL((rtcsm_score_dense_kernel<8, false, DBG>), dense_grid, block, lds2, ctx->stream, g, dom,         \
+                     cloud.d_xs, cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, \
+                     d->trans4, T, t_chunk, *d_sums)
+        if (score_debug == 1) DLIOM_LAUNCH_DEBUG(1);
+        else if (score_debug == 2) DLIOM_LAUNCH_DEBUG(2);
+        else DLIOM_LAUNCH_DEBUG(3);
+#undef DLIOM_LAUNCH_DEBUG
+      } else if (pts_per_iter == 2) {
         if (clamp) DLIOM_LAUNCH_DENSE(2, true); else DLIOM_LAUNCH_DENSE(2, false);
       } else if (pts_per_iter == 4) {
         if (clamp) DLIOM_LAUNCH_DENSE(4, true); else DLIOM_LAUNCH_DENSE(4, false);
