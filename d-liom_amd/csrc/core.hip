@@ -456,6 +456,9 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   ctx->misc.release();
   ctx->sort_tmp.release();
   ctx->voxel.release();
+  ctx->box_tables.release();
+  ctx->box_error.release();
+  ctx->box_counters.release();
   if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

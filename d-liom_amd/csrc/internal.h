@@ -74,6 +74,12 @@ struct dliom_ctx {
   dliom::DevBuf misc;       // small odds and ends (probe outputs, cell lists)
   dliom::DevBuf sort_tmp;   // radix-sort temporary storage (cloud staging)
   dliom::DevBuf voxel;      // voxel-filter hash tables, slots, flags, counters (voxel_filter.hip)
+  dliom::DevBuf box_tables; // per-pass constants of the LDS-box score kernel (rtcsm3d.hip)
+  dliom::DevBuf box_counters; // its chunk dispensers
+  dliom::DevBuf box_error;  // its 'cannot happen' flag word, read by dliom_rtcsm3d_box_error
+  bool box_error_zeroed = false;
+  bool force_dense_score = false;  // rerun after a list overflow of the LDS-box kernel
+  bool last_score_used_box = false;
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
   // profiling

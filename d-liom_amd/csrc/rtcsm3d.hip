@@ -25,6 +25,7 @@
 
 #include "device_common.h"
 #include "host_math.h"
+#include "score_box.h"
 
 namespace dliom {
 
@@ -1101,7 +1102,7 @@ static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidat
     h4[4 * i + 3] = 0.f;
   }
   char* base = static_cast<char*>(ctx->cand.p);
-  if (total <= ctx->pinned_bytes) {
+  if (total + 81920 <= ctx->pinned_bytes) {  // the last 80 KB stage the box-kernel tables and the readbacks
     // Pinned staging: truly asynchronous.  Every entry point that gets here synchronises the
     // stream before it returns, so the block is free again at the next call.
     std::memcpy(ctx->pinned, host.data(), total);
@@ -1123,6 +1124,261 @@ static int env_int(const char* name, int fallback) {
   return e != nullptr ? std::atoi(e) : fallback;
 }
 
+// LDS-box score kernel (score_box.h): builds the per-pass constants in double and launches it.
+// Returns DLIOM_ERR_CAPACITY when the search does not suit the kernel (the caller then uses the dense
+// kernel): boxes that cannot hold a typical point's lookups, or coordinates beyond the scaled range.
+static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const GridView& g, const Candidates& c,
+                            const DeviceCandidates& d, int r_first, int r_last, unsigned long long* d_sums,
+                            unsigned* d_error) {
+  using namespace box;
+  const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
+  const int n = static_cast<int>(cloud.n);
+  static const int cells = env_int("DLIOM_BOX_CELLS", 14336);
+  static const int chunk_pts = env_int("DLIOM_BOX_CHUNK", 32);
+  static const int target_waves = env_int("DLIOM_BOX_WAVES", 0);
+  const double res = static_cast<double>(g.resolution);
+  const int passes = (T + kTC - 1) / kTC;
+  // ---- error budget (score_box.h): E / u = 1 + (2 qmax + rmax + taumax) / 256
+  double tmax = 0.0;
+  for (const F3& t : c.trans) tmax = std::max(tmax, static_cast<double>(std::max(std::fabs(t.x), std::max(std::fabs(t.y), std::fabs(t.z)))));
+  const double rmax = static_cast<double>(cloud.max_norm) / res + 1.0;
+  const double qmax = rmax + tmax / res + 1.0;
+  if (!std::isfinite(qmax) || qmax > 880.0) return DLIOM_ERR_CAPACITY;  // Kb must stay below 1024
+  std::vector<Pass> pass(static_cast<size_t>(passes));
+  std::vector<float> tau(static_cast<size_t>(passes) * kTC * 4, 0.f);
+  double taumax = 0.0;
+  for (int tp = 0; tp < passes; ++tp) {  // pass centres first: taumax enters the band
+    const int j0 = tp * kTC, tc = std::min(kTC, T - j0);
+    for (int a = 0; a < 3; ++a) {
+      double lo = 1e300, hi = -1e300;
+      for (int j = j0; j < j0 + tc; ++j) {
+        const double v = a == 0 ? c.trans[j].x : (a == 1 ? c.trans[j].y : c.trans[j].z);
+        lo = std::min(lo, v);
+        hi = std::max(hi, v);
+      }
+      taumax = std::max(taumax, (hi - lo) * 0.5 / res + 1.0);
+    }
+  }
+  const double e16 = 1.0 + (2.0 * qmax + rmax + taumax) / 256.0;
+  const int B = static_cast<int>(std::ceil(e16 + 0.25));
+  const int s_units = B;
+  const double u = 1.0 / 65536.0;
+  for (int tp = 0; tp < passes; ++tp) {
+    Pass& ps = pass[static_cast<size_t>(tp)];
+    ps.j0 = tp * kTC;
+    ps.tc = std::min(kTC, T - ps.j0);
+    ps.pad[0] = ps.pad[1] = 0;
+    for (int a = 0; a < 3; ++a) {
+      auto comp = [&](int j) { return static_cast<double>(a == 0 ? c.trans[j].x : (a == 1 ? c.trans[j].y : c.trans[j].z)); };
+      double lo = 1e300, hi = -1e300;
+      for (int j = ps.j0; j < ps.j0 + ps.tc; ++j) {
+        lo = std::min(lo, comp(j));
+        hi = std::max(hi, comp(j));
+      }
+      const double tcen = 0.5 * (lo + hi);
+      const double G = tcen / res + 128.5 + s_units * u;
+      const double gi = std::floor(G);
+      const double f = std::nearbyint((G - gi) * 16384.0) / 16384.0;  // 14 fractional bits (may be 1.0)
+      ps.gi[a] = static_cast<int>(gi);
+      ps.f[a] = static_cast<float>(f);
+      ps.uc[a] = static_cast<float>(tcen / res + 0.5);
+      double reach = 0.0;
+      for (int jj = 0; jj < kTC; ++jj) {
+        const int j = ps.j0 + std::min(jj, ps.tc - 1);  // short pass: padding repeats the last translation
+        const double tv = comp(j) / res + 128.5 + s_units * u - (gi + f);
+        const float tf = static_cast<float>(tv);
+        tau[(static_cast<size_t>(tp) * kTC + jj) * 4 + a] = tf;
+        reach = std::max(reach, std::fabs(static_cast<double>(tf)));
+      }
+      ps.reach[a] = static_cast<float>(reach + 0.02);
+    }
+  }
+  // ---- band bitmap: fractions phi of a scaled coordinate for which SOME translation of the pass gives
+  // frac16(fl(phi + tau_j)) <= thr, i.e. frac(phi + tau_j) in [-u/2, (thr + 1/2) u]; one u of margin each side
+  std::vector<unsigned> bitmap(static_cast<size_t>(passes) * kBitmapWords, 0u);
+  const unsigned thr_units = static_cast<unsigned>(s_units + B);
+  for (int tp = 0; tp < passes; ++tp) {
+    const Pass& ps = pass[static_cast<size_t>(tp)];
+    for (int a = 0; a < 3; ++a) {
+      unsigned* words = bitmap.data() + static_cast<size_t>(tp) * kBitmapWords + static_cast<size_t>(a) * (kBuckets / 32);
+      for (int jj = 0; jj < ps.tc; ++jj) {
+        const double tv = static_cast<double>(tau[(static_cast<size_t>(tp) * kTC + jj) * 4 + a]);
+        const double af = tv - std::floor(tv);
+        const double L = -af - 1.5 * u, H = -af + (thr_units + 1.5) * u;
+        const long long b0 = static_cast<long long>(std::floor(L * kBuckets)), b1 = static_cast<long long>(std::floor(H * kBuckets));
+        for (long long b = b0; b <= b1; ++b) {
+          const unsigned m = static_cast<unsigned>(((b % kBuckets) + kBuckets) % kBuckets);
+          words[m >> 5] |= 1u << (m & 31u);
+        }
+      }
+    }
+  }
+  // ---- does a typical point fit?  spread of one point over 64 consecutive rotations <= 2 * 11 steps * rho
+  {
+    const double step = c.w.angular_step_size;
+    const double a_lanes = (2.0 * c.w.angular_window_size + 1.0) * step;  // rotation-vector span of a workgroup (per axis, at most)
+    const double spread = a_lanes * 0.6 * cloud.max_norm / res;                        // cells, at 60 % of the maximum range
+    const double dim = spread + 2.0 * taumax + 8.0;
+    if (dim > kMaxDim || dim * dim * (dim * 0.25) > cells) return DLIOM_ERR_CAPACITY;
+  }
+  // ---- spread of every wave's 64 rotations around its centre lane (window only: q_init cancels)
+  const int rot_groups_all = (r_last - r_first + 63) / 64;
+  // waves per workgroup: the fewest idle waves in the last workgroup (4 unless 3 divides better)
+  const int nw = rot_groups_all % 4 == 0 ? 4 : (rot_groups_all % 3 == 0 ? 3 : (rot_groups_all <= 2 ? rot_groups_all : 4));
+  const int rot_blocks = (rot_groups_all + nw - 1) / nw;
+  struct GroupCache {  // depends on the window and the shard only: cached per thread across matches
+    int A = -1, r_first = -1, r_last = -1, nw = 0;
+    float step = 0.f;
+    std::vector<Group> groups;
+  };
+  static thread_local GroupCache gcache;
+  const bool gcache_hit = gcache.A == c.w.angular_window_size && gcache.step == c.w.angular_step_size &&
+                          gcache.r_first == r_first && gcache.r_last == r_last && gcache.nw == nw;
+  std::vector<Group>& groups = gcache.groups;
+  if (!gcache_hit) {
+    gcache.A = -1;
+    groups.assign(static_cast<size_t>(rot_blocks), Group());
+  }
+  for (size_t gi = 0; !gcache_hit && gi < groups.size(); ++gi) {
+    Group& gr = groups[gi];
+    const int r0 = r_first + static_cast<int>(gi) * nw * 64;
+    const int cnt = std::max(0, std::min(nw * 64, r_last - r0));
+    gr.c_lane = cnt / 2;
+    gr.theta2 = 0.f;
+    for (int a = 0; a < 3; ++a) gr.dc[a] = gr.hd[a] = 0.f;
+    if (cnt <= 0) {
+      gr.c_lane = 0;
+      continue;
+    }
+    auto qd = [&](int r, double q[4]) {
+      const QF& f = c.rot_raw[static_cast<size_t>(r)];
+      const double nn = std::sqrt(double(f.w) * f.w + double(f.x) * f.x + double(f.y) * f.y + double(f.z) * f.z);
+      q[0] = f.w / nn; q[1] = f.x / nn; q[2] = f.y / nn; q[3] = f.z / nn;
+    };
+    double qc[4];
+    qd(r0 + gr.c_lane, qc);
+    double lo3[3] = {1e300, 1e300, 1e300}, hi3[3] = {-1e300, -1e300, -1e300}, th = 0.0;
+    for (int l = 0; l < cnt; ++l) {
+      double q[4];
+      qd(r0 + l, q);
+      // d = conj(qc) * q
+      const double a0 = qc[0], a1 = -qc[1], a2 = -qc[2], a3 = -qc[3];
+      double dq[4] = {a0 * q[0] - a1 * q[1] - a2 * q[2] - a3 * q[3], a0 * q[1] + a1 * q[0] + a2 * q[3] - a3 * q[2],
+                      a0 * q[2] - a1 * q[3] + a2 * q[0] + a3 * q[1], a0 * q[3] + a1 * q[2] - a2 * q[1] + a3 * q[0]};
+      if (dq[0] < 0) for (double& v : dq) v = -v;
+      const double vn = std::sqrt(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+      const double ang = 2.0 * std::atan2(vn, dq[0]);
+      const double k = vn > 1e-300 ? ang / vn : 2.0;
+      const double dv[3] = {k * dq[1], k * dq[2], k * dq[3]};
+      th = std::max(th, ang);
+      for (int a = 0; a < 3; ++a) {
+        lo3[a] = std::min(lo3[a], dv[a]);
+        hi3[a] = std::max(hi3[a], dv[a]);
+      }
+    }
+    if (th > 0.3) return DLIOM_ERR_CAPACITY;  // the second-order bound below assumes small relative rotations
+    for (int a = 0; a < 3; ++a) {
+      gr.dc[a] = static_cast<float>(0.5 * (lo3[a] + hi3[a]));
+      gr.hd[a] = static_cast<float>(0.5 * (hi3[a] - lo3[a]) * 1.0001 + 1e-7);
+    }
+    gr.theta2 = static_cast<float>(0.51 * th * th * 1.01 + 1e-9);
+  }
+  gcache.A = c.w.angular_window_size;
+  gcache.step = c.w.angular_step_size;
+  gcache.r_first = r_first;
+  gcache.r_last = r_last;
+  gcache.nw = nw;
+  // ---- device tables (after the candidate tables inside ctx->cand would alias uploads in flight: own buffer)
+  const size_t tau_bytes = (tau.size() * 4 + 255) & ~static_cast<size_t>(255);
+  const size_t pass_only_bytes = (pass.size() * sizeof(Pass) + 255) & ~static_cast<size_t>(255);
+  const size_t group_bytes = (groups.size() * sizeof(Group) + 255) & ~static_cast<size_t>(255);
+  const size_t bitmap_bytes = (bitmap.size() * 4 + 255) & ~static_cast<size_t>(255);
+  const size_t pass_bytes = pass_only_bytes + group_bytes + bitmap_bytes;  // [passes | groups | bitmaps]
+  DLIOM_TRY(ctx->box_tables.reserve(tau_bytes + pass_bytes));
+  char* base = static_cast<char*>(ctx->box_tables.p);
+  // small (a few KB): staged through the pinned block when it fits, else a synchronous copy
+  if (tau_bytes + pass_bytes <= 65536 && ctx->pinned_bytes >= 81920) {
+    char* h = static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 81920;
+    std::memcpy(h, tau.data(), tau.size() * 4);
+    std::memcpy(h + tau_bytes, pass.data(), pass.size() * sizeof(Pass));
+    std::memcpy(h + tau_bytes + pass_only_bytes, groups.data(), groups.size() * sizeof(Group));
+    std::memcpy(h + tau_bytes + pass_only_bytes + group_bytes, bitmap.data(), bitmap.size() * 4);
+    DLIOM_HIP_TRY(hipMemcpyAsync(base, h, tau_bytes + pass_bytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    DLIOM_HIP_TRY(hipMemcpyAsync(base, tau.data(), tau.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    DLIOM_HIP_TRY(hipMemcpyAsync(base + tau_bytes, pass.data(), pass.size() * sizeof(Pass), hipMemcpyHostToDevice, ctx->stream));
+    DLIOM_HIP_TRY(hipMemcpyAsync(base + tau_bytes + pass_only_bytes, groups.data(), groups.size() * sizeof(Group),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    DLIOM_HIP_TRY(hipMemcpyAsync(base + tau_bytes + pass_only_bytes + group_bytes, bitmap.data(), bitmap.size() * 4,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  Params p;
+  p.tau = reinterpret_cast<const float4*>(base);
+  p.pass = reinterpret_cast<const Pass*>(base + tau_bytes);
+  p.group = reinterpret_cast<const Group*>(base + tau_bytes + pass_only_bytes);
+  p.bitmap = reinterpret_cast<const unsigned*>(base + tau_bytes + pass_only_bytes + group_bytes);
+  p.trans = d.trans;
+  p.rot = d.rot;
+  p.sums = d_sums;
+  p.error = d_error;
+  p.R = R;
+  p.r_first = r_first;
+  p.r_last = r_last;
+  p.T = T;
+  p.passes = passes;
+  p.n = n;
+  p.chunk = std::min(kMaxChunk, std::max(4, chunk_pts & ~3));
+  p.point_chunks = (n + p.chunk - 1) / p.chunk;
+  const int rot_groups = (r_last - r_first + 63) / 64;
+  p.rot_groups = rot_groups;
+  p.rot_blocks = rot_blocks;
+  p.nw = nw;
+  p.thr = thr_units;
+  p.cells = cells;
+  static const int box_debug = env_int("DLIOM_BOX_DEBUG", 0);
+  p.debug = box_debug;
+  const size_t lds = kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(kWaves) * kListWords * 4 +
+                     static_cast<size_t>(cells) * 2;
+  if (lds > 160 * 1024) return DLIOM_ERR_CAPACITY;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rtcsm_score_box_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  // workgroups: one round of residents (every wave walks an equal share of the point chunks, so a second,
+  // partly filled round would only idle); `target_waves` overrides
+  static size_t resident_lds = 0;
+  static int resident = 0, resident_nw = 0;
+  if (resident_lds != lds || resident_nw != nw) {
+    resident_nw = nw;
+    DLIOM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(rtcsm_score_box_kernel),
+                                                                64 * nw, lds));
+    resident_lds = lds;
+  }
+  static const int num_cus = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }();
+  const int want_blocks = target_waves > 0 ? target_waves / kWaves : std::max(1, resident) * num_cus;
+  int slot_quads = std::max(1, want_blocks / std::max(1, rot_blocks * passes));
+  slot_quads = std::min(slot_quads, (p.point_chunks + kBatch - 1) / kBatch);
+  // 32-bit accumulators: even a wave that drew every chunk must stay below 2^32
+  if (static_cast<double>(n) * 32767.0 >= 4294967295.0) return DLIOM_ERR_CAPACITY;
+  p.slots = slot_quads;
+  DLIOM_TRY(ctx->box_counters.reserve(static_cast<size_t>(passes) * rot_blocks * 4 + 256));
+  DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_counters.p, 0, static_cast<size_t>(passes) * rot_blocks * 4, ctx->stream));
+  p.counters = ctx->box_counters.as<unsigned>();
+  const unsigned blocks = static_cast<unsigned>(slot_quads) * passes * rot_blocks;
+  hipLaunchKernelGGL(rtcsm_score_box_kernel, dim3(blocks), dim3(64 * nw), lds, ctx->stream, g, p, cloud.d_xs,
+                     cloud.d_ys, cloud.d_zs);
+  DLIOM_HIP_TRY(hipGetLastError());
+  return DLIOM_OK;
+}
+
 // Launches the score-volume kernel; *pad_processed = padding points visited (each adds 1 to
 // every sum).
 static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid,
@@ -1135,16 +1391,41 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   DLIOM_HIP_TRY(hipMemsetAsync(*d_sums, 0, static_cast<size_t>(C) * 8, ctx->stream));
   const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
   const int n = static_cast<int>(cloud.n);
-  // 2: rotation per lane over the dense mirror (default when the grid allows it),
-  // 1: rotation per lane over the leaf table, 0: point per lane over the leaf table
-  static const int wanted_mapping = env_int("DLIOM_SCORE_MAPPING", 2);
+  // 3: LDS-box kernel over the dense mirror (score_box.h; default when the search suits it),
+  // 2: rotation per lane over the dense mirror, 1: rotation per lane over the leaf table,
+  // 0: point per lane over the leaf table
+  static const int wanted_mapping = env_int("DLIOM_SCORE_MAPPING", 3);
   int mapping = wanted_mapping;
-  if (mapping == 2) {
+  if (ctx->force_dense_score && mapping > 2) mapping = 2;
+  ctx->last_score_used_box = false;
+  if (mapping >= 2) {
     // the mirror is a cache of the grid's contents: building it does not change the grid
     if (const_cast<dliom_grid*>(grid)->ensure_dense() != DLIOM_OK) mapping = 1;  // too large: leaf path
   }
   const GridView g = grid->view();
   DLIOM_TRY(ensure_morton(ctx, &cloud));
+  if (mapping == 3) {
+    static const int box_min_pairs_log2 = env_int("DLIOM_BOX_MIN_LOG2", 24);  // small searches: launch-bound anyway
+    const double pairs = static_cast<double>(C) * static_cast<double>(n);
+    int s3 = DLIOM_ERR_CAPACITY;
+    if (T >= 8 && pairs >= std::ldexp(1.0, box_min_pairs_log2)) {
+      DLIOM_TRY(ctx->box_error.reserve(256));
+      if (!ctx->box_error_zeroed) {
+        DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_error.p, 0, 256, ctx->stream));
+        ctx->box_error_zeroed = true;
+      }
+      const int span3 = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
+      s3 = launch_score_box(ctx, cloud, g, c, *d, r_first, r_last, *d_sums, ctx->box_error.as<unsigned>());
+      ctx->end_span(span3);
+    }
+    if (s3 == DLIOM_OK) {
+      *pad_processed = 0;
+      ctx->last_score_used_box = true;
+      return DLIOM_OK;
+    }
+    if (s3 != DLIOM_ERR_CAPACITY) return s3;
+    mapping = 2;
+  }
   static const int forced_ppt = env_int("DLIOM_SCORE_PPT", 0);   // tuning knobs
   static const int target_blocks = env_int("DLIOM_SCORE_BLOCKS", 8192);
   const int Rs = r_last - r_first;  // rotations of this shard
@@ -1381,7 +1662,19 @@ struct RtcsmState {
   float best_score = -1.f;
   int64_t best_c = -1;
   bool active = false;
+  double init7[7] = {0, 0, 0, 1, 0, 0, 0};
+  int shard = 0, num_shards = 1;
+  bool used_box = false;
 };
+
+// The LDS-box kernel reports a level-1 list overflow in box_error[1]: the sums are then incomplete and the
+// match is redone with the dense kernel.  `err1` is the word as read back; clears it on the device.
+static int box_overflowed(dliom_ctx* ctx, unsigned err1, bool* overflow) {
+  *overflow = err1 != 0u;
+  if (*overflow)
+    DLIOM_HIP_TRY(hipMemsetAsync(static_cast<char*>(ctx->box_error.p) + 4, 0, 4, ctx->stream));
+  return DLIOM_OK;
+}
 
 static RtcsmState* state_of(dliom_ctx* ctx) {
   if (ctx->rtcsm_state == nullptr) {
@@ -1405,6 +1698,10 @@ static int match_begin(dliom_ctx* ctx, const dliom_rtcsm_options* o, const doubl
   st->o = *o;
   st->cloud = cloud;
   st->grid = grid;
+  std::memcpy(st->init7, init7, sizeof st->init7);
+  st->shard = shard;
+  st->num_shards = num_shards;
+  st->used_box = false;
   Candidates& c = st->c;
   generate_candidates(*o, grid->resolution, cloud.max_norm, init7, &c);
   const int64_t C = c.w.num_candidates;
@@ -1425,6 +1722,7 @@ static int match_begin(dliom_ctx* ctx, const dliom_rtcsm_options* o, const doubl
     int64_t pad_processed = 0;
     DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, st->r_first, st->r_last, &st->d, &st->d_sums,
                                &pad_processed));
+    st->used_box = ctx->last_score_used_box;
     const LutModel& lm = lut_model();
     BoundParams bp;
     bp.a = lm.a;
@@ -1447,8 +1745,21 @@ static int match_begin(dliom_ctx* ctx, const dliom_rtcsm_options* o, const doubl
     DLIOM_HIP_TRY(hipGetLastError());
   }
   if (local_best_lo_bits != nullptr) {
+    unsigned* h_err = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 4096 + 2048);
+    *h_err = 0u;
     DLIOM_HIP_TRY(hipMemcpyAsync(local_best_lo_bits, st->d_ctrs, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (st->used_box)
+      DLIOM_HIP_TRY(hipMemcpyAsync(h_err, static_cast<char*>(ctx->box_error.p) + 4, 4, hipMemcpyDeviceToHost, ctx->stream));
     DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    bool overflow = false;
+    DLIOM_TRY(box_overflowed(ctx, *h_err, &overflow));
+    if (overflow && !ctx->force_dense_score) {
+      ctx->force_dense_score = true;
+      const dliom_rtcsm_options o_copy = st->o;
+      const int s = match_begin(ctx, &o_copy, init7, cloud, grid, shard, num_shards, local_best_lo_bits);
+      ctx->force_dense_score = false;
+      return s;
+    }
   }
   st->active = true;
   return DLIOM_OK;
@@ -1500,10 +1811,29 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
       return s;
     };
     DLIOM_TRY(rescore(kSpecK, st->d_ctrs + 1, 0));
+    unsigned* h_err = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 4096 + 2048);
+    *h_err = 0u;
+    if (st->used_box && global_best_lo_bits == nullptr)
+      DLIOM_HIP_TRY(hipMemcpyAsync(h_err, static_cast<char*>(ctx->box_error.p) + 4, 4, hipMemcpyDeviceToHost, ctx->stream));
     DLIOM_HIP_TRY(hipMemcpyAsync(h_ctrs, st->d_ctrs, 8, hipMemcpyDeviceToHost, ctx->stream));
     DLIOM_HIP_TRY(hipMemcpyAsync(h_list, st->d_list, kSpecK * 4, hipMemcpyDeviceToHost, ctx->stream));
     DLIOM_HIP_TRY(hipMemcpyAsync(h_sums, ctx->rescore.p, kSpecK * 4, hipMemcpyDeviceToHost, ctx->stream));
     DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+      bool overflow = false;
+      DLIOM_TRY(box_overflowed(ctx, *h_err, &overflow));
+      if (overflow && !ctx->force_dense_score) {  // redo the whole match on the dense kernel
+        ctx->force_dense_score = true;
+        const dliom_rtcsm_options o_copy = st->o;
+        const dliom_cloud cloud_copy = st->cloud;
+        double init_copy[7];
+        std::memcpy(init_copy, st->init7, sizeof init_copy);
+        int s = match_begin(ctx, &o_copy, init_copy, cloud_copy, st->grid, st->shard, st->num_shards, nullptr);
+        if (s == DLIOM_OK) s = match_finish(ctx, nullptr, local_best_packed);
+        ctx->force_dense_score = false;
+        return s;
+      }
+    }
     K = h_ctrs[1];
     const unsigned first = std::min(K, kSpecK);
     list.assign(h_list, h_list + first);
@@ -1691,6 +2021,16 @@ int dliom_rtcsm3d_shard_decode(dliom_ctx* ctx, uint64_t global_best_packed, doub
   return match_decode(ctx, global_best_packed, pose_estimate, score);
 }
 
+int dliom_rtcsm3d_box_error(dliom_ctx* ctx, uint32_t* flags) {
+  if (ctx == nullptr || flags == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *flags = 0;
+  if (ctx->box_error.p == nullptr) return DLIOM_OK;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_HIP_TRY(hipMemcpyAsync(flags, ctx->box_error.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
 int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats) {
   if (ctx == nullptr || stats == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   *stats = ctx->last_rtcsm;
@@ -1717,9 +2057,24 @@ int dliom_rtcsm3d_score_volume(dliom_ctx* ctx, const dliom_rtcsm_options* o, con
   int64_t pad_processed = 0;
   DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, 0, static_cast<int>(c.w.num_rotations), &d, &d_sums,
                              &pad_processed));
+  unsigned err1 = 0u;
+  if (ctx->last_score_used_box)
+    DLIOM_HIP_TRY(hipMemcpyAsync(&err1, static_cast<char*>(ctx->box_error.p) + 4, 4, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_sums, static_cast<size_t>(c.w.num_candidates) * 8,
                                hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  {
+    bool overflow = false;
+    DLIOM_TRY(box_overflowed(ctx, err1, &overflow));
+    if (overflow) {
+      ctx->force_dense_score = true;
+      const int s = run_score_volume(ctx, cloud, grid, c, 0, static_cast<int>(c.w.num_rotations), &d, &d_sums, &pad_processed);
+      ctx->force_dense_score = false;
+      DLIOM_TRY(s);
+      DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_sums, static_cast<size_t>(c.w.num_candidates) * 8, hipMemcpyDeviceToHost, ctx->stream));
+      DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+  }
   const uint64_t n_pad = static_cast<uint64_t>(pad_processed);
   for (int64_t i = 0; i < c.w.num_candidates; ++i) sums[i] -= n_pad;
   return DLIOM_OK;

@@ -1,0 +1,578 @@
+// RTCSM3D score volume, LDS-box kernel (round 2).  Included by rtcsm3d.hip only.
+//
+// Same exact integer sums as rtcsm_score_dense_kernel (sum_i max(v_i & 0x7fff, 1) per candidate,
+// real_time_correlative_scan_matcher_3d.cc:97-104), restructured around what the gfx950 pipes
+// can do (profiles/r2_ubench_instruction_rates.json, r2_score_pipe_experiment.json):
+//   * a non-coalesced global gather costs the texture addresser 16-29 cycles per wave -- a u16 gather
+//     out of LDS 2-6.  A WORKGROUP stages the sub-box of the dense mirror that its (up to 256) candidate
+//     rotations can reach from a chunk of Morton-adjacent points ("LDS-staged tiles"); each wave walks the
+//     chunk with its own 64 rotations and gathers with ds_read_u16;
+//   * only v_add/sub/mul/fma_f32, v_add/sub_u32, v_and/or/xor, v_lshrrev run at 2 cycles per wave;
+//     v_cvt/v_fract/v_floor/min/max/cmp, every VOP3 integer op, every SDWA op and any VALU op with an
+//     SGPR operand take 4.  The per-lookup index math is: one v_add_f32 per axis (the translation is
+//     added to a pre-scaled coordinate kept in [128, 256), where the float's own bit layout IS
+//     [cell : 7 bits | fraction : 16 bits]) and three v_mad_u32_u16 that read the cell index straight
+//     out of the high half: 7 VALU per lookup, no test, no branch, no scalar work;
+//   * accumulators live in registers (the 27 translations of a pass are unrolled) and are flushed once per
+//     wave: ~7 M 64-bit atomics per launch instead of 74 M.
+// Exactness without a per-lookup test.  A fast lookup can differ from the reference's cell only when its
+// scaled coordinate w lies within a rounding band of a cell boundary (budget below).  Whether ANY of the
+// 27 translations of a pass puts a rotated point into a band depends, per axis, only on the fraction of
+// its scaled coordinate: the host marks those fractions in a bitmap (8192 buckets per axis); the kernel
+// tests the three fractions once per (rotation, point) -- 1/27 of the lookups -- and lists the ~2 % that
+// hit.  Listed (rotation, point) pairs are re-examined 64 at a time, one per lane (level 1: which
+// translations are really inside a band), and those lookups are resolved with the exact IEEE division
+// path, again one per lane (level 2); where the exact cell differs from the fast one the difference of
+// the two grid values is added to the score volume with an atomic (rare).
+//
+// Error budget of the fast index (u = 2^-16 cells, the ulp of a float in [128, 256)):
+//   reference  c = fl(r + t), Q = fl(c / res), i = lround(Q)            (hybrid_grid.h:430-435)
+//   here       w = fl( fl(r * inv + Kb) + tau ),  l = floor(w) - 128    (inv = fl(1 / res))
+//   with  Kb + tau == t / res + 128.5 + s u - i_lo  up to 2^-24 |tau|  (host, double)
+//   |w - (W + s u)| <= u  (two roundings of results < 256)  +  |r / res| 2^-24  (inv)  +  |tau| 2^-24
+//   the reference's i can differ from floor(q + 1/2), q = (r + t) / res real, only when q + 1/2 is
+//   within 2 |q| 2^-24 of an integer (its two roundings; exact ties included)
+//   => E = u + (2 qmax + rmax + taumax) 2^-24;  B = ceil(E / u + 1/4), shift s >= B, and a lookup is
+//   resolved by the fast path only if frac16(w) > s + B -- then floor(w) is the reference's cell.
+#ifndef DLIOM_CSRC_SCORE_BOX_H_
+#define DLIOM_CSRC_SCORE_BOX_H_
+
+#include "device_common.h"
+
+namespace dliom {
+namespace box {
+
+constexpr int kTC = 27;        // translations per pass (register accumulators)
+constexpr int kWaves = 4;      // waves per workgroup at most: consecutive rotation groups, the same point chunks
+constexpr int kMaxDim = 120;   // box cells per axis (scaled coordinates stay below 256)
+constexpr int kMaxChunk = 64;  // points per chunk at most (one per lane in the bounding-box pass)
+constexpr int kBuckets = 8192; // fraction buckets per axis of the band bitmap
+constexpr int kBitmapWords = 3 * kBuckets / 32;
+constexpr int kL1Cap = 320;    // level-1 list: (rotation lane, point, chunk record) per entry
+constexpr int kL2Cap = 128;    // level-2 list: (level-1 slot, translation)
+#ifndef DLIOM_BOX_HOT_P
+#define DLIOM_BOX_HOT_P 4
+#endif
+constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4)
+constexpr int kBatch = 4;      // point chunks per ticket of the work dispenser
+constexpr int kRecords = 8;    // ring of chunk records (lo[3], first point) the level-1 entries refer to
+constexpr int kListWords = kL1Cap + kL2Cap + 4 * kRecords;
+
+struct Pass {      // one per translation pass
+  int gi[3];       // floor(G), G = t_c / res + 128.5 + s u  (t_c: centre translation of the pass)
+  float f[3];      // fraction of G rounded to 14 bits (Kb = float(gi - i_lo) + f is exact)
+  float uc[3];     // float(t_c / res + 0.5): coordinate constant of the bounding-box pass
+  float reach[3];  // max_j |tau_j| per axis + slack (cells)
+  int tc;          // translations in this pass (<= kTC)
+  int j0;          // first translation of the pass
+  int pad[2];
+};
+
+struct Group {     // spread of a workgroup's rotations around its centre lane (host, double):
+  int c_lane;      //   q_lane = q_centre * d_lane,  d_lane = exp(delta_lane)
+  float dc[3];     // centre of the bounding box of the delta_lane (rotation vectors, point frame)
+  float hd[3];     // its half extents
+  float theta2;    // 0.51 max |delta|^2: bound of |R(delta) p - p - delta x p| / |p|
+};
+
+struct Params {
+  const float4* tau;       // passes * kTC entries (x, y, z, 0): translation minus G, in cells
+  const Pass* pass;
+  const unsigned* bitmap;  // passes * kBitmapWords: fractions that reach a rounding band, per axis
+  const float* trans;      // T x 3: the reference's float translations (exact path)
+  const float4* rot;       // candidate rotations (w, x, y, z)
+  const Group* group;      // one per workgroup's rotations (nw * 64 from r_first on)
+  unsigned long long* sums;
+  unsigned* counters;      // passes * rot_groups chunk dispensers, zeroed by the host before the launch
+  unsigned* error;         // [0] sticky: an exact cell more than one cell from the fast one (cannot happen);
+                           // [1] a level-1 list overflowed -- the host reruns the match with the dense kernel
+  int R, r_first, r_last, T, passes;
+  int n;                   // real points (Morton order)
+  int chunk;               // points per chunk, multiple of 4
+  int point_chunks, rot_groups, rot_blocks, nw, slots;  // nw waves per workgroup, rot_blocks = ceil(rot_groups / nw)
+  unsigned thr;            // unresolved  <=>  (bits(w) & 0xffff) <= thr
+  int cells;               // LDS box capacity per workgroup (cells)
+  int debug;               // timing experiments only (wrong sums): 1 skip the lists, 2 skip staging, 4 skip the lookups
+};
+
+typedef __attribute__((address_space(3))) const unsigned short lds_cu16;
+
+__device__ __forceinline__ unsigned min_lo16(unsigned running, float w) {
+  unsigned r;
+  asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+      : "=v"(r)
+      : "v"(running), "v"(w));
+  return r;
+}
+// hi16(w) * m + a
+__device__ __forceinline__ unsigned mad_hi16(float w, unsigned m, unsigned a) {
+  unsigned r;
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(w), "v"(m), "v"(a));
+  return r;
+}
+__device__ __forceinline__ unsigned to_vgpr(unsigned s) {
+  unsigned v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+__device__ __forceinline__ float to_vgpr_f(float s) {
+  float v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+// Maximum over the 64 lanes (DPP butterfly: quad swaps, row half mirror, row mirror, the two row
+// broadcasts; no LDS traffic), returned in every lane.
+__device__ __forceinline__ float wave_max_f(float v) {
+#define DLIOM_DPP_MAX(ctrl, row_mask)                                                                      \
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, row_mask, 0xf, false)))
+  DLIOM_DPP_MAX(0xB1, 0xf);
+  DLIOM_DPP_MAX(0x4E, 0xf);
+  DLIOM_DPP_MAX(0x141, 0xf);
+  DLIOM_DPP_MAX(0x140, 0xf);
+  DLIOM_DPP_MAX(0x142, 0xa);
+  DLIOM_DPP_MAX(0x143, 0xc);
+#undef DLIOM_DPP_MAX
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_min_f(float v) { return -wave_max_f(-v); }
+
+struct Geometry {   // wave-uniform description of the current box
+  int lo[3];        // reference cell index of box cell (0, 0, 0)
+  int dim[3];
+  unsigned sx, sxy; // strides in cells (row, slab)
+  float kb[3];
+};
+
+// value the matcher sums at reference cell (ix, iy, iz), straight from the mirror in HBM (outside: 1)
+__device__ __forceinline__ unsigned mirror_value(const GridView& g, int ix, int iy, int iz) {
+  const int S = g.dense_stride, B = g.dense_bricks;
+  const int mx = ix + g.half + 1, my = iy + g.half + 1, mz = iz + g.half + 1;
+  if (mx < 0 || mx >= S || my < 0 || my >= S || mz < 0 || mz >= S) return 1u;
+  return g.dense[((static_cast<size_t>(mz >> 2) * B + (my >> 2)) * B + (mx >> 2)) * 64u +
+                 static_cast<size_t>(((mz & 3) << 4) | ((my & 3) << 2) | (mx & 3))];
+}
+
+// ---- the lists ---------------------------------------------------------------------------------------
+struct Lists {
+  unsigned* l1;    // kL1Cap entries: lane | point-in-chunk << 6 | record << 12
+  unsigned* l2;    // kL2Cap entries: level-1 slot | translation << 8
+  int* rec;        // kRecords x (lo[3], first point of the chunk)
+  int n1;          // wave-uniform counts
+  int seq;         // chunk records written so far
+  bool overflow;
+};
+
+// Level 2: one listed lookup per lane, resolved with the reference's own arithmetic.
+__device__ __forceinline__ void resolve_l2(const GridView& g, const Params& p, const Pass& ps, const float4* lds_tau,
+                                           const float* __restrict__ px, const float* __restrict__ py,
+                                           const float* __restrict__ pz, const Lists& ls, int base1, int n2, int rot0,
+                                           int lane) {
+  for (int e0 = 0; e0 < n2; e0 += 64) {
+    const int e = e0 + lane;
+    if (e < n2) {
+      const unsigned item = ls.l2[e];
+      const unsigned ent = ls.l1[base1 + static_cast<int>(item & 0xFFu)];
+      const int j = static_cast<int>(item >> 8);
+      const int* rc = ls.rec + 4 * static_cast<int>((ent >> 12) & (kRecords - 1));
+      const int r = rot0 + static_cast<int>(ent & 63u), pt = rc[3] + static_cast<int>((ent >> 6) & 63u);
+      const float4 qq = p.rot[r];
+      const Quat4 q{qq.x, qq.y, qq.z, qq.w};
+      float rx, ry, rz;
+      rotate_point(q, px[pt], py[pt], pz[pt], rx, ry, rz);
+      // the cell the fast path read
+      const float4 t = lds_tau[j];
+      const float ax = __builtin_fmaf(rx, g.inv_resolution, static_cast<float>(ps.gi[0] - rc[0]) + ps.f[0]) + t.x;
+      const float ay = __builtin_fmaf(ry, g.inv_resolution, static_cast<float>(ps.gi[1] - rc[1]) + ps.f[1]) + t.y;
+      const float az = __builtin_fmaf(rz, g.inv_resolution, static_cast<float>(ps.gi[2] - rc[2]) + ps.f[2]) + t.z;
+      const int fx = static_cast<int>((__float_as_uint(ax) >> 16) - 0x4300u) + rc[0];
+      const int fy = static_cast<int>((__float_as_uint(ay) >> 16) - 0x4300u) + rc[1];
+      const int fz = static_cast<int>((__float_as_uint(az) >> 16) - 0x4300u) + rc[2];
+      // the reference's cell (hybrid_grid.h:430-435)
+      const float* tr = p.trans + 3 * (ps.j0 + j);
+      const int ex = cell_of(rx + tr[0], g.resolution), ey = cell_of(ry + tr[1], g.resolution),
+                ez = cell_of(rz + tr[2], g.resolution);
+      if (ex != fx || ey != fy || ez != fz) {
+        if (abs(ex - fx) > 1 || abs(ey - fy) > 1 || abs(ez - fz) > 1) atomicOr(p.error, 1u);  // cannot happen
+        const long long delta = static_cast<long long>(mirror_value(g, ex, ey, ez)) -
+                                static_cast<long long>(mirror_value(g, fx, fy, fz));
+        if (delta != 0)
+          atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + r], static_cast<unsigned long long>(delta));
+      }
+    }
+  }
+}
+
+// Level 1: up to 64 listed (rotation, point) pairs, one per lane: which of the pass's translations put
+// the point inside a rounding band?  Those lookups go to the level-2 list.
+__device__ __forceinline__ void resolve_l1(const GridView& g, const Params& p, const Pass& ps, const float4* lds_tau,
+                                           const float* __restrict__ px, const float* __restrict__ py,
+                                           const float* __restrict__ pz, const Lists& ls, int base1, int count, int rot0,
+                                           int lane) {
+  const bool have = lane < count;
+  float wx = 200.5f, wy = 200.5f, wz = 200.5f;  // idle lanes: a fraction of one half is never listed
+  if (have) {
+    const unsigned ent = ls.l1[base1 + lane];
+    const int* rc = ls.rec + 4 * static_cast<int>((ent >> 12) & (kRecords - 1));
+    const int r = rot0 + static_cast<int>(ent & 63u), pt = rc[3] + static_cast<int>((ent >> 6) & 63u);
+    const float4 qq = p.rot[r];
+    const Quat4 q{qq.x, qq.y, qq.z, qq.w};
+    float rx, ry, rz;
+    rotate_point(q, px[pt], py[pt], pz[pt], rx, ry, rz);
+    wx = __builtin_fmaf(rx, g.inv_resolution, static_cast<float>(ps.gi[0] - rc[0]) + ps.f[0]);
+    wy = __builtin_fmaf(ry, g.inv_resolution, static_cast<float>(ps.gi[1] - rc[1]) + ps.f[1]);
+    wz = __builtin_fmaf(rz, g.inv_resolution, static_cast<float>(ps.gi[2] - rc[2]) + ps.f[2]);
+  }
+  int n2 = 0;
+  for (int j = 0; j < ps.tc; ++j) {
+    const float4 t = lds_tau[j];
+    unsigned m = min_lo16(0xFFFFFFFFu, wx + t.x);
+    m = min_lo16(m, wy + t.y);
+    m = min_lo16(m, wz + t.z);
+    const bool mine = have && m <= p.thr;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
+    if (mask != 0ull) {
+      if (n2 + 64 > kL2Cap) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        resolve_l2(g, p, ps, lds_tau, px, py, pz, ls, base1, n2, rot0, lane);
+        __builtin_amdgcn_wave_barrier();
+        n2 = 0;
+      }
+      const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
+      if (mine) ls.l2[n2 + rank] = static_cast<unsigned>(lane) | (static_cast<unsigned>(j) << 8);
+      n2 += __builtin_popcountll(mask);
+    }
+  }
+  if (n2 > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    resolve_l2(g, p, ps, lds_tau, px, py, pz, ls, base1, n2, rot0, lane);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Drains the level-1 list in groups of 64; keeps a remainder below 64 unless `all`.
+__device__ __forceinline__ void drain_l1(const GridView& g, const Params& p, const Pass& ps, const float4* lds_tau,
+                                         const float* __restrict__ px, const float* __restrict__ py,
+                                         const float* __restrict__ pz, Lists& ls, bool all, int rot0, int lane) {
+  int base = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  while (ls.n1 - base >= 64 || (all && ls.n1 > base)) {
+    const int count = min(64, ls.n1 - base);
+    resolve_l1(g, p, ps, lds_tau, px, py, pz, ls, base, count, rot0, lane);
+    base += count;
+  }
+  if (base > 0) {  // move the remainder to the front
+    const int rest = ls.n1 - base;
+    unsigned v = 0;
+    if (lane < rest) v = ls.l1[base + lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) ls.l1[lane] = v;
+    ls.n1 = rest;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- the hot loop --------------------------------------------------------------------------------------
+// Returns the first point NOT processed: the loop stops early when the level-1 list could not take the
+// worst case of another iteration (every lane listed for every point) -- the caller drains it and re-enters.
+template <int P>
+__device__ __forceinline__ int main_loop(const GridView& g, const Params& p, const Geometry& geo, const Quat4 q,
+                                          const float* __restrict__ px, const float* __restrict__ py,
+                                          const float* __restrict__ pz, int i_begin, int i_end, int chunk_lo,
+                                          const float4* lds_tau, const unsigned* lds_bitmap, unsigned box_base,
+                                          Lists& ls, unsigned rec_id, bool lane_active, int lane,
+                                          unsigned (&acc)[kTC]) {
+  const float inv = to_vgpr_f(g.inv_resolution);
+  const float kbx = to_vgpr_f(geo.kb[0]), kby = to_vgpr_f(geo.kb[1]), kbz = to_vgpr_f(geo.kb[2]);
+  const unsigned s1 = 2u * geo.sx, s2 = 2u * geo.sxy;
+  const unsigned v2 = to_vgpr(2u), v1 = to_vgpr(s1), vs2 = to_vgpr(s2);
+  const unsigned d0 = to_vgpr(box_base - 0x4300u * (2u + s1 + s2));
+  int i = i_begin;
+#pragma unroll 1
+  for (; i < i_end; i += P) {
+    if (ls.n1 + 64 * P > kL1Cap) break;
+    float wx[P], wy[P], wz[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      float rx, ry, rz;
+      rotate_point(q, px[i + k], py[i + k], pz[i + k], rx, ry, rz);
+      wx[k] = __builtin_fmaf(rx, inv, kbx);
+      wy[k] = __builtin_fmaf(ry, inv, kby);
+      wz[k] = __builtin_fmaf(rz, inv, kbz);
+    }
+    // once per (rotation, point): can any translation of the pass put a coordinate into a rounding band?
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      const unsigned bx = static_cast<unsigned>(__builtin_amdgcn_fractf(wx[k]) * static_cast<float>(kBuckets));
+      const unsigned by = static_cast<unsigned>(__builtin_amdgcn_fractf(wy[k]) * static_cast<float>(kBuckets));
+      const unsigned bz = static_cast<unsigned>(__builtin_amdgcn_fractf(wz[k]) * static_cast<float>(kBuckets));
+      const unsigned hit = ((lds_bitmap[bx >> 5] >> (bx & 31u)) | (lds_bitmap[kBuckets / 32 + (by >> 5)] >> (by & 31u)) |
+                            (lds_bitmap[2 * (kBuckets / 32) + (bz >> 5)] >> (bz & 31u))) & 1u;
+      const bool mine = lane_active && hit != 0u;
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
+      if (mask != 0ull) {
+        const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
+        if (mine)
+          ls.l1[ls.n1 + rank] = static_cast<unsigned>(lane) | (static_cast<unsigned>(i + k - chunk_lo) << 6) | (rec_id << 12);
+        ls.n1 += __builtin_popcountll(mask);
+      }
+    }
+    // software pipeline, fixed by scheduling barriers: the translation of step j + 1 is fetched and the
+    // values gathered in step j - 1 are accumulated while the gathers of step j are in flight
+    float4 t = lds_tau[0];
+    unsigned pv[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) pv[k] = 0u;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < kTC; ++j) {
+      const float4 tn = lds_tau[j + 1 < kTC ? j + 1 : j];  // same address in every lane: LDS broadcast
+      unsigned v[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const float ax = wx[k] + t.x, ay = wy[k] + t.y, az = wz[k] + t.z;
+        const unsigned a = mad_hi16(az, vs2, mad_hi16(ay, v1, mad_hi16(ax, v2, d0)));
+        v[k] = *reinterpret_cast<lds_cu16*>(a);
+      }
+      if (j > 0) {
+        unsigned s = pv[0];
+#pragma unroll
+        for (int k = 1; k < P; ++k) s += pv[k];
+        acc[j - 1] += s;
+        asm volatile("" : "+v"(acc[j - 1]));  // keeps the add here (it would be sunk to the loop latch, values spilled)
+      }
+#pragma unroll
+      for (int k = 0; k < P; ++k) pv[k] = v[k];
+      t = tn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      unsigned s = pv[0];
+#pragma unroll
+      for (int k = 1; k < P; ++k) s += pv[k];
+      acc[kTC - 1] += s;
+      asm volatile("" : "+v"(acc[kTC - 1]));
+    }
+  }
+  return i;
+}
+
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rtcsm_score_box_kernel(
+    GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
+  extern __shared__ float4 lds_dyn4[];  // [kTC tau | band bitmap | ticket words | nw x lists | box]
+  float4* lds_tau = lds_dyn4;
+  unsigned* lds_bitmap = reinterpret_cast<unsigned*>(lds_dyn4 + kTC);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nthreads = blockDim.x;
+  // this workgroup: (pass, rotation block); several workgroups share one and draw point chunks together
+  const int rb = blockIdx.x % p.rot_blocks;
+  const int tp = (blockIdx.x / p.rot_blocks) % p.passes;
+  const int slot = blockIdx.x / (p.rot_blocks * p.passes);
+  if (threadIdx.x < kTC) lds_tau[threadIdx.x] = p.tau[tp * kTC + threadIdx.x];
+  for (int w = threadIdx.x; w < kBitmapWords; w += nthreads) lds_bitmap[w] = p.bitmap[tp * kBitmapWords + w];
+  __syncthreads();
+  const int rot_b0 = p.r_first + rb * p.nw * 64;  // first rotation of the workgroup
+  const int rot0 = rot_b0 + wave * 64;            // ... of this wave
+  const bool wave_active = rot0 < p.r_last;       // surplus waves of the last workgroup only help staging
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char*)lds_dyn4));  // LDS byte address of the block
+  const unsigned tick_off = static_cast<unsigned>(kTC * sizeof(float4)) + kBitmapWords * 4u;
+  const unsigned lists_off = tick_off + 16u;
+  const unsigned box_off = lists_off + kWaves * kListWords * 4u;
+  const unsigned box_base = lds0 + box_off;
+  unsigned short* box = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(lds_dyn4) + box_off);
+  unsigned* tick = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_dyn4) + tick_off);
+  Lists ls;
+  ls.l1 = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_dyn4) + lists_off) + wave * kListWords;
+  ls.l2 = ls.l1 + kL1Cap;
+  ls.rec = reinterpret_cast<int*>(ls.l2 + kL2Cap);
+  ls.n1 = 0;
+  ls.seq = 0;
+  ls.overflow = false;
+  const Pass ps = p.pass[tp];
+  const bool lane_active = rot0 + lane < p.r_last;
+  const float4 qq = p.rot[lane_active ? rot0 + lane : (wave_active ? rot0 : rot_b0)];  // idle lanes shadow a real rotation
+  const Quat4 q{qq.x, qq.y, qq.z, qq.w};
+  const float inv = g.inv_resolution;
+  const Group grp = p.group[rb];
+  const float4 qcc = p.rot[rot_b0 + grp.c_lane];
+  const Quat4 qc{qcc.x, qcc.y, qcc.z, qcc.w};
+  float rabs[9];  // |R(qc)|, row major
+  {
+    const float w = qc.w, x = qc.x, y = qc.y, z = qc.z;
+    rabs[0] = fabsf(1.f - 2.f * (y * y + z * z));
+    rabs[1] = fabsf(2.f * (x * y - w * z));
+    rabs[2] = fabsf(2.f * (x * z + w * y));
+    rabs[3] = fabsf(2.f * (x * y + w * z));
+    rabs[4] = fabsf(1.f - 2.f * (x * x + z * z));
+    rabs[5] = fabsf(2.f * (y * z - w * x));
+    rabs[6] = fabsf(2.f * (x * z - w * y));
+    rabs[7] = fabsf(2.f * (y * z + w * x));
+    rabs[8] = fabsf(1.f - 2.f * (x * x + y * y));
+  }
+  unsigned acc[kTC];
+#pragma unroll
+  for (int j = 0; j < kTC; ++j) acc[j] = 0u;
+  const int S = g.dense_stride, B = g.dense_bricks;
+  // Point chunks are handed out by one counter per (pass, rotation block): workgroups that meet cheap chunks
+  // simply take more.  A ticket is a batch of kBatch consecutive chunks; the first one is the workgroup's own
+  // slot (no atomic: same-address atomics serialise at ~0.15 us each), later ones are drawn from the counter
+  // while the current batch is processed.  Control flow below is uniform over the WORKGROUP (barriers).
+  unsigned* counter = p.counters + tp * p.rot_blocks + rb;
+  const int num_batches = (p.point_chunks + kBatch - 1) / kBatch;
+  int ticket = (p.debug & 8) ? num_batches : slot;
+  int n_guess = p.chunk;  // points per box that fitted last time
+  int parity = 0;
+  while (ticket < num_batches) {
+    unsigned next_raw = 0u;
+    if (threadIdx.x == 0) next_raw = atomicAdd(counter, 1u);  // in flight while this batch is processed
+    for (int c = ticket * kBatch; c < min((ticket + 1) * kBatch, p.point_chunks); ++c) {
+      const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
+      int lo = c_begin;
+      while (lo < c_end) {
+        int n = min(c_end - lo, n_guess);
+        Geometry geo;
+        bool fits_out = false;
+        // ---- bounding box of every lookup of (these points) x (the workgroup's rotations) x (this pass);
+        //      every wave computes the same box from the same inputs
+        for (;;) {
+          // lanes = POINTS here: every lookup of point p under rotation q_lane lies within
+          //   R_c (p + dc x p)  +-  |R_c| (hd (x) |p|)  +-  theta2 |p|      (metres, before the translation)
+          // of the centre lane's image (first-order spread of the rotations plus the second-order bound)
+          float lo_f[3], hi_f[3];
+          {
+            const bool have = lane < n;
+            const int i = lo + (have ? lane : 0);
+            const float x = px[i], y = py[i], z = pz[i];
+            const float sx_ = grp.dc[1] * z - grp.dc[2] * y, sy_ = grp.dc[2] * x - grp.dc[0] * z, sz_ = grp.dc[0] * y - grp.dc[1] * x;
+            float cx, cy, cz;
+            rotate_point(qc, x + sx_, y + sy_, z + sz_, cx, cy, cz);
+            const float fx = fabsf(x), fy = fabsf(y), fz = fabsf(z);
+            const float hx = grp.hd[1] * fz + grp.hd[2] * fy, hy = grp.hd[2] * fx + grp.hd[0] * fz, hz = grp.hd[0] * fy + grp.hd[1] * fx;
+            const float m2 = grp.theta2 * (fx + fy + fz) + 1.0e-5f * (fx + fy + fz);
+            const float c3[3] = {cx, cy, cz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              const float he = rabs[3 * a] * hx + rabs[3 * a + 1] * hy + rabs[3 * a + 2] * hz + m2;
+              const float l = __builtin_fmaf(c3[a] - he, inv, ps.uc[a]) - 0.05f, h = __builtin_fmaf(c3[a] + he, inv, ps.uc[a]) + 0.05f;
+              lo_f[a] = wave_min_f(have ? l : 3.0e38f);
+              hi_f[a] = wave_max_f(have ? h : -3.0e38f);
+            }
+          }
+          bool fits = true;
+          fits_out = false;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            // clamp far outliers: a box that large is rejected below anyway
+            const float l = fmaxf(lo_f[a] - ps.reach[a], -1.0e6f), h = fminf(hi_f[a] + ps.reach[a], 1.0e6f);
+            geo.lo[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(l)));
+            geo.dim[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(h))) - geo.lo[a] + 1;
+          }
+          {  // x: whole 4-cell groups of the bricked mirror (mirror coordinate = index + half + 1)
+            const int m_lo = (geo.lo[0] + g.half + 1) & ~3;
+            const int m_hi = geo.lo[0] + g.half + 1 + geo.dim[0];  // exclusive
+            geo.lo[0] = m_lo - g.half - 1;
+            geo.dim[0] = ((m_hi - m_lo) + 3) & ~3;
+          }
+          geo.sx = static_cast<unsigned>(geo.dim[0]);
+          if (((geo.sx >> 2) & 1u) == 0u) geo.sx += 4u;  // row stride = 2 * odd dwords: rows spread over banks
+          const unsigned sy = static_cast<unsigned>(geo.dim[1]) | 1u;
+          geo.sxy = geo.sx * sy;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            fits = fits && geo.dim[a] <= kMaxDim && abs(ps.gi[a] - geo.lo[a]) < 1000;
+            geo.kb[a] = static_cast<float>(ps.gi[a] - geo.lo[a]) + ps.f[a];
+          }
+          fits = fits && static_cast<long long>(geo.sxy) * geo.dim[2] <= p.cells && geo.sxy <= 32767u;
+          fits_out = fits;
+          if (fits) break;
+          if (n == 1) break;
+          n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
+        }
+        n_guess = min(p.chunk, n >= 4 ? 2 * n : 4);
+        if (!fits_out) {
+          // a single point whose lookups do not fit the box (huge angular window / far outlier): the exact
+          // path straight from the mirror in HBM, every lane its own rotation
+          float rx, ry, rz;
+          rotate_point(q, px[lo], py[lo], pz[lo], rx, ry, rz);
+#pragma unroll
+          for (int j = 0; j < kTC; ++j) {
+            const float* tr = p.trans + 3 * (ps.j0 + min(j, ps.tc - 1));
+            acc[j] += mirror_value(g, cell_of(rx + tr[0], g.resolution), cell_of(ry + tr[1], g.resolution),
+                                   cell_of(rz + tr[2], g.resolution));
+          }
+          lo += 1;
+          continue;
+        }
+        __syncthreads();  // every wave is done with the previous box
+        // ---- stage the box, all threads: 4-cell groups (8 bytes) of the bricked mirror, outside reads 1
+        if (!(p.debug & 2)) {
+          const int quads = geo.dim[0] >> 2;
+          const int total = quads * geo.dim[1] * geo.dim[2];
+          const float inv_q = 1.0f / static_cast<float>(quads), inv_dy = 1.0f / static_cast<float>(geo.dim[1]);
+#pragma unroll 4
+          for (int e = threadIdx.x; e < total; e += nthreads) {
+            const int row = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_q);  // exact: e < 2^21
+            const int xq = e - row * quads;
+            const int z = static_cast<int>((static_cast<float>(row) + 0.5f) * inv_dy);
+            const int y = row - z * geo.dim[1];
+            const int mx = geo.lo[0] + g.half + 1 + 4 * xq, my = geo.lo[1] + g.half + 1 + y, mz = geo.lo[2] + g.half + 1 + z;
+            unsigned long long val = 0x0001000100010001ull;
+            if (mx >= 0 && mx < 4 * B && my >= 0 && my < S && mz >= 0 && mz < S) {
+              const size_t off = ((static_cast<size_t>(mz >> 2) * B + (my >> 2)) * B + (mx >> 2)) * 128u +
+                                 static_cast<size_t>(((mz & 3) << 5) | ((my & 3) << 3));
+              val = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(g.dense) + off);
+            }
+            *reinterpret_cast<unsigned long long*>(box + (static_cast<unsigned>(z) * geo.sxy +
+                                                         static_cast<unsigned>(y) * geo.sx + 4u * static_cast<unsigned>(xq))) = val;
+          }
+        }
+        // chunk record for this wave's level-1 entries of these points
+        const unsigned rec_id = static_cast<unsigned>(ls.seq & (kRecords - 1));
+        if (lane < 4) ls.rec[4 * rec_id + lane] = lane < 3 ? geo.lo[lane] : lo;
+        ++ls.seq;
+        __syncthreads();  // the box is complete
+        // ---- all lookups of these points under this wave's rotations
+        if (wave_active && !(p.debug & 4)) {
+          int i = lo;
+          const int e8 = kHotP == 8 ? lo + (n & ~7) : lo, e4 = lo + (n & ~3), e1 = lo + n;
+          for (;;) {
+            if (kHotP == 8 && i < e8)
+              i = main_loop<kHotP>(g, p, geo, q, px, py, pz, i, e8, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+            if (i >= e8 && i < e4)
+              i = main_loop<4>(g, p, geo, q, px, py, pz, i, e4, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+            if (i >= e4 && i < e1)
+              i = main_loop<1>(g, p, geo, q, px, py, pz, i, e1, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+            if (i >= e1) break;
+            drain_l1(g, p, ps, lds_tau, px, py, pz, ls, false, rot0, lane);  // the list was too full to go on
+          }
+          // ---- listed pairs: 64 at a time; everything before the oldest record is overwritten
+          if (!(p.debug & 1) && (ls.n1 >= 64 || (ls.seq & (kRecords - 1)) == 0))
+            drain_l1(g, p, ps, lds_tau, px, py, pz, ls, (ls.seq & (kRecords - 1)) == 0, rot0, lane);
+        }
+        lo += n;
+      }
+    }
+    // the next ticket, through LDS (two words used alternately: one barrier per batch)
+    if (threadIdx.x == 0) tick[parity] = next_raw;
+    __syncthreads();
+    ticket = p.slots + static_cast<int>(tick[parity]);
+    parity ^= 1;
+  }
+  if (wave_active && !(p.debug & 1)) drain_l1(g, p, ps, lds_tau, px, py, pz, ls, true, rot0, lane);
+  if (lane_active) {
+#pragma unroll
+    for (int j = 0; j < kTC; ++j)
+      if (j < ps.tc)
+        atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + rot0 + lane], static_cast<unsigned long long>(acc[j]));
+  }
+}
+
+}  // namespace box
+}  // namespace dliom
+
+#endif  // DLIOM_CSRC_SCORE_BOX_H_

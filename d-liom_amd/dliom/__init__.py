@@ -192,6 +192,7 @@ SYMBOLS = [
     ("dliom_rtcsm3d_shard_decode", C.c_int, [_vp, C.c_uint64, _f64p, _f32p]),
     ("dliom_rtcsm3d_window", C.c_int, [C.POINTER(RtcsmOptions), C.c_float, _f32p, C.c_int64, C.POINTER(RtcsmWindow)]),
     ("dliom_rtcsm3d_last_stats", C.c_int, [_vp, C.POINTER(RtcsmStats)]),
+    ("dliom_rtcsm3d_box_error", C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     ("dliom_csm3d_match", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, C.c_int, C.POINTER(_f32p), _i64p,
                                     C.POINTER(_vp), _f64p, C.POINTER(CsmSummary)]),
     ("dliom_csm3d_match_cloud", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, C.c_int, C.POINTER(_vp),
@@ -606,6 +607,11 @@ class RealTimeCorrelativeScanMatcher3D:
         _check(self._L.dliom_rtcsm3d_window(C.byref(self.options), C.c_float(resolution), _p(pts, _f32p), len(pts),
                                             C.byref(w)), "dliom_rtcsm3d_window")
         return w
+
+    def box_error(self):
+        f = C.c_uint32(0)
+        _check(self._L.dliom_rtcsm3d_box_error(self.ctx.h, C.byref(f)), "box_error")
+        return f.value
 
     def last_stats(self):
         st = RtcsmStats()

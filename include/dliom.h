@@ -206,6 +206,9 @@ typedef struct dliom_rtcsm_stats {
   int64_t best_index;     /* generation order: ((z,y,x) * R + (rz,ry,rx)) */
 } dliom_rtcsm_stats;
 int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats);
+/* Diagnostic: sticky consistency flags of the LDS-box score kernel on this context (0 = every exactly
+ * resolved lookup fell inside its staged box, as the construction guarantees).  Synchronises. */
+int dliom_rtcsm3d_box_error(dliom_ctx* ctx, uint32_t* flags);
 
 /* ---- CeresScanMatcher3D ------------------------------------------------------
  * proto::CeresScanMatcherOptions3D + common.proto.CeresSolverOptions
