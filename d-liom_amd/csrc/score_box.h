@@ -110,6 +110,19 @@ __device__ __forceinline__ unsigned mad_hi16(float w, unsigned m, unsigned a) {
   asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(w), "v"(m), "v"(a));
   return r;
 }
+typedef float float2v __attribute__((ext_vector_type(2)));
+// {a.x + t.x, a.y + t.x}, {a.x + t.y, a.y + t.y}: one VOP3P instruction for two lookups (the kernel is
+// bound by instruction issue -- one per 4 cycles and SIMD whatever the type -- not by lane throughput)
+__device__ __forceinline__ float2v pk_add_lo(float2v a, float2v t) {
+  float2v r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
+__device__ __forceinline__ float2v pk_add_hi(float2v a, float2v t) {
+  float2v r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
 __device__ __forceinline__ unsigned to_vgpr(unsigned s) {
   unsigned v;
   asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
@@ -333,11 +346,41 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
     for (int j = 0; j < kTC; ++j) {
       const float4 tn = lds_tau[j + 1 < kTC ? j + 1 : j];  // same address in every lane: LDS broadcast
       unsigned v[P];
+      if (P % 2 == 0) {
+        // level by level over the P lookups: a dependent v_mad_u32_u16 right behind its producer costs a wait state
+        const float2v txy = {t.x, t.y}, tz0 = {t.z, t.w};
+        float2v ax[P / 2 + 1], ay[P / 2 + 1], az[P / 2 + 1];  // + 1: no zero-length arrays in the P = 1 instantiation
 #pragma unroll
-      for (int k = 0; k < P; ++k) {
-        const float ax = wx[k] + t.x, ay = wy[k] + t.y, az = wz[k] + t.z;
-        const unsigned a = mad_hi16(az, vs2, mad_hi16(ay, v1, mad_hi16(ax, v2, d0)));
-        v[k] = *reinterpret_cast<lds_cu16*>(a);
+        for (int k = 0; k < P / 2; ++k) {
+          ax[k] = pk_add_lo(float2v{wx[2 * k], wx[2 * k + 1]}, txy);
+          ay[k] = pk_add_hi(float2v{wy[2 * k], wy[2 * k + 1]}, txy);
+          az[k] = pk_add_lo(float2v{wz[2 * k], wz[2 * k + 1]}, tz0);
+        }
+        unsigned a[P];
+#pragma unroll
+        for (int k = 0; k < P / 2; ++k) {
+          a[2 * k] = mad_hi16(ax[k].x, v2, d0);
+          a[2 * k + 1] = mad_hi16(ax[k].y, v2, d0);
+        }
+#pragma unroll
+        for (int k = 0; k < P / 2; ++k) {
+          a[2 * k] = mad_hi16(ay[k].x, v1, a[2 * k]);
+          a[2 * k + 1] = mad_hi16(ay[k].y, v1, a[2 * k + 1]);
+        }
+#pragma unroll
+        for (int k = 0; k < P / 2; ++k) {
+          a[2 * k] = mad_hi16(az[k].x, vs2, a[2 * k]);
+          a[2 * k + 1] = mad_hi16(az[k].y, vs2, a[2 * k + 1]);
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) v[k] = *reinterpret_cast<lds_cu16*>(a[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          const float ax = wx[k] + t.x, ay = wy[k] + t.y, az = wz[k] + t.z;
+          const unsigned a = mad_hi16(az, vs2, mad_hi16(ay, v1, mad_hi16(ax, v2, d0)));
+          v[k] = *reinterpret_cast<lds_cu16*>(a);
+        }
       }
       if (j > 0) {
         unsigned s = pv[0];
