@@ -422,6 +422,44 @@ def rtcsm3d_match_range(opts, init7, pts, grid, first, count):
     return s, best.value
 
 
+def _ranges(total, parts):
+    step = (total + parts - 1) // parts
+    return [(f, min(step, total - f)) for f in range(0, total, step)]
+
+
+def rtcsm3d_match_parallel(opts, init7, pts, grid, threads=8):
+    """RealTimeCorrelativeScanMatcher3D::Match with the candidate loop cut into contiguous ranges that run
+    on `threads` host threads (ctypes releases the GIL); the ranges are combined in generation order with
+    the reference's strict `>`, so the result is the serial loop's (rtcsm_3d.cc:40-51)."""
+    from concurrent.futures import ThreadPoolExecutor
+    pts = _f32(pts).reshape(-1, 3)
+    o = _opts4(opts)
+    total = lib().orc_rtcsm3d_candidates(_p(o, _f64p), C.c_float(grid.resolution), _p(pts, _f32p), len(pts),
+                                         _p(_f64(init7), _f64p), None, None)
+    parts = _ranges(total, max(1, threads) * 4)
+    with ThreadPoolExecutor(max(1, threads)) as pool:
+        res = list(pool.map(lambda fc: rtcsm3d_match_range(opts, init7, pts, grid, fc[0], fc[1]), parts))
+    best, best_c = np.float32(-1.0), -1
+    for s, c in res:
+        if np.float32(s) > best:
+            best, best_c = np.float32(s), c
+    _, ca = rtcsm3d_candidates(opts, grid.resolution, pts, init7)
+    return dict(score=float(best), best_index=int(best_c), pose=ca[best_c].astype(np.float64), num_candidates=total)
+
+
+def rtcsm3d_value_sums_parallel(opts, init7, pts, grid, threads=8):
+    """The whole integer score volume (sum_i max(v_i & 0x7fff, 1) per candidate) on `threads` host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    pts = _f32(pts).reshape(-1, 3)
+    o = _opts4(opts)
+    total = lib().orc_rtcsm3d_candidates(_p(o, _f64p), C.c_float(grid.resolution), _p(pts, _f32p), len(pts),
+                                         _p(_f64(init7), _f64p), None, None)
+    parts = _ranges(total, max(1, threads) * 4)
+    with ThreadPoolExecutor(max(1, threads)) as pool:
+        res = list(pool.map(lambda fc: rtcsm3d_value_sums(opts, init7, pts, grid, fc[0], fc[1]), parts))
+    return np.concatenate(res)
+
+
 def rtcsm3d_float_sums(opts, init7, pts, grid, indices):
     """Sequential float sums (before the division by N) of the given candidates."""
     pts = _f32(pts).reshape(-1, 3)

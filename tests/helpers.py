@@ -46,3 +46,59 @@ def pose_distance(a, b):
     qb = np.asarray(b[3:]) / np.linalg.norm(b[3:])
     d = abs(float(np.dot(qa, qb)))
     return dt, 2.0 * np.arccos(min(1.0, d))
+
+
+# ---- the benchmarked configurations (bench.py builds the same scenes with the same constants) --------
+def build_device_scene(dl, ctx, beams, azimuths, res_hi, res_lo, map_scans, num_scans=1, high_res_max_range=20.0):
+    """bench.py's scene: `map_scans` scans inserted at ground truth into a high and a low resolution
+    device grid, then `num_scans` scans to match (truth, points, perturbed initial pose, device cloud)."""
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
+    g_hi, g_lo = dl.HybridGrid(ctx, res_hi), dl.HybridGrid(ctx, res_lo)
+    centers = synth.bubbles()
+    for s in range(map_scans):
+        pose = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(pose, beams, azimuths, centers=centers)
+        cloud = dl.PointCloud(ctx, pts)
+        pf = pose.astype(np.float32)
+        ins.InsertCloud(g_hi, cloud, poses=[pf], max_range=high_res_max_range)
+        ins.InsertCloud(g_lo, cloud, poses=[pf])
+        cloud.close()
+    scans = []
+    for k in range(num_scans):
+        truth = synth.trajectory_pose(0.1 * (map_scans + k))
+        pts, _ = synth.scan(truth, beams, azimuths, centers=centers)
+        init = synth.perturb_pose(truth, 0.1, 0.5, seed=13 + k)
+        scans.append(dict(truth=truth, pts=pts, init=init, cloud=dl.PointCloud(ctx, pts)))
+    return ins, g_hi, g_lo, scans
+
+
+def device_grid_to_oracle(orc, dg):
+    """Oracle HybridGrid with exactly the device grid's non-zero cells (one vectorised upload)."""
+    og = orc.HybridGrid(dg.resolution)
+    origins, values = dg.download_blocks()
+    leaf, cell = np.nonzero(values)
+    if len(leaf):
+        xyz = np.stack([origins[leaf, 0] + (cell & 7), origins[leaf, 1] + ((cell >> 3) & 7), origins[leaf, 2] + (cell >> 6)],
+                       axis=1).astype(np.int32)
+        og.set_values(xyz, values[leaf, cell])
+    return og
+
+
+def device_cells_sorted(dg):
+    """(keys, values) of the device grid's non-zero cells, sorted by a 63-bit cell key."""
+    origins, values = dg.download_blocks()
+    leaf, cell = np.nonzero(values)
+    x = origins[leaf, 0].astype(np.int64) + (cell & 7)
+    y = origins[leaf, 1].astype(np.int64) + ((cell >> 3) & 7)
+    z = origins[leaf, 2].astype(np.int64) + (cell >> 6)
+    key = ((x + (1 << 20)) << 42) | ((y + (1 << 20)) << 21) | (z + (1 << 20))
+    order = np.argsort(key)
+    return key[order], values[leaf, cell][order]
+
+
+def oracle_cells_sorted(og):
+    xyz, v = og.export_cells()
+    xyz = xyz.astype(np.int64)
+    key = ((xyz[:, 0] + (1 << 20)) << 42) | ((xyz[:, 1] + (1 << 20)) << 21) | (xyz[:, 2] + (1 << 20))
+    order = np.argsort(key)
+    return key[order], np.asarray(v)[order]

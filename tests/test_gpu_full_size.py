@@ -1,0 +1,141 @@
+"""Parity at the sizes bench.py measures ("pin parity on the configurations you benchmark").
+
+Config 2 (W-dense): the exact bench scene -- 20 map scans, a 64 x 1024 scan with every return matched,
+C = 35 937 candidates, N = 65 536 points -- against the FULL oracle: the reference's candidate loop over
+all candidates (8 host threads over contiguous ranges, combined in generation order), the whole integer
+score volume, CeresScanMatcher3D, and both grids after the insertion.  The same scene with the search
+window cut into 8 candidate shards.  Config 5 (128 x 2048 @ 5 cm, bits = 4 mirror, T = 343 translations =
+13 passes of the box kernel) on a reduced angular window so that the oracle finishes in seconds.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (DEFAULT_CSM, DEFAULT_RTCSM, FREE, build_device_scene, device_cells_sorted,
+                     device_grid_to_oracle, oracle_cells_sorted, pose_distance)
+
+pytestmark = pytest.mark.gpu
+THREADS = min(8, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module")
+def dl():
+    import dliom
+    dliom.load_library()
+    assert dliom.device_count() > 0, "no HIP device: the GPU tests must not pass on a fallback"
+    return dliom
+
+
+@pytest.fixture(scope="module")
+def ctx(dl):
+    c = dl.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def bench_scene(dl, ctx, orc):
+    ins, g_hi, g_lo, scans = build_device_scene(dl, ctx, 64, 1024, 0.10, 0.45, map_scans=20)
+    sc = scans[0]
+    og_hi, og_lo = device_grid_to_oracle(orc, g_hi), device_grid_to_oracle(orc, g_lo)
+    ref = orc.rtcsm3d_match_parallel(DEFAULT_RTCSM, sc["init"], sc["pts"], og_hi, threads=THREADS)
+    yield dict(ins=ins, g_hi=g_hi, g_lo=g_lo, sc=sc, og_hi=og_hi, og_lo=og_lo, ref=ref)
+    sc["cloud"].close()
+    g_hi.close()
+    g_lo.close()
+
+
+def test_config2_full_oracle_match(dl, ctx, orc, bench_scene):
+    s = bench_scene
+    sc, ref = s["sc"], s["ref"]
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    score, pose = rt.Match(sc["init"], sc["cloud"], s["g_hi"])
+    st = rt.last_stats()
+    assert st.window.num_candidates == 35937 == ref["num_candidates"] and st.num_points == 65536
+    assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
+    assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
+    assert np.array_equal(pose, ref["pose"])
+    assert rt.box_error() == 0
+
+
+def test_config2_full_score_volume(dl, ctx, orc, bench_scene):
+    s = bench_scene
+    sc = s["sc"]
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    got = rt.score_volume(sc["init"], sc["pts"], s["g_hi"])
+    want = orc.rtcsm3d_value_sums_parallel(DEFAULT_RTCSM, sc["init"], sc["pts"], s["og_hi"], threads=THREADS)
+    assert got.shape == want.shape == (35937,)
+    assert np.array_equal(got.astype(np.uint64), want)
+    assert rt.box_error() == 0
+
+
+def test_config2_eight_candidate_shards(dl, ctx, orc, bench_scene):
+    """BASELINE config 4's split at config 2's size: 8 shards, each its own context; the max of the shards'
+    words is the unsharded winner, which is the oracle's."""
+    s = bench_scene
+    sc, ref = s["sc"], s["ref"]
+    ctxs = [dl.Context(0) for _ in range(8)]
+    clouds = [dl.PointCloud(c, sc["pts"]) for c in ctxs]
+    shards = [dl.RtcsmShard(c, DEFAULT_RTCSM, k, 8) for k, c in enumerate(ctxs)]
+    glo = max(sh.begin(sc["init"], cl, s["g_hi"]) for sh, cl in zip(shards, clouds))
+    gbest = max(sh.finish(glo) for sh in shards)
+    for sh in shards:
+        score, pose = sh.decode(gbest)
+        assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
+        assert np.array_equal(pose, ref["pose"])
+    for c in clouds:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_config2_ceres_and_insertion(dl, ctx, orc, bench_scene):
+    s = bench_scene
+    sc, ref = s["sc"], s["ref"]
+    cs = dl.CeresScanMatcher3D(ctx, DEFAULT_CSM)
+    p2, summ = cs.Match(sc["init"][:3], ref["pose"], [(sc["cloud"], s["g_hi"]), (sc["cloud"], s["g_lo"])])
+    r2 = orc.csm3d_match(DEFAULT_CSM, sc["init"][:3], ref["pose"], [(sc["pts"], s["og_hi"]), (sc["pts"], s["og_lo"])])
+    dt, dr = pose_distance(p2, r2["pose"])
+    assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)  # metres / radians; north-star bar 1e-4 m
+    assert summ["num_iterations"] == r2["num_iterations"]
+    # insertion at the matched pose: both grids bit-equal afterwards (must run last: it changes the grids)
+    pf = np.asarray(p2, dtype=np.float32)
+    dl.insert_cloud_multi(s["ins"], sc["cloud"], [(s["g_hi"], [pf], 20.0), (s["g_lo"], [pf], 0.0)])
+    world = orc.transform_points(pf, sc["pts"])
+    origin = orc.transform_points(pf, np.zeros((1, 3), np.float32))[0]
+    d = (world - origin).astype(np.float32)  # FilterRangeDataByMaxRange: float norm, Eigen's reduction order
+    nrm = np.sqrt(d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]), dtype=np.float32)
+    near = world[nrm <= np.float32(20.0)]
+    s["og_hi"].insert_tables(origin, near, s["ins"].hit_table, s["ins"].miss_table, FREE)
+    s["og_lo"].insert_tables(origin, world, s["ins"].hit_table, s["ins"].miss_table, FREE)
+    for dg, og in ((s["g_hi"], s["og_hi"]), (s["g_lo"], s["og_lo"])):
+        dk, dv = device_cells_sorted(dg)
+        ok, ov = oracle_cells_sorted(og)
+        assert np.array_equal(dk, ok) and np.array_equal(dv, ov)
+
+
+def test_config5_reduced_window(dl, ctx, orc):
+    """128 x 2048 @ 5 cm: N = 262 144, the 2 GiB bits = 4 mirror, T = 343 translations (13 box-kernel passes);
+    angular window 0.2 degrees so that the oracle's candidate loop finishes in seconds."""
+    opts = dict(DEFAULT_RTCSM, angular_search_window=float(np.deg2rad(0.2)))
+    ins, g_hi, g_lo, scans = build_device_scene(dl, ctx, 128, 2048, 0.05, 0.45, map_scans=3)
+    sc = scans[0]
+    assert g_hi.bits == 4
+    og_hi = device_grid_to_oracle(orc, g_hi)
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, opts)
+    score, pose = rt.Match(sc["init"], sc["cloud"], g_hi)
+    st = rt.last_stats()
+    assert st.window.num_translations == 343 and st.num_points == 262144
+    ref = orc.rtcsm3d_match_parallel(opts, sc["init"], sc["pts"], og_hi, threads=THREADS)
+    assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
+    assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
+    assert np.array_equal(pose, ref["pose"])
+    sums = rt.score_volume(sc["init"], sc["pts"], g_hi)
+    rng = np.random.RandomState(5)
+    for c in rng.randint(0, len(sums), size=48):
+        assert sums[c] == orc.rtcsm3d_value_sums(opts, sc["init"], sc["pts"], og_hi, first=int(c), count=1)[0]
+    assert rt.box_error() == 0
+    sc["cloud"].close()
+    g_hi.close()
+    g_lo.close()
