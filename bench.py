@@ -30,6 +30,8 @@ for p in (ROOT, os.path.join(ROOT, "d-liom_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); 6.29 TB/s measured copy
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, v_fma_f32 (wave64) = 2 cycles, 2.4 GHz
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
 
 RTCSM_OPTS = dict(linear_search_window=0.15, angular_search_window=float(np.deg2rad(1.0)),
                   translation_delta_cost_weight=1e-1, rotation_delta_cost_weight=1e-1)
@@ -53,7 +55,9 @@ def parse():
     ap.add_argument("--shard-candidates", action="store_true",
                     help="config 4: ONE scan stream; the RTCSM search window is sharded over the ranks "
                          "(two 8-byte RCCL max all-reduces per scan), Ceres + insertion replicated")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skips the CPU oracle leg (cpu_baseline AND the post-timing parity check)")
+    ap.add_argument("--no-wref", action="store_true", help="skips the W-ref (reference-faithful filter chain) line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -184,15 +188,8 @@ def main():
         alg_bytes = 14.0 * C * n_pts / (world if sharded_mode else 1)
         k_ms = score_ms / max(score_n, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("num_points") == n_pts and tj.get("num_candidates") == C:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pairs = float(C) * n_pts / (world if sharded_mode else 1)
+        prof = score_kernel_profile(n_pts, C)
         out = {
             "metric": "scans/sec (%d-beam x %d pts -> %g cm 3D submap)" % (args.beams, args.azimuths, 100 * args.high_resolution),
             "value": value,
@@ -225,22 +222,15 @@ def main():
             },
             "stage_ms_per_scan": {k: 1e3 * v / args.steps for k, v in stage.items()},
             "kernel_ms_per_scan": breakdown,
-            "roofline": {
-                "kernel": {"0": "rtcsm_score_kernel", "1": "rtcsm_score_rot_kernel"}.get(
-                    os.environ.get("DLIOM_SCORE_MAPPING", "2"), "rtcsm_score_dense_kernel"),
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k_ms, "launches": int(score_n),
-                "note": "algorithmic bytes = 14 B x C x N; points are reused from registers and the "
-                        "grid from L2/MALL, so frac > 1 is possible -- see DESIGN.md",
-                # what actually limits the kernel: one gather + ~22.4 VALU instructions (PMC: SQ_INSTS_VALU / pair-rows) per
-                # (candidate, point) pair; VALU peak = 256 CU x 64 lanes x 2.4 GHz lane-instr/s
-                "issue_bound": {"bound": "valu", "unit": "pairs/s",
-                                "achieved": C * n_pts / (world if sharded_mode else 1) / (k_ms * 1e-3) if k_ms > 0 else 0.0,
-                                "peak": 256 * 64 * 2.4e9 / 22.4,
-                                "frac": (C * n_pts / (world if sharded_mode else 1) / (k_ms * 1e-3)) / (256 * 64 * 2.4e9 / 22.4) if k_ms > 0 else 0.0}},
+            "roofline": roofline_block(prof, pairs, k_ms, int(score_n), alg_bytes),
         }
+        if world == 1 and not args.no_wref:
+            out["wref"] = wref_line(dl, ctx)
         if world == 1 and not args.no_cpu_baseline:
+            # the oracle leg: checker first (one more step, compared end to end), then the CPU baseline
+            parity = parity_check(dl, ctx, scans[1 % len(scans)], g_hi, g_lo, ins, rt, cs)
+            out["parity_checked"] = bool(parity["ok"])
+            out["parity"] = parity
             out["cpu_baseline"] = cpu_baseline(args, dl, scans[0], g_hi, g_lo, ins, C, n_pts)
     if out is not None:
         print(json.dumps(out))
@@ -249,6 +239,128 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def score_kernel_profile(n_pts, C):
+    """Counter-derived constants of the score kernel (rocprofv3 --pmc cannot run inside this process):
+    read from the committed profile of the SAME workload, and labelled as such."""
+    path = os.path.join(ROOT, "profiles", "r2_pmc_score_kernel.json")
+    try:
+        pj = json.load(open(path))
+        w = pj.get("workload", {})
+        if w.get("num_points") == n_pts and w.get("num_candidates") == C:
+            return pj
+    except Exception:
+        pass
+    return None
+
+
+def roofline_block(prof, pairs, k_ms, launches, alg_bytes):
+    """What bounds the dominant kernel: the vector ALU's instruction issue -- not HBM (the
+    kernel moves ~2 % of its algorithmic bytes) and not MFMA (no GEMM in it).  achieved = VALU lane-operations
+    per second (SQ_INSTS_VALU x 64 / launch time); peak = 256 CU x 4 SIMD-32 x 2.4 GHz."""
+    t = k_ms * 1e-3
+    kernel = "rtcsm_score_box_kernel" if os.environ.get("DLIOM_SCORE_MAPPING", "3") == "3" else "rtcsm_score_dense_kernel"
+    valu_per_pair = src = traffic = tsrc = None
+    if prof is not None and prof.get("kernel") == kernel:
+        valu_per_pair = prof.get("valu_instructions_per_wave_pair")
+        src = "profiles/r2_pmc_score_kernel.json (SQ_INSTS_VALU / (C N / 64), same workload)"
+        traffic = prof.get("hbm_bytes_per_launch")
+        tsrc = "profiles/r2_pmc_score_kernel.json (rocprofv3 --pmc FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, separate passes)"
+    achieved = (valu_per_pair * pairs / t) if (valu_per_pair and t > 0) else None
+    return {
+        "kernel": kernel,
+        "bound": "valu",
+        "achieved": achieved / 1e12 if achieved else None,
+        "peak": VALU_PEAK_LANE_OPS / 1e12,
+        "unit": "Tlane-op/s",
+        "frac": achieved / VALU_PEAK_LANE_OPS if achieved else None,
+        "valu_instructions_per_pair": valu_per_pair,
+        "valu_source": src,
+        "pairs_per_s": pairs / t if t > 0 else 0.0,
+        "avg_launch_ms": k_ms,
+        "launches": launches,
+        "traffic": traffic,
+        "traffic_source": tsrc,
+        "hbm_side_note": {
+            "algorithmic_bytes_per_launch": alg_bytes,  # SURVEY 8d: 14 B per (candidate, point) pair
+            "algorithmic_rate_GBs": alg_bytes / t / 1e9 if t > 0 else 0.0,
+            "measured_hbm_GBs": (traffic / t / 1e9) if (traffic and t > 0) else None,
+            "measured_frac_of_hbm_peak": (traffic / t / 1e9 / HBM_PEAK_GBS) if (traffic and t > 0) else None,
+            "note": "points are reused from registers across 27 translations and the mirror sub-boxes from LDS: the "
+                    "algorithmic rate is not an HBM rate and is not the roofline",
+        },
+    }
+
+
+def wref_line(dl, ctx):
+    """The reference-faithful workload (voxel filter -> adaptive filters -> RTCSM3D -> Ceres -> insert on
+    N ~ 170 / 210 points), device only: tools/wref.py's chain, labelled; not the headline metric."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import wref
+    return wref.device_line(dl, ctx, scans=28, warmup=4)
+
+
+def parity_check(dl, ctx, sc, g_hi, g_lo, ins, rt, cs):
+    """One more step, compared end to end with the CPU oracle on the grids as they are after the timed region:
+    RTCSM3D winner (index, score bits, pose) against the reference's full candidate loop, CeresScanMatcher3D
+    pose, both grids after the insertion."""
+    from oracle import oracle as orc
+    threads = min(8, os.cpu_count() or 1)
+
+    def to_oracle(dg):
+        og = orc.HybridGrid(dg.resolution)
+        origins, values = dg.download_blocks()
+        leaf, cell = np.nonzero(values)
+        if len(leaf):
+            xyz = np.stack([origins[leaf, 0] + (cell & 7), origins[leaf, 1] + ((cell >> 3) & 7),
+                            origins[leaf, 2] + (cell >> 6)], axis=1).astype(np.int32)
+            og.set_values(xyz, values[leaf, cell])
+        return og
+
+    def cells(keys_from):
+        xyz, v = keys_from
+        xyz = np.asarray(xyz, dtype=np.int64)
+        key = ((xyz[:, 0] + (1 << 20)) << 42) | ((xyz[:, 1] + (1 << 20)) << 21) | (xyz[:, 2] + (1 << 20))
+        order = np.argsort(key)
+        return key[order], np.asarray(v)[order]
+
+    def device_cells(dg):
+        origins, values = dg.download_blocks()
+        leaf, cell = np.nonzero(values)
+        xyz = np.stack([origins[leaf, 0] + (cell & 7), origins[leaf, 1] + ((cell >> 3) & 7), origins[leaf, 2] + (cell >> 6)], axis=1)
+        return cells((xyz, values[leaf, cell]))
+
+    t0 = time.perf_counter()
+    og_hi, og_lo = to_oracle(g_hi), to_oracle(g_lo)
+    score, p1 = rt.Match(sc["init"], sc["cloud"], g_hi)
+    st = rt.last_stats()
+    ref = orc.rtcsm3d_match_parallel(RTCSM_OPTS, sc["init"], sc["pts"], og_hi, threads=threads)
+    rtcsm_ok = (int(st.best_index) == ref["best_index"] and np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
+                and np.array_equal(p1, ref["pose"]))
+    p2, summ = cs.Match(sc["init"][:3], p1, [(sc["cloud"], g_hi), (sc["cloud"], g_lo)])
+    r2 = orc.csm3d_match(CSM_OPTS, sc["init"][:3], ref["pose"], [(sc["pts"], og_hi), (sc["pts"], og_lo)])
+    dt = float(np.linalg.norm(np.asarray(p2[:3]) - np.asarray(r2["pose"][:3])))
+    dq = float(2.0 * np.arccos(min(1.0, abs(float(np.dot(p2[3:], r2["pose"][3:]))))))
+    ceres_ok = dt <= 1e-6 and dq <= 1e-6
+    pf = np.asarray(p2, dtype=np.float32)
+    dl.insert_cloud_multi(ins, sc["cloud"], [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)])
+    world_pts = orc.transform_points(pf, sc["pts"])
+    origin = orc.transform_points(pf, np.zeros((1, 3), np.float32))[0]
+    d = (world_pts - origin).astype(np.float32)
+    nrm = np.sqrt(d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]), dtype=np.float32)
+    og_hi.insert_tables(origin, world_pts[nrm <= np.float32(HIGH_RES_MAX_RANGE)], ins.hit_table, ins.miss_table, FREE)
+    og_lo.insert_tables(origin, world_pts, ins.hit_table, ins.miss_table, FREE)
+    grids_ok = True
+    for dg, og in ((g_hi, og_hi), (g_lo, og_lo)):
+        dk, dv = device_cells(dg)
+        ok_, ov = cells(og.export_cells())
+        grids_ok = grids_ok and np.array_equal(dk, ok_) and np.array_equal(dv, ov)
+    return {"ok": bool(rtcsm_ok and ceres_ok and grids_ok), "rtcsm_winner_bit_equal": bool(rtcsm_ok),
+            "rtcsm_best_index": int(st.best_index), "candidates": int(ref["num_candidates"]),
+            "ceres_translation_error_m": dt, "ceres_rotation_error_rad": dq, "ceres_tolerance": 1e-6,
+            "grids_bit_equal_after_insertion": bool(grids_ok), "box_kernel_flags": int(rt.box_error()),
+            "oracle_threads": threads, "seconds": time.perf_counter() - t0}
 
 
 def cpu_baseline(args, dl, sc, g_hi, g_lo, ins, C, n_pts):

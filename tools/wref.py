@@ -32,6 +32,42 @@ OPTS = dict(
                  hit_probability=0.55, miss_probability=0.49, num_free_space_voxels=2))
 
 
+def device_line(dl, ctx, scans=24, warmup=4, beams=64, azimuths=1024):
+    """Device side of the W-ref chain; returns the `device` object of this tool's JSON line."""
+    from dliom import synth
+    fe = dl.LocalTrajectoryBuilder3D(ctx, OPTS)
+    gravity = np.array([1.0, 0, 0, 0])
+    origin = np.zeros(3, np.float32)
+    rows, keep = [], []
+    for s in range(scans):
+        truth = synth.trajectory_pose(0.025 * s)
+        pts, _ = synth.scan(truth, beams, azimuths)
+        pred = synth.perturb_pose(truth, 0.03, 0.2, seed=100 + s)
+        t0 = time.perf_counter()
+        for c in keep:
+            c.close()
+        raw = dl.PointCloud(ctx, pts)
+        f = raw.voxel_filter(0.15)
+        keep = [raw, f]
+        t1 = time.perf_counter()
+        r = fe.match_cloud(pred, origin, f)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        fe.insert(int(s * 250000), r["pose_estimate"], gravity)
+        ctx.synchronize()
+        t3 = time.perf_counter()
+        rows.append((t1 - t0, t2 - t1, t3 - t2, len(f), r["num_high"], r["num_low"]))
+    for c in keep:
+        c.close()
+    rows = np.array(rows)[warmup:]
+    return {"workload": "W-ref: %dx%d scans, voxel filter 0.15 -> adaptive filters -> RTCSM3D -> Ceres -> insert "
+                        "(trajectory_builder_3d.lua defaults)" % (beams, azimuths),
+            "scans_per_s": 1.0 / float(np.mean(rows[:, :3].sum(axis=1))),
+            "p50_ms": {"voxel_filter": 1e3 * float(np.median(rows[:, 0])), "match": 1e3 * float(np.median(rows[:, 1])),
+                       "insert": 1e3 * float(np.median(rows[:, 2])), "total": 1e3 * float(np.median(rows[:, :3].sum(axis=1)))},
+            "N_filtered": int(np.median(rows[:, 3])), "N_hi": int(np.median(rows[:, 4])), "N_lo": int(np.median(rows[:, 5]))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=24)
