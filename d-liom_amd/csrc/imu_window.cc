@@ -1,0 +1,716 @@
+// LocalTrajectoryBuilder3D::WindowOptimize without GTSAM: the IMU-preintegration
+// cost, the bias random walk, the matched-pose prior and the gravity factor, solved as a fixed-lag smoother.
+//
+// Replaces mapping/internal/3d/local_trajectory_builder_3d.cc:693-863 (WindowOptimize), :179-199 (AddImuData's
+// integrateMeasurement / predict) and gravity_factor/gravity_factor.cc:10-33.  GTSAM 4.0.2 is not in the tree
+// (README.MD:12): its factors are restated from their published definitions, PARITY UNPINNED (the reference
+// has no test at this boundary):
+//   preintegration   PreintegratedImuMeasurements on the manifold (Forster et al.): Delta R, Delta p, Delta v, their
+//                    bias Jacobians and the 9 x 9 covariance (rotation, position, velocity), integration covariance
+//                    (1e-4)^2 dt on the position block (:79-82)
+//   ImuFactor        r_R = Log(DR(bg)^T Ri^T Rj), r_p = Ri^T (pj - pi - vi dt - g dt^2 / 2) - Dp(b),
+//                    r_v = Ri^T (vj - vi - g dt) - Dv(b), whitened with the preintegrated covariance, n_gravity = (0,0,-g)
+//   BetweenFactor    bias_j - bias_i with sigma = sqrt(dt) (acc_bias_noise x3, gyr_bias_noise x3)        (:808-812)
+//   PriorFactor      Pose3 local coordinates [Log(R0^T R), R0^T (p - p0)] with the sigmas IN THE ORDER THE REFERENCE
+//                    FILLS THEM, (t, t, t, r, r, r) (:94-101): the rotation rows get ceres_pose_noise_t -- kept
+//   gravity factor   error = basis(nZ)^T (RzRyRx(roll, pitch, 0) bRef) + 1e-5                              (gravity_factor.cc)
+// ISAM2 (two update() calls per scan, graph reset with the marginal covariances every num_range_data keys,
+// :750-797,841-842) becomes: Gauss-Newton (two iterations per scan) over the last `window_size` states, older states
+// marginalised into a Gaussian prior on the oldest kept one (Schur complement).  For a linear problem both give the
+// same estimate; the difference is where the old factors are linearised.
+// Jacobians are taken numerically on the manifold (central differences in double): 15 or 30 columns of at most 15
+// rows per factor -- microseconds per scan on the host, and one code path shared by every factor.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/dliom.h"
+
+namespace {
+
+struct V3 {
+  double x, y, z;
+};
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+
+struct M3 {
+  double m[9];  // row major
+};
+inline M3 identity() { return {{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+inline M3 operator*(const M3& a, const M3& b) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+  return r;
+}
+inline V3 operator*(const M3& a, V3 v) {
+  return {a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z,
+          a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z};
+}
+inline M3 transpose(const M3& a) { return {{a.m[0], a.m[3], a.m[6], a.m[1], a.m[4], a.m[7], a.m[2], a.m[5], a.m[8]}}; }
+inline M3 scaled(const M3& a, double s) {
+  M3 r = a;
+  for (double& v : r.m) v *= s;
+  return r;
+}
+inline M3 add(const M3& a, const M3& b) {
+  M3 r;
+  for (int i = 0; i < 9; ++i) r.m[i] = a.m[i] + b.m[i];
+  return r;
+}
+inline M3 skew(V3 v) { return {{0, -v.z, v.y, v.z, 0, -v.x, -v.y, v.x, 0}}; }
+
+// SO(3) exponential / logarithm / right Jacobian
+M3 Exp(V3 w) {
+  const double t = norm(w);
+  const M3 K = skew(w);
+  const M3 K2 = K * K;
+  double a, b;
+  if (t < 1e-6) {
+    a = 1.0 - t * t / 6.0;
+    b = 0.5 - t * t / 24.0;
+  } else {
+    a = std::sin(t) / t;
+    b = (1.0 - std::cos(t)) / (t * t);
+  }
+  return add(identity(), add(scaled(K, a), scaled(K2, b)));
+}
+V3 Log(const M3& R) {
+  const double tr = R.m[0] + R.m[4] + R.m[8];
+  const V3 v{R.m[7] - R.m[5], R.m[2] - R.m[6], R.m[3] - R.m[1]};
+  const double c = std::min(1.0, std::max(-1.0, 0.5 * (tr - 1.0)));
+  const double t = std::acos(c);
+  if (t < 1e-6) return 0.5 * (1.0 + t * t / 6.0) * v;
+  if (t > 3.14159265358979 - 1e-6) {  // near pi: from the symmetric part
+    const double xx = std::sqrt(std::max(0.0, 0.5 * (R.m[0] + 1.0))), yy = std::sqrt(std::max(0.0, 0.5 * (R.m[4] + 1.0))),
+                 zz = std::sqrt(std::max(0.0, 0.5 * (R.m[8] + 1.0)));
+    V3 ax{xx, yy, zz};
+    if (v.x < 0) ax.x = -ax.x;
+    if (v.y < 0) ax.y = -ax.y;
+    if (v.z < 0) ax.z = -ax.z;
+    const double n = norm(ax);
+    return n > 0 ? (t / n) * ax : V3{t, 0, 0};
+  }
+  return (t / (2.0 * std::sin(t))) * v;
+}
+M3 RightJacobian(V3 w) {
+  const double t = norm(w);
+  const M3 K = skew(w);
+  const M3 K2 = K * K;
+  double a, b;
+  if (t < 1e-6) {
+    a = 0.5 - t * t / 24.0;
+    b = 1.0 / 6.0 - t * t / 120.0;
+  } else {
+    a = (1.0 - std::cos(t)) / (t * t);
+    b = (t - std::sin(t)) / (t * t * t);
+  }
+  return add(identity(), add(scaled(K, -a), scaled(K2, b)));
+}
+M3 quat_to_matrix(const double q[4]) {  // (w, x, y, z)
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  return {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+           2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+}
+void matrix_to_quat(const M3& R, double q[4]) {
+  const double tr = R.m[0] + R.m[4] + R.m[8];
+  if (tr > 0) {
+    const double s = std::sqrt(tr + 1.0) * 2;
+    q[0] = 0.25 * s;
+    q[1] = (R.m[7] - R.m[5]) / s;
+    q[2] = (R.m[2] - R.m[6]) / s;
+    q[3] = (R.m[3] - R.m[1]) / s;
+  } else if (R.m[0] > R.m[4] && R.m[0] > R.m[8]) {
+    const double s = std::sqrt(1.0 + R.m[0] - R.m[4] - R.m[8]) * 2;
+    q[0] = (R.m[7] - R.m[5]) / s;
+    q[1] = 0.25 * s;
+    q[2] = (R.m[1] + R.m[3]) / s;
+    q[3] = (R.m[2] + R.m[6]) / s;
+  } else if (R.m[4] > R.m[8]) {
+    const double s = std::sqrt(1.0 + R.m[4] - R.m[0] - R.m[8]) * 2;
+    q[0] = (R.m[2] - R.m[6]) / s;
+    q[1] = (R.m[1] + R.m[3]) / s;
+    q[2] = 0.25 * s;
+    q[3] = (R.m[5] + R.m[7]) / s;
+  } else {
+    const double s = std::sqrt(1.0 + R.m[8] - R.m[0] - R.m[4]) * 2;
+    q[0] = (R.m[3] - R.m[1]) / s;
+    q[1] = (R.m[2] + R.m[6]) / s;
+    q[2] = (R.m[5] + R.m[7]) / s;
+    q[3] = 0.25 * s;
+  }
+  if (q[0] < 0)
+    for (int i = 0; i < 4; ++i) q[i] = -q[i];
+}
+
+// ---- state: rotation, position, velocity, accelerometer bias, gyroscope bias; tangent order the same (15)
+struct State {
+  M3 R;
+  V3 p, v, ba, bg;
+};
+State retract(const State& s, const double* d) {
+  State r = s;
+  r.R = s.R * Exp({d[0], d[1], d[2]});
+  r.p = s.p + V3{d[3], d[4], d[5]};
+  r.v = s.v + V3{d[6], d[7], d[8]};
+  r.ba = s.ba + V3{d[9], d[10], d[11]};
+  r.bg = s.bg + V3{d[12], d[13], d[14]};
+  return r;
+}
+void local(const State& origin, const State& s, double* d) {  // s = retract(origin, d)
+  const V3 w = Log(transpose(origin.R) * s.R), dp = s.p - origin.p, dv = s.v - origin.v, da = s.ba - origin.ba, dg = s.bg - origin.bg;
+  const double out[15] = {w.x, w.y, w.z, dp.x, dp.y, dp.z, dv.x, dv.y, dv.z, da.x, da.y, da.z, dg.x, dg.y, dg.z};
+  std::memcpy(d, out, sizeof out);
+}
+
+// ---- preintegration --------------------------------------------------------------------------------
+struct Preint {
+  double dt = 0.0;
+  M3 dR = identity();
+  V3 dp{0, 0, 0}, dv{0, 0, 0};
+  M3 dR_dbg{}, dp_dba{}, dp_dbg{}, dv_dba{}, dv_dbg{};
+  double cov[81];  // rotation, position, velocity
+  V3 ba_lin{0, 0, 0}, bg_lin{0, 0, 0};
+  Preint() { reset({0, 0, 0}, {0, 0, 0}); }
+  void reset(V3 ba, V3 bg) {
+    dt = 0.0;
+    dR = identity();
+    dp = dv = V3{0, 0, 0};
+    std::memset(&dR_dbg, 0, sizeof(M3));
+    dp_dba = dp_dbg = dv_dba = dv_dbg = dR_dbg;
+    std::memset(cov, 0, sizeof cov);
+    ba_lin = ba;
+    bg_lin = bg;
+  }
+};
+
+void integrate(Preint& P, V3 acc_meas, V3 gyr_meas, double h, double acc_sigma, double gyr_sigma, double int_sigma) {
+  const V3 a = acc_meas - P.ba_lin, w = gyr_meas - P.bg_lin;
+  const V3 wh = h * w;
+  const M3 dRk = Exp(wh), Jr = RightJacobian(wh);
+  const M3 R = P.dR;
+  const V3 Ra = R * a;
+  const M3 Ra_x = R * skew(a);
+  // covariance: x+ = A x + B na + C ng
+  double A[81] = {0}, Bm[27] = {0}, Cm[27] = {0};
+  const M3 dRkT = transpose(dRk);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      A[9 * i + j] = dRkT.m[3 * i + j];
+      A[9 * (3 + i) + j] = -0.5 * h * h * Ra_x.m[3 * i + j];
+      A[9 * (6 + i) + j] = -h * Ra_x.m[3 * i + j];
+      Bm[3 * (3 + i) + j] = 0.5 * h * h * R.m[3 * i + j];
+      Bm[3 * (6 + i) + j] = h * R.m[3 * i + j];
+      Cm[3 * i + j] = h * Jr.m[3 * i + j];
+    }
+  for (int i = 0; i < 3; ++i) {
+    A[9 * (3 + i) + 3 + i] = 1.0;
+    A[9 * (3 + i) + 6 + i] = h;
+    A[9 * (6 + i) + 6 + i] = 1.0;
+  }
+  double tmp[81], next[81];
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double s = 0;
+      for (int k = 0; k < 9; ++k) s += A[9 * i + k] * P.cov[9 * k + j];
+      tmp[9 * i + j] = s;
+    }
+  const double qa = acc_sigma * acc_sigma / h, qg = gyr_sigma * gyr_sigma / h;
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double s = 0;
+      for (int k = 0; k < 9; ++k) s += tmp[9 * i + k] * A[9 * j + k];
+      for (int k = 0; k < 3; ++k) s += qa * Bm[3 * i + k] * Bm[3 * j + k] + qg * Cm[3 * i + k] * Cm[3 * j + k];
+      next[9 * i + j] = s;
+    }
+  for (int i = 0; i < 3; ++i) next[9 * (3 + i) + 3 + i] += int_sigma * int_sigma * h;
+  std::memcpy(P.cov, next, sizeof next);
+  // bias Jacobians (old Delta R)
+  const M3 Ra_x_dRdbg = Ra_x * P.dR_dbg;
+  P.dp_dba = add(P.dp_dba, add(scaled(P.dv_dba, h), scaled(R, -0.5 * h * h)));
+  P.dp_dbg = add(P.dp_dbg, add(scaled(P.dv_dbg, h), scaled(Ra_x_dRdbg, -0.5 * h * h)));
+  P.dv_dba = add(P.dv_dba, scaled(R, -h));
+  P.dv_dbg = add(P.dv_dbg, scaled(Ra_x_dRdbg, -h));
+  P.dR_dbg = add(dRkT * P.dR_dbg, scaled(Jr, -h));
+  // deltas
+  P.dp = P.dp + h * P.dv + (0.5 * h * h) * Ra;
+  P.dv = P.dv + h * Ra;
+  P.dR = R * dRk;
+  P.dt += h;
+}
+
+void corrected(const Preint& P, V3 ba, V3 bg, M3* dR, V3* dp, V3* dv) {
+  const V3 da = ba - P.ba_lin, dg = bg - P.bg_lin;
+  *dR = P.dR * Exp(P.dR_dbg * dg);
+  *dp = P.dp + P.dp_dba * da + P.dp_dbg * dg;
+  *dv = P.dv + P.dv_dba * da + P.dv_dbg * dg;
+}
+
+// ---- small dense linear algebra (symmetric positive definite, n <= 15 * 16)
+bool cholesky(std::vector<double>& a, int n) {  // in place, lower
+  for (int j = 0; j < n; ++j) {
+    double d = a[j * n + j];
+    for (int k = 0; k < j; ++k) d -= a[j * n + k] * a[j * n + k];
+    if (!(d > 0)) return false;
+    d = std::sqrt(d);
+    a[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = a[i * n + j];
+      for (int k = 0; k < j; ++k) s -= a[i * n + k] * a[j * n + k];
+      a[i * n + j] = s / d;
+    }
+  }
+  return true;
+}
+void chol_solve(const std::vector<double>& l, int n, double* b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= l[i * n + k] * b[k];
+    b[i] = s / l[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= l[k * n + i] * b[k];
+    b[i] = s / l[i * n + i];
+  }
+}
+
+}  // namespace
+
+struct dliom_imu_window {
+  dliom_imu_window_options o;
+  std::vector<State> x;         // the window, oldest first
+  std::vector<Preint> between;  // between[i]: x[i] -> x[i + 1]
+  struct PosePrior {
+    int index;  // state in the window
+    M3 R;
+    V3 p;
+    double sigma_rot, sigma_trans;
+  };
+  std::vector<PosePrior> pose_priors;
+  struct Gravity {
+    int index;
+    V3 nZ, bRef;
+    double sigma;
+  };
+  std::vector<Gravity> gravity;
+  // Gaussian prior on x[0]: 1/2 d^T H d + b^T d, d = local(lin, x[0])
+  double H0[225], b0[15];
+  State lin0;
+  Preint current;  // since the newest state
+  bool initialized = false;
+  int64_t num_states = 0;
+};
+
+namespace {
+
+constexpr int kD = 15;
+
+// whitened residual of the IMU factor + bias random walk between two states: 15 rows
+void imu_residual(const dliom_imu_window& w, const Preint& P, const std::vector<double>& Linv, const State& a,
+                  const State& b, double* r) {
+  M3 dR;
+  V3 dp, dv;
+  corrected(P, a.ba, a.bg, &dR, &dp, &dv);
+  const V3 g{0, 0, -w.o.gravity};
+  const M3 RiT = transpose(a.R);
+  const V3 rR = Log(transpose(dR) * (RiT * b.R));
+  const V3 rp = RiT * (b.p - a.p - P.dt * a.v - (0.5 * P.dt * P.dt) * g) - dp;
+  const V3 rv = RiT * (b.v - a.v - P.dt * g) - dv;
+  const double raw[9] = {rR.x, rR.y, rR.z, rp.x, rp.y, rp.z, rv.x, rv.y, rv.z};
+  for (int i = 0; i < 9; ++i) {  // r = L^-1 raw (L lower Cholesky factor of the covariance)
+    double s = 0;
+    for (int k = 0; k <= i; ++k) s += Linv[9 * i + k] * raw[k];
+    r[i] = s;
+  }
+  const double sq = std::sqrt(std::max(P.dt, 1e-12));
+  const V3 da = b.ba - a.ba, dg = b.bg - a.bg;
+  const double sa = sq * w.o.acc_bias_noise, sg = sq * w.o.gyr_bias_noise;
+  r[9] = da.x / sa;
+  r[10] = da.y / sa;
+  r[11] = da.z / sa;
+  r[12] = dg.x / sg;
+  r[13] = dg.y / sg;
+  r[14] = dg.z / sg;
+}
+
+void pose_prior_residual(const dliom_imu_window::PosePrior& f, const State& s, double* r) {
+  const V3 w = Log(transpose(f.R) * s.R), t = transpose(f.R) * (s.p - f.p);
+  r[0] = w.x / f.sigma_rot;
+  r[1] = w.y / f.sigma_rot;
+  r[2] = w.z / f.sigma_rot;
+  r[3] = t.x / f.sigma_trans;
+  r[4] = t.y / f.sigma_trans;
+  r[5] = t.z / f.sigma_trans;
+}
+
+void gravity_residual(const dliom_imu_window::Gravity& f, const State& s, double* r) {
+  // Rot3::xyz(): roll, pitch of R = Rz Ry Rx
+  const double roll = std::atan2(s.R.m[7], s.R.m[8]);
+  const double pitch = std::atan2(-s.R.m[6], std::sqrt(s.R.m[7] * s.R.m[7] + s.R.m[8] * s.R.m[8]));
+  const double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch);
+  const M3 Rrp{{cp, sp * sr, sp * cr, 0, cr, -sr, -sp, cp * sr, cp * cr}};  // Ry(pitch) Rx(roll)
+  const V3 nRef = Rrp * f.bRef;
+  // orthonormal basis of the tangent plane at nZ
+  V3 a = std::fabs(f.nZ.x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0};
+  V3 b1 = cross(f.nZ, a);
+  b1 = (1.0 / norm(b1)) * b1;
+  const V3 b2 = cross(f.nZ, b1);
+  r[0] = (dot(b1, nRef) + 1e-5) / f.sigma;
+  r[1] = (dot(b2, nRef) + 1e-5) / f.sigma;
+}
+
+// Lower-triangular inverse of the Cholesky factor of the 9 x 9 preintegrated covariance.
+bool whitening(const Preint& P, std::vector<double>* Linv) {
+  std::vector<double> L(P.cov, P.cov + 81);
+  for (int i = 0; i < 9; ++i) L[10 * i] += 1e-18;
+  if (!cholesky(L, 9)) return false;
+  Linv->assign(81, 0.0);
+  for (int c = 0; c < 9; ++c) {  // solve L X = I column by column
+    for (int i = c; i < 9; ++i) {
+      double s = i == c ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= L[9 * i + k] * (*Linv)[9 * k + c];
+      (*Linv)[9 * i + c] = s / L[9 * i + i];
+    }
+  }
+  return true;
+}
+
+// Accumulates J^T J and J^T r of one factor whose residual depends on states ia (and ib, or -1).
+template <typename F>
+void add_factor(std::vector<State>& x, int ia, int ib, int rows, F residual, std::vector<double>& H, std::vector<double>& g,
+                int n) {
+  const double eps = 1e-6;
+  double r0[15], rp[15], rm[15];
+  residual(r0);
+  const int cols = ib >= 0 ? 2 * kD : kD;
+  std::vector<double> J(static_cast<size_t>(rows) * cols);
+  for (int c = 0; c < cols; ++c) {
+    const int si = c < kD ? ia : ib;
+    double d[kD] = {0};
+    const State keep = x[si];
+    d[c % kD] = eps;
+    x[si] = retract(keep, d);
+    residual(rp);
+    d[c % kD] = -eps;
+    x[si] = retract(keep, d);
+    residual(rm);
+    x[si] = keep;
+    for (int i = 0; i < rows; ++i) J[static_cast<size_t>(i) * cols + c] = (rp[i] - rm[i]) / (2 * eps);
+  }
+  for (int c1 = 0; c1 < cols; ++c1) {
+    const int g1 = (c1 < kD ? ia : ib) * kD + c1 % kD;
+    double s = 0;
+    for (int i = 0; i < rows; ++i) s += J[static_cast<size_t>(i) * cols + c1] * r0[i];
+    g[g1] += s;
+    for (int c2 = 0; c2 < cols; ++c2) {
+      const int g2 = (c2 < kD ? ia : ib) * kD + c2 % kD;
+      double h = 0;
+      for (int i = 0; i < rows; ++i) h += J[static_cast<size_t>(i) * cols + c1] * J[static_cast<size_t>(i) * cols + c2];
+      H[static_cast<size_t>(g1) * n + g2] += h;
+    }
+  }
+}
+
+// Normal equations of every factor in the window at the current estimate.
+bool build(dliom_imu_window& w, std::vector<double>& H, std::vector<double>& g) {
+  const int N = static_cast<int>(w.x.size()), n = N * kD;
+  H.assign(static_cast<size_t>(n) * n, 0.0);
+  g.assign(n, 0.0);
+  // prior on x[0]
+  double d0[kD];
+  local(w.lin0, w.x[0], d0);
+  for (int i = 0; i < kD; ++i) {
+    double s = w.b0[i];
+    for (int j = 0; j < kD; ++j) {
+      s += w.H0[kD * i + j] * d0[j];
+      H[static_cast<size_t>(i) * n + j] += w.H0[kD * i + j];
+    }
+    g[i] += s;
+  }
+  for (int i = 0; i + 1 < N; ++i) {
+    std::vector<double> Linv;
+    if (!whitening(w.between[i], &Linv)) return false;
+    const Preint& P = w.between[i];
+    add_factor(w.x, i, i + 1, 15, [&](double* r) { imu_residual(w, P, Linv, w.x[i], w.x[i + 1], r); }, H, g, n);
+  }
+  for (const auto& f : w.pose_priors)
+    add_factor(w.x, f.index, -1, 6, [&](double* r) { pose_prior_residual(f, w.x[f.index], r); }, H, g, n);
+  for (const auto& f : w.gravity)
+    add_factor(w.x, f.index, -1, 2, [&](double* r) { gravity_residual(f, w.x[f.index], r); }, H, g, n);
+  return true;
+}
+
+bool gauss_newton(dliom_imu_window& w, int iterations) {
+  const int N = static_cast<int>(w.x.size()), n = N * kD;
+  std::vector<double> H, g;
+  for (int it = 0; it < iterations; ++it) {
+    if (!build(w, H, g)) return false;
+    std::vector<double> L = H;
+    for (int i = 0; i < n; ++i) L[static_cast<size_t>(i) * n + i] += 1e-12;
+    if (!cholesky(L, n)) return false;
+    std::vector<double> d(g);
+    for (double& v : d) v = -v;
+    chol_solve(L, n, d.data());
+    for (int i = 0; i < N; ++i) w.x[i] = retract(w.x[i], d.data() + i * kD);
+  }
+  return true;
+}
+
+// Marginalises x[0]: the factors touching it (its prior, the IMU factor to x[1], pose priors / gravity factors on
+// it) become a Gaussian prior on x[1], linearised at the current estimate.
+bool marginalize_oldest(dliom_imu_window& w) {
+  // sub-problem of x[0], x[1] with only those factors
+  std::vector<State> x2 = {w.x[0], w.x[1]};
+  const int n = 2 * kD;
+  std::vector<double> H(static_cast<size_t>(n) * n, 0.0), g(n, 0.0);
+  double d0[kD];
+  local(w.lin0, w.x[0], d0);
+  for (int i = 0; i < kD; ++i) {
+    double s = w.b0[i];
+    for (int j = 0; j < kD; ++j) {
+      s += w.H0[kD * i + j] * d0[j];
+      H[static_cast<size_t>(i) * n + j] += w.H0[kD * i + j];
+    }
+    g[i] += s;
+  }
+  std::vector<double> Linv;
+  if (!whitening(w.between[0], &Linv)) return false;
+  const Preint P = w.between[0];
+  add_factor(x2, 0, 1, 15, [&](double* r) { imu_residual(w, P, Linv, x2[0], x2[1], r); }, H, g, n);
+  for (const auto& f : w.pose_priors)
+    if (f.index == 0) add_factor(x2, 0, -1, 6, [&](double* r) { pose_prior_residual(f, x2[0], r); }, H, g, n);
+  for (const auto& f : w.gravity)
+    if (f.index == 0) add_factor(x2, 0, -1, 2, [&](double* r) { gravity_residual(f, x2[0], r); }, H, g, n);
+  // Schur complement of the first block
+  std::vector<double> Haa(kD * kD);
+  for (int i = 0; i < kD; ++i)
+    for (int j = 0; j < kD; ++j) Haa[kD * i + j] = H[static_cast<size_t>(i) * n + j];
+  for (int i = 0; i < kD; ++i) Haa[kD * i + i] += 1e-12;
+  if (!cholesky(Haa, kD)) return false;
+  // X = Haa^-1 [Hab | ga]
+  double X[kD][kD + 1];
+  for (int c = 0; c <= kD; ++c) {
+    double col[kD];
+    for (int i = 0; i < kD; ++i) col[i] = c < kD ? H[static_cast<size_t>(i) * n + kD + c] : g[i];
+    chol_solve(Haa, kD, col);
+    for (int i = 0; i < kD; ++i) X[i][c] = col[i];
+  }
+  for (int i = 0; i < kD; ++i) {
+    double s = g[kD + i];
+    for (int k = 0; k < kD; ++k) s -= H[static_cast<size_t>(kD + i) * n + k] * X[k][kD];
+    w.b0[i] = s;
+    for (int j = 0; j < kD; ++j) {
+      double h = H[static_cast<size_t>(kD + i) * n + kD + j];
+      for (int k = 0; k < kD; ++k) h -= H[static_cast<size_t>(kD + i) * n + k] * X[k][j];
+      w.H0[kD * i + j] = h;
+    }
+  }
+  for (int i = 0; i < kD; ++i)  // symmetrise
+    for (int j = i + 1; j < kD; ++j) w.H0[kD * i + j] = w.H0[kD * j + i] = 0.5 * (w.H0[kD * i + j] + w.H0[kD * j + i]);
+  w.lin0 = w.x[1];
+  w.x.erase(w.x.begin());
+  w.between.erase(w.between.begin());
+  std::vector<dliom_imu_window::PosePrior> pp;
+  for (auto f : w.pose_priors)
+    if (f.index > 0) {
+      --f.index;
+      pp.push_back(f);
+    }
+  w.pose_priors.swap(pp);
+  std::vector<dliom_imu_window::Gravity> gg;
+  for (auto f : w.gravity)
+    if (f.index > 0) {
+      --f.index;
+      gg.push_back(f);
+    }
+  w.gravity.swap(gg);
+  return true;
+}
+
+State predicted(const dliom_imu_window& w, const State& s, const Preint& P) {
+  M3 dR;
+  V3 dp, dv;
+  corrected(P, s.ba, s.bg, &dR, &dp, &dv);
+  const V3 g{0, 0, -w.o.gravity};
+  State r = s;
+  r.R = s.R * dR;
+  r.p = s.p + P.dt * s.v + (0.5 * P.dt * P.dt) * g + s.R * dp;
+  r.v = s.v + P.dt * g + s.R * dv;
+  return r;
+}
+
+void write_state(const State& s, double pose7[7], double vel3[3], double bias6[6]) {
+  if (pose7 != nullptr) {
+    pose7[0] = s.p.x;
+    pose7[1] = s.p.y;
+    pose7[2] = s.p.z;
+    matrix_to_quat(s.R, pose7 + 3);
+  }
+  if (vel3 != nullptr) {
+    vel3[0] = s.v.x;
+    vel3[1] = s.v.y;
+    vel3[2] = s.v.z;
+  }
+  if (bias6 != nullptr) {
+    bias6[0] = s.ba.x;
+    bias6[1] = s.ba.y;
+    bias6[2] = s.ba.z;
+    bias6[3] = s.bg.x;
+    bias6[4] = s.bg.y;
+    bias6[5] = s.bg.z;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dliom_imu_window_default_options(dliom_imu_window_options* o) {
+  if (o == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  // trajectory_builder_3d.lua:86-101 (imu block) and local_trajectory_builder_3d.cc:79-92
+  o->acc_noise = 3.9939570888238808e-01;
+  o->gyr_noise = 1.5636343949698187e-03;
+  o->acc_bias_noise = 6.4356659353532566e-05;
+  o->gyr_bias_noise = 3.5640318696367613e-05;
+  o->gravity = 9.80511;
+  o->integration_sigma = 1e-4;
+  o->prior_pose_noise = 1e-2;
+  o->prior_velocity_sigma = 1e4;
+  o->prior_bias_sigma = 1e-2;
+  o->ceres_pose_noise_t = 5e-2;
+  o->ceres_pose_noise_r = 5e-2;
+  o->ceres_pose_noise_t_drift = 3e-1;
+  o->ceres_pose_noise_r_drift = 1e-1;
+  o->prior_gravity_noise = 1e-2;
+  o->window_size = 4;
+  o->iterations = 2;
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out) {
+  if (options == nullptr || out == nullptr || options->window_size < 2 || options->window_size > 16 ||
+      options->iterations < 1 || !(options->acc_noise > 0) || !(options->gyr_noise > 0) || !(options->acc_bias_noise > 0) ||
+      !(options->gyr_bias_noise > 0))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  dliom_imu_window* w = new dliom_imu_window;
+  w->o = *options;
+  *out = w;
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_destroy(dliom_imu_window* w) {
+  delete w;
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_initialize(dliom_imu_window* w, const double pose7[7], const double velocity[3], const double bias6[6]) {
+  if (w == nullptr || pose7 == nullptr || velocity == nullptr || bias6 == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  State s;
+  s.R = quat_to_matrix(pose7 + 3);
+  s.p = {pose7[0], pose7[1], pose7[2]};
+  s.v = {velocity[0], velocity[1], velocity[2]};
+  s.ba = {bias6[0], bias6[1], bias6[2]};
+  s.bg = {bias6[3], bias6[4], bias6[5]};
+  w->x.assign(1, s);
+  w->between.clear();
+  w->pose_priors.clear();
+  w->gravity.clear();
+  // PriorFactor<Pose3> (prior_pose_noise x 6), PriorFactor<Vector3> (1e4), PriorFactor<ConstantBias> (1e-2): :712-745
+  std::memset(w->H0, 0, sizeof w->H0);
+  std::memset(w->b0, 0, sizeof w->b0);
+  const double sp = w->o.prior_pose_noise, sv = w->o.prior_velocity_sigma, sb = w->o.prior_bias_sigma;
+  for (int i = 0; i < 6; ++i) w->H0[kD * i + i] = 1.0 / (sp * sp);
+  for (int i = 6; i < 9; ++i) w->H0[kD * i + i] = 1.0 / (sv * sv);
+  for (int i = 9; i < 15; ++i) w->H0[kD * i + i] = 1.0 / (sb * sb);
+  w->lin0 = s;
+  w->current.reset(s.ba, s.bg);
+  w->initialized = true;
+  w->num_states = 1;
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_add_imu(dliom_imu_window* w, const double acc[3], const double gyr[3], double dt) {
+  if (w == nullptr || acc == nullptr || gyr == nullptr || !(dt > 0)) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (!w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
+  integrate(w->current, {acc[0], acc[1], acc[2]}, {gyr[0], gyr[1], gyr[2]}, dt, w->o.acc_noise, w->o.gyr_noise,
+            w->o.integration_sigma);
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_predict(const dliom_imu_window* w, double pose7[7], double velocity[3]) {
+  if (w == nullptr || !w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
+  write_state(predicted(*w, w->x.back(), w->current), pose7, velocity, nullptr);
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_add_gravity(dliom_imu_window* w, int states_back, const double direction[3]) {
+  if (w == nullptr || direction == nullptr || !w->initialized || states_back < 0 || states_back >= static_cast<int>(w->x.size()))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  V3 n{direction[0], direction[1], direction[2]};
+  const double l = norm(n);
+  if (!(l > 0)) return DLIOM_ERR_INVALID_ARGUMENT;
+  dliom_imu_window::Gravity f;
+  f.index = static_cast<int>(w->x.size()) - 1 - states_back;
+  f.nZ = (1.0 / l) * n;
+  f.bRef = {0, 0, -1};  // g_ref_B, :780,825
+  f.sigma = w->o.prior_gravity_noise;
+  w->gravity.push_back(f);
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7], int degenerate, double pose7[7],
+                              double velocity[3], double bias6[6]) {
+  if (w == nullptr || matched_pose7 == nullptr || !w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (!(w->current.dt > 0)) return DLIOM_ERR_INVALID_ARGUMENT;  // no IMU since the last pose
+  // new state at the IMU prediction (:833-838), IMU factor + bias random walk to it, pose prior on it
+  const State prev = w->x.back();
+  State next = predicted(*w, prev, w->current);
+  next.ba = prev.ba;
+  next.bg = prev.bg;
+  w->x.push_back(next);
+  w->between.push_back(w->current);
+  dliom_imu_window::PosePrior f;
+  f.index = static_cast<int>(w->x.size()) - 1;
+  f.R = quat_to_matrix(matched_pose7 + 3);
+  f.p = {matched_pose7[0], matched_pose7[1], matched_pose7[2]};
+  // sigmas as the reference fills them, (t, t, t, r, r, r), against GTSAM's (rotation, translation) tangent order
+  f.sigma_rot = degenerate ? w->o.ceres_pose_noise_t_drift : w->o.ceres_pose_noise_t;
+  f.sigma_trans = degenerate ? w->o.ceres_pose_noise_r_drift : w->o.ceres_pose_noise_r;
+  w->pose_priors.push_back(f);
+  const std::vector<State> backup = w->x;
+  if (!gauss_newton(*w, w->o.iterations)) {
+    w->x = backup;  // keep the prediction; the caller sees the failure
+    w->x.back() = next;
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  }
+  while (static_cast<int>(w->x.size()) > w->o.window_size)
+    if (!marginalize_oldest(*w)) return DLIOM_ERR_INVALID_ARGUMENT;
+  const State& s = w->x.back();
+  w->current.reset(s.ba, s.bg);  // resetIntegrationAndSetBias(prev_bias_), :852
+  ++w->num_states;
+  write_state(s, pose7, velocity, bias6);
+  if (norm(s.v) > 30.0 || norm(s.ba) > 1.0 || norm(s.bg) > 1.0) {  // FailureDetection, :896-913
+    w->initialized = false;                                          // ResetParams(): the caller re-initialises
+    return DLIOM_ERR_DIVERGED;
+  }
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_state(const dliom_imu_window* w, int states_back, double pose7[7], double velocity[3], double bias6[6]) {
+  if (w == nullptr || !w->initialized || states_back < 0 || states_back >= static_cast<int>(w->x.size()))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  write_state(w->x[w->x.size() - 1 - states_back], pose7, velocity, bias6);
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_size(const dliom_imu_window* w) { return w == nullptr ? 0 : static_cast<int>(w->x.size()); }
+
+}  // extern "C"

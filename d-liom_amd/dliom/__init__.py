@@ -128,6 +128,13 @@ class ImuNoise(C.Structure):
     _fields_ = [("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double)]
 
 
+class ImuWindowOptions(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "acc_noise", "gyr_noise", "acc_bias_noise", "gyr_bias_noise", "gravity", "integration_sigma", "prior_pose_noise",
+        "prior_velocity_sigma", "prior_bias_sigma", "ceres_pose_noise_t", "ceres_pose_noise_r", "ceres_pose_noise_t_drift",
+        "ceres_pose_noise_r_drift", "prior_gravity_noise")] + [("window_size", C.c_int), ("iterations", C.c_int)]
+
+
 class ImuPreintegration(C.Structure):
     _fields_ = [("sum_dt", C.c_double), ("delta_p", C.c_double * 3), ("delta_q", C.c_double * 4),
                 ("delta_v", C.c_double * 3), ("linearized_ba", C.c_double * 3), ("linearized_bg", C.c_double * 3),
@@ -222,6 +229,16 @@ SYMBOLS = [
     ("dliom_fast_csm_match_with_3dof_initial", C.c_int, [_vp, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
                                                          C.POINTER(FastCsmResult)]),
     ("dliom_fast_csm_level", C.c_int, [_vp, C.c_int, _i32p, _i32p, C.POINTER(C.c_uint8), C.c_int64]),
+    ("dliom_imu_window_default_options", C.c_int, [C.POINTER(ImuWindowOptions)]),
+    ("dliom_imu_window_create", C.c_int, [C.POINTER(ImuWindowOptions), C.POINTER(_vp)]),
+    ("dliom_imu_window_destroy", C.c_int, [_vp]),
+    ("dliom_imu_window_initialize", C.c_int, [_vp, _f64p, _f64p, _f64p]),
+    ("dliom_imu_window_add_imu", C.c_int, [_vp, _f64p, _f64p, C.c_double]),
+    ("dliom_imu_window_predict", C.c_int, [_vp, _f64p, _f64p]),
+    ("dliom_imu_window_add_gravity", C.c_int, [_vp, C.c_int, _f64p]),
+    ("dliom_imu_window_add_pose", C.c_int, [_vp, _f64p, C.c_int, _f64p, _f64p, _f64p]),
+    ("dliom_imu_window_state", C.c_int, [_vp, C.c_int, _f64p, _f64p, _f64p]),
+    ("dliom_imu_window_size", C.c_int, [_vp]),
     ("dliom_imu_integrator_create", C.c_int, [_f64p, _f64p, C.POINTER(ImuNoise), C.POINTER(_vp)]),
     ("dliom_imu_integrator_destroy", C.c_int, [_vp]),
     ("dliom_imu_integrator_reset", C.c_int, [_vp, _f64p, _f64p, C.POINTER(ImuNoise)]),
@@ -1055,6 +1072,66 @@ def rotational_histogram(points, histogram_size):
     _check(load_library().dliom_rotational_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p)),
            "dliom_rotational_histogram")
     return out
+
+
+ERR_DIVERGED = -11
+
+
+class ImuWindow:
+    """LocalTrajectoryBuilder3D::WindowOptimize without GTSAM (dliom_imu_window_*; host): IMU-preintegration factor,
+    bias random walk, matched-pose prior and gravity factor in a fixed-lag Gauss-Newton smoother."""
+
+    def __init__(self, **overrides):
+        self._L = load_library()
+        self.options = ImuWindowOptions()
+        _check(self._L.dliom_imu_window_default_options(C.byref(self.options)), "dliom_imu_window_default_options")
+        for k, v in overrides.items():
+            setattr(self.options, k, v)
+        h = _vp()
+        _check(self._L.dliom_imu_window_create(C.byref(self.options), C.byref(h)), "dliom_imu_window_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_imu_window_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def initialize(self, pose7, velocity, bias6):
+        _check(self._L.dliom_imu_window_initialize(self.h, _p(_f64(pose7), _f64p), _p(_f64(velocity), _f64p),
+                                                   _p(_f64(bias6), _f64p)), "dliom_imu_window_initialize")
+
+    def add_imu(self, acc, gyr, dt):
+        _check(self._L.dliom_imu_window_add_imu(self.h, _p(_f64(acc), _f64p), _p(_f64(gyr), _f64p), float(dt)),
+               "dliom_imu_window_add_imu")
+
+    def predict(self):
+        pose, vel = np.zeros(7), np.zeros(3)
+        _check(self._L.dliom_imu_window_predict(self.h, _p(pose, _f64p), _p(vel, _f64p)), "dliom_imu_window_predict")
+        return pose, vel
+
+    def add_gravity(self, states_back, direction):
+        _check(self._L.dliom_imu_window_add_gravity(self.h, int(states_back), _p(_f64(direction), _f64p)),
+               "dliom_imu_window_add_gravity")
+
+    def add_pose(self, matched_pose7, is_drift=False):
+        """Returns (pose7, velocity, bias6, status); status is 0 or ERR_DIVERGED (FailureDetection)."""
+        pose, vel, bias = np.zeros(7), np.zeros(3), np.zeros(6)
+        s = self._L.dliom_imu_window_add_pose(self.h, _p(_f64(matched_pose7), _f64p), int(bool(is_drift)), _p(pose, _f64p),
+                                              _p(vel, _f64p), _p(bias, _f64p))
+        if s != ERR_DIVERGED:
+            _check(s, "dliom_imu_window_add_pose")
+        return pose, vel, bias, s
+
+    def state(self, states_back=0):
+        pose, vel, bias = np.zeros(7), np.zeros(3), np.zeros(6)
+        _check(self._L.dliom_imu_window_state(self.h, int(states_back), _p(pose, _f64p), _p(vel, _f64p), _p(bias, _f64p)),
+               "dliom_imu_window_state")
+        return pose, vel, bias
+
+    def __len__(self):
+        return int(self._L.dliom_imu_window_size(self.h))
 
 
 class ImuIntegrator:

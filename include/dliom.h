@@ -468,6 +468,49 @@ int dliom_imu_integrator_evaluate(const dliom_imu_integrator* integrator, const 
 int dliom_imu_integrator_predict(const dliom_imu_integrator* integrator, const double state_i[16],
                                  const double gravity[3], double state_j[16]);
 
+/* ---- LocalTrajectoryBuilder3D::WindowOptimize: IMU-preintegration cost in the optimisation ----------
+ * (host; PARITY UNPINNED: GTSAM 4.0.2 is not in the reference tree and the reference has no
+ * test at this boundary).  Replaces mapping/internal/3d/local_trajectory_builder_3d.cc:693-863 and the
+ * gtsam::PreintegratedImuMeasurements calls of AddImuData (:179-199): manifold preintegration, ImuFactor +
+ * bias BetweenFactor + PriorFactor<Pose3> on the matched pose + Pose3GravityFactor
+ * (gravity_factor/gravity_factor.cc:10-33), solved as a fixed-lag Gauss-Newton smoother with marginalisation
+ * in place of ISAM2.  Poses are [x, y, z, qw, qx, qy, qz], biases [ax, ay, az, gx, gy, gz].
+ * Call order per scan, as the reference's AddImuData / AddRangeData / WindowOptimize:
+ *   _add_imu (every IMU sample) ... _predict (initial pose for the matchers) ... _add_pose (matched pose)
+ * DLIOM_ERR_DIVERGED mirrors FailureDetection (:896-913): |v| > 30 m/s or a bias norm > 1 -- re-initialise. */
+#define DLIOM_ERR_DIVERGED (-11)
+typedef struct dliom_imu_window dliom_imu_window;
+typedef struct dliom_imu_window_options {
+  double acc_noise, gyr_noise, acc_bias_noise, gyr_bias_noise; /* trajectory_builder_3d.lua:88-91 */
+  double gravity;                                               /* :92, n_gravity = (0, 0, -gravity) */
+  double integration_sigma;                                     /* 1e-4, local_trajectory_builder_3d.cc:81-82 */
+  double prior_pose_noise;                                      /* lua :93 */
+  double prior_velocity_sigma, prior_bias_sigma;                /* 1e4 / 1e-2, .cc:88-89 */
+  double ceres_pose_noise_t, ceres_pose_noise_r;                /* lua :96-97 */
+  double ceres_pose_noise_t_drift, ceres_pose_noise_r_drift;    /* lua :98-99 (is_drift) */
+  double prior_gravity_noise;                                   /* lua :100 */
+  int window_size;  /* states kept; older ones are marginalised (2..16) */
+  int iterations;   /* Gauss-Newton iterations per scan (the reference calls ISAM2::update twice) */
+} dliom_imu_window_options;
+int dliom_imu_window_default_options(dliom_imu_window_options* options);
+int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out);
+int dliom_imu_window_destroy(dliom_imu_window* window);
+/* gtsam_initialized_ == false branch (:712-745): X(0), V(0), B(0) with their priors */
+int dliom_imu_window_initialize(dliom_imu_window* window, const double pose7[7], const double velocity[3],
+                                const double bias6[6]);
+/* imu_integrator_opt_->integrateMeasurement(acc, gyr, dt) (:188-196) */
+int dliom_imu_window_add_imu(dliom_imu_window* window, const double acc[3], const double gyr[3], double dt);
+/* imu_integrator_opt_->predict(prev_state_, prev_bias_) (:198-199) */
+int dliom_imu_window_predict(const dliom_imu_window* window, double pose7[7], double velocity[3]);
+/* Pose3GravityFactor on the state `states_back` keys before the newest (:819-831); direction = estimated gravity */
+int dliom_imu_window_add_gravity(dliom_imu_window* window, int states_back, const double direction[3]);
+/* WindowOptimize(matched_pose, is_drift): new key, factors, optimisation; outputs prev_pose_ / prev_vel_ / prev_bias_ */
+int dliom_imu_window_add_pose(dliom_imu_window* window, const double matched_pose7[7], int is_drift, double pose7[7],
+                              double velocity[3], double bias6[6]);
+int dliom_imu_window_state(const dliom_imu_window* window, int states_back, double pose7[7], double velocity[3],
+                           double bias6[6]);
+int dliom_imu_window_size(const dliom_imu_window* window);
+
 /* ---- RealTimeCorrelativeScanMatcher2D (BASELINE config 1: host only, by contract) -------------
  * double Match(initial_pose_estimate, point_cloud, probability_grid, pose_estimate)
  * (mapping/internal/2d/scan_matching/real_time_correlative_scan_matcher_2d.h:66-69, .cc:74-108).

@@ -2,10 +2,10 @@
 """BASELINE config 3: streaming 10 Hz 64-beam scans + 200 Hz synthetic IMU through the whole device
 front end -- IMU preintegration (host) predicts the pose, AddRangeData de-skews and filters the
 motion-distorted scan on the device, adaptive filters -> RTCSM3D -> CeresScanMatcher3D match it
-against the active submap, the result is inserted.  No GTSAM window: the matched pose
-is taken as the new pose and the velocity stays the IMU-propagated one.  The first scans are replayed
-through the CPU oracle chain to show both produce the same poses (the drift under this 16 m/s^2
-corkscrew comes from AddRangeData's linear de-skew, on both).
+against the active submap, the matched pose goes through WindowOptimize (dliom_imu_window_*: IMU factor, bias
+random walk, matched-pose prior in a fixed-lag smoother) and the smoothed pose is inserted and
+seeds the next prediction.  --no-window reproduces round 1 (matched pose taken as is).  The first scans are
+replayed through the CPU oracle chain (same smoother, oracle front end) to show both produce the same poses.
 Prints one JSON line: scans/s, p50 latency, pose error against the ground-truth corkscrew."""
 import argparse
 import json
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--azimuths", type=int, default=1024)
     ap.add_argument("--imu-noise", action="store_true", help="white noise from the reference's imu block")
     ap.add_argument("--oracle-scans", type=int, default=5, help="replay this many scans through the CPU oracle chain")
+    ap.add_argument("--no-window", action="store_true", help="round-1 behaviour: no WindowOptimize")
     args = ap.parse_args()
     import dliom as dl
     from dliom import synth
@@ -45,49 +46,83 @@ def main():
         scans.append(synth.moving_scan(T * k, args.beams, args.azimuths, centers))
         imus.append(synth.imu_samples(T * (k - 1), T * k, 200.0, noise[:2] if args.imu_noise else None, seed=11 + k))
     state = synth.trajectory_state(0.0)  # initialised like the reference's static initialisation would
+
+    def make_window():
+        w = dl.ImuWindow(acc_noise=noise[0], gyr_noise=noise[1], acc_bias_noise=noise[2], gyr_bias_noise=noise[3])
+        w.initialize(state[:7], state[7:10], np.zeros(6))
+        return w
+
+    window = None if args.no_window else make_window()
     lat, errs, stages, ests = [], [], [], []
     for k in range(1, args.scans + 1):
         t0 = time.perf_counter()
         dt, acc, gyr = imus[k - 1]
-        integ.reset(state[10:13], state[13:16])
-        for a, g in zip(acc, gyr):
-            integ.push_back(dt, a, g)
-        pred = integ.predict(state, synth.GRAVITY)
+        if window is not None:
+            for a, g in zip(acc[:-1], gyr[:-1]):
+                window.add_imu(a, g, dt)
+            pp, pv = window.predict()
+            pred = np.concatenate([pp, pv, state[10:]])
+        else:
+            integ.reset(state[10:13], state[13:16])
+            for a, g in zip(acc, gyr):
+                integ.push_back(dt, a, g)
+            pred = integ.predict(state, synth.GRAVITY)
         t1 = time.perf_counter()
         cloud, origin, cur = dl.add_range_data(ctx, state[:7], pred[:7], T, scans[k - 1], (0, 0, 0), 1.0, 100.0, 0.15)
         t2 = time.perf_counter()
         r = fe.match_cloud(cur.astype(np.float64), origin, cloud)
         t3 = time.perf_counter()
-        est = r["pose_estimate"] if not r["dropped"] else pred[:7]
+        matched = r["pose_estimate"] if not r["dropped"] else pred[:7]
+        if window is not None:
+            est, vel, bias, status = window.add_pose(matched)
+            if status != 0:  # FailureDetection: re-initialise at the matched pose
+                state = np.concatenate([matched, pred[7:10], np.zeros(6)])
+                window = make_window()
+                est, vel, bias = matched, pred[7:10], np.zeros(6)
+        else:
+            est, vel, bias = matched, pred[7:10], state[10:]
+        t3b = time.perf_counter()
         fe.insert(int(k * 1e6), est, gravity)
         ctx.synchronize()
         t4 = time.perf_counter()
         cloud.close()
-        # no smoother here: keep the IMU-propagated velocity, nudged by the position correction of the match
-        state = np.concatenate([est, pred[7:10], state[10:]])
+        state = np.concatenate([est, vel, bias])
         ests.append(est)
         if k > 2:
             lat.append(t4 - t0)
-            stages.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+            stages.append((t1 - t0, t2 - t1, t3 - t2, t3b - t3, t4 - t3b))
         truth = synth.trajectory_pose(T * k)
-        errs.append((float(np.linalg.norm(pred[:3] - truth[:3])), float(np.linalg.norm(est[:3] - truth[:3]))))
+        errs.append((float(np.linalg.norm(pred[:3] - truth[:3])), float(np.linalg.norm(matched[:3] - truth[:3])),
+                     float(np.linalg.norm(est[:3] - truth[:3]))))
     oracle_diff = None
     if args.oracle_scans > 0:
         from oracle import oracle as orc
         ofe = orc.FrontEnd(OPTS)
         ostate = synth.trajectory_state(0.0)
+        state = ostate
+        owin = None if args.no_window else make_window()
         oracle_diff = 0.0
         for k in range(1, min(args.oracle_scans, args.scans) + 1):
             dt, acc, gyr = imus[k - 1]
-            integ.reset(ostate[10:13], ostate[13:16])
-            for a, g in zip(acc, gyr):
-                integ.push_back(dt, a, g)
-            pred = integ.predict(ostate, synth.GRAVITY)
+            if owin is not None:
+                for a, g in zip(acc[:-1], gyr[:-1]):
+                    owin.add_imu(a, g, dt)
+                pp, pv = owin.predict()
+                pred = np.concatenate([pp, pv, ostate[10:]])
+            else:
+                integ.reset(ostate[10:13], ostate[13:16])
+                for a, g in zip(acc, gyr):
+                    integ.push_back(dt, a, g)
+                pred = integ.predict(ostate, synth.GRAVITY)
             ref = orc.deskew_and_filter(T, 1.0, 100.0, 0.15, ostate[:7], pred[:7], scans[k - 1])
             r = ofe.match(ref["current_pose"].astype(np.float64), ref["origin_in_tracking"], ref["returns_in_tracking"])
-            ofe.insert(int(k * 1e6), r["pose_estimate"], gravity)
-            oracle_diff = max(oracle_diff, float(np.linalg.norm(r["pose_estimate"][:3] - ests[k - 1][:3])))
-            ostate = np.concatenate([r["pose_estimate"], pred[7:10], ostate[10:]])
+            if owin is not None:
+                est, vel, bias, _ = owin.add_pose(r["pose_estimate"])
+            else:
+                est, vel, bias = r["pose_estimate"], pred[7:10], ostate[10:]
+            ofe.insert(int(k * 1e6), est, gravity)
+            oracle_diff = max(oracle_diff, float(np.linalg.norm(est[:3] - ests[k - 1][:3])))
+            ostate = np.concatenate([est, vel, bias])
     st = np.median(np.array(stages), axis=0)
     e = np.array(errs)
     print(json.dumps({
@@ -95,9 +130,11 @@ def main():
                     % (args.beams, args.azimuths, " (noisy)" if args.imu_noise else ""),
         "scans_per_s": 1.0 / float(np.mean(lat)), "p50_latency_ms": 1e3 * float(np.median(lat)),
         "stage_p50_ms": {"imu_preintegration": 1e3 * st[0], "add_range_data": 1e3 * st[1], "match": 1e3 * st[2],
-                         "insert": 1e3 * st[3]},
+                         "window_optimize": 1e3 * st[3], "insert": 1e3 * st[4]},
         "pose_error_m": {"imu_prediction_mean": float(e[:, 0].mean()), "imu_prediction_max": float(e[:, 0].max()),
-                         "matched_mean": float(e[:, 1].mean()), "matched_max": float(e[:, 1].max())},
+                         "matched_mean": float(e[:, 1].mean()), "matched_max": float(e[:, 1].max()),
+                         "smoothed_mean": float(e[:, 2].mean()), "smoothed_max": float(e[:, 2].max())},
+        "window_optimize": not args.no_window,
         "max_pose_difference_to_cpu_oracle_chain_m": oracle_diff,
         "realtime_factor_at_10Hz": 0.1 / float(np.mean(lat))}))
 
