@@ -131,6 +131,9 @@ def _declare(L):
     sig("orc_fast_csm_match_3dof", None, vp, _f64p, _f64p, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_float,
         _f64p, _f64p)
     sig("orc_compute_histogram", None, _f32p, C.c_int, C.c_int, _f32p)
+    sig("orc_motion_filter_create", C.c_void_p, C.c_double, C.c_double, C.c_double)
+    sig("orc_motion_filter_destroy", None, C.c_void_p)
+    sig("orc_motion_filter_is_similar", C.c_int, C.c_void_p, C.c_int64, _f64p)
     sig("orc_rotational_match", None, _f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p)
     sig("orc_kat_precomputation_grid", C.c_double)
     sig("orc_kat_fast_csm", C.c_int, C.c_int, _f64p)
@@ -676,6 +679,21 @@ def compute_histogram(pts, histogram_size):
     out = np.zeros(histogram_size, dtype=np.float32)
     lib().orc_compute_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p))
     return out
+
+
+class MotionFilter:
+    """mapping/internal/motion_filter.cc:40-58; time in common::Time ticks (100 ns)."""
+
+    def __init__(self, max_time_seconds, max_distance_meters, max_angle_radians):
+        self.h = lib().orc_motion_filter_create(max_time_seconds, max_distance_meters, max_angle_radians)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_motion_filter_destroy(self.h)
+            self.h = None
+
+    def is_similar(self, time_ticks, pose7):
+        return bool(lib().orc_motion_filter_is_similar(self.h, int(time_ticks), _p(_f64(pose7), _f64p)))
 
 
 def rotational_match(node_histograms, node_angles, scan_histogram, initial_angle, angles):

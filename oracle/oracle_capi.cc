@@ -620,6 +620,15 @@ void orc_compute_histogram(const float* pts, int n, int histogram_size, float* o
   const Histogram h = ComputeHistogram(ToCloud(pts, n), histogram_size);
   std::memcpy(out, h.data(), sizeof(float) * histogram_size);
 }
+// MotionFilter (mapping/internal/motion_filter.cc:40-58) as an object, for motion_filter_test.cc.
+void* orc_motion_filter_create(double max_time_seconds, double max_distance_meters, double max_angle_radians) {
+  return new MotionFilter(MotionFilterOptions{max_time_seconds, max_distance_meters, max_angle_radians});
+}
+void orc_motion_filter_destroy(void* f) { delete static_cast<MotionFilter*>(f); }
+int orc_motion_filter_is_similar(void* f, int64_t time_ticks, const double* pose7) {
+  return static_cast<MotionFilter*>(f)->IsSimilar(time_ticks, ToRigid(pose7)) ? 1 : 0;
+}
+
 void orc_rotational_match(const float* histograms, const float* node_angles, int num_nodes, int histogram_size,
                           const float* scan_histogram, float initial_angle, const float* angles, int num_angles,
                           float* scores) {

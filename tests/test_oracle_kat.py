@@ -378,3 +378,88 @@ def test_fast_correlative_scan_matcher_correct_pose_for_match_full_submap(orc):
     import ctypes as C
     failures = orc.lib().orc_kat_fast_csm(1, worst.ctypes.data_as(C.POINTER(C.c_double)))
     assert failures == 0, worst
+
+
+# ---------------------------------------------------------------------------------------------
+# rotational_scan_matcher_test.cc:28-70 and motion_filter_test.cc:45-100 (unpinned until now)
+
+
+def test_rotational_scan_matcher_only_same_histogram_is_score_one(orc):
+    h = np.array([1.0, 43.0, 0.5, 0.3123, 23.0, 42.0, 0.0], dtype=np.float32)
+    scores = orc.rotational_match(h.reshape(1, -1), [0.0], h, 0.0, [0.0, 1.0])
+    assert len(scores) == 2
+    assert abs(scores[0] - 1.0) <= 1e-6
+    assert scores[1] < 1.0
+
+
+def test_rotational_scan_matcher_interpolates_as_expected(orc):
+    n = 10
+    per = np.float32(np.pi / n)
+
+    def unit(i):
+        v = np.zeros(n, dtype=np.float32)
+        v[i] = 1.0
+        return v
+
+    node = unit(3).reshape(1, -1)
+    t = np.float32(0.0)
+    while t < np.float32(1.0):  # for (float t = 0.f; t < 1.f; t += 0.1f)
+        expected = float(t) / np.hypot(float(t), 1.0 - float(t))
+        s = orc.rotational_match(node, [0.0], unit(2), 0.0, [float(t * per)])
+        assert abs(s[0] - expected) <= 1e-6
+        s = orc.rotational_match(node, [0.0], unit(2), 0.0, [float((np.float32(2.0) - t) * per)])
+        assert abs(s[0] - expected) <= 1e-6
+        s = orc.rotational_match(node, [0.0], unit(4), 0.0, [float(-t * per), float((t - np.float32(2.0)) * per)])
+        assert abs(s[0] - expected) <= 1e-6 and abs(s[1] - expected) <= 1e-6
+        t = np.float32(t + np.float32(0.1))
+
+
+def _mf(orc):
+    return orc.MotionFilter(0.5, 0.2, 2.0)
+
+
+def _sec(s):
+    return s * 10000000
+
+
+IDENTITY = [0, 0, 0, 1, 0, 0, 0]
+
+
+def _rot_y(angle):
+    return [0, 0, 0, np.cos(angle / 2.0), 0, np.sin(angle / 2.0), 0]
+
+
+def test_motion_filter_not_initialized(orc):
+    assert not _mf(orc).is_similar(0, IDENTITY)
+
+
+def test_motion_filter_no_change(orc):
+    f = _mf(orc)
+    assert not f.is_similar(_sec(42), IDENTITY)
+    assert f.is_similar(_sec(42), IDENTITY)
+
+
+def test_motion_filter_time_elapsed(orc):
+    f = _mf(orc)
+    assert not f.is_similar(_sec(42), IDENTITY)
+    assert not f.is_similar(_sec(43), IDENTITY)
+    assert f.is_similar(_sec(43), IDENTITY)
+
+
+def test_motion_filter_linear_motion(orc):
+    f = _mf(orc)
+    assert not f.is_similar(_sec(42), IDENTITY)
+    assert not f.is_similar(_sec(42), [0.3, 0, 0, 1, 0, 0, 0])
+    assert f.is_similar(_sec(42), [0.45, 0, 0, 1, 0, 0, 0])
+    assert not f.is_similar(_sec(42), [0.6, 0, 0, 1, 0, 0, 0])
+    assert f.is_similar(_sec(42), [0.6, 0.15, 0, 1, 0, 0, 0])
+
+
+def test_motion_filter_rotational_motion(orc):
+    f = _mf(orc)
+    assert not f.is_similar(_sec(42), IDENTITY)
+    assert f.is_similar(_sec(42), _rot_y(1.9))
+    assert not f.is_similar(_sec(42), _rot_y(2.1))
+    assert f.is_similar(_sec(42), _rot_y(4.0))
+    assert not f.is_similar(_sec(42), _rot_y(5.9))
+    assert f.is_similar(_sec(42), IDENTITY)
