@@ -92,6 +92,27 @@ class Context {
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   dliom_ctx* get() const { return ctx_; }
+  // The calling thread's own context on `device_id` (created on first use, destroyed with the thread): what the
+  // const, concurrently called members of the reference (FastCorrelativeScanMatcher3D::Match from the
+  // ConstraintBuilder3D pool threads, constraint_builder_3d.cc:270-275) run on.
+  static Context* ForThisThread(int device_id = 0) {
+    struct Slot {
+      int device = -1;
+      Context* ctx = nullptr;
+      ~Slot() { delete ctx; }
+    };
+    static thread_local Slot slots[8];
+    for (Slot& s : slots) {
+      if (s.ctx != nullptr && s.device == device_id) return s.ctx;
+      if (s.ctx == nullptr) {
+        s.device = device_id;
+        s.ctx = new Context(device_id);
+        return s.ctx;
+      }
+    }
+    Check(DLIOM_ERR_INVALID_ARGUMENT, "Context::ForThisThread: more than 8 devices per thread");
+    return nullptr;
+  }
 
  private:
   dliom_ctx* ctx_ = nullptr;
@@ -283,6 +304,7 @@ class FastCorrelativeScanMatcher3D {
       h.insert(h.end(), ha.first.begin(), ha.first.end());
       a.push_back(ha.second);
     }
+    device_ = dliom_ctx_device(context->get());
     Check(dliom_fast_csm_create(context->get(), hybrid_grid.get(), low_resolution_hybrid_grid->get(), h.data(), a.data(),
                                 static_cast<int>(a.size()), histogram_size_, &options, &matcher_),
           "dliom_fast_csm_create (CHECK_GE(branch_and_bound_depth, 1), CHECK_GE(full_resolution_depth, 1))");
@@ -291,12 +313,13 @@ class FastCorrelativeScanMatcher3D {
   FastCorrelativeScanMatcher3D(const FastCorrelativeScanMatcher3D&) = delete;
   FastCorrelativeScanMatcher3D& operator=(const FastCorrelativeScanMatcher3D&) = delete;
 
-  // Returns false where the reference returns nullptr.
+  // Returns false where the reference returns nullptr.  const and re-entrant like the reference's: every calling
+  // thread works on its own context; the matcher (pyramid, histogram) is only read.
   bool Match(const transform::Rigid3d& global_node_pose, const transform::Rigid3d& global_submap_pose,
              const TrajectoryNodeData& constant_data, float min_score, Result* result) const {
     const dliom_fast_csm_node_data d = Data(constant_data);
     dliom_fast_csm_result r;
-    Check(dliom_fast_csm_match(matcher_, global_node_pose.ToArray().data(), global_submap_pose.ToArray().data(), &d,
+    Check(dliom_fast_csm_match(Context::ForThisThread(device_)->get(), matcher_, global_node_pose.ToArray().data(), global_submap_pose.ToArray().data(), &d,
                                min_score, &r),
           "FastCorrelativeScanMatcher3D::Match");
     return Store(r, result);
@@ -306,7 +329,7 @@ class FastCorrelativeScanMatcher3D {
                        float min_score, Result* result) const {
     const dliom_fast_csm_node_data d = Data(constant_data);
     dliom_fast_csm_result r;
-    Check(dliom_fast_csm_match_full_submap(matcher_, global_node_rotation.wxyz, global_submap_rotation.wxyz, &d,
+    Check(dliom_fast_csm_match_full_submap(Context::ForThisThread(device_)->get(), matcher_, global_node_rotation.wxyz, global_submap_rotation.wxyz, &d,
                                            min_score, &r),
           "FastCorrelativeScanMatcher3D::MatchFullSubmap");
     return Store(r, result);
@@ -315,7 +338,7 @@ class FastCorrelativeScanMatcher3D {
                             float min_score, Result* result) const {
     const dliom_fast_csm_node_data d = Data(constant_data);
     dliom_fast_csm_result r;
-    Check(dliom_fast_csm_match_with_3dof_initial(matcher_, pose_in_submap_guess.ToArray().data(), &d, min_score, &r),
+    Check(dliom_fast_csm_match_with_3dof_initial(Context::ForThisThread(device_)->get(), matcher_, pose_in_submap_guess.ToArray().data(), &d, min_score, &r),
           "FastCorrelativeScanMatcher3D::MatchWith3DofInitial");
     return Store(r, result);
   }
@@ -343,6 +366,7 @@ class FastCorrelativeScanMatcher3D {
   }
   dliom_fast_csm* matcher_ = nullptr;
   int histogram_size_ = 0;
+  int device_ = 0;
 };
 
 }  // namespace scan_matching

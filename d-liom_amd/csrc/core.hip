@@ -287,7 +287,13 @@ static int pool_alloc(int device, size_t need, void** p, size_t* bytes) {
 }
 
 static void pool_free(int device, void* p, size_t bytes) {
-  (void)hipDeviceSynchronize();  // nothing in flight may still read the block
+  // nothing in flight ON THE OWNING DEVICE may still read the block (a process may drive several GPUs: the
+  // current device is not necessarily the block's)
+  int current = -1;
+  (void)hipGetDevice(&current);
+  if (current != device) (void)hipSetDevice(device);
+  (void)hipDeviceSynchronize();
+  if (current >= 0 && current != device) (void)hipSetDevice(current);
   {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     if (g_pool.size() < kPoolMaxBlocks) {
@@ -464,6 +470,8 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   delete ctx;
   return DLIOM_OK;
 }
+
+int dliom_ctx_device(const dliom_ctx* ctx) { return ctx == nullptr ? -1 : ctx->device; }
 
 int dliom_ctx_synchronize(dliom_ctx* ctx) {
   if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;

@@ -208,7 +208,8 @@ struct Candidate {
 };
 
 struct Search {
-  dliom_fast_csm* m;
+  const dliom_fast_csm* m;
+  dliom_ctx* ctx;  // the CALLER's context: scratch, stream, pinned block (the matcher itself is read-only)
   int linear_xy, linear_z;
   double angular_window;
   // per match
@@ -235,8 +236,8 @@ struct Search {
 
 // Integer sums of `list` at `depth` (device), in list order.
 int device_sums(Search& s, int depth, const std::vector<Candidate>& list, std::vector<int>* sums) {
-  dliom_fast_csm* m = s.m;
-  dliom_ctx* ctx = m->ctx;
+  const dliom_fast_csm* m = s.m;
+  dliom_ctx* ctx = s.ctx;
   const size_t k = list.size();
   sums->assign(k, 0);
   if (k == 0) return DLIOM_OK;
@@ -385,7 +386,7 @@ PoseF pose_from_candidate(const Search& s, const Candidate& c) {  // :431-437
 int low_resolution_score(Search& s, const PoseF& pose, float* score) {  // low_resolution_matcher.cc:23-36
   const float p7[7] = {pose.t.x, pose.t.y, pose.t.z, pose.q.w, pose.q.x, pose.q.y, pose.q.z};
   float sum = 0.f;
-  DLIOM_TRY(sequential_probability_sums(s.m->ctx, *s.lo_cloud, s.m->lo_grid, p7, 1, &sum));
+  DLIOM_TRY(sequential_probability_sums(s.ctx, *s.lo_cloud, s.m->lo_grid, p7, 1, &sum));
   *score = sum / static_cast<float>(s.lo_cloud->n);
   return DLIOM_OK;
 }
@@ -437,8 +438,8 @@ Candidate branch_and_bound(Search& s, const std::vector<Candidate>& candidates, 
 }
 
 int run_search(Search& s, const dliom_cloud& hi_cloud, float min_score, dliom_fast_csm_result* r) {
-  dliom_fast_csm* m = s.m;
-  dliom_ctx* ctx = m->ctx;
+  const dliom_fast_csm* m = s.m;
+  dliom_ctx* ctx = s.ctx;
   std::memset(r, 0, sizeof(*r));
   const int num_scans = static_cast<int>(s.scan_poses.size());
   r->num_discrete_scans = num_scans;
@@ -471,6 +472,8 @@ int run_search(Search& s, const dliom_cloud& hi_cloud, float min_score, dliom_fa
     // exhausting host memory (a whole-submap window with a shallow pyramid is ~1e8 per scan)
     const double per_axis_xy = std::floor((2.0 * s.linear_xy + step) / step), per_axis_z = std::floor((2.0 * s.linear_z + step) / step);
     if (per_axis_xy * per_axis_xy * per_axis_z * num_scans > 3.0e7) return DLIOM_ERR_CAPACITY;
+    // the score cache packs (depth, scan, offsets) into 64 bits: 14-bit offsets, 16-bit scan index (Search::key)
+    if (s.linear_xy > 8191 || s.linear_z > 8191 || num_scans > 65535) return DLIOM_ERR_CAPACITY;
   }
   std::vector<Candidate> lowest;
   for (int scan = 0; scan != num_scans; ++scan)
@@ -507,7 +510,7 @@ int run_search(Search& s, const dliom_cloud& hi_cloud, float min_score, dliom_fa
 // GenerateDiscreteScans (:306-356): poses and rotational scores of the scans worth discretising.
 void generate_discrete_scans(Search& s, const dliom_fast_csm_node_data& data, float max_norm, const PoseF& node,
                              const PoseF& submap) {
-  dliom_fast_csm* m = s.m;
+  const dliom_fast_csm* m = s.m;
   float max_scan_range = 3.f * m->resolution;
   max_scan_range = std::max(max_norm, max_scan_range);
   const float kSafetyMargin = 1.f - 1e-2f;
@@ -550,14 +553,14 @@ struct StagedClouds {
   }
 };
 
-int stage(dliom_fast_csm* m, const dliom_fast_csm_node_data* data, StagedClouds* c) {
+int stage(dliom_ctx* ctx, const dliom_fast_csm_node_data* data, StagedClouds* c) {
   if (data == nullptr || data->num_high_resolution_points < 0 || data->num_low_resolution_points <= 0 ||
       data->rotational_scan_matcher_histogram == nullptr ||
       (data->num_high_resolution_points > 0 && data->high_resolution_points == nullptr) ||
       data->low_resolution_points == nullptr)
     return DLIOM_ERR_INVALID_ARGUMENT;
-  DLIOM_TRY(dliom_cloud_create(m->ctx, data->high_resolution_points, data->num_high_resolution_points, &c->hi));
-  DLIOM_TRY(dliom_cloud_create(m->ctx, data->low_resolution_points, data->num_low_resolution_points, &c->lo));
+  DLIOM_TRY(dliom_cloud_create(ctx, data->high_resolution_points, data->num_high_resolution_points, &c->hi));
+  DLIOM_TRY(dliom_cloud_create(ctx, data->low_resolution_points, data->num_low_resolution_points, &c->lo));
   return DLIOM_OK;
 }
 
@@ -673,15 +676,17 @@ int dliom_fast_csm_level(const dliom_fast_csm* m, int depth, int32_t lo[3], int3
   return DLIOM_OK;
 }
 
-int dliom_fast_csm_match(dliom_fast_csm* m, const double global_node_pose[7], const double global_submap_pose[7],
+int dliom_fast_csm_match(dliom_ctx* ctx, const dliom_fast_csm* m, const double global_node_pose[7], const double global_submap_pose[7],
                          const dliom_fast_csm_node_data* data, float min_score, dliom_fast_csm_result* result) {
-  if (m == nullptr || global_node_pose == nullptr || global_submap_pose == nullptr || result == nullptr)
+  if (ctx == nullptr || m == nullptr || global_node_pose == nullptr || global_submap_pose == nullptr || result == nullptr)
     return DLIOM_ERR_INVALID_ARGUMENT;
-  DLIOM_HIP_TRY(hipSetDevice(m->ctx->device));
+  if (ctx->device != m->ctx->device) return DLIOM_ERR_INVALID_ARGUMENT;  // the pyramid lives on the creating device
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   StagedClouds c;
-  DLIOM_TRY(stage(m, data, &c));
+  DLIOM_TRY(stage(ctx, data, &c));
   Search s;
   s.m = m;
+  s.ctx = ctx;
   s.linear_xy = static_cast<int>(std::lround(m->options.linear_xy_search_window / m->resolution));  // :154-156
   s.linear_z = static_cast<int>(std::lround(m->options.linear_z_search_window / m->resolution));
   s.angular_window = m->options.angular_search_window;
@@ -690,16 +695,18 @@ int dliom_fast_csm_match(dliom_fast_csm* m, const double global_node_pose[7], co
   return run_search(s, *c.hi, min_score, result);
 }
 
-int dliom_fast_csm_match_full_submap(dliom_fast_csm* m, const double global_node_rotation[4],
+int dliom_fast_csm_match_full_submap(dliom_ctx* ctx, const dliom_fast_csm* m, const double global_node_rotation[4],
                                      const double global_submap_rotation[4], const dliom_fast_csm_node_data* data,
                                      float min_score, dliom_fast_csm_result* result) {
-  if (m == nullptr || global_node_rotation == nullptr || global_submap_rotation == nullptr || result == nullptr)
+  if (ctx == nullptr || m == nullptr || global_node_rotation == nullptr || global_submap_rotation == nullptr || result == nullptr)
     return DLIOM_ERR_INVALID_ARGUMENT;
-  DLIOM_HIP_TRY(hipSetDevice(m->ctx->device));
+  if (ctx->device != m->ctx->device) return DLIOM_ERR_INVALID_ARGUMENT;  // the pyramid lives on the creating device
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   StagedClouds c;
-  DLIOM_TRY(stage(m, data, &c));
+  DLIOM_TRY(stage(ctx, data, &c));
   Search s;
   s.m = m;
+  s.ctx = ctx;
   // :209-216
   const int w = (m->width_in_voxels + 1) / 2 + static_cast<int>(std::lround(c.hi->max_norm / m->resolution + 0.5f));
   s.linear_xy = w;
@@ -714,15 +721,17 @@ int dliom_fast_csm_match_full_submap(dliom_fast_csm* m, const double global_node
   return run_search(s, *c.hi, min_score, result);
 }
 
-int dliom_fast_csm_match_with_3dof_initial(dliom_fast_csm* m, const double pose_in_submap_guess[7],
+int dliom_fast_csm_match_with_3dof_initial(dliom_ctx* ctx, const dliom_fast_csm* m, const double pose_in_submap_guess[7],
                                            const dliom_fast_csm_node_data* data, float min_score,
                                            dliom_fast_csm_result* result) {
-  if (m == nullptr || pose_in_submap_guess == nullptr || result == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
-  DLIOM_HIP_TRY(hipSetDevice(m->ctx->device));
+  if (ctx == nullptr || m == nullptr || pose_in_submap_guess == nullptr || result == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (ctx->device != m->ctx->device) return DLIOM_ERR_INVALID_ARGUMENT;  // the pyramid lives on the creating device
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   StagedClouds c;
-  DLIOM_TRY(stage(m, data, &c));
+  DLIOM_TRY(stage(ctx, data, &c));
   Search s;
   s.m = m;
+  s.ctx = ctx;
   s.linear_xy = static_cast<int>(std::lround(m->options.linear_xy_search_window / m->resolution));
   s.linear_z = static_cast<int>(std::lround(m->options.linear_z_search_window / m->resolution));
   s.angular_window = m->options.angular_search_window;

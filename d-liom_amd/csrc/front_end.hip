@@ -99,7 +99,7 @@ struct dliom_front_end {
     bool finished = false;
   };
   std::vector<std::unique_ptr<Submap>> submaps;  // ActiveSubmaps3D::submaps_ (<= 2)
-  std::vector<std::unique_ptr<Submap>> retired;  // finished submaps stay owned (grids resident)
+  std::vector<std::unique_ptr<Submap>> retired;  // finished submaps, oldest first, until the caller takes them
   int matching_submap_index = 0;
   // MotionFilter state
   int64_t num_total = 0;
@@ -117,6 +117,9 @@ struct dliom_front_end {
       // a finished submap is never matched by the online matcher again: give its dense mirror back
       // (272 MB at 10 cm / +-25.6 m); the leaf pool stays for the back end
       if (submaps.front()->hi != nullptr) submaps.front()->hi->drop_dense();
+      // ... and the slack of its leaf pools (sized for the worst case while the submap was active)
+      if (submaps.front()->hi != nullptr) DLIOM_TRY(submaps.front()->hi->shrink_to_fit());
+      if (submaps.front()->lo != nullptr) DLIOM_TRY(submaps.front()->lo->shrink_to_fit());
       ++matching_submap_index;
       retired.push_back(std::move(submaps.front()));
       submaps.erase(submaps.begin());
@@ -330,9 +333,10 @@ int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double
       return DLIOM_OK;  // similar: nothing inserted
     }
   }
-  fe->last_time = time_ticks;
-  fe->last_pose = pose;
-  if (fe->returns_cloud == nullptr) return DLIOM_ERR_EMPTY_CLOUD;
+  if (fe->returns_cloud == nullptr) {
+    --fe->num_total;  // nothing happened: the filter state must not advance on an error
+    return DLIOM_ERR_EMPTY_CLOUD;
+  }
 
   // filtered_range_data_in_local = TransformRangeData(in_tracking, opt_pose.cast<float>()) (:560-561)
   // then per submap TransformRangeData(., local_pose().inverse().cast<float>()) (submap_3d.cc:270-271)
@@ -360,10 +364,19 @@ int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double
       target_max_range[nt] = hl == 0 ? hi_max_range : 0.f;
       ++nt;
     }
-    ++s.num_range_data;
   }
-  DLIOM_TRY(dliom_inserter_insert_cloud_multi(fe->inserter, nt, targets, target_poses, target_num_poses, fe->origin,
-                                              fe->returns_cloud, target_max_range));
+  {
+    const int status = dliom_inserter_insert_cloud_multi(fe->inserter, nt, targets, target_poses, target_num_poses, fe->origin,
+                                                         fe->returns_cloud, target_max_range);
+    if (status != DLIOM_OK) {
+      --fe->num_total;  // a failed insertion leaves MotionFilter and the submap counters where they were
+      std::memset(r, 0, sizeof(*r));
+      return status;
+    }
+  }
+  fe->last_time = time_ticks;  // MotionFilter::IsSimilar's state update (motion_filter.cc:54-56), now that it is final
+  fe->last_pose = pose;
+  for (auto& sm : fe->submaps) ++sm->num_range_data;
   if (fe->submaps.back()->num_range_data == o.num_range_data) {  // submap_3d.cc:310-313
     // new submap at (range_data.origin in the local frame, gravity_alignment)
     const QF qf{poses[3], poses[4], poses[5], poses[6]};
@@ -391,6 +404,24 @@ int dliom_front_end_num_active_submaps(const dliom_front_end* fe, int* n) {
 int dliom_front_end_matching_index(const dliom_front_end* fe, int* index) {
   if (fe == nullptr || index == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   *index = fe->matching_submap_index;
+  return DLIOM_OK;
+}
+
+int dliom_front_end_num_finished_submaps(const dliom_front_end* fe, int* n) {
+  if (fe == nullptr || n == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *n = static_cast<int>(fe->retired.size());
+  return DLIOM_OK;
+}
+
+int dliom_front_end_take_finished_submap(dliom_front_end* fe, double local_pose[7], int* num_range_data, dliom_grid** hi,
+                                         dliom_grid** lo) {
+  if (fe == nullptr || hi == nullptr || lo == nullptr || fe->retired.empty()) return DLIOM_ERR_INVALID_ARGUMENT;
+  std::unique_ptr<dliom_front_end::Submap> s = std::move(fe->retired.front());
+  fe->retired.erase(fe->retired.begin());
+  if (local_pose != nullptr) pose_to(s->local_pose, local_pose);
+  if (num_range_data != nullptr) *num_range_data = s->num_range_data;
+  *hi = s->hi;  // ownership moves to the caller: dliom_grid_destroy() when the back end is done with them
+  *lo = s->lo;
   return DLIOM_OK;
 }
 

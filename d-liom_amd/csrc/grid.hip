@@ -571,6 +571,30 @@ int dliom_grid::ensure_capacity(int64_t additional_slots) {
   return DLIOM_OK;
 }
 
+// Reallocates the leaf pool to the slots in use (rounded up to 256): a finished submap is never inserted into
+// again, and insertion sizes the pool for the worst case (every return and free-space voxel in a new leaf).
+int dliom_grid::shrink_to_fit() {
+  int64_t count = 0;
+  DLIOM_TRY(refresh_count(&count));
+  const int64_t want = std::max<int64_t>(256, (count + 255) & ~int64_t{255});
+  if (d_pool == nullptr || want >= capacity) return DLIOM_OK;
+  uint16_t* new_pool = nullptr;
+  int32_t* new_coord = nullptr;
+  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&new_pool), static_cast<size_t>(want) * 1024));
+  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&new_coord), static_cast<size_t>(want) * 12));
+  DLIOM_HIP_TRY(hipMemsetAsync(new_pool, 0, static_cast<size_t>(want) * 1024, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(new_pool, d_pool, static_cast<size_t>(count) * 1024, hipMemcpyDeviceToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(new_coord, d_slot_coord, static_cast<size_t>(count) * 12, hipMemcpyDeviceToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  DLIOM_HIP_TRY(hipFree(d_pool));
+  DLIOM_HIP_TRY(hipFree(d_slot_coord));
+  d_pool = new_pool;
+  d_slot_coord = new_coord;
+  capacity = want;
+  used_upper = count;
+  return DLIOM_OK;
+}
+
 extern "C" {
 
 int dliom_grid_create(dliom_ctx* ctx, float resolution, dliom_grid** out) {

@@ -120,6 +120,7 @@ struct dliom_grid {
   dliom::GridView view() const;
   int ensure_bits(int needed_bits);
   int ensure_capacity(int64_t additional_slots);
+  int shrink_to_fit();  // pool := the leaves in use (finished submaps keep no slack)
   int refresh_count(int64_t* count);
 };
 

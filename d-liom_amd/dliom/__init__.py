@@ -210,6 +210,8 @@ SYMBOLS = [
     ("dliom_front_end_match_cloud", C.c_int, [_vp, _f64p, _f32p, _vp, C.POINTER(MatchResult)]),
     ("dliom_front_end_insert", C.c_int, [_vp, C.c_int64, _f64p, _f64p, C.POINTER(InsertionResult)]),
     ("dliom_front_end_num_active_submaps", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("dliom_front_end_num_finished_submaps", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("dliom_front_end_take_finished_submap", C.c_int, [_vp, _f64p, C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_front_end_matching_index", C.c_int, [_vp, C.POINTER(C.c_int)]),
     ("dliom_front_end_active_submap", C.c_int, [_vp, C.c_int, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                 C.POINTER(_vp), C.POINTER(_vp)]),
@@ -222,11 +224,12 @@ SYMBOLS = [
     ("dliom_fast_csm_create", C.c_int, [_vp, _vp, _vp, _f32p, _f32p, C.c_int, C.c_int, C.POINTER(FastCsmOptions),
                                         C.POINTER(_vp)]),
     ("dliom_fast_csm_destroy", C.c_int, [_vp]),
-    ("dliom_fast_csm_match", C.c_int, [_vp, _f64p, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
+    ("dliom_ctx_device", C.c_int, [_vp]),
+    ("dliom_fast_csm_match", C.c_int, [_vp, _vp, _f64p, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
                                        C.POINTER(FastCsmResult)]),
-    ("dliom_fast_csm_match_full_submap", C.c_int, [_vp, _f64p, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
+    ("dliom_fast_csm_match_full_submap", C.c_int, [_vp, _vp, _f64p, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
                                                    C.POINTER(FastCsmResult)]),
-    ("dliom_fast_csm_match_with_3dof_initial", C.c_int, [_vp, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
+    ("dliom_fast_csm_match_with_3dof_initial", C.c_int, [_vp, _vp, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
                                                          C.POINTER(FastCsmResult)]),
     ("dliom_fast_csm_level", C.c_int, [_vp, C.c_int, _i32p, _i32p, C.POINTER(C.c_uint8), C.c_int64]),
     ("dliom_imu_window_default_options", C.c_int, [C.POINTER(ImuWindowOptions)]),
@@ -864,6 +867,25 @@ class LocalTrajectoryBuilder3D:
         _check(self._L.dliom_front_end_matching_index(self.h, C.byref(n)), "matching_index")
         return n.value
 
+    def num_finished_submaps(self):
+        n = C.c_int()
+        _check(self._L.dliom_front_end_num_finished_submaps(self.h, C.byref(n)), "num_finished_submaps")
+        return n.value
+
+    def take_finished_submap(self):
+        """Oldest finished submap; its grids are OWNED by the returned HybridGrid objects (close() frees them)."""
+        pose = np.zeros(7)
+        n = C.c_int()
+        hi, lo = _vp(), _vp()
+        _check(self._L.dliom_front_end_take_finished_submap(self.h, _p(pose, _f64p), C.byref(n), C.byref(hi), C.byref(lo)),
+               "take_finished_submap")
+        grids = []
+        for h, res in ((hi, self.resolutions[0]), (lo, self.resolutions[1])):
+            g = HybridGrid.__new__(HybridGrid)
+            g._L, g.ctx, g.resolution, g.h = self._L, self.ctx, float(np.float32(res)), h
+            grids.append(g)
+        return dict(local_pose=pose, num_range_data=n.value, hi=grids[0], lo=grids[1])
+
     def active_submap(self, i):
         pose = np.zeros(7)
         n, fin = C.c_int(), C.c_int()
@@ -1044,22 +1066,23 @@ class FastCorrelativeScanMatcher3D:
                     num_scored_candidates=r.num_scored_candidates, num_score_launches=r.num_score_launches,
                     pose=np.array(r.pose_estimate) if r.found else None)
 
-    def Match(self, global_node_pose, global_submap_pose, data, min_score):
+    def Match(self, global_node_pose, global_submap_pose, data, min_score, ctx=None):
+        """ctx: the calling thread's Context (default: the one the matcher was created on)."""
         d, r = self._data(data), FastCsmResult()
-        _check(self._L.dliom_fast_csm_match(self.h, _p(_f64(global_node_pose), _f64p), _p(_f64(global_submap_pose), _f64p),
+        _check(self._L.dliom_fast_csm_match((ctx or self.ctx).h, self.h, _p(_f64(global_node_pose), _f64p), _p(_f64(global_submap_pose), _f64p),
                                             C.byref(d), C.c_float(min_score), C.byref(r)), "dliom_fast_csm_match")
         return self._result(r)
 
-    def MatchFullSubmap(self, global_node_rotation, global_submap_rotation, data, min_score):
+    def MatchFullSubmap(self, global_node_rotation, global_submap_rotation, data, min_score, ctx=None):
         d, r = self._data(data), FastCsmResult()
-        _check(self._L.dliom_fast_csm_match_full_submap(self.h, _p(_f64(global_node_rotation), _f64p),
+        _check(self._L.dliom_fast_csm_match_full_submap((ctx or self.ctx).h, self.h, _p(_f64(global_node_rotation), _f64p),
                                                         _p(_f64(global_submap_rotation), _f64p), C.byref(d),
                                                         C.c_float(min_score), C.byref(r)), "dliom_fast_csm_match_full_submap")
         return self._result(r)
 
-    def MatchWith3DofInitial(self, pose_in_submap_guess, data, min_score):
+    def MatchWith3DofInitial(self, pose_in_submap_guess, data, min_score, ctx=None):
         d, r = self._data(data), FastCsmResult()
-        _check(self._L.dliom_fast_csm_match_with_3dof_initial(self.h, _p(_f64(pose_in_submap_guess), _f64p), C.byref(d),
+        _check(self._L.dliom_fast_csm_match_with_3dof_initial((ctx or self.ctx).h, self.h, _p(_f64(pose_in_submap_guess), _f64p), C.byref(d),
                                                               C.c_float(min_score), C.byref(r)),
                "dliom_fast_csm_match_with_3dof_initial")
         return self._result(r)

@@ -61,6 +61,7 @@ int dliom_ctx_create(int device_id, dliom_ctx** out);
 int dliom_ctx_create_on_stream(int device_id, void* hip_stream, dliom_ctx** out);
 int dliom_ctx_destroy(dliom_ctx* ctx);
 int dliom_ctx_synchronize(dliom_ctx* ctx);
+int dliom_ctx_device(const dliom_ctx* ctx); /* the device id it was created on (-1 for NULL) */
 
 /* ---- probability value tables (host; mapping/probability_values.cc:73-83) --
  * table[v] = ProbabilityToValue(ProbabilityFromOdds(odds * Odds(p(v)))) + 32768,
@@ -326,6 +327,14 @@ int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double
 /* ActiveSubmaps3D::submaps() / matching_index(). */
 int dliom_front_end_num_active_submaps(const dliom_front_end* fe, int* n);
 int dliom_front_end_matching_index(const dliom_front_end* fe, int* index);
+/* Finished submaps (Submap3D::Finish(), submap_3d.cc:316-326) leave the active pair but stay alive for the back end:
+ * the reference hands them on as shared_ptr and drops them when the pose graph is done.  Here the front end holds
+ * them (leaf pools shrunk to the leaves in use, dense mirror released) until the caller TAKES them, oldest first;
+ * a taken submap's grids belong to the caller (dliom_grid_destroy).  Not taking them keeps every finished submap
+ * resident. */
+int dliom_front_end_num_finished_submaps(const dliom_front_end* fe, int* n);
+int dliom_front_end_take_finished_submap(dliom_front_end* fe, double local_pose[7], int* num_range_data,
+                                         dliom_grid** high_resolution_grid, dliom_grid** low_resolution_grid);
 int dliom_front_end_active_submap(const dliom_front_end* fe, int i, double local_pose[7], int* num_range_data,
                                   int* finished, dliom_grid** high_resolution_grid,
                                   dliom_grid** low_resolution_grid);
@@ -411,12 +420,12 @@ int dliom_fast_csm_create(dliom_ctx* ctx, const dliom_grid* high_resolution_grid
                           const dliom_fast_csm_options* options, dliom_fast_csm** out);
 int dliom_fast_csm_destroy(dliom_fast_csm* matcher);
 /* Match (:147-165), MatchFullSubmap (:204-232), MatchWith3DofInitial (:168-201). */
-int dliom_fast_csm_match(dliom_fast_csm* matcher, const double global_node_pose[7], const double global_submap_pose[7],
+int dliom_fast_csm_match(dliom_ctx* ctx, const dliom_fast_csm* matcher, const double global_node_pose[7], const double global_submap_pose[7],
                          const dliom_fast_csm_node_data* constant_data, float min_score, dliom_fast_csm_result* result);
-int dliom_fast_csm_match_full_submap(dliom_fast_csm* matcher, const double global_node_rotation[4],
+int dliom_fast_csm_match_full_submap(dliom_ctx* ctx, const dliom_fast_csm* matcher, const double global_node_rotation[4],
                                      const double global_submap_rotation[4], const dliom_fast_csm_node_data* constant_data,
                                      float min_score, dliom_fast_csm_result* result);
-int dliom_fast_csm_match_with_3dof_initial(dliom_fast_csm* matcher, const double pose_in_submap_guess[7],
+int dliom_fast_csm_match_with_3dof_initial(dliom_ctx* ctx, const dliom_fast_csm* matcher, const double pose_in_submap_guess[7],
                                            const dliom_fast_csm_node_data* constant_data, float min_score,
                                            dliom_fast_csm_result* result);
 /* One level of the pyramid: a dense box of dims[0]*dims[1]*dims[2] uint8 (x fastest) whose element

@@ -136,3 +136,51 @@ def test_loop_closure_on_synthetic_submap_equals_oracle(dl, ctx, orc, frd, depth
     dm.close()
     for g in (g_hi, g_lo):
         g.close()
+
+
+def test_one_matcher_many_threads(dl, ctx, orc):
+    """FastCorrelativeScanMatcher3D::Match is const and called concurrently from the ConstraintBuilder3D pool
+    threads on ONE per-submap matcher (constraint_builder_3d.cc:270-275): four threads, each with its own
+    context, hammer the same matcher with different node poses; every result equals the serial one."""
+    import threading
+    from dliom import synth
+    og_hi = build_oracle_submap(orc, 0.2, num_scans=6, beams=16, azimuths=256, max_range=40.0)
+    og_lo = build_oracle_submap(orc, 0.5, num_scans=6, beams=16, azimuths=256)
+    g_hi, g_lo = to_device_grid(dl, ctx, og_hi), to_device_grid(dl, ctx, og_lo)
+    opts = dict(branch_and_bound_depth=6, full_resolution_depth=3, min_rotational_score=0.3, min_low_resolution_score=0.3,
+                linear_xy_search_window=3.0, linear_z_search_window=1.0, angular_search_window=np.deg2rad(20.0))
+    hists, yaws = [], []
+    for s in range(6):
+        pose = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(pose, 16, 256)
+        hists.append(orc.compute_histogram(pts, 30))
+        yaws.append(float(np.arctan2(2 * (pose[3] * pose[6] + pose[4] * pose[5]), 1 - 2 * (pose[5] ** 2 + pose[6] ** 2))))
+    dm = dl.FastCorrelativeScanMatcher3D(ctx, g_hi, g_lo, np.array(hists), yaws, opts)
+    truth = synth.trajectory_pose(0.35)
+    pts, _ = synth.scan(truth, 16, 256)
+    data = dict(gravity_alignment=[1, 0, 0, 0], high_resolution_point_cloud=orc.adaptive_voxel_filter(2.0, 150, 15.0, pts),
+                low_resolution_point_cloud=orc.adaptive_voxel_filter(4.0, 200, 60.0, pts),
+                rotational_scan_matcher_histogram=orc.compute_histogram(pts, 30))
+    node_poses = [synth.perturb_pose(truth, 1.0 + 0.2 * k, 6.0, seed=30 + k) for k in range(4)]
+    serial = [dm.Match(p, IDENT, data, 0.2) for p in node_poses]
+    results = [[None] * 6 for _ in node_poses]
+    ctxs = [dl.Context(0) for _ in node_poses]
+
+    def worker(k):
+        for rep in range(6):
+            results[k][rep] = dm.Match(node_poses[k], IDENT, data, 0.2, ctx=ctxs[k])
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(node_poses))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k, want in enumerate(serial):
+        for got in results[k]:
+            assert got is not None
+            same_result(got, want)
+    for c in ctxs:
+        c.close()
+    dm.close()
+    for g in (g_hi, g_lo):
+        g.close()

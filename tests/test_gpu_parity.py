@@ -891,3 +891,44 @@ def test_rtcsm3d_score_volume_ragged_clouds_and_far_poses(dl, ctx, orc, n, seed)
     want = orc.rtcsm3d_value_sums(dict(DEFAULT_RTCSM, angular_search_window=np.deg2rad(0.6)), init, pts, og)
     assert np.array_equal(got, want)
     dg.close()
+
+
+def test_finished_submaps_are_handed_over_and_shrunk(dl, ctx, orc):
+    """Finished submaps leave the active pair, keep exactly their cells (pool shrunk to the leaves in use, dense
+    mirror released) and belong to the caller once taken -- the front end does not accumulate them.  The first
+    finished submap is compared bit for bit with an oracle front end that never rolls over (same first submap)."""
+    from dliom import synth
+    opts = dict(FRONT_END_OPTS)
+    dfe = dl.LocalTrajectoryBuilder3D(ctx, opts)
+    twin = orc.FrontEnd(dict(opts, submaps=dict(opts["submaps"], num_range_data=1000)))
+    gravity = np.array([1.0, 0, 0, 0])
+    taken = 0
+    for s in range(14):
+        truth = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(truth, 16, 256)
+        pts = pts[orc.voxel_filter(0.15, pts)]
+        prediction = synth.perturb_pose(truth, 0.03, 0.2, seed=100 + s)
+        r = dfe.match(prediction, np.zeros(3, np.float32), pts)
+        twin.match(prediction, np.zeros(3, np.float32), pts)
+        before = dfe.num_finished_submaps()
+        front = dfe.active_submap(0)
+        front_n, front_keys = front["num_range_data"], set(front["hi"].cells())
+        dfe.insert(int(s * 1e6), r["pose_estimate"], gravity)
+        twin.insert(int(s * 1e6), r["pose_estimate"], gravity)
+        if dfe.num_finished_submaps() == before + 1:  # this insertion finished the front submap (submap_3d.cc:310-326)
+            sub = dfe.take_finished_submap()
+            taken += 1
+            assert dfe.num_finished_submaps() == before
+            assert sub["num_range_data"] == front_n + 1
+            cells = sub["hi"].cells()
+            assert front_keys <= set(cells)
+            if taken == 1:
+                so = twin.active_submap(0, (0.1, 0.45))
+                assert sub["num_range_data"] == so["num_range_data"]
+                assert cells == oracle_cells_dict(so["hi"]) and sub["lo"].cells() == oracle_cells_dict(so["lo"])
+            sub["hi"].close()
+            sub["lo"].close()
+    assert taken >= 2
+    with pytest.raises(Exception):
+        dfe.take_finished_submap()  # nothing left
+    dfe.close()
