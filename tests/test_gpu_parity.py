@@ -563,10 +563,11 @@ def _timed_scan(beams=32, azimuths=256, k=5):
 
 
 def test_deskew_matches_oracle(dl, ctx, orc):
-    """AddRangeData's per-hit de-skew + range gate on the device vs the oracle.  Float tolerance:
-    the slerp coefficients come from the device's double sin/acos, so a point may differ from the
-    host path by float rounding of its pose (<= 4e-6 m at these ranges); gate decisions must agree
-    except for hits within that tolerance of the min/max range."""
+    """AddRangeData's per-hit de-skew + range gate on the device vs the oracle: bit-identical points, gate
+    decisions and current pose.  (The slerp weights are doubles from the device's sin / acos, which may differ
+    from glibc's in the last ulp of a DOUBLE; the per-hit pose is cast to float right after
+    (local_trajectory_builder_3d.cc:446), which absorbs that unless a value sits within 2^-52 of a float rounding
+    boundary -- never observed: 0 of 65 129 hits on the 64 x 1024 scan.)"""
     prev, cur, ranges = _timed_scan()
     vfs, min_r, max_r, T = 0.15, 1.0, 20.0, 0.1
     ref = orc.deskew_and_filter(T, min_r, max_r, vfs, prev, cur, ranges)
@@ -575,11 +576,9 @@ def test_deskew_matches_oracle(dl, ctx, orc):
     assert len(hits) == len(ref["hits_in_local"])
     xyz, kind, cur_f = dl.deskew(ctx, prev, cur, T, hits, (0, 0, 0), min_r, max_r)
     ret = kind == 1
-    assert np.abs(xyz[ret] - ref["hits_in_local"][ret]).max() <= 4e-6
-    assert np.abs(cur_f - ref["current_pose"]).max() <= 1e-6
-    rng = np.linalg.norm(ref["hits_in_local"].astype(np.float64) - cur[:3], axis=1)  # ~range (origin = sensor)
-    borderline = (np.abs(rng - min_r) < 1e-4) | (np.abs(rng - max_r) < 1e-4)
-    assert np.array_equal(kind[~borderline], ref["kind"][~borderline].astype(np.uint8))
+    assert np.array_equal(xyz[ret].view(np.uint32), ref["hits_in_local"][ret].astype(np.float32).view(np.uint32))
+    assert np.array_equal(cur_f, ref["current_pose"].astype(np.float32))
+    assert np.array_equal(kind, ref["kind"].astype(np.uint8))
     assert (kind == 2).sum() > 0 and (kind == 1).sum() > 0
     # "not de-skewing" branch: no per-point stamps -> every hit takes the predicted pose, bit-exact
     flat = hits.copy()
@@ -597,11 +596,9 @@ def test_add_range_data_preprocess_chain(dl, ctx, orc):
     vfs, min_r, max_r, T = 0.15, 1.0, 100.0, 0.1
     ref = orc.deskew_and_filter(T, min_r, max_r, vfs, prev, cur, ranges)
     returns, origin, cur_f = dl.add_range_data_preprocess(ctx, prev, cur, T, ranges, (0, 0, 0), min_r, max_r, vfs)
-    # same voxels survive (a 1e-6 m wobble can move a point across a voxel face only in rare cases)
-    assert abs(len(returns) - len(ref["returns_in_tracking"])) <= 2
-    if len(returns) == len(ref["returns_in_tracking"]):
-        assert np.abs(returns - ref["returns_in_tracking"]).max() <= 1e-5
-    assert np.abs(origin - ref["origin_in_tracking"]).max() <= 1e-5
+    # the same voxels survive, with the same coordinates
+    assert np.array_equal(returns.view(np.uint32), ref["returns_in_tracking"].astype(np.float32).view(np.uint32))
+    assert np.array_equal(origin, ref["origin_in_tracking"].astype(np.float32))
 
 
 @pytest.mark.gpu
@@ -609,7 +606,7 @@ def test_add_range_data_preprocess_chain(dl, ctx, orc):
 def test_add_range_data_device_chain(dl, ctx, orc, beams, azimuths, k):
     """dliom_add_range_data (every stage in HBM) is bit-identical to the staged chain (host voxel
     filters + device de-skew + host transform), whose filters are pinned to the oracle elsewhere;
-    and within float rounding of the oracle's whole AddRangeData restatement."""
+    and to the oracle's whole AddRangeData restatement: identical survivors, identical coordinates."""
     prev, cur, ranges = _timed_scan(beams, azimuths, k=k)
     vfs, min_r, max_r, T = 0.15, 1.0, 100.0, 0.1
     returns, origin, cur_f = dl.add_range_data_preprocess(ctx, prev, cur, T, ranges, (0, 0, 0), min_r, max_r, vfs)
@@ -619,7 +616,8 @@ def test_add_range_data_device_chain(dl, ctx, orc, beams, azimuths, k):
     assert np.array_equal(got.view(np.uint32), returns.view(np.uint32))
     assert np.array_equal(origin_d, origin) and np.array_equal(cur_d, cur_f)
     ref = orc.deskew_and_filter(T, min_r, max_r, vfs, prev, cur, ranges)
-    assert abs(len(got) - len(ref["returns_in_tracking"])) <= 2 + len(got) // 20000
+    assert np.array_equal(got.view(np.uint32), ref["returns_in_tracking"].astype(np.float32).view(np.uint32))
+    assert np.array_equal(origin_d, ref["origin_in_tracking"].astype(np.float32))
     # a gated scan: min_range above some returns, max_range below others
     r2, o2, c2 = dl.add_range_data_preprocess(ctx, prev, cur, T, ranges, (0, 0, 0), 12.0, 16.0, vfs)
     cl2, od2, cd2 = dl.add_range_data(ctx, prev, cur, T, ranges, (0, 0, 0), 12.0, 16.0, vfs)
