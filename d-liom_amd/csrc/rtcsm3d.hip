@@ -23,6 +23,9 @@
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the library is resolved at run time (dlopen), see rccl_api()
+
 #include "device_common.h"
 #include "host_math.h"
 #include "score_box.h"
@@ -2019,6 +2022,102 @@ int dliom_rtcsm3d_shard_decode(dliom_ctx* ctx, uint64_t global_best_packed, doub
                                float* score) {
   if (ctx == nullptr || pose_estimate == nullptr || score == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   return match_decode(ctx, global_best_packed, pose_estimate, score);
+}
+
+// ---- config 4: the search window sharded over the ranks of a node, ONE 8-byte collective per match --------------
+// Every rank scores its own contiguous range of candidate rotations and finds ITS winner exactly (own bounds, own
+// exact rescoring).  The global winner -- the reference's first strictly greater score in generation order
+// (rtcsm_3d.cc:46-51) -- is the maximum of the ranks' packed words (score_bits << 32 | ~index): positive floats order
+// like their bit patterns and the complemented index lets the lower index win ties.  One MAX all-reduce of one
+// uint64; its 8 bytes are latency, not bandwidth.  The three-phase calls above stay for callers that
+// want the global lower bound exchanged first (less rescoring per rank, two collectives).
+int dliom_rtcsm3d_match_sharded(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7], const dliom_cloud* cloud,
+                                const dliom_grid* grid, int shard, int num_shards, dliom_allreduce_max_u64 exchange,
+                                void* user, double out7[7], float* score) {
+  if (ctx == nullptr || o == nullptr || init7 == nullptr || cloud == nullptr || grid == nullptr || out7 == nullptr ||
+      score == nullptr || (num_shards > 1 && exchange == nullptr))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_TRY(match_begin(ctx, o, init7, *cloud, grid, shard, num_shards, nullptr));
+  uint64_t packed = 0;
+  DLIOM_TRY(match_finish(ctx, nullptr, &packed));
+  if (num_shards > 1 && exchange(&packed, user) != 0) return DLIOM_ERR_INVALID_ARGUMENT;
+  return match_decode(ctx, packed, out7, score);
+}
+
+}  // extern "C"
+
+namespace {
+struct RcclApi {
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  bool ok = false;
+};
+// librccl is looked up when the first sharded match runs: libdliom.so itself loads (and every other entry point
+// works) on machines without RCCL.
+const RcclApi& rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) return a;
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
+    a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.ok = a.CommCount != nullptr && a.CommUserRank != nullptr && a.AllReduce != nullptr;
+    return a;
+  }();
+  return api;
+}
+struct RcclExchange {
+  dliom_ctx* ctx;
+  ncclComm_t comm;
+};
+int rccl_exchange(uint64_t* value, void* user) {
+  RcclExchange* x = static_cast<RcclExchange*>(user);
+  dliom_ctx* ctx = x->ctx;
+  if (ctx->misc.reserve(256) != DLIOM_OK) return 1;
+  uint64_t* d = ctx->misc.as<uint64_t>();
+  uint64_t* h = reinterpret_cast<uint64_t*>(static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 4096 + 3072);
+  *h = *value;
+  if (hipMemcpyAsync(d, h, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 1;
+  if (rccl_api().AllReduce(d, d, 1, ncclUint64, ncclMax, x->comm, ctx->stream) != ncclSuccess) return 1;
+  if (hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 1;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 1;
+  *value = *h;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int dliom_rtcsm3d_match_sharded_rccl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
+                                     const dliom_cloud* cloud, const dliom_grid* grid, void* nccl_comm, double out7[7],
+                                     float* score) {
+  if (ctx == nullptr || nccl_comm == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  const RcclApi& api = rccl_api();
+  if (!api.ok) {
+    set_last_error("dlopen(librccl.so.1): RCCL not available", hipErrorSharedObjectInitFailed, __FILE__, __LINE__);
+    return DLIOM_ERR_HIP;
+  }
+  int rank = 0, size = 1;
+  ncclComm_t comm = static_cast<ncclComm_t>(nccl_comm);
+  if (api.CommCount(comm, &size) != ncclSuccess || api.CommUserRank(comm, &rank) != ncclSuccess) return DLIOM_ERR_INVALID_ARGUMENT;
+  RcclExchange x{ctx, comm};
+  // a communicator of one rank still goes through ncclAllReduce (size 1 is a copy): same code path as on 8 GPUs
+  if (size == 1) {
+    if (ctx == nullptr || o == nullptr || init7 == nullptr || cloud == nullptr || grid == nullptr || out7 == nullptr ||
+        score == nullptr)
+      return DLIOM_ERR_INVALID_ARGUMENT;
+    DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+    DLIOM_TRY(match_begin(ctx, o, init7, *cloud, grid, 0, 1, nullptr));
+    uint64_t packed = 0;
+    DLIOM_TRY(match_finish(ctx, nullptr, &packed));
+    if (rccl_exchange(&packed, &x) != 0) return DLIOM_ERR_HIP;
+    return match_decode(ctx, packed, out7, score);
+  }
+  return dliom_rtcsm3d_match_sharded(ctx, o, init7, cloud, grid, rank, size, rccl_exchange, &x, out7, score);
 }
 
 int dliom_rtcsm3d_box_error(dliom_ctx* ctx, uint32_t* flags) {

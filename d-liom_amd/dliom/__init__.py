@@ -128,6 +128,9 @@ class ImuNoise(C.Structure):
     _fields_ = [("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double)]
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint64), C.c_void_p)
+
+
 class ImuWindowOptions(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "acc_noise", "gyr_noise", "acc_bias_noise", "gyr_bias_noise", "gravity", "integration_sigma", "prior_pose_noise",
@@ -200,6 +203,10 @@ SYMBOLS = [
     ("dliom_rtcsm3d_window", C.c_int, [C.POINTER(RtcsmOptions), C.c_float, _f32p, C.c_int64, C.POINTER(RtcsmWindow)]),
     ("dliom_rtcsm3d_last_stats", C.c_int, [_vp, C.POINTER(RtcsmStats)]),
     ("dliom_rtcsm3d_box_error", C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    ("dliom_rtcsm3d_match_sharded", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, C.c_int, C.c_int, EXCHANGE_FN,
+                                              _vp, _f64p, C.POINTER(C.c_float)]),
+    ("dliom_rtcsm3d_match_sharded_rccl", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, _vp, _f64p,
+                                                   C.POINTER(C.c_float)]),
     ("dliom_csm3d_match", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, C.c_int, C.POINTER(_f32p), _i64p,
                                     C.POINTER(_vp), _f64p, C.POINTER(CsmSummary)]),
     ("dliom_csm3d_match_cloud", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, C.c_int, C.POINTER(_vp),
@@ -662,8 +669,33 @@ class RealTimeCorrelativeScanMatcher3D:
 
 
 class RtcsmShard:
-    """One rank's share of a sharded RealTimeCorrelativeScanMatcher3D::Match (BASELINE config 4):
-    the three local phases of include/dliom.h; the two all-reduces live in dliom.sharded."""
+    """One rank's share of a sharded RealTimeCorrelativeScanMatcher3D::Match (BASELINE config 4): match() is the
+    one-collective protocol of dliom_rtcsm3d_match_sharded (the collective is the caller's function), begin / finish /
+    decode the three local phases of the two-collective variant."""
+
+    def match(self, initial_pose_estimate, cloud, hybrid_grid, all_reduce_max):
+        """all_reduce_max(int) -> int: MAX over the ranks of one unsigned 64-bit value."""
+        def cb(value_ptr, _user):
+            try:
+                value_ptr[0] = int(all_reduce_max(int(value_ptr[0])))
+                return 0
+            except Exception:
+                return 1
+        fn = EXCHANGE_FN(cb)
+        out, score = np.zeros(7), C.c_float()
+        _check(self._L.dliom_rtcsm3d_match_sharded(self.ctx.h, C.byref(self.options), _p(_f64(initial_pose_estimate), _f64p),
+                                                   cloud.h, hybrid_grid.h, self.shard, self.num_shards, fn, None,
+                                                   _p(out, _f64p), C.byref(score)), "dliom_rtcsm3d_match_sharded")
+        return score.value, out
+
+    def match_rccl(self, initial_pose_estimate, cloud, hybrid_grid, nccl_comm):
+        """nccl_comm: an ncclComm_t as an integer / c_void_p; rank and size are the communicator's."""
+        out, score = np.zeros(7), C.c_float()
+        _check(self._L.dliom_rtcsm3d_match_sharded_rccl(self.ctx.h, C.byref(self.options),
+                                                        _p(_f64(initial_pose_estimate), _f64p), cloud.h, hybrid_grid.h,
+                                                        C.c_void_p(nccl_comm), _p(out, _f64p), C.byref(score)),
+               "dliom_rtcsm3d_match_sharded_rccl")
+        return score.value, out
 
     def __init__(self, ctx, options, shard, num_shards):
         self.ctx = ctx

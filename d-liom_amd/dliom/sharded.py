@@ -2,16 +2,14 @@
 (BASELINE config 4).
 
 Every rank holds the scan and the submap grid (replicated: a 64x1024 scan is 786 KB) and owns a
-contiguous range of the candidate rotations.  Two 8-byte MAX all-reduces over RCCL/xGMI make the
-result identical to the unsharded match on every rank:
-
-  1. the best score lower bound  -> every rank prunes against the GLOBAL bound
-  2. the packed winner (score_bits << 32 | 0xFFFFFFFF - candidate_index): positive floats order
-     like their bit patterns and the complemented index makes the LOWER index win ties -- the
-     reference's "first strictly greater score in generation order" (rtcsm_3d.cc:46-51).
-
-Both messages are latency bound (8 B); link bandwidth is irrelevant.  `shard` only needs
-begin(...) -> int, finish(int) -> int and decode(int) -> (score, pose): dliom.RtcsmShard on a GPU.
+contiguous range of the candidate rotations.  ONE 8-byte MAX all-reduce over RCCL/xGMI makes the result
+identical to the unsharded match on every rank: each rank finds its own winner exactly and contributes the
+packed word (score_bits << 32 | 0xFFFFFFFF - candidate_index) -- positive floats order like their bit
+patterns and the complemented index makes the LOWER index win ties, the reference's "first strictly greater
+score in generation order" (rtcsm_3d.cc:46-51).  The C entry points are dliom_rtcsm3d_match_sharded (the
+collective is a callback) and dliom_rtcsm3d_match_sharded_rccl (an ncclComm_t); this module is the Python side
+used by bench.py and the tests.  `sharded_match_two_phase` is the older protocol (global lower bound first:
+less rescoring per rank, two collectives); `shard` there only needs begin / finish / decode.
 """
 import numpy as np
 
@@ -27,7 +25,12 @@ def all_reduce_max_int(value, dist=None, device=None):
 
 
 def sharded_match(shard, initial_pose_estimate, cloud, hybrid_grid, dist=None, device=None):
-    """Runs one sharded match; returns (score, pose_estimate[7]) -- the same on every rank."""
+    """One sharded match through dliom_rtcsm3d_match_sharded (one collective); the same result on every rank."""
+    return shard.match(initial_pose_estimate, cloud, hybrid_grid, lambda v: all_reduce_max_int(v, dist, device))
+
+
+def sharded_match_two_phase(shard, initial_pose_estimate, cloud, hybrid_grid, dist=None, device=None):
+    """The two-collective protocol over begin / finish / decode; returns what decode returns."""
     local_lo = shard.begin(initial_pose_estimate, cloud, hybrid_grid)
     global_lo = all_reduce_max_int(local_lo, dist, device)
     local_best = shard.finish(global_lo)

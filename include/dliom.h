@@ -207,6 +207,19 @@ typedef struct dliom_rtcsm_stats {
   int64_t best_index;     /* generation order: ((z,y,x) * R + (rz,ry,rx)) */
 } dliom_rtcsm_stats;
 int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats);
+/* BASELINE config 4 in one call: this rank scores rotations [shard R / num_shards, (shard + 1) R / num_shards), finds its
+ * own winner exactly, and ONE max all-reduce of one uint64 (score_bits << 32 | ~candidate_index) yields the reference's
+ * winner on every rank (rtcsm_3d.cc:46-51: first strictly greater score in generation order).
+ *   _sharded       the collective is the caller's: `exchange` replaces *value by the maximum over all ranks (0 = ok)
+ *   _sharded_rccl  `nccl_comm` is an ncclComm_t (RCCL, resolved with dlopen at first use; rank and size come from the
+ *                  communicator): ncclAllReduce(ncclMax, ncclUint64, count 1) on the context's stream */
+typedef int (*dliom_allreduce_max_u64)(uint64_t* value, void* user);
+int dliom_rtcsm3d_match_sharded(dliom_ctx* ctx, const dliom_rtcsm_options* options, const double initial_pose_estimate[7],
+                                const dliom_cloud* cloud, const dliom_grid* grid, int shard, int num_shards,
+                                dliom_allreduce_max_u64 exchange, void* user, double pose_estimate[7], float* score);
+int dliom_rtcsm3d_match_sharded_rccl(dliom_ctx* ctx, const dliom_rtcsm_options* options,
+                                     const double initial_pose_estimate[7], const dliom_cloud* cloud, const dliom_grid* grid,
+                                     void* nccl_comm, double pose_estimate[7], float* score);
 /* Diagnostic: sticky consistency flags of the LDS-box score kernel on this context (0 = every exactly
  * resolved lookup fell inside its staged box, as the construction guarantees).  Synchronises. */
 int dliom_rtcsm3d_box_error(dliom_ctx* ctx, uint32_t* flags);

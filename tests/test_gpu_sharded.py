@@ -1,0 +1,92 @@
+"""BASELINE config 4 through the C entry points: dliom_rtcsm3d_match_sharded with a gloo collective between two
+processes (both on GPU 0 -- the collective is the caller's, so a one-GPU box can run the two-rank protocol), and
+dliom_rtcsm3d_match_sharded_rccl on a one-rank RCCL communicator (ncclAllReduce really runs)."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(dl, ctx):
+    from oracle import oracle as orc
+    from dliom import synth
+    from helpers import DEFAULT_RTCSM, build_oracle_submap, to_device_grid
+    og = build_oracle_submap(orc, 0.1, num_scans=6, beams=16, azimuths=256)
+    truth = synth.trajectory_pose(0.6)
+    pts, _ = synth.scan(truth, 32, 512)
+    init = synth.perturb_pose(truth, 0.1, 0.5, seed=13)
+    return orc, og, to_device_grid(dl, ctx, og), pts, init, DEFAULT_RTCSM
+
+
+def _worker(rank, world, port, ret):
+    for p in (ROOT, os.path.join(ROOT, "d-liom_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dliom as dl
+    from dliom import sharded
+    ctx = dl.Context(0)
+    orc, og, dg, pts, init, opts = _scene(dl, ctx)
+    cloud = dl.PointCloud(ctx, pts)
+    shard = dl.RtcsmShard(ctx, opts, rank, world)
+    score, pose = sharded.sharded_match(shard, init, cloud, dg, dist=dist)  # -> dliom_rtcsm3d_match_sharded
+    ref = orc.rtcsm3d_match(opts, init, pts, og)
+    ret[rank] = bool(np.float32(score) == np.float32(ref["score"]) and np.array_equal(pose, ref["pose"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_collective_through_the_c_entry_point():
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    ret = mpc.Manager().dict()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert ret.get(0) is True and ret.get(1) is True
+
+
+def test_rccl_entry_point_on_a_one_rank_communicator():
+    import dliom as dl
+    dl.load_library()
+    rccl = C.CDLL("librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    ctx = dl.Context(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    orc, og, dg, pts, init, opts = _scene(dl, ctx)
+    cloud = dl.PointCloud(ctx, pts)
+    score, pose = dl.RtcsmShard(ctx, opts, 0, 1).match_rccl(init, cloud, dg, comm.value)
+    ref = orc.rtcsm3d_match(opts, init, pts, og)
+    assert np.float32(score) == np.float32(ref["score"]) and np.array_equal(pose, ref["pose"])
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+    cloud.close()
+    dg.close()
+    ctx.close()

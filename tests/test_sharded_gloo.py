@@ -63,7 +63,7 @@ def _worker(rank, world, port, ret):
             score, index = sharded.unpack_winner(packed)
             return score, cand[index].astype(np.float64), index
 
-    score, pose, index = sharded.sharded_match(OracleShard(), init, pts, og, dist=dist)
+    score, pose, index = sharded.sharded_match_two_phase(OracleShard(), init, pts, og, dist=dist)
     ok = (index == ref["best_index"] and np.float32(score) == np.float32(ref["score"]) and
           np.array_equal(pose, ref["pose"]))
     ret[rank] = bool(ok)
