@@ -21,7 +21,8 @@ struct DeskewArgs {
   double rel_t[3], rel_q[4];    // prev^-1 * predicted pose at the scan stamp
   float cur_t[3], cur_q[4];     // predicted pose cast to float ("not de-skewing" branch)
   double scan_period;
-  float ox, oy, oz;             // sensor origin in the tracking frame
+  float ox, oy, oz;             // sensor origin in the tracking frame (origin 0)
+  float origins[4][3];          // synchronized_data.origins (RangeDataSynchronizer: up to two lidars; room for 4)
   float min_range, max_range;
   int use_stamps;               // 0: |t_0| < 1e-3, every hit takes the predicted pose
 };
@@ -46,7 +47,8 @@ __device__ __forceinline__ void quat_mul_sse_d(const double* a, const double* b,
 // Inputs / outputs are strided so that packed host layouts (xyzt stride 4, xyz stride 3) and the
 // device SoA layout (stride 1) run the same code.
 __global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, const float* __restrict__ in_y,
-                              const float* __restrict__ in_z, const float* __restrict__ in_t, int in_stride, int n,
+                              const float* __restrict__ in_z, const float* __restrict__ in_t,
+                              const float* __restrict__ in_origin, int in_stride, int n,
                               float* __restrict__ out_x, float* __restrict__ out_y, float* __restrict__ out_z,
                               int out_stride, unsigned char* __restrict__ out_kind,
                               float* __restrict__ last_pose7) {
@@ -109,7 +111,9 @@ __global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, cons
   hx += tx;
   hy += ty;
   hz += tz;
-  rotate_point(q, a.ox, a.oy, a.oz, ox, oy, oz);
+  // synchronized_data.origins.at(hits[i].origin_index) (:458-459); the index rides along as a float channel
+  const int oi_ = in_origin != nullptr ? min(max(static_cast<int>(in_origin[ii]), 0), 3) : 0;
+  rotate_point(q, a.origins[oi_][0], a.origins[oi_][1], a.origins[oi_][2], ox, oy, oz);
   ox += tx;
   oy += ty;
   oz += tz;
@@ -197,6 +201,8 @@ static int make_deskew_args(const double prev_pose[7], const double predicted_po
   a->ox = origin[0];
   a->oy = origin[1];
   a->oz = origin[2];
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < 3; ++i) a->origins[k][i] = origin[i];
   a->min_range = min_range;
   a->max_range = max_range;
   a->use_stamps = std::abs(first_time) < 1e-3 ? 0 : 1;  // hits.front().point_time[3] (:429)
@@ -207,26 +213,23 @@ static int make_deskew_args(const double prev_pose[7], const double predicted_po
 
 using namespace dliom;
 
-extern "C" int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7],
-                                    double scan_period, const float* ranges_xyzt, int64_t n, const float origin[3],
-                                    float min_range, float max_range, float voxel_filter_size,
-                                    dliom_cloud** returns_in_tracking, float origin_in_tracking[3],
-                                    float current_pose[7]) {
-  if (ctx == nullptr || prev_pose == nullptr || predicted_pose == nullptr || origin == nullptr || n < 0 ||
-      returns_in_tracking == nullptr || origin_in_tracking == nullptr || current_pose == nullptr ||
-      (n > 0 && ranges_xyzt == nullptr) || !(scan_period > 0.) || !(voxel_filter_size > 0.f))
-    return DLIOM_ERR_INVALID_ARGUMENT;
-  *returns_in_tracking = nullptr;
-  if (n == 0) return DLIOM_ERR_EMPTY_CLOUD;  // CHECK(!synchronized_data.ranges.empty()) (:383)
-  if (n > (1 << 30)) return DLIOM_ERR_INVALID_ARGUMENT;
-  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+namespace dliom {
+
+// AddRangeData up to the accumulation (:393-472): VoxelFilter(0.5 size) on the timed hits, per-hit de-skew + range
+// gate, the returns compacted in hit order into ctx->misc (x | y | z with stride *stride).  origin_index (one float
+// per range, may be null) and origins (num_origins x 3) are the RangeDataSynchronizer's origin table.
+static int add_range_data_stage_a(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7],
+                                  double scan_period, const float* ranges_xyzt, const float* origin_index, int64_t n,
+                                  const float* origins, int num_origins, float min_range, float max_range,
+                                  float voxel_filter_size, float current_pose[7], const float** returns,
+                                  size_t* stride, int64_t* num_returns) {
   const size_t nn = static_cast<size_t>(n);
   auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-  // scratch: raw AoS | raw SoA (4) | filtered hits SoA (4) | de-skewed SoA (3) + kind | returns (3) |
-  // filtered returns (3) | pose
+  // scratch: raw AoS | raw SoA (4) | filtered hits SoA (4) | de-skewed SoA (3) + kind | returns (3) | origin index in
+  // | origin index filtered | pose
   const size_t off_raw = 0, off_b = al(16 * nn), off_c = off_b + al(16 * nn), off_d = off_c + al(16 * nn),
-               off_kind = off_d + al(12 * nn), off_e = off_kind + al(nn), off_f = off_e + al(12 * nn),
-               off_pose = off_f + al(12 * nn), total = off_pose + 256;
+               off_kind = off_d + al(12 * nn), off_e = off_kind + al(nn), off_oi = off_e + al(12 * nn),
+               off_of = off_oi + al(4 * nn), off_pose = off_of + al(4 * nn), total = off_pose + 256;
   DLIOM_TRY(ctx->misc.reserve(total));
   char* base = static_cast<char*>(ctx->misc.p);
   float* b = reinterpret_cast<float*>(base + off_b);
@@ -234,9 +237,9 @@ extern "C" int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], c
   float* d = reinterpret_cast<float*>(base + off_d);
   unsigned char* kind = reinterpret_cast<unsigned char*>(base + off_kind);
   float* e = reinterpret_cast<float*>(base + off_e);
-  float* f = reinterpret_cast<float*>(base + off_f);
+  float* oi_in = reinterpret_cast<float*>(base + off_oi);
+  float* oi_f = reinterpret_cast<float*>(base + off_of);
   float* d_pose = reinterpret_cast<float*>(base + off_pose);
-  unsigned* d_max_sq = reinterpret_cast<unsigned*>(d_pose + 8);
   const int threads = 256;
   DLIOM_HIP_TRY(hipMemcpyAsync(base + off_raw, ranges_xyzt, 16 * nn, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(split_xyzt_kernel, dim3(static_cast<unsigned>((n + threads - 1) / threads)), dim3(threads), 0,
@@ -246,21 +249,45 @@ extern "C" int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], c
   int64_t n1 = 0;
   DLIOM_TRY(voxel_filter_arrays(ctx, Soa{b, b + nn, b + 2 * nn, b + 3 * nn, n}, 0.5f * voxel_filter_size, c, c + nn,
                                 c + 2 * nn, c + 3 * nn, &n1));
+  const bool multi = origin_index != nullptr && num_origins > 1;
+  if (multi) {  // the same filter once more with the origin index as the passenger: same survivors, same order
+    DLIOM_HIP_TRY(hipMemcpyAsync(oi_in, origin_index, 4 * nn, hipMemcpyHostToDevice, ctx->stream));
+    int64_t n1b = 0;
+    DLIOM_TRY(voxel_filter_arrays(ctx, Soa{b, b + nn, b + 2 * nn, oi_in, n}, 0.5f * voxel_filter_size, d, d + nn,
+                                  d + 2 * nn, oi_f, &n1b));
+    if (n1b != n1) return DLIOM_ERR_INVALID_ARGUMENT;
+  }
   DeskewArgs a;
   // the first range always survives the filter, so hits.front() is ranges.front()
-  DLIOM_TRY(make_deskew_args(prev_pose, predicted_pose, scan_period, origin, min_range, max_range, ranges_xyzt[3], &a));
+  DLIOM_TRY(make_deskew_args(prev_pose, predicted_pose, scan_period, origins, min_range, max_range, ranges_xyzt[3], &a));
+  for (int k = 0; k < std::min(num_origins, 4); ++k)
+    for (int i = 0; i < 3; ++i) a.origins[k][i] = origins[3 * k + i];
   hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n1 + threads - 1) / threads)), dim3(threads), 0,
-                     ctx->stream, a, c, c + nn, c + 2 * nn, c + 3 * nn, 1, static_cast<int>(n1), d, d + nn, d + 2 * nn,
-                     1, kind, d_pose);
+                     ctx->stream, a, c, c + nn, c + 2 * nn, c + 3 * nn, multi ? oi_f : static_cast<const float*>(nullptr),
+                     1, static_cast<int>(n1), d, d + nn, d + 2 * nn, 1, kind, d_pose);
   DLIOM_HIP_TRY(hipGetLastError());
   DLIOM_HIP_TRY(hipMemcpyAsync(current_pose, d_pose, 28, hipMemcpyDeviceToHost, ctx->stream));
-  // returns (kind 1), in hit order; misses (kind 2) are not used by the 3D path
-  int64_t n2 = 0;
-  DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, &n2));
+  // returns (kind 1), in hit order; misses (kind 2) are not used by the 3D path (compaction synchronises)
+  DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, num_returns));
+  *returns = e;
+  *stride = nn;
+  return DLIOM_OK;
+}
+
+// :476-487: VoxelFilter(size) over the accumulated returns (local frame), then into the tracking frame of
+// current_pose (TransformRangeData(., current_pose.inverse())), as a device cloud.
+static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* ry, const float* rz, int64_t n2,
+                                  float voxel_filter_size, const float current_pose[7], dliom_cloud** returns_in_tracking,
+                                  float origin_in_tracking[3]) {
+  const size_t nn = static_cast<size_t>(std::max<int64_t>(n2, 1));
+  auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  DLIOM_TRY(ctx->rescore.reserve(3 * al(4 * nn) + 256));  // filtered returns | max-norm word (misc holds the inputs)
+  float* f = ctx->rescore.as<float>();
+  unsigned* d_max_sq = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->rescore.p) + 3 * al(4 * nn));
+  const size_t fs = al(4 * nn) / 4;
   int64_t n3 = 0;
-  DLIOM_TRY(voxel_filter_arrays(ctx, Soa{e, e + nn, e + 2 * nn, nullptr, n2}, voxel_filter_size, f, f + nn, f + 2 * nn,
-                                nullptr, &n3));
-  // current_pose.inverse() in float (rigid_transform.h:167-171); current_pose arrived with the sync above
+  DLIOM_TRY(voxel_filter_arrays(ctx, Soa{rx, ry, rz, nullptr, n2}, voxel_filter_size, f, f + fs, f + 2 * fs, nullptr, &n3));
+  // current_pose.inverse() in float (rigid_transform.h:167-171)
   const QF qc{current_pose[3], -current_pose[4], -current_pose[5], -current_pose[6]};
   const F3 rt = qrot(qc, F3{current_pose[0], current_pose[1], current_pose[2]});
   const F3 ti{-rt.x, -rt.y, -rt.z};
@@ -272,10 +299,11 @@ extern "C" int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], c
   DLIOM_TRY(alloc_device_cloud(ctx, n3, returns_in_tracking, &ox, &oy, &oz));
   float max_norm = 0.f;
   int st = DLIOM_OK;
+  const int threads = 256;
   if (n3 > 0) {
     if (hipMemsetAsync(d_max_sq, 0, 4, ctx->stream) != hipSuccess) st = DLIOM_ERR_HIP;
     hipLaunchKernelGGL(transform_kernel, dim3(static_cast<unsigned>((n3 + threads - 1) / threads)), dim3(threads), 0,
-                       ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y, ti.z, f, f + nn, f + 2 * nn,
+                       ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y, ti.z, f, f + fs, f + 2 * fs,
                        static_cast<int>(n3), ox, oy, oz, d_max_sq);
     unsigned* host = static_cast<unsigned*>(ctx->pinned);
     if (st == DLIOM_OK && (hipMemcpyAsync(host, d_max_sq, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -290,6 +318,115 @@ extern "C" int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], c
     dliom_cloud_destroy(*returns_in_tracking);
     *returns_in_tracking = nullptr;
   }
+  return st;
+}
+
+}  // namespace dliom
+
+extern "C" int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7],
+                                    double scan_period, const float* ranges_xyzt, int64_t n, const float origin[3],
+                                    float min_range, float max_range, float voxel_filter_size,
+                                    dliom_cloud** returns_in_tracking, float origin_in_tracking[3],
+                                    float current_pose[7]) {
+  if (ctx == nullptr || prev_pose == nullptr || predicted_pose == nullptr || origin == nullptr || n < 0 ||
+      returns_in_tracking == nullptr || origin_in_tracking == nullptr || current_pose == nullptr ||
+      (n > 0 && ranges_xyzt == nullptr) || !(scan_period > 0.) || !(voxel_filter_size > 0.f))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  *returns_in_tracking = nullptr;
+  if (n == 0) return DLIOM_ERR_EMPTY_CLOUD;  // CHECK(!synchronized_data.ranges.empty()) (:383)
+  if (n > (1 << 30)) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const float* e = nullptr;
+  size_t stride = 0;
+  int64_t n2 = 0;
+  DLIOM_TRY(add_range_data_stage_a(ctx, prev_pose, predicted_pose, scan_period, ranges_xyzt, nullptr, n, origin, 1,
+                                   min_range, max_range, voxel_filter_size, current_pose, &e, &stride, &n2));
+  return add_range_data_stage_b(ctx, e, e + stride, e + 2 * stride, n2, voxel_filter_size, current_pose,
+                                returns_in_tracking, origin_in_tracking);
+}
+
+// ---- num_accumulated_range_data > 1 (:449-476): several AddRangeData calls feed one AddAccumulatedRangeData --------
+struct dliom_range_accumulator {
+  dliom_ctx* ctx = nullptr;
+  dliom::DevBuf points;  // x | y | z, capacity `cap` each
+  size_t cap = 0;
+  int64_t count = 0;
+  int num_accumulated = 0;
+  float current_pose[7] = {0, 0, 0, 1, 0, 0, 0};
+};
+
+extern "C" int dliom_range_accumulator_create(dliom_ctx* ctx, dliom_range_accumulator** out) {
+  if (ctx == nullptr || out == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  dliom_range_accumulator* a = new dliom_range_accumulator;
+  a->ctx = ctx;
+  *out = a;
+  return DLIOM_OK;
+}
+
+extern "C" int dliom_range_accumulator_destroy(dliom_range_accumulator* a) {
+  if (a == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  a->points.release();
+  delete a;
+  return DLIOM_OK;
+}
+
+extern "C" int dliom_range_accumulator_add(dliom_range_accumulator* a, const double prev_pose[7],
+                                           const double predicted_pose[7], double scan_period, const float* ranges_xyzt,
+                                           const float* origin_index, int64_t n, const float* origins, int num_origins,
+                                           float min_range, float max_range, float voxel_filter_size,
+                                           float current_pose[7], int* num_accumulated) {
+  if (a == nullptr || prev_pose == nullptr || predicted_pose == nullptr || origins == nullptr || num_origins < 1 ||
+      num_origins > 4 || n < 0 || current_pose == nullptr || (n > 0 && ranges_xyzt == nullptr) || !(scan_period > 0.) ||
+      !(voxel_filter_size > 0.f))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_ERR_EMPTY_CLOUD;
+  if (n > (1 << 30)) return DLIOM_ERR_INVALID_ARGUMENT;
+  dliom_ctx* ctx = a->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const float* e = nullptr;
+  size_t stride = 0;
+  int64_t n2 = 0;
+  DLIOM_TRY(add_range_data_stage_a(ctx, prev_pose, predicted_pose, scan_period, ranges_xyzt, origin_index, n, origins,
+                                   num_origins, min_range, max_range, voxel_filter_size, current_pose, &e, &stride, &n2));
+  const size_t need = static_cast<size_t>(a->count + n2);
+  if (need > a->cap) {  // grow, keeping what is there
+    const size_t new_cap = std::max<size_t>(need * 2, 4096);
+    dliom::DevBuf grown;
+    DLIOM_TRY(grown.reserve(new_cap * 12));
+    float* g = grown.as<float>();
+    const float* old = a->points.as<float>();
+    for (int k = 0; k < 3 && a->count > 0; ++k)
+      DLIOM_HIP_TRY(hipMemcpyAsync(g + k * new_cap, old + k * a->cap, static_cast<size_t>(a->count) * 4,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    a->points.release();
+    a->points = grown;
+    a->cap = new_cap;
+  }
+  float* dst = a->points.as<float>();
+  for (int k = 0; k < 3 && n2 > 0; ++k)
+    DLIOM_HIP_TRY(hipMemcpyAsync(dst + k * a->cap + a->count, e + k * stride, static_cast<size_t>(n2) * 4,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // ctx->misc is reused by the next call
+  a->count += n2;
+  ++a->num_accumulated;
+  std::memcpy(a->current_pose, current_pose, sizeof a->current_pose);
+  if (num_accumulated != nullptr) *num_accumulated = a->num_accumulated;
+  return DLIOM_OK;
+}
+
+extern "C" int dliom_range_accumulator_finish(dliom_range_accumulator* a, float voxel_filter_size,
+                                              dliom_cloud** returns_in_tracking, float origin_in_tracking[3]) {
+  if (a == nullptr || returns_in_tracking == nullptr || origin_in_tracking == nullptr || !(voxel_filter_size > 0.f) ||
+      a->num_accumulated == 0)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  *returns_in_tracking = nullptr;
+  DLIOM_HIP_TRY(hipSetDevice(a->ctx->device));
+  const float* p = a->points.as<float>();
+  const int st = add_range_data_stage_b(a->ctx, p, p + a->cap, p + 2 * a->cap, a->count, voxel_filter_size, a->current_pose,
+                                        returns_in_tracking, origin_in_tracking);
+  a->count = 0;  // num_accumulated_ = 0; accumulated_range_data_ reset at the next first call (:449-452)
+  a->num_accumulated = 0;
   return st;
 }
 
@@ -314,8 +451,8 @@ extern "C" int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const dou
   DLIOM_HIP_TRY(hipMemcpyAsync(base, hits_xyzt, in_bytes, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, a,
                      reinterpret_cast<const float*>(base), reinterpret_cast<const float*>(base) + 1,
-                     reinterpret_cast<const float*>(base) + 2, reinterpret_cast<const float*>(base) + 3, 4,
-                     static_cast<int>(n), reinterpret_cast<float*>(base + xyz_off),
+                     reinterpret_cast<const float*>(base) + 2, reinterpret_cast<const float*>(base) + 3,
+                     static_cast<const float*>(nullptr), 4, static_cast<int>(n), reinterpret_cast<float*>(base + xyz_off),
                      reinterpret_cast<float*>(base + xyz_off) + 1, reinterpret_cast<float*>(base + xyz_off) + 2, 3,
                      reinterpret_cast<unsigned char*>(base + kind_off), reinterpret_cast<float*>(base + pose_off));
   DLIOM_HIP_TRY(hipGetLastError());

@@ -239,6 +239,11 @@ SYMBOLS = [
     ("dliom_fast_csm_match_with_3dof_initial", C.c_int, [_vp, _vp, _f64p, C.POINTER(FastCsmNodeData), C.c_float,
                                                          C.POINTER(FastCsmResult)]),
     ("dliom_fast_csm_level", C.c_int, [_vp, C.c_int, _i32p, _i32p, C.POINTER(C.c_uint8), C.c_int64]),
+    ("dliom_range_accumulator_create", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("dliom_range_accumulator_destroy", C.c_int, [_vp]),
+    ("dliom_range_accumulator_add", C.c_int, [_vp, _f64p, _f64p, C.c_double, _f32p, _f32p, C.c_int64, _f32p, C.c_int,
+                                              C.c_float, C.c_float, C.c_float, _f32p, C.POINTER(C.c_int)]),
+    ("dliom_range_accumulator_finish", C.c_int, [_vp, C.c_float, C.POINTER(_vp), _f32p]),
     ("dliom_imu_window_default_options", C.c_int, [C.POINTER(ImuWindowOptions)]),
     ("dliom_imu_window_create", C.c_int, [C.POINTER(ImuWindowOptions), C.POINTER(_vp)]),
     ("dliom_imu_window_destroy", C.c_int, [_vp]),
@@ -1130,6 +1135,45 @@ def rotational_histogram(points, histogram_size):
 
 
 ERR_DIVERGED = -11
+
+
+class RangeDataAccumulator:
+    """dliom_range_accumulator_*: AddRangeData calls feeding one AddAccumulatedRangeData
+    (num_accumulated_range_data > 1), with the RangeDataSynchronizer's origin table."""
+
+    def __init__(self, ctx):
+        self.ctx, self._L = ctx, ctx._L
+        h = _vp()
+        _check(self._L.dliom_range_accumulator_create(ctx.h, C.byref(h)), "dliom_range_accumulator_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.dliom_range_accumulator_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def add(self, prev_pose, predicted_pose, scan_period, ranges_xyzt, min_range, max_range, voxel_filter_size,
+            origins=((0.0, 0.0, 0.0),), origin_index=None):
+        r = _f32(ranges_xyzt).reshape(-1, 4)
+        og = _f32(origins).reshape(-1, 3)
+        oi = None if origin_index is None else _f32(origin_index)
+        cur = np.zeros(7, dtype=np.float32)
+        k = C.c_int()
+        _check(self._L.dliom_range_accumulator_add(self.h, _p(_f64(prev_pose), _f64p), _p(_f64(predicted_pose), _f64p),
+                                                   float(scan_period), _p(r, _f32p), None if oi is None else _p(oi, _f32p),
+                                                   len(r), _p(og, _f32p), len(og), C.c_float(min_range), C.c_float(max_range),
+                                                   C.c_float(voxel_filter_size), _p(cur, _f32p), C.byref(k)),
+               "dliom_range_accumulator_add")
+        return cur, k.value
+
+    def finish(self, voxel_filter_size):
+        h = _vp()
+        org = np.zeros(3, dtype=np.float32)
+        _check(self._L.dliom_range_accumulator_finish(self.h, C.c_float(voxel_filter_size), C.byref(h), _p(org, _f32p)),
+               "dliom_range_accumulator_finish")
+        return PointCloud(self.ctx, _handle=h), org
 
 
 class ImuWindow:

@@ -391,6 +391,21 @@ int dliom_add_range_data(dliom_ctx* ctx, const double prev_pose[7], const double
                          double scan_period, const float* ranges_xyzt, int64_t n, const float origin[3],
                          float min_range, float max_range, float voxel_filter_size,
                          dliom_cloud** returns_in_tracking, float origin_in_tracking[3], float current_pose[7]);
+/* num_accumulated_range_data > 1 (local_trajectory_builder_3d.cc:449-476) and the RangeDataSynchronizer's two-lidar
+ * output (internal/3d/range_data_synchronizer.cc:29-130): _add is one AddRangeData call up to the accumulation -- the
+ * returns are de-skewed into the local frame and appended; origin_index (one float per range, NULL = all 0) selects
+ * the sensor origin of `origins` (num_origins x 3, <= 4) a hit is gated against.  _finish is the tail
+ * (VoxelFilter(size) over everything accumulated, TransformRangeData by the LAST current_pose^-1) and resets. */
+typedef struct dliom_range_accumulator dliom_range_accumulator;
+int dliom_range_accumulator_create(dliom_ctx* ctx, dliom_range_accumulator** out);
+int dliom_range_accumulator_destroy(dliom_range_accumulator* accumulator);
+int dliom_range_accumulator_add(dliom_range_accumulator* accumulator, const double prev_pose[7],
+                                const double predicted_pose[7], double scan_period, const float* ranges_xyzt,
+                                const float* origin_index, int64_t n, const float* origins, int num_origins,
+                                float min_range, float max_range, float voxel_filter_size, float current_pose[7],
+                                int* num_accumulated);
+int dliom_range_accumulator_finish(dliom_range_accumulator* accumulator, float voxel_filter_size,
+                                   dliom_cloud** returns_in_tracking, float origin_in_tracking[3]);
 
 /* ---- FastCorrelativeScanMatcher3D (loop closure) --------------------------------
  * mapping/internal/3d/scan_matching/fast_correlative_scan_matcher_3d.h:100-132.  The constructor's

@@ -131,6 +131,10 @@ def _declare(L):
     sig("orc_fast_csm_match_3dof", None, vp, _f64p, _f64p, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_float,
         _f64p, _f64p)
     sig("orc_compute_histogram", None, _f32p, C.c_int, C.c_int, _f32p)
+    sig("orc_accumulator_new", C.c_void_p)
+    sig("orc_accumulator_free", None, C.c_void_p)
+    sig("orc_accumulator_add", None, C.c_void_p, _f64p, _f64p, _f64p, _f32p, C.c_int, _i32p, _f32p, C.c_int, _f32p)
+    sig("orc_accumulator_finish", C.c_int, C.c_void_p, _f64p, _f32p, C.c_int, _f32p)
     sig("orc_motion_filter_create", C.c_void_p, C.c_double, C.c_double, C.c_double)
     sig("orc_motion_filter_destroy", None, C.c_void_p)
     sig("orc_motion_filter_is_similar", C.c_int, C.c_void_p, C.c_int64, _f64p)
@@ -663,6 +667,39 @@ def deskew_and_filter(scan_period, min_range, max_range, voxel_filter_size, prev
     return dict(hits_in_local=hits[:counts[0]].copy(), kind=kind[:counts[0]].copy(),
                 returns_in_tracking=ret[:counts[1]].copy(), misses_in_tracking=mis[:counts[2]].copy(),
                 current_pose=cur, origin_in_tracking=org)
+
+
+class RangeDataAccumulator:
+    """AddRangeData with the synchronizer's origin table and num_accumulated_range_data > 1
+    (local_trajectory_builder_3d.cc:393-487)."""
+
+    def __init__(self, scan_period, min_range, max_range, voxel_filter_size):
+        self.opts = _f64([scan_period, min_range, max_range, voxel_filter_size])
+        self.h = lib().orc_accumulator_new()
+        self.capacity = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_accumulator_free(self.h)
+            self.h = None
+
+    def add(self, prev_pose, cur_pose, ranges_xyzt, origins=((0.0, 0.0, 0.0),), origin_index=None):
+        r = _f32(ranges_xyzt).reshape(-1, 4)
+        og = _f32(origins).reshape(-1, 3)
+        oi = None if origin_index is None else np.ascontiguousarray(origin_index, dtype=np.int32)
+        cur = np.zeros(7, dtype=np.float32)
+        lib().orc_accumulator_add(self.h, _p(self.opts, _f64p), _p(_f64(prev_pose), _f64p), _p(_f64(cur_pose), _f64p),
+                                  _p(r, _f32p), len(r), None if oi is None else _p(oi, _i32p), _p(og, _f32p), len(og),
+                                  _p(cur, _f32p))
+        self.capacity += len(r)
+        return cur
+
+    def finish(self):
+        out = np.zeros((max(self.capacity, 1), 3), dtype=np.float32)
+        org = np.zeros(3, dtype=np.float32)
+        n = lib().orc_accumulator_finish(self.h, _p(self.opts, _f64p), _p(out, _f32p), len(out), _p(org, _f32p))
+        self.capacity = 0
+        return out[:n].copy(), org
 
 
 # ------------------------------------------------------------------ fast correlative scan matcher 3D

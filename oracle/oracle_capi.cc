@@ -488,6 +488,31 @@ void orc_deskew_and_filter(const double* opts, const double* prev7, const double
   origin_tracking3[2] = d.filtered_in_tracking.origin.z;
 }
 
+// RangeDataAccumulator: AddRangeData with an origin table and num_accumulated_range_data > 1.
+void* orc_accumulator_new() { return new RangeDataAccumulator; }
+void orc_accumulator_free(void* a) { delete static_cast<RangeDataAccumulator*>(a); }
+void orc_accumulator_add(void* a, const double* opts, const double* prev7, const double* cur7, const float* ranges, int n,
+                         const int* origin_index, const float* origins, int num_origins, float* current_pose7) {
+  std::vector<TimedPoint> r(n);
+  for (int i = 0; i < n; ++i) r[i] = TimedPoint{ranges[4 * i], ranges[4 * i + 1], ranges[4 * i + 2], ranges[4 * i + 3]};
+  std::vector<int> oi;
+  if (origin_index != nullptr) oi.assign(origin_index, origin_index + n);
+  std::vector<Vec3f> og;
+  for (int k = 0; k < num_origins; ++k) og.emplace_back(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
+  const DeskewOptions o{opts[0], static_cast<float>(opts[1]), static_cast<float>(opts[2]), static_cast<float>(opts[3])};
+  FromRigidF(static_cast<RangeDataAccumulator*>(a)->Add(o, ToRigid(prev7), ToRigid(cur7), r, oi, og), current_pose7);
+}
+int orc_accumulator_finish(void* a, const double* opts, float* returns_tracking, int capacity, float* origin_tracking3) {
+  const DeskewOptions o{opts[0], static_cast<float>(opts[1]), static_cast<float>(opts[2]), static_cast<float>(opts[3])};
+  const RangeData d = static_cast<RangeDataAccumulator*>(a)->Finish(o);
+  const int n = static_cast<int>(d.returns.size());
+  for (int i = 0; i < n && i < capacity; ++i) {
+    returns_tracking[3 * i] = d.returns[i].x; returns_tracking[3 * i + 1] = d.returns[i].y; returns_tracking[3 * i + 2] = d.returns[i].z;
+  }
+  origin_tracking3[0] = d.origin.x; origin_tracking3[1] = d.origin.y; origin_tracking3[2] = d.origin.z;
+  return n;
+}
+
 // ---------------------------------------------------------------- 2D (config 1, CPU only)
 void* orc_pg_new(double resolution, double max_x, double max_y, int num_x_cells, int num_y_cells) {
   return new ProbabilityGrid(MapLimits{resolution, max_x, max_y, num_x_cells, num_y_cells});

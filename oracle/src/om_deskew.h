@@ -106,6 +106,64 @@ inline DeskewResult DeskewAndFilter(const DeskewOptions& o, const Rigid3d& prev_
   return r;
 }
 
+// The same per-scan steps with the synchronizer's origin table (every range carries an origin index,
+// internal/3d/range_data_synchronizer.cc:92-113) and num_accumulated_range_data > 1 (:449-476): Add() is one
+// AddRangeData call up to `++num_accumulated_`, Finish() the block guarded by
+// `num_accumulated_ >= options_.num_accumulated_range_data()`.
+class RangeDataAccumulator {
+ public:
+  Rigid3f Add(const DeskewOptions& o, const Rigid3d& prev_pose, const Rigid3d& cur_pose,
+              const std::vector<TimedPoint>& ranges, const std::vector<int>& origin_index,
+              const std::vector<Vec3f>& origins) {
+    std::vector<int> keep;
+    {
+      VoxelFilter f(0.5f * o.voxel_filter_size);
+      PointCloud xyz;
+      xyz.reserve(ranges.size());
+      for (const TimedPoint& p : ranges) xyz.emplace_back(p.x, p.y, p.z);
+      keep = f.FilterIndices(xyz);
+    }
+    const Rigid3d rel_trans = prev_pose.inverse() * cur_pose;
+    const bool stamps = !(std::abs(ranges[keep.front()].t) < 1e-3);
+    if (num_ == 0) accumulated_ = RangeData{Vec3f(), {}, {}};
+    Rigid3f pose = cur_pose.cast<float>();
+    for (int i : keep) {
+      const TimedPoint& h = ranges[i];
+      if (stamps) {
+        const double s = (o.scan_period + h.t) / o.scan_period;
+        const Rigid3d tmp(s * rel_trans.translation, SlerpFromIdentity(s, rel_trans.rotation));
+        pose = (prev_pose * tmp).cast<float>();
+      }
+      const Vec3f hit_in_local = pose * Vec3f(h.x, h.y, h.z);
+      const Vec3f origin_in_local = pose * origins.at(origin_index.empty() ? 0 : origin_index[i]);
+      const Vec3f delta = hit_in_local - origin_in_local;
+      const float range = delta.norm();
+      if (range >= o.min_range) {
+        if (range <= o.max_range) {
+          accumulated_.returns.push_back(hit_in_local);
+        } else {
+          accumulated_.misses.push_back(origin_in_local + (o.max_range / range) * delta);
+        }
+      }
+    }
+    current_pose_ = pose;  // hits_poses.back()
+    ++num_;
+    return current_pose_;
+  }
+  RangeData Finish(const DeskewOptions& o) {
+    num_ = 0;
+    const RangeData filtered{current_pose_.translation, VoxelFilter(o.voxel_filter_size).Filter(accumulated_.returns),
+                             VoxelFilter(o.voxel_filter_size).Filter(accumulated_.misses)};
+    return TransformRangeData(filtered, current_pose_.inverse());
+  }
+  int num_accumulated() const { return num_; }
+
+ private:
+  RangeData accumulated_{Vec3f(), {}, {}};
+  Rigid3f current_pose_;
+  int num_ = 0;
+};
+
 }  // namespace oracle
 
 #endif  // ORACLE_OM_DESKEW_H_

@@ -930,3 +930,79 @@ def test_finished_submaps_are_handed_over_and_shrunk(dl, ctx, orc):
     with pytest.raises(Exception):
         dfe.take_finished_submap()  # nothing left
     dfe.close()
+
+
+def _plane_and_corridor(orc, kind):
+    """Degenerate geometry for CeresScanMatcher3D: `plane` = one floor plane (x, y, yaw unobservable from the
+    occupied-space cost), `corridor` = floor + two parallel walls (x unobservable).  Grids are built by inserting
+    the points of the surfaces themselves from an origin above the floor."""
+    rng = np.random.RandomState(8)
+    n = 6000
+    floor = np.stack([rng.uniform(-8, 8, n), rng.uniform(-8, 8, n), np.full(n, -1.5)], axis=1)
+    surf = [floor]
+    if kind == "corridor":
+        for y in (-2.0, 2.0):
+            surf.append(np.stack([rng.uniform(-8, 8, n // 2), np.full(n // 2, y), rng.uniform(-1.5, 1.5, n // 2)], axis=1))
+    world = np.concatenate(surf).astype(np.float32)
+    hit = orc.lookup_table_to_apply_odds(orc.odds(HIT_P))
+    miss = orc.lookup_table_to_apply_odds(orc.odds(MISS_P))
+    grids = []
+    for res in (0.1, 0.45):
+        g = orc.HybridGrid(res)
+        for _ in range(3):
+            g.insert_tables(np.zeros(3, np.float32), world, hit, miss, FREE)
+        grids.append(g)
+    cloud = world[rng.choice(len(world), 3000, replace=False)]
+    return grids[0], grids[1], cloud
+
+
+@pytest.mark.parametrize("kind", ["plane", "corridor"])
+@pytest.mark.parametrize("weights", [(5.0, 4e2), (1e-3, 1e-3)])
+def test_csm3d_degenerate_geometry(dl, ctx, orc, kind, weights):
+    """The LM restatement solves the scaled NORMAL equations (Cholesky) where Ceres uses Householder QR of [J; D]:
+    squared condition number.  On geometry that leaves directions unconstrained -- with the reference's prior
+    weights and with priors a million times weaker -- the pose still agrees with the oracle's QR path to 1e-6."""
+    og_hi, og_lo, cloud = _plane_and_corridor(orc, kind)
+    dg_hi, dg_lo = to_device_grid(dl, ctx, og_hi), to_device_grid(dl, ctx, og_lo)
+    init = np.array([0.07, -0.05, 0.06, np.cos(0.01), 0.0, np.sin(0.01) * 0.6, np.sin(0.01) * 0.8])
+    opts = dict(DEFAULT_CSM, translation_weight=weights[0], rotation_weight=weights[1])
+    pose, summary = dl.CeresScanMatcher3D(ctx, opts).Match(init[:3], init, [(cloud, dg_hi), (cloud, dg_lo)])
+    ref = orc.csm3d_match(opts, init[:3], init, [(cloud, og_hi), (cloud, og_lo)])
+    dt, da = pose_distance(pose, ref["pose"])
+    assert dt <= 1e-6 and da <= 1e-6, (kind, weights, dt, da, summary, ref)
+    assert summary["num_iterations"] == ref["num_iterations"]
+    dg_hi.close()
+    dg_lo.close()
+
+
+def test_range_accumulator_two_scans_two_origins(dl, ctx, orc):
+    """num_accumulated_range_data = 2 with the synchronizer's two-lidar origin table: two AddRangeData calls feed one
+    AddAccumulatedRangeData (local_trajectory_builder_3d.cc:449-487).  Device accumulator vs the oracle's: identical
+    survivors, identical coordinates, identical current pose after every call."""
+    vfs, min_r, max_r, T = 0.15, 1.0, 30.0, 0.1
+    origins = np.array([[0, 0, 0], [0.4, -0.2, 0.3]], dtype=np.float32)
+    dacc = dl.RangeDataAccumulator(ctx)
+    oacc = orc.RangeDataAccumulator(T, min_r, max_r, vfs)
+    rng = np.random.RandomState(12)
+    for k in (5, 6):
+        prev, cur, ranges = _timed_scan(32, 256, k=k)
+        oi = (rng.uniform(size=len(ranges)) < 0.3).astype(np.int32)  # 30 % of the ranges come from the second lidar
+        cur_d, n_acc = dacc.add(prev, cur, T, ranges, min_r, max_r, vfs, origins=origins, origin_index=oi)
+        cur_o = oacc.add(prev, cur, ranges, origins=origins, origin_index=oi)
+        assert np.array_equal(cur_d, cur_o)
+    assert n_acc == 2
+    cloud, origin_d = dacc.finish(vfs)
+    want, origin_o = oacc.finish()
+    got = cloud.download()
+    assert got.shape == want.shape and len(got) > 5000
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(origin_d, origin_o)
+    # a single accumulated scan with one origin is dliom_add_range_data
+    prev, cur, ranges = _timed_scan(16, 256, k=7)
+    dacc.add(prev, cur, T, ranges, min_r, max_r, vfs)
+    c1, o1 = dacc.finish(vfs)
+    c2, o2, _ = dl.add_range_data(ctx, prev, cur, T, ranges, (0, 0, 0), min_r, max_r, vfs)
+    assert np.array_equal(c1.download().view(np.uint32), c2.download().view(np.uint32)) and np.array_equal(o1, o2)
+    for c in (cloud, c1, c2):
+        c.close()
+    dacc.close()
