@@ -9,6 +9,9 @@
 //   dliom::mapping::scan_matching::CeresScanMatcher3D         .../scan_matching/ceres_scan_matcher_3d.h:37-63
 //   dliom::mapping::scan_matching::FastCorrelativeScanMatcher3D
 //                                  .../scan_matching/fast_correlative_scan_matcher_3d.h:100-132
+//   dliom::mapping::ActiveSubmaps3D / Submap3D                mapping/3d/submap_3d.h:43-130
+//   dliom::mapping::RangeDataSynchronizer                     mapping/internal/3d/range_data_synchronizer.h
+//   dliom::mapping::LocalTrajectoryBuilder3D                  mapping/internal/3d/local_trajectory_builder_3d.h:83-111
 //
 // The value types below are layout-compatible stand-ins for Eigen::Vector3f / transform::Rigid3d
 // so that this header builds without Eigen; inside cartographer the same adapters are
@@ -17,10 +20,16 @@
 #ifndef DLIOM_CPP_DLIOM_CARTOGRAPHER_H_
 #define DLIOM_CPP_DLIOM_CARTOGRAPHER_H_
 
+#include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
+#include <memory>
+#include <set>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -370,6 +379,357 @@ class FastCorrelativeScanMatcher3D {
 };
 
 }  // namespace scan_matching
+
+// ---- sensor data of the LocalTrajectoryBuilder3D surface (sensor/timed_point_cloud_data.h, sensor/imu_data.h) ----
+}  // namespace mapping
+namespace sensor {
+struct TimedPoint {
+  float x, y, z, t;  // Eigen::Vector4f: position and time relative to TimedPointCloudData::time (<= 0)
+};
+using TimedPointCloud = std::vector<TimedPoint>;
+struct TimedPointCloudData {
+  int64_t time;  // common::Time ticks (100 ns): when the last point was acquired
+  Vector3f origin;
+  TimedPointCloud ranges;
+};
+struct ImuData {
+  int64_t time;
+  double linear_acceleration[3];
+  double angular_velocity[3];
+};
+struct OdometryData {
+  int64_t time;
+  transform::Rigid3d pose;
+};
+// TimedPointCloudOriginData (sensor/timed_point_cloud_data.h:37-46)
+struct TimedPointCloudOriginData {
+  struct RangeMeasurement {
+    TimedPoint point_time;
+    size_t origin_index;
+  };
+  int64_t time = 0;
+  std::vector<Vector3f> origins;
+  std::vector<RangeMeasurement> ranges;
+};
+}  // namespace sensor
+namespace mapping {
+
+// Host logic restated from mapping/internal/3d/range_data_synchronizer.cc:29-130: the prior lidar's cloud is passed
+// on, with the part of a secondary lidar's cloud that overlaps it in time merged in (second origin, times re-based,
+// ranges sorted by time).  `descrew` stamps the ranges linearly over the scan period (StampRangeData, :115-130).
+class RangeDataSynchronizer {
+ public:
+  explicit RangeDataSynchronizer(const std::vector<std::string>& expected_range_sensor_ids)
+      : expected_sensor_ids_(expected_range_sensor_ids.begin(), expected_range_sensor_ids.end()),
+        prior_sensor_id_(expected_range_sensor_ids.empty() ? std::string() : expected_range_sensor_ids.front()) {}
+
+  sensor::TimedPointCloudOriginData AddRangeData(const std::string& sensor_id, const sensor::TimedPointCloudData& data,
+                                                 bool descrew) {
+    if (expected_sensor_ids_.count(sensor_id) == 0)
+      Check(DLIOM_ERR_INVALID_ARGUMENT, "CHECK_NE(expected_sensor_ids_.count(sensor_id), 0)");
+    sensor::TimedPointCloudOriginData result;
+    sensor::TimedPointCloudData cloud = data;
+    if (descrew) StampRangeData(&cloud, 0.1);
+    if (sensor_id != prior_sensor_id_) {
+      secondary_cloud_.push_back(cloud);
+      return result;
+    }
+    const double current_end = Seconds(cloud.time);
+    const double current_start = cloud.ranges.empty() ? current_end : current_end + cloud.ranges.front().t;
+    while (!secondary_cloud_.empty() && Seconds(secondary_cloud_.front().time) < current_start) secondary_cloud_.pop_front();
+    if (secondary_cloud_.empty() || secondary_cloud_.front().ranges.empty() ||
+        Seconds(secondary_cloud_.front().time) + secondary_cloud_.front().ranges.front().t > current_end) {
+      ToOriginData(cloud, &result);  // no secondary cloud, or "the secondary lidar may be too fast"
+      return result;
+    }
+    const sensor::TimedPointCloudData& sec = secondary_cloud_.front();
+    const double sec_time = Seconds(sec.time);
+    int i_start = -1, i_end = -1;
+    for (int i = 0; i < static_cast<int>(sec.ranges.size()); ++i) {
+      const double t = sec_time + sec.ranges[i].t;
+      if (t >= current_start && t <= current_end && i_start == -1) i_start = i;
+      if (i_start != -1 && t > current_end) {
+        i_end = i - 1;
+        break;
+      }
+    }
+    if (i_start == -1) Check(DLIOM_ERR_INVALID_ARGUMENT, "CHECK(i_start != -1) range_data_synchronizer.cc:84");
+    if (i_end == -1) i_end = static_cast<int>(sec.ranges.size()) - 1;
+    result.time = cloud.time;
+    result.origins.push_back(cloud.origin);
+    for (const sensor::TimedPoint& p : data.ranges) result.ranges.push_back({p, 0});  // the UNSTAMPED input, as :97
+    result.origins.push_back(sec.origin);
+    for (int i = i_start; i <= i_end; ++i) {
+      sensor::TimedPoint p = sec.ranges[i];
+      p.t = static_cast<float>(static_cast<double>(sec.ranges[i].t) + sec_time - current_end);
+      result.ranges.push_back({p, 1});
+    }
+    std::sort(result.ranges.begin(), result.ranges.end(),
+              [](const sensor::TimedPointCloudOriginData::RangeMeasurement& a,
+                 const sensor::TimedPointCloudOriginData::RangeMeasurement& b) { return a.point_time.t < b.point_time.t; });
+    return result;
+  }
+
+ private:
+  static double Seconds(int64_t ticks) { return static_cast<double>(ticks) * 1e-7; }
+  static void ToOriginData(const sensor::TimedPointCloudData& c, sensor::TimedPointCloudOriginData* out) {
+    out->time = c.time;
+    out->origins.assign(1, c.origin);
+    out->ranges.clear();
+    for (const sensor::TimedPoint& p : c.ranges) out->ranges.push_back({p, 0});
+  }
+  static void StampRangeData(sensor::TimedPointCloudData* cloud, double scan_period) {
+    const int n = static_cast<int>(cloud->ranges.size());
+    if (n < 2) return;
+    const double duration = scan_period / (n - 1);
+    for (int i = 0; i < n; ++i) cloud->ranges[i].t = static_cast<float>(-scan_period + i * duration);
+    cloud->ranges.back().t = 0.f;
+  }
+  std::set<std::string> expected_sensor_ids_;
+  std::string prior_sensor_id_;
+  std::deque<sensor::TimedPointCloudData> secondary_cloud_;
+};
+
+// proto::LocalTrajectoryBuilderOptions3D: the front end's options plus the AddRangeData / IMU fields
+struct LocalTrajectoryBuilderOptions3D {
+  dliom_front_end_options front_end;     // adaptive filters, matchers, motion filter, submaps
+  dliom_imu_window_options imu;          // imu block + WindowOptimize
+  float min_range = 1.f, max_range = 100.f;
+  int num_accumulated_range_data = 1;
+  float voxel_filter_size = 0.15f;
+  double scan_period = 0.1;
+  bool enable_manual_descrew = false;    // eable_mannually_discrew_
+};
+
+// A submap of the active pair; the grids stay owned by the front end (borrowed handles).
+class Submap3D {
+ public:
+  Submap3D(const transform::Rigid3d& local_pose, int num_range_data, bool finished, dliom_grid* hi, dliom_grid* lo)
+      : local_pose_(local_pose), num_range_data_(num_range_data), finished_(finished), hi_(hi), lo_(lo) {}
+  const transform::Rigid3d& local_pose() const { return local_pose_; }
+  int num_range_data() const { return num_range_data_; }
+  bool finished() const { return finished_; }
+  dliom_grid* high_resolution_hybrid_grid() const { return hi_; }
+  dliom_grid* low_resolution_hybrid_grid() const { return lo_; }
+
+ private:
+  transform::Rigid3d local_pose_;
+  int num_range_data_;
+  bool finished_;
+  dliom_grid* hi_;
+  dliom_grid* lo_;
+};
+
+// ActiveSubmaps3D (mapping/3d/submap_3d.h:95-122) over the front end's submap pair.
+class ActiveSubmaps3D {
+ public:
+  ActiveSubmaps3D(Context* context, const dliom_front_end_options& options) : context_(context) {
+    Check(dliom_front_end_create(context->get(), &options, &fe_), "dliom_front_end_create");
+  }
+  ~ActiveSubmaps3D() { dliom_front_end_destroy(fe_); }
+  ActiveSubmaps3D(const ActiveSubmaps3D&) = delete;
+  ActiveSubmaps3D& operator=(const ActiveSubmaps3D&) = delete;
+
+  int matching_index() const {
+    int i = 0;
+    Check(dliom_front_end_matching_index(fe_, &i), "ActiveSubmaps3D::matching_index");
+    return i;
+  }
+  void InsertRangeData(const sensor::RangeData& range_data, const transform::Quaterniond& gravity_alignment) {
+    dliom_cloud* cloud = nullptr;
+    Check(dliom_cloud_create(context_->get(), range_data.returns.empty() ? nullptr : &range_data.returns[0].x,
+                             static_cast<int64_t>(range_data.returns.size()), &cloud),
+          "ActiveSubmaps3D::InsertRangeData (upload)");
+    dliom_insertion_result r;
+    Check(dliom_front_end_insert_range_data(fe_, &range_data.origin.x, cloud, gravity_alignment.wxyz, &r),
+          "ActiveSubmaps3D::InsertRangeData");
+    dliom_cloud_destroy(cloud);
+  }
+  std::vector<std::shared_ptr<Submap3D>> submaps() const {
+    int n = 0;
+    Check(dliom_front_end_num_active_submaps(fe_, &n), "ActiveSubmaps3D::submaps");
+    std::vector<std::shared_ptr<Submap3D>> out;
+    for (int i = 0; i < n; ++i) {
+      double pose[7];
+      int num = 0, fin = 0;
+      dliom_grid *hi = nullptr, *lo = nullptr;
+      Check(dliom_front_end_active_submap(fe_, i, pose, &num, &fin, &hi, &lo), "ActiveSubmaps3D::submaps");
+      out.push_back(std::make_shared<Submap3D>(transform::Rigid3d::FromArray(pose), num, fin != 0, hi, lo));
+    }
+    return out;
+  }
+  dliom_front_end* get() const { return fe_; }
+
+ private:
+  Context* context_;
+  dliom_front_end* fe_ = nullptr;
+};
+
+// LocalTrajectoryBuilder3D (mapping/internal/3d/local_trajectory_builder_3d.h:83-111), steady state: the state after
+// the reference's IMU-lidar initialisation (InitializeStatic / InitilizeByNDT: PCL + VINS alignment, start-up only,
+// out of scope -- SURVEY 8c) is supplied through SetInitialState().  AddOdometryData is accepted and ignored like in
+// the reference's D-LIOM path, whose extrapolator is never created (.cc:324-333).
+class LocalTrajectoryBuilder3D {
+ public:
+  struct InsertionResult {
+    int64_t time;
+    transform::Quaterniond gravity_alignment;
+    transform::Rigid3d local_pose;
+    std::vector<int> insertion_submap_indices;  // trajectory-wide indices of the submaps inserted into
+    bool submap_finished;                        // take it with dliom_front_end_take_finished_submap
+  };
+  struct MatchingResult {
+    int64_t time;
+    transform::Rigid3d local_pose;
+    sensor::RangeData range_data_in_local;
+    std::unique_ptr<const InsertionResult> insertion_result;  // nullptr if dropped by the motion filter
+  };
+
+  LocalTrajectoryBuilder3D(Context* context, const LocalTrajectoryBuilderOptions3D& options,
+                           const std::vector<std::string>& expected_range_sensor_ids)
+      : context_(context), options_(options), active_submaps_(context, options.front_end),
+        synchronizer_(expected_range_sensor_ids) {
+    Check(dliom_imu_window_create(&options.imu, &window_), "dliom_imu_window_create");
+    Check(dliom_range_accumulator_create(context->get(), &accumulator_), "dliom_range_accumulator_create");
+  }
+  ~LocalTrajectoryBuilder3D() {
+    dliom_range_accumulator_destroy(accumulator_);
+    dliom_imu_window_destroy(window_);
+  }
+  LocalTrajectoryBuilder3D(const LocalTrajectoryBuilder3D&) = delete;
+  LocalTrajectoryBuilder3D& operator=(const LocalTrajectoryBuilder3D&) = delete;
+
+  // prev_state_ / prev_bias_ as InitializeIMU() leaves them (.cc:322-345)
+  void SetInitialState(const transform::Rigid3d& pose, const transform::Vector3d& velocity, const double bias6[6]) {
+    Check(dliom_imu_window_initialize(window_, pose.ToArray().data(), velocity.v, bias6), "dliom_imu_window_initialize");
+    last_imu_time_ = -1;
+    imu_initialized_ = true;
+    have_prediction_ = false;
+  }
+  void AddImuData(const sensor::ImuData& imu) {
+    if (!imu_initialized_) return;  // the reference buffers it for its initialisation
+    const double dt = last_imu_time_ < 0 ? 1.0 / 500.0 : static_cast<double>(imu.time - last_imu_time_) * 1e-7;  // .cc:183-185
+    last_imu_time_ = imu.time;
+    if (!(dt > 0)) return;
+    Check(dliom_imu_window_add_imu(window_, imu.linear_acceleration, imu.angular_velocity, dt), "AddImuData");
+    have_prediction_ = true;
+  }
+  void AddOdometryData(const sensor::OdometryData&) {}
+
+  std::unique_ptr<MatchingResult> AddRangeData(const std::string& sensor_id, const sensor::TimedPointCloudData& unsynchronized) {
+    const sensor::TimedPointCloudOriginData sync =
+        synchronizer_.AddRangeData(sensor_id, unsynchronized, options_.enable_manual_descrew);
+    if (sync.ranges.empty() || !imu_initialized_ || !have_prediction_) return nullptr;
+    if (sync.ranges.back().point_time.t > 0.1f) Check(DLIOM_ERR_INVALID_ARGUMENT, "CHECK_LE(ranges.back().point_time[3], 0.1f)");
+    // prev_state_ and predicted_states_.back() (.cc:424-427)
+    double prev[7], vel[3], bias[6], predicted[7], pvel[3];
+    Check(dliom_imu_window_state(window_, 0, prev, vel, bias), "dliom_imu_window_state");
+    Check(dliom_imu_window_predict(window_, predicted, pvel), "dliom_imu_window_predict");
+    std::vector<float> xyzt(4 * sync.ranges.size()), index(sync.ranges.size()), origins(3 * sync.origins.size());
+    for (size_t i = 0; i < sync.ranges.size(); ++i) {
+      xyzt[4 * i] = sync.ranges[i].point_time.x;
+      xyzt[4 * i + 1] = sync.ranges[i].point_time.y;
+      xyzt[4 * i + 2] = sync.ranges[i].point_time.z;
+      xyzt[4 * i + 3] = sync.ranges[i].point_time.t;
+      index[i] = static_cast<float>(sync.ranges[i].origin_index);
+    }
+    for (size_t k = 0; k < sync.origins.size(); ++k) {
+      origins[3 * k] = sync.origins[k].x;
+      origins[3 * k + 1] = sync.origins[k].y;
+      origins[3 * k + 2] = sync.origins[k].z;
+    }
+    float current_pose[7];
+    int accumulated = 0;
+    Check(dliom_range_accumulator_add(accumulator_, prev, predicted, options_.scan_period, xyzt.data(),
+                                      sync.origins.size() > 1 ? index.data() : nullptr,
+                                      static_cast<int64_t>(sync.ranges.size()), origins.data(),
+                                      static_cast<int>(sync.origins.size()), options_.min_range, options_.max_range,
+                                      options_.voxel_filter_size, current_pose, &accumulated),
+          "AddRangeData (de-skew + accumulate)");
+    if (accumulated < options_.num_accumulated_range_data) return nullptr;
+    dliom_cloud* cloud = nullptr;
+    float origin_in_tracking[3];
+    Check(dliom_range_accumulator_finish(accumulator_, options_.voxel_filter_size, &cloud, origin_in_tracking),
+          "AddRangeData (voxel filter + tracking frame)");
+    return AddAccumulatedRangeData(sync.time, current_pose, origin_in_tracking, cloud);
+  }
+
+  const ActiveSubmaps3D& active_submaps() const { return active_submaps_; }
+
+ private:
+  // .cc:493-572
+  std::unique_ptr<MatchingResult> AddAccumulatedRangeData(int64_t time, const float current_pose[7], const float origin[3],
+                                                          dliom_cloud* cloud) {
+    struct Owner {
+      dliom_cloud* c;
+      ~Owner() { dliom_cloud_destroy(c); }
+    } owner{cloud};
+    int64_t n = 0;
+    Check(dliom_cloud_size(cloud, &n), "dliom_cloud_size");
+    if (n == 0) return nullptr;  // "Dropped empty range data."
+    double prediction[7];
+    for (int i = 0; i < 7; ++i) prediction[i] = static_cast<double>(current_pose[i]);  // current_pose.cast<double>()
+    dliom_match_result m;
+    Check(dliom_front_end_match_cloud(active_submaps_.get(), prediction, origin, cloud, &m), "AddAccumulatedRangeData (match)");
+    if (m.dropped) return nullptr;
+    // WindowOptimize(pose_estimate, false) and opt_pose = PoseFromGtsamNavState(prev_state_)
+    double opt[7], vel[3], bias[6];
+    const int ws = dliom_imu_window_add_pose(window_, m.pose_estimate, 0, opt, vel, bias);
+    if (ws == DLIOM_ERR_DIVERGED) {
+      imu_initialized_ = false;  // ResetParams(): the caller re-initialises (SetInitialState)
+      have_prediction_ = false;
+      return nullptr;
+    }
+    Check(ws, "WindowOptimize");
+    have_prediction_ = false;
+    std::unique_ptr<MatchingResult> result(new MatchingResult);
+    result->time = time;
+    result->local_pose = transform::Rigid3d::FromArray(opt);
+    // filtered_range_data_in_local = TransformRangeData(in_tracking, opt_pose.cast<float>())
+    std::vector<float> pts(3 * static_cast<size_t>(n));
+    Check(dliom_cloud_download(cloud, pts.data()), "dliom_cloud_download");
+    float pf[7];
+    for (int i = 0; i < 7; ++i) pf[i] = static_cast<float>(opt[i]);
+    result->range_data_in_local.origin = TransformPoint(pf, origin[0], origin[1], origin[2]);
+    result->range_data_in_local.returns.resize(static_cast<size_t>(n));
+    for (int64_t i = 0; i < n; ++i)
+      result->range_data_in_local.returns[static_cast<size_t>(i)] = TransformPoint(pf, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    // InsertIntoSubmap (.cc:584-622): gravity_alignment = opt_pose.rotation()
+    dliom_insertion_result ins;
+    Check(dliom_front_end_insert(active_submaps_.get(), time, opt, opt + 3, &ins), "InsertIntoSubmap");
+    if (ins.inserted) {
+      std::unique_ptr<InsertionResult> ir(new InsertionResult);
+      ir->time = time;
+      ir->gravity_alignment = transform::Quaterniond{{opt[3], opt[4], opt[5], opt[6]}};
+      ir->local_pose = result->local_pose;
+      for (int i = 0; i < ins.num_insertion_submaps; ++i) ir->insertion_submap_indices.push_back(ins.insertion_submap_index[i]);
+      ir->submap_finished = ins.submap_finished != 0;
+      result->insertion_result = std::move(ir);
+    }
+    return result;
+  }
+  // Rigid3f * Vector3f with Eigen's operation order (rotation * p + translation)
+  static sensor::Vector3f TransformPoint(const float p7[7], float x, float y, float z) {
+    const float w = p7[3], qx = p7[4], qy = p7[5], qz = p7[6];
+    float uvx = qy * z - qz * y, uvy = qz * x - qx * z, uvz = qx * y - qy * x;
+    uvx += uvx;
+    uvy += uvy;
+    uvz += uvz;
+    const float cx = qy * uvz - qz * uvy, cy = qz * uvx - qx * uvz, cz = qx * uvy - qy * uvx;
+    return sensor::Vector3f{((x + w * uvx) + cx) + p7[0], ((y + w * uvy) + cy) + p7[1], ((z + w * uvz) + cz) + p7[2]};
+  }
+
+  Context* context_;
+  LocalTrajectoryBuilderOptions3D options_;
+  ActiveSubmaps3D active_submaps_;
+  RangeDataSynchronizer synchronizer_;
+  dliom_imu_window* window_ = nullptr;
+  dliom_range_accumulator* accumulator_ = nullptr;
+  int64_t last_imu_time_ = -1;
+  bool imu_initialized_ = false;
+  bool have_prediction_ = false;
+};
+
 }  // namespace mapping
 }  // namespace dliom
 

@@ -310,34 +310,13 @@ static int front_end_match_cloud(dliom_front_end* fe, const double pose_predicti
 
 extern "C" {
 
-int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double pose_estimate7[7],
-                           const double gravity_alignment[4], dliom_insertion_result* r) {
-  if (fe == nullptr || pose_estimate7 == nullptr || gravity_alignment == nullptr || r == nullptr)
-    return DLIOM_ERR_INVALID_ARGUMENT;
-  std::memset(r, 0, sizeof(*r));
-  const dliom_front_end_options& o = fe->options;
-  const PoseD pose = pose_from(pose_estimate7);
-  // MotionFilter::IsSimilar (motion_filter.cc:40-58)
-  ++fe->num_total;
-  if (fe->num_total > 1) {
-    const int64_t max_ticks = static_cast<int64_t>(o.motion_filter_max_time_seconds * 1e7);  // FromSeconds
-    const double dx = pose.t[0] - fe->last_pose.t[0], dy = pose.t[1] - fe->last_pose.t[1],
-                 dz = pose.t[2] - fe->last_pose.t[2];
-    const double d2 = dx * dx + (dy * dy + dz * dz);  // Eigen Vector3d::norm() reduction order
-    const PoseD rel = pose_mul(pose_inverse(pose), fe->last_pose);
-    const double angle =
-        2.0 * std::atan2(std::sqrt(rel.q[1] * rel.q[1] + (rel.q[2] * rel.q[2] + rel.q[3] * rel.q[3])),
-                         std::fabs(rel.q[0]));
-    if (time_ticks - fe->last_time <= max_ticks && std::sqrt(d2) <= o.motion_filter_max_distance_meters &&
-        angle <= o.motion_filter_max_angle_radians) {
-      return DLIOM_OK;  // similar: nothing inserted
-    }
-  }
-  if (fe->returns_cloud == nullptr) {
-    --fe->num_total;  // nothing happened: the filter state must not advance on an error
-    return DLIOM_ERR_EMPTY_CLOUD;
-  }
+}  // extern "C"
 
+// ActiveSubmaps3D::InsertRangeData (submap_3d.cc:296-314) for range data given in the frame `pose` maps into the
+// local frame: fused insertion into every active grid, counters, submap roll-over.  No MotionFilter here.
+static int insert_into_active_submaps(dliom_front_end* fe, const PoseD& pose, const float origin[3], const dliom_cloud* cloud,
+                                      const double gravity_alignment[4], dliom_insertion_result* r) {
+  const dliom_front_end_options& o = fe->options;
   // filtered_range_data_in_local = TransformRangeData(in_tracking, opt_pose.cast<float>()) (:560-561)
   // then per submap TransformRangeData(., local_pose().inverse().cast<float>()) (submap_3d.cc:270-271)
   float poses[14];
@@ -366,21 +345,18 @@ int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double
     }
   }
   {
-    const int status = dliom_inserter_insert_cloud_multi(fe->inserter, nt, targets, target_poses, target_num_poses, fe->origin,
-                                                         fe->returns_cloud, target_max_range);
+    const int status = dliom_inserter_insert_cloud_multi(fe->inserter, nt, targets, target_poses, target_num_poses, origin,
+                                                         cloud, target_max_range);
     if (status != DLIOM_OK) {
-      --fe->num_total;  // a failed insertion leaves MotionFilter and the submap counters where they were
       std::memset(r, 0, sizeof(*r));
       return status;
     }
   }
-  fe->last_time = time_ticks;  // MotionFilter::IsSimilar's state update (motion_filter.cc:54-56), now that it is final
-  fe->last_pose = pose;
   for (auto& sm : fe->submaps) ++sm->num_range_data;
   if (fe->submaps.back()->num_range_data == o.num_range_data) {  // submap_3d.cc:310-313
     // new submap at (range_data.origin in the local frame, gravity_alignment)
     const QF qf{poses[3], poses[4], poses[5], poses[6]};
-    const F3 ol = add3(qrot(qf, F3{fe->origin[0], fe->origin[1], fe->origin[2]}), F3{poses[0], poses[1], poses[2]});
+    const F3 ol = add3(qrot(qf, F3{origin[0], origin[1], origin[2]}), F3{poses[0], poses[1], poses[2]});
     origin_local[0] = ol.x;
     origin_local[1] = ol.y;
     origin_local[2] = ol.z;
@@ -394,6 +370,59 @@ int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double
   }
   return DLIOM_OK;
 }
+
+
+extern "C" {
+
+int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double pose_estimate7[7],
+                           const double gravity_alignment[4], dliom_insertion_result* r) {
+  if (fe == nullptr || pose_estimate7 == nullptr || gravity_alignment == nullptr || r == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  std::memset(r, 0, sizeof(*r));
+  const dliom_front_end_options& o = fe->options;
+  const PoseD pose = pose_from(pose_estimate7);
+  // MotionFilter::IsSimilar (motion_filter.cc:40-58)
+  ++fe->num_total;
+  if (fe->num_total > 1) {
+    const int64_t max_ticks = static_cast<int64_t>(o.motion_filter_max_time_seconds * 1e7);  // FromSeconds
+    const double dx = pose.t[0] - fe->last_pose.t[0], dy = pose.t[1] - fe->last_pose.t[1],
+                 dz = pose.t[2] - fe->last_pose.t[2];
+    const double d2 = dx * dx + (dy * dy + dz * dz);  // Eigen Vector3d::norm() reduction order
+    const PoseD rel = pose_mul(pose_inverse(pose), fe->last_pose);
+    const double angle =
+        2.0 * std::atan2(std::sqrt(rel.q[1] * rel.q[1] + (rel.q[2] * rel.q[2] + rel.q[3] * rel.q[3])),
+                         std::fabs(rel.q[0]));
+    if (time_ticks - fe->last_time <= max_ticks && std::sqrt(d2) <= o.motion_filter_max_distance_meters &&
+        angle <= o.motion_filter_max_angle_radians) {
+      return DLIOM_OK;  // similar: nothing inserted
+    }
+  }
+  if (fe->returns_cloud == nullptr) {
+    --fe->num_total;  // nothing happened: the filter state must not advance on an error
+    return DLIOM_ERR_EMPTY_CLOUD;
+  }
+  const int status = insert_into_active_submaps(fe, pose, fe->origin, fe->returns_cloud, gravity_alignment, r);
+  if (status != DLIOM_OK) {
+    --fe->num_total;  // a failed insertion leaves MotionFilter where it was
+    return status;
+  }
+  fe->last_time = time_ticks;  // MotionFilter::IsSimilar's state update (motion_filter.cc:54-56), now that it is final
+  fe->last_pose = pose;
+  return DLIOM_OK;
+}
+
+int dliom_front_end_insert_range_data(dliom_front_end* fe, const float origin_in_local[3], const dliom_cloud* returns_in_local,
+                                      const double gravity_alignment[4], dliom_insertion_result* r) {
+  if (fe == nullptr || origin_in_local == nullptr || returns_in_local == nullptr || gravity_alignment == nullptr || r == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  std::memset(r, 0, sizeof(*r));
+  PoseD identity;
+  identity.t[0] = identity.t[1] = identity.t[2] = 0.0;
+  identity.q[0] = 1.0;
+  identity.q[1] = identity.q[2] = identity.q[3] = 0.0;
+  return insert_into_active_submaps(fe, identity, origin_in_local, returns_in_local, gravity_alignment, r);
+}
+
 
 int dliom_front_end_num_active_submaps(const dliom_front_end* fe, int* n) {
   if (fe == nullptr || n == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;

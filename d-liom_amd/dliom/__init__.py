@@ -217,6 +217,7 @@ SYMBOLS = [
     ("dliom_front_end_match_cloud", C.c_int, [_vp, _f64p, _f32p, _vp, C.POINTER(MatchResult)]),
     ("dliom_front_end_insert", C.c_int, [_vp, C.c_int64, _f64p, _f64p, C.POINTER(InsertionResult)]),
     ("dliom_front_end_num_active_submaps", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("dliom_front_end_insert_range_data", C.c_int, [_vp, _f32p, _vp, _f64p, C.POINTER(InsertionResult)]),
     ("dliom_front_end_num_finished_submaps", C.c_int, [_vp, C.POINTER(C.c_int)]),
     ("dliom_front_end_take_finished_submap", C.c_int, [_vp, _f64p, C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_front_end_matching_index", C.c_int, [_vp, C.POINTER(C.c_int)]),
@@ -821,9 +822,33 @@ class _BorrowedGrid(HybridGrid):
         self.h = None
 
 
+def front_end_options_struct(options):
+    """dliom_front_end_options from the nested dict the tests and tools use."""
+    o = FrontEndOptions()
+    hi, lo = options["high_resolution_adaptive_voxel_filter"], options["low_resolution_adaptive_voxel_filter"]
+    o.high_resolution_adaptive_voxel_filter = AdaptiveVoxelFilterOptions(hi["max_length"], hi["min_num_points"], hi["max_range"])
+    o.low_resolution_adaptive_voxel_filter = AdaptiveVoxelFilterOptions(lo["max_length"], lo["min_num_points"], lo["max_range"])
+    o.use_online_correlative_scan_matching = int(options["use_online_correlative_scan_matching"])
+    o.real_time_correlative_scan_matcher = _rtcsm_opts(options["real_time_correlative_scan_matcher"])
+    o.ceres_scan_matcher = _csm_opts(options["ceres_scan_matcher"])
+    m, s = options["motion_filter"], options["submaps"]
+    o.motion_filter_max_time_seconds = m["max_time_seconds"]
+    o.motion_filter_max_distance_meters = m["max_distance_meters"]
+    o.motion_filter_max_angle_radians = m["max_angle_radians"]
+    o.high_resolution = s["high_resolution"]
+    o.high_resolution_max_range = s["high_resolution_max_range"]
+    o.low_resolution = s["low_resolution"]
+    o.num_range_data = s["num_range_data"]
+    o.hit_probability = s["hit_probability"]
+    o.miss_probability = s["miss_probability"]
+    o.num_free_space_voxels = s["num_free_space_voxels"]
+    return o
+
+
 class LocalTrajectoryBuilder3D:
     """AddAccumulatedRangeData + InsertIntoSubmap of the reference's LocalTrajectoryBuilder3D
-    (local_trajectory_builder_3d.cc:493-622) minus the GTSAM window, over ActiveSubmaps3D."""
+    (local_trajectory_builder_3d.cc:493-622), over ActiveSubmaps3D; WindowOptimize sits between match and insert
+    (dliom.ImuWindow)."""
 
     def __init__(self, ctx, options):
         self.ctx = ctx

@@ -340,6 +340,11 @@ int dliom_front_end_insert(dliom_front_end* fe, int64_t time_ticks, const double
 /* ActiveSubmaps3D::submaps() / matching_index(). */
 int dliom_front_end_num_active_submaps(const dliom_front_end* fe, int* n);
 int dliom_front_end_matching_index(const dliom_front_end* fe, int* index);
+/* ActiveSubmaps3D::InsertRangeData(range_data, gravity_alignment) (mapping/3d/submap_3d.h:111-112, .cc:296-314) on the
+ * front end's active submaps: range data already in the LOCAL frame, no MotionFilter. */
+int dliom_front_end_insert_range_data(dliom_front_end* fe, const float origin_in_local[3],
+                                      const dliom_cloud* returns_in_local, const double gravity_alignment[4],
+                                      dliom_insertion_result* result);
 /* Finished submaps (Submap3D::Finish(), submap_3d.cc:316-326) leave the active pair but stay alive for the back end:
  * the reference hands them on as shared_ptr and drops them when the pose graph is done.  Here the front end holds
  * them (leaf pools shrunk to the leaves in use, dense mirror released) until the caller TAKES them, oldest first;

@@ -1,0 +1,74 @@
+// LocalTrajectoryBuilder3D / ActiveSubmaps3D adapters (d-liom_amd/cpp/dliom_cartographer.h) driven like
+// cartographer drives the reference's classes: AddImuData at 200 Hz, AddRangeData at 10 Hz
+// (mapping/internal/3d/local_trajectory_builder_3d.h:83-111).  Input: a binary file written by
+// tests/test_gpu_parity.py (scans with per-point times, IMU samples, the initial state); output: one line per
+// MatchingResult with the local pose, compared there with the Python-driven chain.
+//   g++ -std=c++17 ltb3d_adapter.cc -L../../d-liom_amd -ldliom
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../d-liom_amd/cpp/dliom_cartographer.h"
+
+using namespace dliom;
+
+static bool read_all(FILE* f, void* p, size_t bytes) { return std::fread(p, 1, bytes, f) == bytes; }
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  FILE* f = std::fopen(argv[1], "rb");
+  if (f == nullptr) return 2;
+  int32_t header[4];  // num_scans, points_per_scan, imu_per_scan, num_accumulated_range_data
+  double init[16];    // pose7, velocity3, bias6
+  if (!read_all(f, header, sizeof header) || !read_all(f, init, sizeof init)) return 2;
+  Context context(0);
+  mapping::LocalTrajectoryBuilderOptions3D options;
+  std::memset(&options.front_end, 0, sizeof options.front_end);
+  if (!read_all(f, &options.front_end, sizeof options.front_end)) return 2;
+  Check(dliom_imu_window_default_options(&options.imu), "dliom_imu_window_default_options");
+  double imu_noise[4];
+  if (!read_all(f, imu_noise, sizeof imu_noise)) return 2;
+  options.imu.acc_noise = imu_noise[0];
+  options.imu.gyr_noise = imu_noise[1];
+  options.imu.acc_bias_noise = imu_noise[2];
+  options.imu.gyr_bias_noise = imu_noise[3];
+  options.num_accumulated_range_data = header[3];
+  options.min_range = 1.f;
+  options.max_range = 100.f;
+  options.voxel_filter_size = 0.15f;
+  options.scan_period = 0.1;
+  mapping::LocalTrajectoryBuilder3D builder(&context, options, {"lidar"});
+  builder.SetInitialState(transform::Rigid3d::FromArray(init), transform::Vector3d{{init[7], init[8], init[9]}}, init + 10);
+  int64_t t = 0;
+  int results = 0;
+  for (int s = 0; s < header[0]; ++s) {
+    std::vector<double> imu(static_cast<size_t>(header[2]) * 7);  // dt, acc3, gyr3
+    if (!read_all(f, imu.data(), imu.size() * 8)) return 2;
+    for (int k = 0; k < header[2]; ++k) {
+      t += static_cast<int64_t>(imu[7 * k] * 1e7 + 0.5);
+      sensor::ImuData d;
+      d.time = t;
+      std::memcpy(d.linear_acceleration, &imu[7 * k + 1], 24);
+      std::memcpy(d.angular_velocity, &imu[7 * k + 4], 24);
+      builder.AddImuData(d);
+    }
+    sensor::TimedPointCloudData cloud;
+    cloud.time = t;
+    cloud.origin = sensor::Vector3f{0.f, 0.f, 0.f};
+    cloud.ranges.resize(static_cast<size_t>(header[1]));
+    if (!read_all(f, cloud.ranges.data(), cloud.ranges.size() * 16)) return 2;
+    std::unique_ptr<mapping::LocalTrajectoryBuilder3D::MatchingResult> r = builder.AddRangeData("lidar", cloud);
+    if (r != nullptr) {
+      const std::array<double, 7> p = r->local_pose.ToArray();
+      std::printf("RESULT %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %zu %d\n", s, p[0], p[1], p[2], p[3], p[4], p[5], p[6],
+                  r->range_data_in_local.returns.size(), r->insertion_result != nullptr ? 1 : 0);
+      ++results;
+    }
+  }
+  std::fclose(f);
+  const auto submaps = builder.active_submaps().submaps();
+  std::printf("SUBMAPS %zu matching_index %d results %d\n", submaps.size(), builder.active_submaps().matching_index(), results);
+  std::printf("LTB3D ADAPTER DONE\n");
+  return 0;
+}

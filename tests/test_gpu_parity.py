@@ -1006,3 +1006,71 @@ def test_range_accumulator_two_scans_two_origins(dl, ctx, orc):
     for c in (cloud, c1, c2):
         c.close()
     dacc.close()
+
+
+@pytest.mark.parametrize("num_accumulated", [1, 2])
+def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumulated):
+    """tests/cpp/ltb3d_adapter.cc drives the C++ LocalTrajectoryBuilder3D adapter (AddImuData at 200 Hz, AddRangeData
+    at 10 Hz, reference signatures) on a recorded stream; the same stream through the Python binding, step by step
+    (ImuWindow.add_imu / predict -> RangeDataAccumulator -> match_cloud -> add_pose -> insert), gives the same poses
+    bit for bit."""
+    import ctypes
+    import os
+    import struct
+    import subprocess
+    from dliom import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    noise = [0.08, 0.004, 4e-5, 2e-6]
+    T, scans_n, beams, az = 0.1, 6, 16, 256
+    centers = synth.bubbles()
+    st = synth.trajectory_state(0.0)
+    scans = [synth.moving_scan(T * k, beams, az, centers) for k in range(1, scans_n + 1)]
+    imus = [synth.imu_samples(T * (k - 1), T * k, 200.0) for k in range(1, scans_n + 1)]
+    path = str(tmp_path / "stream.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", scans_n, len(scans[0]), len(imus[0][1]) - 1, num_accumulated))
+        f.write(np.asarray(st, dtype=np.float64).tobytes())
+        f.write(bytes(dl.front_end_options_struct(FRONT_END_OPTS)))
+        f.write(np.asarray(noise, dtype=np.float64).tobytes())
+        for (dt, acc, gyr), sc in zip(imus, scans):
+            rows = np.concatenate([np.full((len(acc) - 1, 1), dt), acc[:-1], gyr[:-1]], axis=1)
+            f.write(np.ascontiguousarray(rows, dtype=np.float64).tobytes())
+            f.write(np.ascontiguousarray(sc, dtype=np.float32).tobytes())
+    exe = str(tmp_path / "ltb3d_adapter")
+    libdir = os.path.join(root, "d-liom_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(root, "tests", "cpp", "ltb3d_adapter.cc"),
+                           "-L", libdir, "-ldliom", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "LTB3D ADAPTER DONE" in out.stdout, out.stdout + out.stderr
+    got = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:9]]) for l in out.stdout.splitlines() if l.startswith("RESULT")}
+    # the same stream through the Python binding
+    window = dl.ImuWindow(acc_noise=noise[0], gyr_noise=noise[1], acc_bias_noise=noise[2], gyr_bias_noise=noise[3])
+    window.initialize(st[:7], st[7:10], np.zeros(6))
+    acc_dev = dl.RangeDataAccumulator(ctx)
+    fe = dl.LocalTrajectoryBuilder3D(ctx, FRONT_END_OPTS)
+    ticks, last, want = 0, -1, {}
+    for s, ((dt, acc, gyr), sc) in enumerate(zip(imus, scans)):
+        for a, g in zip(acc[:-1], gyr[:-1]):
+            ticks += int(dt * 1e7 + 0.5)
+            h = 1.0 / 500.0 if last < 0 else (ticks - last) * 1e-7
+            last = ticks
+            window.add_imu(a, g, h)
+        prev, _, _ = window.state()
+        pred, _ = window.predict()
+        cur, k = acc_dev.add(prev, pred, T, sc, 1.0, 100.0, 0.15)
+        if k < num_accumulated:
+            continue
+        cloud, origin = acc_dev.finish(0.15)
+        r = fe.match_cloud(cur.astype(np.float64), origin, cloud)
+        est, vel, bias, status = window.add_pose(r["pose_estimate"])
+        assert status == 0 and not r["dropped"]
+        fe.insert(ticks, est, est[3:])
+        cloud.close()
+        want[s] = est
+    assert sorted(got) == sorted(want) and len(want) == scans_n // num_accumulated
+    for s in want:
+        assert np.array_equal(got[s], want[s]), (s, got[s], want[s])
+    assert ("SUBMAPS 2" if num_accumulated == 1 else "SUBMAPS 1") in out.stdout  # num_range_data = 4: roll-over after 4 insertions
+    fe.close()
+    acc_dev.close()
+    del ctypes
