@@ -15,6 +15,8 @@
 // (jacobi scaling, radius update, tolerances) on those 6x6 systems.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -25,6 +27,7 @@ namespace dliom {
 
 constexpr int kCsmBlock = 256;
 constexpr int kAcc = 28;  // 21 JtJ (upper triangle, row-major) + 6 Jtr + 1 sum r^2
+static_assert(kAcc % 4 == 0 && kCsmBlock == 256, "the block reductions fold four waves x kAcc / 4 sums");
 
 struct CsmCloudArg {
   GridView g;
@@ -34,14 +37,17 @@ struct CsmCloudArg {
   int n;
   double scale;  // occupied_space_weight / sqrt(n)
 };
-struct CsmArgs {
-  CsmCloudArg cloud[DLIOM_MAX_CLOUDS];
-  int num_clouds;
-  int total_points;
+struct CsmPose {
   double t[3];
   double q[4];      // w,x,y,z (not normalised, as in the reference's Jet evaluation)
   double plus[12];  // d q / d local, 4 x nloc row-major (QuaternionParameterization::ComputeJacobian)
   int nloc;         // 3, or 1 for the yaw-only parameterisation
+};
+struct CsmArgs {
+  CsmCloudArg cloud[DLIOM_MAX_CLOUDS];
+  int num_clouds;
+  int total_points;
+  CsmPose pose;
 };
 
 __device__ __forceinline__ double lut_probability(unsigned v, float k_scale, float k_offset,
@@ -52,7 +58,7 @@ __device__ __forceinline__ double lut_probability(unsigned v, float k_scale, flo
 }
 
 // One point: residual r = s (1 - P(T p)) and its 6 tangent-space derivatives.
-__device__ __forceinline__ void csm_point(const CsmArgs& a, const CsmCloudArg& c, int i,
+__device__ __forceinline__ void csm_point(const CsmPose& a, const CsmCloudArg& c, int i,
                                           float k_scale, float k_offset, float k_unknown,
                                           double* r_out, double jrow[6]) {
   const double vx = static_cast<double>(c.x[i]);
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(kCsmBlock) void csm_eval_kernel(CsmArgs a, float k_
     const CsmCloudArg& c = a.cloud[ci];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += stride) {
       double r, j[6];
-      csm_point(a, c, i, k_scale, k_offset, k_unknown, &r, j);
+      csm_point(a.pose, c, i, k_scale, k_offset, k_unknown, &r, j);
       int idx = 0;
 #pragma unroll
       for (int p = 0; p < 6; ++p)
@@ -244,7 +250,7 @@ struct CsmProblem {
   int evaluations;
 };
 
-static void quat_product(const double z[4], const double w[4], double zw[4]) {
+__host__ __device__ static void quat_product(const double z[4], const double w[4], double zw[4]) {
   zw[0] = z[0] * w[0] - z[1] * w[1] - z[2] * w[2] - z[3] * w[3];
   zw[1] = z[0] * w[1] + z[1] * w[0] + z[2] * w[3] - z[3] * w[2];
   zw[2] = z[0] * w[2] - z[1] * w[3] + z[2] * w[0] + z[3] * w[1];
@@ -252,7 +258,7 @@ static void quat_product(const double z[4], const double w[4], double zw[4]) {
 }
 
 // QuaternionParameterization / YawOnlyQuaternionPlus (rotation_parameterization.h:27-39)
-static void plus_jacobian(const double q[4], int nloc, double j[12]) {
+__host__ __device__ static void plus_jacobian(const double q[4], int nloc, double j[12]) {
   if (nloc == 3) {
     j[0] = -q[1]; j[1] = -q[2]; j[2] = -q[3];
     j[3] = q[0];  j[4] = q[3];  j[5] = -q[2];
@@ -265,14 +271,14 @@ static void plus_jacobian(const double q[4], int nloc, double j[12]) {
     j[3] = q[0];
   }
 }
-static void plus(const double x[7], const double* delta, int nloc, double out[7]) {
+__host__ __device__ static void plus(const double x[7], const double* delta, int nloc, double out[7]) {
   for (int i = 0; i < 3; ++i) out[i] = x[i] + delta[i];
   const double* d = delta + 3;
   if (nloc == 3) {
-    const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     if (n > 0.0) {
-      const double s = std::sin(n) / n;
-      const double qd[4] = {std::cos(n), s * d[0], s * d[1], s * d[2]};
+      const double s = sin(n) / n;
+      const double qd[4] = {cos(n), s * d[0], s * d[1], s * d[2]};
       quat_product(qd, x + 3, out + 3);
     } else {
       for (int i = 0; i < 4; ++i) out[3 + i] = x[3 + i];
@@ -281,19 +287,76 @@ static void plus(const double x[7], const double* delta, int nloc, double out[7]
     double c = d[0];
     if (c > 0.5) c = 0.5;
     if (c < -0.5) c = -0.5;
-    const double qd[4] = {std::sqrt(1. - c * c), 0., 0., c};
+    const double qd[4] = {sqrt(1. - c * c), 0., 0., c};
     quat_product(qd, x + 3, out + 3);
   }
+}
+
+// The 28 occupied-space sums -> full normal equations, plus the two prior residual blocks
+// (translation_delta_cost_functor_3d.h:39-45, rotation_delta_cost_functor_3d.h:43-54).
+template <int nloc>
+__host__ __device__ static void finish_normal(const double* sums28, const double x[7], const double* plusj, double wt,
+                                              double wr, const double target_t[3], const double init_q[4], Normal* out) {
+  int idx = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) {
+      out->H[r * 6 + c] = sums28[idx];
+      out->H[c * 6 + r] = sums28[idx];
+      ++idx;
+    }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) out->g[r] = sums28[21 + r];
+  double sumsq = sums28[27];
+  // translation_delta_cost_functor_3d.h:39-45 (only if weight > 0: ceres_scan_matcher_3d.cc:104-110)
+  if (wt > 0.) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double r = wt * (x[i] - target_t[i]);
+      out->H[i * 6 + i] += wt * wt;
+      out->g[i] += wt * r;
+      sumsq += r * r;
+    }
+  }
+  // rotation_delta_cost_functor_3d.h:43-54: r = w * (q_init^-1 (x) q).xyz, linear in q
+  if (wr > 0.) {
+    const double z[4] = {init_q[0], -init_q[1], -init_q[2], -init_q[3]};
+    double d[4];
+    quat_product(z, x + 3, d);
+    // rows of d(delta_k)/dq for k = 1..3 (common/math.h:74-81)
+    const double D[3][4] = {{z[1], z[0], -z[3], z[2]}, {z[2], z[3], z[0], -z[1]}, {z[3], -z[2], z[1], z[0]}};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double r = wr * d[k + 1];
+      double jl[3] = {0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < nloc; ++c) {
+        double s = 0.;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s += (wr * D[k][m]) * plusj[m * nloc + c];
+        jl[c] = s;
+      }
+#pragma unroll
+      for (int c1 = 0; c1 < nloc; ++c1) {
+        out->g[3 + c1] += jl[c1] * r;
+#pragma unroll
+        for (int c2 = 0; c2 < nloc; ++c2) out->H[(3 + c1) * 6 + 3 + c2] += jl[c1] * jl[c2];
+      }
+      sumsq += r * r;
+    }
+  }
+  out->cost = 0.5 * sumsq;
 }
 
 // One evaluation at x = [t, q]: device occupied-space sums + host prior residuals.
 static int evaluate(CsmProblem* p, const double x[7], Normal* out) {
   dliom_ctx* ctx = p->ctx;
   CsmArgs& a = p->args;
-  for (int i = 0; i < 3; ++i) a.t[i] = x[i];
-  for (int i = 0; i < 4; ++i) a.q[i] = x[3 + i];
-  a.nloc = p->nloc;
-  plus_jacobian(x + 3, p->nloc, a.plus);
+  for (int i = 0; i < 3; ++i) a.pose.t[i] = x[i];
+  for (int i = 0; i < 4; ++i) a.pose.q[i] = x[3 + i];
+  a.pose.nloc = p->nloc;
+  plus_jacobian(x + 3, p->nloc, a.pose.plus);
   const float kMin = 0.1f, kMax = 1.f - 0.1f;
   const float k_scale = (kMax - kMin) / 32766.f;
   const float k_offset = kMin - k_scale;
@@ -309,87 +372,66 @@ static int evaluate(CsmProblem* p, const double x[7], Normal* out) {
   DLIOM_HIP_TRY(hipGetLastError());
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   ++p->evaluations;
-  int idx = 0;
-  for (int r = 0; r < 6; ++r)
-    for (int c = r; c < 6; ++c) {
-      out->H[r * 6 + c] = host[idx];
-      out->H[c * 6 + r] = host[idx];
-      ++idx;
-    }
-  for (int r = 0; r < 6; ++r) out->g[r] = host[21 + r];
-  double sumsq = host[27];
-  // translation_delta_cost_functor_3d.h:39-45 (only if weight > 0: ceres_scan_matcher_3d.cc:104-110)
-  const double wt = p->o->translation_weight;
-  if (wt > 0.) {
-    for (int i = 0; i < 3; ++i) {
-      const double r = wt * (x[i] - p->target_t[i]);
-      out->H[i * 6 + i] += wt * wt;
-      out->g[i] += wt * r;
-      sumsq += r * r;
-    }
-  }
-  // rotation_delta_cost_functor_3d.h:43-54: r = w * (q_init^-1 (x) q).xyz, linear in q
-  const double wr = p->o->rotation_weight;
-  if (wr > 0.) {
-    const double z[4] = {p->init_q[0], -p->init_q[1], -p->init_q[2], -p->init_q[3]};
-    double d[4];
-    quat_product(z, x + 3, d);
-    // rows of d(delta_k)/dq for k = 1..3 (common/math.h:74-81)
-    const double D[3][4] = {{z[1], z[0], -z[3], z[2]}, {z[2], z[3], z[0], -z[1]}, {z[3], -z[2], z[1], z[0]}};
-    for (int k = 0; k < 3; ++k) {
-      const double r = wr * d[k + 1];
-      double jl[3] = {0, 0, 0};
-      for (int c = 0; c < p->nloc; ++c) {
-        double s = 0.;
-        for (int m = 0; m < 4; ++m) s += (wr * D[k][m]) * a.plus[m * p->nloc + c];
-        jl[c] = s;
-      }
-      for (int c1 = 0; c1 < p->nloc; ++c1) {
-        out->g[3 + c1] += jl[c1] * r;
-        for (int c2 = 0; c2 < p->nloc; ++c2) out->H[(3 + c1) * 6 + 3 + c2] += jl[c1] * jl[c2];
-      }
-      sumsq += r * r;
-    }
-  }
-  out->cost = 0.5 * sumsq;
+  if (p->nloc == 3)
+    finish_normal<3>(host, x, a.pose.plus, p->o->translation_weight, p->o->rotation_weight, p->target_t, p->init_q, out);
+  else
+    finish_normal<1>(host, x, a.pose.plus, p->o->translation_weight, p->o->rotation_weight, p->target_t, p->init_q, out);
   return DLIOM_OK;
 }
 
 // (A + diag(d2)) y = b for the leading n x n block, Cholesky; false if not positive definite.
-static bool solve_spd(const double* A, const double* d2, const double* b, int n, double* y) {
+// (n is a template argument and every loop is unrolled: in csm_lm_kernel the matrices must live in registers, a
+// dynamically indexed local array would sit in scratch memory at ~1 us per dependent access.)
+template <int n>
+__host__ __device__ static bool solve_spd(const double* A, const double* d2, const double* b, double* y) {
   double Lm[36];
+#pragma unroll
   for (int i = 0; i < n; ++i) {
+#pragma unroll
     for (int j = 0; j <= i; ++j) {
       double s = A[i * 6 + j] + (i == j ? d2[i] : 0.0);
+#pragma unroll
       for (int k = 0; k < j; ++k) s -= Lm[i * 6 + k] * Lm[j * 6 + k];
       if (i == j) {
         if (!(s > 0.0)) return false;
-        Lm[i * 6 + i] = std::sqrt(s);
+        Lm[i * 6 + i] = sqrt(s);
       } else {
         Lm[i * 6 + j] = s / Lm[j * 6 + j];
       }
     }
   }
   double z[6];
+#pragma unroll
   for (int i = 0; i < n; ++i) {
     double s = b[i];
+#pragma unroll
     for (int k = 0; k < i; ++k) s -= Lm[i * 6 + k] * z[k];
     z[i] = s / Lm[i * 6 + i];
   }
+#pragma unroll
   for (int i = n - 1; i >= 0; --i) {
     double s = z[i];
+#pragma unroll
     for (int k = i + 1; k < n; ++k) s -= Lm[k * 6 + i] * y[k];
     y[i] = s / Lm[i * 6 + i];
   }
+#pragma unroll
   for (int i = 0; i < n; ++i)
-    if (!std::isfinite(y[i])) return false;
+    if (!(fabs(y[i]) <= 1.7976931348623157e308)) return false;  // !isfinite
   return true;
 }
 
 // Ceres 1.13 trust-region minimizer (LEVENBERG_MARQUARDT) on the normal equations.
-static int minimize(CsmProblem* p, double x[7], dliom_csm_summary* sum) {
-  const dliom_csm_options& o = *p->o;
-  const int ne = 3 + p->nloc;
+// `ev(x, &normal)` evaluates the normal equations at x (0 = ok) and counts in ev.evaluations; on the host it launches
+// the evaluation kernel per call, inside csm_lm_kernel it is the workgroup's own reduction -- the SAME loop either way.
+struct LmConfig {
+  int max_num_iterations;
+  int use_nonmonotonic_steps;
+  int nloc;
+};
+template <int nloc, class Eval>
+__host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7], dliom_csm_summary* sum) {
+  constexpr int ne = 3 + nloc;
   const double kFunctionTol = 1e-6, kGradientTol = 1e-10, kParameterTol = 1e-8;
   const double kMinRelDecrease = 1e-3, kMinDiag = 1e-6, kMaxDiag = 1e32;
   const double kMaxRadius = 1e16, kMinRadius = 1e-32;
@@ -397,36 +439,47 @@ static int minimize(CsmProblem* p, double x[7], dliom_csm_summary* sum) {
   double radius = 1e4, decrease_factor = 2.0;
   auto norm7 = [](const double* v) {
     double s = 0;
+#pragma unroll
     for (int i = 0; i < 7; ++i) s += v[i] * v[i];
-    return std::sqrt(s);
+    return sqrt(s);
   };
   auto grad_max_norm = [&](const double* xx, const Normal& nrm) {
     double neg[6] = {0, 0, 0, 0, 0, 0}, proj[7];
+#pragma unroll
     for (int i = 0; i < ne; ++i) neg[i] = -nrm.g[i];
-    plus(xx, neg, p->nloc, proj);
+    plus(xx, neg, nloc, proj);
     double m = 0;
-    for (int i = 0; i < 7; ++i) m = std::max(m, std::fabs(xx[i] - proj[i]));
+#pragma unroll
+    for (int i = 0; i < 7; ++i) m = fmax(m, fabs(xx[i] - proj[i]));
     return m;
   };
-  std::memset(sum, 0, sizeof(*sum));
+  sum->initial_cost = sum->final_cost = 0.0;
+  sum->num_successful_steps = sum->num_unsuccessful_steps = sum->num_iterations = 0;
+  sum->num_residual_evaluations = sum->num_jacobian_evaluations = sum->termination_type = 0;
   Normal cur;
-  DLIOM_TRY(evaluate(p, x, &cur));
+  {
+    const int es = ev(x, &cur);
+    if (es != DLIOM_OK) return es;
+  }
   double x_cost = cur.cost, minimum_cost = cur.cost;
   double best_x[7];
-  std::memcpy(best_x, x, sizeof(best_x));
+#pragma unroll
+  for (int i = 0; i < 7; ++i) best_x[i] = x[i];
   sum->initial_cost = x_cost;
   double min_iter_cost = x_cost;
   int num_iter_records = 1;
   double scale[6] = {1, 1, 1, 1, 1, 1};
-  for (int i = 0; i < ne; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(cur.H[i * 6 + i]));
+#pragma unroll
+  for (int i = 0; i < ne; ++i) scale[i] = 1.0 / (1.0 + sqrt(cur.H[i * 6 + i]));
   double x_norm = norm7(x);
   double gmax = grad_max_norm(x, cur);
   auto finish = [&](int type) {
-    std::memcpy(x, best_x, sizeof(best_x));
-    sum->final_cost = std::min(sum->initial_cost, min_iter_cost);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = best_x[i];
+    sum->final_cost = fmin(sum->initial_cost, min_iter_cost);
     sum->num_iterations = num_iter_records;
-    sum->num_residual_evaluations = p->evaluations;
-    sum->num_jacobian_evaluations = p->evaluations;
+    sum->num_residual_evaluations = ev.evaluations;
+    sum->num_jacobian_evaluations = ev.evaluations;
     sum->termination_type = type;
     return type == 2 ? DLIOM_ERR_SOLVER : DLIOM_OK;
   };
@@ -445,7 +498,8 @@ static int minimize(CsmProblem* p, double x[7], dliom_csm_summary* sum) {
       ++sum->num_successful_steps;
       if (x_cost < minimum_cost) {
         minimum_cost = x_cost;
-        std::memcpy(best_x, x, sizeof(best_x));
+#pragma unroll
+        for (int i = 0; i < 7; ++i) best_x[i] = x[i];
       }
     } else if (iteration > 0) {
       ++sum->num_unsuccessful_steps;
@@ -458,21 +512,27 @@ static int minimize(CsmProblem* p, double x[7], dliom_csm_summary* sum) {
 
     // scaled normal equations Hs = S H S, gs = S g; LM diagonal from diag(Hs)
     double Hs[36], gs[6], d2[6], y[6], step[6];
+#pragma unroll
     for (int r = 0; r < ne; ++r) {
       gs[r] = cur.g[r] * scale[r];
+#pragma unroll
       for (int c = 0; c < ne; ++c) Hs[r * 6 + c] = cur.H[r * 6 + c] * scale[r] * scale[c];
     }
+#pragma unroll
     for (int r = 0; r < ne; ++r)
-      d2[r] = std::min(std::max(Hs[r * 6 + r], kMinDiag), kMaxDiag) / radius;
-    bool valid = solve_spd(Hs, d2, gs, ne, y);
+      d2[r] = fmin(fmax(Hs[r * 6 + r], kMinDiag), kMaxDiag) / radius;
+    bool valid = solve_spd<ne>(Hs, d2, gs, y);
     double model_cost_change = 0.0;
     if (valid) {
+#pragma unroll
       for (int r = 0; r < ne; ++r) step[r] = -y[r];
       // -(J s)^T (r + J s / 2) = -s^T gs - 1/2 s^T Hs s
       double sg = 0.0, shs = 0.0;
+#pragma unroll
       for (int r = 0; r < ne; ++r) {
         sg += step[r] * gs[r];
         double t = 0.0;
+#pragma unroll
         for (int c = 0; c < ne; ++c) t += Hs[r * 6 + c] * step[c];
         shs += step[r] * t;
       }
@@ -482,34 +542,40 @@ static int minimize(CsmProblem* p, double x[7], dliom_csm_summary* sum) {
     if (!valid) {
       if (++invalid >= kMaxInvalid) return finish(2);
       radius *= 0.5;
-      min_iter_cost = std::min(min_iter_cost, x_cost);
+      min_iter_cost = fmin(min_iter_cost, x_cost);
       ++num_iter_records;
       continue;
     }
     invalid = 0;
     double delta[6] = {0, 0, 0, 0, 0, 0}, cand[7];
+#pragma unroll
     for (int r = 0; r < ne; ++r) delta[r] = step[r] * scale[r];
-    plus(x, delta, p->nloc, cand);
+    plus(x, delta, nloc, cand);
     Normal cn;
-    DLIOM_TRY(evaluate(p, cand, &cn));
+    {
+      const int es = ev(cand, &cn);
+      if (es != DLIOM_OK) return es;
+    }
     const double cand_cost = cn.cost;
     double step_norm = 0;
+#pragma unroll
     for (int i = 0; i < 7; ++i) step_norm += (x[i] - cand[i]) * (x[i] - cand[i]);
-    step_norm = std::sqrt(step_norm);
+    step_norm = sqrt(step_norm);
     if (step_norm <= kParameterTol * (x_norm + kParameterTol)) return finish(0);
-    if (std::fabs(x_cost - cand_cost) <= kFunctionTol * x_cost) return finish(0);
+    if (fabs(x_cost - cand_cost) <= kFunctionTol * x_cost) return finish(0);
     const double rel = (ev_cur - cand_cost) / model_cost_change;
     const double hist = (ev_ref - cand_cost) / (acc_ref + model_cost_change);
-    const double quality = std::max(rel, hist);
+    const double quality = fmax(rel, hist);
     if (quality > kMinRelDecrease) {
-      std::memcpy(x, cand, sizeof(cand));
+#pragma unroll
+      for (int i = 0; i < 7; ++i) x[i] = cand[i];
       x_norm = norm7(x);
       cur = cn;
       x_cost = cand_cost;
       gmax = grad_max_norm(x, cur);
       last_ok = true;
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * quality - 1.0, 3));
-      radius = std::min(kMaxRadius, radius);
+      radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * quality - 1.0, 3));
+      radius = fmin(kMaxRadius, radius);
       decrease_factor = 2.0;
       ev_cur = cand_cost;
       acc_cand += model_cost_change;
@@ -530,13 +596,139 @@ static int minimize(CsmProblem* p, double x[7], dliom_csm_summary* sum) {
         ev_ref = ev_cand;
         acc_ref = acc_cand;
       }
-      min_iter_cost = std::min(min_iter_cost, x_cost);
+      min_iter_cost = fmin(min_iter_cost, x_cost);
     } else {
       radius = radius / decrease_factor;
       decrease_factor *= 2.0;
-      min_iter_cost = std::min(min_iter_cost, cand_cost);
+      min_iter_cost = fmin(min_iter_cost, cand_cost);
     }
     ++num_iter_records;
+  }
+}
+
+struct HostEval {
+  CsmProblem* p;
+  int evaluations = 0;
+  int operator()(const double x[7], Normal* out) {
+    const int s = evaluate(p, x, out);
+    evaluations = p->evaluations;
+    return s;
+  }
+};
+
+// ---- the whole Levenberg-Marquardt loop in ONE launch (small clouds: the reference's own configuration matches
+// ~170 + ~210 points after the adaptive voxel filters, where ten launch + synchronise round trips of ~25 us each
+// were 90 % of CeresScanMatcher3D's time).  One workgroup: every thread runs the same minimize<> loop on the same
+// numbers (uniform control flow); an evaluation is the workgroup's strided accumulation + the fixed-order LDS
+// reduction of csm_eval_kernel, so for clouds that fit one workgroup of that kernel the sums are bit-identical.
+struct LmKernelParams {
+  LmConfig cfg;
+  double translation_weight, rotation_weight;
+  double target_t[3];
+  double init_q[4];
+  double x0[7];
+  float k_scale, k_offset, k_unknown;
+};
+struct LmKernelOut {
+  double x[7];
+  dliom_csm_summary summary;
+  int status;
+};
+
+template <int NLOC>
+struct DeviceEval {
+  const CsmArgs* a;  // clouds (kernel argument)
+  const LmKernelParams* prm;
+  double (*red)[kCsmBlock];  // [kAcc][kCsmBlock]
+  double* tot;               // [kAcc]
+  int evaluations = 0;
+  __device__ int operator()(const double x[7], Normal* out) {
+    CsmPose pose;
+    for (int i = 0; i < 3; ++i) pose.t[i] = x[i];
+    for (int i = 0; i < 4; ++i) pose.q[i] = x[3 + i];
+    pose.nloc = NLOC;
+    plus_jacobian(x + 3, NLOC, pose.plus);
+    double acc[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) acc[k] = 0.;
+    auto add = [&acc](double r, const double* j) {
+      int idx = 0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int q = p; q < 6; ++q) acc[idx++] += j[p] * j[q];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) acc[21 + p] += j[p] * r;
+      acc[27] += r * r;
+    };
+    const int n0 = a->cloud[0].n, n1 = a->cloud[1].n;
+    if (a->num_clouds == 2 && n0 > 0 && n1 > 0 && n0 <= kCsmBlock && n1 <= kCsmBlock) {
+      // The reference's own case (two adaptively filtered clouds of ~150 and ~200 points): one point of each cloud per
+      // thread.  Both are evaluated in ONE basic block (index clamped, sums predicated) so that the two chains of
+      // dependent loads (point -> leaf table -> leaf) overlap; same additions in the same order as the loop below.
+      const int t = threadIdx.x;
+      double r0, j0[6], r1, j1[6];
+      csm_point(pose, a->cloud[0], t < n0 ? t : n0 - 1, prm->k_scale, prm->k_offset, prm->k_unknown, &r0, j0);
+      csm_point(pose, a->cloud[1], t < n1 ? t : n1 - 1, prm->k_scale, prm->k_offset, prm->k_unknown, &r1, j1);
+      if (t < n0) add(r0, j0);
+      if (t < n1) add(r1, j1);
+    } else {
+      for (int ci = 0; ci < a->num_clouds; ++ci) {
+        const CsmCloudArg& c = a->cloud[ci];
+        for (int i = threadIdx.x; i < c.n; i += kCsmBlock) {
+          double r, j[6];
+          csm_point(pose, c, i, prm->k_scale, prm->k_offset, prm->k_unknown, &r, j);
+          add(r, j);
+        }
+      }
+    }
+    __syncthreads();  // the previous evaluation's totals have been read by everyone
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    // wave w folds sums w, w+4, ..., w+24 -- the seven butterflies are independent, so they are unrolled side by side
+    // (one after the other they cost seven times the cross-lane latency); same order of additions as csm_eval_kernel
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double v[kAcc / 4];
+#pragma unroll
+    for (int m = 0; m < kAcc / 4; ++m) {
+      const int k = wave + 4 * m;
+      v[m] = (red[k][lane] + red[k][lane + 64]) + (red[k][lane + 128] + red[k][lane + 192]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int m = 0; m < kAcc / 4; ++m) v[m] += __shfl_xor(v[m], off, 64);
+    if (lane == 0)
+#pragma unroll
+      for (int m = 0; m < kAcc / 4; ++m) tot[wave + 4 * m] = v[m];
+    __syncthreads();
+    double sums[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) sums[k] = tot[k];
+    finish_normal<NLOC>(sums, x, pose.plus, prm->translation_weight, prm->rotation_weight, prm->target_t, prm->init_q, out);
+    ++evaluations;
+    return DLIOM_OK;
+  }
+};
+
+template <int NLOC>
+__global__ __launch_bounds__(kCsmBlock) void csm_lm_kernel(CsmArgs a, LmKernelParams prm, LmKernelOut* out) {
+  __shared__ double red[kAcc][kCsmBlock];
+  __shared__ double tot[kAcc];
+  DeviceEval<NLOC> ev;
+  ev.a = &a;
+  ev.prm = &prm;
+  ev.red = red;
+  ev.tot = tot;
+  double x[7];
+  for (int i = 0; i < 7; ++i) x[i] = prm.x0[i];
+  dliom_csm_summary sum;
+  const int status = minimize<NLOC>(ev, prm.cfg, x, &sum);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 7; ++i) out->x[i] = x[i];
+    out->summary = sum;
+    out->status = status;
   }
 }
 
@@ -612,7 +804,38 @@ int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* o, const do
   double x[7];
   std::memcpy(x, init7, sizeof(x));
   dliom_csm_summary local;
-  const int s = minimize(&p, x, summary != nullptr ? summary : &local);
+  dliom_csm_summary* sum = summary != nullptr ? summary : &local;
+  const LmConfig cfg{o->max_num_iterations, o->use_nonmonotonic_steps, p.nloc};
+  // total points up to which the one-launch loop is used (0 = never); read per call so a test can flip it
+  const char* pm_env = std::getenv("DLIOM_CSM_PERSISTENT_MAX");
+  const int persistent_max = pm_env != nullptr ? std::atoi(pm_env) : 4096;
+  if (p.args.total_points <= persistent_max) {
+    LmKernelParams prm;
+    prm.cfg = cfg;
+    prm.translation_weight = o->translation_weight;
+    prm.rotation_weight = o->rotation_weight;
+    for (int i = 0; i < 3; ++i) prm.target_t[i] = p.target_t[i];
+    for (int i = 0; i < 4; ++i) prm.init_q[i] = p.init_q[i];
+    for (int i = 0; i < 7; ++i) prm.x0[i] = x[i];
+    const float kMin = 0.1f, kMax = 1.f - 0.1f;
+    prm.k_scale = (kMax - kMin) / 32766.f;
+    prm.k_offset = kMin - prm.k_scale;
+    prm.k_unknown = kMin;
+    LmKernelOut* host = reinterpret_cast<LmKernelOut*>(static_cast<char*>(ctx->pinned) + 1024);  // device-visible
+    const int span = ctx->begin_span(DLIOM_KERNEL_CSM_EVAL);
+    if (p.nloc == 3)
+      hipLaunchKernelGGL(csm_lm_kernel<3>, dim3(1), dim3(kCsmBlock), 0, ctx->stream, p.args, prm, host);
+    else
+      hipLaunchKernelGGL(csm_lm_kernel<1>, dim3(1), dim3(kCsmBlock), 0, ctx->stream, p.args, prm, host);
+    ctx->end_span(span);
+    DLIOM_HIP_TRY(hipGetLastError());
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::memcpy(out7, host->x, sizeof(x));
+    *sum = host->summary;
+    return host->status;
+  }
+  HostEval ev{&p};
+  const int s = p.nloc == 3 ? minimize<3>(ev, cfg, x, sum) : minimize<1>(ev, cfg, x, sum);
   std::memcpy(out7, x, sizeof(x));
   return s;
 }

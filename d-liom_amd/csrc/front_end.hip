@@ -260,7 +260,10 @@ static int front_end_match_cloud(dliom_front_end* fe, const double pose_predicti
   const PoseD pose_prediction = pose_from(pose_prediction7);
   const PoseD prediction_in_submap = pose_mul(pose_inverse(matching.local_pose), pose_prediction);  // :504-505
   PoseD initial_ceres_pose = prediction_in_submap;
-  DLIOM_TRY(dliom_cloud_adaptive_voxel_filter(fe->ctx, cloud, &o.high_resolution_adaptive_voxel_filter, &hi.c));
+  // both adaptive filters (:507-512 and :523-533) in one joint search: they are functions of `cloud` alone, and
+  // together they cost the launch / readback round trips of one
+  DLIOM_TRY(dliom_cloud_adaptive_voxel_filter_pair(fe->ctx, cloud, &o.high_resolution_adaptive_voxel_filter,
+                                                   &o.low_resolution_adaptive_voxel_filter, &hi.c, &lo.c));
   if (hi.c->n == 0) {
     r->dropped = 1;
     return DLIOM_OK;
@@ -276,7 +279,6 @@ static int front_end_match_cloud(dliom_front_end* fe, const double pose_predicti
     initial_ceres_pose = pose_from(out7);
     pose_to(initial_ceres_pose, init7);
   }
-  DLIOM_TRY(dliom_cloud_adaptive_voxel_filter(fe->ctx, cloud, &o.low_resolution_adaptive_voxel_filter, &lo.c));
   if (lo.c->n == 0) {
     r->dropped = 1;
     return DLIOM_OK;

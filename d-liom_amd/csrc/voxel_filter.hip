@@ -20,6 +20,7 @@
 // per axis (|p / size| < 2^20: +-15 km at the adaptive filter's smallest edge of 1.5 cm);
 // anything else returns DLIOM_ERR_INVALID_ARGUMENT.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -31,24 +32,34 @@ namespace dliom {
 int read_max_norm(dliom_ctx* ctx, const unsigned* d_max_sq, float* max_norm);
 
 constexpr int kVfBlock = 256;
-constexpr int kMaxLengths = 16;
+constexpr int kMaxLengths = 32;   // edge lengths per insert launch (two filters x 16 bisection nodes)
+constexpr int kMaxTreeNodes = 16;  // nodes of one filter's bisection tree
+constexpr int kMaxFilters = 2;     // adaptive filters searched together (high and low resolution)
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr unsigned kNoSlot = 0xFFFFFFFFu;
 
 struct VfLengths {
   float size[kMaxLengths];
+  float max_range[kMaxLengths];  // FilterByMaxRange bound of this length's filter; < 0: no crop
   int count;
 };
 
 // Scratch carved out of ctx->voxel for one insert launch of `num` lengths over `n` points.
 struct VfTables {
-  unsigned long long* keys;  // [num][capacity]
-  unsigned* min_index;       // [num][capacity]
+  char* tables;              // [num] x { keys[capacity] (8 B), min_index[capacity] (4 B) }: one fill clears a launch's
+                             // tables however many lengths it carries
   unsigned* slot;            // [num][n]
-  unsigned* counters;        // [num] distinct voxels, then [num] = in-range points, [num+1] = overflow
+  unsigned* counters;        // [num] distinct voxels, [num] in-range points, one overflow flag; kVfCounterStride apart
   unsigned capacity;         // power of two >= 2 n
   int num;
 };
+
+__host__ __device__ __forceinline__ unsigned long long* table_keys(const VfTables& t, int l) {
+  return reinterpret_cast<unsigned long long*>(t.tables + static_cast<size_t>(l) * t.capacity * 12);
+}
+__host__ __device__ __forceinline__ unsigned* table_min_index(const VfTables& t, int l) {
+  return reinterpret_cast<unsigned*>(t.tables + static_cast<size_t>(l) * t.capacity * 12 + static_cast<size_t>(t.capacity) * 8);
+}
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
   k ^= k >> 33;
@@ -59,20 +70,36 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
   return k;
 }
 
-__global__ __launch_bounds__(kVfBlock) void voxel_insert_kernel(const float* __restrict__ x,
-                                                                const float* __restrict__ y,
-                                                                const float* __restrict__ z, unsigned n,
-                                                                int crop, float max_range, VfLengths lengths,
-                                                                VfTables t) {
-  const unsigned i = blockIdx.x * kVfBlock + threadIdx.x;
+// One workgroup = 1024 consecutive points of one edge length.  The whole cloud is resident at once, so with 2 m
+// voxels tens of thousands of threads would hit the same few hundred table slots in the same microsecond (and
+// device-scope atomics are resolved at the memory side, one at a time per address).  The points of a workgroup are
+// therefore folded in an LDS table first -- voxel key -> smallest index -- and only the owner of each LDS entry
+// goes to the global table: one compare-and-swap + one atomicMin per distinct voxel of the workgroup.
+constexpr int kVfInsertBlock = 1024;
+constexpr int kVfCounterStride = 32;  // words between two counters
+constexpr unsigned kVfLocalSlots = 2048;  // >= 2 x points: the LDS table is at most half full
+
+__global__ __launch_bounds__(kVfInsertBlock) void voxel_insert_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ y,
+                                                                      const float* __restrict__ z, unsigned n,
+                                                                      VfLengths lengths, VfTables t) {
+  __shared__ unsigned long long s_key[kVfLocalSlots];
+  __shared__ unsigned s_min[kVfLocalSlots];   // smallest point index of the entry
+  __shared__ unsigned s_slot[kVfLocalSlots];  // the entry's slot in the global table
+  for (unsigned k = threadIdx.x; k < kVfLocalSlots; k += kVfInsertBlock) {
+    s_key[k] = kEmptyKey;
+    s_min[k] = 0xFFFFFFFFu;
+  }
+  const unsigned i = blockIdx.x * kVfInsertBlock + threadIdx.x;
   const int l = blockIdx.y;
   const float size = lengths.size[l];
-  bool claimed = false, in_range = false, overflow = false;
+  const float max_range = lengths.max_range[l];
+  bool claimed = false, in_range = false, overflow = false, has_key = false;
+  unsigned long long key = 0;
   if (i < n) {
     const float px = x[i], py = y[i], pz = z[i];
     // FilterByMaxRange: point.norm() <= max_range, Eigen's Vector3f reduction order
-    in_range = !crop || sqrtf(px * px + (py * py + pz * pz)) <= max_range;
-    unsigned my_slot = kNoSlot;
+    in_range = max_range < 0.f || sqrtf(px * px + (py * py + pz * pz)) <= max_range;
     if (in_range) {
       const float qx = px / size, qy = py / size, qz = pz / size;
       const float lim = 1048575.f;  // 2^20 - 1: the rounded index stays inside 21 bits
@@ -82,39 +109,56 @@ __global__ __launch_bounds__(kVfBlock) void voxel_insert_kernel(const float* __r
         const unsigned long long kx = static_cast<unsigned long long>(lround_away(qx) + (1 << 20));
         const unsigned long long ky = static_cast<unsigned long long>(lround_away(qy) + (1 << 20));
         const unsigned long long kz = static_cast<unsigned long long>(lround_away(qz) + (1 << 20));
-        const unsigned long long key = (kx << 42) | (ky << 21) | kz;
-        unsigned long long* keys = t.keys + static_cast<size_t>(l) * t.capacity;
-        unsigned* min_index = t.min_index + static_cast<size_t>(l) * t.capacity;
-        const unsigned mask = t.capacity - 1;
-        unsigned h = static_cast<unsigned>(mix64(key)) & mask;
-        for (;;) {
-          // look before locking: with large voxels thousands of points share a slot, and all but
-          // the first few find their key in place and a smaller index already recorded
-          unsigned long long prev = __builtin_nontemporal_load(&keys[h]);
-          if (prev == kEmptyKey) prev = atomicCAS(&keys[h], kEmptyKey, key);
-          if (prev == kEmptyKey || prev == key) {
-            claimed = prev == kEmptyKey;
-            if (__builtin_nontemporal_load(&min_index[h]) > i) atomicMin(&min_index[h], i);
-            my_slot = h;
-            break;
-          }
-          h = (h + 1) & mask;  // load factor <= 1/2: terminates
-        }
+        key = (kx << 42) | (ky << 21) | kz;
+        has_key = true;
       }
     }
-    t.slot[static_cast<size_t>(l) * n + i] = my_slot;
   }
-  // one atomic per wavefront and counter
-  const unsigned long long mc = __ballot(claimed);
-  const unsigned lane = threadIdx.x & 63u;
-  if (mc != 0 && lane == static_cast<unsigned>(__ffsll(static_cast<long long>(mc)) - 1))
-    atomicAdd(&t.counters[l], static_cast<unsigned>(__popcll(mc)));
-  if (l == 0) {
-    const unsigned long long mr = __ballot(in_range);
-    if (mr != 0 && lane == static_cast<unsigned>(__ffsll(static_cast<long long>(mr)) - 1))
-      atomicAdd(&t.counters[t.num], static_cast<unsigned>(__popcll(mr)));
+  const unsigned long long hash = mix64(key);
+  __syncthreads();
+  unsigned local = 0;
+  if (has_key) {
+    local = static_cast<unsigned>(hash >> 32) & (kVfLocalSlots - 1);
+    for (;;) {
+      const unsigned long long prev = atomicCAS(&s_key[local], kEmptyKey, key);
+      if (prev == kEmptyKey || prev == key) break;
+      local = (local + 1) & (kVfLocalSlots - 1);
+    }
+    atomicMin(&s_min[local], i);
   }
-  if (overflow) t.counters[t.num + 1] = 1u;
+  __syncthreads();
+  if (has_key && s_min[local] == i) {  // this entry's first point: the only one the global table hears of
+    unsigned long long* keys = table_keys(t, l);
+    unsigned* min_index = table_min_index(t, l);
+    const unsigned mask = t.capacity - 1;
+    unsigned h = static_cast<unsigned>(hash) & mask;
+    for (;;) {
+      // A cached look first: a stale answer can only be "still empty" (slots go from empty to one key, once) or
+      // a min index that is too large, and both just send this thread on to the atomic.
+      unsigned long long prev = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (prev == kEmptyKey) prev = atomicCAS(&keys[h], kEmptyKey, key);
+      if (prev == kEmptyKey || prev == key) {
+        claimed = prev == kEmptyKey;
+        if (__hip_atomic_load(&min_index[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > i) atomicMin(&min_index[h], i);
+        s_slot[local] = h;
+        break;
+      }
+      h = (h + 1) & mask;  // load factor <= 1/2: terminates
+    }
+  }
+  __syncthreads();
+  if (i < n) t.slot[static_cast<size_t>(l) * n + i] = has_key ? s_slot[local] : kNoSlot;
+  // One atomic per workgroup and counter, every counter on its own 128-byte line: these adds are resolved one at a
+  // time per line, and with one add per wavefront on a shared line they WERE the kernel (49 us of 55 for six lengths).
+  const int num_claimed = __syncthreads_count(claimed ? 1 : 0);
+  const int num_in_range = __syncthreads_count(in_range ? 1 : 0);
+  const int any_overflow = __syncthreads_or(overflow ? 1 : 0);
+  if (threadIdx.x == 0) {
+    if (num_claimed != 0) atomicAdd(&t.counters[kVfCounterStride * l], static_cast<unsigned>(num_claimed));
+    if (max_range >= 0.f && num_in_range != 0)  // uncropped launches know the count: n
+      atomicAdd(&t.counters[kVfCounterStride * (t.num + l)], static_cast<unsigned>(num_in_range));
+    if (any_overflow) t.counters[kVfCounterStride * 2 * t.num] = 1u;
+  }
 }
 
 // mode 0: survivors of the voxel filter of table `l`; mode 1: every in-range point (the adaptive
@@ -126,7 +170,7 @@ __global__ __launch_bounds__(kVfBlock) void voxel_flag_kernel(unsigned n, VfTabl
   bool keep = false;
   if (i < n) {
     const unsigned s = t.slot[static_cast<size_t>(l) * n + i];
-    keep = s != kNoSlot && (mode == 1 || t.min_index[static_cast<size_t>(l) * t.capacity + s] == i);
+    keep = s != kNoSlot && (mode == 1 || table_min_index(t, l)[s] == i);
     flags[i] = keep ? 1 : 0;
   }
   const int c = __syncthreads_count(keep ? 1 : 0);
@@ -183,32 +227,32 @@ struct VfScratch {
   VfTables tables[3];      // insert launches that can be alive together: first halvings, remaining halvings, bisection tree
   unsigned char* flags;
   unsigned* block_counts;
-  unsigned* max_sq;
+  unsigned* max_sq;        // kMaxFilters words
+  int max_lengths;
 };
 
 static size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
-static int carve_scratch(dliom_ctx* ctx, int64_t n, VfScratch* s) {
+// `lengths`: the most edge lengths one insert launch of this call will carry.
+static int carve_scratch(dliom_ctx* ctx, int64_t n, int lengths, VfScratch* s) {
   const unsigned cap = table_capacity(n);
-  const size_t per_launch = align256(static_cast<size_t>(kMaxLengths) * cap * 8) +
-                            align256(static_cast<size_t>(kMaxLengths) * cap * 4) +
-                            align256(static_cast<size_t>(kMaxLengths) * n * 4) + align256((kMaxLengths + 2) * 4);
+  const size_t L = static_cast<size_t>(lengths);
+  const size_t per_launch = align256(L * cap * 12) + align256(L * n * 4) + align256((2 * kMaxLengths + 1) * kVfCounterStride * 4);
   const unsigned blocks = static_cast<unsigned>((n + kVfBlock - 1) / kVfBlock);
   const size_t total = 3 * per_launch + align256(static_cast<size_t>(n)) + align256(static_cast<size_t>(blocks) * 4) + 256;
+  s->max_lengths = lengths;
   DLIOM_TRY(ctx->voxel.reserve(total));
   char* p = static_cast<char*>(ctx->voxel.p);
   for (int k = 0; k < 3; ++k) {
     VfTables& t = s->tables[k];
     t.capacity = cap;
     t.num = 0;
-    t.keys = reinterpret_cast<unsigned long long*>(p);
-    p += align256(static_cast<size_t>(kMaxLengths) * cap * 8);
-    t.min_index = reinterpret_cast<unsigned*>(p);
-    p += align256(static_cast<size_t>(kMaxLengths) * cap * 4);
+    t.tables = p;
+    p += align256(L * cap * 12);
     t.slot = reinterpret_cast<unsigned*>(p);
-    p += align256(static_cast<size_t>(kMaxLengths) * n * 4);
+    p += align256(L * n * 4);
     t.counters = reinterpret_cast<unsigned*>(p);
-    p += align256((kMaxLengths + 2) * 4);
+    p += align256((2 * kMaxLengths + 1) * kVfCounterStride * 4);
   }
   s->flags = reinterpret_cast<unsigned char*>(p);
   p += align256(static_cast<size_t>(n));
@@ -218,32 +262,40 @@ static int carve_scratch(dliom_ctx* ctx, int64_t n, VfScratch* s) {
   return DLIOM_OK;
 }
 
-// Insert launch for `sizes`; counts[k] = survivors of VoxelFilter(sizes[k]); *in_range = points
-// passing the crop.  Synchronises the stream (8..100-byte readback through pinned memory).
-static int run_insert(dliom_ctx* ctx, const Soa& in, bool crop, float max_range,
-                      const std::vector<float>& sizes, VfTables* t, std::vector<unsigned>* counts,
-                      unsigned* in_range) {
+// Insert launch for `sizes`; counts[k] = survivors of VoxelFilter(sizes[k]) over the points within ranges[k]
+// (< 0: every point), in_range[k] = how many those are.  Synchronises the stream (one readback of <= 260 bytes
+// through pinned memory).
+static int run_insert(dliom_ctx* ctx, const Soa& in, const std::vector<float>& sizes, const std::vector<float>& ranges,
+                      VfTables* t, std::vector<unsigned>* counts, std::vector<unsigned>* in_range) {
   const int num = static_cast<int>(sizes.size());
-  if (num <= 0 || num > kMaxLengths) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (num <= 0 || num > kMaxLengths || ranges.size() != sizes.size()) return DLIOM_ERR_INVALID_ARGUMENT;
   t->num = num;
   VfLengths lengths;
   lengths.count = num;
-  for (int k = 0; k < num; ++k) lengths.size[k] = sizes[k];
+  for (int k = 0; k < num; ++k) {
+    lengths.size[k] = sizes[k];
+    lengths.max_range[k] = ranges[k];
+  }
   // 0xFF bytes = empty keys, "infinite" min indices; counters start at zero
-  DLIOM_HIP_TRY(hipMemsetAsync(t->keys, 0xFF, static_cast<size_t>(num) * t->capacity * 8, ctx->stream));
-  DLIOM_HIP_TRY(hipMemsetAsync(t->min_index, 0xFF, static_cast<size_t>(num) * t->capacity * 4, ctx->stream));
-  DLIOM_HIP_TRY(hipMemsetAsync(t->counters, 0, (num + 2) * 4, ctx->stream));
+  DLIOM_HIP_TRY(hipMemsetAsync(t->tables, 0xFF, static_cast<size_t>(num) * t->capacity * 12, ctx->stream));
+  const size_t counter_bytes = static_cast<size_t>(2 * num + 1) * kVfCounterStride * 4;
+  DLIOM_HIP_TRY(hipMemsetAsync(t->counters, 0, counter_bytes, ctx->stream));
   const unsigned n = static_cast<unsigned>(in.n);
-  const dim3 grid((n + kVfBlock - 1) / kVfBlock, num);
-  hipLaunchKernelGGL(voxel_insert_kernel, grid, dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z, n,
-                     crop ? 1 : 0, max_range, lengths, *t);
+  const dim3 grid((n + kVfInsertBlock - 1) / kVfInsertBlock, num);
+  hipLaunchKernelGGL(voxel_insert_kernel, grid, dim3(kVfInsertBlock), 0, ctx->stream, in.x, in.y, in.z, n, lengths, *t);
   DLIOM_HIP_TRY(hipGetLastError());
   unsigned* host = static_cast<unsigned*>(ctx->pinned);
-  DLIOM_HIP_TRY(hipMemcpyAsync(host, t->counters, (num + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(host, t->counters, counter_bytes, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (host[num + 1] != 0) return DLIOM_ERR_INVALID_ARGUMENT;  // voxel index outside 21 bits
-  counts->assign(host, host + num);
-  *in_range = host[num];
+  if (host[kVfCounterStride * 2 * num] != 0) return DLIOM_ERR_INVALID_ARGUMENT;  // voxel index outside 21 bits
+  counts->resize(num);
+  in_range->resize(num);
+  for (int k = 0; k < num; ++k) {
+    (*counts)[k] = host[kVfCounterStride * k];
+    (*in_range)[k] = host[kVfCounterStride * (num + k)];
+  }
+  for (int k = 0; k < num; ++k)
+    if (ranges[k] < 0.f) (*in_range)[k] = n;
   return DLIOM_OK;
 }
 
@@ -304,10 +356,9 @@ int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, fl
   if (!(size > 0.f)) return DLIOM_ERR_INVALID_ARGUMENT;
   if (in.n == 0) return DLIOM_OK;
   VfScratch s;
-  DLIOM_TRY(carve_scratch(ctx, in.n, &s));
-  std::vector<unsigned> counts;
-  unsigned in_range = 0;
-  DLIOM_TRY(run_insert(ctx, in, false, 0.f, {size}, &s.tables[0], &counts, &in_range));
+  DLIOM_TRY(carve_scratch(ctx, in.n, 1, &s));
+  std::vector<unsigned> counts, in_range;
+  DLIOM_TRY(run_insert(ctx, in, {size}, {-1.f}, &s.tables[0], &counts, &in_range));
   *n_out = counts[0];
   return emit_arrays(ctx, in, s, s.tables[0], 0, 0, ox, oy, oz, ow, nullptr);
 }
@@ -317,7 +368,7 @@ int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kin
   *n_out = 0;
   if (in.n == 0) return DLIOM_OK;
   VfScratch s;
-  DLIOM_TRY(carve_scratch(ctx, in.n, &s));
+  DLIOM_TRY(carve_scratch(ctx, in.n, 1, &s));
   const unsigned n = static_cast<unsigned>(in.n);
   const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
   DLIOM_HIP_TRY(hipMemsetAsync(s.max_sq, 0, 4, ctx->stream));
@@ -353,110 +404,227 @@ int voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, float size, dliom_
     return finish_device_cloud(ctx, *out, 0.f);
   }
   VfScratch s;
-  DLIOM_TRY(carve_scratch(ctx, in.n, &s));
-  std::vector<unsigned> counts;
-  unsigned in_range = 0;
+  DLIOM_TRY(carve_scratch(ctx, in.n, 1, &s));
+  std::vector<unsigned> counts, in_range;
   const Soa soa{in.d_x, in.d_y, in.d_z, nullptr, in.n};
-  DLIOM_TRY(run_insert(ctx, soa, false, 0.f, {size}, &s.tables[0], &counts, &in_range));
+  DLIOM_TRY(run_insert(ctx, soa, {size}, {-1.f}, &s.tables[0], &counts, &in_range));
   return emit_cloud(ctx, soa, s, s.tables[0], 0, 0, counts[0], out);
 }
 
-int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dliom_adaptive_voxel_filter_options& o,
-                                dliom_cloud** out) {
-  *out = nullptr;
-  if (!(o.max_length > 0.f)) return DLIOM_ERR_INVALID_ARGUMENT;
+// AdaptiveVoxelFilter::Filter for `num_filters` option sets over the same cloud (the front end's high and low
+// resolution filters, local_trajectory_builder_3d.cc:507-533), searched TOGETHER: every insert launch carries the
+// pending edge lengths of all filters, so two filters cost the three launch + readback round trips of one.
+//   round 1   max_length and its first two halvings, per filter            (voxel_filter.cc:46-58)
+//   round 1b  the remaining halvings of the filters none of those decided  (rare)
+//   round 2   every mid_length each filter's bisection (:63-73) can reach  (<= 16 tree nodes per filter)
+//   emit      flag + compact per filter, one readback of the survivors' largest norms
+int adaptive_voxel_filter_clouds(dliom_ctx* ctx, const dliom_cloud& in, const dliom_adaptive_voxel_filter_options* const* opts,
+                                 int num_filters, dliom_cloud** outs) {
+  if (num_filters <= 0 || num_filters > kMaxFilters) return DLIOM_ERR_INVALID_ARGUMENT;
+  for (int f = 0; f < num_filters; ++f) {
+    outs[f] = nullptr;
+    if (!(opts[f]->max_length > 0.f)) return DLIOM_ERR_INVALID_ARGUMENT;
+  }
+  auto fail = [&](int st) {
+    for (int f = 0; f < num_filters; ++f) {
+      if (outs[f] != nullptr) dliom_cloud_destroy(outs[f]);
+      outs[f] = nullptr;
+    }
+    return st;
+  };
   if (in.n == 0) {
-    float *x, *y, *z;
-    DLIOM_TRY(alloc_device_cloud(ctx, 0, out, &x, &y, &z));
-    return finish_device_cloud(ctx, *out, 0.f);
+    for (int f = 0; f < num_filters; ++f) {
+      float *x, *y, *z;
+      int st = alloc_device_cloud(ctx, 0, &outs[f], &x, &y, &z);
+      if (st == DLIOM_OK) st = finish_device_cloud(ctx, outs[f], 0.f);
+      if (st != DLIOM_OK) return fail(st);
+    }
+    return DLIOM_OK;
   }
   VfScratch s;
-  DLIOM_TRY(carve_scratch(ctx, in.n, &s));
+  DLIOM_TRY(carve_scratch(ctx, in.n, kMaxTreeNodes * num_filters, &s));
   const Soa soa{in.d_x, in.d_y, in.d_z, nullptr, in.n};
-  // launch 1: max_length and every low_length of the halving loop (voxel_filter.cc:55-58)
-  std::vector<float> sizes{o.max_length};
-  std::vector<float> highs;
-  for (float high = o.max_length; high > 1e-2f * o.max_length; high /= 2.f) {
-    highs.push_back(high);
-    sizes.push_back(high / 2.f);
-  }
-  // The halving search almost always ends within its first two steps, and the small edge lengths
-  // are the expensive ones (most distinct voxels): count max_length and the first two halvings
-  // first, the rest only if none of them is dense enough.
-  const size_t first_batch = std::min<size_t>(3, sizes.size());
-  std::vector<unsigned> counts;
-  unsigned in_range = 0;
-  DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, std::vector<float>(sizes.begin(), sizes.begin() + first_batch),
-                       &s.tables[0], &counts, &in_range));
-  const float min_points = o.min_num_points;
-  if (static_cast<float>(in_range) <= min_points)  // "already sparse enough" (:42-45)
-    return emit_cloud(ctx, soa, s, s.tables[0], 0, 1, in_range, out);
-  if (static_cast<float>(counts[0]) >= min_points)  // max_length is dense enough (:46-50)
-    return emit_cloud(ctx, soa, s, s.tables[0], 0, 0, counts[0], out);
-  bool decided = false;
-  for (size_t k = 1; k < first_batch; ++k) decided = decided || static_cast<float>(counts[k]) >= min_points;
-  if (!decided && sizes.size() > first_batch) {
-    std::vector<unsigned> more;
-    unsigned dummy = 0;
-    DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, std::vector<float>(sizes.begin() + first_batch, sizes.end()),
-                         &s.tables[2], &more, &dummy));
-    counts.insert(counts.end(), more.begin(), more.end());
-  }
-  // table / slot of sizes[i]
-  auto table_of = [&](size_t i) -> const VfTables& { return i < first_batch ? s.tables[0] : s.tables[2]; };
-  auto slot_of = [&](size_t i) { return static_cast<int>(i < first_batch ? i : i - first_batch); };
-  for (size_t k = 0; k < highs.size() && k + 1 < counts.size(); ++k) {
-    if (!(static_cast<float>(counts[k + 1]) >= min_points)) continue;
-    // launch 2: every mid_length the bisection (:63-73) can reach from (low, high)
-    struct Node {
-      float low, high, mid;
-      int ok_child, fail_child;  // -1: the loop ends
-    };
+
+  struct Node {
+    float low, high, mid;
+    int ok_child, fail_child;  // -1: the loop ends
+  };
+  struct Search {
+    std::vector<float> sizes, highs;  // max_length, then every low_length of the halving loop (:55-58)
+    size_t first_batch = 0;
+    std::vector<unsigned> counts;     // survivors per entry of sizes (as far as counted)
+    std::vector<int> table, slot;     // where entry i of sizes was counted
+    unsigned in_range = 0;
+    bool chosen = false;
+    const VfTables* chosen_table = nullptr;
+    int chosen_l = 0, chosen_mode = 0;
+    unsigned chosen_count = 0;
     std::vector<Node> nodes;
+    int tree_base = 0;  // first slot of this filter's nodes in the round-2 launch
+  } search[kMaxFilters];
+
+  // round 1.  The halving search almost always ends within its first two steps, and the small edge lengths are the
+  // expensive ones (most distinct voxels): count max_length and two halvings first, the rest only if needed.
+  std::vector<float> sizes, ranges;
+  for (int f = 0; f < num_filters; ++f) {
+    Search& q = search[f];
+    const dliom_adaptive_voxel_filter_options& o = *opts[f];
+    q.sizes.push_back(o.max_length);
+    for (float high = o.max_length; high > 1e-2f * o.max_length; high /= 2.f) {
+      q.highs.push_back(high);
+      q.sizes.push_back(high / 2.f);
+    }
+    q.first_batch = std::min<size_t>(3, q.sizes.size());
+    for (size_t i = 0; i < q.first_batch; ++i) {
+      q.table.push_back(0);
+      q.slot.push_back(static_cast<int>(sizes.size()));
+      sizes.push_back(q.sizes[i]);
+      ranges.push_back(o.max_range);
+    }
+  }
+  std::vector<unsigned> counts, in_range;
+  DLIOM_TRY(run_insert(ctx, soa, sizes, ranges, &s.tables[0], &counts, &in_range));
+  sizes.clear();
+  ranges.clear();
+  for (int f = 0; f < num_filters; ++f) {
+    Search& q = search[f];
+    const float min_points = opts[f]->min_num_points;
+    q.in_range = in_range[q.slot[0]];
+    for (size_t i = 0; i < q.first_batch; ++i) q.counts.push_back(counts[q.slot[i]]);
+    if (static_cast<float>(q.in_range) <= min_points) {  // "already sparse enough" (:42-45)
+      q.chosen = true;
+      q.chosen_table = &s.tables[0];
+      q.chosen_l = q.slot[0];
+      q.chosen_mode = 1;
+      q.chosen_count = q.in_range;
+      continue;
+    }
+    if (static_cast<float>(q.counts[0]) >= min_points) {  // max_length is dense enough (:46-50)
+      q.chosen = true;
+      q.chosen_table = &s.tables[0];
+      q.chosen_l = q.slot[0];
+      q.chosen_count = q.counts[0];
+      continue;
+    }
+    bool decided = false;
+    for (size_t k = 1; k < q.first_batch; ++k) decided = decided || static_cast<float>(q.counts[k]) >= min_points;
+    if (!decided) {
+      for (size_t i = q.first_batch; i < q.sizes.size(); ++i) {
+        q.table.push_back(2);
+        q.slot.push_back(static_cast<int>(sizes.size()));
+        sizes.push_back(q.sizes[i]);
+        ranges.push_back(opts[f]->max_range);
+      }
+    }
+  }
+  if (!sizes.empty()) {  // round 1b
+    if (static_cast<int>(sizes.size()) > s.max_lengths) return DLIOM_ERR_CAPACITY;
+    DLIOM_TRY(run_insert(ctx, soa, sizes, ranges, &s.tables[2], &counts, &in_range));
+    for (int f = 0; f < num_filters; ++f) {
+      Search& q = search[f];
+      for (size_t i = q.counts.size(); i < q.slot.size(); ++i) q.counts.push_back(counts[q.slot[i]]);
+    }
+    sizes.clear();
+    ranges.clear();
+  }
+  // round 2: the bisection tree of every filter whose halving loop found a dense-enough low_length
+  for (int f = 0; f < num_filters; ++f) {
+    Search& q = search[f];
+    if (q.chosen) continue;
+    const float min_points = opts[f]->min_num_points;
+    const VfTables* tables[3] = {&s.tables[0], &s.tables[1], &s.tables[2]};
+    size_t k = 0;
+    for (; k < q.highs.size() && k + 1 < q.counts.size(); ++k)
+      if (static_cast<float>(q.counts[k + 1]) >= min_points) break;
+    if (!(k < q.highs.size() && k + 1 < q.counts.size())) {
+      // no edge length was dense enough: the last low_length's result stands (:56-57,76)
+      const size_t last = q.counts.size() - 1;
+      q.chosen = true;
+      q.chosen_table = tables[q.table[last]];
+      q.chosen_l = q.slot[last];
+      q.chosen_count = q.counts[last];
+      continue;
+    }
+    q.chosen_table = tables[q.table[k + 1]];
+    q.chosen_l = q.slot[k + 1];
+    q.chosen_count = q.counts[k + 1];
     // breadth-first expansion of the (low, high) states; a child is linked when it is popped
-    std::vector<std::pair<float, float>> todo{{highs[k] / 2.f, highs[k]}};
-    size_t head = 0;
+    std::vector<std::pair<float, float>> todo{{q.highs[k] / 2.f, q.highs[k]}};
     std::vector<std::pair<int, int>> origin{{-1, 0}};  // (parent node, 0 = ok branch / 1 = fail branch)
+    size_t head = 0;
     while (head < todo.size()) {
       const float low = todo[head].first, high = todo[head].second;
       const std::pair<int, int> from = origin[head];
       ++head;
       if (!((high - low) / low > 1e-1f)) continue;
-      if (static_cast<int>(nodes.size()) == kMaxLengths) return DLIOM_ERR_CAPACITY;
+      if (static_cast<int>(q.nodes.size()) == kMaxTreeNodes) return DLIOM_ERR_CAPACITY;
       Node nd{low, high, (low + high) / 2.f, -1, -1};
-      const int id = static_cast<int>(nodes.size());
-      nodes.push_back(nd);
-      if (from.first >= 0) (from.second == 0 ? nodes[from.first].ok_child : nodes[from.first].fail_child) = id;
+      const int id = static_cast<int>(q.nodes.size());
+      q.nodes.push_back(nd);
+      if (from.first >= 0) (from.second == 0 ? q.nodes[from.first].ok_child : q.nodes[from.first].fail_child) = id;
       todo.push_back({nd.mid, high});  // candidate dense enough: low = mid
       origin.push_back({id, 0});
       todo.push_back({low, nd.mid});   // else: high = mid
       origin.push_back({id, 1});
     }
-    const VfTables* chosen_table = &table_of(k + 1);
-    int chosen_l = slot_of(k + 1);
-    unsigned chosen_count = counts[k + 1];
-    if (!nodes.empty()) {
-      std::vector<float> mids;
-      for (const Node& nd : nodes) mids.push_back(nd.mid);
-      std::vector<unsigned> mid_counts;
-      unsigned dummy = 0;
-      DLIOM_TRY(run_insert(ctx, soa, true, o.max_range, mids, &s.tables[1], &mid_counts, &dummy));
+    q.tree_base = static_cast<int>(sizes.size());
+    for (const Node& nd : q.nodes) {
+      sizes.push_back(nd.mid);
+      ranges.push_back(opts[f]->max_range);
+    }
+  }
+  if (!sizes.empty()) {
+    DLIOM_TRY(run_insert(ctx, soa, sizes, ranges, &s.tables[1], &counts, &in_range));
+    for (int f = 0; f < num_filters; ++f) {
+      Search& q = search[f];
+      if (q.chosen || q.nodes.empty()) continue;
+      const float min_points = opts[f]->min_num_points;
       for (int id = 0; id >= 0;) {
-        if (static_cast<float>(mid_counts[id]) >= min_points) {
-          chosen_table = &s.tables[1];
-          chosen_l = id;
-          chosen_count = mid_counts[id];
-          id = nodes[id].ok_child;
+        if (static_cast<float>(counts[q.tree_base + id]) >= min_points) {
+          q.chosen_table = &s.tables[1];
+          q.chosen_l = q.tree_base + id;
+          q.chosen_count = counts[q.tree_base + id];
+          id = q.nodes[id].ok_child;
         } else {
-          id = nodes[id].fail_child;
+          id = q.nodes[id].fail_child;
         }
       }
     }
-    return emit_cloud(ctx, soa, s, *chosen_table, chosen_l, 0, chosen_count, out);
   }
-  // no edge length was dense enough: the last low_length's result stands (:56-57,76)
-  const size_t last = sizes.size() - 1;
-  return emit_cloud(ctx, soa, s, table_of(last), slot_of(last), 0, counts[last], out);
+  // emit: both compactions are queued, then ONE readback of the largest squared norms
+  bool any = false;
+  for (int f = 0; f < num_filters; ++f) {
+    Search& q = search[f];
+    float *ox, *oy, *oz;
+    int st = alloc_device_cloud(ctx, q.chosen_count, &outs[f], &ox, &oy, &oz);
+    if (st == DLIOM_OK && q.chosen_count > 0) {
+      st = emit_arrays(ctx, soa, s, *q.chosen_table, q.chosen_l, q.chosen_mode, ox, oy, oz, nullptr, s.max_sq + f);
+      any = true;
+    }
+    if (st != DLIOM_OK) return fail(st);
+  }
+  float max_sq[kMaxFilters] = {0.f, 0.f};
+  if (any) {
+    unsigned* host = static_cast<unsigned*>(ctx->pinned);
+    int st = DLIOM_OK;
+    if (hipMemcpyAsync(host, s.max_sq, 4 * num_filters, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+      st = DLIOM_ERR_HIP;
+    if (st != DLIOM_OK) return fail(st);
+    std::memcpy(max_sq, host, 4 * num_filters);
+  }
+  for (int f = 0; f < num_filters; ++f) {
+    // sqrt is monotone and correctly rounded: == max of the norms
+    const int st = finish_device_cloud(ctx, outs[f], search[f].chosen_count > 0 ? std::sqrt(max_sq[f]) : 0.f);
+    if (st != DLIOM_OK) return fail(st);
+  }
+  return DLIOM_OK;
+}
+
+int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dliom_adaptive_voxel_filter_options& o,
+                                dliom_cloud** out) {
+  const dliom_adaptive_voxel_filter_options* opts[1] = {&o};
+  return adaptive_voxel_filter_clouds(ctx, in, opts, 1, out);
 }
 
 }  // namespace dliom
@@ -476,6 +644,22 @@ int dliom_cloud_adaptive_voxel_filter(dliom_ctx* ctx, const dliom_cloud* in,
   if (ctx == nullptr || in == nullptr || options == nullptr || out == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   return adaptive_voxel_filter_cloud(ctx, *in, *options, out);
+}
+
+int dliom_cloud_adaptive_voxel_filter_pair(dliom_ctx* ctx, const dliom_cloud* in,
+                                           const dliom_adaptive_voxel_filter_options* first,
+                                           const dliom_adaptive_voxel_filter_options* second, dliom_cloud** out_first,
+                                           dliom_cloud** out_second) {
+  if (ctx == nullptr || in == nullptr || first == nullptr || second == nullptr || out_first == nullptr ||
+      out_second == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const dliom_adaptive_voxel_filter_options* opts[2] = {first, second};
+  dliom_cloud* outs[2] = {nullptr, nullptr};
+  const int st = adaptive_voxel_filter_clouds(ctx, *in, opts, 2, outs);
+  *out_first = outs[0];
+  *out_second = outs[1];
+  return st;
 }
 
 int dliom_cloud_download(const dliom_cloud* cloud, float* points_xyz) {

@@ -193,6 +193,8 @@ SYMBOLS = [
     ("dliom_cloud_size", C.c_int, [_vp, _i64p]),
     ("dliom_cloud_voxel_filter", C.c_int, [_vp, _vp, C.c_float, C.POINTER(_vp)]),
     ("dliom_cloud_adaptive_voxel_filter", C.c_int, [_vp, _vp, C.POINTER(AdaptiveVoxelFilterOptions), C.POINTER(_vp)]),
+    ("dliom_cloud_adaptive_voxel_filter_pair", C.c_int, [_vp, _vp, C.POINTER(AdaptiveVoxelFilterOptions),
+                                                         C.POINTER(AdaptiveVoxelFilterOptions), C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_cloud_download", C.c_int, [_vp, _f32p]),
     ("dliom_rtcsm3d_match", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _f64p, _f32p]),
     ("dliom_rtcsm3d_match_cloud", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, _f64p, _f32p]),
@@ -418,6 +420,15 @@ class PointCloud:
         _check(self._L.dliom_cloud_adaptive_voxel_filter(self.ctx.h, self.h, C.byref(o), C.byref(h)),
                "dliom_cloud_adaptive_voxel_filter")
         return PointCloud(self.ctx, _handle=h)
+
+    def adaptive_voxel_filter_pair(self, first, second):
+        """Two AdaptiveVoxelFilter option triples (max_length, min_num_points, max_range) searched together
+        -> (PointCloud, PointCloud), each equal to adaptive_voxel_filter(*triple)."""
+        a, b = AdaptiveVoxelFilterOptions(*first), AdaptiveVoxelFilterOptions(*second)
+        ha, hb = _vp(), _vp()
+        _check(self._L.dliom_cloud_adaptive_voxel_filter_pair(self.ctx.h, self.h, C.byref(a), C.byref(b), C.byref(ha),
+                                                              C.byref(hb)), "dliom_cloud_adaptive_voxel_filter_pair")
+        return PointCloud(self.ctx, _handle=ha), PointCloud(self.ctx, _handle=hb)
 
     def download(self):
         out = np.zeros((self.n, 3), dtype=np.float32)

@@ -363,6 +363,14 @@ int dliom_front_end_active_submap(const dliom_front_end* fe, int i, double local
 int dliom_cloud_voxel_filter(dliom_ctx* ctx, const dliom_cloud* in, float size, dliom_cloud** out);
 int dliom_cloud_adaptive_voxel_filter(dliom_ctx* ctx, const dliom_cloud* in,
                                       const dliom_adaptive_voxel_filter_options* options, dliom_cloud** out);
+/* The two AdaptiveVoxelFilter::Filter calls of LocalTrajectoryBuilder3D::AddAccumulatedRangeData
+ * (local_trajectory_builder_3d.cc:507-512 high resolution, :523-533 low resolution) on the same cloud, searched
+ * together: each result equals dliom_cloud_adaptive_voxel_filter() with that option set, for the launch and
+ * readback round trips of one call. */
+int dliom_cloud_adaptive_voxel_filter_pair(dliom_ctx* ctx, const dliom_cloud* in,
+                                           const dliom_adaptive_voxel_filter_options* first,
+                                           const dliom_adaptive_voxel_filter_options* second, dliom_cloud** out_first,
+                                           dliom_cloud** out_second);
 /* The points of a cloud in input order, packed xyz (room for dliom_cloud_size points). */
 int dliom_cloud_download(const dliom_cloud* cloud, float* points_xyz);
 /* The same filters on host buffers (the reference's own placement): out_xyz has room for n points;

@@ -344,6 +344,40 @@ def test_csm3d_match_close_to_oracle(dl, ctx, orc, beams, azimuths, yaw_only):
     dg_lo.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_hi,n_lo,yaw_only", [(167, 218, False), (150, 200, True), (1, 256, False), (300, 90, False),
+                                                (2000, 2096, False)])
+def test_csm3d_one_launch_equals_per_evaluation_loop(dl, ctx, orc, monkeypatch, n_hi, n_lo, yaw_only):
+    """The single-workgroup Levenberg-Marquardt kernel (clouds up to 4096 points: one launch per Match) and the
+    launch-per-evaluation loop run the SAME minimize<> template; where the evaluation kernel also uses one workgroup
+    (<= 512 points) the two accumulate in the same order and the results are bit-identical, beyond that they agree
+    to rounding.  Both stay within 1e-6 of the oracle (ceres_scan_matcher_3d.cc:71-123)."""
+    og_hi, pts, init, truth = _synthetic_case(orc, 16, 256, resolution=0.1, max_range=20.0)
+    og_lo = build_oracle_submap(orc, 0.45, num_scans=6, beams=16, azimuths=256)
+    dg_hi, dg_lo = to_device_grid(dl, ctx, og_hi), to_device_grid(dl, ctx, og_lo)
+    rng = np.random.default_rng(n_hi * 7 + n_lo)
+    hi = pts[rng.choice(len(pts), n_hi, replace=False)]
+    lo = pts[rng.choice(len(pts), n_lo, replace=False)]
+    opts = dict(DEFAULT_CSM, only_optimize_yaw=yaw_only)
+    m = dl.CeresScanMatcher3D(ctx, opts)
+    monkeypatch.setenv("DLIOM_CSM_PERSISTENT_MAX", "4096")
+    pose_a, sum_a = m.Match(init[:3], init, [(hi, dg_hi), (lo, dg_lo)])
+    monkeypatch.setenv("DLIOM_CSM_PERSISTENT_MAX", "0")
+    pose_b, sum_b = m.Match(init[:3], init, [(hi, dg_hi), (lo, dg_lo)])
+    if n_hi + n_lo <= 512:
+        assert np.array_equal(pose_a, pose_b), (pose_a, pose_b)
+        assert sum_a == sum_b
+    else:
+        assert np.allclose(pose_a, pose_b, rtol=0, atol=1e-9)
+        assert sum_a["num_iterations"] == sum_b["num_iterations"]
+    ref = orc.csm3d_match(opts, init[:3], init, [(hi, og_hi), (lo, og_lo)])
+    dt, da = pose_distance(pose_a, ref["pose"])
+    assert dt <= 1e-6 and da <= 1e-6, (dt, da, sum_a, ref)
+    assert sum_a["num_iterations"] == ref["num_iterations"]
+    dg_hi.close()
+    dg_lo.close()
+
+
 def test_csm3d_error_codes(dl, ctx, orc):
     og, dg = _kat_grids(dl, ctx, orc, 1.0)
     bad = dict(CSM_TEST_OPTS, occupied_space_weight=[1.0, 2.0])  # CHECK_EQ(weights, clouds)
@@ -770,6 +804,37 @@ def test_device_adaptive_voxel_filter_equals_oracle(dl, ctx, orc, opts):
     assert np.array_equal(got, dl.adaptive_voxel_filter(opts[0], opts[1], opts[2], pts))
     out.close()
     cloud.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first,second", [((2.0, 150, 15.0), (4.0, 200, 60.0)), ((0.5, 20000, 30.0), (2.0, 1e9, 50.0)),
+                                          ((2.0, 10, 1.0), (0.05, 5, 60.0)), ((4.0, 200, 60.0), (4.0, 200, 60.0)),
+                                          ((0.05, 5, 60.0), (2.0, 150, 15.0))])
+def test_device_adaptive_voxel_filter_pair_equals_oracle(dl, ctx, orc, first, second):
+    """The joint search of two adaptive filters (one insert launch per round for both) returns, for each option
+    set, exactly AdaptiveVoxelFilter(options).Filter(cloud): every pairing of the search's branches, the max norms
+    the matchers read, and an empty cloud."""
+    from dliom import synth
+    truth = synth.trajectory_pose(0.3)
+    pts, _ = synth.scan(truth, 64, 1024)
+    pts = pts[orc.voxel_filter(0.15, pts)]
+    cloud = dl.PointCloud(ctx, pts)
+    a, b = cloud.adaptive_voxel_filter_pair(first, second)
+    for out, o in ((a, first), (b, second)):
+        want = orc.adaptive_voxel_filter(o[0], o[1], o[2], pts)
+        got = out.download()
+        assert got.shape == want.shape, (o, got.shape, want.shape)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), o
+        single = cloud.adaptive_voxel_filter(*o)
+        assert np.array_equal(single.download(), got)
+        single.close()
+        out.close()
+    cloud.close()
+    empty = dl.PointCloud(ctx, np.zeros((0, 3), np.float32))
+    ea, eb = empty.adaptive_voxel_filter_pair(first, second)
+    assert len(ea) == 0 and len(eb) == 0
+    for c in (ea, eb, empty):
+        c.close()
 
 
 @pytest.mark.gpu

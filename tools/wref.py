@@ -171,16 +171,14 @@ def stages(args, dl, synth, ctx):
     init = synth.perturb_pose(truth, 0.03, 0.2, seed=3)
     rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, OPTS["real_time_correlative_scan_matcher"])
     cs = dl.CeresScanMatcher3D(ctx, OPTS["ceres_scan_matcher"])
-    t = {k: [] for k in ("upload", "voxel_filter", "adaptive_hi", "adaptive_lo", "rtcsm", "ceres", "insert", "free")}
+    t = {k: [] for k in ("upload", "voxel_filter", "adaptive_pair", "rtcsm", "ceres", "insert", "free")}
     for rep in range(24):
         a = time.perf_counter()
         raw = dl.PointCloud(ctx, pts)
         b = time.perf_counter()
         f = raw.voxel_filter(0.15)
         c0 = time.perf_counter()
-        hi = f.adaptive_voxel_filter(2.0, 150, 15.0)
-        d = time.perf_counter()
-        lo = f.adaptive_voxel_filter(4.0, 200, 60.0)
+        hi, lo = f.adaptive_voxel_filter_pair((2.0, 150, 15.0), (4.0, 200, 60.0))
         e = time.perf_counter()
         _, p1 = rt.Match(init, hi, g_hi)
         g = time.perf_counter()
@@ -192,7 +190,7 @@ def stages(args, dl, synth, ctx):
         for cl in (raw, f, hi, lo):
             cl.close()
         j = time.perf_counter()
-        for k, v in zip(t, (b - a, c0 - b, d - c0, e - d, g - e, h - g, i - h, j - i)):
+        for k, v in zip(t, (b - a, c0 - b, e - c0, g - e, h - g, i - h, j - i)):
             t[k].append(v)
     print(json.dumps({"stage_p50_us": {k: 1e6 * float(np.median(v[4:])) for k, v in t.items()},
                       "N_filtered": len(f), "N_hi": len(hi), "N_lo": len(lo)}))
