@@ -248,7 +248,7 @@ def main():
             },
             "stage_ms_per_scan": {k: 1e3 * v / args.steps for k, v in stage.items()},
             "kernel_ms_per_scan": breakdown,
-            "roofline": roofline_block(prof, pairs, k_ms, int(score_n), alg_bytes),
+            "roofline": roofline_block(prof, pairs, k_ms, int(score_n), alg_bytes, int(st.score_kernel)),
         }
         if sharded_line is not None:
             out["sharded"] = sharded_line
@@ -283,12 +283,13 @@ def score_kernel_profile(n_pts, C):
     return None
 
 
-def roofline_block(prof, pairs, k_ms, launches, alg_bytes):
+def roofline_block(prof, pairs, k_ms, launches, alg_bytes, score_kernel):
     """What bounds the dominant kernel: the vector ALU's instruction issue -- not HBM (the
     kernel moves ~2 % of its algorithmic bytes) and not MFMA (no GEMM in it).  achieved = VALU lane-operations
     per second (SQ_INSTS_VALU x 64 / launch time); peak = 256 CU x 4 SIMD-32 x 2.4 GHz."""
     t = k_ms * 1e-3
-    kernel = "rtcsm_score_box_kernel" if os.environ.get("DLIOM_SCORE_MAPPING", "3") == "3" else "rtcsm_score_dense_kernel"
+    kernel = {3: "rtcsm_score_box_kernel", 2: "rtcsm_score_dense_kernel", 1: "rtcsm_score_rot_kernel",
+              0: "rtcsm_score_kernel"}.get(score_kernel, "?")  # the kernel that ran (dliom_rtcsm_stats.score_kernel)
     valu_per_pair = src = traffic = tsrc = None
     if prof is not None and prof.get("kernel") == kernel:
         valu_per_pair = prof.get("valu_instructions_per_wave_pair")

@@ -80,6 +80,7 @@ struct dliom_ctx {
   bool box_error_zeroed = false;
   bool force_dense_score = false;  // rerun after a list overflow of the LDS-box kernel
   bool last_score_used_box = false;
+  int last_score_mapping = -1;     // 3 box, 2 dense mirror, 1 / 0 leaf table kernels
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
   // profiling

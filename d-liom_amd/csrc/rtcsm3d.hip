@@ -1369,8 +1369,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   const int want_blocks = target_waves > 0 ? target_waves / kWaves : std::max(1, resident) * num_cus;
   int slot_quads = std::max(1, want_blocks / std::max(1, rot_blocks * passes));
   slot_quads = std::min(slot_quads, (p.point_chunks + kBatch - 1) / kBatch);
-  // 32-bit accumulators: even a wave that drew every chunk must stay below 2^32
-  if (static_cast<double>(n) * 32767.0 >= 4294967295.0) return DLIOM_ERR_CAPACITY;
+  // (32-bit register accumulators: the kernel adds them to the 64-bit volume every box::kFlushPoints points)
   p.slots = slot_quads;
   DLIOM_TRY(ctx->box_counters.reserve(static_cast<size_t>(passes) * rot_blocks * 4 + 256));
   DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_counters.p, 0, static_cast<size_t>(passes) * rot_blocks * 4, ctx->stream));
@@ -1424,6 +1423,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
     if (s3 == DLIOM_OK) {
       *pad_processed = 0;
       ctx->last_score_used_box = true;
+      ctx->last_score_mapping = 3;
       return DLIOM_OK;
     }
     if (s3 != DLIOM_ERR_CAPACITY) return s3;
@@ -1434,6 +1434,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   const int Rs = r_last - r_first;  // rotations of this shard
   int span = -1;
   int64_t processed = 0;
+  ctx->last_score_mapping = mapping;
   if (mapping >= 1) {
     static const int forced_chunk = env_int("DLIOM_SCORE_CHUNK", 0);
     const int rot_groups = (Rs + kBlock - 1) / kBlock;
@@ -1873,6 +1874,7 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
   ctx->last_rtcsm.window = c.w;
   ctx->last_rtcsm.num_points = cloud.n;
   ctx->last_rtcsm.num_rescored = K;
+  ctx->last_rtcsm.score_kernel = ctx->last_score_mapping;
   ctx->last_rtcsm.best_index = st->best_c;
   if (local_best_packed != nullptr) {
     uint64_t packed = 0;  // a shard without a positive-score survivor contributes nothing

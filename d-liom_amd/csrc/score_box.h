@@ -405,6 +405,18 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
   return i;
 }
 
+// The register accumulators are 32 bits wide and a value is at most 32767: after kFlushPoints points they are
+// added to the 64-bit score volume and cleared (large clouds: 128 x 2048 returns and up).
+constexpr int kFlushPoints = 131072;  // 131072 * 32767 < 2^32
+__device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsigned (&acc)[kTC], int r, bool lane_active) {
+#pragma unroll
+  for (int j = 0; j < kTC; ++j) {
+    if (lane_active && j < ps.tc && acc[j] != 0u)
+      atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + r], static_cast<unsigned long long>(acc[j]));
+    acc[j] = 0u;
+  }
+}
+
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rtcsm_score_box_kernel(
     GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
   extern __shared__ float4 lds_dyn4[];  // [kTC tau | band bitmap | ticket words | nw x lists | box]
@@ -470,6 +482,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
   int ticket = (p.debug & 8) ? num_batches : slot;
   int n_guess = p.chunk;  // points per box that fitted last time
   int parity = 0;
+  int since_flush = 0;     // points added to the accumulators since they were last cleared (uniform)
   while (ticket < num_batches) {
     unsigned next_raw = 0u;
     if (threadIdx.x == 0) next_raw = atomicAdd(counter, 1u);  // in flight while this batch is processed
@@ -537,6 +550,11 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
           n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
         }
         n_guess = min(p.chunk, n >= 4 ? 2 * n : 4);
+        if (since_flush + n > kFlushPoints) {
+          flush_acc(p, ps, acc, rot0 + lane, lane_active);
+          since_flush = 0;
+        }
+        since_flush += fits_out ? n : 1;
         if (!fits_out) {
           // a single point whose lookups do not fit the box (huge angular window / far outlier): the exact
           // path straight from the mirror in HBM, every lane its own rotation
@@ -607,12 +625,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     parity ^= 1;
   }
   if (wave_active && !(p.debug & 1)) drain_l1(g, p, ps, lds_tau, px, py, pz, ls, true, rot0, lane);
-  if (lane_active) {
-#pragma unroll
-    for (int j = 0; j < kTC; ++j)
-      if (j < ps.tc)
-        atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + rot0 + lane], static_cast<unsigned long long>(acc[j]));
-  }
+  flush_acc(p, ps, acc, rot0 + lane, lane_active);
 }
 
 }  // namespace box

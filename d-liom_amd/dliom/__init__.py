@@ -65,7 +65,7 @@ class RtcsmWindow(C.Structure):
 
 class RtcsmStats(C.Structure):
     _fields_ = [("window", RtcsmWindow), ("num_points", C.c_int64), ("num_rescored", C.c_int64),
-                ("best_index", C.c_int64)]
+                ("best_index", C.c_int64), ("score_kernel", C.c_int64)]
 
 
 MAX_CLOUDS = 8

@@ -57,9 +57,19 @@ def pose_inverse(a):
     return np.concatenate([t, q])
 
 
+# p(t) = (R sin wt, R (1 - cos wt), t).  The reference test's corkscrew is R = 1 m, w = 4 rad/s (4 m/s on a 1 m
+# circle: 16 m/s^2); set_trajectory(10.0, 0.4) is a vehicle-like arc (4 m/s, 1.6 m/s^2) for the streaming tool.
+TRAJ = {"radius": 1.0, "omega": 4.0}
+
+
+def set_trajectory(radius=1.0, omega=4.0):
+    TRAJ["radius"], TRAJ["omega"] = float(radius), float(omega)
+
+
 def trajectory_pose(t):
     """Corkscrew pose at time t (seconds)."""
-    p = np.array([np.sin(4.0 * t), 1.0 - np.cos(4.0 * t), t])
+    R, w = TRAJ["radius"], TRAJ["omega"]
+    p = np.array([R * np.sin(w * t), R * (1.0 - np.cos(w * t)), t])
     q = quat_from_axis_angle([1.0, -1.0, 2.0], 0.3 * t)
     return np.concatenate([p, q])
 
@@ -141,7 +151,8 @@ GRAVITY = np.array([0.0, 0.0, 9.80511])  # trajectory_builder_3d.lua:92; the IMU
 
 
 def trajectory_velocity(t):
-    return np.array([4.0 * np.cos(4.0 * t), 4.0 * np.sin(4.0 * t), 1.0])
+    R, w = TRAJ["radius"], TRAJ["omega"]
+    return np.array([R * w * np.cos(w * t), R * w * np.sin(w * t), 1.0])
 
 
 def trajectory_state(t):
@@ -154,7 +165,8 @@ def imu_samples(t0, t1, rate=200.0, noise=None, seed=11):
     """Specific force R^T (a + G) and body rate at t0, t0 + 1/rate, ..., t1 (inclusive)."""
     n = int(round((t1 - t0) * rate)) + 1
     ts = t0 + np.arange(n) / rate
-    acc_w = np.stack([-16.0 * np.sin(4.0 * ts), 16.0 * np.cos(4.0 * ts), np.zeros(n)], axis=1) + GRAVITY
+    R, w = TRAJ["radius"], TRAJ["omega"]
+    acc_w = np.stack([-R * w * w * np.sin(w * ts), R * w * w * np.cos(w * ts), np.zeros(n)], axis=1) + GRAVITY
     acc = np.stack([quat_to_matrix(quat_from_axis_angle(AXIS, 0.3 * t)).T @ a for t, a in zip(ts, acc_w)])
     gyr = np.tile(0.3 * AXIS, (n, 1))  # rotation about a fixed axis: body rate == world rate
     if noise is not None:
@@ -191,7 +203,8 @@ def moving_scan(t_end, num_beams=64, num_azimuths=1024, centers=None):
     sensor frame OF THAT INSTANT.  Returns float32 [x, y, z, rel_t] rows."""
     dirs_s, rel_t = beam_directions(num_beams, num_azimuths)
     ts = t_end + rel_t
-    pos = np.stack([np.sin(4.0 * ts), 1.0 - np.cos(4.0 * ts), ts], axis=1)
+    R, w = TRAJ["radius"], TRAJ["omega"]
+    pos = np.stack([R * np.sin(w * ts), R * (1.0 - np.cos(w * ts)), ts], axis=1)
     ang = 0.3 * ts
     K = np.array([[0, -AXIS[2], AXIS[1]], [AXIS[2], 0, -AXIS[0]], [-AXIS[1], AXIS[0], 0]])
     # Rodrigues: R d = d + sin(a) K d + (1 - cos a) K K d

@@ -205,6 +205,8 @@ typedef struct dliom_rtcsm_stats {
   int64_t num_points;
   int64_t num_rescored;   /* candidates re-scored with the sequential float sum */
   int64_t best_index;     /* generation order: ((z,y,x) * R + (rz,ry,rx)) */
+  int64_t score_kernel;   /* score-volume kernel that ran: 3 LDS-box, 2 dense mirror, 1 rotation per lane over the leaf
+                             table, 0 point per lane over the leaf table */
 } dliom_rtcsm_stats;
 int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats);
 /* BASELINE config 4 in one call: this rank scores rotations [shard R / num_shards, (shard + 1) R / num_shards), finds its

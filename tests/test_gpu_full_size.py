@@ -53,6 +53,7 @@ def test_config2_full_oracle_match(dl, ctx, orc, bench_scene):
     score, pose = rt.Match(sc["init"], sc["cloud"], s["g_hi"])
     st = rt.last_stats()
     assert st.window.num_candidates == 35937 == ref["num_candidates"] and st.num_points == 65536
+    assert st.score_kernel == 3  # the LDS-box kernel is what bench.py times
     assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
     assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
     assert np.array_equal(pose, ref["pose"])
@@ -127,6 +128,7 @@ def test_config5_reduced_window(dl, ctx, orc):
     score, pose = rt.Match(sc["init"], sc["cloud"], g_hi)
     st = rt.last_stats()
     assert st.window.num_translations == 343 and st.num_points == 262144
+    assert st.score_kernel == 3  # LDS-box kernel; N > box::kFlushPoints exercises the accumulator flush
     ref = orc.rtcsm3d_match_parallel(opts, sc["init"], sc["pts"], og_hi, threads=THREADS)
     assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
     assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()

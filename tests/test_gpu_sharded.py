@@ -66,7 +66,10 @@ def test_two_ranks_one_collective_through_the_c_entry_point():
     assert ret.get(0) is True and ret.get(1) is True
 
 
-def test_rccl_entry_point_on_a_one_rank_communicator():
+def _rccl_one_rank_main():
+    """Body of the RCCL test; runs in a process of its own (see the test)."""
+    for p in (ROOT, os.path.join(ROOT, "d-liom_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
     import dliom as dl
     dl.load_library()
     rccl = C.CDLL("librccl.so.1")
@@ -75,11 +78,13 @@ def test_rccl_entry_point_on_a_one_rank_communicator():
         _fields_ = [("internal", C.c_char * 128)]
 
     uid = UniqueId()
-    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rc = rccl.ncclGetUniqueId(C.byref(uid))
+    assert rc == 0, "ncclGetUniqueId -> %d" % rc
     comm = C.c_void_p()
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     ctx = dl.Context(0)
-    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    rc = rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0)
+    assert rc == 0, "ncclCommInitRank -> %d" % rc
     orc, og, dg, pts, init, opts = _scene(dl, ctx)
     cloud = dl.PointCloud(ctx, pts)
     score, pose = dl.RtcsmShard(ctx, opts, 0, 1).match_rccl(init, cloud, dg, comm.value)
@@ -90,3 +95,19 @@ def test_rccl_entry_point_on_a_one_rank_communicator():
     cloud.close()
     dg.close()
     ctx.close()
+    print("rccl-one-rank ok")
+
+
+def test_rccl_entry_point_on_a_one_rank_communicator():
+    """In a fresh process: RCCL's bootstrap (sockets, its own HIP streams and IPC probing) must not depend on
+    what the 100+ earlier tests left behind in the pytest process.  RCCL's own log is part of the failure text."""
+    import subprocess
+    env = dict(os.environ, NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo",
+               MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "rccl-one-rank"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "rccl-one-rank ok" in r.stdout, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+
+
+if __name__ == "__main__" and sys.argv[1:] == ["rccl-one-rank"]:
+    _rccl_one_rank_main()
