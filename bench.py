@@ -59,6 +59,7 @@ def parse():
                     help="skips the CPU oracle leg (cpu_baseline AND the post-timing parity check)")
     ap.add_argument("--no-wref", action="store_true", help="skips the W-ref (reference-faithful filter chain) line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--dump-steps", action="store_true", help="per-step stage times on stderr (debugging)")
     return ap.parse_args()
 
 
@@ -132,6 +133,9 @@ def main():
         # Submap3D::InsertRangeData: high-resolution grid (range filtered) + low-resolution grid, fused
         dl.insert_cloud_multi(ins, sc["cloud"], [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)])
         d = time.perf_counter()
+        if timed and args.dump_steps:
+            sys.stderr.write("step %d scan %d: rtcsm %.3f ceres %.3f insert %.3f ms, E %d\n" % (
+                i, i % len(scans), 1e3 * (b - a), 1e3 * (c - b), 1e3 * (d - c), summ["num_residual_evaluations"]))
         if timed:
             stage["rtcsm"] += b - a
             stage["ceres"] += c - b
@@ -152,6 +156,12 @@ def main():
     # per-kernel breakdown comes from a few extra, untimed steps with every kernel timed
     ctx.set_profiling(2)
     ctx.reset_profiling()
+    # The harness, not the product: with torch imported a full (generation 2) collection of CPython's cyclic garbage
+    # collector takes ~35 ms -- 24 steps of this benchmark -- and when it fires depends on the interpreter's allocation
+    # count.  Collect now, keep the collector off for the timed steps.
+    import gc
+    gc.collect()
+    gc.disable()
     fence()
     lat = []
     t_begin = time.perf_counter()
@@ -166,6 +176,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gc.enable()
     score_ms, score_n = ctx.kernel_time(dl.KERNEL_RTCSM_SCORE)
     ctx.set_profiling(0)
     # N > 1 replica run: the same scans once more with the search window SHARDED over the ranks (BASELINE config 4).

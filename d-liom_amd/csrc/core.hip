@@ -254,6 +254,89 @@ int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud*
   return fill_cloud(ctx, base, points_xyz, n, out);
 }
 
+// ---- several fills / small read-backs per dispatch (internal.h) ------------------------------------------
+namespace {
+struct FillArgs {
+  uint4* p[4];
+  unsigned long long vec[4];  // 16-byte units
+  unsigned* tail[4];          // the words after the last whole unit
+  unsigned tail_words[4];
+  unsigned value[4];
+};
+__global__ __launch_bounds__(256) void fill_multi_kernel(FillArgs a) {
+  const int j = blockIdx.y;
+  const unsigned v = a.value[j];
+  const uint4 v4 = make_uint4(v, v, v, v);
+  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256u;
+  for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * 256u + threadIdx.x; i < a.vec[j]; i += stride)
+    a.p[j][i] = v4;
+  if (blockIdx.x == 0 && threadIdx.x < a.tail_words[j]) a.tail[j][threadIdx.x] = v;
+}
+struct GatherArgs {
+  const unsigned* src[6];
+  unsigned words[6];
+  unsigned offset[6];
+  unsigned* dst;
+  int n;
+};
+__global__ __launch_bounds__(256) void gather_to_pinned_kernel(GatherArgs a) {
+  for (int j = 0; j < a.n; ++j)
+    for (unsigned i = threadIdx.x; i < a.words[j]; i += 256u) a.dst[a.offset[j] + i] = a.src[j][i];
+}
+}  // namespace
+
+int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs) {
+  if (num_jobs <= 0) return DLIOM_OK;
+  if (num_jobs > 4) return DLIOM_ERR_INVALID_ARGUMENT;
+  FillArgs a;
+  unsigned long long most = 1;
+  for (int j = 0; j < num_jobs; ++j) {
+    char* p = static_cast<char*>(jobs[j].p);
+    size_t bytes = jobs[j].bytes;
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) != 0 || (bytes & 3u) != 0) return DLIOM_ERR_INVALID_ARGUMENT;
+    // leading words up to 16-byte alignment are rare (every caller's buffers are 256-byte aligned): plain memset then
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) != 0) {
+      const unsigned char b = static_cast<unsigned char>(jobs[j].value & 0xFFu);
+      if (jobs[j].value != 0x01010101u * b) return DLIOM_ERR_INVALID_ARGUMENT;
+      DLIOM_HIP_TRY(hipMemsetAsync(p, b, bytes, ctx->stream));
+      bytes = 0;
+    }
+    a.p[j] = reinterpret_cast<uint4*>(p);
+    a.vec[j] = bytes / 16;
+    a.tail[j] = reinterpret_cast<unsigned*>(p + a.vec[j] * 16);
+    a.tail_words[j] = static_cast<unsigned>((bytes % 16) / 4);
+    a.value[j] = jobs[j].value;
+    most = std::max(most, a.vec[j]);
+  }
+  const unsigned blocks = static_cast<unsigned>(std::min<unsigned long long>((most + 255) / 256, 2048));
+  hipLaunchKernelGGL(fill_multi_kernel, dim3(blocks, num_jobs), dim3(256), 0, ctx->stream, a);
+  DLIOM_HIP_TRY(hipGetLastError());
+  return DLIOM_OK;
+}
+
+int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst) {
+  if (num_jobs <= 0) return DLIOM_OK;
+  if (num_jobs > 6 || pinned_dst == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  GatherArgs a;
+  unsigned off = 0;
+  for (int j = 0; j < 6; ++j) {
+    a.src[j] = nullptr;
+    a.words[j] = a.offset[j] = 0;
+  }
+  for (int j = 0; j < num_jobs; ++j) {
+    if (jobs[j].words > 1024u) return DLIOM_ERR_INVALID_ARGUMENT;
+    a.src[j] = static_cast<const unsigned*>(jobs[j].src);
+    a.words[j] = jobs[j].words;
+    a.offset[j] = off;
+    off += jobs[j].words;
+  }
+  a.dst = static_cast<unsigned*>(pinned_dst);
+  a.n = num_jobs;
+  hipLaunchKernelGGL(gather_to_pinned_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+  DLIOM_HIP_TRY(hipGetLastError());
+  return DLIOM_OK;
+}
+
 // Cloud allocations are pooled per device: a scan makes four clouds (raw, filtered, high, low) and
 // hipMalloc/hipFree cost more than the kernels that fill them.  Blocks are power-of-two sized and
 // handed back by dliom_cloud_destroy after a device synchronise (what hipFree would have done).

@@ -58,12 +58,9 @@ __device__ __forceinline__ double lut_probability(unsigned v, float k_scale, flo
 }
 
 // One point: residual r = s (1 - P(T p)) and its 6 tangent-space derivatives.
-__device__ __forceinline__ void csm_point(const CsmPose& a, const CsmCloudArg& c, int i,
-                                          float k_scale, float k_offset, float k_unknown,
-                                          double* r_out, double jrow[6]) {
-  const double vx = static_cast<double>(c.x[i]);
-  const double vy = static_cast<double>(c.y[i]);
-  const double vz = static_cast<double>(c.z[i]);
+__device__ __forceinline__ void csm_point_v(const CsmPose& a, const CsmCloudArg& c, double vx, double vy, double vz,
+                                            float k_scale, float k_offset, float k_unknown,
+                                            double* r_out, double jrow[6]) {
   const double qw = a.q[0], ux = a.q[1], uy = a.q[2], uz = a.q[3];
   // Eigen _transformVector on doubles: uv = 2 (u x v); world = (v + w uv) + u x uv, then + t
   double uvx = uy * vz - uz * vy, uvy = uz * vx - ux * vz, uvz = ux * vy - uy * vx;
@@ -172,6 +169,13 @@ __device__ __forceinline__ void csm_point(const CsmPose& a, const CsmCloudArg& c
     for (int k = 0; k < 4; ++k) acc += dq[k] * a.plus[k * a.nloc + c2];
     jrow[3 + c2] = acc;
   }
+}
+
+__device__ __forceinline__ void csm_point(const CsmPose& a, const CsmCloudArg& c, int i,
+                                          float k_scale, float k_offset, float k_unknown,
+                                          double* r_out, double jrow[6]) {
+  csm_point_v(a, c, static_cast<double>(c.x[i]), static_cast<double>(c.y[i]), static_cast<double>(c.z[i]), k_scale,
+              k_offset, k_unknown, r_out, jrow);
 }
 
 // Every thread strides over the stacked clouds, accumulates its 28 sums in registers, then the
@@ -384,7 +388,10 @@ static int evaluate(CsmProblem* p, const double x[7], Normal* out) {
 // dynamically indexed local array would sit in scratch memory at ~1 us per dependent access.)
 template <int n>
 __host__ __device__ static bool solve_spd(const double* A, const double* d2, const double* b, double* y) {
-  double Lm[36];
+  // One IEEE division per pivot (its reciprocal), multiplications elsewhere: a double division is a ~30-instruction
+  // dependent sequence on the device, and this solve runs on the critical path of every LM iteration (csm_lm_kernel).
+  // Host and device run this same code, so the launch-per-evaluation loop and the one-launch kernel stay identical.
+  double Lm[36], rd[6];
 #pragma unroll
   for (int i = 0; i < n; ++i) {
 #pragma unroll
@@ -395,8 +402,9 @@ __host__ __device__ static bool solve_spd(const double* A, const double* d2, con
       if (i == j) {
         if (!(s > 0.0)) return false;
         Lm[i * 6 + i] = sqrt(s);
+        rd[i] = 1.0 / Lm[i * 6 + i];
       } else {
-        Lm[i * 6 + j] = s / Lm[j * 6 + j];
+        Lm[i * 6 + j] = s * rd[j];
       }
     }
   }
@@ -406,14 +414,14 @@ __host__ __device__ static bool solve_spd(const double* A, const double* d2, con
     double s = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) s -= Lm[i * 6 + k] * z[k];
-    z[i] = s / Lm[i * 6 + i];
+    z[i] = s * rd[i];
   }
 #pragma unroll
   for (int i = n - 1; i >= 0; --i) {
     double s = z[i];
 #pragma unroll
     for (int k = i + 1; k < n; ++k) s -= Lm[k * 6 + i] * y[k];
-    y[i] = s / Lm[i * 6 + i];
+    y[i] = s * rd[i];
   }
 #pragma unroll
   for (int i = 0; i < n; ++i)
@@ -518,9 +526,10 @@ __host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7]
 #pragma unroll
       for (int c = 0; c < ne; ++c) Hs[r * 6 + c] = cur.H[r * 6 + c] * scale[r] * scale[c];
     }
+    const double inv_radius = 1.0 / radius;
 #pragma unroll
     for (int r = 0; r < ne; ++r)
-      d2[r] = fmin(fmax(Hs[r * 6 + r], kMinDiag), kMaxDiag) / radius;
+      d2[r] = fmin(fmax(Hs[r * 6 + r], kMinDiag), kMaxDiag) * inv_radius;
     bool valid = solve_spd<ne>(Hs, d2, gs, y);
     double model_cost_change = 0.0;
     if (valid) {
@@ -641,6 +650,7 @@ struct DeviceEval {
   const LmKernelParams* prm;
   double (*red)[kCsmBlock];  // [kAcc][kCsmBlock]
   double* tot;               // [kAcc]
+  double pts[6];             // two-cloud fast path: this thread's point of cloud 0 and of cloud 1 (index clamped)
   int evaluations = 0;
   __device__ int operator()(const double x[7], Normal* out) {
     CsmPose pose;
@@ -668,8 +678,9 @@ struct DeviceEval {
       // dependent loads (point -> leaf table -> leaf) overlap; same additions in the same order as the loop below.
       const int t = threadIdx.x;
       double r0, j0[6], r1, j1[6];
-      csm_point(pose, a->cloud[0], t < n0 ? t : n0 - 1, prm->k_scale, prm->k_offset, prm->k_unknown, &r0, j0);
-      csm_point(pose, a->cloud[1], t < n1 ? t : n1 - 1, prm->k_scale, prm->k_offset, prm->k_unknown, &r1, j1);
+      // the thread's two points were loaded once, before the first evaluation (pts: registers across the whole loop)
+      csm_point_v(pose, a->cloud[0], pts[0], pts[1], pts[2], prm->k_scale, prm->k_offset, prm->k_unknown, &r0, j0);
+      csm_point_v(pose, a->cloud[1], pts[3], pts[4], pts[5], prm->k_scale, prm->k_offset, prm->k_unknown, &r1, j1);
       if (t < n0) add(r0, j0);
       if (t < n1) add(r1, j1);
     } else {
@@ -721,6 +732,18 @@ __global__ __launch_bounds__(kCsmBlock) void csm_lm_kernel(CsmArgs a, LmKernelPa
   ev.prm = &prm;
   ev.red = red;
   ev.tot = tot;
+  {
+    const int n0 = a.cloud[0].n, n1 = a.cloud[1].n;
+    const bool pair = a.num_clouds == 2 && n0 > 0 && n1 > 0 && n0 <= kCsmBlock && n1 <= kCsmBlock;
+    const int t = threadIdx.x;
+    const int i0 = pair ? (t < n0 ? t : n0 - 1) : 0, i1 = pair ? (t < n1 ? t : n1 - 1) : 0;
+    ev.pts[0] = pair ? static_cast<double>(a.cloud[0].x[i0]) : 0.0;
+    ev.pts[1] = pair ? static_cast<double>(a.cloud[0].y[i0]) : 0.0;
+    ev.pts[2] = pair ? static_cast<double>(a.cloud[0].z[i0]) : 0.0;
+    ev.pts[3] = pair ? static_cast<double>(a.cloud[1].x[i1]) : 0.0;
+    ev.pts[4] = pair ? static_cast<double>(a.cloud[1].y[i1]) : 0.0;
+    ev.pts[5] = pair ? static_cast<double>(a.cloud[1].z[i1]) : 0.0;
+  }
   double x[7];
   for (int i = 0; i < 7; ++i) x[i] = prm.x0[i];
   dliom_csm_summary sum;

@@ -177,6 +177,20 @@ int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, fl
 int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
                          float* oy, float* oz, int64_t* n_out);
 int needed_bits_for_cell_range(int min_index, int max_index);
+// core.hip: several small device fills / read-backs in ONE dispatch each (a hipMemsetAsync or hipMemcpyAsync is a
+// dispatch of its own: ~3 us of GPU time plus the gap to its neighbours, and the filtered-cloud chain issued ~25 per scan)
+struct FillJob {
+  void* p;
+  size_t bytes;    // multiple of 4
+  unsigned value;  // 32-bit pattern
+};
+int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs);  // num_jobs <= 4, on ctx->stream
+struct GatherJob {
+  const void* src;  // device, 4-byte aligned
+  unsigned words;
+};
+// Copies the jobs' words back to back into `pinned_dst` (device-visible pinned host memory, e.g. inside ctx->pinned).
+int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst);  // num_jobs <= 6, <= 1024 words each
 // rtcsm3d.hip: exact sequential float sums of LUT probabilities under explicit float poses
 int sequential_probability_sums(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid, const float* poses7,
                                 int k, float* sums);

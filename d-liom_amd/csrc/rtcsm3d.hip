@@ -1385,12 +1385,16 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
 // every sum).
 static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid,
                             const Candidates& c, int r_first, int r_last, DeviceCandidates* d,
-                            unsigned long long** d_sums, int64_t* pad_processed) {
+                            unsigned long long** d_sums, int64_t* pad_processed, const FillJob* also_fill = nullptr) {
   DLIOM_TRY(upload_candidates(ctx, c, d));
   const int64_t C = c.w.num_candidates;
   DLIOM_TRY(ctx->sums.reserve(static_cast<size_t>(C) * 8));
   *d_sums = ctx->sums.as<unsigned long long>();
-  DLIOM_HIP_TRY(hipMemsetAsync(*d_sums, 0, static_cast<size_t>(C) * 8, ctx->stream));
+  {
+    FillJob fills[2] = {{*d_sums, static_cast<size_t>(C) * 8, 0u}, {nullptr, 0, 0u}};
+    if (also_fill != nullptr) fills[1] = *also_fill;
+    DLIOM_TRY(fill_multi(ctx, fills, also_fill != nullptr ? 2 : 1));  // one dispatch
+  }
   const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
   const int n = static_cast<int>(cloud.n);
   // 3: LDS-box kernel over the dense mirror (score_box.h; default when the search suits it),
@@ -1721,11 +1725,12 @@ static int match_begin(dliom_ctx* ctx, const dliom_rtcsm_options* o, const doubl
   st->d_hi = reinterpret_cast<float*>(bb + bytes_f);
   st->d_list = reinterpret_cast<unsigned*>(bb + 2 * bytes_f);
   st->d_ctrs = reinterpret_cast<unsigned*>(bb + 3 * bytes_f);  // [0] best_lo bits, [1] count
-  DLIOM_HIP_TRY(hipMemsetAsync(st->d_ctrs, 0, 8, ctx->stream));
+  const FillJob zero_ctrs{st->d_ctrs, 8, 0u};
+  if (st->r_last <= st->r_first) DLIOM_TRY(fill_multi(ctx, &zero_ctrs, 1));
   if (st->r_last > st->r_first) {
     int64_t pad_processed = 0;
     DLIOM_TRY(run_score_volume(ctx, cloud, grid, c, st->r_first, st->r_last, &st->d, &st->d_sums,
-                               &pad_processed));
+                               &pad_processed, &zero_ctrs));
     st->used_box = ctx->last_score_used_box;
     const LutModel& lm = lut_model();
     BoundParams bp;
@@ -1815,13 +1820,13 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
       return s;
     };
     DLIOM_TRY(rescore(kSpecK, st->d_ctrs + 1, 0));
-    unsigned* h_err = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 4096 + 2048);
+    // one read-back dispatch: [count pair | list | sums | box overflow word]
+    unsigned* h_err = h_ctrs + 2 + 2 * kSpecK;
     *h_err = 0u;
-    if (st->used_box && global_best_lo_bits == nullptr)
-      DLIOM_HIP_TRY(hipMemcpyAsync(h_err, static_cast<char*>(ctx->box_error.p) + 4, 4, hipMemcpyDeviceToHost, ctx->stream));
-    DLIOM_HIP_TRY(hipMemcpyAsync(h_ctrs, st->d_ctrs, 8, hipMemcpyDeviceToHost, ctx->stream));
-    DLIOM_HIP_TRY(hipMemcpyAsync(h_list, st->d_list, kSpecK * 4, hipMemcpyDeviceToHost, ctx->stream));
-    DLIOM_HIP_TRY(hipMemcpyAsync(h_sums, ctx->rescore.p, kSpecK * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const bool want_err = st->used_box && global_best_lo_bits == nullptr;
+    const GatherJob back[4] = {{st->d_ctrs, 2}, {st->d_list, kSpecK}, {ctx->rescore.p, kSpecK},
+                               {static_cast<char*>(ctx->box_error.p) + 4, 1}};
+    DLIOM_TRY(gather_to_pinned(ctx, back, want_err ? 4 : 3, h_ctrs));
     DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     {
       bool overflow = false;

@@ -266,7 +266,8 @@ static int carve_scratch(dliom_ctx* ctx, int64_t n, int lengths, VfScratch* s) {
 // (< 0: every point), in_range[k] = how many those are.  Synchronises the stream (one readback of <= 260 bytes
 // through pinned memory).
 static int run_insert(dliom_ctx* ctx, const Soa& in, const std::vector<float>& sizes, const std::vector<float>& ranges,
-                      VfTables* t, std::vector<unsigned>* counts, std::vector<unsigned>* in_range) {
+                      VfTables* t, std::vector<unsigned>* counts, std::vector<unsigned>* in_range,
+                      unsigned* also_zero = nullptr, int also_zero_words = 0) {
   const int num = static_cast<int>(sizes.size());
   if (num <= 0 || num > kMaxLengths || ranges.size() != sizes.size()) return DLIOM_ERR_INVALID_ARGUMENT;
   t->num = num;
@@ -277,9 +278,12 @@ static int run_insert(dliom_ctx* ctx, const Soa& in, const std::vector<float>& s
     lengths.max_range[k] = ranges[k];
   }
   // 0xFF bytes = empty keys, "infinite" min indices; counters start at zero
-  DLIOM_HIP_TRY(hipMemsetAsync(t->tables, 0xFF, static_cast<size_t>(num) * t->capacity * 12, ctx->stream));
+  // (one dispatch; `also_zero`: the words the emit step's compaction will atomicMax into)
   const size_t counter_bytes = static_cast<size_t>(2 * num + 1) * kVfCounterStride * 4;
-  DLIOM_HIP_TRY(hipMemsetAsync(t->counters, 0, counter_bytes, ctx->stream));
+  const FillJob fills[3] = {{t->tables, static_cast<size_t>(num) * t->capacity * 12, 0xFFFFFFFFu},
+                            {t->counters, counter_bytes, 0u},
+                            {also_zero, static_cast<size_t>(also_zero_words) * 4, 0u}};
+  DLIOM_TRY(fill_multi(ctx, fills, also_zero != nullptr && also_zero_words > 0 ? 3 : 2));
   const unsigned n = static_cast<unsigned>(in.n);
   const dim3 grid((n + kVfInsertBlock - 1) / kVfInsertBlock, num);
   hipLaunchKernelGGL(voxel_insert_kernel, grid, dim3(kVfInsertBlock), 0, ctx->stream, in.x, in.y, in.z, n, lengths, *t);
@@ -301,12 +305,11 @@ static int run_insert(dliom_ctx* ctx, const Soa& in, const std::vector<float>& s
 
 // flag + compact of table (t, l) into caller-provided arrays (room for the survivor count the
 // insert launch reported).  max_sq != nullptr: device word receiving the survivors' largest
-// squared norm (zeroed here).  No synchronisation.
+// squared norm -- the CALLER has zeroed it (run_insert's also_zero).  No synchronisation.
 static int emit_arrays(dliom_ctx* ctx, const Soa& in, const VfScratch& s, const VfTables& t, int l, int mode,
                        float* ox, float* oy, float* oz, float* ow, unsigned* max_sq) {
   const unsigned n = static_cast<unsigned>(in.n);
   const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
-  if (max_sq != nullptr) DLIOM_HIP_TRY(hipMemsetAsync(max_sq, 0, 4, ctx->stream));
   hipLaunchKernelGGL(voxel_flag_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, n, t, l, mode, s.flags,
                      s.block_counts);
   hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z, in.w, n,
@@ -407,7 +410,7 @@ int voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, float size, dliom_
   DLIOM_TRY(carve_scratch(ctx, in.n, 1, &s));
   std::vector<unsigned> counts, in_range;
   const Soa soa{in.d_x, in.d_y, in.d_z, nullptr, in.n};
-  DLIOM_TRY(run_insert(ctx, soa, {size}, {-1.f}, &s.tables[0], &counts, &in_range));
+  DLIOM_TRY(run_insert(ctx, soa, {size}, {-1.f}, &s.tables[0], &counts, &in_range, s.max_sq, 1));
   return emit_cloud(ctx, soa, s, s.tables[0], 0, 0, counts[0], out);
 }
 
@@ -483,7 +486,7 @@ int adaptive_voxel_filter_clouds(dliom_ctx* ctx, const dliom_cloud& in, const dl
     }
   }
   std::vector<unsigned> counts, in_range;
-  DLIOM_TRY(run_insert(ctx, soa, sizes, ranges, &s.tables[0], &counts, &in_range));
+  DLIOM_TRY(run_insert(ctx, soa, sizes, ranges, &s.tables[0], &counts, &in_range, s.max_sq, kMaxFilters));
   sizes.clear();
   ranges.clear();
   for (int f = 0; f < num_filters; ++f) {
