@@ -54,9 +54,21 @@ constexpr int kL2Cap = 128;    // level-2 list: (level-1 slot, translation)
 #define DLIOM_BOX_HOT_P 4
 #endif
 constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4)
+#ifndef DLIOM_BOX_EXP
+#define DLIOM_BOX_EXP 0  // 1, 2, 3: timing experiments of the hot loop (wrong sums)
+#endif
+#ifndef DLIOM_BOX_PIPE
+#define DLIOM_BOX_PIPE 1
+#endif
+#ifndef DLIOM_BOX_LATE_ACC
+#define DLIOM_BOX_LATE_ACC 1
+#endif
+constexpr int kPipe = DLIOM_BOX_PIPE;            // steps between a gather and the accumulation of its value
+constexpr bool kLateAcc = DLIOM_BOX_LATE_ACC != 0;  // accumulate after the step's address arithmetic (else: anywhere)
 constexpr int kBatch = 4;      // point chunks per ticket of the work dispenser
 constexpr int kRecords = 8;    // ring of chunk records (lo[3], first point) the level-1 entries refer to
-constexpr int kListWords = kL1Cap + kL2Cap + 4 * kRecords;
+constexpr int kListTrash = kL1Cap + kL2Cap + 4 * kRecords;  // a word nobody reads: where unlisted lanes "append"
+constexpr int kListWords = kListTrash + 4;
 
 struct Pass {      // one per translation pass
   int gi[3];       // floor(G), G = t_c / res + 128.5 + s u  (t_c: centre translation of the pass)
@@ -305,48 +317,100 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
   const unsigned v2 = to_vgpr(2u), v1 = to_vgpr(s1), vs2 = to_vgpr(s2);
   const unsigned d0 = to_vgpr(box_base - 0x4300u * (2u + s1 + s2));
   int i = i_begin;
+  // the points of the NEXT iteration are fetched while this one's 27 * P lookups run: the loads used to be waited
+  // for right where they were issued, a full memory latency per iteration with nothing else in flight
+  float nx[P], ny[P], nz[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) {
+    nx[k] = px[i + k];
+    ny[k] = py[i + k];
+    nz[k] = pz[i + k];
+  }
 #pragma unroll 1
   for (; i < i_end; i += P) {
     if (ls.n1 + 64 * P > kL1Cap) break;
+    float cx[P], cy[P], cz[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      cx[k] = nx[k];
+      cy[k] = ny[k];
+      cz[k] = nz[k];
+    }
+    {
+      const int in = min(i + P, i_end - P);  // the last iteration reloads its own points (in range, unused)
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        nx[k] = px[in + k];
+        ny[k] = py[in + k];
+        nz[k] = pz[in + k];
+      }
+    }
     float wx[P], wy[P], wz[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       float rx, ry, rz;
-      rotate_point(q, px[i + k], py[i + k], pz[i + k], rx, ry, rz);
+      rotate_point(q, cx[k], cy[k], cz[k], rx, ry, rz);
       wx[k] = __builtin_fmaf(rx, inv, kbx);
       wy[k] = __builtin_fmaf(ry, inv, kby);
       wz[k] = __builtin_fmaf(rz, inv, kbz);
     }
     // once per (rotation, point): can any translation of the pass put a coordinate into a rounding band?
+    // All 3 P bitmap words are fetched together (one LDS latency per iteration, not P) and the list append is
+    // branch-free: a lane that is not listed writes to the wave's scratch word.  The per-point version -- fetch,
+    // wait, ballot, branch, append -- exposed an LDS round trip and two branches per point with nothing else to
+    // issue, a third of the wave's time at 2-3 waves per SIMD.
+    unsigned bkt[P][3], word[P][3];
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-      const unsigned bx = static_cast<unsigned>(__builtin_amdgcn_fractf(wx[k]) * static_cast<float>(kBuckets));
-      const unsigned by = static_cast<unsigned>(__builtin_amdgcn_fractf(wy[k]) * static_cast<float>(kBuckets));
-      const unsigned bz = static_cast<unsigned>(__builtin_amdgcn_fractf(wz[k]) * static_cast<float>(kBuckets));
-      const unsigned hit = ((lds_bitmap[bx >> 5] >> (bx & 31u)) | (lds_bitmap[kBuckets / 32 + (by >> 5)] >> (by & 31u)) |
-                            (lds_bitmap[2 * (kBuckets / 32) + (bz >> 5)] >> (bz & 31u))) & 1u;
+      // the scaled coordinate lies in [128, 256): its low 16 bits are the fraction, bucket = fraction >> 3
+      bkt[k][0] = (__float_as_uint(wx[k]) >> 3) & (kBuckets - 1);
+      bkt[k][1] = (__float_as_uint(wy[k]) >> 3) & (kBuckets - 1);
+      bkt[k][2] = (__float_as_uint(wz[k]) >> 3) & (kBuckets - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      word[k][0] = lds_bitmap[bkt[k][0] >> 5];
+      word[k][1] = lds_bitmap[kBuckets / 32 + (bkt[k][1] >> 5)];
+      word[k][2] = lds_bitmap[2 * (kBuckets / 32) + (bkt[k][2] >> 5)];
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      const unsigned hit = ((word[k][0] >> (bkt[k][0] & 31u)) | (word[k][1] >> (bkt[k][1] & 31u)) | (word[k][2] >> (bkt[k][2] & 31u))) & 1u;
       const bool mine = lane_active && hit != 0u;
       const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
-      if (mask != 0ull) {
-        const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
-                                                   __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
-        if (mine)
-          ls.l1[ls.n1 + rank] = static_cast<unsigned>(lane) | (static_cast<unsigned>(i + k - chunk_lo) << 6) | (rec_id << 12);
-        ls.n1 += __builtin_popcountll(mask);
-      }
+      const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u));
+      const int slot = mine ? ls.n1 + rank : kListTrash;
+      ls.l1[slot] = static_cast<unsigned>(lane) | (static_cast<unsigned>(i + k - chunk_lo) << 6) | (rec_id << 12);
+      ls.n1 += __builtin_popcountll(mask);
     }
-    // software pipeline, fixed by scheduling barriers: the translation of step j + 1 is fetched and the
-    // values gathered in step j - 1 are accumulated while the gathers of step j are in flight
+    // software pipeline, fixed by scheduling barriers: the translation of step j + 1 is fetched at the top of step j;
+    // the values gathered in step j - kPipe are accumulated AFTER step j's address arithmetic and right before its own
+    // gathers are issued, so that a gather has kPipe whole steps of another ~85 VALU cycles to return (accumulating
+    // in the middle of the next step's arithmetic left ~45 cycles: the wave then sat in s_waitcnt 40 % of the time)
     float4 t = lds_tau[0];
-    unsigned pv[P];
+    unsigned pv[kPipe][P];
 #pragma unroll
-    for (int k = 0; k < P; ++k) pv[k] = 0u;
+    for (int d = 0; d < kPipe; ++d)
+#pragma unroll
+      for (int k = 0; k < P; ++k) pv[d][k] = 0u;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < kTC; ++j) {
+#if DLIOM_BOX_EXP == 3
+      const float4 tn = t;  // timing experiment: no translation fetch
+#else
       const float4 tn = lds_tau[j + 1 < kTC ? j + 1 : j];  // same address in every lane: LDS broadcast
-      unsigned v[P];
+#endif
+      unsigned a[P];
+#if DLIOM_BOX_EXP == 2
+      // timing experiment: no address arithmetic (wrong sums)
+#pragma unroll
+      for (int k = 0; k < P; ++k) a[k] = d0 + 0x4300u * (2u + s1 + s2) + static_cast<unsigned>(2 * (4 * j + k)) + (__float_as_uint(wx[k]) & 0x3cu);
+      if (false) {
+#else
       if (P % 2 == 0) {
+#endif
         // level by level over the P lookups: a dependent v_mad_u32_u16 right behind its producer costs a wait state
         const float2v txy = {t.x, t.y}, tz0 = {t.z, t.w};
         float2v ax[P / 2 + 1], ay[P / 2 + 1], az[P / 2 + 1];  // + 1: no zero-length arrays in the P = 1 instantiation
@@ -356,7 +420,6 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
           ay[k] = pk_add_hi(float2v{wy[2 * k], wy[2 * k + 1]}, txy);
           az[k] = pk_add_lo(float2v{wz[2 * k], wz[2 * k + 1]}, tz0);
         }
-        unsigned a[P];
 #pragma unroll
         for (int k = 0; k < P / 2; ++k) {
           a[2 * k] = mad_hi16(ax[k].x, v2, d0);
@@ -372,34 +435,46 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
           a[2 * k] = mad_hi16(az[k].x, vs2, a[2 * k]);
           a[2 * k + 1] = mad_hi16(az[k].y, vs2, a[2 * k + 1]);
         }
-#pragma unroll
-        for (int k = 0; k < P; ++k) v[k] = *reinterpret_cast<lds_cu16*>(a[k]);
       } else {
 #pragma unroll
         for (int k = 0; k < P; ++k) {
           const float ax = wx[k] + t.x, ay = wy[k] + t.y, az = wz[k] + t.z;
-          const unsigned a = mad_hi16(az, vs2, mad_hi16(ay, v1, mad_hi16(ax, v2, d0)));
-          v[k] = *reinterpret_cast<lds_cu16*>(a);
+          a[k] = mad_hi16(az, vs2, mad_hi16(ay, v1, mad_hi16(ax, v2, d0)));
         }
       }
-      if (j > 0) {
-        unsigned s = pv[0];
+      if (kLateAcc) __builtin_amdgcn_sched_barrier(0);
+      if (j >= kPipe) {
+        unsigned s = pv[kPipe - 1][0];
 #pragma unroll
-        for (int k = 1; k < P; ++k) s += pv[k];
-        acc[j - 1] += s;
-        asm volatile("" : "+v"(acc[j - 1]));  // keeps the add here (it would be sunk to the loop latch, values spilled)
+        for (int k = 1; k < P; ++k) s += pv[kPipe - 1][k];
+        acc[j - kPipe] += s;
+        asm volatile("" : "+v"(acc[j - kPipe]));  // keeps the add here (it would be sunk to the loop latch, values spilled)
       }
+      if (kLateAcc) __builtin_amdgcn_sched_barrier(0);
+      unsigned v[P];
+#if DLIOM_BOX_EXP == 1
 #pragma unroll
-      for (int k = 0; k < P; ++k) pv[k] = v[k];
+      for (int k = 0; k < P; ++k) v[k] = a[k] & 0x7fffu;  // timing experiment: no gathers (wrong sums)
+#else
+#pragma unroll
+      for (int k = 0; k < P; ++k) v[k] = *reinterpret_cast<lds_cu16*>(a[k]);
+#endif
+#pragma unroll
+      for (int d = kPipe - 1; d > 0; --d)
+#pragma unroll
+        for (int k = 0; k < P; ++k) pv[d][k] = pv[d - 1][k];
+#pragma unroll
+      for (int k = 0; k < P; ++k) pv[0][k] = v[k];
       t = tn;
       __builtin_amdgcn_sched_barrier(0);
     }
-    {
-      unsigned s = pv[0];
 #pragma unroll
-      for (int k = 1; k < P; ++k) s += pv[k];
-      acc[kTC - 1] += s;
-      asm volatile("" : "+v"(acc[kTC - 1]));
+    for (int d = kPipe - 1; d >= 0; --d) {
+      unsigned s = pv[d][0];
+#pragma unroll
+      for (int k = 1; k < P; ++k) s += pv[d][k];
+      acc[kTC - 1 - d] += s;
+      asm volatile("" : "+v"(acc[kTC - 1 - d]));
     }
   }
   return i;
@@ -625,7 +700,14 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     parity ^= 1;
   }
   if (wave_active && !(p.debug & 1)) drain_l1(g, p, ps, lds_tau, px, py, pz, ls, true, rot0, lane);
-  flush_acc(p, ps, acc, rot0 + lane, lane_active);
+  if (p.debug & 16) {  // timing experiment: unconditional atomics of the accumulators' flush, even for zeros
+#pragma unroll
+    for (int j = 0; j < kTC; ++j)
+      if (lane_active && j < ps.tc)
+        atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + rot0 + lane], static_cast<unsigned long long>(acc[j]));
+    return;
+  }
+  if (!(p.debug & 32)) flush_acc(p, ps, acc, rot0 + lane, lane_active);
 }
 
 }  // namespace box

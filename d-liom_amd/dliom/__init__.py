@@ -289,7 +289,7 @@ def load_library(path=None):
     missing).  Loading needs the HIP runtime but no GPU."""
     global _lib
     if _lib is None:
-        p = path or LIB_PATH
+        p = path or os.environ.get("DLIOM_LIB") or LIB_PATH  # DLIOM_LIB: A/B builds of the library (tools/)
         if not os.path.exists(p):
             raise DliomError(ERR_NO_DEVICE, "libdliom.so not built at %s (run __graft_entry__.build())" % p)
         lib = C.CDLL(p)
