@@ -1227,7 +1227,10 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   // ---- spread of every wave's 64 rotations around its centre lane (window only: q_init cancels)
   const int rot_groups_all = (r_last - r_first + 63) / 64;
   // waves per workgroup: the fewest idle waves in the last workgroup (4 unless 3 divides better)
-  const int nw = rot_groups_all % 4 == 0 ? 4 : (rot_groups_all % 3 == 0 ? 3 : (rot_groups_all <= 2 ? rot_groups_all : 4));
+  static const int forced_nw = env_int("DLIOM_BOX_NW", 0);  // tuning knob
+  const int nw = forced_nw >= 1 && forced_nw <= kWaves
+                     ? std::min(forced_nw, rot_groups_all)
+                     : (rot_groups_all % 4 == 0 ? 4 : (rot_groups_all % 3 == 0 ? 3 : (rot_groups_all <= 2 ? rot_groups_all : 4)));
   const int rot_blocks = (rot_groups_all + nw - 1) / nw;
   struct GroupCache {  // depends on the window and the shard only: cached per thread across matches
     int A = -1, r_first = -1, r_last = -1, nw = 0;
@@ -1341,7 +1344,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   p.cells = cells;
   static const int box_debug = env_int("DLIOM_BOX_DEBUG", 0);
   p.debug = box_debug;
-  const size_t lds = kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(kWaves) * kListWords * 4 +
+  const size_t lds = kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 +
                      static_cast<size_t>(cells) * 2;
   if (lds > 160 * 1024) return DLIOM_ERR_CAPACITY;
   static bool attr_set = false;
@@ -1366,7 +1369,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
     (void)hipGetDevice(&dev);
     return hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }();
-  const int want_blocks = target_waves > 0 ? target_waves / kWaves : std::max(1, resident) * num_cus;
+  const int want_blocks = target_waves > 0 ? target_waves / nw : std::max(1, resident) * num_cus;
   int slot_quads = std::max(1, want_blocks / std::max(1, rot_blocks * passes));
   slot_quads = std::min(slot_quads, (p.point_chunks + kBatch - 1) / kBatch);
   // (32-bit register accumulators: the kernel adds them to the 64-bit volume every box::kFlushPoints points)

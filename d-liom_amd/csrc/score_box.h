@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char*)lds_dyn4));  // LDS byte address of the block
   const unsigned tick_off = static_cast<unsigned>(kTC * sizeof(float4)) + kBitmapWords * 4u;
   const unsigned lists_off = tick_off + 16u;
-  const unsigned box_off = lists_off + kWaves * kListWords * 4u;
+  const unsigned box_off = lists_off + static_cast<unsigned>(p.nw) * kListWords * 4u;  // lists of the waves present
   const unsigned box_base = lds0 + box_off;
   unsigned short* box = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(lds_dyn4) + box_off);
   unsigned* tick = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_dyn4) + tick_off);
