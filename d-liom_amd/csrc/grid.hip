@@ -50,24 +50,28 @@ __device__ __forceinline__ void ensure_leaf(uint32_t* table, int32_t* slot_coord
   }
 }
 
-// HybridGrid::ApplyLookupTable (hybrid_grid.h:509-520) on a 16-bit cell through
-// a 32-bit CAS: cells that already carry the update marker are left alone, so
-// the result does not depend on which thread gets there first.
+// HybridGrid::ApplyLookupTable (hybrid_grid.h:509-520) on one 16-bit cell: cells that already carry the update
+// marker are left alone, so the result does not depend on which thread gets there first.
 // Returns the value written (with the marker bit) or 0 when the cell was already updated.
 __device__ __forceinline__ uint32_t apply_table(uint32_t* pool32, size_t value_index,
                                                 const uint16_t* __restrict__ lut) {
-  uint32_t* word = pool32 + (value_index >> 1);
-  const unsigned shift = (value_index & 1u) ? 16u : 0u;
-  uint32_t old = *word;
-  for (;;) {
-    const uint32_t v = (old >> shift) & 0xFFFFu;
-    if (v >= 0x8000u) return 0u;
-    const uint32_t nv = lut[v];
-    const uint32_t desired = (old & ~(0xFFFFu << shift)) | (nv << shift);
-    const uint32_t seen = atomicCAS(word, old, desired);
-    if (seen == old) return nv;
-    old = seen;
-  }
+  // No atomic is needed: a thread that finds the cell unmarked writes lut[old] (marker included), and every thread that
+  // finds it unmarked -- racing threads, threads on another XCD whose L2 still holds the old line -- writes that SAME
+  // value from the SAME old value; a thread that finds the marker leaves the cell alone.  The 16-bit store touches only
+  // this cell's two bytes, so the neighbour in the same dword is not involved (the 32-bit compare-and-swap this replaces
+  // was: device-scope atomics execute on the memory side at ~30 G/s, and they were the whole cost of the three passes).
+  volatile uint16_t* cell = reinterpret_cast<volatile uint16_t*>(pool32) + value_index;
+  const uint32_t v = *cell;
+  if (v >= 0x8000u) return 0u;
+  const uint32_t nv = lut[v];
+  *cell = static_cast<uint16_t>(nv);
+  return nv;
+}
+// FinishUpdate for one cell (hybrid_grid.h:494-500): drops the marker; idempotent, plain 16-bit accesses as above.
+__device__ __forceinline__ void clear_marker(uint32_t* pool32, size_t value_index) {
+  volatile uint16_t* cell = reinterpret_cast<volatile uint16_t*>(pool32) + value_index;
+  const uint16_t v = *cell;
+  if (v & 0x8000u) *cell = v & 0x7FFFu;
 }
 
 struct InsertArgs {
@@ -173,7 +177,7 @@ __global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ t
         if (nv != 0u && a.dense != nullptr)
           a.dense[dense_index(hx, hy, hz, a.half, a.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
       } else {
-        atomicAnd(pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
+        clear_marker(pool32, vi);
       }
     }
   }
@@ -192,7 +196,7 @@ __global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ t
         if (nv != 0u && a.dense != nullptr)
           a.dense[dense_index(mx, my, mz, a.half, a.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
       } else {
-        atomicAnd(pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
+        clear_marker(pool32, vi);
       }
     }
   }
@@ -421,7 +425,7 @@ __global__ void multi_insert_kernel(MultiInsertArgs a) {
         if (nv != 0u && tg.dense != nullptr)
           tg.dense[dense_index(hx, hy, hz, tg.half, tg.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
       } else {
-        atomicAnd(tg.pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
+        clear_marker(tg.pool32, vi);
       }
     }
   }
@@ -436,7 +440,7 @@ __global__ void multi_insert_kernel(MultiInsertArgs a) {
         if (nv != 0u && tg.dense != nullptr)
           tg.dense[dense_index(mx, my, mz, tg.half, tg.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
       } else {
-        atomicAnd(tg.pool32 + (vi >> 1), ~((vi & 1u) ? 0x80000000u : 0x00008000u));
+        clear_marker(tg.pool32, vi);
       }
     }
   }
