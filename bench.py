@@ -70,13 +70,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # DLIOM_BENCH_BACKEND=gloo: control-flow check of the N > 1 path on a one-GPU box (every rank on GPU 0, host
+    # collectives); the driver's runs use the default, nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("DLIOM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libdliom has no CPU fallback)")
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libdliom has no CPU fallback)")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     import dliom as dl
     from dliom import synth
@@ -113,7 +122,7 @@ def main():
     shard = dl.RtcsmShard(ctx, RTCSM_OPTS, rank, world) if world > 1 else None
     if world > 1:
         from dliom import sharded
-        dev = torch.device("cuda", local_rank)
+        dev = coll_device
     stage = {"rtcsm": 0.0, "ceres": 0.0, "insert": 0.0}
     evals = []
     use_shards = [sharded_mode]  # flipped for the second (config 4) line of an N > 1 replica run
@@ -172,7 +181,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_begin
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -192,7 +201,7 @@ def main():
             step(2 * args.warmup + args.steps + i, False)
         fence()
         el = time.perf_counter() - t_s
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([el], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         use_shards[0] = False
         sharded_line = {"workload": "config4: ONE scan stream, RTCSM3D search window sharded over %d ranks (one 8-byte RCCL "
