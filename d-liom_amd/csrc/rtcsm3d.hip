@@ -1226,12 +1226,16 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   }
   // ---- spread of every wave's 64 rotations around its centre lane (window only: q_init cancels)
   const int rot_groups_all = (r_last - r_first + 63) / 64;
-  // waves per workgroup: the fewest idle waves in the last workgroup (4 unless 3 divides better)
+  // waves per workgroup
   static const int forced_nw = env_int("DLIOM_BOX_NW", 0);  // tuning knob
   const int nw = forced_nw >= 1 && forced_nw <= kWaves
                      ? std::min(forced_nw, rot_groups_all)
-                     : (rot_groups_all % 4 == 0 ? 4 : (rot_groups_all % 3 == 0 ? 3 : (rot_groups_all <= 2 ? rot_groups_all : 4)));
+                     : std::min(rot_groups_all, kWaves);  // four waves = one per SIMD: measured 2-3 % faster than three even
+                                                          // when that leaves idle waves in the last rotation block
   const int rot_blocks = (rot_groups_all + nw - 1) / nw;
+  if (kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 + static_cast<size_t>(cells) * 2 >
+      160 * 1024)
+    return DLIOM_ERR_CAPACITY;  // LDS budget (checked again where the launch is sized)
   struct GroupCache {  // depends on the window and the shard only: cached per thread across matches
     int A = -1, r_first = -1, r_last = -1, nw = 0;
     float step = 0.f;
@@ -1294,6 +1298,12 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   gcache.r_first = r_first;
   gcache.r_last = r_last;
   gcache.nw = nw;
+  // every refusal (DLIOM_ERR_CAPACITY) is behind us: the launch below is what DLIOM_KERNEL_RTCSM_SCORE times
+  struct SpanGuard {
+    dliom_ctx* c;
+    int span;
+    ~SpanGuard() { c->end_span(span); }
+  } span_guard{ctx, ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE)};
   // ---- device tables (after the candidate tables inside ctx->cand would alias uploads in flight: own buffer)
   const size_t tau_bytes = (tau.size() * 4 + 255) & ~static_cast<size_t>(255);
   const size_t pass_only_bytes = (pass.size() * sizeof(Pass) + 255) & ~static_cast<size_t>(255);
@@ -1347,7 +1357,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   const size_t lds = kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 +
                      static_cast<size_t>(cells) * 2;
   if (lds > 160 * 1024) return DLIOM_ERR_CAPACITY;
-  static bool attr_set = false;
+  static thread_local bool attr_set = false;  // one context per thread: per-thread, not process-wide
   if (!attr_set) {
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rtcsm_score_box_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1355,8 +1365,8 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   }
   // workgroups: one round of residents (every wave walks an equal share of the point chunks, so a second,
   // partly filled round would only idle); `target_waves` overrides
-  static size_t resident_lds = 0;
-  static int resident = 0, resident_nw = 0;
+  static thread_local size_t resident_lds = 0;
+  static thread_local int resident = 0, resident_nw = 0;
   if (resident_lds != lds || resident_nw != nw) {
     resident_nw = nw;
     DLIOM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(rtcsm_score_box_kernel),
@@ -1423,9 +1433,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
         DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_error.p, 0, 256, ctx->stream));
         ctx->box_error_zeroed = true;
       }
-      const int span3 = ctx->begin_span(DLIOM_KERNEL_RTCSM_SCORE);
       s3 = launch_score_box(ctx, cloud, g, c, *d, r_first, r_last, *d_sums, ctx->box_error.as<unsigned>());
-      ctx->end_span(span3);
     }
     if (s3 == DLIOM_OK) {
       *pad_processed = 0;

@@ -104,7 +104,8 @@ struct Params {
   int point_chunks, rot_groups, rot_blocks, nw, slots;  // nw waves per workgroup, rot_blocks = ceil(rot_groups / nw)
   unsigned thr;            // unresolved  <=>  (bits(w) & 0xffff) <= thr
   int cells;               // LDS box capacity per workgroup (cells)
-  int debug;               // timing experiments only (wrong sums): 1 skip the lists, 2 skip staging, 4 skip the lookups
+  int debug;               // timing experiments only (wrong sums): 1 skip the lists, 2 skip staging, 4 skip the lookups,
+                           // 8 no work at all, 16 unconditional flush atomics, 32 no flush (DLIOM_BOX_DEBUG)
 };
 
 typedef __attribute__((address_space(3))) const unsigned short lds_cu16;

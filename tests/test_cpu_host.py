@@ -237,3 +237,25 @@ def test_rotational_scan_match_equals_oracle(orc):
     # all-zero histograms: MatchHistograms returns 1 (normalisation < 1e-3)
     z = np.zeros((1, 10), np.float32)
     assert np.array_equal(dl.rotational_scan_match(z, [0.0], z[0], 0.0, [0.0, 0.1]), np.ones(2, np.float32))
+
+
+def test_synthetic_imu_matches_the_trajectory_it_was_derived_from():
+    """tools/stream.py's inputs: integrating the synthetic specific force / body rate over one scan period reproduces
+    the analytic trajectory, for the reference test's corkscrew and for the vehicle-like arc of --gentle."""
+    from dliom import synth
+    try:
+        for radius, omega in ((1.0, 4.0), (10.0, 0.4)):
+            synth.set_trajectory(radius, omega)
+            st = synth.trajectory_state(0.2)
+            dt, acc, gyr = synth.imu_samples(0.2, 0.3)
+            p, v = st[:3].copy(), st[7:10].copy()
+            for k in range(len(acc) - 1):
+                R = synth.quat_to_matrix(synth.trajectory_pose(0.2 + k * dt)[3:])
+                a = R @ acc[k] - synth.GRAVITY
+                p += v * dt + 0.5 * a * dt * dt
+                v += a * dt
+            assert np.linalg.norm(p - synth.trajectory_pose(0.3)[:3]) < 2e-3 * radius * omega * omega / 16.0 + 1e-4
+            assert np.linalg.norm(v - synth.trajectory_velocity(0.3)) < 5e-2 * radius * omega * omega / 16.0 + 1e-3
+            assert np.allclose(gyr, 0.3 * synth.AXIS)
+    finally:
+        synth.set_trajectory(1.0, 4.0)
