@@ -14,7 +14,13 @@
 //     [cell : 7 bits | fraction : 16 bits]) and three v_mad_u32_u16 that read the cell index straight
 //     out of the high half: 7 VALU per lookup, no test, no branch, no scalar work;
 //   * accumulators live in registers (the 27 translations of a pass are unrolled) and are flushed once per
-//     wave: ~7 M 64-bit atomics per launch instead of 74 M.
+//     wave (~7 M 64-bit atomics per launch instead of 74 M), and every kFlushPoints points so that clouds of any
+//     size keep 32-bit accumulators;
+//   * per iteration of kHotP points the next points are already in registers (fetched during the previous
+//     iteration's 27 steps), the 3 kHotP band-bitmap words are fetched together and the list append is branch-free;
+//     the values gathered in one step are accumulated after the next step's address arithmetic (kPipe, kLateAcc).
+// What bounds it and what was tried: DESIGN.md 3.1 (the DLIOM_BOX_EXP / DLIOM_BOX_DEBUG switches below are the
+// timing experiments quoted there; they produce wrong sums by design and are off in every build that ships).
 // Exactness without a per-lookup test.  A fast lookup can differ from the reference's cell only when its
 // scaled coordinate w lies within a rounding band of a cell boundary (budget below).  Whether ANY of the
 // 27 translations of a pass puts a rotated point into a band depends, per axis, only on the fraction of
