@@ -289,7 +289,9 @@ __global__ __launch_bounds__(kDenseMaxBlock) void rtcsm_score_dense_kernel(
   const int to_table = g.half + 1 - dom.lo;
   const int p_begin = chunk_id * points_per_chunk;
   const int p_end = p_begin + points_per_chunk;  // the cloud is padded: no tail handling
-  for (int jc = 0; jc < T; jc += t_chunk) {
+  // gridDim.y > 1 (small searches): the translation slices are spread over workgroups as well -- a search of a few
+  // hundred points fills a fraction of the chip, and each of a workgroup's steps is one exposed gather latency
+  for (int jc = blockIdx.y * t_chunk; jc < T; jc += t_chunk * gridDim.y) {
     const int tc = min(t_chunk, T - jc);
     for (int jj = 0; jj < tc; ++jj) lds_acc[jj * bs + threadIdx.x] = 0u;
 #pragma unroll 1
@@ -1522,10 +1524,19 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
       static const int t_chunk_max = env_int("DLIOM_SCORE_TCHUNK", 27);
       const size_t fixed_lds = lds + static_cast<size_t>(dom.size) * 12;
       const size_t acc_budget = fixed_lds < 34 * 1024 ? 36 * 1024 - fixed_lds : 2 * 1024;
-      const int t_chunk = std::max(4, std::min(std::min(T, t_chunk_max), static_cast<int>(acc_budget / (static_cast<size_t>(bs) * 4))));
-      const size_t lds2 = fixed_lds + static_cast<size_t>(t_chunk) * bs * 4;
+      int t_chunk = std::max(4, std::min(std::min(T, t_chunk_max), static_cast<int>(acc_budget / (static_cast<size_t>(bs) * 4))));
       const int chunks_per_xcd = (point_chunks + 7) / 8;
-      const dim3 dense_grid(8 * chunks_per_xcd * rot_groups);
+      // small searches (the reference's ~170 filtered points): translation slices over gridDim.y until ~4 workgroups per CU
+      static const int small_slices = env_int("DLIOM_SCORE_SLICES", 1);
+      int t_slices = 1;
+      const int base_blocks = 8 * chunks_per_xcd * rot_groups;
+      if (small_slices != 0 && base_blocks < 512 && T > 1) {
+        const int want = std::min(T, (1024 + base_blocks - 1) / base_blocks);
+        t_chunk = std::min(t_chunk, (T + want - 1) / want);
+        t_slices = (T + t_chunk - 1) / t_chunk;
+      }
+      const size_t lds2 = fixed_lds + static_cast<size_t>(t_chunk) * bs * 4;
+      const dim3 dense_grid(base_blocks, t_slices);
 #define DLIOM_LAUNCH_DENSE(PP, CL)                                                                                    \
   hipLaunchKernelGGL((rtcsm_score_dense_kernel<PP, CL>), dense_grid, block, lds2, ctx->stream, g, dom, cloud.d_xs,     \
                      cloud.d_ys, cloud.d_zs, chunk, point_chunks, rot_groups, d->rot, R, r_first, r_last, d->trans4, T, \
@@ -1628,6 +1639,12 @@ static const LutModel& lut_model() {
 static int rescore_method_default() {
   static const int m = env_int("DLIOM_RESCORE", 2);
   return m;
+}
+// Small clouds (the reference's ~170 filtered points): the serial replay is one launch of ~5 us, the chunk scan three;
+// all methods return identical bits (test_sequential_sum_kernels_bit_exact).
+static int rescore_method_for(int64_t n) {
+  static const int small_n = env_int("DLIOM_RESCORE_SERIAL_BELOW", 1024);
+  return n <= small_n ? 0 : rescore_method_default();
 }
 static int launch_sequential_sums(dliom_ctx* ctx, int method, const GridView& gv, const dliom_cloud& cloud,
                                   const float4* d_rot, int R, const float* d_trans, const unsigned* d_list,
@@ -1825,7 +1842,7 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
     auto rescore = [&](unsigned count, const unsigned* d_count, size_t list_offset) -> int {
       DLIOM_TRY(ctx->rescore.reserve((static_cast<size_t>(count) * 4 + 255) & ~static_cast<size_t>(255)));
       const int span = ctx->begin_span(DLIOM_KERNEL_RTCSM_RESCORE);
-      const int s = launch_sequential_sums(ctx, rescore_method_default(), st->grid->view(), cloud, st->d.rot, R, st->d.trans,
+      const int s = launch_sequential_sums(ctx, rescore_method_for(cloud.n), st->grid->view(), cloud, st->d.rot, R, st->d.trans,
                                            st->d_list + list_offset, d_count, count, &ctx->misc, ctx->rescore.as<float>());
       ctx->end_span(span);
       return s;
