@@ -342,6 +342,7 @@ struct MultiInsertArgs {
   const uint16_t* hit;
   const uint16_t* miss;
   int* status;  // per target: [needed bits, ray too long]
+  int* host_status;  // pinned host copy of `status`, written by pass 1 (null: not wanted) -- saves a copy dispatch
 };
 
 // Transformed + range-filtered hit of point i for target tg; false if filtered out.
@@ -376,6 +377,10 @@ __global__ void multi_insert_kernel(MultiInsertArgs a) {
   const int tgi = blockIdx.y;
   if (!((a.run_mask >> tgi) & 1u)) return;
   const InsertTarget& tg = a.tg[tgi];
+  // pass 0 has finished: its verdict goes to the host from here (the passes that follow are skipped per target)
+  if (PASS == 1 && a.host_status != nullptr && blockIdx.x == 0 && tgi == __ffs(a.run_mask) - 1 &&
+      threadIdx.x < 2 * kMaxInsertTargets)
+    a.host_status[threadIdx.x] = a.status[threadIdx.x];
   if (PASS > 0 && (a.status[2 * tgi] > tg.bits || a.status[2 * tgi + 1] != 0)) return;  // host first
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int hx = 0, hy = 0, hz = 0;
@@ -1014,6 +1019,7 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
   a.miss = ins->d_tables + 32768;
   a.run_mask = (1u << num_targets) - 1u;
   DLIOM_HIP_TRY(hipMemsetAsync(a.status, 0, 8 * kMaxInsertTargets, ctx->stream));
+  a.host_status = static_cast<int*>(ctx->pinned);  // device-visible; this call owns the block until it returns
   const dim3 grid_dim(blocks_for(n, 256), num_targets), block(256);
   const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
   hipLaunchKernelGGL(multi_insert_kernel<0>, grid_dim, block, 0, ctx->stream, a);
@@ -1025,8 +1031,9 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
     hipLaunchKernelGGL(multi_insert_kernel<4>, grid_dim, block, 0, ctx->stream, a);
     DLIOM_HIP_TRY(hipGetLastError());
     if (attempt == 0) {
-      DLIOM_HIP_TRY(hipMemcpyAsync(status, a.status, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
       DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      std::memcpy(status, a.host_status, sizeof(status));
+      a.host_status = nullptr;
       unsigned redo = 0;
       for (int k = 0; k < num_targets; ++k) {
         if (status[2 * k + 1] != 0) {
