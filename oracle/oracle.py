@@ -140,6 +140,8 @@ def _declare(L):
     sig("orc_motion_filter_is_similar", C.c_int, C.c_void_p, C.c_int64, _f64p)
     sig("orc_rotational_match", None, _f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p)
     sig("orc_kat_precomputation_grid", C.c_double)
+    sig("orc_kat_transform_get_angle", C.c_double)
+    sig("orc_kat_rigid_transform", C.c_double, C.c_int)
     sig("orc_kat_fast_csm", C.c_int, C.c_int, _f64p)
     sig("orc_imu_new", vp, _f64p, _f64p, _f64p)
     sig("orc_imu_free", None, vp)

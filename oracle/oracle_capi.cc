@@ -45,6 +45,59 @@ HybridGrid* G(void* g) { return static_cast<HybridGrid*>(g); }
 
 }  // namespace
 
+namespace {
+template <typename T>
+void ToMatrix(const Rigid3<T>& r, T m[16]) {  // Translation * Quaternion -> Transform::matrix()
+  const T w = r.rotation.w, x = r.rotation.x, y = r.rotation.y, z = r.rotation.z;
+  const T tx = T(2) * x, ty = T(2) * y, tz = T(2) * z;  // Eigen QuaternionBase::toRotationMatrix()
+  const T twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y,
+          tzz = tz * z;
+  const T rot[9] = {T(1) - (tyy + tzz), txy - twz, txz + twy, txy + twz, T(1) - (txx + tzz), tyz - twx,
+                    txz - twy,          tyz + twx, T(1) - (txx + tyy)};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) m[4 * i + j] = rot[3 * i + j];
+    m[12 + i] = T(0);
+  }
+  m[3] = r.translation.x;
+  m[7] = r.translation.y;
+  m[11] = r.translation.z;
+  m[15] = T(1);
+}
+template <typename T>
+double ApproxRatio(const Rigid3<T>& a, const Rigid3<T>& b) {
+  T ma[16], mb[16];
+  ToMatrix(a, ma);
+  ToMatrix(b, mb);
+  double d2 = 0., na = 0., nb = 0.;
+  for (int i = 0; i < 16; ++i) {
+    d2 += static_cast<double>(ma[i] - mb[i]) * static_cast<double>(ma[i] - mb[i]);
+    na += static_cast<double>(ma[i]) * ma[i];
+    nb += static_cast<double>(mb[i]) * mb[i];
+  }
+  return std::sqrt(d2) / (static_cast<double>(std::numeric_limits<T>::epsilon()) * std::sqrt(std::min(na, nb)));
+}
+template <typename T>
+double RigidTransformKat() {
+  double worst = 0.;
+  for (int test = 0; test < 2; ++test) {  // every TYPED_TEST has a fresh fixture: prng_(42)
+    std::mt19937 prng(42);
+    std::uniform_real_distribution<T> distribution(-1., 1.);
+    const T x = T(0.7) * distribution(prng), y = T(0.7) * distribution(prng), z = T(0.7) * distribution(prng);
+    const T ax = T(0.7) * distribution(prng), ay = T(0.7) * distribution(prng), az = T(0.7) * distribution(prng);
+    const Rigid3<T> pose(Vec3<T>(x, y, z), AngleAxisVectorToRotationQuaternion(Vec3<T>(ax, ay, az)));
+    const Rigid3<T> identity;
+    if (test == 0) {
+      worst = std::max(worst, ApproxRatio(pose * identity, pose));
+      worst = std::max(worst, ApproxRatio(identity * pose, pose));
+    } else {
+      worst = std::max(worst, ApproxRatio(pose.inverse() * pose, identity));
+      worst = std::max(worst, ApproxRatio(pose * pose.inverse(), identity));
+    }
+  }
+  return worst;
+}
+}  // namespace
+
 extern "C" {
 
 // ---------------------------------------------------------------- probability values
@@ -701,6 +754,35 @@ double orc_kat_precomputation_grid(void) {
   }
   return worst;
 }
+
+// transform/transform_test.cc:29-46 (TransformTest.GetAngle) run natively: 100 random (angle, axis) pairs from
+// std::mt19937(42); returns the largest |angle - GetAngle(Rotation(AngleAxisVectorToRotationQuaternion(angle * axis)))|
+// (the reference expects <= 1e-6).  Pins the two functions the RTCSM3D candidate generation is built from
+// (real_time_correlative_scan_matcher_3d.cc:58-92 -> transform/transform.h:33-37,85-99).
+double orc_kat_transform_get_angle(void) {
+  std::mt19937 rng(42);
+  std::uniform_real_distribution<float> angle_distribution(0.f, static_cast<float>(M_PI));
+  std::uniform_real_distribution<float> position_distribution(-1.f, 1.f);
+  double worst = 0.;
+  for (int i = 0; i != 100; ++i) {
+    const float angle = angle_distribution(rng);
+    const float x = position_distribution(rng);
+    const float y = position_distribution(rng);
+    const float z = position_distribution(rng);
+    const float n = std::sqrt(x * x + y * y + z * z);  // Eigen normalized(): v / sqrt(squaredNorm)
+    const Vec3f axis(x / n, y / n, z / n);
+    const Vec3f angle_axis(angle * axis.x, angle * axis.y, angle * axis.z);
+    const float got = GetAngle(Rigid3f::Rotation(AngleAxisVectorToRotationQuaternion(angle_axis)));
+    worst = std::max(worst, static_cast<double>(std::abs(angle - got)));
+  }
+  return worst;
+}
+
+// transform/rigid_transform_test.cc:33-94 (RigidTransformTest Identity3DTest / Inverse3DTest, float and double) run
+// natively with the fixture's std::mt19937(42) draws.  The reference compares 4 x 4 matrices with Eigen's
+// isApprox(eps): ||a - b||_F <= eps * min(||a||_F, ||b||_F), eps = numeric_limits<T>::epsilon().  Returns the largest
+// ||a - b||_F / (eps * min(||a||_F, ||b||_F)) over the six expectations of the two tests (<= 1 passes).
+double orc_kat_rigid_transform(int use_float) { return use_float ? RigidTransformKat<float>() : RigidTransformKat<double>(); }
 
 // fast_correlative_scan_matcher_3d_test.cc:35-190.  mode 0: CorrectPoseForMatch (20 random poses),
 // mode 1: CorrectPoseForMatchFullSubmap (1 pose).  Returns the number of failed expectations;

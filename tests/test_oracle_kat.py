@@ -271,6 +271,30 @@ def test_rtcsm3d_recovers_pose(orc, init):
     assert is_nearly(r["pose"], EXPECTED, 1e-3), r["pose"]
 
 
+def test_transform_get_angle(orc):
+    """transform/transform_test.cc:29-46 (TransformTest.GetAngle), run natively with the reference's std::mt19937(42)
+    draws: AngleAxisVectorToRotationQuaternion / GetAngle -- what the candidate rotations and their penalty angles
+    are made of (real_time_correlative_scan_matcher_3d.cc:58-92,105-110)."""
+    assert orc.lib().orc_kat_transform_get_angle() <= 1e-6
+
+
+@pytest.mark.parametrize("use_float", [1, 0])
+def test_rigid_transform_identity_and_inverse_3d(orc, use_float):
+    """transform/rigid_transform_test.cc:78-94 (Identity3DTest, Inverse3DTest, float and double), run natively with the
+    fixture's std::mt19937(42) draws and Eigen's isApprox(numeric epsilon) on the 4 x 4 matrices: Rigid3 product and
+    inverse (rigid_transform.h:167-171,206-212) -- every pose chain of the path goes through them."""
+    assert orc.lib().orc_kat_rigid_transform(use_float) <= 1.0
+
+
+def test_transform_point_cloud(orc):
+    """sensor/point_cloud_test.cc:28-39 (PointCloudTest.TransformPointCloud): Embed3D(Rigid2f::Rotation(pi / 2))."""
+    a = np.float32(np.pi / 2)
+    pose = np.array([0, 0, 0, np.cos(np.float32(0.5) * a), 0, 0, np.sin(np.float32(0.5) * a)], dtype=np.float32)
+    out = orc.transform_points(pose, np.array([[0.5, 0.5, 1.0], [3.5, 0.5, 42.0]], dtype=np.float32))
+    assert abs(out[0, 0] + 0.5) <= 1e-6 and abs(out[0, 1] - 0.5) <= 1e-6
+    assert abs(out[1, 0] + 0.5) <= 1e-6 and abs(out[1, 1] - 3.5) <= 1e-6
+
+
 def test_rtcsm3d_window_counts(orc):
     # SURVEY.md §8: reference unit test window = 7^3 x 3^3 = 9261 candidates
     w = orc.rtcsm3d_window(RTCSM_OPTS, 0.1, SEVEN_POINTS)
