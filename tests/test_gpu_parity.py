@@ -503,6 +503,57 @@ FRONT_END_OPTS = dict(
                  hit_probability=HIT_P, miss_probability=MISS_P, num_free_space_voxels=FREE))
 
 
+def test_front_end_reference_test_scenario(dl, ctx, orc):
+    """local_trajectory_builder_3d_test.cc's scenario (MoveInsideCubeUsingOnlyCeresScanMatcher: two orthogonal 16-beam
+    rangefinders, five scans at rest, the corkscrew in steps of t = 0.05, Ceres only, non-monotonic steps, 0.2 / 0.5 m
+    grids, no free-space voxels -- see tests/test_oracle_kat.py for the CPU side) through the device front end: the
+    same poses as the oracle's front end (<= 1e-6) and the reference test's IsNearly(expected, 1e-1)."""
+    from dliom import synth
+    import test_oracle_kat as kat
+    opts = dict(
+        high_resolution_adaptive_voxel_filter=dict(max_length=0.7, min_num_points=200, max_range=50.0),
+        low_resolution_adaptive_voxel_filter=dict(max_length=0.7, min_num_points=200, max_range=50.0),
+        use_online_correlative_scan_matching=False,
+        real_time_correlative_scan_matcher=dict(linear_search_window=0.2, angular_search_window=np.deg2rad(1.0),
+                                                translation_delta_cost_weight=1e-1, rotation_delta_cost_weight=1.0),
+        ceres_scan_matcher=dict(occupied_space_weight=[5.0, 20.0], translation_weight=0.1, rotation_weight=0.3,
+                                only_optimize_yaw=False, use_nonmonotonic_steps=True, max_num_iterations=20),
+        motion_filter=dict(max_time_seconds=0.2, max_distance_meters=0.02, max_angle_radians=0.001),
+        submaps=dict(high_resolution=0.2, high_resolution_max_range=50.0, low_resolution=0.5, num_range_data=45000,
+                     hit_probability=0.7, miss_probability=0.4, num_free_space_voxels=0))
+    bubbles = synth.bubbles()
+    identity = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    nodes = [identity] * 5 + [np.concatenate([[np.sin(4 * t), 1 - np.cos(4 * t), t],
+                                              synth.quat_from_axis_angle([1.0, -1.0, 2.0], 0.3 * t)])
+                              for t in 0.05 * np.arange(13)]
+    ofe, dfe = orc.FrontEnd(opts), dl.LocalTrajectoryBuilder3D(ctx, opts)
+    gravity = np.array([1.0, 0, 0, 0])
+    origin = np.zeros(3, np.float32)
+    est = []
+    for i, truth in enumerate(nodes):
+        pts = kat._ltb3d_test_scan(truth, bubbles)
+        rng = np.linalg.norm(pts, axis=1)
+        pts = pts[(rng >= 0.5) & (rng <= 50.0)]
+        pts = pts[orc.voxel_filter(0.2, pts)]
+        if len(est) >= 2:
+            pred = synth.pose_compose(est[-1], synth.pose_compose(synth.pose_inverse(est[-2]), est[-1]))
+        else:
+            pred = est[-1] if est else identity
+        ro, rd = ofe.match(pred, origin, pts), dfe.match(pred, origin, pts)
+        assert rd["dropped"] == ro["dropped"] is False
+        assert rd["num_high"] == ro["num_high"] and rd["num_low"] == ro["num_low"]
+        dt, da = pose_distance(rd["pose_estimate"], ro["pose_estimate"])
+        assert dt <= 1e-6 and da <= 1e-6, (i, dt, da)
+        assert np.linalg.norm(rd["pose_estimate"][:3] - truth[:3]) <= 0.1
+        t = int(3e6 * (i + 1))
+        io, idv = ofe.insert(t, ro["pose_estimate"], gravity), dfe.insert(t, ro["pose_estimate"], gravity)
+        assert idv["inserted"] == (io > 0)
+        est.append(ro["pose_estimate"])
+    so, sd = ofe.active_submap(0, (0.2, 0.5)), dfe.active_submap(0)
+    assert sd["hi"].cells() == oracle_cells_dict(so["hi"]) and sd["lo"].cells() == oracle_cells_dict(so["lo"])
+    dfe.close()
+
+
 @pytest.mark.parametrize("online", [True, False])
 def test_front_end_sequence_equals_oracle(dl, ctx, orc, online):
     """A 12-scan trajectory through LocalTrajectoryBuilder3D's AddAccumulatedRangeData /

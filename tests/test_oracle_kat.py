@@ -487,3 +487,81 @@ def test_motion_filter_rotational_motion(orc):
     assert f.is_similar(_sec(42), _rot_y(4.0))
     assert not f.is_similar(_sec(42), _rot_y(5.9))
     assert f.is_similar(_sec(42), IDENTITY)
+
+
+# ------------------------------------------------------------------ local_trajectory_builder_3d_test.cc (scenario)
+def _ltb3d_test_scan(pose, bubbles):
+    """GenerateRangeData (local_trajectory_builder_3d_test.cc:168-216): 16 beams x 500 azimuths of a horizontal
+    rangefinder and the same again rotated by pi / 2 about x, cast inside the 30 m cube with the 100 bubbles;
+    returns the hits in the SENSOR frame."""
+    from dliom import synth
+    r = np.arange(-8, 8)
+    s = np.arange(-250, 250)
+    th = (np.pi / 12.0) * r / 8.0           # AngleAxis(theta, UnitY) * UnitX = (cos, 0, -sin)
+    ph = np.pi * s / 250.0                  # AngleAxis(phi, UnitZ)
+    ct, st = np.cos(th), np.sin(th)
+    cp, sp = np.cos(ph), np.sin(ph)
+    first = np.stack([np.outer(ct, cp), np.outer(ct, sp), np.tile(-st[:, None], (1, len(s)))], axis=-1).reshape(-1, 3)
+    second = np.stack([first[:, 0], -first[:, 2], first[:, 1]], axis=1)  # AngleAxis(pi / 2, UnitX): (x, y, z) -> (x, -z, y)
+    dirs_s = np.concatenate([first, second])
+    R = synth.quat_to_matrix(pose[3:])
+    rng = synth.cast(pose[:3], dirs_s @ R.T, centers=bubbles)
+    return (dirs_s * rng[:, None]).astype(np.float32)
+
+
+def test_local_trajectory_builder_scenario_of_the_reference_test(orc):
+    """local_trajectory_builder_3d_test.cc:40-279, MoveInsideCubeUsingOnlyCeresScanMatcher: five scans at rest, then
+    the corkscrew in steps of t = 0.05, matched with CeresScanMatcher3D only under the test's options; every matched
+    pose must be IsNearly(expected, 1e-1) (Eigen isApprox on the 4 x 4 matrices).  The reference's own fixture is stale
+    in this fork (its Lua dictionary lacks keys the option parser reads), so the SCENARIO is run through the
+    oracle's front end (voxel filter 0.2 -> adaptive filters -> Ceres -> insertion) with a constant-velocity prediction
+    from the last two estimates where upstream uses its PoseExtrapolator."""
+    from dliom import synth
+    opts = dict(
+        high_resolution_adaptive_voxel_filter=dict(max_length=0.7, min_num_points=200, max_range=50.0),
+        low_resolution_adaptive_voxel_filter=dict(max_length=0.7, min_num_points=200, max_range=50.0),
+        use_online_correlative_scan_matching=False,
+        real_time_correlative_scan_matcher=dict(linear_search_window=0.2, angular_search_window=np.deg2rad(1.0),
+                                                translation_delta_cost_weight=1e-1, rotation_delta_cost_weight=1.0),
+        ceres_scan_matcher=dict(occupied_space_weight=[5.0, 20.0], translation_weight=0.1, rotation_weight=0.3,
+                                only_optimize_yaw=False, use_nonmonotonic_steps=True, max_num_iterations=20),
+        motion_filter=dict(max_time_seconds=0.2, max_distance_meters=0.02, max_angle_radians=0.001),
+        submaps=dict(high_resolution=0.2, high_resolution_max_range=50.0, low_resolution=0.5, num_range_data=45000,
+                     hit_probability=0.7, miss_probability=0.4, num_free_space_voxels=0))
+    bubbles = synth.bubbles()
+    identity = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    nodes = [identity] * 5
+    for k in range(13):  # t = 0, 0.05, ..., 0.6
+        t = 0.05 * k
+        nodes.append(np.concatenate([[np.sin(4 * t), 1 - np.cos(4 * t), t], synth.quat_from_axis_angle([1.0, -1.0, 2.0], 0.3 * t)]))
+    fe = orc.FrontEnd(opts)
+    gravity = np.array([1.0, 0, 0, 0])
+    est = []
+    worst = 0.0
+
+    def matrix(p):
+        m = np.eye(4)
+        m[:3, :3] = synth.quat_to_matrix(p[3:] / np.linalg.norm(p[3:]))
+        m[:3, 3] = p[:3]
+        return m
+
+    for i, truth in enumerate(nodes):
+        pts = _ltb3d_test_scan(truth, bubbles)
+        rng = np.linalg.norm(pts, axis=1)
+        pts = pts[(rng >= 0.5) & (rng <= 50.0)]
+        pts = pts[orc.voxel_filter(0.2, pts)]
+        if len(est) >= 2:  # constant velocity in the local frame of the last estimate
+            step = synth.pose_compose(synth.pose_inverse(est[-2]), est[-1])
+            pred = synth.pose_compose(est[-1], step)
+        else:
+            pred = est[-1] if est else identity
+        r = fe.match(pred, np.zeros(3, np.float32), pts)
+        assert not r["dropped"]
+        pose = r["pose_estimate"]
+        fe.insert(int(3e6 * (i + 1)), pose, gravity)
+        est.append(pose)
+        a, b = matrix(pose), matrix(truth)
+        ratio = np.linalg.norm(a - b) / min(np.linalg.norm(a), np.linalg.norm(b))
+        worst = max(worst, ratio)
+    assert worst <= 1e-1, worst
+    print("worst isApprox ratio %.4f" % worst)
