@@ -511,6 +511,34 @@ class Submap3D {
   bool finished() const { return finished_; }
   dliom_grid* high_resolution_hybrid_grid() const { return hi_; }
   dliom_grid* low_resolution_hybrid_grid() const { return lo_; }
+  // Submap3D::ToProto(proto::Submap*, include_probability_grid_data) (mapping/3d/submap_3d.cc:217-230) as the
+  // serialized bytes of proto::Submap{submap_3d}: proto.ParseFromString(submap.ToProtoBytes(true)) on the caller's side.
+  std::string ToProtoBytes(bool include_probability_grid_data) const {
+    std::string grids[2];
+    if (include_probability_grid_data) {
+      dliom_grid* const g[2] = {hi_, lo_};
+      for (int k = 0; k < 2; ++k) {
+        int64_t n = 0;
+        Check(dliom_grid_to_proto(g[k], nullptr, 0, &n), "dliom_grid_to_proto");
+        grids[k].resize(static_cast<size_t>(n));
+        Check(dliom_grid_to_proto(g[k], reinterpret_cast<uint8_t*>(&grids[k][0]), n, &n), "dliom_grid_to_proto");
+      }
+    }
+    const uint8_t dummy = 0;
+    auto ptr = [&](const std::string& b) {
+      return include_probability_grid_data ? (b.empty() ? &dummy : reinterpret_cast<const uint8_t*>(b.data())) : nullptr;
+    };
+    const std::array<double, 7> pose = local_pose_.ToArray();
+    int64_t n = 0;
+    Check(dliom_submap3d_to_proto(pose.data(), num_range_data_, finished_ ? 1 : 0, ptr(grids[0]),
+                                  static_cast<int64_t>(grids[0].size()), ptr(grids[1]), static_cast<int64_t>(grids[1].size()), 1,
+                                  nullptr, 0, &n), "dliom_submap3d_to_proto");
+    std::string out(static_cast<size_t>(n), '\0');
+    Check(dliom_submap3d_to_proto(pose.data(), num_range_data_, finished_ ? 1 : 0, ptr(grids[0]),
+                                  static_cast<int64_t>(grids[0].size()), ptr(grids[1]), static_cast<int64_t>(grids[1].size()), 1,
+                                  reinterpret_cast<uint8_t*>(&out[0]), n, &n), "dliom_submap3d_to_proto");
+    return out;
+  }
 
  private:
   transform::Rigid3d local_pose_;

@@ -192,3 +192,171 @@ extern "C" int dliom_grid_from_proto(dliom_ctx* ctx, const uint8_t* buffer, int6
   }
   return DLIOM_OK;
 }
+
+
+// ---- mapping::proto::Submap3D around two serialized grids (mapping/proto/submap.proto, transform/proto/transform.proto)
+namespace {
+void put_double_field(std::vector<uint8_t>* out, int field, double v) {
+  if (v == 0.0) return;  // proto3 implicit presence, as the C++ runtime decides it (x != 0)
+  put_varint(out, static_cast<uint64_t>(field) << 3 | 1);
+  uint64_t bits;
+  std::memcpy(&bits, &v, 8);
+  for (int i = 0; i < 8; ++i) out->push_back(static_cast<uint8_t>(bits >> (8 * i)));
+}
+void put_message(std::vector<uint8_t>* out, int field, const std::vector<uint8_t>& payload) {
+  put_varint(out, static_cast<uint64_t>(field) << 3 | 2);  // a present sub-message is emitted even when empty
+  put_varint(out, payload.size());
+  out->insert(out->end(), payload.begin(), payload.end());
+}
+void put_bytes(std::vector<uint8_t>* out, int field, const uint8_t* p, int64_t n) {
+  put_varint(out, static_cast<uint64_t>(field) << 3 | 2);
+  put_varint(out, static_cast<uint64_t>(n));
+  out->insert(out->end(), p, p + n);
+}
+bool skip_field(const uint8_t*& p, const uint8_t* end, unsigned wire) {
+  uint64_t v;
+  switch (wire) {
+    case 0: return get_varint(p, end, &v);
+    case 1: if (end - p < 8) return false; p += 8; return true;
+    case 2: if (!get_varint(p, end, &v) || static_cast<uint64_t>(end - p) < v) return false; p += v; return true;
+    case 5: if (end - p < 4) return false; p += 4; return true;
+    default: return false;
+  }
+}
+// doubles of a Vector3d / Quaterniond message into dst[field - 1]
+bool parse_doubles(const uint8_t* p, const uint8_t* end, double* dst, int max_field) {
+  while (p < end) {
+    uint64_t tag;
+    if (!get_varint(p, end, &tag)) return false;
+    const unsigned wire = static_cast<unsigned>(tag & 7), field = static_cast<unsigned>(tag >> 3);
+    if (wire == 1 && field >= 1 && field <= static_cast<unsigned>(max_field)) {
+      if (end - p < 8) return false;
+      uint64_t bits = 0;
+      for (int i = 0; i < 8; ++i) bits |= static_cast<uint64_t>(p[i]) << (8 * i);
+      std::memcpy(&dst[field - 1], &bits, 8);
+      p += 8;
+    } else if (!skip_field(p, end, wire)) {
+      return false;
+    }
+  }
+  return true;
+}
+}  // namespace
+
+extern "C" int dliom_submap3d_to_proto(const double local_pose7[7], int32_t num_range_data, int finished,
+                                       const uint8_t* hi, int64_t hi_size, const uint8_t* lo, int64_t lo_size,
+                                       int wrap_in_submap, uint8_t* buffer, int64_t capacity, int64_t* size) {
+  if (local_pose7 == nullptr || size == nullptr || capacity < 0 || (hi != nullptr && hi_size < 0) ||
+      (lo != nullptr && lo_size < 0))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  std::vector<uint8_t> translation, rotation, pose, msg;
+  for (int i = 0; i < 3; ++i) put_double_field(&translation, i + 1, local_pose7[i]);  // Vector3d x, y, z
+  put_double_field(&rotation, 1, local_pose7[4]);                                      // Quaterniond x, y, z, w
+  put_double_field(&rotation, 2, local_pose7[5]);
+  put_double_field(&rotation, 3, local_pose7[6]);
+  put_double_field(&rotation, 4, local_pose7[3]);
+  put_message(&pose, 1, translation);  // transform::ToProto(Rigid3d) sets both sub-messages
+  put_message(&pose, 2, rotation);
+  put_message(&msg, 1, pose);
+  if (num_range_data != 0) {
+    put_varint(&msg, 2u << 3 | 0);
+    put_varint(&msg, static_cast<uint64_t>(static_cast<int64_t>(num_range_data)));  // int32: sign-extended to 64 bits
+  }
+  if (finished != 0) {
+    put_varint(&msg, 3u << 3 | 0);
+    msg.push_back(1);
+  }
+  if (hi != nullptr) put_bytes(&msg, 4, hi, hi_size);
+  if (lo != nullptr) put_bytes(&msg, 5, lo, lo_size);
+  std::vector<uint8_t> outer;
+  if (wrap_in_submap != 0) {
+    put_message(&outer, 2, msg);  // proto::Submap.submap_3d
+    msg.swap(outer);
+  }
+  *size = static_cast<int64_t>(msg.size());
+  if (buffer == nullptr) return DLIOM_OK;
+  if (capacity < *size) return DLIOM_ERR_CAPACITY;
+  std::memcpy(buffer, msg.data(), msg.size());
+  return DLIOM_OK;
+}
+
+extern "C" int dliom_submap3d_from_proto(const uint8_t* buffer, int64_t size, int wrapped_in_submap, double local_pose7[7],
+                                         int32_t* num_range_data, int* finished, int64_t* hi_offset, int64_t* hi_size,
+                                         int64_t* lo_offset, int64_t* lo_size) {
+  if (buffer == nullptr || size < 0 || local_pose7 == nullptr || num_range_data == nullptr || finished == nullptr ||
+      hi_offset == nullptr || hi_size == nullptr || lo_offset == nullptr || lo_size == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  const uint8_t* p = buffer;
+  const uint8_t* end = buffer + size;
+  if (wrapped_in_submap != 0) {  // proto::Submap: find field 2 (the last occurrence wins, as protobuf merges)
+    const uint8_t* body = nullptr;
+    uint64_t body_len = 0;
+    while (p < end) {
+      uint64_t tag, len;
+      if (!get_varint(p, end, &tag)) return DLIOM_ERR_INVALID_ARGUMENT;
+      if ((tag & 7) == 2 && (tag >> 3) == 2) {
+        if (!get_varint(p, end, &len) || static_cast<uint64_t>(end - p) < len) return DLIOM_ERR_INVALID_ARGUMENT;
+        body = p;
+        body_len = len;
+        p += len;
+      } else if (!skip_field(p, end, static_cast<unsigned>(tag & 7))) {
+        return DLIOM_ERR_INVALID_ARGUMENT;
+      }
+    }
+    if (body == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;  // CHECK(proto.has_submap_3d())
+    p = body;
+    end = body + body_len;
+  }
+  double t[3] = {0, 0, 0}, q[4] = {0, 0, 0, 0};  // proto3 defaults (x, y, z, w)
+  *num_range_data = 0;
+  *finished = 0;
+  *hi_offset = *lo_offset = 0;
+  *hi_size = *lo_size = -1;
+  while (p < end) {
+    uint64_t tag;
+    if (!get_varint(p, end, &tag)) return DLIOM_ERR_INVALID_ARGUMENT;
+    const unsigned wire = static_cast<unsigned>(tag & 7), field = static_cast<unsigned>(tag >> 3);
+    if (wire == 2 && (field == 1 || field == 4 || field == 5)) {
+      uint64_t len;
+      if (!get_varint(p, end, &len) || static_cast<uint64_t>(end - p) < len) return DLIOM_ERR_INVALID_ARGUMENT;
+      if (field == 4) {
+        *hi_offset = p - buffer;
+        *hi_size = static_cast<int64_t>(len);
+      } else if (field == 5) {
+        *lo_offset = p - buffer;
+        *lo_size = static_cast<int64_t>(len);
+      } else {  // Rigid3d: 1 translation, 2 rotation
+        const uint8_t* r = p;
+        const uint8_t* rend = p + len;
+        while (r < rend) {
+          uint64_t rtag, rlen;
+          if (!get_varint(r, rend, &rtag)) return DLIOM_ERR_INVALID_ARGUMENT;
+          if ((rtag & 7) == 2 && ((rtag >> 3) == 1 || (rtag >> 3) == 2)) {
+            if (!get_varint(r, rend, &rlen) || static_cast<uint64_t>(rend - r) < rlen) return DLIOM_ERR_INVALID_ARGUMENT;
+            const bool ok = (rtag >> 3) == 1 ? parse_doubles(r, r + rlen, t, 3) : parse_doubles(r, r + rlen, q, 4);
+            if (!ok) return DLIOM_ERR_INVALID_ARGUMENT;
+            r += rlen;
+          } else if (!skip_field(r, rend, static_cast<unsigned>(rtag & 7))) {
+            return DLIOM_ERR_INVALID_ARGUMENT;
+          }
+        }
+      }
+      p += len;
+    } else if (wire == 0 && (field == 2 || field == 3)) {
+      uint64_t v;
+      if (!get_varint(p, end, &v)) return DLIOM_ERR_INVALID_ARGUMENT;
+      if (field == 2) *num_range_data = static_cast<int32_t>(v);
+      else *finished = v != 0 ? 1 : 0;
+    } else if (!skip_field(p, end, wire)) {
+      return DLIOM_ERR_INVALID_ARGUMENT;
+    }
+  }
+  local_pose7[0] = t[0];
+  local_pose7[1] = t[1];
+  local_pose7[2] = t[2];
+  local_pose7[3] = q[3];  // w
+  local_pose7[4] = q[0];
+  local_pose7[5] = q[1];
+  local_pose7[6] = q[2];
+  return DLIOM_OK;
+}

@@ -181,6 +181,10 @@ SYMBOLS = [
     ("dliom_grid_get_values", C.c_int, [_vp, _i32p, C.c_int64, _u16p]),
     ("dliom_grid_to_proto", C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int64, _i64p]),
     ("dliom_grid_from_proto", C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int64, C.POINTER(_vp)]),
+    ("dliom_submap3d_to_proto", C.c_int, [_f64p, C.c_int32, C.c_int, C.POINTER(C.c_uint8), C.c_int64, C.POINTER(C.c_uint8),
+                                          C.c_int64, C.c_int, C.POINTER(C.c_uint8), C.c_int64, _i64p]),
+    ("dliom_submap3d_from_proto", C.c_int, [C.POINTER(C.c_uint8), C.c_int64, C.c_int, _f64p, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int), _i64p, _i64p, _i64p, _i64p]),
     ("dliom_grid_insert", C.c_int, [_vp, _f32p, _f32p, C.c_int64, _u16p, _u16p, C.c_int]),
     ("dliom_inserter_create", C.c_int, [_vp, C.c_double, C.c_double, C.c_int, C.POINTER(_vp)]),
     ("dliom_inserter_destroy", C.c_int, [_vp]),
@@ -797,6 +801,40 @@ class CeresScanMatcher3D:
                                             _p(ns, _i64p), grids, C.byref(cost), _p(grad, _f64p), _p(jtj, _f64p)),
                "dliom_csm3d_evaluate")
         return cost.value, grad, jtj
+
+
+def submap3d_to_proto(local_pose7, num_range_data, finished, high_grid_proto=None, low_grid_proto=None, wrap=False):
+    """Serialized mapping::proto::Submap3D (or proto::Submap around it) -- Submap3D::ToProto, host only."""
+    L = load_library()
+
+    def buf(b):
+        return (None, 0) if b is None else ((C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if len(b) else b"\0"), len(b))
+    (hp, hn), (lp, ln) = buf(high_grid_proto), buf(low_grid_proto)
+    if high_grid_proto is not None and hn == 0:
+        hp = (C.c_uint8 * 1)()
+    if low_grid_proto is not None and ln == 0:
+        lp = (C.c_uint8 * 1)()
+    pose = _f64(local_pose7)
+    n = C.c_int64()
+    args = (_p(pose, _f64p), int(num_range_data), int(bool(finished)), hp, hn, lp, ln, int(bool(wrap)))
+    _check(L.dliom_submap3d_to_proto(*args, None, 0, C.byref(n)), "dliom_submap3d_to_proto")
+    out = (C.c_uint8 * max(n.value, 1))()
+    _check(L.dliom_submap3d_to_proto(*args, out, n.value, C.byref(n)), "dliom_submap3d_to_proto")
+    return bytes(out[:n.value])
+
+
+def submap3d_from_proto(data, wrapped=False):
+    """(local_pose7, num_range_data, finished, high grid bytes or None, low grid bytes or None)."""
+    L = load_library()
+    b = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if len(data) else b"\0")
+    pose = np.zeros(7)
+    n, fin = C.c_int32(), C.c_int()
+    ho, hs, lo, ls = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    _check(L.dliom_submap3d_from_proto(b, len(data), int(bool(wrapped)), _p(pose, _f64p), C.byref(n), C.byref(fin),
+                                       C.byref(ho), C.byref(hs), C.byref(lo), C.byref(ls)), "dliom_submap3d_from_proto")
+    hi = None if hs.value < 0 else bytes(data[ho.value:ho.value + hs.value])
+    low = None if ls.value < 0 else bytes(data[lo.value:lo.value + ls.value])
+    return pose, n.value, bool(fin.value), hi, low
 
 
 def voxel_filter(size, points):

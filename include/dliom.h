@@ -99,6 +99,21 @@ int dliom_grid_set_values(dliom_grid* grid, const int32_t* cell_xyz, const uint1
  * pbstream files and Submap3D::ToProto / UpdateFromProto (submap_3d.cc:217-250). */
 int dliom_grid_to_proto(const dliom_grid* grid, uint8_t* buffer, int64_t capacity, int64_t* size);
 int dliom_grid_from_proto(dliom_ctx* ctx, const uint8_t* buffer, int64_t size, dliom_grid** out);
+/* mapping::proto::Submap3D (mapping/proto/submap.proto) around two serialized HybridGrid messages -- the message
+ * Submap3D::ToProto fills (submap_3d.cc:217-230: local_pose, num_range_data, finished, the grids when
+ * include_probability_grid_data) and the Submap3D(proto) constructor / UpdateFromProto read (:207-215,232-250).
+ * Host only; the grid bytes come from / go to dliom_grid_to_proto / dliom_grid_from_proto.
+ *   to_proto    *_grid_proto == NULL: that grid is absent (include_probability_grid_data == false);
+ *               wrap_in_submap != 0: the bytes of proto::Submap{submap_3d = ...} as Submap3D::ToProto(proto::Submap*) emits;
+ *               scalar fields equal to zero are omitted as the C++ proto3 runtime does; buffer == NULL queries *size
+ *   from_proto  the grids are returned as (offset, size) into `buffer`, size -1 = absent */
+int dliom_submap3d_to_proto(const double local_pose7[7], int32_t num_range_data, int finished,
+                            const uint8_t* high_resolution_grid_proto, int64_t high_size,
+                            const uint8_t* low_resolution_grid_proto, int64_t low_size, int wrap_in_submap,
+                            uint8_t* buffer, int64_t capacity, int64_t* size);
+int dliom_submap3d_from_proto(const uint8_t* buffer, int64_t size, int wrapped_in_submap, double local_pose7[7],
+                              int32_t* num_range_data, int* finished, int64_t* high_offset, int64_t* high_size,
+                              int64_t* low_offset, int64_t* low_size);
 /* HybridGrid::value() for n cell indices (0 outside / unallocated). */
 int dliom_grid_get_values(const dliom_grid* grid, const int32_t* cell_xyz, int64_t n,
                           uint16_t* values);

@@ -259,3 +259,105 @@ def test_synthetic_imu_matches_the_trajectory_it_was_derived_from():
             assert np.allclose(gyr, 0.3 * synth.AXIS)
     finally:
         synth.set_trajectory(1.0, 4.0)
+
+
+def _submap_proto_classes():
+    """Message classes built from the reference's .proto files (transform/proto/transform.proto,
+    mapping/proto/3d/hybrid_grid.proto, mapping/proto/submap.proto) with google.protobuf's descriptor API."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    T = descriptor_pb2.FieldDescriptorProto
+    pool = descriptor_pool.DescriptorPool()
+    f = descriptor_pb2.FileDescriptorProto()
+    f.name, f.package, f.syntax = "cartographer/transform/proto/transform.proto", "cartographer.transform.proto", "proto3"
+    for name, fields in (("Vector3d", "xyz"), ("Quaterniond", "xyzw")):
+        m = f.message_type.add()
+        m.name = name
+        for i, c in enumerate(fields):
+            fd = m.field.add()
+            fd.name, fd.number, fd.type, fd.label = c, i + 1, T.TYPE_DOUBLE, T.LABEL_OPTIONAL
+    m = f.message_type.add()
+    m.name = "Rigid3d"
+    for i, (n, t) in enumerate((("translation", "Vector3d"), ("rotation", "Quaterniond"))):
+        fd = m.field.add()
+        fd.name, fd.number, fd.type, fd.label = n, i + 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL
+        fd.type_name = ".cartographer.transform.proto." + t
+    pool.Add(f)
+    g = descriptor_pb2.FileDescriptorProto()
+    g.name, g.package, g.syntax = "cartographer/mapping/proto/submap.proto", "cartographer.mapping.proto", "proto3"
+    g.dependency.append(f.name)
+    m = g.message_type.add()
+    m.name = "HybridGrid"
+    for name, number, typ, label in (("resolution", 1, T.TYPE_FLOAT, T.LABEL_OPTIONAL), ("x_indices", 3, T.TYPE_SINT32, T.LABEL_REPEATED),
+                                     ("y_indices", 4, T.TYPE_SINT32, T.LABEL_REPEATED), ("z_indices", 5, T.TYPE_SINT32, T.LABEL_REPEATED),
+                                     ("values", 6, T.TYPE_INT32, T.LABEL_REPEATED)):
+        fd = m.field.add()
+        fd.name, fd.number, fd.type, fd.label = name, number, typ, label
+    m = g.message_type.add()
+    m.name = "Submap3D"
+    for name, number, typ, tn in (("local_pose", 1, T.TYPE_MESSAGE, ".cartographer.transform.proto.Rigid3d"),
+                                  ("num_range_data", 2, T.TYPE_INT32, None), ("finished", 3, T.TYPE_BOOL, None),
+                                  ("high_resolution_hybrid_grid", 4, T.TYPE_MESSAGE, ".cartographer.mapping.proto.HybridGrid"),
+                                  ("low_resolution_hybrid_grid", 5, T.TYPE_MESSAGE, ".cartographer.mapping.proto.HybridGrid")):
+        fd = m.field.add()
+        fd.name, fd.number, fd.type, fd.label = name, number, typ, T.LABEL_OPTIONAL
+        if tn:
+            fd.type_name = tn
+    m = g.message_type.add()
+    m.name = "Submap"
+    fd = m.field.add()  # submap_2d = 1 is not needed here
+    fd.name, fd.number, fd.type, fd.label, fd.type_name = "submap_3d", 2, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".cartographer.mapping.proto.Submap3D"
+    pool.Add(g)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName(n))  # noqa: E731
+    return get("cartographer.mapping.proto.Submap3D"), get("cartographer.mapping.proto.Submap"), get("cartographer.mapping.proto.HybridGrid")
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_submap3d_proto_equals_google_protobuf(case):
+    """dliom_submap3d_to_proto / _from_proto against google.protobuf's serialisation of mapping::proto::Submap3D as
+    Submap3D::ToProto fills it (mapping/3d/submap_3d.cc:217-230) -- the submap_3d_test.cc:ToFromProto round trip
+    included (case 0: its pose, no range data, not finished, empty grids)."""
+    import dliom as dl
+    Submap3D, Submap, HybridGrid = _submap_proto_classes()
+    rng = np.random.RandomState(case)
+    if case == 0:
+        pose, num, fin = np.array([1.0, 2.0, 0.0, 0.0, 0.0, 0.0, 1.0]), 0, False  # Rigid3d((1, 2, 0), Quaterniond(0, 0, 0, 1))
+        grids = [HybridGrid(resolution=0.05), HybridGrid(resolution=0.25)]
+    else:
+        q = rng.normal(size=4)
+        pose = np.concatenate([rng.uniform(-50, 50, 3), q / np.linalg.norm(q)])
+        num, fin = int(rng.randint(0, 200)), bool(case % 2)
+        grids = []
+        for res in (0.1, 0.45):
+            gmsg = HybridGrid(resolution=res)
+            n = int(rng.randint(0, 300))
+            gmsg.x_indices.extend(int(v) for v in rng.randint(-400, 400, n))
+            gmsg.y_indices.extend(int(v) for v in rng.randint(-400, 400, n))
+            gmsg.z_indices.extend(int(v) for v in rng.randint(-60, 60, n))
+            gmsg.values.extend(int(v) for v in rng.randint(1, 32768, n))
+            grids.append(gmsg)
+    with_grids = case != 3  # include_probability_grid_data == false
+    msg = Submap3D()
+    msg.local_pose.translation.x, msg.local_pose.translation.y, msg.local_pose.translation.z = pose[:3]
+    msg.local_pose.rotation.w, msg.local_pose.rotation.x, msg.local_pose.rotation.y, msg.local_pose.rotation.z = pose[3:]
+    msg.local_pose.translation.SetInParent()
+    msg.local_pose.rotation.SetInParent()
+    msg.num_range_data, msg.finished = num, fin
+    if with_grids:
+        msg.high_resolution_hybrid_grid.CopyFrom(grids[0])
+        msg.low_resolution_hybrid_grid.CopyFrom(grids[1])
+    want = msg.SerializeToString(deterministic=True)
+    hi = grids[0].SerializeToString() if with_grids else None
+    lo = grids[1].SerializeToString() if with_grids else None
+    got = dl.submap3d_to_proto(pose, num, fin, hi, lo)
+    assert got == want
+    outer = Submap()
+    outer.submap_3d.CopyFrom(msg)
+    assert dl.submap3d_to_proto(pose, num, fin, hi, lo, wrap=True) == outer.SerializeToString(deterministic=True)
+    for data, wrapped in ((want, False), (outer.SerializeToString(), True)):
+        p2, n2, f2, h2, l2 = dl.submap3d_from_proto(data, wrapped=wrapped)
+        assert np.array_equal(p2, pose) and n2 == num and f2 == fin
+        assert h2 == hi and l2 == lo
+        if with_grids:
+            back = HybridGrid()
+            back.ParseFromString(h2)
+            assert back == grids[0]
