@@ -69,6 +69,19 @@ int main(int argc, char** argv) {
   std::fclose(f);
   const auto submaps = builder.active_submaps().submaps();
   std::printf("SUBMAPS %zu matching_index %d results %d\n", submaps.size(), builder.active_submaps().matching_index(), results);
+  if (!submaps.empty()) {  // Submap3D::ToProto round trip: header fields back out of the serialized proto::Submap
+    const std::string bytes = submaps[0]->ToProtoBytes(true);
+    double pose[7];
+    int32_t num = -1;
+    int fin = -1;
+    int64_t ho = 0, hs = 0, lo = 0, ls = 0;
+    const int st = dliom_submap3d_from_proto(reinterpret_cast<const uint8_t*>(bytes.data()), static_cast<int64_t>(bytes.size()), 1,
+                                             pose, &num, &fin, &ho, &hs, &lo, &ls);
+    std::printf("SUBMAP_PROTO status %d bytes %zu num_range_data %d (%d) finished %d (%d) grids %lld %lld\n", st, bytes.size(), num,
+                submaps[0]->num_range_data(), fin, submaps[0]->finished() ? 1 : 0, static_cast<long long>(hs),
+                static_cast<long long>(ls));
+    if (st != 0 || num != submaps[0]->num_range_data() || fin != (submaps[0]->finished() ? 1 : 0) || hs <= 0 || ls <= 0) return 3;
+  }
   std::printf("LTB3D ADAPTER DONE\n");
   return 0;
 }
