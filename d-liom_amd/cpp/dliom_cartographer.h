@@ -499,6 +499,7 @@ struct LocalTrajectoryBuilderOptions3D {
   float voxel_filter_size = 0.15f;
   double scan_period = 0.1;
   bool enable_manual_descrew = false;    // eable_mannually_discrew_
+  int rotational_histogram_size = 120;   // trajectory_builder_3d.lua: rotational_histogram_size
 };
 
 // A submap of the active pair; the grids stay owned by the front end (borrowed handles).
@@ -605,6 +606,9 @@ class LocalTrajectoryBuilder3D {
     transform::Rigid3d local_pose;
     std::vector<int> insertion_submap_indices;  // trajectory-wide indices of the submaps inserted into
     bool submap_finished;                        // take it with dliom_front_end_take_finished_submap
+    // TrajectoryNode::Data::rotational_scan_matcher_histogram (.cc:605-610): what the loop-closure matcher's
+    // RotationalScanMatcher is built from (FastCorrelativeScanMatcher3D's `nodes`)
+    std::vector<float> rotational_scan_matcher_histogram;
   };
   struct MatchingResult {
     int64_t time;
@@ -732,6 +736,20 @@ class LocalTrajectoryBuilder3D {
       ir->local_pose = result->local_pose;
       for (int i = 0; i < ins.num_insertion_submaps; ++i) ir->insertion_submap_indices.push_back(ins.insertion_submap_index[i]);
       ir->submap_finished = ins.submap_finished != 0;
+      // ComputeHistogram(TransformPointCloud(filtered_range_data_in_tracking.returns, Rotation(gravity_alignment.cast<float>())), size)
+      if (options_.rotational_histogram_size > 0) {
+        const float rot[7] = {0.f, 0.f, 0.f, pf[3], pf[4], pf[5], pf[6]};
+        std::vector<float> aligned(3 * static_cast<size_t>(n));
+        for (int64_t i = 0; i < n; ++i) {
+          const sensor::Vector3f a = TransformPoint(rot, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+          aligned[3 * i] = a.x;
+          aligned[3 * i + 1] = a.y;
+          aligned[3 * i + 2] = a.z;
+        }
+        ir->rotational_scan_matcher_histogram.resize(static_cast<size_t>(options_.rotational_histogram_size));
+        Check(dliom_rotational_histogram(aligned.data(), n, options_.rotational_histogram_size,
+                                         ir->rotational_scan_matcher_histogram.data()), "RotationalScanMatcher::ComputeHistogram");
+      }
       result->insertion_result = std::move(ir);
     }
     return result;

@@ -63,6 +63,12 @@ int main(int argc, char** argv) {
       const std::array<double, 7> p = r->local_pose.ToArray();
       std::printf("RESULT %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %zu %d\n", s, p[0], p[1], p[2], p[3], p[4], p[5], p[6],
                   r->range_data_in_local.returns.size(), r->insertion_result != nullptr ? 1 : 0);
+      if (r->insertion_result != nullptr) {  // TrajectoryNode::Data::rotational_scan_matcher_histogram
+        double sum = 0.;
+        for (float v : r->insertion_result->rotational_scan_matcher_histogram) sum += v;
+        std::printf("HISTOGRAM %d %zu %.9g\n", s, r->insertion_result->rotational_scan_matcher_histogram.size(), sum);
+        if (r->insertion_result->rotational_scan_matcher_histogram.size() != 120u || !(sum > 0.)) return 4;
+      }
       ++results;
     }
   }
