@@ -609,6 +609,9 @@ class LocalTrajectoryBuilder3D {
     // TrajectoryNode::Data::rotational_scan_matcher_histogram (.cc:605-610): what the loop-closure matcher's
     // RotationalScanMatcher is built from (FastCorrelativeScanMatcher3D's `nodes`)
     std::vector<float> rotational_scan_matcher_histogram;
+    // TrajectoryNode::Data::high_resolution_point_cloud / low_resolution_point_cloud (.cc:613-619): the adaptively
+    // filtered clouds in the tracking frame, what ConstraintBuilder3D matches against finished submaps
+    sensor::PointCloud high_resolution_point_cloud, low_resolution_point_cloud;
   };
   struct MatchingResult {
     int64_t time;
@@ -749,6 +752,16 @@ class LocalTrajectoryBuilder3D {
         ir->rotational_scan_matcher_histogram.resize(static_cast<size_t>(options_.rotational_histogram_size));
         Check(dliom_rotational_histogram(aligned.data(), n, options_.rotational_histogram_size,
                                          ir->rotational_scan_matcher_histogram.data()), "RotationalScanMatcher::ComputeHistogram");
+      }
+      const dliom_cloud* filtered[2] = {nullptr, nullptr};
+      Check(dliom_front_end_matched_clouds(active_submaps_.get(), &filtered[0], &filtered[1]), "matched clouds");
+      sensor::PointCloud* const dst[2] = {&ir->high_resolution_point_cloud, &ir->low_resolution_point_cloud};
+      for (int k = 0; k < 2; ++k) {
+        int64_t m_points = 0;
+        if (filtered[k] == nullptr) continue;
+        Check(dliom_cloud_size(filtered[k], &m_points), "dliom_cloud_size");
+        dst[k]->resize(static_cast<size_t>(m_points));
+        if (m_points > 0) Check(dliom_cloud_download(filtered[k], &(*dst[k])[0].x), "dliom_cloud_download");
       }
       result->insertion_result = std::move(ir);
     }

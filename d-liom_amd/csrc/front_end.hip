@@ -109,6 +109,15 @@ struct dliom_front_end {
   float origin[3] = {0, 0, 0};
   dliom_cloud* returns_cloud = nullptr;
   bool owns_returns_cloud = false;
+  // the adaptively filtered clouds of the last match (TrajectoryNode::Data::high / low_resolution_point_cloud),
+  // kept until the next match replaces them
+  dliom_cloud* matched_hi = nullptr;
+  dliom_cloud* matched_lo = nullptr;
+  void drop_matched() {
+    if (matched_hi != nullptr) dliom_cloud_destroy(matched_hi);
+    if (matched_lo != nullptr) dliom_cloud_destroy(matched_lo);
+    matched_hi = matched_lo = nullptr;
+  }
 
   int add_submap(const PoseD& local_pose, int* finished_flag) {
     // submap_3d.cc:316-326
@@ -208,6 +217,7 @@ int dliom_front_end_destroy(dliom_front_end* fe) {
       if (s->lo) dliom_grid_destroy(s->lo);
     }
   if (fe->returns_cloud && fe->owns_returns_cloud) dliom_cloud_destroy(fe->returns_cloud);
+  fe->drop_matched();
   if (fe->inserter) dliom_inserter_destroy(fe->inserter);
   delete fe;
   return DLIOM_OK;
@@ -224,6 +234,14 @@ int dliom_front_end_match(dliom_front_end* fe, const double pose_prediction7[7],
   const int s = front_end_match_cloud(fe, pose_prediction7, origin, cloud, true, r);
   if (s != DLIOM_OK && fe->returns_cloud != cloud) dliom_cloud_destroy(cloud);
   return s;
+}
+
+int dliom_front_end_matched_clouds(const dliom_front_end* fe, const dliom_cloud** high_resolution,
+                                   const dliom_cloud** low_resolution) {
+  if (fe == nullptr || high_resolution == nullptr || low_resolution == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *high_resolution = fe->matched_hi;
+  *low_resolution = fe->matched_lo;
+  return DLIOM_OK;
 }
 
 int dliom_front_end_match_cloud(dliom_front_end* fe, const double pose_prediction7[7], const float origin[3],
@@ -245,6 +263,7 @@ static int front_end_match_cloud(dliom_front_end* fe, const double pose_predicti
   if (fe->returns_cloud != nullptr && fe->owns_returns_cloud) dliom_cloud_destroy(fe->returns_cloud);
   fe->returns_cloud = cloud;
   fe->owns_returns_cloud = take_ownership;
+  fe->drop_matched();
   if (cloud->n == 0) {  // "Dropped empty range data." (:497-500)
     r->dropped = 1;
     return DLIOM_OK;
@@ -307,6 +326,9 @@ static int front_end_match_cloud(dliom_front_end* fe, const double pose_predicti
     r->residual_angle = 2.0 * std::atan2(std::sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]), std::fabs(d[0]));
   }
   pose_to(pose_mul(matching.local_pose, observation), r->pose_estimate);  // :552-553
+  fe->matched_hi = hi.c;  // the guards let go: dliom_front_end_matched_clouds hands them to the caller's InsertionResult
+  fe->matched_lo = lo.c;
+  hi.c = lo.c = nullptr;
   return DLIOM_OK;
 }
 

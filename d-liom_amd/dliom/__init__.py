@@ -227,6 +227,7 @@ SYMBOLS = [
     ("dliom_front_end_num_finished_submaps", C.c_int, [_vp, C.POINTER(C.c_int)]),
     ("dliom_front_end_take_finished_submap", C.c_int, [_vp, _f64p, C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_front_end_matching_index", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("dliom_front_end_matched_clouds", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_front_end_active_submap", C.c_int, [_vp, C.c_int, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                 C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_voxel_filter", C.c_int, [C.c_float, _f32p, C.c_int64, _f32p, _i64p]),

@@ -370,6 +370,11 @@ int dliom_front_end_insert_range_data(dliom_front_end* fe, const float origin_in
 int dliom_front_end_num_finished_submaps(const dliom_front_end* fe, int* n);
 int dliom_front_end_take_finished_submap(dliom_front_end* fe, double local_pose[7], int* num_range_data,
                                          dliom_grid** high_resolution_grid, dliom_grid** low_resolution_grid);
+/* The adaptively filtered clouds of the last successful match, in the tracking frame -- TrajectoryNode::Data's
+ * high_resolution_point_cloud / low_resolution_point_cloud (local_trajectory_builder_3d.cc:506-533,613-619).  Borrowed:
+ * valid until the next match on this front end; NULL when the last match dropped its scan. */
+int dliom_front_end_matched_clouds(const dliom_front_end* fe, const dliom_cloud** high_resolution,
+                                   const dliom_cloud** low_resolution);
 int dliom_front_end_active_submap(const dliom_front_end* fe, int i, double local_pose[7], int* num_range_data,
                                   int* finished, dliom_grid** high_resolution_grid,
                                   dliom_grid** low_resolution_grid);

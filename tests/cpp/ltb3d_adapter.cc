@@ -67,6 +67,9 @@ int main(int argc, char** argv) {
         double sum = 0.;
         for (float v : r->insertion_result->rotational_scan_matcher_histogram) sum += v;
         std::printf("HISTOGRAM %d %zu %.9g\n", s, r->insertion_result->rotational_scan_matcher_histogram.size(), sum);
+        std::printf("FILTERED %d %zu %zu\n", s, r->insertion_result->high_resolution_point_cloud.size(),
+                    r->insertion_result->low_resolution_point_cloud.size());
+        if (r->insertion_result->high_resolution_point_cloud.empty() || r->insertion_result->low_resolution_point_cloud.empty()) return 5;
         if (r->insertion_result->rotational_scan_matcher_histogram.size() != 120u || !(sum > 0.)) return 4;
       }
       ++results;

@@ -1164,7 +1164,7 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
     window.initialize(st[:7], st[7:10], np.zeros(6))
     acc_dev = dl.RangeDataAccumulator(ctx)
     fe = dl.LocalTrajectoryBuilder3D(ctx, FRONT_END_OPTS)
-    ticks, last, want, hists = 0, -1, {}, {}
+    ticks, last, want, hists, filtered = 0, -1, {}, {}, {}
     for s, ((dt, acc, gyr), sc) in enumerate(zip(imus, scans)):
         for a, g in zip(acc[:-1], gyr[:-1]):
             ticks += int(dt * 1e7 + 0.5)
@@ -1181,6 +1181,8 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
         est, vel, bias, status = window.add_pose(r["pose_estimate"])
         assert status == 0 and not r["dropped"]
         ins = fe.insert(ticks, est, est[3:])
+        if ins["inserted"]:
+            filtered[s] = (r["num_high"], r["num_low"])
         if ins["inserted"]:  # TrajectoryNode::Data::rotational_scan_matcher_histogram (.cc:605-610)
             rot = np.concatenate([np.zeros(3), est[3:]]).astype(np.float32)
             hists[s] = float(np.sum(orc.compute_histogram(orc.transform_points(rot, cloud.download()), 120).astype(np.float64)))
@@ -1193,6 +1195,8 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
     assert sorted(got_h) == sorted(hists) and len(hists) > 0
     for s in hists:  # the adapter's histogram is the oracle's ComputeHistogram of the gravity-aligned returns
         assert got_h[s][0] == 120 and abs(got_h[s][1] - hists[s]) <= 1e-6 * max(1.0, abs(hists[s])), (s, got_h[s], hists[s])
+    got_f = {int(l.split()[1]): (int(l.split()[2]), int(l.split()[3])) for l in out.stdout.splitlines() if l.startswith("FILTERED")}
+    assert got_f == filtered  # TrajectoryNode::Data's high / low resolution clouds: sizes of the adaptive filters' outputs
     assert ("SUBMAPS 2" if num_accumulated == 1 else "SUBMAPS 1") in out.stdout  # num_range_data = 4: roll-over after 4 insertions
     fe.close()
     acc_dev.close()
