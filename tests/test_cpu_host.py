@@ -361,3 +361,110 @@ def test_submap3d_proto_equals_google_protobuf(case):
             back = HybridGrid()
             back.ParseFromString(h2)
             assert back == grids[0]
+
+
+def _reference_synchronizer(calls, prior="lidar_a"):
+    """mapping/internal/3d/range_data_synchronizer.cc:29-113 restated independently of the C++ adapter (numpy, the
+    reference's double / float mix): returns per call (time, num_origins, [(origin_index, x, y, z, t), ...])."""
+    secondary, out = [], []
+
+    def seconds(ticks):
+        return float(ticks) * 1e-7
+
+    for sid, time, descrew, origin, ranges in calls:
+        ranges = np.array(ranges, dtype=np.float32).reshape(-1, 4)
+        stamped = ranges.copy()
+        if descrew and len(stamped) >= 2:  # StampRangeData (:115-130), scan period 0.1
+            n = len(stamped)
+            duration = 0.1 / (n - 1)
+            stamped[:, 3] = np.array([-0.1 + i * duration for i in range(n)], dtype=np.float64).astype(np.float32)
+            stamped[-1, 3] = 0.0
+        if sid != prior:
+            secondary.append((time, origin, stamped))
+            out.append((0, 0, []))
+            continue
+        cur_end = seconds(time)
+        cur_start = cur_end + float(stamped[0, 3]) if len(stamped) else cur_end
+        while secondary and seconds(secondary[0][0]) < cur_start:
+            secondary.pop(0)
+        single = (time, 1, [(0,) + tuple(r) for r in stamped])
+        if not secondary or seconds(secondary[0][0]) + float(secondary[0][2][0, 3]) > cur_end:
+            out.append(single)
+            continue
+        s_time, s_origin, s_ranges = secondary[0]
+        st = seconds(s_time)
+        i_start = i_end = -1
+        for i, r in enumerate(s_ranges):
+            t = st + float(r[3])
+            if cur_start <= t <= cur_end and i_start == -1:
+                i_start = i
+            if i_start != -1 and t > cur_end:
+                i_end = i - 1
+                break
+        assert i_start != -1
+        if i_end == -1:
+            i_end = len(s_ranges) - 1
+        merged = [(0,) + tuple(r) for r in ranges]  # the UNSTAMPED input (:97 uses timed_point_cloud_data.ranges)
+        for i in range(i_start, i_end + 1):
+            r = s_ranges[i]
+            merged.append((1, r[0], r[1], r[2], np.float32(float(r[3]) + st - cur_end)))
+        merged.sort(key=lambda m: float(m[4]))  # std::sort by time; ties: see the test's data (no equal times)
+        out.append((time, 2, merged))
+    return out
+
+
+def test_cpp_range_data_synchronizer_on_the_cpu(tmp_path):
+    """The adapter header's RangeDataSynchronizer (host logic, no device call) compiled with plain g++ and driven on
+    the CPU: pass-through of a single lidar, a secondary cloud merged into the overlapping part of the prior one
+    (second origin, times re-based to the prior cloud's stamp, sorted by time), stale secondary clouds dropped, the
+    'secondary lidar too fast' case, and `descrew` stamping -- against an independent restatement of
+    range_data_synchronizer.cc:29-130."""
+    import subprocess
+    rng = np.random.RandomState(3)
+
+    def cloud(n, t0, t1):
+        ts = np.sort(rng.uniform(t0, t1, n)).astype(np.float32)
+        ts[-1] = np.float32(t1)
+        return [tuple(rng.uniform(-20, 20, 3).astype(np.float32)) + (t,) for t in ts]
+
+    T = 10_000_000  # ticks per second
+    calls = [
+        ("lidar_a", 1 * T, 0, (0.0, 0.0, 0.0), cloud(6, -0.1, 0.0)),             # no secondary cloud yet: pass-through
+        ("lidar_b", int(1.95 * T), 0, (0.5, 0.0, 0.2), cloud(9, -0.1, 0.0)),     # ends at 1.95 s, covers [1.85, 1.95]
+        ("lidar_b", int(2.03 * T), 0, (0.5, 0.0, 0.2), cloud(8, -0.1, 0.0)),     # covers [1.93, 2.03]
+        ("lidar_a", 2 * T, 0, (0.0, 0.0, 0.0), cloud(7, -0.1, 0.0)),             # [1.9, 2.0]: merges part of the 1.95 s cloud
+        ("lidar_a", int(2.1 * T), 0, (0.0, 0.0, 0.0), cloud(5, -0.1, 0.0)),      # [2.0, 2.1]: 1.95 s cloud is stale; 2.03 s merges
+        ("lidar_b", int(3.5 * T), 0, (0.5, 0.0, 0.2), cloud(4, -0.1, 0.0)),      # far in the future
+        ("lidar_a", 3 * T, 0, (0.0, 0.0, 0.0), cloud(5, -0.1, 0.0)),             # "secondary lidar too fast": prior only
+        ("lidar_a", int(3.55 * T), 1, (0.0, 0.0, 0.0), cloud(6, -0.05, 0.0)),    # descrew: stamped -0.1 .. 0; merges the 3.5 s cloud
+    ]
+    script = ""
+    for sid, time, descrew, origin, ranges in calls:
+        script += "%s %d %d %r %r %r %d" % (sid, time, descrew, origin[0], origin[1], origin[2], len(ranges))
+        for r in ranges:
+            script += " " + " ".join(repr(float(v)) for v in r)
+        script += "\n"
+    exe = str(tmp_path / "synchronizer_cpu")
+    libdir = os.path.join(ROOT, "d-liom_amd")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "synchronizer_cpu.cc"),
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "d-liom_amd", "cpp"),
+                           "-L", libdir, "-ldliom", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], input=script, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "SYNCHRONIZER DONE" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    got, cur = [], None
+    for line in out.stdout.splitlines():
+        f = line.split()
+        if f[0] == "RESULT":
+            cur = (int(f[1]), int(f[2]), [])
+            got.append(cur)
+        elif f[0] == "R":
+            cur[2].append((int(f[1]),) + tuple(np.array([int(v) for v in f[2:6]], dtype=np.uint32).view(np.float32)))
+    want = _reference_synchronizer(calls)
+    assert len(got) == len(want) == len(calls)
+    merged_calls = 0
+    for g, w in zip(got, want):
+        assert g[0] == w[0] and g[1] == w[1] and len(g[2]) == len(w[2]), (g[:2], w[:2], len(g[2]), len(w[2]))
+        for a, b in zip(g[2], w[2]):
+            assert a[0] == b[0] and np.array_equal(np.array(a[1:], np.float32).view(np.uint32), np.array(b[1:], np.float32).view(np.uint32)), (a, b)
+        merged_calls += g[1] == 2
+    assert merged_calls == 3
