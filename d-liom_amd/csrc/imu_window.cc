@@ -269,6 +269,40 @@ bool cholesky(std::vector<double>& a, int n) {  // in place, lower
   }
   return true;
 }
+// The window's normal equations are block tridiagonal (every factor touches one state or two neighbours; the
+// marginal prior sits on the first block), and so is their Cholesky factor: the same loops as cholesky() /
+// chol_solve() restricted to the entries that can be non-zero -- the skipped terms are exact zeros.
+bool cholesky_chain(std::vector<double>& a, int n, int block) {
+  for (int j = 0; j < n; ++j) {
+    const int k0 = std::max(0, (j / block - 1) * block);
+    double d = a[j * n + j];
+    for (int k = k0; k < j; ++k) d -= a[j * n + k] * a[j * n + k];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    a[j * n + j] = d;
+    const int i_end = std::min(n, (j / block + 2) * block);  // rows of this block and the next
+    for (int i = j + 1; i < i_end; ++i) {
+      const int ki = std::max(k0, (i / block - 1) * block);
+      double s = a[i * n + j];
+      for (int k = ki; k < j; ++k) s -= a[i * n + k] * a[j * n + k];
+      a[i * n + j] = s / d;
+    }
+    for (int i = i_end; i < n; ++i) a[i * n + j] = 0.0;
+  }
+  return true;
+}
+void chol_solve_chain(const std::vector<double>& l, int n, int block, double* b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = std::max(0, (i / block - 1) * block); k < i; ++k) s -= l[i * n + k] * b[k];
+    b[i] = s / l[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < std::min(n, (i / block + 2) * block); ++k) s -= l[k * n + i] * b[k];
+    b[i] = s / l[i * n + i];
+  }
+}
 void chol_solve(const std::vector<double>& l, int n, double* b) {
   for (int i = 0; i < n; ++i) {
     double s = b[i];
@@ -314,11 +348,35 @@ namespace {
 constexpr int kD = 15;
 
 // whitened residual of the IMU factor + bias random walk between two states: 15 rows
+// The bias-corrected preintegrated measurement at the factor's UNPERTURBED biases: 48 of the 61 residual evaluations of
+// a numerical Jacobian (everything but the 6 + 6 bias columns) reuse it instead of recomputing Exp / the corrections.
+struct CorrectedCache {
+  bool valid = false;
+  V3 ba{0, 0, 0}, bg{0, 0, 0};
+  M3 dR{};
+  V3 dp{0, 0, 0}, dv{0, 0, 0};
+};
+inline bool same(V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
 void imu_residual(const dliom_imu_window& w, const Preint& P, const std::vector<double>& Linv, const State& a,
-                  const State& b, double* r) {
+                  const State& b, double* r, CorrectedCache* cache = nullptr) {
   M3 dR;
   V3 dp, dv;
-  corrected(P, a.ba, a.bg, &dR, &dp, &dv);
+  if (cache != nullptr && cache->valid && same(cache->ba, a.ba) && same(cache->bg, a.bg)) {
+    dR = cache->dR;
+    dp = cache->dp;
+    dv = cache->dv;
+  } else {
+    corrected(P, a.ba, a.bg, &dR, &dp, &dv);
+    if (cache != nullptr && !cache->valid) {  // the first call is the unperturbed one (add_factor evaluates r0 first)
+      cache->valid = true;
+      cache->ba = a.ba;
+      cache->bg = a.bg;
+      cache->dR = dR;
+      cache->dp = dp;
+      cache->dv = dv;
+    }
+  }
   const V3 g{0, 0, -w.o.gravity};
   const M3 RiT = transpose(a.R);
   const V3 rR = Log(transpose(dR) * (RiT * b.R));
@@ -410,11 +468,12 @@ void add_factor(std::vector<State>& x, int ia, int ib, int rows, F residual, std
     double s = 0;
     for (int i = 0; i < rows; ++i) s += J[static_cast<size_t>(i) * cols + c1] * r0[i];
     g[g1] += s;
-    for (int c2 = 0; c2 < cols; ++c2) {
+    for (int c2 = c1; c2 < cols; ++c2) {  // J^T J is symmetric: the mirrored entry is the same sum of the same products
       const int g2 = (c2 < kD ? ia : ib) * kD + c2 % kD;
       double h = 0;
       for (int i = 0; i < rows; ++i) h += J[static_cast<size_t>(i) * cols + c1] * J[static_cast<size_t>(i) * cols + c2];
       H[static_cast<size_t>(g1) * n + g2] += h;
+      if (c2 != c1) H[static_cast<size_t>(g2) * n + g1] += h;
     }
   }
 }
@@ -439,7 +498,8 @@ bool build(dliom_imu_window& w, std::vector<double>& H, std::vector<double>& g) 
     std::vector<double> Linv;
     if (!whitening(w.between[i], &Linv)) return false;
     const Preint& P = w.between[i];
-    add_factor(w.x, i, i + 1, 15, [&](double* r) { imu_residual(w, P, Linv, w.x[i], w.x[i + 1], r); }, H, g, n);
+    CorrectedCache cache;
+    add_factor(w.x, i, i + 1, 15, [&](double* r) { imu_residual(w, P, Linv, w.x[i], w.x[i + 1], r, &cache); }, H, g, n);
   }
   for (const auto& f : w.pose_priors)
     add_factor(w.x, f.index, -1, 6, [&](double* r) { pose_prior_residual(f, w.x[f.index], r); }, H, g, n);
@@ -455,10 +515,10 @@ bool gauss_newton(dliom_imu_window& w, int iterations) {
     if (!build(w, H, g)) return false;
     std::vector<double> L = H;
     for (int i = 0; i < n; ++i) L[static_cast<size_t>(i) * n + i] += 1e-12;
-    if (!cholesky(L, n)) return false;
+    if (!cholesky_chain(L, n, kD)) return false;
     std::vector<double> d(g);
     for (double& v : d) v = -v;
-    chol_solve(L, n, d.data());
+    chol_solve_chain(L, n, kD, d.data());
     for (int i = 0; i < N; ++i) w.x[i] = retract(w.x[i], d.data() + i * kD);
   }
   return true;
@@ -484,7 +544,8 @@ bool marginalize_oldest(dliom_imu_window& w) {
   std::vector<double> Linv;
   if (!whitening(w.between[0], &Linv)) return false;
   const Preint P = w.between[0];
-  add_factor(x2, 0, 1, 15, [&](double* r) { imu_residual(w, P, Linv, x2[0], x2[1], r); }, H, g, n);
+  CorrectedCache cache;
+  add_factor(x2, 0, 1, 15, [&](double* r) { imu_residual(w, P, Linv, x2[0], x2[1], r, &cache); }, H, g, n);
   for (const auto& f : w.pose_priors)
     if (f.index == 0) add_factor(x2, 0, -1, 6, [&](double* r) { pose_prior_residual(f, x2[0], r); }, H, g, n);
   for (const auto& f : w.gravity)
