@@ -151,6 +151,14 @@ def test_rotational_histogram_equals_oracle(orc):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         assert got.sum() > 0
     assert np.array_equal(dl.rotational_histogram(np.zeros((0, 3), np.float32), 8), np.zeros(8, np.float32))
+    # a whole 64 x 1024 scan: above 8192 points the slices are sorted on several host threads; the additions into the
+    # histogram stay in slice order, so the bits do not depend on the thread count
+    pts, _ = synth.scan(synth.trajectory_pose(0.2), 64, 1024)
+    assert len(pts) > 8192
+    assert np.array_equal(dl.rotational_histogram(pts, 120).view(np.uint32), orc.compute_histogram(pts, 120).view(np.uint32))
+    # heights spread over far more slices than points: the sparse (map) walk
+    sparse = np.array([[1.0, 2.0, 0.0], [3.0, 1.0, 4000.0], [-2.0, 0.5, -9000.0], [1.5, 2.5, 0.05]], np.float32)
+    assert np.array_equal(dl.rotational_histogram(sparse, 16).view(np.uint32), orc.compute_histogram(sparse, 16).view(np.uint32))
 
 
 def _imu_stream(seed, n=40, dt=0.005):
