@@ -51,7 +51,8 @@ if "FETCH_SIZE" in summary:
     out["hbm_bytes_per_launch"] = 2.0 * out["fetch_bytes_raw"] + out["write_bytes_raw"]
 json.dump(out, open(os.path.join(dst, "%s_pmc_score_kernel.json" % tag), "w"), indent=1)
 for name, o in (("bench_full.json", "%s_bench.json"), ("wref.json", "%s_wref.json"),
-                ("wref_stages.json", "%s_wref_stages.json")):
+                ("wref_stages.json", "%s_wref_stages.json"), ("stream.json", "%s_stream_config3.json"),
+                ("stream_gentle.json", "%s_stream_config3_gentle.json")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         lines = [l for l in open(f).read().splitlines() if l.startswith("{")]

@@ -27,4 +27,8 @@ timeout 600 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
 echo "bench rc=$?"
 timeout 200 python tools/wref.py > $OUT/wref.json 2> $OUT/wref.err
 timeout 100 python tools/wref.py --stages > $OUT/wref_stages.json 2>> $OUT/wref.err
+timeout 200 python tools/stream.py > $OUT/stream.json 2> $OUT/stream.err
+timeout 200 python tools/stream.py --gentle --imu-noise > $OUT/stream_gentle.json 2>> $OUT/stream.err
 find $OUT -name "*.csv" | head -20
+# config 5 (128x2048, 5 cm), the fallback kernels and the W-ref kernel trace have their own scripts:
+#   tools/r2_config5.sh  tools/r2_fallback.sh  tools/r2_wref_trace.sh
