@@ -97,27 +97,28 @@ struct Contribution {
   float value;
 };
 
-P3 centroid_of(const std::vector<P3>& slice) {  // :52-59
+P3 centroid_of(const P3* slice, size_t n) {  // :52-59
   float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (const P3& p : slice) {
-    sx += p.x;
-    sy += p.y;
-    sz += p.z;
+  for (size_t i = 0; i < n; ++i) {
+    sx += slice[i].x;
+    sy += slice[i].y;
+    sz += slice[i].z;
   }
-  const float n = static_cast<float>(slice.size());
-  return P3{sx / n, sy / n, sz / n};
+  const float fn = static_cast<float>(n);
+  return P3{sx / fn, sy / fn, sz / fn};
 }
 
-std::vector<P3> sort_slice(const std::vector<P3>& slice) {  // :97-121
+std::vector<P3> sort_slice(const P3* slice, size_t n) {  // :97-121
   struct Pair {
     bool operator<(const Pair& rhs) const { return angle < rhs.angle; }
     float angle;
     P3 point;
   };
-  const P3 c = centroid_of(slice);
+  const P3 c = centroid_of(slice, n);
   std::vector<Pair> by_angle;
-  by_angle.reserve(slice.size());
-  for (const P3& p : slice) {
+  by_angle.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    const P3& p = slice[i];
     const float dx = p.x - c.x, dy = p.y - c.y;
     if (norm2(dx, dy) < kMinDistance) continue;
     by_angle.push_back(Pair{std::atan2(dy, dx), p});
@@ -133,7 +134,7 @@ std::vector<P3> sort_slice(const std::vector<P3>& slice) {  // :97-121
 void slice_contributions(const std::vector<P3>& slice, int size, std::vector<Contribution>* out) {
   out->clear();
   if (slice.empty()) return;
-  const P3 c = centroid_of(slice);
+  const P3 c = centroid_of(slice.data(), slice.size());
   P3 last = slice.front();
   for (const P3& p : slice) {
     const float dx = p.x - last.x, dy = p.y - last.y;
@@ -150,64 +151,131 @@ void slice_contributions(const std::vector<P3>& slice, int size, std::vector<Con
   }
 }
 
+// All threads of one call meet here between the phases (short phases: spin, then yield).
+class SpinBarrier {
+ public:
+  explicit SpinBarrier(int n) : n_(n) {}
+  void wait() {
+    const int gen = generation_.load(std::memory_order_acquire);
+    if (arrived_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
+      arrived_.store(0, std::memory_order_relaxed);
+      generation_.fetch_add(1, std::memory_order_release);
+      return;
+    }
+    for (int spins = 0; generation_.load(std::memory_order_acquire) == gen; ++spins)
+      if (spins > 2000) std::this_thread::yield();
+  }
+
+ private:
+  const int n_;
+  std::atomic<int> arrived_{0};
+  std::atomic<int> generation_{0};
+};
+
 }  // namespace
 
+// ComputeHistogram (:159-170).  The reference walks a std::map of height slices (key lround(z / 0.2), points in
+// input order), sorts every slice by angle around its centroid and adds the slice's contributions to the histogram.
+// Everything but those additions is independent per point or per slice: for whole scans (46 000 returns took 2.9 ms
+// on one core of the GPU box's host, six times the device chain they follow) the keys, a stable counting sort into
+// slices, and the per-slice sort + evaluation run on up to 8 host threads; the additions stay in slice order, so the
+// bits do not depend on the thread count (tools/hist_bench.cc, DLIOM_HISTOGRAM_THREADS).
 extern "C" int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram) {
   if (n < 0 || histogram_size <= 0 || histogram == nullptr || (n > 0 && points_xyz == nullptr))
     return DLIOM_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < histogram_size; ++i) histogram[i] = 0.f;
   if (n == 0) return DLIOM_OK;
-  // slices by height (:162-166: std::map keyed by lround(z / 0.2), points in input order): a counting sort
+  const unsigned hw = std::thread::hardware_concurrency();
+  static const int forced_threads =
+      std::getenv("DLIOM_HISTOGRAM_THREADS") != nullptr ? std::atoi(std::getenv("DLIOM_HISTOGRAM_THREADS")) : 0;
+  const int T = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>(n, forced_threads > 0 ? std::min(forced_threads, 64) : (n < 8192 ? 1 : std::min<unsigned>(hw == 0 ? 1 : hw, 8u)))));
   std::vector<int> key(static_cast<size_t>(n));
-  int kmin = INT_MAX, kmax = INT_MIN;
-  for (int64_t i = 0; i < n; ++i) {
-    key[static_cast<size_t>(i)] = static_cast<int>(std::lround(points_xyz[3 * i + 2] / kSliceHeight));
-    kmin = std::min(kmin, key[static_cast<size_t>(i)]);
-    kmax = std::max(kmax, key[static_cast<size_t>(i)]);
+  std::vector<int> tmin(static_cast<size_t>(T), INT_MAX), tmax(static_cast<size_t>(T), INT_MIN);
+  std::vector<std::vector<int64_t>> offset(static_cast<size_t>(T));  // per thread and slice: count, then write position
+  std::vector<int64_t> slice_begin;
+  std::vector<P3> flat;
+  std::vector<std::vector<Contribution>> contributions;
+  int kmin = 0;
+  int64_t span = 0;
+  bool sparse = false;
+  SpinBarrier barrier(T);
+  std::atomic<int64_t> next(0);
+  auto work = [&](int t) {
+    const int64_t a = n * t / T, b = n * (t + 1) / T;
+    int lo = INT_MAX, hi = INT_MIN;
+    for (int64_t i = a; i < b; ++i) {
+      const int k = static_cast<int>(std::lround(points_xyz[3 * i + 2] / kSliceHeight));
+      key[static_cast<size_t>(i)] = k;
+      lo = std::min(lo, k);
+      hi = std::max(hi, k);
+    }
+    tmin[static_cast<size_t>(t)] = lo;
+    tmax[static_cast<size_t>(t)] = hi;
+    barrier.wait();
+    if (t == 0) {
+      int gmin = INT_MAX, gmax = INT_MIN;
+      for (int u = 0; u < T; ++u) {
+        gmin = std::min(gmin, tmin[static_cast<size_t>(u)]);
+        gmax = std::max(gmax, tmax[static_cast<size_t>(u)]);
+      }
+      kmin = gmin;
+      span = static_cast<int64_t>(gmax) - gmin + 1;
+      sparse = span > 4 * n + 1024;  // absurdly spread heights: the map-based walk below
+      if (!sparse) {
+        for (int u = 0; u < T; ++u) offset[static_cast<size_t>(u)].assign(static_cast<size_t>(span), 0);
+        slice_begin.assign(static_cast<size_t>(span) + 1, 0);
+        flat.resize(static_cast<size_t>(n));
+        contributions.resize(static_cast<size_t>(span));
+      }
+    }
+    barrier.wait();
+    if (sparse) return;
+    std::vector<int64_t>& mine = offset[static_cast<size_t>(t)];
+    for (int64_t i = a; i < b; ++i) ++mine[static_cast<size_t>(key[static_cast<size_t>(i)] - kmin)];
+    barrier.wait();
+    if (t == 0) {  // slice k holds thread 0's points, then thread 1's, ...: the input order
+      int64_t running = 0;
+      for (int64_t k = 0; k < span; ++k) {
+        slice_begin[static_cast<size_t>(k)] = running;
+        for (int u = 0; u < T; ++u) {
+          const int64_t c = offset[static_cast<size_t>(u)][static_cast<size_t>(k)];
+          offset[static_cast<size_t>(u)][static_cast<size_t>(k)] = running;
+          running += c;
+        }
+      }
+      slice_begin[static_cast<size_t>(span)] = running;
+    }
+    barrier.wait();
+    for (int64_t i = a; i < b; ++i)
+      flat[static_cast<size_t>(mine[static_cast<size_t>(key[static_cast<size_t>(i)] - kmin)]++)] =
+          P3{points_xyz[3 * i], points_xyz[3 * i + 1], points_xyz[3 * i + 2]};
+    barrier.wait();
+    for (int64_t k = next.fetch_add(1); k < span; k = next.fetch_add(1)) {
+      const int64_t first = slice_begin[static_cast<size_t>(k)], count = slice_begin[static_cast<size_t>(k) + 1] - first;
+      if (count == 0) continue;
+      slice_contributions(sort_slice(flat.data() + first, static_cast<size_t>(count)), histogram_size,
+                          &contributions[static_cast<size_t>(k)]);
+    }
+  };
+  if (T == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (std::thread& th : pool) th.join();
   }
-  const int64_t span = static_cast<int64_t>(kmax) - kmin + 1;
-  if (span > 4 * n + 1024) {  // absurdly sparse heights: the map-based walk of the reference
+  if (sparse) {
     std::map<int, std::vector<P3>> slices;
     for (int64_t i = 0; i < n; ++i)
       slices[key[static_cast<size_t>(i)]].push_back(P3{points_xyz[3 * i], points_xyz[3 * i + 1], points_xyz[3 * i + 2]});
     std::vector<Contribution> c;
-    for (const auto& s : slices) {
-      slice_contributions(sort_slice(s.second), histogram_size, &c);
+    for (const auto& sl : slices) {
+      slice_contributions(sort_slice(sl.second.data(), sl.second.size()), histogram_size, &c);
       for (const Contribution& k : c) histogram[k.bucket] += k.value;
     }
     return DLIOM_OK;
-  }
-  std::vector<std::vector<P3>> slices(static_cast<size_t>(span));
-  {
-    std::vector<int> count(static_cast<size_t>(span), 0);
-    for (int64_t i = 0; i < n; ++i) ++count[static_cast<size_t>(key[static_cast<size_t>(i)] - kmin)];
-    for (int64_t k = 0; k < span; ++k) slices[static_cast<size_t>(k)].reserve(static_cast<size_t>(count[static_cast<size_t>(k)]));
-    for (int64_t i = 0; i < n; ++i)
-      slices[static_cast<size_t>(key[static_cast<size_t>(i)] - kmin)].push_back(
-          P3{points_xyz[3 * i], points_xyz[3 * i + 1], points_xyz[3 * i + 2]});
-  }
-  // Sorting a slice by angle and evaluating its contributions are independent per slice: host threads for whole
-  // scans (46 000 returns: 2.9 ms on one core of the GPU box's host, six times the device chain they follow; 1.2 ms on 4-8 threads,
-  // tools/hist_bench.cc); the additions into
-  // the histogram stay in slice order, so the result does not depend on the thread count.
-  std::vector<std::vector<Contribution>> contributions(static_cast<size_t>(span));
-  const unsigned hw = std::thread::hardware_concurrency();
-  static const int forced_threads = std::getenv("DLIOM_HISTOGRAM_THREADS") != nullptr ? std::atoi(std::getenv("DLIOM_HISTOGRAM_THREADS")) : 0;
-  const int num_threads = forced_threads > 0
-                              ? forced_threads
-                              : (n < 8192 ? 1 : static_cast<int>(std::min<int64_t>(std::min<unsigned>(hw == 0 ? 1 : hw, 8u), span)));
-  std::atomic<int64_t> next(0);
-  auto work = [&]() {
-    for (int64_t k = next.fetch_add(1); k < span; k = next.fetch_add(1))
-      slice_contributions(sort_slice(slices[static_cast<size_t>(k)]), histogram_size, &contributions[static_cast<size_t>(k)]);
-  };
-  if (num_threads <= 1) {
-    work();
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < num_threads; ++t) pool.emplace_back(work);
-    work();
-    for (std::thread& t : pool) t.join();
   }
   for (int64_t k = 0; k < span; ++k)
     for (const Contribution& c : contributions[static_cast<size_t>(k)]) histogram[c.bucket] += c.value;
