@@ -497,7 +497,9 @@ int dliom_fast_csm_level(const dliom_fast_csm* matcher, int depth, int32_t lo[3]
                          int64_t capacity);
 
 /* RotationalScanMatcher::ComputeHistogram (rotational_scan_matcher.cc:159-170; called per inserted
- * scan, local_trajectory_builder_3d.cc:605-610) on the host: histogram_size floats. */
+ * scan, local_trajectory_builder_3d.cc:605-610) on the host: histogram_size floats.  Clouds of 8192 points and more
+ * are processed on up to 8 host threads (same bits at any thread count; DLIOM_HISTOGRAM_THREADS=1 keeps the call on
+ * the caller's thread). */
 int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram);
 /* RotationalScanMatcher(histograms_at_angles).Match(histogram, initial_angle, angles)
  * (rotational_scan_matcher.cc:174-194), host: one score per angle.  The loop-closure matcher calls
