@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -12,6 +13,13 @@
 #include "internal.h"
 
 namespace dliom {
+
+#ifdef DLIOM_EXPERIMENTS
+int tuning_int(const char* name, int fallback) {
+  const char* e = std::getenv(name);
+  return e != nullptr ? std::atoi(e) : fallback;
+}
+#endif
 
 static thread_local std::string g_last_error;
 
@@ -474,6 +482,8 @@ const char* dliom_status_string(int status) {
     case DLIOM_ERR_EMPTY_CLOUD: return "empty point cloud";
     case DLIOM_ERR_CAPACITY: return "output buffer too small";
     case DLIOM_ERR_SOLVER: return "solver failure";
+    case DLIOM_ERR_DIVERGED: return "IMU window diverged (velocity or bias beyond the FailureDetection limits)";
+    case DLIOM_ERR_PEER_FAILED: return "sharded match: another rank failed before the exchange";
     default: return "unknown status";
   }
 }
@@ -559,6 +569,28 @@ int dliom_ctx_device(const dliom_ctx* ctx) { return ctx == nullptr ? -1 : ctx->d
 int dliom_ctx_synchronize(dliom_ctx* ctx) {
   if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
+int dliom_ctx_set_tuning(dliom_ctx* ctx, int knob, int value) {
+  if (ctx == nullptr || knob < 0 || knob >= DLIOM_TUNE_COUNT) return DLIOM_ERR_INVALID_ARGUMENT;
+  switch (knob) {
+    case DLIOM_TUNE_SCORE_KERNEL:
+      if (value < 0 || value > 3) return DLIOM_ERR_INVALID_ARGUMENT;
+      break;
+    case DLIOM_TUNE_CSM_ONE_LAUNCH_MAX:
+      if (value < 0 || value > 4096) return DLIOM_ERR_INVALID_ARGUMENT;
+      break;
+    default:
+      if (value != 0 && value != 1) return DLIOM_ERR_INVALID_ARGUMENT;
+  }
+  ctx->tuning[knob] = value;
+  return DLIOM_OK;
+}
+
+int dliom_ctx_get_tuning(const dliom_ctx* ctx, int knob, int* value) {
+  if (ctx == nullptr || value == nullptr || knob < 0 || knob >= DLIOM_TUNE_COUNT) return DLIOM_ERR_INVALID_ARGUMENT;
+  *value = ctx->tuning[knob];
   return DLIOM_OK;
 }
 

@@ -829,9 +829,8 @@ int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* o, const do
   dliom_csm_summary local;
   dliom_csm_summary* sum = summary != nullptr ? summary : &local;
   const LmConfig cfg{o->max_num_iterations, o->use_nonmonotonic_steps, p.nloc};
-  // total points up to which the one-launch loop is used (0 = never); read per call so a test can flip it
-  const char* pm_env = std::getenv("DLIOM_CSM_PERSISTENT_MAX");
-  const int persistent_max = pm_env != nullptr ? std::atoi(pm_env) : 4096;
+  // total points up to which the one-launch loop is used (0 = never)
+  const int persistent_max = ctx->tuning[DLIOM_TUNE_CSM_ONE_LAUNCH_MAX];
   if (p.args.total_points <= persistent_max) {
     LmKernelParams prm;
     prm.cfg = cfg;

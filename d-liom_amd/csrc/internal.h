@@ -31,6 +31,16 @@ void set_last_error(const char* what, hipError_t e, const char* file, int line);
     if (_s != DLIOM_OK) return _s;   \
   } while (0)
 
+// Tuning knobs and timing experiments read from the environment exist only in builds made with -DDLIOM_EXPERIMENTS
+// (`make experiments` -> ab/libdliom_exp.so, for tools/).  The library that ships never reads the environment: a call
+// gives the same result through the same kernels every time.  What a caller may legitimately choose (which score
+// kernel, the one-launch Ceres limit, host threads) is set per context with dliom_ctx_set_tuning().
+#ifdef DLIOM_EXPERIMENTS
+int tuning_int(const char* name, int fallback);  // std::getenv (core.hip)
+#else
+inline int tuning_int(const char*, int fallback) { return fallback; }
+#endif
+
 // Grow-only device buffer.
 struct DevBuf {
   void* p = nullptr;
@@ -78,7 +88,8 @@ struct dliom_ctx {
   dliom::DevBuf box_counters; // its chunk dispensers
   dliom::DevBuf box_error;  // its 'cannot happen' flag word, read by dliom_rtcsm3d_box_error
   bool box_error_zeroed = false;
-  bool force_dense_score = false;  // rerun after a list overflow of the LDS-box kernel
+  bool force_dense_score = false;  // rerun after the LDS-box kernel flagged an inconsistency
+  int tuning[DLIOM_TUNE_COUNT] = {3, 4096, 0, 0};  // dliom_ctx_set_tuning (defaults: dliom.h)
   bool last_score_used_box = false;
   int last_score_mapping = -1;     // 3 box, 2 dense mirror, 1 / 0 leaf table kernels
   void* pinned = nullptr;   // small pinned host staging block

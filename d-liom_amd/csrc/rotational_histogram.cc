@@ -179,15 +179,18 @@ class SpinBarrier {
 // Everything but those additions is independent per point or per slice: for whole scans (46 000 returns took 2.9 ms
 // on one core of the GPU box's host, six times the device chain they follow) the keys, a stable counting sort into
 // slices, and the per-slice sort + evaluation run on up to 8 host threads; the additions stay in slice order, so the
-// bits do not depend on the thread count (tools/hist_bench.cc, DLIOM_HISTOGRAM_THREADS).
+// bits do not depend on the thread count (tools/hist_bench.cc, dliom_rotational_histogram_mt).
 extern "C" int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram) {
-  if (n < 0 || histogram_size <= 0 || histogram == nullptr || (n > 0 && points_xyz == nullptr))
+  return dliom_rotational_histogram_mt(points_xyz, n, histogram_size, 0, histogram);
+}
+
+extern "C" int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n, int histogram_size, int forced_threads,
+                                             float* histogram) {
+  if (n < 0 || histogram_size <= 0 || histogram == nullptr || (n > 0 && points_xyz == nullptr) || forced_threads < 0)
     return DLIOM_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < histogram_size; ++i) histogram[i] = 0.f;
   if (n == 0) return DLIOM_OK;
   const unsigned hw = std::thread::hardware_concurrency();
-  static const int forced_threads =
-      std::getenv("DLIOM_HISTOGRAM_THREADS") != nullptr ? std::atoi(std::getenv("DLIOM_HISTOGRAM_THREADS")) : 0;
   const int T = static_cast<int>(std::max<int64_t>(
       1, std::min<int64_t>(n, forced_threads > 0 ? std::min(forced_threads, 64) : (n < 8192 ? 1 : std::min<unsigned>(hw == 0 ? 1 : hw, 8u)))));
   std::vector<int> key(static_cast<size_t>(n));

@@ -1124,10 +1124,7 @@ static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidat
   return DLIOM_OK;
 }
 
-static int env_int(const char* name, int fallback) {
-  const char* e = std::getenv(name);
-  return e != nullptr ? std::atoi(e) : fallback;
-}
+static int env_int(const char* name, int fallback) { return tuning_int(name, fallback); }  // experiments builds only
 
 // LDS-box score kernel (score_box.h): builds the per-pass constants in double and launches it.
 // Returns DLIOM_ERR_CAPACITY when the search does not suit the kernel (the caller then uses the dense
@@ -1354,8 +1351,12 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   p.nw = nw;
   p.thr = thr_units;
   p.cells = cells;
+#ifdef DLIOM_EXPERIMENTS
   static const int box_debug = env_int("DLIOM_BOX_DEBUG", 0);
   p.debug = box_debug;
+#else
+  p.debug = 0;
+#endif
   const size_t lds = kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 +
                      static_cast<size_t>(cells) * 2;
   if (lds > 160 * 1024) return DLIOM_ERR_CAPACITY;
@@ -1386,6 +1387,21 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   slot_quads = std::min(slot_quads, (p.point_chunks + kBatch - 1) / kBatch);
   // (32-bit register accumulators: the kernel adds them to the 64-bit volume every box::kFlushPoints points)
   p.slots = slot_quads;
+  p.units = passes * rot_blocks;
+  {
+    // guided ticket sizes: about half of a unit's chunks in tickets of kBatch, half of the rest in tickets of two, the
+    // remainder one by one -- whole rounds of the unit's home workgroups each, so that the first tickets (no atomic) are
+    // full ones and the last few rounds are short
+    static const int pct_a = env_int("DLIOM_BOX_PCT_A", 50), pct_b = env_int("DLIOM_BOX_PCT_B", 50);
+    const int64_t M = p.point_chunks, W = slot_quads;
+    int64_t n_a = (M * pct_a / 100) / (kBatch * W) * W;
+    if (n_a == 0 && M >= kBatch * W) n_a = W;
+    const int64_t m1 = M - n_a * kBatch;
+    const int64_t n_b = (m1 * pct_b / 100) / (2 * W) * W;
+    p.n_a = static_cast<int>(n_a);
+    p.n_b = static_cast<int>(n_b);
+    p.tickets = static_cast<int>(n_a + n_b + (m1 - 2 * n_b));
+  }
   DLIOM_TRY(ctx->box_counters.reserve(static_cast<size_t>(passes) * rot_blocks * 4 + 256));
   DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_counters.p, 0, static_cast<size_t>(passes) * rot_blocks * 4, ctx->stream));
   p.counters = ctx->box_counters.as<unsigned>();
@@ -1393,6 +1409,10 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   hipLaunchKernelGGL(rtcsm_score_box_kernel, dim3(blocks), dim3(64 * nw), lds, ctx->stream, g, p, cloud.d_xs,
                      cloud.d_ys, cloud.d_zs);
   DLIOM_HIP_TRY(hipGetLastError());
+  if (ctx->tuning[DLIOM_TUNE_INJECT_BOX_FAULT] != 0) {  // test hook: as if the kernel had flagged an inconsistency
+    ctx->tuning[DLIOM_TUNE_INJECT_BOX_FAULT] = 0;
+    DLIOM_HIP_TRY(hipMemsetAsync(static_cast<char*>(ctx->box_error.p) + 4, 1, 1, ctx->stream));
+  }
   return DLIOM_OK;
 }
 
@@ -1415,8 +1435,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   // 3: LDS-box kernel over the dense mirror (score_box.h; default when the search suits it),
   // 2: rotation per lane over the dense mirror, 1: rotation per lane over the leaf table,
   // 0: point per lane over the leaf table
-  static const int wanted_mapping = env_int("DLIOM_SCORE_MAPPING", 3);
-  int mapping = wanted_mapping;
+  int mapping = ctx->tuning[DLIOM_TUNE_SCORE_KERNEL];
   if (ctx->force_dense_score && mapping > 2) mapping = 2;
   ctx->last_score_used_box = false;
   if (mapping >= 2) {
@@ -1703,8 +1722,12 @@ struct RtcsmState {
   bool used_box = false;
 };
 
-// The LDS-box kernel reports a level-1 list overflow in box_error[1]: the sums are then incomplete and the
-// match is redone with the dense kernel.  `err1` is the word as read back; clears it on the device.
+// The LDS-box kernel checks its own fast index against the reference's arithmetic wherever the two could differ; an
+// exact cell more than one cell away from the fast one contradicts the error budget of score_box.h ("cannot
+// happen").  If it ever does, the kernel sets box_error[0] (sticky, dliom_rtcsm3d_box_error) and box_error[1]: the
+// sums are then not trusted and the match is redone with the dense kernel, which has no fast path.
+// DLIOM_TUNE_INJECT_BOX_FAULT sets the word from the host so that a test can walk this path.
+// `err1` is the word as read back; clears it on the device.
 static int box_overflowed(dliom_ctx* ctx, unsigned err1, bool* overflow) {
   *overflow = err1 != 0u;
   if (*overflow)
@@ -2066,17 +2089,29 @@ int dliom_rtcsm3d_shard_decode(dliom_ctx* ctx, uint64_t global_best_packed, doub
 // like their bit patterns and the complemented index lets the lower index win ties.  One MAX all-reduce of one
 // uint64; its 8 bytes are latency, not bandwidth.  The three-phase calls above stay for callers that
 // want the global lower bound exchanged first (less rescoring per rank, two collectives).
+// reserved word of a rank that failed: above every real packed word (score bits of a finite positive float are at most
+// 0x7F7FFFFF) under unsigned AND signed 64-bit MAX -- torch.distributed has no uint64, callers reduce int64
+static constexpr uint64_t kShardFailed = 0x7FFFFFFFFFFFFFFFull;
 int dliom_rtcsm3d_match_sharded(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7], const dliom_cloud* cloud,
                                 const dliom_grid* grid, int shard, int num_shards, dliom_allreduce_max_u64 exchange,
                                 void* user, double out7[7], float* score) {
-  if (ctx == nullptr || o == nullptr || init7 == nullptr || cloud == nullptr || grid == nullptr || out7 == nullptr ||
-      score == nullptr || (num_shards > 1 && exchange == nullptr))
-    return DLIOM_ERR_INVALID_ARGUMENT;
-  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  DLIOM_TRY(match_begin(ctx, o, init7, *cloud, grid, shard, num_shards, nullptr));
+  if (num_shards > 1 && exchange == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  // Every rank ALWAYS takes part in the exchange: a rank that failed locally (bad arguments, a HIP error, an
+  // allocation, a refusal, an empty cloud) contributes the reserved word kShardFailed -- the maximum, so every rank
+  // sees it -- and returns its own status afterwards; the others return DLIOM_ERR_PEER_FAILED.  Returning before the
+  // collective would leave the peers blocked in it (on RCCL: a device-side hang without an error).
+  int local = ctx == nullptr || o == nullptr || init7 == nullptr || cloud == nullptr || grid == nullptr || out7 == nullptr ||
+                      score == nullptr
+                  ? DLIOM_ERR_INVALID_ARGUMENT
+                  : DLIOM_OK;
+  if (local == DLIOM_OK && hipSetDevice(ctx->device) != hipSuccess) local = DLIOM_ERR_HIP;
   uint64_t packed = 0;
-  DLIOM_TRY(match_finish(ctx, nullptr, &packed));
-  if (num_shards > 1 && exchange(&packed, user) != 0) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (local == DLIOM_OK) local = match_begin(ctx, o, init7, *cloud, grid, shard, num_shards, nullptr);
+  if (local == DLIOM_OK) local = match_finish(ctx, nullptr, &packed);
+  if (local != DLIOM_OK) packed = kShardFailed;
+  if (num_shards > 1 && exchange(&packed, user) != 0) return local != DLIOM_OK ? local : DLIOM_ERR_HIP;
+  if (local != DLIOM_OK) return local;
+  if (packed == kShardFailed) return DLIOM_ERR_PEER_FAILED;
   return match_decode(ctx, packed, out7, score);
 }
 
@@ -2145,11 +2180,13 @@ int dliom_rtcsm3d_match_sharded_rccl(dliom_ctx* ctx, const dliom_rtcsm_options* 
     if (ctx == nullptr || o == nullptr || init7 == nullptr || cloud == nullptr || grid == nullptr || out7 == nullptr ||
         score == nullptr)
       return DLIOM_ERR_INVALID_ARGUMENT;
-    DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-    DLIOM_TRY(match_begin(ctx, o, init7, *cloud, grid, 0, 1, nullptr));
+    int local = hipSetDevice(ctx->device) == hipSuccess ? DLIOM_OK : DLIOM_ERR_HIP;
     uint64_t packed = 0;
-    DLIOM_TRY(match_finish(ctx, nullptr, &packed));
-    if (rccl_exchange(&packed, &x) != 0) return DLIOM_ERR_HIP;
+    if (local == DLIOM_OK) local = match_begin(ctx, o, init7, *cloud, grid, 0, 1, nullptr);
+    if (local == DLIOM_OK) local = match_finish(ctx, nullptr, &packed);
+    if (local != DLIOM_OK) packed = kShardFailed;
+    if (rccl_exchange(&packed, &x) != 0) return local != DLIOM_OK ? local : DLIOM_ERR_HIP;
+    if (local != DLIOM_OK) return local;
     return match_decode(ctx, packed, out7, score);
   }
   return dliom_rtcsm3d_match_sharded(ctx, o, init7, cloud, grid, rank, size, rccl_exchange, &x, out7, score);

@@ -19,8 +19,10 @@
 //   * per iteration of kHotP points the next points are already in registers (fetched during the previous
 //     iteration's 27 steps), the 3 kHotP band-bitmap words are fetched together and the list append is branch-free;
 //     the values gathered in one step are accumulated after the next step's address arithmetic (kPipe, kLateAcc).
-// What bounds it and what was tried: DESIGN.md 3.1 (the DLIOM_BOX_EXP / DLIOM_BOX_DEBUG switches below are the
-// timing experiments quoted there; they produce wrong sums by design and are off in every build that ships).
+// What bounds it and what was tried: DESIGN.md 3.1.  The timing experiments quoted there (DLIOM_BOX_EXP,
+// Params::debug) produce wrong sums by design: they exist only in builds made with -DDLIOM_EXPERIMENTS
+// (`make experiments` -> ab/libdliom_exp.so); the library that ships contains neither them nor any switch that
+// reads the environment.
 // Exactness without a per-lookup test.  A fast lookup can differ from the reference's cell only when its
 // scaled coordinate w lies within a rounding band of a cell boundary (budget below).  Whether ANY of the
 // 27 translations of a pass puts a rotated point into a band depends, per axis, only on the fraction of
@@ -60,8 +62,14 @@ constexpr int kL2Cap = 128;    // level-2 list: (level-1 slot, translation)
 #define DLIOM_BOX_HOT_P 4
 #endif
 constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4)
-#ifndef DLIOM_BOX_EXP
-#define DLIOM_BOX_EXP 0  // 1, 2, 3: timing experiments of the hot loop (wrong sums)
+#if !defined(DLIOM_EXPERIMENTS) || !defined(DLIOM_BOX_EXP)
+#undef DLIOM_BOX_EXP
+#define DLIOM_BOX_EXP 0  // 1, 2, 3: timing experiments of the hot loop (wrong sums; -DDLIOM_EXPERIMENTS builds only)
+#endif
+#ifdef DLIOM_EXPERIMENTS
+#define DLIOM_BOX_DBG(p, bit) (((p).debug & (bit)) != 0)
+#else
+#define DLIOM_BOX_DBG(p, bit) false
 #endif
 #ifndef DLIOM_BOX_PIPE
 #define DLIOM_BOX_PIPE 1
@@ -71,7 +79,7 @@ constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4
 #endif
 constexpr int kPipe = DLIOM_BOX_PIPE;            // steps between a gather and the accumulation of its value
 constexpr bool kLateAcc = DLIOM_BOX_LATE_ACC != 0;  // accumulate after the step's address arithmetic (else: anywhere)
-constexpr int kBatch = 4;      // point chunks per ticket of the work dispenser
+constexpr int kBatch = 4;      // point chunks per ticket of the work dispenser (first tickets; later ones 2, then 1)
 constexpr int kRecords = 8;    // ring of chunk records (lo[3], first point) the level-1 entries refer to
 constexpr int kListTrash = kL1Cap + kL2Cap + 4 * kRecords;  // a word nobody reads: where unlisted lanes "append"
 constexpr int kListWords = kListTrash + 4;
@@ -101,17 +109,20 @@ struct Params {
   const float4* rot;       // candidate rotations (w, x, y, z)
   const Group* group;      // one per workgroup's rotations (nw * 64 from r_first on)
   unsigned long long* sums;
-  unsigned* counters;      // passes * rot_groups chunk dispensers, zeroed by the host before the launch
+  unsigned* counters;      // one chunk dispenser per unit = (pass, rotation block), zeroed by the host before the launch
   unsigned* error;         // [0] sticky: an exact cell more than one cell from the fast one (cannot happen);
-                           // [1] a level-1 list overflowed -- the host reruns the match with the dense kernel
+                           // [1] the same, cleared by the host when it reruns the match with the dense kernel
+                           // (the level-1 list itself cannot overflow: the hot loop stops and drains it first)
   int R, r_first, r_last, T, passes;
   int n;                   // real points (Morton order)
   int chunk;               // points per chunk, multiple of 4
   int point_chunks, rot_groups, rot_blocks, nw, slots;  // nw waves per workgroup, rot_blocks = ceil(rot_groups / nw)
+  int units;               // passes * rot_blocks
+  int n_a, n_b, tickets;   // tickets [0, n_a) hold kBatch chunks, [n_a, n_a + n_b) two, the rest one (guided sizes)
   unsigned thr;            // unresolved  <=>  (bits(w) & 0xffff) <= thr
   int cells;               // LDS box capacity per workgroup (cells)
-  int debug;               // timing experiments only (wrong sums): 1 skip the lists, 2 skip staging, 4 skip the lookups,
-                           // 8 no work at all, 16 unconditional flush atomics, 32 no flush (DLIOM_BOX_DEBUG)
+  int debug;               // -DDLIOM_EXPERIMENTS builds only (wrong sums): 1 skip the lists, 2 skip staging, 4 skip the
+                           // lookups, 8 no work at all, 16 unconditional flush atomics, 32 no flush, 64 no stealing
 };
 
 typedef __attribute__((address_space(3))) const unsigned short lds_cu16;
@@ -191,7 +202,6 @@ struct Lists {
   int* rec;        // kRecords x (lo[3], first point of the chunk)
   int n1;          // wave-uniform counts
   int seq;         // chunk records written so far
-  bool overflow;
 };
 
 // Level 2: one listed lookup per lane, resolved with the reference's own arithmetic.
@@ -224,7 +234,10 @@ __device__ __forceinline__ void resolve_l2(const GridView& g, const Params& p, c
       const int ex = cell_of(rx + tr[0], g.resolution), ey = cell_of(ry + tr[1], g.resolution),
                 ez = cell_of(rz + tr[2], g.resolution);
       if (ex != fx || ey != fy || ez != fz) {
-        if (abs(ex - fx) > 1 || abs(ey - fy) > 1 || abs(ez - fz) > 1) atomicOr(p.error, 1u);  // cannot happen
+        if (abs(ex - fx) > 1 || abs(ey - fy) > 1 || abs(ez - fz) > 1) {  // cannot happen (error budget above)
+          atomicOr(p.error, 1u);
+          atomicOr(p.error + 1, 1u);  // the host redoes the match on the dense kernel
+        }
         const long long delta = static_cast<long long>(mirror_value(g, ex, ey, ez)) -
                                 static_cast<long long>(mirror_value(g, fx, fy, fz));
         if (delta != 0)
@@ -499,22 +512,27 @@ __device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsig
   }
 }
 
+// chunks [c0, c1) of ticket t: guided sizes (kBatch, then 2, then 1), so that the last tickets of a unit are short
+__device__ __forceinline__ void ticket_chunks(const Params& p, int t, int& c0, int& c1) {
+  if (t < p.n_a) {
+    c0 = t * kBatch;
+    c1 = c0 + kBatch;
+  } else if (t < p.n_a + p.n_b) {
+    c0 = p.n_a * kBatch + (t - p.n_a) * 2;
+    c1 = c0 + 2;
+  } else {
+    c0 = p.n_a * kBatch + p.n_b * 2 + (t - p.n_a - p.n_b);
+    c1 = c0 + 1;
+  }
+  c1 = min(c1, p.point_chunks);
+}
+
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rtcsm_score_box_kernel(
     GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
   extern __shared__ float4 lds_dyn4[];  // [kTC tau | band bitmap | ticket words | nw x lists | box]
   float4* lds_tau = lds_dyn4;
   unsigned* lds_bitmap = reinterpret_cast<unsigned*>(lds_dyn4 + kTC);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nthreads = blockDim.x;
-  // this workgroup: (pass, rotation block); several workgroups share one and draw point chunks together
-  const int rb = blockIdx.x % p.rot_blocks;
-  const int tp = (blockIdx.x / p.rot_blocks) % p.passes;
-  const int slot = blockIdx.x / (p.rot_blocks * p.passes);
-  if (threadIdx.x < kTC) lds_tau[threadIdx.x] = p.tau[tp * kTC + threadIdx.x];
-  for (int w = threadIdx.x; w < kBitmapWords; w += nthreads) lds_bitmap[w] = p.bitmap[tp * kBitmapWords + w];
-  __syncthreads();
-  const int rot_b0 = p.r_first + rb * p.nw * 64;  // first rotation of the workgroup
-  const int rot0 = rot_b0 + wave * 64;            // ... of this wave
-  const bool wave_active = rot0 < p.r_last;       // surplus waves of the last workgroup only help staging
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char*)lds_dyn4));  // LDS byte address of the block
   const unsigned tick_off = static_cast<unsigned>(kTC * sizeof(float4)) + kBitmapWords * 4u;
@@ -529,192 +547,229 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
   ls.rec = reinterpret_cast<int*>(ls.l2 + kL2Cap);
   ls.n1 = 0;
   ls.seq = 0;
-  ls.overflow = false;
-  const Pass ps = p.pass[tp];
-  const bool lane_active = rot0 + lane < p.r_last;
-  const float4 qq = p.rot[lane_active ? rot0 + lane : (wave_active ? rot0 : rot_b0)];  // idle lanes shadow a real rotation
-  const Quat4 q{qq.x, qq.y, qq.z, qq.w};
   const float inv = g.inv_resolution;
-  const Group grp = p.group[rb];
-  const float4 qcc = p.rot[rot_b0 + grp.c_lane];
-  const Quat4 qc{qcc.x, qcc.y, qcc.z, qcc.w};
-  float rabs[9];  // |R(qc)|, row major
-  {
-    const float w = qc.w, x = qc.x, y = qc.y, z = qc.z;
-    rabs[0] = fabsf(1.f - 2.f * (y * y + z * z));
-    rabs[1] = fabsf(2.f * (x * y - w * z));
-    rabs[2] = fabsf(2.f * (x * z + w * y));
-    rabs[3] = fabsf(2.f * (x * y + w * z));
-    rabs[4] = fabsf(1.f - 2.f * (x * x + z * z));
-    rabs[5] = fabsf(2.f * (y * z - w * x));
-    rabs[6] = fabsf(2.f * (x * z - w * y));
-    rabs[7] = fabsf(2.f * (y * z + w * x));
-    rabs[8] = fabsf(1.f - 2.f * (x * x + y * y));
-  }
   unsigned acc[kTC];
 #pragma unroll
   for (int j = 0; j < kTC; ++j) acc[j] = 0u;
   const int S = g.dense_stride, B = g.dense_bricks;
-  // Point chunks are handed out by one counter per (pass, rotation block): workgroups that meet cheap chunks
-  // simply take more.  A ticket is a batch of kBatch consecutive chunks; the first one is the workgroup's own
-  // slot (no atomic: same-address atomics serialise at ~0.15 us each), later ones are drawn from the counter
-  // while the current batch is processed.  Control flow below is uniform over the WORKGROUP (barriers).
-  unsigned* counter = p.counters + tp * p.rot_blocks + rb;
-  const int num_batches = (p.point_chunks + kBatch - 1) / kBatch;
-  int ticket = (p.debug & 8) ? num_batches : slot;
-  int n_guess = p.chunk;  // points per box that fitted last time
+  // Work units are (pass, rotation block); each has its own chunk dispenser.  A workgroup starts in its HOME unit
+  // (blockIdx -> unit as evenly as the launch allows; its first ticket is its own slot, no atomic: same-address
+  // atomics serialise at ~0.15 us each) and, when that unit's tickets are gone, moves on to the other units and helps
+  // there (its accumulators are flushed per unit).  Tickets shrink (kBatch, 2, 1 chunks): with equal tickets of 4 a unit's
+  // 512 tickets over 170 workgroups left all but two of them idle for the length of a fourth ticket -- a quarter of
+  // the kernel (profiles/r2_pmc_score_kernel.json: 2.7 of 4 resident waves per SIMD on average).  Later tickets are
+  // drawn while the current one is processed.  Control flow below is uniform over the WORKGROUP (barriers).
+  const int home = static_cast<int>(blockIdx.x % static_cast<unsigned>(p.units));
+  const int slot = static_cast<int>(blockIdx.x / static_cast<unsigned>(p.units));
   int parity = 0;
-  int since_flush = 0;     // points added to the accumulators since they were last cleared (uniform)
-  while (ticket < num_batches) {
-    unsigned next_raw = 0u;
-    if (threadIdx.x == 0) next_raw = atomicAdd(counter, 1u);  // in flight while this batch is processed
-    for (int c = ticket * kBatch; c < min((ticket + 1) * kBatch, p.point_chunks); ++c) {
-      const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
-      int lo = c_begin;
-      while (lo < c_end) {
-        int n = min(c_end - lo, n_guess);
-        Geometry geo;
-        bool fits_out = false;
-        // ---- bounding box of every lookup of (these points) x (the workgroup's rotations) x (this pass);
-        //      every wave computes the same box from the same inputs
-        for (;;) {
-          // lanes = POINTS here: every lookup of point p under rotation q_lane lies within
-          //   R_c (p + dc x p)  +-  |R_c| (hd (x) |p|)  +-  theta2 |p|      (metres, before the translation)
-          // of the centre lane's image (first-order spread of the rotations plus the second-order bound)
-          float lo_f[3], hi_f[3];
-          {
-            const bool have = lane < n;
-            const int i = lo + (have ? lane : 0);
-            const float x = px[i], y = py[i], z = pz[i];
-            const float sx_ = grp.dc[1] * z - grp.dc[2] * y, sy_ = grp.dc[2] * x - grp.dc[0] * z, sz_ = grp.dc[0] * y - grp.dc[1] * x;
-            float cx, cy, cz;
-            rotate_point(qc, x + sx_, y + sy_, z + sz_, cx, cy, cz);
-            const float fx = fabsf(x), fy = fabsf(y), fz = fabsf(z);
-            const float hx = grp.hd[1] * fz + grp.hd[2] * fy, hy = grp.hd[2] * fx + grp.hd[0] * fz, hz = grp.hd[0] * fy + grp.hd[1] * fx;
-            const float m2 = grp.theta2 * (fx + fy + fz) + 1.0e-5f * (fx + fy + fz);
-            const float c3[3] = {cx, cy, cz};
+  int loaded_pass = -1;
+  const int hops = DLIOM_BOX_DBG(p, 64) ? 1 : p.units;
+  for (int hop = 0; hop < hops; ++hop) {
+    int unit = home + hop;
+    if (unit >= p.units) unit -= p.units;
+    unsigned* counter = p.counters + unit;
+    int ticket;
+    if (hop == 0) {
+      ticket = DLIOM_BOX_DBG(p, 8) ? p.tickets : slot;
+    } else {
+      if (threadIdx.x == 0) tick[parity] = atomicAdd(counter, 1u);
+      __syncthreads();
+      ticket = p.slots + static_cast<int>(tick[parity]);
+      parity ^= 1;
+    }
+    if (ticket >= p.tickets) continue;  // nothing left here
+    // this unit: (pass, rotation block)
+    const int rb = unit % p.rot_blocks;
+    const int tp = unit / p.rot_blocks;
+    if (tp != loaded_pass) {
+      __syncthreads();  // nobody still reads the previous pass's tables
+      if (threadIdx.x < kTC) lds_tau[threadIdx.x] = p.tau[tp * kTC + threadIdx.x];
+      for (int w = threadIdx.x; w < kBitmapWords; w += nthreads) lds_bitmap[w] = p.bitmap[tp * kBitmapWords + w];
+      __syncthreads();
+      loaded_pass = tp;
+    }
+    const int rot_b0 = p.r_first + rb * p.nw * 64;  // first rotation of the workgroup
+    const int rot0 = rot_b0 + wave * 64;            // ... of this wave
+    const bool wave_active = rot0 < p.r_last;       // surplus waves of the last workgroup only help staging
+    const Pass ps = p.pass[tp];
+    const bool lane_active = rot0 + lane < p.r_last;
+    const float4 qq = p.rot[lane_active ? rot0 + lane : (wave_active ? rot0 : rot_b0)];  // idle lanes shadow a real rotation
+    const Quat4 q{qq.x, qq.y, qq.z, qq.w};
+    const Group grp = p.group[rb];
+    const float4 qcc = p.rot[rot_b0 + grp.c_lane];
+    const Quat4 qc{qcc.x, qcc.y, qcc.z, qcc.w};
+    float rabs[9];  // |R(qc)|, row major
+    {
+      const float w = qc.w, x = qc.x, y = qc.y, z = qc.z;
+      rabs[0] = fabsf(1.f - 2.f * (y * y + z * z));
+      rabs[1] = fabsf(2.f * (x * y - w * z));
+      rabs[2] = fabsf(2.f * (x * z + w * y));
+      rabs[3] = fabsf(2.f * (x * y + w * z));
+      rabs[4] = fabsf(1.f - 2.f * (x * x + z * z));
+      rabs[5] = fabsf(2.f * (y * z - w * x));
+      rabs[6] = fabsf(2.f * (x * z - w * y));
+      rabs[7] = fabsf(2.f * (y * z + w * x));
+      rabs[8] = fabsf(1.f - 2.f * (x * x + y * y));
+    }
+    int n_guess = p.chunk;  // points per box that fitted last time
+    int since_flush = 0;    // points added to the accumulators since they were last cleared (uniform)
+    while (ticket < p.tickets) {
+      unsigned next_raw = 0u;
+      if (threadIdx.x == 0) next_raw = atomicAdd(counter, 1u);  // in flight while this ticket is processed
+      int c_first, c_last;
+      ticket_chunks(p, ticket, c_first, c_last);
+      for (int c = c_first; c < c_last; ++c) {
+        const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
+        int lo = c_begin;
+        while (lo < c_end) {
+          int n = min(c_end - lo, n_guess);
+          Geometry geo;
+          bool fits_out = false;
+          // ---- bounding box of every lookup of (these points) x (the workgroup's rotations) x (this pass);
+          //      every wave computes the same box from the same inputs
+          for (;;) {
+            // lanes = POINTS here: every lookup of point p under rotation q_lane lies within
+            //   R_c (p + dc x p)  +-  |R_c| (hd (x) |p|)  +-  theta2 |p|      (metres, before the translation)
+            // of the centre lane's image (first-order spread of the rotations plus the second-order bound)
+            float lo_f[3], hi_f[3];
+            {
+              const bool have = lane < n;
+              const int i = lo + (have ? lane : 0);
+              const float x = px[i], y = py[i], z = pz[i];
+              const float sx_ = grp.dc[1] * z - grp.dc[2] * y, sy_ = grp.dc[2] * x - grp.dc[0] * z, sz_ = grp.dc[0] * y - grp.dc[1] * x;
+              float cx, cy, cz;
+              rotate_point(qc, x + sx_, y + sy_, z + sz_, cx, cy, cz);
+              const float fx = fabsf(x), fy = fabsf(y), fz = fabsf(z);
+              const float hx = grp.hd[1] * fz + grp.hd[2] * fy, hy = grp.hd[2] * fx + grp.hd[0] * fz, hz = grp.hd[0] * fy + grp.hd[1] * fx;
+              const float m2 = grp.theta2 * (fx + fy + fz) + 1.0e-5f * (fx + fy + fz);
+              const float c3[3] = {cx, cy, cz};
+#pragma unroll
+              for (int a = 0; a < 3; ++a) {
+                const float he = rabs[3 * a] * hx + rabs[3 * a + 1] * hy + rabs[3 * a + 2] * hz + m2;
+                const float l = __builtin_fmaf(c3[a] - he, inv, ps.uc[a]) - 0.05f, h = __builtin_fmaf(c3[a] + he, inv, ps.uc[a]) + 0.05f;
+                lo_f[a] = wave_min_f(have ? l : 3.0e38f);
+                hi_f[a] = wave_max_f(have ? h : -3.0e38f);
+              }
+            }
+            bool fits = true;
+            fits_out = false;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-              const float he = rabs[3 * a] * hx + rabs[3 * a + 1] * hy + rabs[3 * a + 2] * hz + m2;
-              const float l = __builtin_fmaf(c3[a] - he, inv, ps.uc[a]) - 0.05f, h = __builtin_fmaf(c3[a] + he, inv, ps.uc[a]) + 0.05f;
-              lo_f[a] = wave_min_f(have ? l : 3.0e38f);
-              hi_f[a] = wave_max_f(have ? h : -3.0e38f);
+              // clamp far outliers: a box that large is rejected below anyway
+              const float l = fmaxf(lo_f[a] - ps.reach[a], -1.0e6f), h = fminf(hi_f[a] + ps.reach[a], 1.0e6f);
+              geo.lo[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(l)));
+              geo.dim[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(h))) - geo.lo[a] + 1;
             }
-          }
-          bool fits = true;
-          fits_out = false;
+            {  // x: whole 4-cell groups of the bricked mirror (mirror coordinate = index + half + 1)
+              const int m_lo = (geo.lo[0] + g.half + 1) & ~3;
+              const int m_hi = geo.lo[0] + g.half + 1 + geo.dim[0];  // exclusive
+              geo.lo[0] = m_lo - g.half - 1;
+              geo.dim[0] = ((m_hi - m_lo) + 3) & ~3;
+            }
+            geo.sx = static_cast<unsigned>(geo.dim[0]);
+            if (((geo.sx >> 2) & 1u) == 0u) geo.sx += 4u;  // row stride = 2 * odd dwords: rows spread over banks
+            const unsigned sy = static_cast<unsigned>(geo.dim[1]) | 1u;
+            geo.sxy = geo.sx * sy;
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            // clamp far outliers: a box that large is rejected below anyway
-            const float l = fmaxf(lo_f[a] - ps.reach[a], -1.0e6f), h = fminf(hi_f[a] + ps.reach[a], 1.0e6f);
-            geo.lo[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(l)));
-            geo.dim[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(h))) - geo.lo[a] + 1;
+            for (int a = 0; a < 3; ++a) {
+              fits = fits && geo.dim[a] <= kMaxDim && abs(ps.gi[a] - geo.lo[a]) < 1000;
+              geo.kb[a] = static_cast<float>(ps.gi[a] - geo.lo[a]) + ps.f[a];
+            }
+            fits = fits && static_cast<long long>(geo.sxy) * geo.dim[2] <= p.cells && geo.sxy <= 32767u;
+            fits_out = fits;
+            if (fits) break;
+            if (n == 1) break;
+            n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
           }
-          {  // x: whole 4-cell groups of the bricked mirror (mirror coordinate = index + half + 1)
-            const int m_lo = (geo.lo[0] + g.half + 1) & ~3;
-            const int m_hi = geo.lo[0] + g.half + 1 + geo.dim[0];  // exclusive
-            geo.lo[0] = m_lo - g.half - 1;
-            geo.dim[0] = ((m_hi - m_lo) + 3) & ~3;
+          n_guess = min(p.chunk, n >= 4 ? 2 * n : 4);
+          if (since_flush + n > kFlushPoints) {
+            flush_acc(p, ps, acc, rot0 + lane, lane_active);
+            since_flush = 0;
           }
-          geo.sx = static_cast<unsigned>(geo.dim[0]);
-          if (((geo.sx >> 2) & 1u) == 0u) geo.sx += 4u;  // row stride = 2 * odd dwords: rows spread over banks
-          const unsigned sy = static_cast<unsigned>(geo.dim[1]) | 1u;
-          geo.sxy = geo.sx * sy;
+          since_flush += fits_out ? n : 1;
+          if (!fits_out) {
+            // a single point whose lookups do not fit the box (huge angular window / far outlier): the exact
+            // path straight from the mirror in HBM, every lane its own rotation
+            float rx, ry, rz;
+            rotate_point(q, px[lo], py[lo], pz[lo], rx, ry, rz);
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            fits = fits && geo.dim[a] <= kMaxDim && abs(ps.gi[a] - geo.lo[a]) < 1000;
-            geo.kb[a] = static_cast<float>(ps.gi[a] - geo.lo[a]) + ps.f[a];
+            for (int j = 0; j < kTC; ++j) {
+              const float* tr = p.trans + 3 * (ps.j0 + min(j, ps.tc - 1));
+              acc[j] += mirror_value(g, cell_of(rx + tr[0], g.resolution), cell_of(ry + tr[1], g.resolution),
+                                     cell_of(rz + tr[2], g.resolution));
+            }
+            lo += 1;
+            continue;
           }
-          fits = fits && static_cast<long long>(geo.sxy) * geo.dim[2] <= p.cells && geo.sxy <= 32767u;
-          fits_out = fits;
-          if (fits) break;
-          if (n == 1) break;
-          n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
-        }
-        n_guess = min(p.chunk, n >= 4 ? 2 * n : 4);
-        if (since_flush + n > kFlushPoints) {
-          flush_acc(p, ps, acc, rot0 + lane, lane_active);
-          since_flush = 0;
-        }
-        since_flush += fits_out ? n : 1;
-        if (!fits_out) {
-          // a single point whose lookups do not fit the box (huge angular window / far outlier): the exact
-          // path straight from the mirror in HBM, every lane its own rotation
-          float rx, ry, rz;
-          rotate_point(q, px[lo], py[lo], pz[lo], rx, ry, rz);
-#pragma unroll
-          for (int j = 0; j < kTC; ++j) {
-            const float* tr = p.trans + 3 * (ps.j0 + min(j, ps.tc - 1));
-            acc[j] += mirror_value(g, cell_of(rx + tr[0], g.resolution), cell_of(ry + tr[1], g.resolution),
-                                   cell_of(rz + tr[2], g.resolution));
-          }
-          lo += 1;
-          continue;
-        }
-        __syncthreads();  // every wave is done with the previous box
-        // ---- stage the box, all threads: 4-cell groups (8 bytes) of the bricked mirror, outside reads 1
-        if (!(p.debug & 2)) {
-          const int quads = geo.dim[0] >> 2;
-          const int total = quads * geo.dim[1] * geo.dim[2];
-          const float inv_q = 1.0f / static_cast<float>(quads), inv_dy = 1.0f / static_cast<float>(geo.dim[1]);
+          __syncthreads();  // every wave is done with the previous box
+          // ---- stage the box, all threads: 4-cell groups (8 bytes) of the bricked mirror, outside reads 1
+          if (!DLIOM_BOX_DBG(p, 2)) {
+            const int quads = geo.dim[0] >> 2;
+            const int total = quads * geo.dim[1] * geo.dim[2];
+            const float inv_q = 1.0f / static_cast<float>(quads), inv_dy = 1.0f / static_cast<float>(geo.dim[1]);
 #pragma unroll 4
-          for (int e = threadIdx.x; e < total; e += nthreads) {
-            const int row = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_q);  // exact: e < 2^21
-            const int xq = e - row * quads;
-            const int z = static_cast<int>((static_cast<float>(row) + 0.5f) * inv_dy);
-            const int y = row - z * geo.dim[1];
-            const int mx = geo.lo[0] + g.half + 1 + 4 * xq, my = geo.lo[1] + g.half + 1 + y, mz = geo.lo[2] + g.half + 1 + z;
-            unsigned long long val = 0x0001000100010001ull;
-            if (mx >= 0 && mx < 4 * B && my >= 0 && my < S && mz >= 0 && mz < S) {
-              const size_t off = ((static_cast<size_t>(mz >> 2) * B + (my >> 2)) * B + (mx >> 2)) * 128u +
-                                 static_cast<size_t>(((mz & 3) << 5) | ((my & 3) << 3));
-              val = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(g.dense) + off);
+            for (int e = threadIdx.x; e < total; e += nthreads) {
+              const int row = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_q);  // exact: e < 2^21
+              const int xq = e - row * quads;
+              const int z = static_cast<int>((static_cast<float>(row) + 0.5f) * inv_dy);
+              const int y = row - z * geo.dim[1];
+              const int mx = geo.lo[0] + g.half + 1 + 4 * xq, my = geo.lo[1] + g.half + 1 + y, mz = geo.lo[2] + g.half + 1 + z;
+              unsigned long long val = 0x0001000100010001ull;
+              if (mx >= 0 && mx < 4 * B && my >= 0 && my < S && mz >= 0 && mz < S) {
+                const size_t off = ((static_cast<size_t>(mz >> 2) * B + (my >> 2)) * B + (mx >> 2)) * 128u +
+                                   static_cast<size_t>(((mz & 3) << 5) | ((my & 3) << 3));
+                val = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(g.dense) + off);
+              }
+              *reinterpret_cast<unsigned long long*>(box + (static_cast<unsigned>(z) * geo.sxy +
+                                                           static_cast<unsigned>(y) * geo.sx + 4u * static_cast<unsigned>(xq))) = val;
             }
-            *reinterpret_cast<unsigned long long*>(box + (static_cast<unsigned>(z) * geo.sxy +
-                                                         static_cast<unsigned>(y) * geo.sx + 4u * static_cast<unsigned>(xq))) = val;
           }
-        }
-        // chunk record for this wave's level-1 entries of these points
-        const unsigned rec_id = static_cast<unsigned>(ls.seq & (kRecords - 1));
-        if (lane < 4) ls.rec[4 * rec_id + lane] = lane < 3 ? geo.lo[lane] : lo;
-        ++ls.seq;
-        __syncthreads();  // the box is complete
-        // ---- all lookups of these points under this wave's rotations
-        if (wave_active && !(p.debug & 4)) {
-          int i = lo;
-          const int e8 = kHotP == 8 ? lo + (n & ~7) : lo, e4 = lo + (n & ~3), e1 = lo + n;
-          for (;;) {
-            if (kHotP == 8 && i < e8)
-              i = main_loop<kHotP>(g, p, geo, q, px, py, pz, i, e8, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
-            if (i >= e8 && i < e4)
-              i = main_loop<4>(g, p, geo, q, px, py, pz, i, e4, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
-            if (i >= e4 && i < e1)
-              i = main_loop<1>(g, p, geo, q, px, py, pz, i, e1, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
-            if (i >= e1) break;
-            drain_l1(g, p, ps, lds_tau, px, py, pz, ls, false, rot0, lane);  // the list was too full to go on
+          // chunk record for this wave's level-1 entries of these points
+          const unsigned rec_id = static_cast<unsigned>(ls.seq & (kRecords - 1));
+          if (lane < 4) ls.rec[4 * rec_id + lane] = lane < 3 ? geo.lo[lane] : lo;
+          ++ls.seq;
+          __syncthreads();  // the box is complete
+          // ---- all lookups of these points under this wave's rotations
+          if (wave_active && !DLIOM_BOX_DBG(p, 4)) {
+            int i = lo;
+            const int e8 = kHotP == 8 ? lo + (n & ~7) : lo, e4 = lo + (n & ~3), e1 = lo + n;
+            for (;;) {
+              if (kHotP == 8 && i < e8)
+                i = main_loop<kHotP>(g, p, geo, q, px, py, pz, i, e8, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+              if (i >= e8 && i < e4)
+                i = main_loop<4>(g, p, geo, q, px, py, pz, i, e4, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+              if (i >= e4 && i < e1)
+                i = main_loop<1>(g, p, geo, q, px, py, pz, i, e1, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+              if (i >= e1) break;
+              drain_l1(g, p, ps, lds_tau, px, py, pz, ls, false, rot0, lane);  // the list was too full to go on
+            }
+            // ---- listed pairs: 64 at a time; everything before the oldest record is overwritten
+            if (!DLIOM_BOX_DBG(p, 1) && (ls.n1 >= 64 || (ls.seq & (kRecords - 1)) == 0))
+              drain_l1(g, p, ps, lds_tau, px, py, pz, ls, (ls.seq & (kRecords - 1)) == 0, rot0, lane);
           }
-          // ---- listed pairs: 64 at a time; everything before the oldest record is overwritten
-          if (!(p.debug & 1) && (ls.n1 >= 64 || (ls.seq & (kRecords - 1)) == 0))
-            drain_l1(g, p, ps, lds_tau, px, py, pz, ls, (ls.seq & (kRecords - 1)) == 0, rot0, lane);
+          lo += n;
         }
-        lo += n;
       }
+      // the next ticket, through LDS (two words used alternately: one barrier per ticket)
+      if (threadIdx.x == 0) tick[parity] = next_raw;
+      __syncthreads();
+      ticket = p.slots + static_cast<int>(tick[parity]);
+      parity ^= 1;
     }
-    // the next ticket, through LDS (two words used alternately: one barrier per batch)
-    if (threadIdx.x == 0) tick[parity] = next_raw;
-    __syncthreads();
-    ticket = p.slots + static_cast<int>(tick[parity]);
-    parity ^= 1;
-  }
-  if (wave_active && !(p.debug & 1)) drain_l1(g, p, ps, lds_tau, px, py, pz, ls, true, rot0, lane);
-  if (p.debug & 16) {  // timing experiment: unconditional atomics of the accumulators' flush, even for zeros
+    // leaving the unit: the lists refer to its rotations and pass, the accumulators to its candidates
+    if (wave_active && !DLIOM_BOX_DBG(p, 1)) drain_l1(g, p, ps, lds_tau, px, py, pz, ls, true, rot0, lane);
+    ls.n1 = 0;
+    if (DLIOM_BOX_DBG(p, 16)) {  // timing experiment: unconditional atomics of the accumulators' flush, even for zeros
 #pragma unroll
-    for (int j = 0; j < kTC; ++j)
-      if (lane_active && j < ps.tc)
-        atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + rot0 + lane], static_cast<unsigned long long>(acc[j]));
-    return;
+      for (int j = 0; j < kTC; ++j) {
+        if (lane_active && j < ps.tc)
+          atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + rot0 + lane], static_cast<unsigned long long>(acc[j]));
+        acc[j] = 0u;
+      }
+    } else if (!DLIOM_BOX_DBG(p, 32)) {
+      flush_acc(p, ps, acc, rot0 + lane, lane_active);
+    }
   }
-  if (!(p.debug & 32)) flush_acc(p, ps, acc, rot0 + lane, lane_active);
 }
 
 }  // namespace box

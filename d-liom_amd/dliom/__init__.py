@@ -39,6 +39,8 @@ ERR_RAY_TOO_LONG = -7
 ERR_EMPTY_CLOUD = -8
 ERR_CAPACITY = -9
 ERR_SOLVER = -10
+ERR_PEER_FAILED = -12
+TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_INJECT_BOX_FAULT, TUNE_CSM_GRID_SYNC = 0, 1, 2, 3
 
 KERNEL_RTCSM_SCORE, KERNEL_RTCSM_SELECT, KERNEL_RTCSM_RESCORE, KERNEL_CSM_EVAL, KERNEL_INSERT = range(5)
 
@@ -271,6 +273,7 @@ SYMBOLS = [
     ("dliom_imu_integrator_evaluate", C.c_int, [_vp, _f64p, _f64p, _f64p, _f64p]),
     ("dliom_imu_integrator_predict", C.c_int, [_vp, _f64p, _f64p, _f64p]),
     ("dliom_rotational_histogram", C.c_int, [_f32p, C.c_int64, C.c_int, _f32p]),
+    ("dliom_rotational_histogram_mt", C.c_int, [_f32p, C.c_int64, C.c_int, C.c_int, _f32p]),
     ("dliom_rotational_scan_match", C.c_int, [_f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
@@ -281,6 +284,8 @@ SYMBOLS = [
                                                 C.c_int64, C.c_int, _f32p]),
     ("dliom_csm3d_evaluate", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, _f64p, C.c_int, C.POINTER(_f32p),
                                        _i64p, C.POINTER(_vp), _f64p, _f64p, _f64p]),
+    ("dliom_ctx_set_tuning", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("dliom_ctx_get_tuning", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("dliom_ctx_set_profiling", C.c_int, [_vp, C.c_int]),
     ("dliom_ctx_reset_profiling", C.c_int, [_vp]),
     ("dliom_ctx_kernel_time", C.c_int, [_vp, C.c_int, _f64p, _i64p]),
@@ -370,6 +375,15 @@ class Context:
 
     def synchronize(self):
         _check(self._L.dliom_ctx_synchronize(self.h), "synchronize")
+
+    def set_tuning(self, knob, value):
+        """dliom_ctx_set_tuning: TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_INJECT_BOX_FAULT, TUNE_CSM_GRID_SYNC."""
+        _check(self._L.dliom_ctx_set_tuning(self.h, int(knob), int(value)), "set_tuning")
+
+    def get_tuning(self, knob):
+        v = C.c_int(0)
+        _check(self._L.dliom_ctx_get_tuning(self.h, int(knob), C.byref(v)), "get_tuning")
+        return v.value
 
     def set_profiling(self, on):
         _check(self._L.dliom_ctx_set_profiling(self.h, int(on)), "set_profiling")
@@ -1200,12 +1214,16 @@ class FastCorrelativeScanMatcher3D:
         return self._result(r)
 
 
-def rotational_histogram(points, histogram_size):
-    """RotationalScanMatcher::ComputeHistogram (host)."""
+def rotational_histogram(points, histogram_size, threads=None):
+    """RotationalScanMatcher::ComputeHistogram (host); threads: explicit host thread count (same bits at any)."""
     pts = _f32(points).reshape(-1, 3)
     out = np.zeros(histogram_size, dtype=np.float32)
-    _check(load_library().dliom_rotational_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p)),
-           "dliom_rotational_histogram")
+    if threads is None:
+        _check(load_library().dliom_rotational_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p)),
+               "dliom_rotational_histogram")
+    else:
+        _check(load_library().dliom_rotational_histogram_mt(_p(pts, _f32p), len(pts), histogram_size, int(threads), _p(out, _f32p)),
+               "dliom_rotational_histogram_mt")
     return out
 
 

@@ -43,6 +43,7 @@ extern "C" {
 #define DLIOM_ERR_EMPTY_CLOUD (-8)      /* division by size()==0 in ScoreCandidate / sqrt(N) scaling */
 #define DLIOM_ERR_CAPACITY (-9)         /* caller-provided output buffer too small */
 #define DLIOM_ERR_SOLVER (-10)          /* Ceres would report FAILURE (evaluation or invalid steps) */
+#define DLIOM_ERR_PEER_FAILED (-12)     /* sharded match: another rank failed before the exchange (it still took part) */
 
 typedef struct dliom_ctx dliom_ctx;
 typedef struct dliom_grid dliom_grid;
@@ -229,7 +230,10 @@ int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats);
  * winner on every rank (rtcsm_3d.cc:46-51: first strictly greater score in generation order).
  *   _sharded       the collective is the caller's: `exchange` replaces *value by the maximum over all ranks (0 = ok)
  *   _sharded_rccl  `nccl_comm` is an ncclComm_t (RCCL, resolved with dlopen at first use; rank and size come from the
- *                  communicator): ncclAllReduce(ncclMax, ncclUint64, count 1) on the context's stream */
+ *                  communicator): ncclAllReduce(ncclMax, ncclUint64, count 1) on the context's stream
+ * A rank whose local part fails still takes part in the exchange (it contributes the reserved word
+ * 0x7FFFFFFFFFFFFFFF, above every real word under signed or unsigned MAX) and returns its own status afterwards;
+ * every other rank returns DLIOM_ERR_PEER_FAILED.  No rank is ever left waiting in the collective. */
 typedef int (*dliom_allreduce_max_u64)(uint64_t* value, void* user);
 int dliom_rtcsm3d_match_sharded(dliom_ctx* ctx, const dliom_rtcsm_options* options, const double initial_pose_estimate[7],
                                 const dliom_cloud* cloud, const dliom_grid* grid, int shard, int num_shards,
@@ -501,6 +505,8 @@ int dliom_fast_csm_level(const dliom_fast_csm* matcher, int depth, int32_t lo[3]
  * are processed on up to 8 host threads (same bits at any thread count; DLIOM_HISTOGRAM_THREADS=1 keeps the call on
  * the caller's thread). */
 int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram);
+/* The same with an explicit number of host threads (0 = as many as pay, at most 8; the bits do not depend on it). */
+int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n, int histogram_size, int num_threads, float* histogram);
 /* RotationalScanMatcher(histograms_at_angles).Match(histogram, initial_angle, angles)
  * (rotational_scan_matcher.cc:174-194), host: one score per angle.  The loop-closure matcher calls
  * the same code to pick the yaw candidates worth discretising. */
@@ -626,6 +632,23 @@ int dliom_csm3d_evaluate(dliom_ctx* ctx, const dliom_csm_options* options,
                          int num_clouds, const float* const* points_xyz, const int64_t* n,
                          const dliom_grid* const* grids, double* cost, double gradient[6],
                          double jtj[36]);
+
+/* Per-context choices a caller may make; none of them changes a result (every kernel variant is parity-tested).  The
+ * library never reads the environment (tuning experiments live in `make experiments` builds only). */
+enum {
+  DLIOM_TUNE_SCORE_KERNEL = 0,        /* RTCSM3D score volume: 3 LDS-box kernel over the dense mirror when the search suits
+                                         it (default), 2 rotation-per-lane over the dense mirror, 1 rotation-per-lane over
+                                         the leaf table, 0 point-per-lane over the leaf table */
+  DLIOM_TUNE_CSM_ONE_LAUNCH_MAX = 1,  /* CeresScanMatcher3D: clouds up to this many points (sum over grids) run the whole
+                                         trust-region loop in one launch (default 4096, 0 = never) */
+  DLIOM_TUNE_INJECT_BOX_FAULT = 2,    /* test hook: the next match treats the box kernel's consistency word as set, i.e.
+                                         takes the "redo on the dense kernel" path once (same result by construction) */
+  DLIOM_TUNE_CSM_GRID_SYNC = 3,       /* CeresScanMatcher3D on large clouds: 1 = one cooperative launch with grid barriers,
+                                         0 = one launch per evaluation */
+  DLIOM_TUNE_COUNT = 4
+};
+int dliom_ctx_set_tuning(dliom_ctx* ctx, int knob, int value);
+int dliom_ctx_get_tuning(const dliom_ctx* ctx, int knob, int* value);
 
 /* Kernel timing (HIP events on the context's stream). */
 enum {

@@ -92,6 +92,7 @@ def _declare(L):
     sig("orc_rtcsm3d_match_range", C.c_float, _f64p, _f64p, _f32p, C.c_int, vp, C.c_int64, C.c_int64,
         C.POINTER(C.c_int64))
     sig("orc_rtcsm3d_float_sums", None, _f64p, _f64p, _f32p, C.c_int, vp, C.POINTER(C.c_int64), C.c_int64, _f32p)
+    sig("orc_rtcsm3d_at", None, _f64p, _f64p, _f32p, C.c_int, vp, C.POINTER(C.c_int64), C.c_int64, _u64p, _f32p)
     sig("orc_rtcsm3d_value_sums", None, _f64p, _f64p, _f32p, C.c_int, vp, C.c_int64, C.c_int64, _u64p)
     sig("orc_transform_cell_indices", None, _f32p, _f32p, C.c_int, C.c_float, _i32p)
     sig("orc_interpolated_probability", C.c_double, vp, C.c_double, C.c_double, C.c_double)
@@ -477,6 +478,27 @@ def rtcsm3d_float_sums(opts, init7, pts, grid, indices):
     lib().orc_rtcsm3d_float_sums(_p(_opts4(opts), _f64p), _p(_f64(init7), _f64p), _p(pts, _f32p), len(pts), grid.h,
                                  idx.ctypes.data_as(C.POINTER(C.c_int64)), len(idx), _p(out, _f32p))
     return out
+
+
+def rtcsm3d_at(opts, init7, pts, grid, indices, threads=8):
+    """Integer value sums and reference scores (ScoreCandidate) of the candidates `indices`, on host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    pts = _f32(pts).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, dtype=np.int64)
+    sums = np.zeros(len(idx), dtype=np.uint64)
+    scores = np.zeros(len(idx), dtype=np.float32)
+    o, i7 = _opts4(opts), _f64(init7)
+
+    def run(fc):
+        f, c = fc
+        if c > 0:
+            lib().orc_rtcsm3d_at(_p(o, _f64p), _p(i7, _f64p), _p(pts, _f32p), len(pts), grid.h,
+                                 idx[f:f + c].ctypes.data_as(C.POINTER(C.c_int64)), c, _p(sums[f:f + c], _u64p),
+                                 _p(scores[f:f + c], _f32p))
+    parts = _ranges(len(idx), max(1, threads)) if len(idx) else []
+    with ThreadPoolExecutor(max(1, threads)) as pool:
+        list(pool.map(run, parts))
+    return sums, scores
 
 
 def rtcsm3d_value_sums(opts, init7, pts, grid, first=0, count=-1):

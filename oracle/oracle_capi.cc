@@ -379,6 +379,30 @@ void orc_rtcsm3d_float_sums(const double* opts, const double* init7, const float
     sums[i] = score;
   }
 }
+// Candidates given by index (huge windows where the full loop would take hours): the integer value sum and the
+// reference's score (ScoreCandidate, rtcsm_3d.cc:97-113) of each.  The candidate list is generated once per call.
+void orc_rtcsm3d_at(const double* opts, const double* init7, const float* pts, int n, void* grid,
+                    const int64_t* indices, int64_t k, uint64_t* value_sums, float* scores) {
+  const RealTimeCorrelativeScanMatcher3D m(
+      RealTimeCorrelativeScanMatcherOptions{opts[0], opts[1], opts[2], opts[3]});
+  const PointCloud cloud = ToCloud(pts, n);
+  const HybridGrid& g = *G(grid);
+  const std::vector<Rigid3f> ts = m.GenerateExhaustiveSearchTransforms(g.resolution(), cloud);
+  const Rigid3f init = ToRigid(init7).cast<float>();
+  for (int64_t i = 0; i < k; ++i) {
+    const Rigid3f cand = init * ts[indices[i]];
+    const PointCloud moved = TransformPointCloud(cloud, cand);
+    if (value_sums != nullptr) {
+      uint64_t s = 0;
+      for (const Vec3f& p : moved) {
+        const uint16 v = g.value(g.GetCellIndex(p)) & 0x7fff;
+        s += v == 0 ? 1 : v;
+      }
+      value_sums[i] = s;
+    }
+    if (scores != nullptr) scores[i] = m.ScoreCandidate(g, moved, ts[indices[i]]);
+  }
+}
 // Cell indices of a cloud under a float pose (the bit-exactness probe).
 void orc_transform_cell_indices(const float* pose7, const float* pts, int n, float resolution,
                                 int* out) {

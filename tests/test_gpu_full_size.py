@@ -5,7 +5,10 @@ C = 35 937 candidates, N = 65 536 points -- against the FULL oracle: the referen
 all candidates (8 host threads over contiguous ranges, combined in generation order), the whole integer
 score volume, CeresScanMatcher3D, and both grids after the insertion.  The same scene with the search
 window cut into 8 candidate shards.  Config 5 (128 x 2048 @ 5 cm, bits = 4 mirror, T = 343 translations =
-13 passes of the box kernel) on a reduced angular window so that the oracle finishes in seconds.
+13 passes of the box kernel) on a reduced angular window so that the oracle finishes in seconds, and at the
+benchmarked 1 degree window (C = 3 176 523) on 10 000 random candidates plus the neighbourhood of the winner.
+The "redo on the dense kernel" path of the box kernel (fault injected) and the three fallback score kernels at
+config 2's size.
 """
 import os
 
@@ -17,6 +20,7 @@ from helpers import (DEFAULT_CSM, DEFAULT_RTCSM, FREE, build_device_scene, devic
 
 pytestmark = pytest.mark.gpu
 THREADS = min(8, os.cpu_count() or 1)
+THREADS_BIG = min(32, os.cpu_count() or 1)
 
 
 @pytest.fixture(scope="module")
@@ -69,6 +73,62 @@ def test_config2_full_score_volume(dl, ctx, orc, bench_scene):
     assert got.shape == want.shape == (35937,)
     assert np.array_equal(got.astype(np.uint64), want)
     assert rt.box_error() == 0
+
+
+def test_config2_dense_rerun_after_box_fault(dl, ctx, orc, bench_scene):
+    """The box kernel cross-checks its fast index; if the check ever fails the match is redone on the dense kernel
+    (rtcsm3d.hip `box_overflowed`).  The kernel cannot be made to fail, so the host-side flag is injected: the rerun must
+    give the oracle's winner, report the dense kernel, and leave the next match on the box kernel."""
+    s = bench_scene
+    sc, ref = s["sc"], s["ref"]
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    ctx.set_tuning(dl.TUNE_INJECT_BOX_FAULT, 1)
+    score, pose = rt.Match(sc["init"], sc["cloud"], s["g_hi"])
+    st = rt.last_stats()
+    assert ctx.get_tuning(dl.TUNE_INJECT_BOX_FAULT) == 0  # consumed
+    assert st.score_kernel == 2, st.score_kernel          # the rerun ran on the dense-mirror kernel
+    assert st.best_index == ref["best_index"]
+    assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
+    assert np.array_equal(pose, ref["pose"])
+    # the score-volume entry point takes the same path
+    ctx.set_tuning(dl.TUNE_INJECT_BOX_FAULT, 1)
+    got = rt.score_volume(sc["init"], sc["pts"], s["g_hi"])
+    idx = np.random.RandomState(3).randint(0, len(got), size=64)
+    want, _ = orc.rtcsm3d_at(DEFAULT_RTCSM, sc["init"], sc["pts"], s["og_hi"], idx, threads=THREADS)
+    assert np.array_equal(got[idx].astype(np.uint64), want)
+    # and the sharded phases (begin reads the word, finish does not)
+    ctx.set_tuning(dl.TUNE_INJECT_BOX_FAULT, 1)
+    sh = dl.RtcsmShard(ctx, DEFAULT_RTCSM, 0, 1)
+    score2, pose2 = sh.decode(sh.finish(sh.begin(sc["init"], sc["cloud"], s["g_hi"])))
+    assert rt.last_stats().score_kernel == 2
+    assert np.float32(score2).tobytes() == np.float32(ref["score"]).tobytes() and np.array_equal(pose2, ref["pose"])
+    ctx.set_tuning(dl.TUNE_INJECT_BOX_FAULT, 1)
+    score2, pose2 = sh.match(sc["init"], sc["cloud"], s["g_hi"], lambda v: v)
+    assert rt.last_stats().score_kernel == 2
+    assert np.float32(score2).tobytes() == np.float32(ref["score"]).tobytes() and np.array_equal(pose2, ref["pose"])
+    ctx.set_tuning(dl.TUNE_INJECT_BOX_FAULT, 0)
+    score3, _ = rt.Match(sc["init"], sc["cloud"], s["g_hi"])
+    assert rt.last_stats().score_kernel == 3 and np.float32(score3).tobytes() == np.float32(ref["score"]).tobytes()
+    assert rt.box_error() == 0
+
+
+def test_config2_every_score_kernel_gives_the_same_volume(dl, ctx, orc, bench_scene):
+    """The fallback kernels (dense mirror, leaf table by rotation, leaf table by point: what runs when the search does
+    not suit the box kernel or the grid has no mirror) produce the box kernel's volume bit for bit at the bench size."""
+    s = bench_scene
+    sc = s["sc"]
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    want = rt.score_volume(sc["init"], sc["pts"], s["g_hi"])
+    try:
+        for kernel in (2, 1, 0):
+            ctx.set_tuning(dl.TUNE_SCORE_KERNEL, kernel)
+            got = rt.score_volume(sc["init"], sc["pts"], s["g_hi"])
+            assert np.array_equal(got, want), kernel
+            score, pose = rt.Match(sc["init"], sc["cloud"], s["g_hi"])
+            assert rt.last_stats().score_kernel == kernel
+            assert np.float32(score).tobytes() == np.float32(s["ref"]["score"]).tobytes() and np.array_equal(pose, s["ref"]["pose"])
+    finally:
+        ctx.set_tuning(dl.TUNE_SCORE_KERNEL, 3)
 
 
 def test_config2_eight_candidate_shards(dl, ctx, orc, bench_scene):
@@ -137,6 +197,53 @@ def test_config5_reduced_window(dl, ctx, orc):
     rng = np.random.RandomState(5)
     for c in rng.randint(0, len(sums), size=48):
         assert sums[c] == orc.rtcsm3d_value_sums(opts, sc["init"], sc["pts"], og_hi, first=int(c), count=1)[0]
+    assert rt.box_error() == 0
+    sc["cloud"].close()
+    g_hi.close()
+    g_lo.close()
+
+
+def test_config5_benchmarked_window_sampled(dl, ctx, orc):
+    """Config 5 exactly as tools/r2_config5.sh / bench.py --config 5 run it: 128 x 2048 @ 5 cm, the 1 degree angular
+    window, C = 3 176 523 candidates, N = 262 144.  The oracle's full loop would take hours, so: (a) 10 000 random
+    candidates' integer sums against the oracle; (b) the winner: the device's index, score bits and pose against the
+    oracle's ScoreCandidate of that candidate, and against the first maximum (generation order, strict >) of the oracle's
+    exact scores over the 512 candidates that rank highest by the real-valued score computed from the (sample-checked)
+    integer volume -- the float rounding of the reference's sequential sum moves a score by ~1e-6 relative, the 512th
+    candidate is orders of magnitude further down."""
+    opts = dict(DEFAULT_RTCSM)
+    ins, g_hi, g_lo, scans = build_device_scene(dl, ctx, 128, 2048, 0.05, 0.45, map_scans=3)
+    sc = scans[0]
+    assert g_hi.bits == 4
+    og_hi = device_grid_to_oracle(orc, g_hi)
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, opts)
+    score, pose = rt.Match(sc["init"], sc["cloud"], g_hi)
+    st = rt.last_stats()
+    C = st.window.num_candidates
+    assert C == 3176523 and st.window.num_translations == 343 and st.num_points == 262144
+    assert st.score_kernel == 3
+    sums = rt.score_volume(sc["init"], sc["pts"], g_hi)
+    assert len(sums) == C
+    # (a)
+    idx = np.random.RandomState(11).randint(0, C, size=10000)
+    want, _ = orc.rtcsm3d_at(opts, sc["init"], sc["pts"], og_hi, idx, threads=THREADS_BIG)
+    assert np.array_equal(sums[idx].astype(np.uint64), want)
+    # (b)
+    tr, ca = orc.rtcsm3d_candidates(opts, 0.05, sc["pts"], sc["init"])
+    assert len(tr) == C
+    t_norm = np.linalg.norm(tr[:, :3].astype(np.float64), axis=1)
+    angle = 2.0 * np.arctan2(np.linalg.norm(tr[:, 4:7].astype(np.float64), axis=1), np.abs(tr[:, 3].astype(np.float64)))
+    arg = t_norm * opts["translation_delta_cost_weight"] + angle * opts["rotation_delta_cost_weight"]
+    k_scale = (0.9 - 0.1) / 32766.0
+    real = (sums.astype(np.float64) * k_scale + (0.1 - k_scale) * st.num_points) / st.num_points * np.exp(-arg * arg)
+    top = np.sort(np.argsort(-real, kind="stable")[:512])  # generation order
+    assert st.best_index in top
+    _, exact = orc.rtcsm3d_at(opts, sc["init"], sc["pts"], og_hi, top, threads=THREADS_BIG)
+    best = int(top[int(np.argmax(exact))])  # argmax returns the first maximum
+    assert real[np.argsort(-real, kind="stable")[511]] < real[st.best_index] * (1.0 - 1e-4)  # the cut is far below the top
+    assert best == st.best_index, (best, st.best_index)
+    assert np.float32(score).tobytes() == np.float32(exact.max()).tobytes()
+    assert np.array_equal(pose, ca[best].astype(np.float64))
     assert rt.box_error() == 0
     sc["cloud"].close()
     g_hi.close()

@@ -360,10 +360,11 @@ def test_csm3d_one_launch_equals_per_evaluation_loop(dl, ctx, orc, monkeypatch, 
     lo = pts[rng.choice(len(pts), n_lo, replace=False)]
     opts = dict(DEFAULT_CSM, only_optimize_yaw=yaw_only)
     m = dl.CeresScanMatcher3D(ctx, opts)
-    monkeypatch.setenv("DLIOM_CSM_PERSISTENT_MAX", "4096")
+    ctx.set_tuning(dl.TUNE_CSM_ONE_LAUNCH_MAX, 4096)
     pose_a, sum_a = m.Match(init[:3], init, [(hi, dg_hi), (lo, dg_lo)])
-    monkeypatch.setenv("DLIOM_CSM_PERSISTENT_MAX", "0")
+    ctx.set_tuning(dl.TUNE_CSM_ONE_LAUNCH_MAX, 0)
     pose_b, sum_b = m.Match(init[:3], init, [(hi, dg_hi), (lo, dg_lo)])
+    ctx.set_tuning(dl.TUNE_CSM_ONE_LAUNCH_MAX, 4096)
     if n_hi + n_lo <= 512:
         assert np.array_equal(pose_a, pose_b), (pose_a, pose_b)
         assert sum_a == sum_b

@@ -66,6 +66,45 @@ def test_two_ranks_one_collective_through_the_c_entry_point():
     assert ret.get(0) is True and ret.get(1) is True
 
 
+def _failing_worker(rank, world, port, ret):
+    """Rank 1 hands in an empty cloud (DLIOM_ERR_EMPTY_CLOUD before any kernel): it must still join the collective,
+    and rank 0 must come back with DLIOM_ERR_PEER_FAILED instead of hanging in the all-reduce."""
+    for p in (ROOT, os.path.join(ROOT, "d-liom_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dliom as dl
+    from dliom import sharded
+    ctx = dl.Context(0)
+    orc, og, dg, pts, init, opts = _scene(dl, ctx)
+    cloud = dl.PointCloud(ctx, pts if rank == 0 else pts[:0])
+    shard = dl.RtcsmShard(ctx, opts, rank, world)
+    try:
+        sharded.sharded_match(shard, init, cloud, dg, dist=dist)
+        ret[rank] = "no error"
+    except dl.DliomError as e:
+        ret[rank] = e.status
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_still_joins_the_collective():
+    import torch.multiprocessing as mp
+    import dliom as dl
+    mpc = mp.get_context("spawn")
+    ret = mpc.Manager().dict()
+    port = _free_port()
+    procs = [mpc.Process(target=_failing_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "a rank hung or crashed"
+    assert ret.get(0) == dl.ERR_PEER_FAILED and ret.get(1) == dl.ERR_EMPTY_CLOUD, dict(ret)
+
+
 def _rccl_one_rank_main():
     """Body of the RCCL test; runs in a process of its own (see the test)."""
     for p in (ROOT, os.path.join(ROOT, "d-liom_amd"), os.path.join(ROOT, "tests")):
