@@ -13,8 +13,12 @@ region starts.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, every rank runs its own independent scan stream against its own
-submap (weak scaling, no data-path collective; SURVEY.md 8e "replicas").  Rank 0 prints ONE JSON
-line.  The CPU oracle is used ONLY for the `cpu_baseline` leg (rank 0, N == 1).
+submap (weak scaling, no data-path collective; SURVEY.md 8e "replicas").  `python bench.py --gpus N`
+without a launcher starts the N ranks itself (re-executes under torch.distributed.run); the printed
+`n_gpus` is the communicator's size.  Rank 0 prints ONE JSON line; for N > 1 it also carries `sharded`
+(config 4: the same stream with the search window sharded over the ranks) and `sharded_config5` (the
+128 x 2048 @ 5 cm search, 98 % score volume, sharded the same way).  The CPU oracle is used ONLY for the
+`cpu_baseline` / `parity` legs (rank 0, N == 1), after the timed region.
 """
 import argparse
 import json
@@ -60,14 +64,80 @@ def parse():
     ap.add_argument("--no-wref", action="store_true", help="skips the W-ref (reference-faithful filter chain) line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--dump-steps", action="store_true", help="per-step stage times on stderr (debugging)")
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="5 = BASELINE config 5 (128 x 2048 returns, 5 cm voxels, 3 map scans); 2 = the headline config")
+    ap.add_argument("--no-pmc", action="store_true", help="skips the rocprofv3 --pmc child runs (roofline counters)")
+    ap.add_argument("--no-config5", action="store_true", help="N > 1: skips the sharded config-5 line")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: scene + 3 matches, no timing
+    a = ap.parse_args()
+    if a.config == 5:
+        a.beams, a.azimuths, a.high_resolution = 128, 2048, 0.05
+        a.map_scans = min(a.map_scans, 3)
+        a.distinct_scans = min(a.distinct_scans, 2)
+        if a.steps == 20 and a.warmup == 3:  # the defaults: a config-5 step takes ~0.4 s
+            a.steps, a.warmup = 5, 1
+    return a
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks (one per GPU) under torch.distributed.run."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def build_scene(args, dl, synth, ctx):
+    """Submap (map_scans scans inserted at ground truth) and the scans to match; the same on every rank."""
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
+    g_hi = dl.HybridGrid(ctx, args.high_resolution)
+    g_lo = dl.HybridGrid(ctx, args.low_resolution)
+    centers = synth.bubbles()
+    for s in range(args.map_scans):
+        pose = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(pose, args.beams, args.azimuths, centers=centers)
+        cloud = dl.PointCloud(ctx, pts)
+        pf = pose.astype(np.float32)
+        ins.InsertCloud(g_hi, cloud, poses=[pf], max_range=HIGH_RES_MAX_RANGE)
+        ins.InsertCloud(g_lo, cloud, poses=[pf])
+        cloud.close()
+    scans = []
+    for k in range(args.distinct_scans):
+        truth = synth.trajectory_pose(0.1 * (args.map_scans + k))
+        pts, _ = synth.scan(truth, args.beams, args.azimuths, centers=centers)
+        init = synth.perturb_pose(truth, 0.1, 0.5, seed=13 + k)
+        scans.append(dict(truth=truth, pts=pts, init=init, cloud=dl.PointCloud(ctx, pts)))
+    return ins, g_hi, g_lo, scans
+
+
+def pmc_child(args):
+    """Body of the rocprofv3 --pmc child runs (tools/pmc_live.py): the bench scene, three RTCSM3D matches."""
+    import dliom as dl
+    from dliom import synth
+    dl.load_library()
+    ctx = dl.Context(0)
+    ins, g_hi, g_lo, scans = build_scene(args, dl, synth, ctx)
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_OPTS)
+    for i in range(3):
+        rt.Match(scans[i % len(scans)]["init"], scans[i % len(scans)]["cloud"], g_hi)
+    ctx.synchronize()
 
 
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)" % (args.gpus, world))
     import torch
     dist = None
     # DLIOM_BENCH_BACKEND=gloo: control-flow check of the N > 1 path on a one-GPU box (every rank on GPU 0, host
@@ -81,9 +151,14 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                raise SystemExit("bench.py: --gpus %d needs %d GPUs, %d visible (DLIOM_BENCH_BACKEND=gloo runs the "
+                                 "N-rank control flow on one GPU)" % (world, world, torch.cuda.device_count()))
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        world = dist.get_world_size()
     torch.cuda.set_device(local_rank)
     coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
@@ -97,25 +172,9 @@ def main():
     # replicas: every rank runs the SAME scan stream on its own submap copy, so that the per-GPU work
     # (N, C, evaluations) is identical and the max-over-ranks time measures scaling, not scene
     # differences; sharded: all ranks share one stream by construction
-    t0 = 0.0
-    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
-    g_hi = dl.HybridGrid(ctx, args.high_resolution)
-    g_lo = dl.HybridGrid(ctx, args.low_resolution)
-    centers = synth.bubbles()
-    for s in range(args.map_scans):
-        pose = synth.trajectory_pose(t0 + 0.1 * s)
-        pts, _ = synth.scan(pose, args.beams, args.azimuths, centers=centers)
-        cloud = dl.PointCloud(ctx, pts)
-        pf = pose.astype(np.float32)
-        ins.InsertCloud(g_hi, cloud, poses=[pf], max_range=HIGH_RES_MAX_RANGE)
-        ins.InsertCloud(g_lo, cloud, poses=[pf])
-        cloud.close()
-    scans = []
-    for k in range(args.distinct_scans):
-        truth = synth.trajectory_pose(t0 + 0.1 * (args.map_scans + k))
-        pts, _ = synth.scan(truth, args.beams, args.azimuths, centers=centers)
-        init = synth.perturb_pose(truth, 0.1, 0.5, seed=13 + k)
-        scans.append(dict(truth=truth, pts=pts, init=init, cloud=dl.PointCloud(ctx, pts)))
+    ins, g_hi, g_lo, scans = build_scene(args, dl, synth, ctx)
+    if world > 1:
+        args.no_pmc = True  # the counters belong to the 1-GPU line
 
     rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_OPTS)
     cs = dl.CeresScanMatcher3D(ctx, CSM_OPTS)
@@ -211,6 +270,12 @@ def main():
                         "note": "Amdahl: only the score volume (~60 % of a 1-GPU step) shards; Ceres, insertion, the "
                                 "bounds / rescoring kernels and two host synchronisations per scan stay serial"}
 
+    # ... and the search where sharding pays: config 5 (128 x 2048 returns, 5 cm voxels, ~3e6 candidates), whose step
+    # is 98 % score volume -- every rank builds the same small submap and takes its share of the rotations
+    config5_line = None
+    if world > 1 and not sharded_mode and args.config == 2 and not args.no_config5:
+        config5_line = config5_sharded_line(args, dl, synth, ctx, rank, world, dist, coll_device, torch, sharded)
+
     extra = max(1, min(5, args.steps))
     ctx.set_profiling(1)
     ctx.reset_profiling()
@@ -235,7 +300,6 @@ def main():
         k_ms = score_ms / max(score_n, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         pairs = float(C) * n_pts / (world if sharded_mode else 1)
-        prof = score_kernel_profile(n_pts, C)
         out = {
             "metric": "scans/sec (%d-beam x %d pts -> %g cm 3D submap)" % (args.beams, args.azimuths, 100 * args.high_resolution),
             "value": value,
@@ -268,10 +332,12 @@ def main():
             },
             "stage_ms_per_scan": {k: 1e3 * v / args.steps for k, v in stage.items()},
             "kernel_ms_per_scan": breakdown,
-            "roofline": roofline_block(prof, pairs, k_ms, int(score_n), alg_bytes, int(st.score_kernel)),
+            "roofline": roofline_block(args, pairs, k_ms, int(score_n), alg_bytes, int(st.score_kernel)),
         }
         if sharded_line is not None:
             out["sharded"] = sharded_line
+        if config5_line is not None:
+            out["sharded_config5"] = config5_line
         if world == 1 and not args.no_wref:
             out["wref"] = wref_line(dl, ctx)
         if world == 1 and not args.no_cpu_baseline:
@@ -289,33 +355,82 @@ def main():
         dist.destroy_process_group()
 
 
-def score_kernel_profile(n_pts, C):
-    """Counter-derived constants of the score kernel (rocprofv3 --pmc cannot run inside this process):
-    read from the committed profile of the SAME workload, and labelled as such."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_score_kernel.json")
-    try:
-        pj = json.load(open(path))
-        w = pj.get("workload", {})
-        if w.get("num_points") == n_pts and w.get("num_candidates") == C:
-            return pj
-    except Exception:
-        pass
-    return None
+def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sharded):
+    """BASELINE config 5 with the search window sharded over the ranks (config 4's protocol): one 128 x 2048 scan
+    stream, every rank scores its own rotations of the ~3e6-candidate window, one 8-byte max all-reduce per scan,
+    Ceres + insertion replicated."""
+    import copy
+    a5 = copy.copy(args)
+    a5.beams, a5.azimuths, a5.high_resolution, a5.map_scans, a5.distinct_scans = 128, 2048, 0.05, 3, 1
+    ins, g_hi, g_lo, scans = build_scene(a5, dl, synth, ctx)
+    shard = dl.RtcsmShard(ctx, RTCSM_OPTS, rank, world)
+    cs = dl.CeresScanMatcher3D(ctx, CSM_OPTS)
+    sc = scans[0]
+
+    def one():
+        _, p1 = sharded.sharded_match(shard, sc["init"], sc["cloud"], g_hi, dist=dist, device=dev)
+        p2, _ = cs.Match(sc["init"][:3], p1, [(sc["cloud"], g_hi), (sc["cloud"], g_lo)])
+        pf = p2.astype(np.float32)
+        dl.insert_cloud_multi(ins, sc["cloud"], [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)])
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    steps = 3
+    one()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    fence()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    st = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_OPTS).last_stats()
+    sc["cloud"].close()
+    g_hi.close()
+    g_lo.close()
+    return {"workload": "config5 W-dense: ONE 128x2048 scan stream @ 5 cm, RTCSM3D window sharded over %d ranks (one 8-byte "
+                        "RCCL max all-reduce per scan), Ceres + insertion replicated" % world,
+            "value": steps / float(tt.item()), "unit": "scans/s", "scaling": "strong", "steps": steps,
+            "ms_per_step": 1e3 * float(tt.item()) / steps, "C": int(st.window.num_candidates), "N": int(st.num_points)}
 
 
-def roofline_block(prof, pairs, k_ms, launches, alg_bytes, score_kernel):
+def score_kernel_counters(args, kernel):
+    """Hardware counters of the score kernel measured NOW: child runs of this script (--pmc-child: the same scene,
+    three matches) under `rocprofv3 --pmc`, one per counter group (tools/pmc_live.py).  Nothing is read from a
+    committed file; what cannot be measured is absent and printed as null."""
+    if args.no_pmc:
+        return {}, ["skipped (--no-pmc or N > 1)"]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_live
+    child = [os.path.abspath(__file__), "--pmc-child", "--config", str(args.config), "--beams", str(args.beams),
+             "--azimuths", str(args.azimuths), "--high-resolution", str(args.high_resolution),
+             "--low-resolution", str(args.low_resolution), "--map-scans", str(args.map_scans),
+             "--distinct-scans", str(args.distinct_scans)]
+    return pmc_live.measure(child, kernel, timeout=240 if args.config == 5 else 150)
+
+
+# cheapest known instruction sequence per lookup on gfx950 (DESIGN.md 3.1): 1.5 v_pk_add_f32 + 3 v_mad_u32_u16 +
+# 0.5 v_add3_u32 = 5 VALU per wave-lookup at one issue per 4 cycles and SIMD -> 256 x 4 x 2.4e9 / (5 x 4) x 64 lanes
+USEFUL_PAIRS_PER_S = 256 * 4 * 2.4e9 / (5.0 * 4.0) * 64.0
+
+
+def roofline_block(args, pairs, k_ms, launches, alg_bytes, score_kernel):
     """What bounds the dominant kernel: the vector ALU's instruction issue -- not HBM (the
-    kernel moves ~2 % of its algorithmic bytes) and not MFMA (no GEMM in it).  achieved = VALU lane-operations
-    per second (SQ_INSTS_VALU x 64 / launch time); peak = 256 CU x 4 SIMD-32 x 2.4 GHz."""
+    kernel moves ~1 % of its algorithmic bytes) and not MFMA (no GEMM in it).  achieved = VALU lane-operations
+    per second (SQ_INSTS_VALU x 64 / launch time, both measured in this run); peak = 256 CU x 4 SIMD-32 x 2.4 GHz."""
     t = k_ms * 1e-3
     kernel = {3: "rtcsm_score_box_kernel", 2: "rtcsm_score_dense_kernel", 1: "rtcsm_score_rot_kernel",
               0: "rtcsm_score_kernel"}.get(score_kernel, "?")  # the kernel that ran (dliom_rtcsm_stats.score_kernel)
-    valu_per_pair = src = traffic = tsrc = None
-    if prof is not None and prof.get("kernel") == kernel:
-        valu_per_pair = prof.get("valu_instructions_per_wave_pair")
-        src = "profiles/r2_pmc_score_kernel.json (SQ_INSTS_VALU / (C N / 64), same workload)"
-        traffic = prof.get("hbm_bytes_per_launch")
-        tsrc = "profiles/r2_pmc_score_kernel.json (rocprofv3 --pmc FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE, separate passes)"
+    counters, problems = score_kernel_counters(args, kernel)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_live
+    d = pmc_live.derive(counters, pairs, t) if counters else {}
+    valu_per_pair = d.get("valu_instructions_per_pair")
+    traffic = d.get("traffic_bytes")
     achieved = (valu_per_pair * pairs / t) if (valu_per_pair and t > 0) else None
     return {
         "kernel": kernel,
@@ -324,13 +439,19 @@ def roofline_block(prof, pairs, k_ms, launches, alg_bytes, score_kernel):
         "peak": VALU_PEAK_LANE_OPS / 1e12,
         "unit": "Tlane-op/s",
         "frac": achieved / VALU_PEAK_LANE_OPS if achieved else None,
+        # the same launch time against the cheapest instruction sequence known for a lookup: how much of the
+        # kernel's issue slots do useful lookups (the headroom; `frac` counts every instruction the kernel issues)
+        "frac_useful": (pairs / t) / USEFUL_PAIRS_PER_S if t > 0 else None,
         "valu_instructions_per_pair": valu_per_pair,
-        "valu_source": src,
         "pairs_per_s": pairs / t if t > 0 else 0.0,
         "avg_launch_ms": k_ms,
         "launches": launches,
         "traffic": traffic,
-        "traffic_source": tsrc,
+        "counters_source": "rocprofv3 --pmc child runs of this bench.py invocation (tools/pmc_live.py), %d passes; "
+                           "FETCH_SIZE x 2 [gfx950 correction] + WRITE_SIZE" % len(pmc_live.PASSES) if counters else None,
+        "counters": {k: v["mean"] for k, v in counters.items()} or None,
+        "derived": d or None,
+        "counter_problems": problems or None,
         "hbm_side_note": {
             "algorithmic_bytes_per_launch": alg_bytes,  # 14 B per (candidate, point) pair
             "algorithmic_rate_GBs": alg_bytes / t / 1e9 if t > 0 else 0.0,

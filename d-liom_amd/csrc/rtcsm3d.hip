@@ -1384,24 +1384,10 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   }();
   const int want_blocks = target_waves > 0 ? target_waves / nw : std::max(1, resident) * num_cus;
   int slot_quads = std::max(1, want_blocks / std::max(1, rot_blocks * passes));
-  slot_quads = std::min(slot_quads, (p.point_chunks + kBatch - 1) / kBatch);
+  slot_quads = std::min(slot_quads, p.point_chunks);
   // (32-bit register accumulators: the kernel adds them to the 64-bit volume every box::kFlushPoints points)
   p.slots = slot_quads;
   p.units = passes * rot_blocks;
-  {
-    // guided ticket sizes: about half of a unit's chunks in tickets of kBatch, half of the rest in tickets of two, the
-    // remainder one by one -- whole rounds of the unit's home workgroups each, so that the first tickets (no atomic) are
-    // full ones and the last few rounds are short
-    static const int pct_a = env_int("DLIOM_BOX_PCT_A", 50), pct_b = env_int("DLIOM_BOX_PCT_B", 50);
-    const int64_t M = p.point_chunks, W = slot_quads;
-    int64_t n_a = (M * pct_a / 100) / (kBatch * W) * W;
-    if (n_a == 0 && M >= kBatch * W) n_a = W;
-    const int64_t m1 = M - n_a * kBatch;
-    const int64_t n_b = (m1 * pct_b / 100) / (2 * W) * W;
-    p.n_a = static_cast<int>(n_a);
-    p.n_b = static_cast<int>(n_b);
-    p.tickets = static_cast<int>(n_a + n_b + (m1 - 2 * n_b));
-  }
   DLIOM_TRY(ctx->box_counters.reserve(static_cast<size_t>(passes) * rot_blocks * 4 + 256));
   DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_counters.p, 0, static_cast<size_t>(passes) * rot_blocks * 4, ctx->stream));
   p.counters = ctx->box_counters.as<unsigned>();

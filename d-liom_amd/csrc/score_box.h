@@ -79,7 +79,6 @@ constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4
 #endif
 constexpr int kPipe = DLIOM_BOX_PIPE;            // steps between a gather and the accumulation of its value
 constexpr bool kLateAcc = DLIOM_BOX_LATE_ACC != 0;  // accumulate after the step's address arithmetic (else: anywhere)
-constexpr int kBatch = 4;      // point chunks per ticket of the work dispenser (first tickets; later ones 2, then 1)
 constexpr int kRecords = 8;    // ring of chunk records (lo[3], first point) the level-1 entries refer to
 constexpr int kListTrash = kL1Cap + kL2Cap + 4 * kRecords;  // a word nobody reads: where unlisted lanes "append"
 constexpr int kListWords = kListTrash + 4;
@@ -118,7 +117,6 @@ struct Params {
   int chunk;               // points per chunk, multiple of 4
   int point_chunks, rot_groups, rot_blocks, nw, slots;  // nw waves per workgroup, rot_blocks = ceil(rot_groups / nw)
   int units;               // passes * rot_blocks
-  int n_a, n_b, tickets;   // tickets [0, n_a) hold kBatch chunks, [n_a, n_a + n_b) two, the rest one (guided sizes)
   unsigned thr;            // unresolved  <=>  (bits(w) & 0xffff) <= thr
   int cells;               // LDS box capacity per workgroup (cells)
   int debug;               // -DDLIOM_EXPERIMENTS builds only (wrong sums): 1 skip the lists, 2 skip staging, 4 skip the
@@ -512,21 +510,6 @@ __device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsig
   }
 }
 
-// chunks [c0, c1) of ticket t: guided sizes (kBatch, then 2, then 1), so that the last tickets of a unit are short
-__device__ __forceinline__ void ticket_chunks(const Params& p, int t, int& c0, int& c1) {
-  if (t < p.n_a) {
-    c0 = t * kBatch;
-    c1 = c0 + kBatch;
-  } else if (t < p.n_a + p.n_b) {
-    c0 = p.n_a * kBatch + (t - p.n_a) * 2;
-    c1 = c0 + 2;
-  } else {
-    c0 = p.n_a * kBatch + p.n_b * 2 + (t - p.n_a - p.n_b);
-    c1 = c0 + 1;
-  }
-  c1 = min(c1, p.point_chunks);
-}
-
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rtcsm_score_box_kernel(
     GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
   extern __shared__ float4 lds_dyn4[];  // [kTC tau | band bitmap | ticket words | nw x lists | box]
@@ -555,10 +538,11 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
   // Work units are (pass, rotation block); each has its own chunk dispenser.  A workgroup starts in its HOME unit
   // (blockIdx -> unit as evenly as the launch allows; its first ticket is its own slot, no atomic: same-address
   // atomics serialise at ~0.15 us each) and, when that unit's tickets are gone, moves on to the other units and helps
-  // there (its accumulators are flushed per unit).  Tickets shrink (kBatch, 2, 1 chunks): with equal tickets of 4 a unit's
-  // 512 tickets over 170 workgroups left all but two of them idle for the length of a fourth ticket -- a quarter of
-  // the kernel (profiles/r2_pmc_score_kernel.json: 2.7 of 4 resident waves per SIMD on average).  Later tickets are
-  // drawn while the current one is processed.  Control flow below is uniform over the WORKGROUP (barriers).
+  // there (its accumulators are flushed per unit).  A ticket is ONE chunk: with tickets of four chunks a unit's 512
+  // tickets over 170 workgroups left all but two of them idle for the length of a fourth ticket -- a quarter of the
+  // kernel (profiles/r2_pmc_score_kernel.json: 2.7 of 4 resident waves per SIMD on average; round 3, same box:
+  // 0.871 ms with tickets of four, 0.797 with 4-2-1, 0.767 with single chunks).  The next ticket is drawn while the
+  // current one is processed.  Control flow below is uniform over the WORKGROUP (barriers).
   const int home = static_cast<int>(blockIdx.x % static_cast<unsigned>(p.units));
   const int slot = static_cast<int>(blockIdx.x / static_cast<unsigned>(p.units));
   int parity = 0;
@@ -570,14 +554,14 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     unsigned* counter = p.counters + unit;
     int ticket;
     if (hop == 0) {
-      ticket = DLIOM_BOX_DBG(p, 8) ? p.tickets : slot;
+      ticket = DLIOM_BOX_DBG(p, 8) ? p.point_chunks : slot;
     } else {
       if (threadIdx.x == 0) tick[parity] = atomicAdd(counter, 1u);
       __syncthreads();
       ticket = p.slots + static_cast<int>(tick[parity]);
       parity ^= 1;
     }
-    if (ticket >= p.tickets) continue;  // nothing left here
+    if (ticket >= p.point_chunks) continue;  // nothing left here
     // this unit: (pass, rotation block)
     const int rb = unit % p.rot_blocks;
     const int tp = unit / p.rot_blocks;
@@ -613,12 +597,11 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     }
     int n_guess = p.chunk;  // points per box that fitted last time
     int since_flush = 0;    // points added to the accumulators since they were last cleared (uniform)
-    while (ticket < p.tickets) {
+    while (ticket < p.point_chunks) {
       unsigned next_raw = 0u;
       if (threadIdx.x == 0) next_raw = atomicAdd(counter, 1u);  // in flight while this ticket is processed
-      int c_first, c_last;
-      ticket_chunks(p, ticket, c_first, c_last);
-      for (int c = c_first; c < c_last; ++c) {
+      {
+        const int c = ticket;
         const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
         int lo = c_begin;
         while (lo < c_end) {

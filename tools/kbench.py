@@ -64,6 +64,14 @@ def main():
             k_ms = ks["score"][0] / a.reps
             print("        C=%d N=%d rescored=%d  pairs/s=%.3e  alg GB/s=%.0f" %
                   (C, n, st.num_rescored, C * n / (k_ms * 1e-3), 14.0 * C * n / (k_ms * 1e-3) / 1e9))
+            fn_stats = getattr(dl.load_library(), "dliom_exp_box_stats", None)
+            if fn_stats is not None and (int(os.environ.get("DLIOM_BOX_DEBUG", "0")) & 128):
+                import ctypes
+                buf = (ctypes.c_uint32 * 8)()
+                fn_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+                fn_stats(ctx.h, buf)
+                names = ("boxes", "staged_quads", "box_points", "exact_points", "l1_rounds", "l1_entries", "l2_entries", "l2_rounds")
+                print("        stats/launch: " + ", ".join("%s %.0f" % (k, v / (a.reps + 1.0)) for k, v in zip(names, buf)))
         if name == "ceres":
             print("        evals=%d iterations=%d" % (r[1]["num_residual_evaluations"], r[1]["num_iterations"]))
     if a.check:
