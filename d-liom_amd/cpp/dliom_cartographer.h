@@ -690,6 +690,13 @@ class LocalTrajectoryBuilder3D {
   }
 
   const ActiveSubmaps3D& active_submaps() const { return active_submaps_; }
+  // g_vec_est_G_ of the last EstimateGravity() (.cc:1106-1154), whether it passed the gates, gravity factors added so far
+  // (options.imu.enable_gravity_factor: WindowOptimize adds the Pose3GravityFactor itself, .cc:819-831)
+  bool GravityEstimate(transform::Vector3d* gravity_in_global, int64_t* factors_added = nullptr) const {
+    int valid = 0;
+    Check(dliom_imu_window_gravity_estimate(window_, gravity_in_global->v, &valid, factors_added), "EstimateGravity");
+    return valid != 0;
+  }
 
  private:
   // .cc:493-572

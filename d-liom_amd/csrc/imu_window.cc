@@ -13,7 +13,16 @@
 //   BetweenFactor    bias_j - bias_i with sigma = sqrt(dt) (acc_bias_noise x3, gyr_bias_noise x3)        (:808-812)
 //   PriorFactor      Pose3 local coordinates [Log(R0^T R), R0^T (p - p0)] with the sigmas IN THE ORDER THE REFERENCE
 //                    FILLS THEM, (t, t, t, r, r, r) (:94-101): the rotation rows get ceres_pose_noise_t -- kept
-//   gravity factor   error = basis(nZ)^T (RzRyRx(roll, pitch, 0) bRef) + 1e-5                              (gravity_factor.cc)
+//   gravity factor   error = basis(nZ)^T (RzRyRx(roll, pitch, 0) bRef) + 1e-5 per component (gravity_factor.cc:10-33), with
+//                    Unit3::basis() as GTSAM 4.0.2 builds it (b1 = n x e_k / |.|, e_k the coordinate axis along which |n|
+//                    is smallest, ties x before y before z; b2 = n x b1) and the factor's OWN Jacobian
+//                    H = B_nZ^T B_q (-B_q^T R_rp [bRef]x) on the rotation block -- the derivative of rotating bRef by
+//                    R_rp = Ry(pitch) Rx(roll) taken as if R_rp were the state's rotation (the chain through xyz() is not
+//                    in the reference's factor either)
+//   EstimateGravity  :1106-1154 + gravity_factor/gravity_estimator.cc (in the tree, followed line by line, quirks kept):
+//                    a deque of (pose of the previous key, copy of the running preintegration, previous velocity), linear
+//                    solve for g in the first frame + four tangent-plane refinements; the factor goes on the state
+//                    frames_for_online_gravity_estimate keys back when the estimate passes the reference's two gates
 // ISAM2 (two update() calls per scan, graph reset with the marginal covariances every num_range_data keys,
 // :750-797,841-842) becomes: Gauss-Newton (two iterations per scan) over the last `window_size` states, older states
 // marginalised into a Gaussian prior on the oldest kept one (Schur complement).  For a linear problem both give the
@@ -23,6 +32,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <vector>
 
 #include "../../include/dliom.h"
@@ -316,6 +326,119 @@ void chol_solve(const std::vector<double>& l, int n, double* b) {
   }
 }
 
+// ---- GravityEstimator (gravity_factor/gravity_estimator.cc, in the reference tree: followed line by line) ---------
+struct GFrame {   // Rigid3dWithPreintegrator: a pose and the preintegration that was running when it was stored
+  M3 R;
+  V3 p;
+  double dt;      // deltaTij()
+  V3 dP, dV;      // deltaPij(), deltaVij()
+};
+bool solve_sym(const double* A, const double* b, int n, double* x) {  // A.ldlt().solve(b), n <= 3
+  double M[3][4];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) M[i][j] = A[i * n + j];
+    M[i][n] = b[i];
+  }
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+    if (!(std::fabs(M[piv][c]) > 0.0)) return false;
+    for (int j = 0; j <= n; ++j) std::swap(M[c][j], M[piv][j]);
+    for (int r = c + 1; r < n; ++r) {
+      const double f = M[r][c] / M[c][c];
+      for (int j = c; j <= n; ++j) M[r][j] -= f * M[c][j];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double v = M[i][n];
+    for (int j = i + 1; j < n; ++j) v -= M[i][j] * x[j];
+    x[i] = v / M[i][i];
+  }
+  return true;
+}
+// ApproximateGravity (:20-97): [R_i^T dt^2/2; R_i^T dt] g = [dP_j + R_i^T R_j tlb - tlb - R_i^T (T_j - T_i) + dt V_i;
+// dV_j + V_i - R_i^T R_j V_{i+1}], normal equations over the consecutive pairs, x 1000, solved; |g| within 0.5 of g_norm.
+// frame_j's OWN preintegration is paired with the poses of frames i and j, as the reference does.
+bool approximate_gravity(const std::vector<GFrame>& f, V3 tlb, const std::vector<V3>& Vs, double g_norm, V3* g) {
+  const size_t window = f.size();
+  if (window < 3) return false;
+  double A[9] = {0}, b[3] = {0};
+  for (size_t i = 0; i + 1 < window; ++i) {
+    const GFrame &fi = f[i], &fj = f[i + 1];
+    const double dt = fj.dt;
+    const M3 RiT = transpose(fi.R);
+    const M3 RiTRj = RiT * fj.R;
+    const M3 A0 = scaled(RiT, dt * dt / 2), A1 = scaled(RiT, dt);
+    const V3 b0 = fj.dP + RiTRj * tlb - tlb - RiT * (fj.p - fi.p) + dt * Vs[i];
+    const V3 b1 = fj.dV + Vs[i] - RiTRj * Vs[i + 1];
+    const double bb0[3] = {b0.x, b0.y, b0.z}, bb1[3] = {b1.x, b1.y, b1.z};
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        double v = 0;
+        for (int k = 0; k < 3; ++k) v += A0.m[3 * k + r] * A0.m[3 * k + c] + A1.m[3 * k + r] * A1.m[3 * k + c];
+        A[3 * r + c] += v;
+      }
+      double v = 0;
+      for (int k = 0; k < 3; ++k) v += A0.m[3 * k + r] * bb0[k] + A1.m[3 * k + r] * bb1[k];
+      b[r] += v;
+    }
+  }
+  for (double& v : A) v *= 1000.0;
+  for (double& v : b) v *= 1000.0;
+  double x[3];
+  if (!solve_sym(A, b, 3, x)) return false;
+  *g = {x[0], x[1], x[2]};
+  return std::fabs(norm(*g) - g_norm) < 0.5;
+}
+// TangentBasis (:6-18)
+void tangent_basis(V3 g0, V3* b, V3* c) {
+  const V3 a = (1.0 / norm(g0)) * g0;
+  V3 tmp{0, 0, 1};
+  if (a.x == tmp.x && a.y == tmp.y && a.z == tmp.z) tmp = {1, 0, 0};
+  V3 bb = tmp - dot(a, tmp) * a;
+  *b = (1.0 / norm(bb)) * bb;
+  *c = cross(a, *b);
+}
+// RefineGravity (:99-170): four corrections of g0 in its tangent plane at fixed norm.  A and b are declared outside the
+// loop over the four rounds and never cleared in the reference (every round adds to 1000 x the previous sums): kept.
+void refine_gravity(const std::vector<GFrame>& f, V3 tlb, const std::vector<V3>& Vs, double g_norm, V3* g_approx) {
+  V3 g0 = (g_norm / norm(*g_approx)) * *g_approx;
+  const size_t window = f.size();
+  double A[4] = {0}, b[2] = {0};
+  for (int k = 0; k < 4; ++k) {
+    V3 lx, ly;
+    tangent_basis(g0, &lx, &ly);
+    for (size_t i = 0; i + 1 < window; ++i) {
+      const GFrame &fi = f[i], &fj = f[i + 1];
+      const double dt = fj.dt;
+      const M3 RiT = transpose(fi.R);
+      const M3 RiTRj = RiT * fj.R;
+      const V3 a0[2] = {(dt * dt / 2) * (RiT * lx), (dt * dt / 2) * (RiT * ly)};  // columns of the 6 x 2 block
+      const V3 a1[2] = {dt * (RiT * lx), dt * (RiT * ly)};
+      const V3 b0 = fj.dP + RiTRj * tlb - tlb - (dt * dt / 2) * (RiT * g0) - RiT * (fj.p - fi.p) + dt * Vs[i];
+      const V3 b1 = fj.dV - dt * (RiT * g0) + Vs[i] - RiTRj * Vs[i + 1];
+      for (int r = 0; r < 2; ++r) {
+        for (int c = 0; c < 2; ++c) A[2 * r + c] += dot(a0[r], a0[c]) + dot(a1[r], a1[c]);
+        b[r] += dot(a0[r], b0) + dot(a1[r], b1);
+      }
+    }
+    for (double& v : A) v *= 1000.0;
+    for (double& v : b) v *= 1000.0;
+    double dg[2] = {0, 0};
+    if (!solve_sym(A, b, 2, dg)) return;
+    const V3 gn = g0 + dg[0] * lx + dg[1] * ly;
+    g0 = (g_norm / norm(gn)) * gn;
+  }
+  *g_approx = g0;
+}
+// Estimate (:172-188)
+bool estimate_gravity_vector(const std::vector<GFrame>& f, V3 tlb, const std::vector<V3>& Vs, double g_norm, V3* g) {
+  if (!approximate_gravity(f, tlb, Vs, g_norm, g)) return false;
+  refine_gravity(f, tlb, Vs, g_norm, g);
+  return std::fabs(norm(*g) - g_norm) < 0.2;
+}
+
 }  // namespace
 
 struct dliom_imu_window {
@@ -335,6 +458,12 @@ struct dliom_imu_window {
     double sigma;
   };
   std::vector<Gravity> gravity;
+  // EstimateGravity (:1106-1154): g_est_transforms_ / g_est_Vs_ / g_vec_est_G_
+  std::deque<GFrame> g_frames;
+  std::deque<V3> g_vs;
+  V3 g_est_G{0, 0, 0};
+  bool g_est_valid = false;     // the last EstimateGravity() call returned true
+  int64_t gravity_factors = 0;  // factors added by add_pose so far
   // Gaussian prior on x[0]: 1/2 d^T H d + b^T d, d = local(lin, x[0])
   double H0[225], b0[15];
   State lin0;
@@ -409,20 +538,51 @@ void pose_prior_residual(const dliom_imu_window::PosePrior& f, const State& s, d
   r[5] = t.z / f.sigma_trans;
 }
 
-void gravity_residual(const dliom_imu_window::Gravity& f, const State& s, double* r) {
+// gtsam::Unit3::basis() (GTSAM 4.0.2, geometry/Unit3.cpp): the coordinate axis with the smallest |component| of n
+// (x before y before z on ties), b1 = normalize(n x axis), b2 = n x b1.
+void unit3_basis(V3 n, V3* b1, V3* b2) {
+  const double mx = std::fabs(n.x), my = std::fabs(n.y), mz = std::fabs(n.z);
+  V3 axis{0, 0, 1};
+  if (mx <= my && mx <= mz)
+    axis = {1, 0, 0};
+  else if (my <= mx && my <= mz)
+    axis = {0, 1, 0};
+  V3 B1 = cross(n, axis);
+  *b1 = (1.0 / norm(B1)) * B1;
+  *b2 = cross(n, *b1);
+}
+
+// Pose3GravityFactor::evaluateError (gravity_factor.cc:10-33, .h:190-199): r (2, whitened) and, if J != nullptr, the
+// factor's 2 x 15 Jacobian (only the rotation block is non-zero).
+void gravity_residual(const dliom_imu_window::Gravity& f, const State& s, double* r, double* J = nullptr) {
   // Rot3::xyz(): roll, pitch of R = Rz Ry Rx
   const double roll = std::atan2(s.R.m[7], s.R.m[8]);
   const double pitch = std::atan2(-s.R.m[6], std::sqrt(s.R.m[7] * s.R.m[7] + s.R.m[8] * s.R.m[8]));
   const double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch);
-  const M3 Rrp{{cp, sp * sr, sp * cr, 0, cr, -sr, -sp, cp * sr, cp * cr}};  // Ry(pitch) Rx(roll)
+  const M3 Rrp{{cp, sp * sr, sp * cr, 0, cr, -sr, -sp, cp * sr, cp * cr}};  // Rot3::RzRyRx(roll, pitch, 0) = Ry(pitch) Rx(roll)
   const V3 nRef = Rrp * f.bRef;
-  // orthonormal basis of the tangent plane at nZ
-  V3 a = std::fabs(f.nZ.x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0};
-  V3 b1 = cross(f.nZ, a);
-  b1 = (1.0 / norm(b1)) * b1;
-  const V3 b2 = cross(f.nZ, b1);
-  r[0] = (dot(b1, nRef) + 1e-5) / f.sigma;
-  r[1] = (dot(b2, nRef) + 1e-5) / f.sigma;
+  V3 p1, p2;
+  unit3_basis(f.nZ, &p1, &p2);
+  const double k_cost_value = 1e-5;
+  r[0] = (dot(p1, nRef) + k_cost_value) / f.sigma;  // nZ_.error(nRef) = B_nZ^T nRef, + 1e-5 per component
+  r[1] = (dot(p2, nRef) + k_cost_value) / f.sigma;
+  if (J != nullptr) {
+    // D_nRef_R = -B_q^T R_rp [bRef]x (Rot3::rotate(Unit3)), D_e_nRef = B_nZ^T B_q (Unit3::error): H = D_e_nRef D_nRef_R
+    V3 q1, q2;
+    unit3_basis(nRef, &q1, &q2);
+    const M3 RS = Rrp * skew(f.bRef);
+    double D[2][3];
+    const V3 rows[2] = {q1, q2};
+    for (int i = 0; i < 2; ++i) {
+      D[i][0] = -(rows[i].x * RS.m[0] + rows[i].y * RS.m[3] + rows[i].z * RS.m[6]);
+      D[i][1] = -(rows[i].x * RS.m[1] + rows[i].y * RS.m[4] + rows[i].z * RS.m[7]);
+      D[i][2] = -(rows[i].x * RS.m[2] + rows[i].y * RS.m[5] + rows[i].z * RS.m[8]);
+    }
+    const double E[2][2] = {{dot(p1, q1), dot(p1, q2)}, {dot(p2, q1), dot(p2, q2)}};
+    for (int i = 0; i < 2 * kD; ++i) J[i] = 0.0;
+    for (int i = 0; i < 2; ++i)
+      for (int c = 0; c < 3; ++c) J[i * kD + c] = (E[i][0] * D[0][c] + E[i][1] * D[1][c]) / f.sigma;
+  }
 }
 
 // Lower-triangular inverse of the Cholesky factor of the 9 x 9 preintegrated covariance.
@@ -478,6 +638,24 @@ void add_factor(std::vector<State>& x, int ia, int ib, int rows, F residual, std
   }
 }
 
+// The same accumulation for a factor on ONE state that supplies its own Jacobian (rows x 15).
+void add_factor_with_jacobian(int ia, int rows, const double* r0, const double* J, std::vector<double>& H, std::vector<double>& g,
+                              int n) {
+  for (int c1 = 0; c1 < kD; ++c1) {
+    const int g1 = ia * kD + c1;
+    double s = 0;
+    for (int i = 0; i < rows; ++i) s += J[i * kD + c1] * r0[i];
+    g[g1] += s;
+    for (int c2 = c1; c2 < kD; ++c2) {
+      const int g2 = ia * kD + c2;
+      double h = 0;
+      for (int i = 0; i < rows; ++i) h += J[i * kD + c1] * J[i * kD + c2];
+      H[static_cast<size_t>(g1) * n + g2] += h;
+      if (c2 != c1) H[static_cast<size_t>(g2) * n + g1] += h;
+    }
+  }
+}
+
 // Normal equations of every factor in the window at the current estimate.
 bool build(dliom_imu_window& w, std::vector<double>& H, std::vector<double>& g) {
   const int N = static_cast<int>(w.x.size()), n = N * kD;
@@ -503,8 +681,11 @@ bool build(dliom_imu_window& w, std::vector<double>& H, std::vector<double>& g) 
   }
   for (const auto& f : w.pose_priors)
     add_factor(w.x, f.index, -1, 6, [&](double* r) { pose_prior_residual(f, w.x[f.index], r); }, H, g, n);
-  for (const auto& f : w.gravity)
-    add_factor(w.x, f.index, -1, 2, [&](double* r) { gravity_residual(f, w.x[f.index], r); }, H, g, n);
+  for (const auto& f : w.gravity) {
+    double r[2], J[2 * kD];
+    gravity_residual(f, w.x[f.index], r, J);
+    add_factor_with_jacobian(f.index, 2, r, J, H, g, n);
+  }
   return true;
 }
 
@@ -549,7 +730,11 @@ bool marginalize_oldest(dliom_imu_window& w) {
   for (const auto& f : w.pose_priors)
     if (f.index == 0) add_factor(x2, 0, -1, 6, [&](double* r) { pose_prior_residual(f, x2[0], r); }, H, g, n);
   for (const auto& f : w.gravity)
-    if (f.index == 0) add_factor(x2, 0, -1, 2, [&](double* r) { gravity_residual(f, x2[0], r); }, H, g, n);
+    if (f.index == 0) {
+      double r[2], J[2 * kD];
+      gravity_residual(f, x2[0], r, J);
+      add_factor_with_jacobian(0, 2, r, J, H, g, n);
+    }
   // Schur complement of the first block
   std::vector<double> Haa(kD * kD);
   for (int i = 0; i < kD; ++i)
@@ -630,9 +815,61 @@ void write_state(const State& s, double pose7[7], double vel3[3], double bias6[6
   }
 }
 
+// LocalTrajectoryBuilder3D::EstimateGravity (:1106-1154).  `prev` is prev_pose_ / prev_vel_ (the newest optimised state),
+// `running` the preintegration since it (imu_integrator_opt_).  Kept as written: the velocities in g_est_Vs_ are rotated
+// into their frames IN PLACE on every call (:1135-1136), i.e. again on every later call while they stay in the deque.
+bool estimate_gravity(dliom_imu_window& w, const State& prev, const Preint& running) {
+  const int win = w.o.frames_for_online_gravity_estimate;
+  w.g_frames.push_back(GFrame{prev.R, prev.p, running.dt, running.dp, running.dv});
+  w.g_vs.push_back(prev.v);
+  if (static_cast<int>(w.g_frames.size()) <= win + 1) return false;
+  w.g_frames.pop_front();
+  w.g_vs.pop_front();
+  std::vector<GFrame> tmp(w.g_frames.begin(), w.g_frames.end());
+  const M3 RwT = transpose(w.g_frames.front().R);
+  const V3 pw = w.g_frames.front().p;
+  for (size_t i = 0; i < tmp.size(); ++i) {
+    tmp[i].R = RwT * w.g_frames[i].R;            // T_w_inv * tsf.transform
+    tmp[i].p = RwT * (w.g_frames[i].p - pw);
+    w.g_vs[i] = transpose(w.g_frames[i].R) * w.g_vs[i];
+  }
+  const std::vector<V3> vs(w.g_vs.begin(), w.g_vs.end());
+  const V3 tlb{w.o.lidar_in_imu_translation[0], w.o.lidar_in_imu_translation[1], w.o.lidar_in_imu_translation[2]};
+  V3 g_B;
+  if (!estimate_gravity_vector(tmp, tlb, vs, w.o.gravity, &g_B)) return false;
+  w.g_est_G = w.g_frames.front().R * (-1.0 * g_B);
+  return w.g_est_G.z + w.o.gravity < 0.5;
+}
+
 }  // namespace
 
 extern "C" {
+
+int dliom_gravity_estimate(int num_frames, const double* poses7, const double* delta_t, const double* delta_p,
+                           const double* delta_v, const double* velocities, const double lidar_in_imu_translation[3],
+                           double gravity_norm, double gravity_out[3], int* accepted) {
+  if (num_frames < 0 || (num_frames > 0 && (poses7 == nullptr || delta_t == nullptr || delta_p == nullptr || delta_v == nullptr ||
+                                             velocities == nullptr)) ||
+      lidar_in_imu_translation == nullptr || gravity_out == nullptr || accepted == nullptr)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  std::vector<GFrame> f(static_cast<size_t>(num_frames));
+  std::vector<V3> vs(static_cast<size_t>(num_frames));
+  for (int i = 0; i < num_frames; ++i) {
+    f[i].R = quat_to_matrix(poses7 + 7 * i + 3);
+    f[i].p = {poses7[7 * i], poses7[7 * i + 1], poses7[7 * i + 2]};
+    f[i].dt = delta_t[i];
+    f[i].dP = {delta_p[3 * i], delta_p[3 * i + 1], delta_p[3 * i + 2]};
+    f[i].dV = {delta_v[3 * i], delta_v[3 * i + 1], delta_v[3 * i + 2]};
+    vs[i] = {velocities[3 * i], velocities[3 * i + 1], velocities[3 * i + 2]};
+  }
+  V3 g{0, 0, 0};
+  const V3 tlb{lidar_in_imu_translation[0], lidar_in_imu_translation[1], lidar_in_imu_translation[2]};
+  *accepted = estimate_gravity_vector(f, tlb, vs, gravity_norm, &g) ? 1 : 0;
+  gravity_out[0] = g.x;
+  gravity_out[1] = g.y;
+  gravity_out[2] = g.z;
+  return DLIOM_OK;
+}
 
 int dliom_imu_window_default_options(dliom_imu_window_options* o) {
   if (o == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
@@ -653,6 +890,9 @@ int dliom_imu_window_default_options(dliom_imu_window_options* o) {
   o->prior_gravity_noise = 1e-2;
   o->window_size = 4;
   o->iterations = 2;
+  o->enable_gravity_factor = 0;                // trajectory_builder_3d.lua:31 (dlio/config/basic_config_3d.lua:80 sets true)
+  o->frames_for_online_gravity_estimate = 7;   // :29
+  o->lidar_in_imu_translation[0] = o->lidar_in_imu_translation[1] = o->lidar_in_imu_translation[2] = 0.0;
   return DLIOM_OK;
 }
 
@@ -660,6 +900,10 @@ int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_w
   if (options == nullptr || out == nullptr || options->window_size < 2 || options->window_size > 16 ||
       options->iterations < 1 || !(options->acc_noise > 0) || !(options->gyr_noise > 0) || !(options->acc_bias_noise > 0) ||
       !(options->gyr_bias_noise > 0))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  // the gravity factor goes on the state frames_for_online_gravity_estimate keys back (:828): it has to be in the window
+  if (options->enable_gravity_factor != 0 &&
+      (options->frames_for_online_gravity_estimate < 2 || options->window_size < options->frames_for_online_gravity_estimate + 1))
     return DLIOM_ERR_INVALID_ARGUMENT;
   dliom_imu_window* w = new dliom_imu_window;
   w->o = *options;
@@ -684,6 +928,9 @@ int dliom_imu_window_initialize(dliom_imu_window* w, const double pose7[7], cons
   w->between.clear();
   w->pose_priors.clear();
   w->gravity.clear();
+  w->g_frames.clear();  // ResetParams() / a fresh start: the estimator's window starts over
+  w->g_vs.clear();
+  w->g_est_valid = false;
   // PriorFactor<Pose3> (prior_pose_noise x 6), PriorFactor<Vector3> (1e4), PriorFactor<ConstantBias> (1e-2): :712-745
   std::memset(w->H0, 0, sizeof w->H0);
   std::memset(w->b0, 0, sizeof w->b0);
@@ -746,12 +993,38 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
   f.sigma_rot = degenerate ? w->o.ceres_pose_noise_t_drift : w->o.ceres_pose_noise_t;
   f.sigma_trans = degenerate ? w->o.ceres_pose_noise_r_drift : w->o.ceres_pose_noise_r;
   w->pose_priors.push_back(f);
+  // gravity factor for the state frames_for_online_gravity_estimate keys back (:819-831); key_ of the new state is
+  // num_states (1 for the first scan after initialisation; this window has no graph reset)
+  const std::deque<GFrame> g_frames_before = w->g_frames;
+  const std::deque<V3> g_vs_before = w->g_vs;
+  bool gravity_added = false;
+  if (w->o.enable_gravity_factor != 0) {
+    w->g_est_valid = estimate_gravity(*w, prev, w->current);
+    const int win = w->o.frames_for_online_gravity_estimate;
+    if (w->g_est_valid && w->num_states - win >= 0 && static_cast<int>(w->x.size()) - 1 - win >= 0) {
+      dliom_imu_window::Gravity gf;
+      gf.index = static_cast<int>(w->x.size()) - 1 - win;
+      gf.nZ = (1.0 / norm(w->g_est_G)) * w->g_est_G;
+      gf.bRef = {0, 0, -1};
+      gf.sigma = w->o.prior_gravity_noise;
+      w->gravity.push_back(gf);
+      gravity_added = true;
+    }
+  }
   const std::vector<State> backup = w->x;
   if (!gauss_newton(*w, w->o.iterations)) {
-    w->x = backup;  // keep the prediction; the caller sees the failure
-    w->x.back() = next;
-    return DLIOM_ERR_INVALID_ARGUMENT;
+    // nothing of this scan stays: the new key, its factors and the estimator's entry are taken back and the running
+    // preintegration is kept, so that the caller may try again (or re-initialise) without IMU samples counted twice
+    w->x = backup;
+    w->x.pop_back();
+    w->between.pop_back();
+    w->pose_priors.pop_back();
+    if (gravity_added) w->gravity.pop_back();
+    w->g_frames = g_frames_before;
+    w->g_vs = g_vs_before;
+    return DLIOM_ERR_SOLVER;
   }
+  if (gravity_added) ++w->gravity_factors;
   while (static_cast<int>(w->x.size()) > w->o.window_size)
     if (!marginalize_oldest(*w)) return DLIOM_ERR_INVALID_ARGUMENT;
   const State& s = w->x.back();
@@ -773,5 +1046,15 @@ int dliom_imu_window_state(const dliom_imu_window* w, int states_back, double po
 }
 
 int dliom_imu_window_size(const dliom_imu_window* w) { return w == nullptr ? 0 : static_cast<int>(w->x.size()); }
+
+int dliom_imu_window_gravity_estimate(const dliom_imu_window* w, double gravity_in_global[3], int* valid, int64_t* factors_added) {
+  if (w == nullptr || gravity_in_global == nullptr || valid == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  gravity_in_global[0] = w->g_est_G.x;
+  gravity_in_global[1] = w->g_est_G.y;
+  gravity_in_global[2] = w->g_est_G.z;
+  *valid = w->g_est_valid ? 1 : 0;
+  if (factors_added != nullptr) *factors_added = w->gravity_factors;
+  return DLIOM_OK;
+}
 
 }  // extern "C"

@@ -137,7 +137,9 @@ class ImuWindowOptions(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "acc_noise", "gyr_noise", "acc_bias_noise", "gyr_bias_noise", "gravity", "integration_sigma", "prior_pose_noise",
         "prior_velocity_sigma", "prior_bias_sigma", "ceres_pose_noise_t", "ceres_pose_noise_r", "ceres_pose_noise_t_drift",
-        "ceres_pose_noise_r_drift", "prior_gravity_noise")] + [("window_size", C.c_int), ("iterations", C.c_int)]
+        "ceres_pose_noise_r_drift", "prior_gravity_noise")] + [
+            ("window_size", C.c_int), ("iterations", C.c_int), ("enable_gravity_factor", C.c_int),
+            ("frames_for_online_gravity_estimate", C.c_int), ("lidar_in_imu_translation", C.c_double * 3)]
 
 
 class ImuPreintegration(C.Structure):
@@ -264,6 +266,8 @@ SYMBOLS = [
     ("dliom_imu_window_add_pose", C.c_int, [_vp, _f64p, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_imu_window_state", C.c_int, [_vp, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_imu_window_size", C.c_int, [_vp]),
+    ("dliom_imu_window_gravity_estimate", C.c_int, [_vp, _f64p, C.POINTER(C.c_int), _i64p]),
+    ("dliom_gravity_estimate", C.c_int, [C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, _f64p, C.POINTER(C.c_int)]),
     ("dliom_imu_integrator_create", C.c_int, [_f64p, _f64p, C.POINTER(ImuNoise), C.POINTER(_vp)]),
     ("dliom_imu_integrator_destroy", C.c_int, [_vp]),
     ("dliom_imu_integrator_reset", C.c_int, [_vp, _f64p, _f64p, C.POINTER(ImuNoise)]),
@@ -1312,7 +1316,7 @@ class ImuWindow:
         pose, vel, bias = np.zeros(7), np.zeros(3), np.zeros(6)
         s = self._L.dliom_imu_window_add_pose(self.h, _p(_f64(matched_pose7), _f64p), int(bool(is_drift)), _p(pose, _f64p),
                                               _p(vel, _f64p), _p(bias, _f64p))
-        if s != ERR_DIVERGED:
+        if s not in (ERR_DIVERGED, ERR_SOLVER):
             _check(s, "dliom_imu_window_add_pose")
         return pose, vel, bias, s
 
@@ -1324,6 +1328,25 @@ class ImuWindow:
 
     def __len__(self):
         return int(self._L.dliom_imu_window_size(self.h))
+
+    def gravity_estimate(self):
+        """(g_vec_est_G_, passed the reference's gates?, gravity factors added so far) -- EstimateGravity, .cc:1106-1154."""
+        g, ok, n = np.zeros(3), C.c_int(0), C.c_int64(0)
+        _check(self._L.dliom_imu_window_gravity_estimate(self.h, _p(g, _f64p), C.byref(ok), C.byref(n)),
+               "dliom_imu_window_gravity_estimate")
+        return g, bool(ok.value), int(n.value)
+
+
+def gravity_estimate(poses7, delta_t, delta_p, delta_v, velocities, gravity_norm, lidar_in_imu_translation=(0.0, 0.0, 0.0)):
+    """GravityEstimator::Estimate (gravity_estimator.cc:172-188) -> (gravity in the first frame, accepted)."""
+    poses7 = _f64(poses7).reshape(-1, 7)
+    g, ok = np.zeros(3), C.c_int(0)
+    _check(load_library().dliom_gravity_estimate(len(poses7), _p(poses7, _f64p), _p(_f64(delta_t), _f64p),
+                                                 _p(_f64(delta_p).reshape(-1, 3), _f64p), _p(_f64(delta_v).reshape(-1, 3), _f64p),
+                                                 _p(_f64(velocities).reshape(-1, 3), _f64p),
+                                                 _p(_f64(lidar_in_imu_translation), _f64p), float(gravity_norm), _p(g, _f64p),
+                                                 C.byref(ok)), "dliom_gravity_estimate")
+    return g, bool(ok.value)
 
 
 class ImuIntegrator:

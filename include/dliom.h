@@ -559,6 +559,8 @@ int dliom_imu_integrator_predict(const dliom_imu_integrator* integrator, const d
  *   _add_imu (every IMU sample) ... _predict (initial pose for the matchers) ... _add_pose (matched pose)
  * DLIOM_ERR_DIVERGED mirrors FailureDetection (:896-913): |v| > 30 m/s or a bias norm > 1 -- re-initialise. */
 #define DLIOM_ERR_DIVERGED (-11)
+/* add_pose returns DLIOM_ERR_SOLVER when the normal equations cannot be factorised: the window is then exactly as before
+ * the call (the new key, its factors and the gravity estimator's entry are taken back, the running preintegration kept). */
 typedef struct dliom_imu_window dliom_imu_window;
 typedef struct dliom_imu_window_options {
   double acc_noise, gyr_noise, acc_bias_noise, gyr_bias_noise; /* trajectory_builder_3d.lua:88-91 */
@@ -571,6 +573,11 @@ typedef struct dliom_imu_window_options {
   double prior_gravity_noise;                                   /* lua :100 */
   int window_size;  /* states kept; older ones are marginalised (2..16) */
   int iterations;   /* Gauss-Newton iterations per scan (the reference calls ISAM2::update twice) */
+  int enable_gravity_factor;               /* lua :31 (false; dlio/config/basic_config_3d.lua:80 true): EstimateGravity per
+                                              scan and, when it succeeds, a Pose3GravityFactor (.cc:819-831) */
+  int frames_for_online_gravity_estimate;  /* lua :29 (7): estimator window, and the factor's key distance; needs
+                                              window_size >= this + 1 */
+  double lidar_in_imu_translation[3];      /* transform_lb_.translation() (.cc:1140), zero if the poses are the IMU's */
 } dliom_imu_window_options;
 int dliom_imu_window_default_options(dliom_imu_window_options* options);
 int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out);
@@ -590,6 +597,16 @@ int dliom_imu_window_add_pose(dliom_imu_window* window, const double matched_pos
 int dliom_imu_window_state(const dliom_imu_window* window, int states_back, double pose7[7], double velocity[3],
                            double bias6[6]);
 int dliom_imu_window_size(const dliom_imu_window* window);
+/* g_vec_est_G_ of the last EstimateGravity() (local_trajectory_builder_3d.cc:1106-1154), whether that call passed the
+ * reference's gates, and how many gravity factors add_pose has added so far */
+int dliom_imu_window_gravity_estimate(const dliom_imu_window* window, double gravity_in_global[3], int* valid,
+                                      int64_t* factors_added);
+/* GravityEstimator::Estimate (gravity_factor/gravity_estimator.cc:172-188) on explicit frames: pose [t, q(wxyz)] relative to
+ * the first frame, the preintegration stored WITH each frame (deltaTij, deltaPij, deltaVij) and its body-frame velocity.
+ * gravity_out is in the first frame (the reference's sign: it points up); *accepted = the function's return value. */
+int dliom_gravity_estimate(int num_frames, const double* poses7, const double* delta_t, const double* delta_p,
+                           const double* delta_v, const double* velocities, const double lidar_in_imu_translation[3],
+                           double gravity_norm, double gravity_out[3], int* accepted);
 
 /* ---- RealTimeCorrelativeScanMatcher2D (BASELINE config 1: host only, by contract) -------------
  * double Match(initial_pose_estimate, point_cloud, probability_grid, pose_estimate)

@@ -4,6 +4,9 @@ d-liom_amd/csrc/imu_window.cc: manifold IMU preintegration (Forster et al., the 
 gtsam::PreintegratedImuMeasurements), ImuFactor, bias BetweenFactor (:808-812), PriorFactor<Pose3> on the matched
 pose with the reference's (t,t,t,r,r,r) sigma order (:94-101), initial priors (:712-745).  Solved as ONE batch
 Gauss-Newton problem over every state (no window, no marginalisation), numerical Jacobians.
+The gravity factor (gravity_factor/gravity_factor.cc:10-33 with GTSAM 4.0.2's Unit3::basis / Unit3::error /
+Rot3::rotate Jacobians restated) and GravityEstimator (gravity_factor/gravity_estimator.cc, in the tree: restated line
+by line with numpy, quirks kept) + EstimateGravity's deque handling (local_trajectory_builder_3d.cc:1106-1154).
 PARITY UNPINNED: GTSAM 4.0.2 is not in /root/reference and the reference holds no test at this boundary."""
 import numpy as np
 from scipy.spatial.transform import Rotation as Rot
@@ -76,6 +79,78 @@ class Preintegration:
             self.dv + self.J_v_ba @ da + self.J_v_bg @ dg
 
 
+def unit3_basis(n):
+    """gtsam::Unit3::basis(): axis of the smallest |component| (x, then y, then z on ties)."""
+    n = np.asarray(n, float)
+    m = np.abs(n)
+    axis = np.array([0.0, 0.0, 1.0])
+    if m[0] <= m[1] and m[0] <= m[2]:
+        axis = np.array([1.0, 0.0, 0.0])
+    elif m[1] <= m[0] and m[1] <= m[2]:
+        axis = np.array([0.0, 1.0, 0.0])
+    b1 = np.cross(n, axis)
+    b1 /= np.linalg.norm(b1)
+    return np.stack([b1, np.cross(n, b1)], axis=1)  # 3 x 2
+
+
+def gravity_factor(R, nZ, bRef, sigma):
+    """Pose3GravityFactor::evaluateError: whitened error (2) and the factor's own 2 x 3 rotation Jacobian."""
+    roll = np.arctan2(R[2, 1], R[2, 2])
+    pitch = np.arctan2(-R[2, 0], np.hypot(R[2, 1], R[2, 2]))
+    Rrp = Rot.from_euler("y", pitch).as_matrix() @ Rot.from_euler("x", roll).as_matrix()
+    q = Rrp @ bRef
+    Bp, Bq = unit3_basis(nZ), unit3_basis(q)
+    e = Bp.T @ q + 1e-5
+    H = (Bp.T @ Bq) @ (-Bq.T @ Rrp @ skew(bRef))
+    return e / sigma, H / sigma
+
+
+def tangent_basis(g0):
+    a = g0 / np.linalg.norm(g0)
+    tmp = np.array([0.0, 0.0, 1.0])
+    if np.array_equal(a, tmp):
+        tmp = np.array([1.0, 0.0, 0.0])
+    b = tmp - a * (a @ tmp)
+    b /= np.linalg.norm(b)
+    return np.stack([b, np.cross(a, b)], axis=1)
+
+
+def estimate_gravity_vector(frames, tlb, Vs, g_norm):
+    """GravityEstimator::Estimate.  frames: list of (R, T, dt, dP, dV) -- a pose and the preintegration stored with it."""
+    n = len(frames)
+    if n < 3:
+        return np.zeros(3), False
+    A, b = np.zeros((3, 3)), np.zeros(3)
+    for i in range(n - 1):
+        Ri, Ti = frames[i][0], frames[i][1]
+        Rj, Tj, dt, dP, dV = frames[i + 1]
+        tA = np.vstack([Ri.T * dt * dt / 2, Ri.T * dt])
+        tb = np.concatenate([dP + Ri.T @ Rj @ tlb - tlb - Ri.T @ (Tj - Ti) + dt * Vs[i], dV + Vs[i] - Ri.T @ Rj @ Vs[i + 1]])
+        A += tA.T @ tA
+        b += tA.T @ tb
+    g = np.linalg.solve(A * 1000.0, b * 1000.0)
+    if not abs(np.linalg.norm(g) - g_norm) < 0.5:
+        return g, False
+    g0 = g / np.linalg.norm(g) * g_norm
+    A2, b2 = np.zeros((2, 2)), np.zeros(2)  # never cleared between the four rounds (gravity_estimator.cc:117-167)
+    for _ in range(4):
+        lxly = tangent_basis(g0)
+        for i in range(n - 1):
+            Ri, Ti = frames[i][0], frames[i][1]
+            Rj, Tj, dt, dP, dV = frames[i + 1]
+            tA = np.vstack([Ri.T * dt * dt / 2 @ lxly, Ri.T * dt @ lxly])
+            tb = np.concatenate([dP + Ri.T @ Rj @ tlb - tlb - Ri.T * dt * dt / 2 @ g0 - Ri.T @ (Tj - Ti) + dt * Vs[i],
+                                 dV - Ri.T * dt @ g0 + Vs[i] - Ri.T @ Rj @ Vs[i + 1]])
+            A2 += tA.T @ tA
+            b2 += tA.T @ tb
+        A2 *= 1000.0
+        b2 *= 1000.0
+        dg = np.linalg.solve(A2, b2)
+        g0 = g0 + lxly @ dg
+        g0 = g0 / np.linalg.norm(g0) * g_norm
+    return g0, bool(abs(np.linalg.norm(g0) - g_norm) < 0.2)
+
+
 def retract(s, d):
     R, p, v, ba, bg = s
     return (R @ exp_so3(d[0:3]), p + d[3:6], v + d[6:9], ba + d[9:12], bg + d[12:15])
@@ -88,11 +163,36 @@ class BatchSmoother:
         self.o = opts
         self.x, self.pre, self.pose_priors = [], [], []
         self.cur = None
+        self.gravity = []            # (state index, nZ)
+        self.g_frames, self.g_vs = [], []
+        self.g_est, self.g_valid = np.zeros(3), False
+
+    def _estimate_gravity(self, prev, running):
+        """LocalTrajectoryBuilder3D::EstimateGravity (:1106-1154), including the in-place rotation of g_est_Vs_."""
+        win = self.o["frames_for_online_gravity_estimate"]
+        self.g_frames.append((prev[0], prev[1], running.dt, running.dp.copy(), running.dv.copy()))
+        self.g_vs.append(prev[2].copy())
+        if len(self.g_frames) <= win + 1:
+            return False
+        self.g_frames.pop(0)
+        self.g_vs.pop(0)
+        Rw, pw = self.g_frames[0][0], self.g_frames[0][1]
+        tmp = []
+        for i, (R, T, dt, dP, dV) in enumerate(self.g_frames):
+            tmp.append((Rw.T @ R, Rw.T @ (T - pw), dt, dP, dV))
+            self.g_vs[i] = R.T @ self.g_vs[i]
+        g_B, ok = estimate_gravity_vector(tmp, np.asarray(self.o.get("lidar_in_imu_translation", (0, 0, 0)), float),
+                                          self.g_vs, self.o["gravity"])
+        if not ok:
+            return False
+        self.g_est = Rw @ (-g_B)
+        return bool(self.g_est[2] + self.o["gravity"] < 0.5)
 
     def initialize(self, pose7, vel, bias6):
         s = (quat_to_matrix(pose7[3:]), np.array(pose7[:3], float), np.array(vel, float), np.array(bias6[:3], float),
              np.array(bias6[3:], float))
         self.x, self.pre, self.pose_priors = [s], [], []
+        self.gravity, self.g_frames, self.g_vs, self.g_valid = [], [], [], False
         self.prior0 = s
         self.cur = Preintegration(s[3], s[4], self.o)
 
@@ -130,6 +230,12 @@ class BatchSmoother:
 
     def add_pose(self, matched7, is_drift=False, iterations=8):
         nxt = self._predict(self.x[-1], self.cur)
+        if self.o.get("enable_gravity_factor", 0):
+            self.g_valid = self._estimate_gravity(self.x[-1], self.cur)
+            win = self.o["frames_for_online_gravity_estimate"]
+            key = len(self.x)  # key_ of the new state
+            if self.g_valid and key - win >= 0:
+                self.gravity.append((key - win, self.g_est / np.linalg.norm(self.g_est)))
         self.x.append(nxt)
         self.pre.append(self.cur)
         o = self.o
@@ -148,6 +254,16 @@ class BatchSmoother:
                 xm = list(self.x)
                 xm[c // 15] = retract(self.x[c // 15], -d)
                 J[:, c] = (self._residuals(xp) - self._residuals(xm)) / 2e-6
+            # the gravity factors bring their own (the reference factor's) Jacobian
+            bRef = np.array([0.0, 0.0, -1.0])
+            rows_r, rows_J = [r0], [J]
+            for idx, nZ in self.gravity:
+                e, H = gravity_factor(self.x[idx][0], nZ, bRef, o["prior_gravity_noise"])
+                Jg = np.zeros((2, n))
+                Jg[:, 15 * idx:15 * idx + 3] = H
+                rows_r.append(e)
+                rows_J.append(Jg)
+            r0, J = np.concatenate(rows_r), np.vstack(rows_J)
             step = np.linalg.solve(J.T @ J + 1e-12 * np.eye(n), -J.T @ r0)
             self.x = [retract(s, step[15 * i:15 * i + 15]) for i, s in enumerate(self.x)]
         s = self.x[-1]

@@ -33,6 +33,12 @@ int main(int argc, char** argv) {
   options.imu.gyr_noise = imu_noise[1];
   options.imu.acc_bias_noise = imu_noise[2];
   options.imu.gyr_bias_noise = imu_noise[3];
+  const bool gravity = argc > 2 && std::string(argv[2]) == "gravity";
+  if (gravity) {  // dlio/config/basic_config_3d.lua:80: EstimateGravity + Pose3GravityFactor inside WindowOptimize
+    options.imu.enable_gravity_factor = 1;
+    options.imu.frames_for_online_gravity_estimate = 3;
+    options.imu.window_size = 8;
+  }
   options.num_accumulated_range_data = header[3];
   options.min_range = 1.f;
   options.max_range = 100.f;
@@ -76,6 +82,12 @@ int main(int argc, char** argv) {
     }
   }
   std::fclose(f);
+  {
+    transform::Vector3d g{{0, 0, 0}};
+    int64_t factors = 0;
+    const bool valid = builder.GravityEstimate(&g, &factors);
+    std::printf("GRAVITY valid %d factors %lld g %.17g %.17g %.17g\n", valid ? 1 : 0, static_cast<long long>(factors), g.v[0], g.v[1], g.v[2]);
+  }
   const auto submaps = builder.active_submaps().submaps();
   std::printf("SUBMAPS %zu matching_index %d results %d\n", submaps.size(), builder.active_submaps().matching_index(), results);
   if (!submaps.empty()) {  // Submap3D::ToProto round trip: header fields back out of the serialized proto::Submap

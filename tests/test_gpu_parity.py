@@ -1125,12 +1125,13 @@ def test_range_accumulator_two_scans_two_origins(dl, ctx, orc):
     dacc.close()
 
 
-@pytest.mark.parametrize("num_accumulated", [1, 2])
-def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumulated):
+@pytest.mark.parametrize("num_accumulated,gravity", [(1, False), (2, False), (1, True)])
+def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumulated, gravity):
     """tests/cpp/ltb3d_adapter.cc drives the C++ LocalTrajectoryBuilder3D adapter (AddImuData at 200 Hz, AddRangeData
     at 10 Hz, reference signatures) on a recorded stream; the same stream through the Python binding, step by step
     (ImuWindow.add_imu / predict -> RangeDataAccumulator -> match_cloud -> add_pose -> insert), gives the same poses
-    bit for bit."""
+    bit for bit.  gravity: enable_gravity_factor (dlio/config/basic_config_3d.lua:80) on a vehicle-like arc, where
+    EstimateGravity passes its gates -- the adapter's WindowOptimize must add the same Pose3GravityFactors."""
     import ctypes
     import os
     import struct
@@ -1138,11 +1139,16 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
     from dliom import synth
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     noise = [0.08, 0.004, 4e-5, 2e-6]
-    T, scans_n, beams, az = 0.1, 6, 16, 256
+    T, scans_n, beams, az = 0.1, (10 if gravity else 6), 16, 256
     centers = synth.bubbles()
-    st = synth.trajectory_state(0.0)
-    scans = [synth.moving_scan(T * k, beams, az, centers) for k in range(1, scans_n + 1)]
-    imus = [synth.imu_samples(T * (k - 1), T * k, 200.0) for k in range(1, scans_n + 1)]
+    if gravity:
+        synth.set_trajectory(10.0, 0.4)  # 4 m/s on a 10 m radius
+    try:
+        st = synth.trajectory_state(0.0)
+        scans = [synth.moving_scan(T * k, beams, az, centers) for k in range(1, scans_n + 1)]
+        imus = [synth.imu_samples(T * (k - 1), T * k, 200.0) for k in range(1, scans_n + 1)]
+    finally:
+        synth.set_trajectory()
     path = str(tmp_path / "stream.bin")
     with open(path, "wb") as f:
         f.write(struct.pack("4i", scans_n, len(scans[0]), len(imus[0][1]) - 1, num_accumulated))
@@ -1157,11 +1163,12 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
     libdir = os.path.join(root, "d-liom_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(root, "tests", "cpp", "ltb3d_adapter.cc"),
                            "-L", libdir, "-ldliom", "-Wl,-rpath," + libdir])
-    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, path] + (["gravity"] if gravity else []), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "LTB3D ADAPTER DONE" in out.stdout, out.stdout + out.stderr
     got = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:9]]) for l in out.stdout.splitlines() if l.startswith("RESULT")}
     # the same stream through the Python binding
-    window = dl.ImuWindow(acc_noise=noise[0], gyr_noise=noise[1], acc_bias_noise=noise[2], gyr_bias_noise=noise[3])
+    g_opts = dict(enable_gravity_factor=1, frames_for_online_gravity_estimate=3, window_size=8) if gravity else {}
+    window = dl.ImuWindow(acc_noise=noise[0], gyr_noise=noise[1], acc_bias_noise=noise[2], gyr_bias_noise=noise[3], **g_opts)
     window.initialize(st[:7], st[7:10], np.zeros(6))
     acc_dev = dl.RangeDataAccumulator(ctx)
     fe = dl.LocalTrajectoryBuilder3D(ctx, FRONT_END_OPTS)
@@ -1192,6 +1199,14 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
     assert sorted(got) == sorted(want) and len(want) == scans_n // num_accumulated
     for s in want:
         assert np.array_equal(got[s], want[s]), (s, got[s], want[s])
+    gline = [l.split() for l in out.stdout.splitlines() if l.startswith("GRAVITY")][0]
+    g_want, valid_want, factors_want = window.gravity_estimate()
+    assert int(gline[2]) == int(valid_want) and int(gline[4]) == factors_want
+    assert np.array_equal(np.array([float(v) for v in gline[6:9]]), g_want)
+    if gravity:
+        assert factors_want >= 1, "EstimateGravity never passed its gates: the factor path was not exercised"
+    else:
+        assert factors_want == 0
     got_h = {int(l.split()[1]): (int(l.split()[2]), float(l.split()[3])) for l in out.stdout.splitlines() if l.startswith("HISTOGRAM")}
     assert sorted(got_h) == sorted(hists) and len(hists) > 0
     for s in hists:  # the adapter's histogram is the oracle's ComputeHistogram of the gravity-aligned returns

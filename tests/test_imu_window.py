@@ -129,3 +129,181 @@ def test_failure_detection_and_argument_checks(dl):
     assert status == dl.ERR_DIVERGED
     with pytest.raises(Exception):
         w.add_imu([0, 0, 9.8], [0, 0, 0], 0.005)  # ResetParams(): must be re-initialised
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Gravity: GravityEstimator / EstimateGravity / Pose3GravityFactor (the "D" of D-LIOM, basic_config_3d.lua:80)
+GRAVITY_OPTS = dict(enable_gravity_factor=1, frames_for_online_gravity_estimate=4)
+
+
+def _frames_from_motion(synth, ref_mod, opts, n, T, tilt=None, moving=True):
+    """n estimator frames as EstimateGravity builds them: the pose at the START of each scan interval and the
+    preintegration over that interval, velocities in the body frame; poses relative to the first frame."""
+    from scipy.spatial.transform import Rotation as Rot
+    frames, vs = [], []
+    for k in range(n):
+        st = synth.trajectory_state(T * k) if moving else np.concatenate([[0, 0, 0, 1, 0, 0, 0], np.zeros(9)])
+        R = ref_mod.quat_to_matrix(st[3:7])
+        if tilt is not None:
+            R = R @ Rot.from_euler("xy", tilt).as_matrix()
+        P = ref_mod.Preintegration(np.zeros(3), np.zeros(3), opts)
+        if moving:
+            dt, acc, gyr = synth.imu_samples(T * k, T * (k + 1), 200.0)
+            for a, g in zip(acc[:-1], gyr[:-1]):
+                P.add(a, g, dt)
+        else:
+            for _ in range(20):
+                P.add(R.T @ np.array([0, 0, opts["gravity"]]), np.zeros(3), T / 20)
+        frames.append((R, st[:3].copy(), P.dt, P.dp.copy(), P.dv.copy()))
+        vs.append(R.T @ st[7:10])
+    R0, p0 = frames[0][0], frames[0][1]
+    rel = [(R0.T @ R, R0.T @ (p - p0), dt, dP, dV) for (R, p, dt, dP, dV) in frames]
+    return rel, vs, R0
+
+
+def _poses7(rel):
+    from scipy.spatial.transform import Rotation as Rot
+    out = []
+    for R, p, *_ in rel:
+        q = Rot.from_matrix(R).as_quat()
+        out.append(np.concatenate([p, [q[3], q[0], q[1], q[2]]]))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("moving", [False, True])
+def test_gravity_estimator_equals_the_numpy_restatement(dl, moving):
+    """dliom_gravity_estimate (C++) against oracle/imu_window_ref.estimate_gravity_vector (numpy), both restating
+    gravity_factor/gravity_estimator.cc; at rest the estimate is exact: |g| up, in the first frame."""
+    from dliom import synth
+    import oracle.imu_window_ref as ref
+    w = dl.ImuWindow()
+    opts = {n: getattr(w.options, n) for n in OPT_NAMES}
+    tlb = np.array([0.1, -0.05, 0.2])
+    rel, vs, R0 = _frames_from_motion(synth, ref, opts, 6, 0.1, tilt=(0.05, -0.08), moving=moving)
+    want, ok_ref = ref.estimate_gravity_vector(rel, tlb, vs, opts["gravity"])
+    got, ok = dl.gravity_estimate(_poses7(rel), [f[2] for f in rel], [f[3] for f in rel], [f[4] for f in rel], vs,
+                                  opts["gravity"], tlb)
+    assert ok == ok_ref
+    assert np.allclose(got, want, rtol=0, atol=1e-9), (got, want)
+    if not moving:
+        assert ok and np.allclose(got, R0.T @ np.array([0, 0, opts["gravity"]]), atol=1e-6)
+    # fewer than three frames: refused like the reference (:39-42)
+    _, ok2 = dl.gravity_estimate(_poses7(rel[:2]), [f[2] for f in rel[:2]], [f[3] for f in rel[:2]], [f[4] for f in rel[:2]],
+                                 vs[:2], opts["gravity"], tlb)
+    assert not ok2
+
+
+def test_window_with_gravity_factor_equals_the_batch_reference(dl):
+    """enable_gravity_factor: EstimateGravity per scan, a Pose3GravityFactor on the state 4 keys back whenever it passes
+    the gates.  While nothing is marginalised the window must agree with the numpy batch smoother that restates the same
+    deque handling, estimator, Unit3 basis and the factor's own Jacobian -- and the factor must actually be there.
+    Trajectory: a straight line under constant acceleration with a fixed 2 degree roll (on the reference test's corkscrew
+    -- 23 degrees of heading per scan -- the estimator never passes its gates, in both implementations: checked below)."""
+    from dliom import synth
+    from oracle.imu_window_ref import BatchSmoother
+    from scipy.spatial.transform import Rotation as Rot
+    g = 9.80511
+    Rb = Rot.from_euler("x", np.deg2rad(2.0))
+    qb = Rb.as_quat()
+    q7 = np.array([qb[3], qb[0], qb[1], qb[2]])
+    acc_w, v0 = np.array([0.5, 0.2, 0.0]), np.array([1.0, 0.0, 0.0])
+
+    def pose_at(t):
+        return np.concatenate([v0 * t + 0.5 * acc_w * t * t, q7])
+
+    for corkscrew in (False, True):
+        w = dl.ImuWindow(window_size=16, iterations=6, **GRAVITY_OPTS)
+        opts = {n: getattr(w.options, n) for n in OPT_NAMES}
+        opts.update(GRAVITY_OPTS)
+        ref = BatchSmoother(opts)
+        if corkscrew:
+            st = synth.trajectory_state(0.0)
+            w.initialize(st[:7], st[7:10], np.zeros(6))
+            ref.initialize(st[:7], st[7:10], np.zeros(6))
+        else:
+            w.initialize(pose_at(0.0), v0, np.zeros(6))
+            ref.initialize(pose_at(0.0), v0, np.zeros(6))
+        T = 0.1
+        added = 0
+        f_body = Rb.as_matrix().T @ (acc_w + np.array([0, 0, g]))
+        for k in range(1, 11):
+            if corkscrew:
+                _feed(w, ref, k, T, synth)
+                truth = synth.trajectory_pose(T * k)
+            else:
+                for _ in range(20):
+                    w.add_imu(f_body, np.zeros(3), T / 20)
+                    ref.add_imu(f_body, np.zeros(3), T / 20)
+                truth = pose_at(T * k)
+            matched = synth.perturb_pose(truth, 0.02, 0.1, seed=40 + k)
+            pose, vel, bias, status = w.add_pose(matched)
+            R, p, v, ba, bg = ref.add_pose(matched, iterations=6)
+            gv, valid, n_factors = w.gravity_estimate()
+            assert status == 0
+            assert valid == ref.g_valid and n_factors == len(ref.gravity), (k, valid, ref.g_valid, n_factors, len(ref.gravity))
+            if valid:
+                assert np.allclose(gv, ref.g_est, atol=1e-6), (gv, ref.g_est)
+            added = n_factors
+            qr = Rot.from_matrix(R).as_quat()
+            assert np.linalg.norm(pose[:3] - p) < 1e-6
+            assert _angle(pose[3:], np.array([qr[3], qr[0], qr[1], qr[2]])) < 1e-6
+            assert np.linalg.norm(vel - v) < 1e-5
+        if corkscrew:
+            assert added == 0  # gates never passed at 16 m/s^2 and 23 degrees per scan
+        else:
+            assert added >= 3  # the factor is exercised, not just wired
+
+
+def test_gravity_estimate_at_rest_and_its_gates(dl):
+    """A level platform at rest: g_vec_est_G_ = R_front * -g_B (:1142) is straight down, passes both gates (|g| within
+    0.2 of the norm, z + g < 0.5), the factor is added every scan once the window is full and the attitude stays put.
+    What the reference's factor does on a platform that is NOT level follows from its definition and is asserted as such:
+    nZ is the gravity direction in the GLOBAL frame, (0, 0, -1) whenever the attitude estimate is right, and the error
+    basis(nZ)^T (R_rp bRef) with bRef = (0, 0, -1) vanishes only for roll = pitch = 0 -- the factor pulls the state
+    frames_for_online_gravity_estimate keys back towards level."""
+    from scipy.spatial.transform import Rotation as Rot
+    g = 9.80511
+    roll_after = {}
+    for true_roll in (0.0, np.deg2rad(3.0)):
+        w = dl.ImuWindow(window_size=8, **GRAVITY_OPTS)
+        R_true = Rot.from_euler("x", true_roll).as_matrix()
+        q = Rot.from_euler("x", true_roll).as_quat()
+        pose = np.array([0, 0, 0, q[3], q[0], q[1], q[2]], float)
+        w.initialize(pose, np.zeros(3), np.zeros(6))
+        f = R_true.T @ np.array([0, 0, g])  # specific force of a body at rest
+        first = None
+        for k in range(8):
+            for _ in range(20):
+                w.add_imu(f, np.zeros(3), 0.005)
+            out, vel, bias, status = w.add_pose(pose)
+            assert status == 0
+            gv, valid, n = w.gravity_estimate()
+            if valid and first is None:
+                first = gv.copy()
+                assert k == 5  # the deque holds frames + 1 = 5 entries after the 5th scan, the 6th pops and estimates
+        assert first is not None and n >= 2
+        # the first estimate is made while the attitude estimate is still the true one: straight down
+        assert np.arccos(np.clip(-first[2] / np.linalg.norm(first), -1, 1)) < np.deg2rad(0.05)
+        assert abs(np.linalg.norm(first) - g) < 1e-6
+        roll_after[true_roll] = Rot.from_quat([out[4], out[5], out[6], out[3]]).as_euler("xyz")[0]
+    assert abs(roll_after[0.0]) < np.deg2rad(0.01)                     # level stays level
+    assert roll_after[np.deg2rad(3.0)] < np.deg2rad(3.0) - np.deg2rad(0.5)  # tilted: pulled towards level, by definition
+
+
+def test_gravity_options_are_validated_and_failed_solves_roll_back(dl):
+    with pytest.raises(Exception):
+        dl.ImuWindow(window_size=4, enable_gravity_factor=1, frames_for_online_gravity_estimate=7)  # factor key not in the window
+    from dliom import synth
+    w = dl.ImuWindow()
+    st = synth.trajectory_state(0.0)
+    w.initialize(st[:7], st[7:10], np.zeros(6))
+    for _ in range(20):
+        w.add_imu([0.0, 0.0, 9.80511], [0, 0, 0], 0.005)
+    bad = st[:7].copy()
+    bad[0] = float("nan")  # normal equations full of NaN: Cholesky refuses
+    n_before = len(w)
+    pose, vel, bias, status = w.add_pose(bad)
+    assert status == dl.ERR_SOLVER and len(w) == n_before
+    pose, vel, bias, status = w.add_pose(st[:7])  # the same IMU samples, counted once
+    assert status == 0 and len(w) == n_before + 1
+    assert np.linalg.norm(pose[:3] - st[:3]) < 0.05
