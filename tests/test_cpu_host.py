@@ -223,6 +223,77 @@ def test_imu_preintegration_against_closed_form_motion():
     integ.close()
 
 
+def test_imu_preintegration_bias_jacobians_against_finite_differences():
+    """The first-order bias corrections IntegrationBase carries (integration_base.h:156-265: the O_P / O_R / O_V rows of
+    the O_BA / O_BG columns of `jacobian`) against central differences of a full repropagation with perturbed biases.
+    The reference propagates the Jacobian with its mid-point F matrix (:203-237), itself accurate to first order in the step:
+    the columns agree with the true derivative to ~1e-3 of the block's largest entry (bit-equality with the restated formulas is
+    test_imu_preintegration_equals_oracle's job)."""
+    import dliom as dl
+    noise = [0.08, 0.004, 4e-5, 2e-6]
+    ba, bg = np.array([0.02, -0.01, 0.03]), np.array([1e-3, -2e-3, 5e-4])
+    dt, acc, gyr = _imu_stream(2)
+    integ = dl.ImuIntegrator(ba, bg, noise)
+    for k in range(len(acc)):
+        integ.push_back(dt, acc[k], gyr[k])
+    base = integ.get()
+    J = np.asarray(base["jacobian"]).reshape(15, 15)
+
+    def deltas(ba_, bg_):
+        integ.repropagate(ba_, bg_)
+        g = integ.get()
+        return np.array(g["delta_p"]), np.array(g["delta_q"]), np.array(g["delta_v"])
+
+    def qmul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+    eps = 1e-5
+    p0, q0, v0 = deltas(ba, bg)
+    for col, (is_gyro, axis) in enumerate([(False, 0), (False, 1), (False, 2), (True, 0), (True, 1), (True, 2)]):
+        d = np.zeros(3)
+        d[axis] = eps
+        pp, qp, vp = deltas(ba + (0 if is_gyro else 1) * d, bg + (1 if is_gyro else 0) * d)
+        pm, qm, vm = deltas(ba - (0 if is_gyro else 1) * d, bg - (1 if is_gyro else 0) * d)
+        c = 9 + col
+        def close(fd, jac, what):
+            rows = {"dp": slice(0, 3), "dq": slice(3, 6), "dv": slice(6, 9)}[what]
+            scale = np.abs(J[rows, 9:15]).max()  # the block's largest entry: small columns carry the same absolute error
+            assert np.linalg.norm(fd - jac) <= 2e-3 * scale, (what, col, fd, jac)
+        close((pp - pm) / (2 * eps), J[0:3, c], "dp")
+        close((vp - vm) / (2 * eps), J[6:9, c], "dv")
+        # rotation: theta = 2 vec(q0^-1 (x) q_perturbed), right perturbation like the residual uses it (:244)
+        q0c = q0 * np.array([1, -1, -1, -1])
+        th = (2 * qmul(q0c, qp)[1:] - 2 * qmul(q0c, qm)[1:]) / (2 * eps)
+        close(th, J[3:6, c], "dq")
+    integ.close()
+
+
+def test_gravity_factor_jacobian_is_the_derivative_its_definition_implies():
+    """The restated GTSAM pieces behind Pose3GravityFactor (oracle/imu_window_ref.gravity_factor: Unit3::basis, Unit3::error
+    and Rot3::rotate(Unit3) Jacobians) against central differences of the error under a right perturbation of
+    R_rp = RzRyRx(roll, pitch, 0) -- the variable the reference's factor differentiates (gravity_factor.cc:15-23)."""
+    import oracle.imu_window_ref as ref
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.RandomState(3)
+    bRef = np.array([0.0, 0.0, -1.0])
+    for _ in range(20):
+        roll, pitch = rng.uniform(-0.3, 0.3, 2)
+        R = Rot.from_euler("ZYX", [rng.uniform(-3, 3), pitch, roll]).as_matrix()  # Rz Ry Rx
+        nZ = np.array([0, 0, -1.0]) + 0.2 * rng.normal(size=3)
+        nZ /= np.linalg.norm(nZ)
+        e, H = ref.gravity_factor(R, nZ, bRef, 1.0)
+        Rrp = Rot.from_euler("y", pitch).as_matrix() @ Rot.from_euler("x", roll).as_matrix()
+        Bp = ref.unit3_basis(nZ)
+        num = np.zeros((2, 3))
+        for k in range(3):
+            d = np.zeros(3)
+            d[k] = 1e-6
+            num[:, k] = (Bp.T @ (Rrp @ ref.exp_so3(d) @ bRef) - Bp.T @ (Rrp @ ref.exp_so3(-d) @ bRef)) / 2e-6
+        assert np.allclose(e, Bp.T @ (Rrp @ bRef) + 1e-5, atol=1e-12)
+        assert np.allclose(H, num, atol=1e-8), (H, num)
+
+
 def test_rotational_scan_match_equals_oracle(orc):
     """RotationalScanMatcher ctor + Match (histogram rotation, normalised dot product with Eigen's
     packet reduction order) -- host code on both sides, bit-identical scores."""
