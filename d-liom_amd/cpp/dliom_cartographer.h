@@ -747,18 +747,28 @@ class LocalTrajectoryBuilder3D {
       for (int i = 0; i < ins.num_insertion_submaps; ++i) ir->insertion_submap_indices.push_back(ins.insertion_submap_index[i]);
       ir->submap_finished = ins.submap_finished != 0;
       // ComputeHistogram(TransformPointCloud(filtered_range_data_in_tracking.returns, Rotation(gravity_alignment.cast<float>())), size)
+      // on the device, where the filtered cloud already is (rotation fused); the host version only for the two cases the
+      // device one refuses (|z| beyond 409 m, more than 4096 points in one 0.2 m slice)
       if (options_.rotational_histogram_size > 0) {
-        const float rot[7] = {0.f, 0.f, 0.f, pf[3], pf[4], pf[5], pf[6]};
-        std::vector<float> aligned(3 * static_cast<size_t>(n));
-        for (int64_t i = 0; i < n; ++i) {
-          const sensor::Vector3f a = TransformPoint(rot, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-          aligned[3 * i] = a.x;
-          aligned[3 * i + 1] = a.y;
-          aligned[3 * i + 2] = a.z;
-        }
         ir->rotational_scan_matcher_histogram.resize(static_cast<size_t>(options_.rotational_histogram_size));
-        Check(dliom_rotational_histogram(aligned.data(), n, options_.rotational_histogram_size,
-                                         ir->rotational_scan_matcher_histogram.data()), "RotationalScanMatcher::ComputeHistogram");
+        const float rot_wxyz[4] = {pf[3], pf[4], pf[5], pf[6]};
+        int hs = options_.rotational_histogram_size <= 255
+                     ? dliom_cloud_rotational_histogram(context_->get(), cloud, rot_wxyz, options_.rotational_histogram_size,
+                                                        ir->rotational_scan_matcher_histogram.data())
+                     : DLIOM_ERR_CAPACITY;
+        if (hs == DLIOM_ERR_CAPACITY) {
+          const float rot[7] = {0.f, 0.f, 0.f, pf[3], pf[4], pf[5], pf[6]};
+          std::vector<float> aligned(3 * static_cast<size_t>(n));
+          for (int64_t i = 0; i < n; ++i) {
+            const sensor::Vector3f a = TransformPoint(rot, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+            aligned[3 * i] = a.x;
+            aligned[3 * i + 1] = a.y;
+            aligned[3 * i + 2] = a.z;
+          }
+          hs = dliom_rotational_histogram(aligned.data(), n, options_.rotational_histogram_size,
+                                          ir->rotational_scan_matcher_histogram.data());
+        }
+        Check(hs, "RotationalScanMatcher::ComputeHistogram");
       }
       const dliom_cloud* filtered[2] = {nullptr, nullptr};
       Check(dliom_front_end_matched_clouds(active_submaps_.get(), &filtered[0], &filtered[1]), "matched clouds");

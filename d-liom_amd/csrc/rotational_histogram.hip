@@ -1,0 +1,753 @@
+// RotationalScanMatcher::ComputeHistogram on the device
+// (mapping/internal/3d/scan_matching/rotational_scan_matcher.cc:29-123,159-170), the per-scan O(N) step that
+// LocalTrajectoryBuilder3D runs after insertion (local_trajectory_builder_3d.cc:605-610) on
+//   TransformPointCloud(filtered_range_data_in_tracking.returns, Rigid3f::Rotation(gravity_alignment.cast<float>()))
+// -- the filtered cloud is already in HBM; the host version (rotational_histogram.cc) cost more than the whole
+// device chain it followed.
+//
+// What makes it order dependent, and how each dependence is kept (bit for bit):
+//   * slices: key lround(z / 0.2f), points in INPUT order inside a slice (std::map of vectors, :162-165).  Kernel 1
+//     counts the keys (4096 bins, |z| < 409 m); kernel 2 runs one workgroup per non-empty slice, whose 16 waves each
+//     compact their contiguous 1/16 of the input (count, prefix over the waves, write): input order, no atomics.
+//   * ComputeCentroid (:52-59): a SEQUENTIAL float sum.  One thread per coordinate walks the slice in LDS.
+//   * SortSlice (:97-121): atan2f of the reference's libm (glibc 2.35 flt-32 = fdlibm, no FMA; restated below and
+//     pinned against the host's atan2f by tests/test_cpu_host.py), std::sort by angle.  Here: a bitonic sort of
+//     (angle, position in the slice) -- identical to any std::sort unless two DISTINCT points of a slice have
+//     bit-identical angles (std::sort's order of equal keys is unspecified; identical points commute).
+//   * AddPointCloudSliceToHistogram (:61-92): `last_point` only moves when a point is more than 0.9 m from it -- a
+//     sequential state machine.  One wave evaluates 64 sorted points against the current anchor at once, takes the
+//     lanes before the first jump, moves the anchor and goes on.
+//   * histogram(bucket) += value (:49): float additions in slice order, then point order.  The slices' contribution
+//     lists lie back to back in slice order; kernel 3: one wave per bucket queues the positions of its entries in
+//     order, fetches the values and one thread adds them one after the other.
+// Limits (DLIOM_ERR_CAPACITY, the host entry point has none): |z| < 409.6 m, at most 4096 points per slice.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "device_common.h"
+
+namespace dliom {
+namespace rothist {
+
+constexpr int kBins = 4096;
+constexpr int kBinOrigin = 2048;
+constexpr int kMaxSlice = 4096;
+constexpr int kThreads = 1024;
+constexpr float kMinDistance = 0.2f;
+constexpr float kMaxDistance = 0.9f;
+constexpr float kSliceHeight = 0.2f;
+
+// ---- glibc 2.35 sysdeps/ieee754/flt-32/{s_atanf.c, e_atan2f.c} (fdlibm), the algorithm the reference's
+// common::atan2 -> std::atan2(float, float) runs on the host; every operation rounded to float, no contraction.
+__device__ __forceinline__ float fd_atanf(float x) {
+  const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+  const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+  const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f,
+                        9.0908870101e-02f, -7.6918758452e-02f, 6.6610731184e-02f, -5.8335702866e-02f,
+                        4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+  const int hx = __float_as_int(x);
+  const int ix = hx & 0x7fffffff;
+  int id;
+  if (ix >= 0x4c000000) {  // |x| >= 2^25
+    if (ix > 0x7f800000) return x + x;
+    return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+  }
+  if (ix < 0x3ee00000) {  // |x| < 0.4375
+    if (ix < 0x31000000) return x;
+    id = -1;
+  } else {
+    x = fabsf(x);
+    if (ix < 0x3f980000) {
+      if (ix < 0x3f300000) {
+        id = 0;
+        x = (2.0f * x - 1.0f) / (2.0f + x);
+      } else {
+        id = 1;
+        x = (x - 1.0f) / (x + 1.0f);
+      }
+    } else {
+      if (ix < 0x401c0000) {
+        id = 2;
+        x = (x - 1.5f) / (1.0f + 1.5f * x);
+      } else {
+        id = 3;
+        x = -1.0f / x;
+      }
+    }
+  }
+  const float z = x * x;
+  const float w = z * z;
+  const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+  const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+  if (id < 0) return x - x * (s1 + s2);
+  const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+  return hx < 0 ? -r : r;
+}
+__device__ __forceinline__ float fd_atan2f(float y, float x) {
+  const float tiny = 1.0e-30f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const int hx = __float_as_int(x), hy = __float_as_int(y);
+  const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+  if (hx == 0x3f800000) return fd_atanf(y);
+  const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+  if (iy == 0) {
+    if (m < 2) return y;
+    return m == 2 ? pi + tiny : -pi - tiny;
+  }
+  if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000) {
+    const float pi_o_4 = 7.8539818525e-01f;
+    if (iy == 0x7f800000) {
+      if (m == 0) return pi_o_4 + tiny;
+      if (m == 1) return -pi_o_4 - tiny;
+      if (m == 2) return 3.0f * pi_o_4 + tiny;
+      return -3.0f * pi_o_4 - tiny;
+    }
+    if (m == 0) return 0.0f;
+    if (m == 1) return -0.0f;
+    if (m == 2) return pi + tiny;
+    return -pi - tiny;
+  }
+  if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  const int k = (iy - ix) >> 23;
+  float z;
+  if (k > 60)
+    z = pi_o_2 + 0.5f * pi_lo;
+  else if (hx < 0 && k < -60)
+    z = 0.0f;
+  else
+    z = fd_atanf(fabsf(y / x));
+  if (m == 0) return z;
+  if (m == 1) return -z;
+  if (m == 2) return pi - (z - pi_lo);
+  return (z - pi_lo) - pi;
+}
+
+__device__ __forceinline__ float norm2(float x, float y) { return sqrtf(x * x + y * y); }
+
+// AddValueToHistogram's bucket (:35-48)
+__device__ __forceinline__ int bucket_of(float angle, int size) {
+  const float pi = 3.14159274101257324f;  // static_cast<float>(M_PI)
+  while (angle > pi) angle -= pi;
+  while (angle < 0.f) angle += pi;
+  const float zero_to_one = angle / pi;
+  const int bucket = lround_away(static_cast<float>(size) * zero_to_one - 0.5f);
+  return min(max(bucket, 0), size - 1);
+}
+
+// ---- kernel 1: rotated points, slice keys, key counts ------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void prepare_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, int n, Quat4 q, int rotate,
+                                                           float* __restrict__ rx, float* __restrict__ ry,
+                                                           float* __restrict__ rz, short* __restrict__ keys,
+                                                           unsigned* __restrict__ bin_counts, unsigned* __restrict__ flags) {
+  __shared__ unsigned hist[kBins];
+  for (int b = threadIdx.x; b < kBins; b += kThreads) hist[b] = 0u;
+  __syncthreads();
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) {
+    float px = x[i], py = y[i], pz = z[i];
+    if (rotate) {
+      // Rigid3f::Rotation(q) * point = rotation * point + translation with a zero translation (rigid_transform.h:214-219)
+      float ox, oy, oz;
+      rotate_point(q, px, py, pz, ox, oy, oz);
+      px = ox + 0.f;
+      py = oy + 0.f;
+      pz = oz + 0.f;
+    }
+    rx[i] = px;
+    ry[i] = py;
+    rz[i] = pz;
+    const float kf = pz / kSliceHeight;
+    int key = 0;
+    if (!(fabsf(kf) < 2047.f)) {  // also NaN
+      atomicOr(flags, 1u);
+    } else {
+      key = lround_away(kf);
+      atomicAdd(&hist[key + kBinOrigin], 1u);
+    }
+    keys[i] = static_cast<short>(key);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins; b += kThreads)
+    if (hist[b] != 0u) atomicAdd(&bin_counts[b], hist[b]);
+}
+
+// ---- kernel 2: one workgroup per non-empty slice ------------------------------------------------------------------
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* wave_sums, unsigned* total) {
+  // 1024 threads: inclusive scan inside the wave, then over the 16 waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  __syncthreads();  // wave_sums may still be read from an earlier call
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  unsigned before = 0u, all = 0u;
+  for (int w = 0; w < kThreads / 64; ++w) {
+    const unsigned s = wave_sums[w];
+    if (w < wave) before += s;
+    all += s;
+  }
+  *total = all;
+  return before + incl - v;
+}
+
+// sum = ((acc + a[0]) + a[1]) + ... in exactly that order, by ONE thread: 64 values per step (sixteen 16-byte LDS
+// reads in flight), then 64 dependent additions.  `a` is 16-byte aligned; entries past n up to the next multiple of 64
+// are read and must be readable (they are replaced by +0, which changes nothing).
+__device__ __forceinline__ float thread_sequential_sum(const float* a, int n, float acc) {
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    float4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const float4*>(a + i0 + 4 * k);
+    const int left = n - i0;
+    if (left >= 64) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        acc += v[k].x;
+        acc += v[k].y;
+        acc += v[k].z;
+        acc += v[k].w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        acc += 4 * k < left ? v[k].x : 0.f;
+        acc += 4 * k + 1 < left ? v[k].y : 0.f;
+        acc += 4 * k + 2 < left ? v[k].z : 0.f;
+        acc += 4 * k + 3 < left ? v[k].w : 0.f;
+      }
+    }
+  }
+  return acc;
+}
+
+// float -> unsigned with the same order as operator< on floats (NaN excluded), -0 folded onto +0 first
+__device__ __forceinline__ unsigned ordered_bits(float f) {
+  if (f == 0.f) f = 0.f;
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+#ifdef DLIOM_EXPERIMENTS
+__device__ unsigned long long dbg_stamps[64 * 16];
+__device__ unsigned long long dbg_acc[128 * 8];
+#endif
+
+__global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict__ rx, const float* __restrict__ ry,
+                                                         const float* __restrict__ rz, const short* __restrict__ keys, int n,
+                                                         const unsigned* __restrict__ bin_counts, int histogram_size,
+                                                         float squared_jump, unsigned char* __restrict__ c_bucket,
+                                                         float* __restrict__ c_value, unsigned* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds_dyn[];  // [sort keys kMaxSlice | sx | sy | sz]; later [.. | px py of the sorted points]
+  unsigned long long* skey = lds_dyn;
+  float* sx = reinterpret_cast<float*>(skey + kMaxSlice);
+  float* sy = sx + kMaxSlice;
+  float* sz = sy + kMaxSlice;
+  __shared__ unsigned wave_sums[kThreads / 64];
+  __shared__ unsigned sh_bin, sh_count, sh_begin, sh_valid, sh_written;
+  __shared__ float sh_centroid[3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- which slice: the (blockIdx.x)-th non-empty bin, then every gridDim.x-th; offsets = prefix of the counts
+  unsigned my_counts[kBins / kThreads], my_sum = 0u, my_nonempty = 0u;
+#pragma unroll
+  for (int k = 0; k < kBins / kThreads; ++k) {
+    my_counts[k] = bin_counts[threadIdx.x * (kBins / kThreads) + k];
+    my_sum += my_counts[k];
+    my_nonempty += my_counts[k] != 0u ? 1u : 0u;
+  }
+  unsigned total_points, total_slices;
+  const unsigned points_before = block_exclusive_scan(my_sum, wave_sums, &total_points);
+  const unsigned slices_before = block_exclusive_scan(my_nonempty, wave_sums, &total_slices);
+#ifdef DLIOM_EXPERIMENTS
+#define DLIOM_STAMP(k) if (threadIdx.x == 0 && blockIdx.x < 64) dbg_stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter()
+#else
+#define DLIOM_STAMP(k)
+#endif
+  DLIOM_STAMP(0);
+  for (unsigned ordinal = blockIdx.x; ordinal < total_slices; ordinal += gridDim.x) {
+    __syncthreads();
+    {
+      unsigned pb = points_before, sb = slices_before;
+#pragma unroll
+      for (int k = 0; k < kBins / kThreads; ++k) {
+        if (my_counts[k] != 0u) {
+          if (sb == ordinal) {
+            sh_bin = threadIdx.x * (kBins / kThreads) + k;
+            sh_count = my_counts[k];
+            sh_begin = pb;
+          }
+          ++sb;
+        }
+        pb += my_counts[k];
+      }
+    }
+    __syncthreads();
+    const int key = static_cast<int>(sh_bin) - kBinOrigin;
+    const int count = static_cast<int>(sh_count);
+    const unsigned begin = sh_begin;
+    if (count > kMaxSlice) {
+      if (threadIdx.x == 0) atomicOr(flags, 2u);
+      continue;
+    }
+    // ---- the slice's points in input order: wave w compacts its contiguous share of the input, 512 keys (8 per lane,
+    //      one 16-byte load) per step; a lane's keys are consecutive, so input order = (step, lane, position in lane)
+    const int blocks512 = (n + 511) / 512;
+    const int per_wave = (blocks512 + kThreads / 64 - 1) / (kThreads / 64);
+    const int blk_lo = wave * per_wave, blk_hi = min(blocks512, blk_lo + per_wave);
+    unsigned mine = 0u;
+    for (int blk = blk_lo; blk < blk_hi; ++blk) {
+      const int i0 = blk * 512 + lane * 8;
+      uint4 kk = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);  // no key is 0x7fff
+      if (i0 < n) kk = *reinterpret_cast<const uint4*>(keys + i0);                 // the key array is padded to 512
+      const unsigned w4[4] = {kk.x, kk.y, kk.z, kk.w};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const short kv = static_cast<short>((w4[t >> 1] >> ((t & 1) * 16)) & 0xffffu);
+        mine += (i0 + t < n && kv == key) ? 1u : 0u;
+      }
+    }
+    // per-wave totals -> where this wave's points start
+    unsigned wave_total = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) wave_total += __shfl_xor(wave_total, d, 64);
+    __syncthreads();
+    if (lane == 0) wave_sums[wave] = wave_total;
+    __syncthreads();
+    unsigned at = 0u;
+    for (int w = 0; w < wave; ++w) at += wave_sums[w];
+    for (int blk = blk_lo; blk < blk_hi; ++blk) {
+      const int i0 = blk * 512 + lane * 8;
+      uint4 kk = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+      if (i0 < n) kk = *reinterpret_cast<const uint4*>(keys + i0);
+      const unsigned w4[4] = {kk.x, kk.y, kk.z, kk.w};
+      unsigned hits = 0u, cnt = 0u;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const short kv = static_cast<short>((w4[t >> 1] >> ((t & 1) * 16)) & 0xffffu);
+        if (i0 + t < n && kv == key) {
+          hits |= 1u << t;
+          ++cnt;
+        }
+      }
+      unsigned incl = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      unsigned slot = at + incl - cnt;
+      while (hits != 0u) {
+        const int t = __builtin_ctz(hits);
+        sx[slot] = rx[i0 + t];
+        sy[slot] = ry[i0 + t];
+        sz[slot] = rz[i0 + t];
+        ++slot;
+        hits &= hits - 1u;
+      }
+      at += __shfl(incl, 63, 64);
+    }
+    __syncthreads();
+    DLIOM_STAMP(1);
+    // ---- SortSlice: centroid (sequential float sums), angles, sort by angle
+    if (lane == 0 && wave < 3)  // one thread per coordinate (on three different SIMDs)
+      sh_centroid[wave] = thread_sequential_sum(wave == 0 ? sx : (wave == 1 ? sy : sz), count, 0.f) / static_cast<float>(count);
+    __syncthreads();
+    DLIOM_STAMP(2);
+    int pow2 = 64;
+    while (pow2 < count) pow2 <<= 1;
+    {
+      const float cx = sh_centroid[0], cy = sh_centroid[1];
+      unsigned valid = 0u;
+      for (int i = threadIdx.x; i < pow2; i += kThreads) {
+        unsigned long long k64 = ~0ull;  // padding and skipped points sort to the end
+        if (i < count) {
+          const float dx = sx[i] - cx, dy = sy[i] - cy;
+          if (!(norm2(dx, dy) < kMinDistance)) {
+            k64 = (static_cast<unsigned long long>(ordered_bits(fd_atan2f(dy, dx))) << 32) | static_cast<unsigned>(i);
+            ++valid;
+          }
+        }
+        skey[i] = k64;
+      }
+      unsigned total_valid;
+      block_exclusive_scan(valid, wave_sums, &total_valid);
+      if (threadIdx.x == 0) sh_valid = total_valid;
+    }
+    __syncthreads();
+    DLIOM_STAMP(3);
+    {
+      // bitonic sort, up to four keys per thread in registers (key i = t + r * 1024): exchanges at distance < 64 are lane
+      // shuffles, at distance >= 1024 stay inside the thread, and only the distances 64 .. 512 go through LDS
+      constexpr int kR = kMaxSlice / kThreads;
+      const int rows = max(1, pow2 / kThreads);  // keys per thread in use
+      unsigned long long v[kR];
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+        v[r] = i < pow2 ? skey[i] : ~0ull;
+      }
+      for (int k = 2; k <= pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          if (j >= kThreads) {  // partner key in the same thread: rows (0,1),(2,3) for j = 1024, (0,2),(1,3) for j = 2048
+            static_assert(kR == 4, "the in-thread exchanges below are written for four keys per thread");
+            auto exchange = [&](unsigned long long& a, unsigned long long& b, int row) {
+              const int i = static_cast<int>(threadIdx.x) + row * kThreads;
+              const bool up = (i & k) == 0;
+              const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+              a = up ? lo : hi;
+              b = up ? hi : lo;
+            };
+            if (j == kThreads) {
+              exchange(v[0], v[1], 0);
+              exchange(v[2], v[3], 2);
+            } else {
+              exchange(v[0], v[2], 0);
+              exchange(v[1], v[3], 1);
+            }
+          } else if (j >= 64) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+              const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+              if (r < rows && i < pow2) skey[i] = v[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+              const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+              if (r < rows && i < pow2) {
+                const unsigned long long other = skey[i ^ j];
+                const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+                v[r] = keep_min ? (v[r] < other ? v[r] : other) : (v[r] < other ? other : v[r]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < kR; ++r) {
+              if (r >= rows) break;  // uniform
+              const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+              const unsigned lo32 = static_cast<unsigned>(__shfl_xor(static_cast<int>(v[r] & 0xffffffffull), j, 64));
+              const unsigned hi32 = static_cast<unsigned>(__shfl_xor(static_cast<int>(v[r] >> 32), j, 64));
+              const unsigned long long other = (static_cast<unsigned long long>(hi32) << 32) | lo32;
+              const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+              v[r] = keep_min ? (v[r] < other ? v[r] : other) : (v[r] < other ? other : v[r]);
+            }
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+        if (i < pow2) skey[i] = v[r];
+      }
+      __syncthreads();
+    }
+    const int m = static_cast<int>(sh_valid);
+    DLIOM_STAMP(4);
+    // ---- the sorted slice, contiguous (x into the z array -- z is not needed any more -- and y behind the sort keys'
+    //      low words is not possible: y goes to a second pass over sy via registers)
+    float* px_sorted = sz;
+    float my_py[kMaxSlice / kThreads];
+#pragma unroll
+    for (int r = 0; r < kMaxSlice / kThreads; ++r) {
+      const int j = threadIdx.x + r * kThreads;
+      my_py[r] = 0.f;
+      if (j < m) {
+        const unsigned idx = static_cast<unsigned>(skey[j]);
+        px_sorted[j] = sx[idx];
+        my_py[r] = sy[idx];
+      }
+    }
+    __syncthreads();
+    float* py_sorted = sx;  // sx has been read out
+#pragma unroll
+    for (int r = 0; r < kMaxSlice / kThreads; ++r) {
+      const int j = threadIdx.x + r * kThreads;
+      if (j < m) py_sorted[j] = my_py[r];
+    }
+    __syncthreads();
+    // ---- AddPointCloudSliceToHistogram: centroid of the SORTED points (sequential again; z is not used below)
+    if (lane == 0 && wave < 2)
+      sh_centroid[wave] = thread_sequential_sum(wave == 0 ? px_sorted : py_sorted, m, 0.f) / static_cast<float>(m);
+    __syncthreads();
+    DLIOM_STAMP(5);
+    // (a) which points can never contribute: closer than kMinDistance to the centroid (:73-75)
+    unsigned char* dead = reinterpret_cast<unsigned char*>(skey);                 // [kMaxSlice] bytes
+    unsigned short* anchor_of = reinterpret_cast<unsigned short*>(dead + kMaxSlice);  // [kMaxSlice]: last_point, 0xFFFF = jump
+    unsigned char* cb = reinterpret_cast<unsigned char*>(anchor_of + kMaxSlice);  // contributions in order: bucket ...
+    float* cv = sy;                                                                // ... and value (sy has been read out)
+    {
+      const float cx = sh_centroid[0], cy = sh_centroid[1];
+      for (int j = threadIdx.x; j < m; j += kThreads) dead[j] = norm2(px_sorted[j] - cx, py_sorted[j] - cy) < kMinDistance ? 1 : 0;
+    }
+    __syncthreads();
+    // (b) the chain of `last_point`s (:70-80), one wave: last_point moves to the first live point farther than
+    //     kMaxDistance from it.  fl(sqrt(s)) > kMaxDistance is a threshold on s itself (sqrt is monotone and correctly
+    //     rounded): the comparison needs no square root.
+    if (wave == 0) {
+      int anchor = 0;
+      float ax = m > 0 ? px_sorted[0] : 0.f, ay = m > 0 ? py_sorted[0] : 0.f;
+      for (int j0 = 0; j0 < m; j0 += 64) {  // a window of 64 points in the lanes; several jumps may fall into it
+        const int j = j0 + lane;
+        const bool have = j < m;
+        const float px = have ? px_sorted[j] : 0.f, py = have ? py_sorted[j] : 0.f;
+        const bool live = have && dead[j] == 0;
+        int from = 0;  // lanes below `from` are settled
+        unsigned short mine = 0;
+        for (;;) {
+          const float dx = px - ax, dy = py - ay;
+          const float s2 = dx * dx + dy * dy;
+          const bool jump = live && lane >= from && s2 >= squared_jump;
+          const unsigned long long jumps = __builtin_amdgcn_ballot_w64(jump);
+          const int first_jump = jumps != 0ull ? __builtin_ctzll(jumps) : 64;
+          if (lane >= from && lane < first_jump) mine = static_cast<unsigned short>(anchor);
+          if (first_jump == 64) break;
+          if (lane == first_jump) mine = 0xFFFFu;
+          anchor = j0 + first_jump;
+          ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), first_jump));
+          ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), first_jump));
+          from = first_jump + 1;
+        }
+        if (have) anchor_of[j] = mine;
+      }
+    }
+    __syncthreads();
+    // (c) every point against its last_point, all threads; contributions keep the order of the points
+    {
+      const float cx = sh_centroid[0], cy = sh_centroid[1];
+      unsigned running = 0u;
+      for (int j0 = 0; j0 < m; j0 += kThreads) {
+        const int j = j0 + static_cast<int>(threadIdx.x);
+        bool emit = false;
+        float value = 0.f;
+        int bucket = 0;
+        if (j < m && dead[j] == 0 && anchor_of[j] != 0xFFFFu) {
+          const int a = anchor_of[j];
+          const float px = px_sorted[j], py = py_sorted[j];
+          const float dx = px - px_sorted[a], dy = py - py_sorted[a];
+          const float distance = norm2(dx, dy);
+          if (!(distance < kMinDistance)) {
+            const float ex = px - cx, ey = py - cy;
+            const float direction_norm = norm2(ex, ey);
+            const float dot = (dx / distance) * (ex / direction_norm) + (dy / distance) * (ey / direction_norm);
+            bucket = bucket_of(fd_atan2f(dy, dx), histogram_size);
+            value = fmaxf(0.f, 1.f - fabsf(dot));
+            emit = true;
+          }
+        }
+        unsigned round_total;
+        const unsigned rank = block_exclusive_scan(emit ? 1u : 0u, wave_sums, &round_total);
+        if (emit) {
+          cb[running + rank] = static_cast<unsigned char>(bucket);
+          cv[running + rank] = value;
+        }
+        running += round_total;
+      }
+      if (threadIdx.x == 0) sh_written = running;
+    }
+    __syncthreads();
+    DLIOM_STAMP(6);
+    if (threadIdx.x == 0 && blockIdx.x < 64) {
+#ifdef DLIOM_EXPERIMENTS
+      dbg_stamps[blockIdx.x * 16 + 10] = static_cast<unsigned long long>(count);
+      dbg_stamps[blockIdx.x * 16 + 11] = static_cast<unsigned long long>(m);
+      dbg_stamps[blockIdx.x * 16 + 12] = static_cast<unsigned long long>(sh_written);
+#endif
+    }
+    // ---- stable partition of the slice's contributions by bucket into its region of c_value: kernel 3 then finds the
+    //      values of (slice, bucket) contiguous and in order.  Wave w counts / writes buckets w, w + 16, ...
+    {  // the slice's list goes to its region of the contribution arrays (entries it does not use keep bucket 255)
+      const int E = static_cast<int>(sh_written);
+      for (int e = threadIdx.x; e < E; e += kThreads) {
+        c_bucket[begin + e] = cb[e];
+        c_value[begin + e] = cv[e];
+      }
+    }
+    DLIOM_STAMP(7);
+  }
+}
+
+// ---- kernel 3: the additions, in the reference's order ------------------------------------------------------------
+// The slices' contribution lists lie in slice order in ONE array (a slice's list starts where its points start; entries
+// it did not use keep the bucket 255 the array was filled with): the order of the additions is the order of the array.
+// One wave per bucket: (1) scan the bucket bytes, 1024 entries per step, and queue the positions of its own entries in
+// order (wave prefix sums); (2) fetch their values, every lane busy; (3) one thread adds them one after the other.
+constexpr int kAccCap = 8192;
+__global__ __launch_bounds__(64) void accumulate_kernel(const unsigned char* __restrict__ c_bucket,
+                                                        const float* __restrict__ c_value, int n_padded, int histogram_size,
+                                                        float* __restrict__ histogram) {
+  __shared__ __attribute__((aligned(16))) float queue[kAccCap + 64];  // positions (as bits), then the values in place
+  const int bucket = blockIdx.x, lane = threadIdx.x;
+  if (bucket >= histogram_size) return;
+  float sum = 0.f;
+  unsigned queued = 0u;
+  const unsigned want = static_cast<unsigned>(bucket) * 0x01010101u;
+#ifdef DLIOM_EXPERIMENTS
+#define DLIOM_ASTAMP(k) if (lane == 0 && bucket < 128) dbg_acc[bucket * 8 + (k)] = __builtin_readcyclecounter()
+#else
+#define DLIOM_ASTAMP(k)
+#endif
+  DLIOM_ASTAMP(0);
+  auto drain = [&]() {
+    DLIOM_ASTAMP(1);
+#ifdef DLIOM_EXPERIMENTS
+    if (lane == 0 && bucket < 128) dbg_acc[bucket * 8 + 5] = queued;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned e0 = 0; e0 < queued; e0 += 64 * 16) {  // sixteen gathers in flight per lane
+      float got[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const unsigned e = e0 + 64u * u + lane;
+        got[u] = e < queued ? c_value[__float_as_uint(queue[e])] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const unsigned e = e0 + 64u * u + lane;
+        if (e < queued) queue[e] = got[u];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    DLIOM_ASTAMP(2);
+    if (lane == 0) sum = thread_sequential_sum(queue, static_cast<int>(queued), sum);
+    __builtin_amdgcn_wave_barrier();
+    DLIOM_ASTAMP(3);
+    queued = 0u;
+  };
+  const uint4* b16 = reinterpret_cast<const uint4*>(c_bucket);
+  const int steps = n_padded / 1024;
+  constexpr int kAhead = 8;  // bucket bytes of eight steps in flight: one memory latency per 8192 entries
+  for (int s0 = 0; s0 < steps; s0 += kAhead) {
+    uint4 ahead[kAhead];
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a)
+      ahead[a] = s0 + a < steps ? b16[(s0 + a) * 64 + lane] : make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) {
+      const int s = s0 + a;
+      const uint4 w = ahead[a];  // entries s * 1024 + 16 * lane + (0 .. 15); past the end: bucket 255
+      const unsigned ws[4] = {w.x ^ want, w.y ^ want, w.z ^ want, w.w ^ want};
+      unsigned bits = 0u;
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (((ws[t >> 2] >> ((t & 3) * 8)) & 0xffu) == 0u) bits |= 1u << t;
+      if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0ull) continue;  // nothing of this bucket in these 1024 entries
+      // entries are ordered (lane, position in lane): a lane's first slot = the matches of all lower lanes = the sum
+      // over the 16 positions of "lower lanes whose bit t is set" -- ballots and mbcnt pairs, no cross-lane data movement
+      unsigned before = 0u, step_total = 0u;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const unsigned long long mt = __builtin_amdgcn_ballot_w64((bits >> t) & 1u);
+        before = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mt >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mt), before));
+        step_total += static_cast<unsigned>(__builtin_popcountll(mt));
+      }
+      if (queued + step_total > kAccCap) drain();
+      const unsigned slot = queued + before;
+#pragma unroll
+      for (int t = 0; t < 16; ++t)  // straight-line: a per-lane loop over the set bits cost 250 cycles per iteration
+        if ((bits >> t) & 1u)
+          queue[slot + __builtin_popcount(bits & ((1u << t) - 1u))] = __uint_as_float(static_cast<unsigned>(s) * 1024u + 16u * lane + t);
+      queued += step_total;
+    }
+  }
+  drain();
+  if (lane == 0) histogram[bucket] = sum;
+}
+
+}  // namespace rothist
+}  // namespace dliom
+
+using namespace dliom;
+
+#ifdef DLIOM_EXPERIMENTS
+extern "C" int dliom_exp_rothist_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rothist::dbg_stamps), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : -2;
+}
+#endif
+
+#ifdef DLIOM_EXPERIMENTS
+extern "C" int dliom_exp_rothist_acc_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rothist::dbg_acc), sizeof(unsigned long long) * 128 * 8) == hipSuccess ? 0 : -2;
+}
+#endif
+
+extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
+                                                int histogram_size, float* histogram) {
+  using namespace rothist;
+  if (ctx == nullptr || cloud == nullptr || histogram == nullptr || histogram_size <= 0 || histogram_size > 255)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const int n = static_cast<int>(cloud->n);
+  if (n == 0) {
+    for (int i = 0; i < histogram_size; ++i) histogram[i] = 0.f;
+    return DLIOM_OK;
+  }
+  if (cloud->n > (int64_t{1} << 26)) return DLIOM_ERR_CAPACITY;
+  // scratch: [rx | ry | rz | c_value] floats, [keys] shorts (padded to 512), [c_bucket] bytes (padded to 1024),
+  // [bin_counts | flags], [histogram]
+  const size_t N = static_cast<size_t>(n);
+  const size_t n_padded = (N + 1023) & ~static_cast<size_t>(1023);
+  const size_t f_bytes = n_padded * 4;
+  const size_t k_bytes = n_padded * 2;
+  const size_t b_bytes = n_padded;
+  const size_t counts_bytes = (kBins + 64) * 4;
+  const size_t hist_bytes = 1024;
+  DLIOM_TRY(ctx->misc.reserve(4 * f_bytes + k_bytes + b_bytes + counts_bytes + hist_bytes));
+  char* base = static_cast<char*>(ctx->misc.p);
+  float* rx = reinterpret_cast<float*>(base);
+  float* ry = reinterpret_cast<float*>(base + f_bytes);
+  float* rz = reinterpret_cast<float*>(base + 2 * f_bytes);
+  float* c_value = reinterpret_cast<float*>(base + 3 * f_bytes);
+  short* keys = reinterpret_cast<short*>(base + 4 * f_bytes);
+  unsigned char* c_bucket = reinterpret_cast<unsigned char*>(base + 4 * f_bytes + k_bytes);
+  unsigned* bin_counts = reinterpret_cast<unsigned*>(base + 4 * f_bytes + k_bytes + b_bytes);
+  unsigned* flags = bin_counts + kBins;
+  float* d_hist = reinterpret_cast<float*>(base + 4 * f_bytes + k_bytes + b_bytes + counts_bytes);
+  {
+    const FillJob fills[2] = {{bin_counts, counts_bytes, 0u}, {c_bucket, b_bytes, 0xFFFFFFFFu}};  // bucket 255 = no entry
+    DLIOM_TRY(fill_multi(ctx, fills, 2));
+  }
+  Quat4 q{1.f, 0.f, 0.f, 0.f};
+  if (rotation_wxyz != nullptr) q = Quat4{rotation_wxyz[0], rotation_wxyz[1], rotation_wxyz[2], rotation_wxyz[3]};
+  const unsigned blocks = static_cast<unsigned>((N + kThreads - 1) / kThreads);
+  hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, cloud->d_x, cloud->d_y, cloud->d_z, n, q,
+                     rotation_wxyz != nullptr ? 1 : 0, rx, ry, rz, keys, bin_counts, flags);
+  const size_t lds = static_cast<size_t>(kMaxSlice) * (8 + 12) + 1024;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+    attr_set = true;
+  }
+  // the smallest float s with fl(sqrt(s)) > kMaxDistance: `distance > kMaxDistance` as a comparison of squared lengths
+  static const float squared_jump = [] {
+    float s2 = kMaxDistance * kMaxDistance;
+    while (std::sqrt(s2) > kMaxDistance) s2 = std::nextafter(s2, 0.f);
+    while (!(std::sqrt(s2) > kMaxDistance)) s2 = std::nextafter(s2, 2.f);
+    return s2;
+  }();
+  hipLaunchKernelGGL(slice_kernel, dim3(256), dim3(kThreads), lds, ctx->stream, rx, ry, rz, keys, n, bin_counts, histogram_size,
+                     squared_jump, c_bucket, c_value, flags);
+  hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64), 0, ctx->stream, c_bucket, c_value,
+                     static_cast<int>(n_padded), histogram_size, d_hist);
+  DLIOM_HIP_TRY(hipGetLastError());
+  // one read-back: [histogram | flags] through pinned memory
+  float* h = reinterpret_cast<float*>(static_cast<char*>(ctx->pinned) + 2048);
+  const GatherJob back[2] = {{d_hist, static_cast<unsigned>(histogram_size)}, {flags, 1}};
+  DLIOM_TRY(gather_to_pinned(ctx, back, 2, h));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  unsigned f;
+  std::memcpy(&f, h + histogram_size, 4);
+  if (f != 0u) return DLIOM_ERR_CAPACITY;  // |z| >= 409.6 m or a slice of more than 4096 points: use dliom_rotational_histogram
+  std::memcpy(histogram, h, static_cast<size_t>(histogram_size) * 4);
+  return DLIOM_OK;
+}

@@ -278,6 +278,7 @@ SYMBOLS = [
     ("dliom_imu_integrator_predict", C.c_int, [_vp, _f64p, _f64p, _f64p]),
     ("dliom_rotational_histogram", C.c_int, [_f32p, C.c_int64, C.c_int, _f32p]),
     ("dliom_rotational_histogram_mt", C.c_int, [_f32p, C.c_int64, C.c_int, C.c_int, _f32p]),
+    ("dliom_cloud_rotational_histogram", C.c_int, [_vp, _vp, _f32p, C.c_int, _f32p]),
     ("dliom_rotational_scan_match", C.c_int, [_f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
@@ -1216,6 +1217,16 @@ class FastCorrelativeScanMatcher3D:
                                                               C.c_float(min_score), C.byref(r)),
                "dliom_fast_csm_match_with_3dof_initial")
         return self._result(r)
+
+
+def cloud_rotational_histogram(ctx, cloud, histogram_size, rotation_wxyz=None):
+    """RotationalScanMatcher::ComputeHistogram on the device (dliom_cloud_rotational_histogram) of a device cloud,
+    optionally rotated by a float quaternion first (the gravity alignment)."""
+    out = np.zeros(histogram_size, dtype=np.float32)
+    rot = None if rotation_wxyz is None else _p(_f32(rotation_wxyz), _f32p)
+    _check(load_library().dliom_cloud_rotational_histogram(ctx.h, cloud.h, rot, int(histogram_size), _p(out, _f32p)),
+           "dliom_cloud_rotational_histogram")
+    return out
 
 
 def rotational_histogram(points, histogram_size, threads=None):

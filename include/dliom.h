@@ -505,6 +505,14 @@ int dliom_fast_csm_level(const dliom_fast_csm* matcher, int depth, int32_t lo[3]
  * are processed on up to 8 host threads (same bits at any thread count; DLIOM_HISTOGRAM_THREADS=1 keeps the call on
  * the caller's thread). */
 int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram);
+/* The same on the device, on a cloud that is already in HBM (the filtered cloud of the front end), fused with the
+ * gravity alignment of local_trajectory_builder_3d.cc:605-610: histogram of Rigid3f::Rotation(rotation_wxyz) * point
+ * (rotation_wxyz == NULL: the points as they are).  Bit-identical to the host function (additions in the reference's
+ * order; atan2f is glibc 2.35's float algorithm) unless two DISTINCT points of one 0.2 m slice have bit-identical
+ * angles around the slice's centroid (the reference's std::sort leaves their order unspecified).  histogram_size <= 255.
+ * DLIOM_ERR_CAPACITY: |z| >= 409.6 m or more than 4096 points in one slice -- use the host function. */
+int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
+                                     int histogram_size, float* histogram);
 /* The same with an explicit number of host threads (0 = as many as pay, at most 8; the bits do not depend on it). */
 int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n, int histogram_size, int num_threads, float* histogram);
 /* RotationalScanMatcher(histograms_at_angles).Match(histogram, initial_angle, angles)

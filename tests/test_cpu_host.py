@@ -294,6 +294,19 @@ def test_gravity_factor_jacobian_is_the_derivative_its_definition_implies():
         assert np.allclose(H, num, atol=1e-8), (H, num)
 
 
+def test_device_atan2f_restatement_equals_this_machines_libm(tmp_path):
+    """The device histogram evaluates glibc 2.35's float atan2f (fdlibm) operation by operation; tests/cpp/atan2f_pin.c
+    holds the same restatement in C and compares it with libm's atan2f on 3 million inputs (ordinary, tiny-x and
+    near-axis): zero mismatches, or the bit-exactness claim of dliom_cloud_rotational_histogram does not hold here."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "atan2f_pin")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(root, "tests", "cpp", "atan2f_pin.c"), "-lm"])
+    out = subprocess.run([exe, "3000000"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "mismatches: 0 of 3000000" in out.stdout, out.stdout
+
+
 def test_rotational_scan_match_equals_oracle(orc):
     """RotationalScanMatcher ctor + Match (histogram rotation, normalised dot product with Eigen's
     packet reduction order) -- host code on both sides, bit-identical scores."""

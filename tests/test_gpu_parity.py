@@ -1217,3 +1217,60 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
     fe.close()
     acc_dev.close()
     del ctypes
+
+
+@pytest.mark.parametrize("case", ["random", "scan", "scan_rotated", "small", "duplicates"])
+def test_device_rotational_histogram_equals_oracle(dl, ctx, orc, case):
+    """dliom_cloud_rotational_histogram (three kernels, additions in the reference's order, glibc's atan2f restated)
+    against the oracle's ComputeHistogram (rotational_scan_matcher.cc:159-170), bit for bit: a random cloud, the
+    0.15 m-filtered 64 x 1024 scan LocalTrajectoryBuilder3D hands it (46 k points), the same rotated by a gravity
+    alignment on the device, a cloud smaller than one slice's minimum, and a cloud full of duplicated points."""
+    from dliom import synth
+    rng = np.random.RandomState(5)
+    rot = None
+    if case == "random":
+        a = rng.uniform(0, 2 * np.pi, 20000)
+        r = rng.uniform(3, 25, 20000)
+        pts = np.stack([r * np.cos(a), r * np.sin(a), rng.uniform(-4, 6, 20000)], axis=1).astype(np.float32)
+    elif case in ("scan", "scan_rotated"):
+        pose = synth.trajectory_pose(0.7)
+        raw, _ = synth.scan(pose, 64, 1024)
+        pts = raw[orc.voxel_filter(0.15, raw)]
+        assert len(pts) > 30000
+        if case == "scan_rotated":
+            rot = synth.perturb_pose(np.array([0, 0, 0, 1, 0, 0, 0], float), 0.0, 3.0, seed=2)[3:].astype(np.float32)
+    elif case == "small":
+        pts = np.array([[1, 0, 0], [1.3, 0.1, 0.05], [0, 2, 0.02], [-1, -1, 0.3]], dtype=np.float32)
+    else:
+        base = rng.uniform(-10, 10, (3000, 3)).astype(np.float32)
+        pts = np.concatenate([base, base[:1500], base[::3]]).astype(np.float32)
+    cloud = dl.PointCloud(ctx, pts)
+    got = dl.cloud_rotational_histogram(ctx, cloud, 120, rotation_wxyz=rot)
+    aligned = pts if rot is None else orc.transform_points(np.concatenate([np.zeros(3, np.float32), rot]), pts)
+    want = orc.compute_histogram(aligned, 120)
+    assert np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).view(np.uint32)), \
+        (case, np.abs(got - want).max(), int((got != want).sum()))
+    assert np.array_equal(got, dl.rotational_histogram(aligned, 120))  # and the host entry point
+    if case == "scan":
+        for size in (1, 37, 255):
+            assert np.array_equal(dl.cloud_rotational_histogram(ctx, cloud, size), np.asarray(orc.compute_histogram(pts, size), np.float32))
+    cloud.close()
+
+
+def test_device_rotational_histogram_limits(dl, ctx):
+    high = np.array([[1, 0, 500.0], [2, 0, 0]], dtype=np.float32)  # |z| >= 409.6 m
+    c = dl.PointCloud(ctx, high)
+    with pytest.raises(dl.DliomError) as e:
+        dl.cloud_rotational_histogram(ctx, c, 120)
+    assert e.value.status == dl.ERR_CAPACITY
+    c.close()
+    rng = np.random.RandomState(1)
+    flat = np.concatenate([rng.uniform(-20, 20, (5000, 2)), np.full((5000, 1), 0.03)], axis=1).astype(np.float32)  # one slice, 5000 points
+    c = dl.PointCloud(ctx, flat)
+    with pytest.raises(dl.DliomError) as e:
+        dl.cloud_rotational_histogram(ctx, c, 120)
+    assert e.value.status == dl.ERR_CAPACITY
+    c.close()
+    empty = dl.PointCloud(ctx, np.zeros((0, 3), np.float32))
+    assert np.array_equal(dl.cloud_rotational_histogram(ctx, empty, 16), np.zeros(16, np.float32))
+    empty.close()
