@@ -339,7 +339,7 @@ def main():
         if config5_line is not None:
             out["sharded_config5"] = config5_line
         if world == 1 and not args.no_wref:
-            out["wref"] = wref_line(dl, ctx)
+            out["wref"] = wref_line(dl, ctx, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             # the oracle leg: checker first (one more step, compared end to end), then the CPU baseline
             parity = parity_check(dl, ctx, scans[1 % len(scans)], g_hi, g_lo, ins, rt, cs)
@@ -463,12 +463,15 @@ def roofline_block(args, pairs, k_ms, launches, alg_bytes, score_kernel):
     }
 
 
-def wref_line(dl, ctx):
-    """The reference-faithful workload (voxel filter -> adaptive filters -> RTCSM3D -> Ceres -> insert on
-    N ~ 170 / 210 points), device only: tools/wref.py's chain, labelled; not the headline metric."""
+def wref_line(dl, ctx, cpu):
+    """What the reference does with a 64 x 1024 scan, complete (tools/wref_full.py): AddImuData, AddRangeData (voxel
+    filters + de-skew), adaptive filters + [RTCSM3D] + Ceres, WindowOptimize, insertion, ComputeHistogram -- with
+    trajectory_builder_3d.lua's options and with dlio/config/basic_config_3d.lua's (what D-LIOM ships: RTCSM3D off, 0.3 /
+    0.2 / 60 m, gravity factor on); each with the same stream on the CPU oracle and the pose difference between the legs."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import wref
-    return wref.device_line(dl, ctx, scans=28, warmup=4)
+    import wref_full
+    return {name: wref_full.line(dl, ctx, name, scans=24, warmup=4, cpu_scans=6, cpu=cpu)
+            for name in ("trajectory_builder_3d", "basic_config_3d")}
 
 
 def parity_check(dl, ctx, sc, g_hi, g_lo, ins, rt, cs):
