@@ -471,7 +471,14 @@ class RangeDataSynchronizer {
   }
 
  private:
-  static double Seconds(int64_t ticks) { return static_cast<double>(ticks) * 1e-7; }
+  // common::ToSecondsStamp (common/time.cc:48-56), operation by operation: universal-time ticks (100 ns since 0001-01-01)
+  // minus the Unix epoch, in nanoseconds as an integer, times 1e-9.  (ticks * 1e-7 on raw ~6.3e17 ticks would round
+  // to 12.8 us; this resolves ~0.25 us like the reference and picks the same overlap indices.)
+  static double Seconds(int64_t ticks) {
+    constexpr int64_t kUtsEpochOffsetFromUnixEpochInSeconds = 719162ll * 24ll * 60ll * 60ll;  // common/time.h:29-30
+    const int64_t ns_since_unix_epoch = (ticks - kUtsEpochOffsetFromUnixEpochInSeconds * 10000000ll) * 100ll;
+    return static_cast<double>(ns_since_unix_epoch) * 1e-9;
+  }
   static void ToOriginData(const sensor::TimedPointCloudData& c, sensor::TimedPointCloudOriginData* out) {
     out->time = c.time;
     out->origins.assign(1, c.origin);

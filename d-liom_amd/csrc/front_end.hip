@@ -127,8 +127,11 @@ struct dliom_front_end {
       // (272 MB at 10 cm / +-25.6 m); the leaf pool stays for the back end
       if (submaps.front()->hi != nullptr) submaps.front()->hi->drop_dense();
       // ... and the slack of its leaf pools (sized for the worst case while the submap was active)
-      if (submaps.front()->hi != nullptr) DLIOM_TRY(submaps.front()->hi->shrink_to_fit());
-      if (submaps.front()->lo != nullptr) DLIOM_TRY(submaps.front()->lo->shrink_to_fit());
+      // best effort: the scan IS inserted and the counters have moved; a failed reallocation only means the finished
+      // submap keeps its slack (an error here would leave the caller with a rolled-back MotionFilter and a submap that
+      // never rolls over)
+      if (submaps.front()->hi != nullptr) (void)submaps.front()->hi->shrink_to_fit();
+      if (submaps.front()->lo != nullptr) (void)submaps.front()->lo->shrink_to_fit();
       ++matching_submap_index;
       retired.push_back(std::move(submaps.front()));
       submaps.erase(submaps.begin());

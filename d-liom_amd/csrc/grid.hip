@@ -591,14 +591,27 @@ int dliom_grid::shrink_to_fit() {
   if (d_pool == nullptr || want >= capacity) return DLIOM_OK;
   uint16_t* new_pool = nullptr;
   int32_t* new_coord = nullptr;
-  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&new_pool), static_cast<size_t>(want) * 1024));
-  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&new_coord), static_cast<size_t>(want) * 12));
-  DLIOM_HIP_TRY(hipMemsetAsync(new_pool, 0, static_cast<size_t>(want) * 1024, ctx->stream));
-  DLIOM_HIP_TRY(hipMemcpyAsync(new_pool, d_pool, static_cast<size_t>(count) * 1024, hipMemcpyDeviceToDevice, ctx->stream));
-  DLIOM_HIP_TRY(hipMemcpyAsync(new_coord, d_slot_coord, static_cast<size_t>(count) * 12, hipMemcpyDeviceToDevice, ctx->stream));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  DLIOM_HIP_TRY(hipFree(d_pool));
-  DLIOM_HIP_TRY(hipFree(d_slot_coord));
+  // every failure below leaves the grid exactly as it was (old pool, old capacity) and frees what was allocated
+  if (hipMalloc(reinterpret_cast<void**>(&new_pool), static_cast<size_t>(want) * 1024) != hipSuccess) {
+    (void)hipGetLastError();
+    return DLIOM_ERR_HIP;
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&new_coord), static_cast<size_t>(want) * 12) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(new_pool);
+    return DLIOM_ERR_HIP;
+  }
+  const bool ok = hipMemsetAsync(new_pool, 0, static_cast<size_t>(want) * 1024, ctx->stream) == hipSuccess &&
+                  hipMemcpyAsync(new_pool, d_pool, static_cast<size_t>(count) * 1024, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                  hipMemcpyAsync(new_coord, d_slot_coord, static_cast<size_t>(count) * 12, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                  hipStreamSynchronize(ctx->stream) == hipSuccess;
+  if (!ok) {
+    (void)hipFree(new_pool);
+    (void)hipFree(new_coord);
+    return DLIOM_ERR_HIP;
+  }
+  (void)hipFree(d_pool);
+  (void)hipFree(d_slot_coord);
   d_pool = new_pool;
   d_slot_coord = new_coord;
   capacity = want;

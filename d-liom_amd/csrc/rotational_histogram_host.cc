@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <map>
 #include <thread>
+
+#include <sched.h>
 #include <vector>
 
 #include "../../include/dliom.h"
@@ -190,7 +192,15 @@ extern "C" int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n,
     return DLIOM_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < histogram_size; ++i) histogram[i] = 0.f;
   if (n == 0) return DLIOM_OK;
-  const unsigned hw = std::thread::hardware_concurrency();
+  unsigned hw = std::thread::hardware_concurrency();
+  {  // hardware_concurrency() ignores cgroup / affinity limits; spinning barriers must not be oversubscribed
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+      const int allowed = CPU_COUNT(&set);
+      if (allowed > 0) hw = std::min<unsigned>(hw == 0 ? static_cast<unsigned>(allowed) : hw, static_cast<unsigned>(allowed));
+    }
+  }
   const int T = static_cast<int>(std::max<int64_t>(
       1, std::min<int64_t>(n, forced_threads > 0 ? std::min(forced_threads, 64) : (n < 8192 ? 1 : std::min<unsigned>(hw == 0 ? 1 : hw, 8u)))));
   std::vector<int> key(static_cast<size_t>(n));
@@ -201,7 +211,7 @@ extern "C" int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n,
   std::vector<std::vector<Contribution>> contributions;
   int kmin = 0;
   int64_t span = 0;
-  bool sparse = false;
+  bool sparse = false, out_of_memory = false;
   SpinBarrier barrier(T);
   std::atomic<int64_t> next(0);
   auto work = [&](int t) {
@@ -226,10 +236,15 @@ extern "C" int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n,
       span = static_cast<int64_t>(gmax) - gmin + 1;
       sparse = span > 4 * n + 1024;  // absurdly spread heights: the map-based walk below
       if (!sparse) {
-        for (int u = 0; u < T; ++u) offset[static_cast<size_t>(u)].assign(static_cast<size_t>(span), 0);
-        slice_begin.assign(static_cast<size_t>(span) + 1, 0);
-        flat.resize(static_cast<size_t>(n));
-        contributions.resize(static_cast<size_t>(span));
+        try {
+          for (int u = 0; u < T; ++u) offset[static_cast<size_t>(u)].assign(static_cast<size_t>(span), 0);
+          slice_begin.assign(static_cast<size_t>(span) + 1, 0);
+          flat.resize(static_cast<size_t>(n));
+          contributions.resize(static_cast<size_t>(span));
+        } catch (...) {  // out of memory: every worker leaves at the next barrier, the call reports it
+          out_of_memory = true;
+          sparse = true;
+        }
       }
     }
     barrier.wait();
@@ -264,11 +279,30 @@ extern "C" int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n,
   if (T == 1) {
     work(0);
   } else {
+    // all T workers meet at barriers sized for T: they are started only if every one of them can be (a failed
+    // std::thread construction would otherwise leave the started ones spinning for a partner that never comes)
     std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+    std::atomic<int> go(0);  // 0 wait, 1 run, -1 give up
+    auto gated = [&](int t) {
+      while (go.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+      if (go.load(std::memory_order_acquire) > 0) work(t);
+    };
+    bool all_started = true;
+    try {
+      for (int t = 1; t < T; ++t) pool.emplace_back(gated, t);
+    } catch (...) {
+      all_started = false;
+    }
+    if (!all_started) {
+      go.store(-1, std::memory_order_release);
+      for (std::thread& th : pool) th.join();
+      return dliom_rotational_histogram_mt(points_xyz, n, histogram_size, 1, histogram);  // the single-thread path
+    }
+    go.store(1, std::memory_order_release);
     work(0);
     for (std::thread& th : pool) th.join();
   }
+  if (out_of_memory) return DLIOM_ERR_CAPACITY;
   if (sparse) {
     std::map<int, std::vector<P3>> slices;
     for (int64_t i = 0; i < n; ++i)

@@ -460,8 +460,8 @@ def _reference_synchronizer(calls, prior="lidar_a"):
     reference's double / float mix): returns per call (time, num_origins, [(origin_index, x, y, z, t), ...])."""
     secondary, out = [], []
 
-    def seconds(ticks):
-        return float(ticks) * 1e-7
+    def seconds(ticks):  # common::ToSecondsStamp (common/time.cc:48-56)
+        return float((int(ticks) - 719162 * 24 * 60 * 60 * 10000000) * 100) * 1e-9
 
     for sid, time, descrew, origin, ranges in calls:
         ranges = np.array(ranges, dtype=np.float32).reshape(-1, 4)
@@ -520,15 +520,18 @@ def test_cpp_range_data_synchronizer_on_the_cpu(tmp_path):
         return [tuple(rng.uniform(-20, 20, 3).astype(np.float32)) + (t,) for t in ts]
 
     T = 10_000_000  # ticks per second
+    # universal-time ticks of a real stamp (2026-09-26: ~6.39e17): double(ticks) resolves 12.8 us there, the reference's
+    # ToSecondsStamp ~0.25 us -- the merged overlap must be picked with the latter
+    E = (719162 * 24 * 60 * 60 + 1790000000) * T
     calls = [
-        ("lidar_a", 1 * T, 0, (0.0, 0.0, 0.0), cloud(6, -0.1, 0.0)),             # no secondary cloud yet: pass-through
-        ("lidar_b", int(1.95 * T), 0, (0.5, 0.0, 0.2), cloud(9, -0.1, 0.0)),     # ends at 1.95 s, covers [1.85, 1.95]
-        ("lidar_b", int(2.03 * T), 0, (0.5, 0.0, 0.2), cloud(8, -0.1, 0.0)),     # covers [1.93, 2.03]
-        ("lidar_a", 2 * T, 0, (0.0, 0.0, 0.0), cloud(7, -0.1, 0.0)),             # [1.9, 2.0]: merges part of the 1.95 s cloud
-        ("lidar_a", int(2.1 * T), 0, (0.0, 0.0, 0.0), cloud(5, -0.1, 0.0)),      # [2.0, 2.1]: 1.95 s cloud is stale; 2.03 s merges
-        ("lidar_b", int(3.5 * T), 0, (0.5, 0.0, 0.2), cloud(4, -0.1, 0.0)),      # far in the future
-        ("lidar_a", 3 * T, 0, (0.0, 0.0, 0.0), cloud(5, -0.1, 0.0)),             # "secondary lidar too fast": prior only
-        ("lidar_a", int(3.55 * T), 1, (0.0, 0.0, 0.0), cloud(6, -0.05, 0.0)),    # descrew: stamped -0.1 .. 0; merges the 3.5 s cloud
+        ("lidar_a", E + 1 * T, 0, (0.0, 0.0, 0.0), cloud(6, -0.1, 0.0)),             # no secondary cloud yet: pass-through
+        ("lidar_b", E + int(1.95 * T), 0, (0.5, 0.0, 0.2), cloud(9, -0.1, 0.0)),     # ends at 1.95 s, covers [1.85, 1.95]
+        ("lidar_b", E + int(2.03 * T), 0, (0.5, 0.0, 0.2), cloud(8, -0.1, 0.0)),     # covers [1.93, 2.03]
+        ("lidar_a", E + 2 * T, 0, (0.0, 0.0, 0.0), cloud(7, -0.1, 0.0)),             # [1.9, 2.0]: merges part of the 1.95 s cloud
+        ("lidar_a", E + int(2.1 * T), 0, (0.0, 0.0, 0.0), cloud(5, -0.1, 0.0)),      # [2.0, 2.1]: 1.95 s cloud is stale; 2.03 s merges
+        ("lidar_b", E + int(3.5 * T), 0, (0.5, 0.0, 0.2), cloud(4, -0.1, 0.0)),      # far in the future
+        ("lidar_a", E + 3 * T, 0, (0.0, 0.0, 0.0), cloud(5, -0.1, 0.0)),             # "secondary lidar too fast": prior only
+        ("lidar_a", E + int(3.55 * T), 1, (0.0, 0.0, 0.0), cloud(6, -0.05, 0.0)),    # descrew: stamped -0.1 .. 0; merges the 3.5 s cloud
     ]
     script = ""
     for sid, time, descrew, origin, ranges in calls:
