@@ -755,6 +755,122 @@ __global__ __launch_bounds__(kCsmBlock) void csm_lm_kernel(CsmArgs a, LmKernelPa
   }
 }
 
+// ---- the whole Levenberg-Marquardt loop in ONE launch for LARGE clouds: the same grid as csm_eval_kernel (every
+// workgroup resident), every thread of every workgroup runs the same minimize<> loop on the same numbers, and an
+// evaluation is csm_eval_kernel's accumulation + block reduction, a grid barrier, and csm_final_reduce_kernel's
+// reduction done by every workgroup for itself -- the same additions in the same order, hence the same bits as the
+// per-evaluation loop, without its launch + synchronise round trip per evaluation (ten of them per match: 0.29 ms per
+// 131 072-point match, of which the kernels were 0.17).  The partial sums alternate between two buffers, so one barrier
+// per evaluation is enough.  Barrier: agent-scope release / acquire on one counter (MI355X_MICROARCH.md, "Inter-workgroup
+// visibility"), every spin bounded.
+struct GridSync {
+  unsigned* counter;   // zeroed by the host before the launch
+  unsigned target;     // arrivals expected so far
+  bool timed_out;
+};
+__device__ __forceinline__ void grid_barrier(GridSync& gs) {
+  __syncthreads();  // this workgroup's partial sums are written
+  gs.target += gridDim.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(gs.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(gs.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gs.target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 24)) break;  // ~seconds: a workgroup that never became resident; the match reports an error
+    }
+  }
+  __syncthreads();
+}
+
+template <int NLOC>
+struct DeviceGridEval {
+  const CsmArgs* a;
+  const LmKernelParams* prm;
+  double (*red)[kCsmBlock];  // [kAcc][kCsmBlock]
+  double* tot;               // [kAcc]
+  double* partials;          // 2 x gridDim.x x kAcc
+  GridSync gs;
+  int evaluations = 0;
+  __device__ int operator()(const double x[7], Normal* out) {
+    CsmPose pose;
+    for (int i = 0; i < 3; ++i) pose.t[i] = x[i];
+    for (int i = 0; i < 4; ++i) pose.q[i] = x[3 + i];
+    pose.nloc = NLOC;
+    plus_jacobian(x + 3, NLOC, pose.plus);
+    double acc[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) acc[k] = 0.;
+    const int stride = gridDim.x * blockDim.x;
+    for (int ci = 0; ci < a->num_clouds; ++ci) {
+      const CsmCloudArg& c = a->cloud[ci];
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < c.n; i += stride) {
+        double r, j[6];
+        csm_point(pose, c, i, prm->k_scale, prm->k_offset, prm->k_unknown, &r, j);
+        int idx = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+          for (int q = p; q < 6; ++q) acc[idx++] += j[p] * j[q];
+#pragma unroll
+        for (int p = 0; p < 6; ++p) acc[21 + p] += j[p] * r;
+        acc[27] += r * r;
+      }
+    }
+    __syncthreads();  // the previous evaluation's LDS values have been read by everyone
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* mine = partials + static_cast<size_t>(evaluations & 1) * gridDim.x * kAcc;
+    for (int k = wave; k < kAcc; k += kCsmBlock / 64) {  // csm_eval_kernel's block reduction
+      double v = (red[k][lane] + red[k][lane + 64]) + (red[k][lane + 128] + red[k][lane + 192]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) mine[blockIdx.x * kAcc + k] = v;
+    }
+    grid_barrier(gs);
+    for (int k = wave; k < kAcc; k += kCsmBlock / 64) {  // csm_final_reduce_kernel's reduction
+      double sk = 0.;
+      for (int b = lane; b < static_cast<int>(gridDim.x); b += 64) sk += mine[b * kAcc + k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sk += __shfl_xor(sk, off, 64);
+      if (lane == 0) tot[k] = sk;
+    }
+    __syncthreads();
+    double sums[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; ++k) sums[k] = tot[k];
+    finish_normal<NLOC>(sums, x, pose.plus, prm->translation_weight, prm->rotation_weight, prm->target_t, prm->init_q, out);
+    ++evaluations;
+    return DLIOM_OK;
+  }
+};
+
+template <int NLOC>
+__global__ __launch_bounds__(kCsmBlock) void csm_lm_grid_kernel(CsmArgs a, LmKernelParams prm, double* partials,
+                                                                unsigned* counter, LmKernelOut* out) {
+  __shared__ double red[kAcc][kCsmBlock];
+  __shared__ double tot[kAcc];
+  DeviceGridEval<NLOC> ev;
+  ev.a = &a;
+  ev.prm = &prm;
+  ev.red = red;
+  ev.tot = tot;
+  ev.partials = partials;
+  ev.gs = GridSync{counter, 0u, false};
+  double x[7];
+  for (int i = 0; i < 7; ++i) x[i] = prm.x0[i];
+  dliom_csm_summary sum;
+  const int status = minimize<NLOC>(ev, prm.cfg, x, &sum);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = 0; i < 7; ++i) out->x[i] = x[i];
+    out->summary = sum;
+    // every workgroup must have taken part in every barrier: the counter tells
+    const unsigned arrived = __hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    out->status = arrived >= ev.gs.target ? status : DLIOM_ERR_HIP;
+  }
+}
+
 static int setup_problem(dliom_ctx* ctx, const dliom_csm_options* o, const double target_t[3],
                          const double init7[7], int k, const dliom_cloud* const* clouds,
                          const dliom_grid* const* grids, CsmProblem* p) {
@@ -849,6 +965,44 @@ int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* o, const do
       hipLaunchKernelGGL(csm_lm_kernel<3>, dim3(1), dim3(kCsmBlock), 0, ctx->stream, p.args, prm, host);
     else
       hipLaunchKernelGGL(csm_lm_kernel<1>, dim3(1), dim3(kCsmBlock), 0, ctx->stream, p.args, prm, host);
+    ctx->end_span(span);
+    DLIOM_HIP_TRY(hipGetLastError());
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::memcpy(out7, host->x, sizeof(x));
+    *sum = host->summary;
+    return host->status;
+  }
+  static const int num_cus = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }();
+  // large clouds: the loop in one launch with grid barriers when every workgroup of the evaluation grid is resident at
+  // once (256 threads and 57 KB of LDS each: two per CU)
+  if (ctx->tuning[DLIOM_TUNE_CSM_GRID_SYNC] != 0 && p.num_blocks > 1 && p.num_blocks <= 2 * num_cus) {
+    LmKernelParams prm;
+    prm.cfg = cfg;
+    prm.translation_weight = o->translation_weight;
+    prm.rotation_weight = o->rotation_weight;
+    for (int i = 0; i < 3; ++i) prm.target_t[i] = p.target_t[i];
+    for (int i = 0; i < 4; ++i) prm.init_q[i] = p.init_q[i];
+    for (int i = 0; i < 7; ++i) prm.x0[i] = x[i];
+    const float kMin = 0.1f, kMax = 1.f - 0.1f;
+    prm.k_scale = (kMax - kMin) / 32766.f;
+    prm.k_offset = kMin - prm.k_scale;
+    prm.k_unknown = kMin;
+    const size_t part_bytes = (2 * static_cast<size_t>(p.num_blocks) * kAcc * sizeof(double) + 255) & ~static_cast<size_t>(255);
+    DLIOM_TRY(ctx->partials.reserve(part_bytes + 256));
+    double* partials = ctx->partials.as<double>();
+    unsigned* counter = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->partials.p) + part_bytes);
+    DLIOM_HIP_TRY(hipMemsetAsync(counter, 0, 4, ctx->stream));
+    LmKernelOut* host = reinterpret_cast<LmKernelOut*>(static_cast<char*>(ctx->pinned) + 1024);  // device-visible
+    const int span = ctx->begin_span(DLIOM_KERNEL_CSM_EVAL);
+    if (p.nloc == 3)
+      hipLaunchKernelGGL(csm_lm_grid_kernel<3>, dim3(p.num_blocks), dim3(kCsmBlock), 0, ctx->stream, p.args, prm, partials, counter, host);
+    else
+      hipLaunchKernelGGL(csm_lm_grid_kernel<1>, dim3(p.num_blocks), dim3(kCsmBlock), 0, ctx->stream, p.args, prm, partials, counter, host);
     ctx->end_span(span);
     DLIOM_HIP_TRY(hipGetLastError());
     DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -379,6 +379,35 @@ def test_csm3d_one_launch_equals_per_evaluation_loop(dl, ctx, orc, monkeypatch, 
     dg_lo.close()
 
 
+@pytest.mark.parametrize("n_hi,n_lo,yaw_only", [(3000, 2500, False), (40000, 40000, False), (65536, 65536, True), (1100, 900, False)])
+def test_csm3d_grid_barrier_loop_equals_per_evaluation_loop(dl, ctx, orc, n_hi, n_lo, yaw_only):
+    """Large clouds: the trust-region loop in ONE launch with grid barriers (csm_lm_grid_kernel) must give the bits of
+    the loop that launches csm_eval_kernel + csm_final_reduce_kernel per evaluation -- same grid, same strided
+    accumulation, same two reductions -- and the same summary."""
+    from dliom import synth
+    og_hi, pts, init, truth = _synthetic_case(orc, 64, 1024, resolution=0.1, max_range=40.0)
+    og_lo = build_oracle_submap(orc, 0.45, num_scans=6, beams=16, azimuths=256)
+    dg_hi, dg_lo = to_device_grid(dl, ctx, og_hi), to_device_grid(dl, ctx, og_lo)
+    rng = np.random.default_rng(n_hi + 3 * n_lo)
+    hi = pts[rng.choice(len(pts), min(n_hi, len(pts)), replace=False)]
+    lo = pts[rng.choice(len(pts), min(n_lo, len(pts)), replace=False)]
+    m = dl.CeresScanMatcher3D(ctx, dict(DEFAULT_CSM, only_optimize_yaw=yaw_only))
+    ctx.set_tuning(dl.TUNE_CSM_ONE_LAUNCH_MAX, 0)  # both runs take the large-cloud paths
+    try:
+        ctx.set_tuning(dl.TUNE_CSM_GRID_SYNC, 1)
+        pose_a, sum_a = m.Match(init[:3], init, [(hi, dg_hi), (lo, dg_lo)])
+        ctx.set_tuning(dl.TUNE_CSM_GRID_SYNC, 0)
+        pose_b, sum_b = m.Match(init[:3], init, [(hi, dg_hi), (lo, dg_lo)])
+    finally:
+        ctx.set_tuning(dl.TUNE_CSM_GRID_SYNC, 0)
+        ctx.set_tuning(dl.TUNE_CSM_ONE_LAUNCH_MAX, 4096)
+    assert np.array_equal(pose_a, pose_b), (pose_a, pose_b)
+    assert sum_a == sum_b, (sum_a, sum_b)
+    assert sum_a["num_iterations"] >= 2
+    dg_hi.close()
+    dg_lo.close()
+
+
 def test_csm3d_error_codes(dl, ctx, orc):
     og, dg = _kat_grids(dl, ctx, orc, 1.0)
     bad = dict(CSM_TEST_OPTS, occupied_space_weight=[1.0, 2.0])  # CHECK_EQ(weights, clouds)
