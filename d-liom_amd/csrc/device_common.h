@@ -61,8 +61,8 @@ __device__ __forceinline__ unsigned grid_value(const GridView& g, int ix, int iy
   const unsigned sy = static_cast<unsigned>(iy + g.half);
   const unsigned sz = static_cast<unsigned>(iz + g.half);
   const bool inside = (sx < g.grid_size) & (sy < g.grid_size) & (sz < g.grid_size);
-  const unsigned L = static_cast<unsigned>(g.leaves_per_axis);
-  const unsigned tidx = inside ? ((sz >> 3) * L + (sy >> 3)) * L + (sx >> 3) : 0u;
+  const size_t L = static_cast<size_t>(g.leaves_per_axis);
+  const size_t tidx = inside ? ((sz >> 3) * L + (sy >> 3)) * L + (sx >> 3) : 0u;  // 2^33 entries at bits = 8
   unsigned slot = g.table[tidx];
   slot = inside ? slot : 0u;
   const unsigned cell = ((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u);
@@ -82,7 +82,8 @@ __device__ __forceinline__ int cell_fast(float p, float inv_resolution, bool* ne
   return __float2int_rn(y);
 }
 
-// grid_value() with shift/or index math and 32-bit byte offsets (pool <= 4 GiB, table <= 4 GiB).
+// grid_value() with shift/or index math and 32-bit byte offsets (pool <= 4 GiB, table <= 4 GiB: bits <= 7; callers
+// send bits = 8 grids to grid_value()).
 __device__ __forceinline__ unsigned grid_value_fast(const GridView& g, int ix, int iy, int iz) {
   const unsigned sx = static_cast<unsigned>(ix + g.half);
   const unsigned sy = static_cast<unsigned>(iy + g.half);

@@ -18,16 +18,16 @@
 namespace dliom {
 
 constexpr uint32_t kSlotLocked = 0xFFFFFFFFu;
-constexpr int kMaxFlatBits = 7;  // (8<<7)^3 entries = 2^30 fits 32-bit index math
+constexpr int kMaxFlatBits = 8;  // DynamicGrid's own limit (hybrid_grid.h:389); (8<<8)^3 entries = 2^33: 64-bit index math
 constexpr int kMaxDenseBits = 4; // dense mirror: (64<<4 + 2)^3 * 2 B = 2.0 GiB
 
 __device__ __forceinline__ bool leaf_table_index(int ix, int iy, int iz, int half, unsigned gsize,
-                                                 unsigned L, unsigned* tidx, unsigned* cell) {
+                                                 unsigned L, size_t* tidx, unsigned* cell) {
   const unsigned sx = static_cast<unsigned>(ix + half);
   const unsigned sy = static_cast<unsigned>(iy + half);
   const unsigned sz = static_cast<unsigned>(iz + half);
   if (!((sx < gsize) & (sy < gsize) & (sz < gsize))) return false;
-  *tidx = ((sz >> 3) * L + (sy >> 3)) * L + (sx >> 3);
+  *tidx = (static_cast<size_t>(sz >> 3) * L + (sy >> 3)) * L + (sx >> 3);  // up to 2^33 entries at bits = 8
   *cell = ((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u);
   return true;
 }
@@ -38,7 +38,8 @@ __device__ __forceinline__ bool leaf_table_index(int ix, int iy, int iz, int hal
 __device__ __forceinline__ void ensure_leaf(uint32_t* table, int32_t* slot_coord, uint32_t* count,
                                             int ix, int iy, int iz, int half, unsigned gsize,
                                             unsigned L) {
-  unsigned tidx, cell;
+  size_t tidx;
+  unsigned cell;
   if (!leaf_table_index(ix, iy, iz, half, gsize, L, &tidx, &cell)) return;
   if (table[tidx] != 0u) return;
   if (atomicCAS(&table[tidx], 0u, kSlotLocked) == 0u) {
@@ -167,7 +168,8 @@ __global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ t
   const int hx = cell_of(a.returns[3 * i], a.resolution);
   const int hy = cell_of(a.returns[3 * i + 1], a.resolution);
   const int hz = cell_of(a.returns[3 * i + 2], a.resolution);
-  unsigned tidx, cell;
+  size_t tidx;
+  unsigned cell;
   if (MODE == 0 || MODE == 2) {
     if (leaf_table_index(hx, hy, hz, a.half, a.gsize, a.L, &tidx, &cell)) {
       const size_t vi = static_cast<size_t>(table[tidx]) * 512u + cell;
@@ -211,7 +213,7 @@ __global__ void rebuild_table_kernel(const int32_t* __restrict__ slot_coord, uin
   const unsigned lx = static_cast<unsigned>(slot_coord[3 * static_cast<size_t>(s)] + leaf_half);
   const unsigned ly = static_cast<unsigned>(slot_coord[3 * static_cast<size_t>(s) + 1] + leaf_half);
   const unsigned lz = static_cast<unsigned>(slot_coord[3 * static_cast<size_t>(s) + 2] + leaf_half);
-  table[(lz * L + ly) * L + lx] = s;
+  table[(static_cast<size_t>(lz) * L + ly) * L + lx] = s;
 }
 
 // Dense mirror (re)build: one workgroup per allocated leaf copies its 512 cells.
@@ -238,7 +240,8 @@ __global__ void upload_copy_kernel(const int32_t* __restrict__ origins,
                                    const uint16_t* __restrict__ values, const uint32_t* __restrict__ table,
                                    uint16_t* pool, int half, unsigned gsize, unsigned L) {
   const int64_t b = blockIdx.x;
-  unsigned tidx, cell;
+  size_t tidx;
+  unsigned cell;
   if (!leaf_table_index(origins[3 * b], origins[3 * b + 1], origins[3 * b + 2], half, gsize, L, &tidx,
                         &cell))
     return;
@@ -260,7 +263,8 @@ __global__ void set_values_kernel(const int32_t* __restrict__ cells, const uint1
                                   unsigned gsize, unsigned L) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  unsigned tidx, cell;
+  size_t tidx;
+  unsigned cell;
   if (!leaf_table_index(cells[3 * i], cells[3 * i + 1], cells[3 * i + 2], half, gsize, L, &tidx, &cell)) return;
   pool[static_cast<size_t>(table[tidx]) * 512u + cell] = values[i];
 }
@@ -412,7 +416,8 @@ __global__ void multi_insert_kernel(MultiInsertArgs a) {
     return;
   }
   if (!valid) return;
-  unsigned tidx, cell;
+  size_t tidx;
+  unsigned cell;
   if (PASS == 1) {
     ensure_leaf(tg.table, tg.slot_coord, tg.count, hx, hy, hz, tg.half, tg.gsize, tg.L);
     for (int position = first; position < num_samples; ++position) {

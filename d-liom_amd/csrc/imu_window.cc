@@ -843,6 +843,12 @@ bool estimate_gravity(dliom_imu_window& w, const State& prev, const Preint& runn
 
 }  // namespace
 
+#define DLIOM_TRY_STATUS(expr)       \
+  do {                               \
+    const int _s = (expr);           \
+    if (_s != DLIOM_OK) return _s;   \
+  } while (0)
+
 extern "C" {
 
 int dliom_gravity_estimate(int num_frames, const double* poses7, const double* delta_t, const double* delta_p,
@@ -950,6 +956,12 @@ int dliom_imu_window_add_imu(dliom_imu_window* w, const double acc[3], const dou
   if (!w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
   integrate(w->current, {acc[0], acc[1], acc[2]}, {gyr[0], gyr[1], gyr[2]}, dt, w->o.acc_noise, w->o.gyr_noise,
             w->o.integration_sigma);
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_add_imu_batch(dliom_imu_window* w, int n, const double* acc, const double* gyr, const double* dt) {
+  if (w == nullptr || n < 0 || (n > 0 && (acc == nullptr || gyr == nullptr || dt == nullptr))) return DLIOM_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < n; ++i) DLIOM_TRY_STATUS(dliom_imu_window_add_imu(w, acc + 3 * i, gyr + 3 * i, dt[i]));
   return DLIOM_OK;
 }
 

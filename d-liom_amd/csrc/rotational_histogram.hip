@@ -588,7 +588,6 @@ __global__ __launch_bounds__(64) void accumulate_kernel(const unsigned char* __r
   if (bucket >= histogram_size) return;
   float sum = 0.f;
   unsigned queued = 0u;
-  const unsigned want = static_cast<unsigned>(bucket) * 0x01010101u;
 #ifdef DLIOM_EXPERIMENTS
 #define DLIOM_ASTAMP(k) if (lane == 0 && bucket < 128) dbg_acc[bucket * 8 + (k)] = __builtin_readcyclecounter()
 #else
@@ -623,41 +622,34 @@ __global__ __launch_bounds__(64) void accumulate_kernel(const unsigned char* __r
     DLIOM_ASTAMP(3);
     queued = 0u;
   };
-  const uint4* b16 = reinterpret_cast<const uint4*>(c_bucket);
+  // 1024 entries per step as 16 rows of 64: lane l of row t looks at entry s * 1024 + t * 64 + l, so a row's matches are
+  // neighbours in the array AND in the queue (consecutive lanes -> consecutive LDS words).  With 16 consecutive entries
+  // per lane the queue writes of a hot bucket landed 16 words apart: 32-way bank conflicts, 5 us per step.
   const int steps = n_padded / 1024;
-  constexpr int kAhead = 8;  // bucket bytes of eight steps in flight: one memory latency per 8192 entries
-  for (int s0 = 0; s0 < steps; s0 += kAhead) {
-    uint4 ahead[kAhead];
+  const unsigned char want8 = static_cast<unsigned char>(bucket);
+  for (int s = 0; s < steps; ++s) {
+    unsigned char row[16];
 #pragma unroll
-    for (int a = 0; a < kAhead; ++a)
-      ahead[a] = s0 + a < steps ? b16[(s0 + a) * 64 + lane] : make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (int t = 0; t < 16; ++t) row[t] = c_bucket[s * 1024 + t * 64 + lane];
+    unsigned long long masks[16];
+    unsigned step_total = 0u;
 #pragma unroll
-    for (int a = 0; a < kAhead; ++a) {
-      const int s = s0 + a;
-      const uint4 w = ahead[a];  // entries s * 1024 + 16 * lane + (0 .. 15); past the end: bucket 255
-      const unsigned ws[4] = {w.x ^ want, w.y ^ want, w.z ^ want, w.w ^ want};
-      unsigned bits = 0u;
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-        if (((ws[t >> 2] >> ((t & 3) * 8)) & 0xffu) == 0u) bits |= 1u << t;
-      if (__builtin_amdgcn_ballot_w64(bits != 0u) == 0ull) continue;  // nothing of this bucket in these 1024 entries
-      // entries are ordered (lane, position in lane): a lane's first slot = the matches of all lower lanes = the sum
-      // over the 16 positions of "lower lanes whose bit t is set" -- ballots and mbcnt pairs, no cross-lane data movement
-      unsigned before = 0u, step_total = 0u;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const unsigned long long mt = __builtin_amdgcn_ballot_w64((bits >> t) & 1u);
-        before = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mt >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mt), before));
-        step_total += static_cast<unsigned>(__builtin_popcountll(mt));
-      }
-      if (queued + step_total > kAccCap) drain();
-      const unsigned slot = queued + before;
-#pragma unroll
-      for (int t = 0; t < 16; ++t)  // straight-line: a per-lane loop over the set bits cost 250 cycles per iteration
-        if ((bits >> t) & 1u)
-          queue[slot + __builtin_popcount(bits & ((1u << t) - 1u))] = __uint_as_float(static_cast<unsigned>(s) * 1024u + 16u * lane + t);
-      queued += step_total;
+    for (int t = 0; t < 16; ++t) {
+      masks[t] = __builtin_amdgcn_ballot_w64(row[t] == want8);
+      step_total += static_cast<unsigned>(__builtin_popcountll(masks[t]));
     }
+    if (step_total == 0u) continue;
+    if (queued + step_total > kAccCap) drain();
+    unsigned base = queued;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      if (row[t] == want8)
+        queue[base + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(masks[t] >> 32),
+                                               __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(masks[t]), 0u))] =
+            __uint_as_float(static_cast<unsigned>(s) * 1024u + 64u * t + lane);
+      base += static_cast<unsigned>(__builtin_popcountll(masks[t]));
+    }
+    queued += step_total;
   }
   drain();
   if (lane == 0) histogram[bucket] = sum;

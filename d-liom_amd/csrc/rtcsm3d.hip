@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include <dlfcn.h>
@@ -42,7 +43,8 @@ constexpr int kBlock = 256;
 // batches of independent gathers (PPT leaf-table loads, then PPT voxel loads).  The per-lane
 // integer sum is reduced across the wave with six DPP adds, combined across the block's four
 // waves in LDS, and leaves the block as ONE atomic per candidate per rotation.
-template <int PPT>
+// WIDE: 64-bit leaf-table indices, for DynamicGrid bits = 8 ((8 << 8)^3 = 2^33 table entries).
+template <int PPT, bool WIDE = false>
 __global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
     GridView g, const float* __restrict__ px, const float* __restrict__ py,
     const float* __restrict__ pz, const float4* __restrict__ rot, int R, int r_first, int r_last,
@@ -63,7 +65,8 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
   const int r_end = min(r_begin + rots_per_block, r_last);
   const int lane = threadIdx.x & 63;
   const float inv = g.inv_resolution;
-  const unsigned sentinel = 1u << (3 * g.log2_leaves);  // table[L^3] is always 0 (null leaf)
+  typedef typename std::conditional<WIDE, unsigned long long, unsigned>::type idx_t;
+  const idx_t sentinel = static_cast<idx_t>(1) << (3 * g.log2_leaves);  // table[L^3] is always 0 (null leaf)
   const unsigned lb = static_cast<unsigned>(g.log2_leaves);
   for (int r = r_begin; r < r_end; ++r) {
     for (int j = threadIdx.x; j < T; j += kBlock) block_sum[j] = 0u;
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
 #pragma unroll 1
     for (int j = 0; j < T; ++j) {
       const float tx = trans[3 * j], ty = trans[3 * j + 1], tz = trans[3 * j + 2];
-      unsigned tix[PPT], cel[PPT];
+      idx_t tix[PPT];
+      unsigned cel[PPT];
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const float cx = rx[k] + tx, cy = ry[k] + ty, cz = rz[k] + tz;
@@ -93,14 +97,14 @@ __global__ __launch_bounds__(kBlock) void rtcsm_score_kernel(
         const unsigned sy = static_cast<unsigned>(iy + g.half);
         const unsigned sz = static_cast<unsigned>(iz + g.half);
         const bool inside = (sx | sy | sz) < g.grid_size;  // grid_size is a power of two
-        const unsigned t = (((sz >> 3) << lb | (sy >> 3)) << lb) | (sx >> 3);
+        const idx_t t = (((static_cast<idx_t>(sz >> 3) << lb) | (sy >> 3)) << lb) | (sx >> 3);
         tix[k] = inside ? t : sentinel;
         cel[k] = ((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u);
       }
 #pragma unroll
       for (int k = 0; k < PPT; ++k) tix[k] = g.table[tix[k]];
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) cel[k] = g.pool[(tix[k] << 9) | cel[k]];
+      for (int k = 0; k < PPT; ++k) cel[k] = g.pool[(static_cast<size_t>(tix[k]) << 9) | cel[k]];
       unsigned a = 0;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) a += max(cel[k] & 0x7FFFu, 1u);
@@ -1430,6 +1434,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   }
   const GridView g = grid->view();
   DLIOM_TRY(ensure_morton(ctx, &cloud));
+  if (g.log2_leaves > 10 && mapping >= 1) mapping = 0;  // bits = 8: only the point-per-lane kernel has 64-bit table indices
   if (mapping == 3) {
     static const int box_min_pairs_log2 = env_int("DLIOM_BOX_MIN_LOG2", 24);  // small searches: launch-bound anyway
     const double pairs = static_cast<double>(C) * static_cast<double>(n);
@@ -1595,6 +1600,17 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   hipLaunchKernelGGL((rtcsm_score_kernel<PP>), grid_dim, block, lds, ctx->stream, g, cloud.d_xs,  \
                      cloud.d_ys, cloud.d_zs, d->rot, R, r_first, r_last, d->trans, T,             \
                      rots_per_block, *d_sums, debug_no_atomic)
+    if (g.log2_leaves > 10) {  // bits = 8: the leaf table has 2^33 entries
+      if (ppt >= 4)
+        hipLaunchKernelGGL((rtcsm_score_kernel<4, true>), dim3((n + 4 * kBlock - 1) / (4 * kBlock), rot_tiles), block, lds, ctx->stream,
+                           g, cloud.d_xs, cloud.d_ys, cloud.d_zs, d->rot, R, r_first, r_last, d->trans, T, rots_per_block, *d_sums,
+                           debug_no_atomic);
+      else
+        hipLaunchKernelGGL((rtcsm_score_kernel<1, true>), dim3((n + kBlock - 1) / kBlock, rot_tiles), block, lds, ctx->stream, g,
+                           cloud.d_xs, cloud.d_ys, cloud.d_zs, d->rot, R, r_first, r_last, d->trans, T, rots_per_block, *d_sums,
+                           debug_no_atomic);
+      processed = static_cast<int64_t>((n + (ppt >= 4 ? 4 : 1) * kBlock - 1) / ((ppt >= 4 ? 4 : 1) * kBlock)) * (ppt >= 4 ? 4 : 1) * kBlock;
+    } else
     switch (ppt) {
       case 16: DLIOM_LAUNCH_SCORE(16); break;
       case 8: DLIOM_LAUNCH_SCORE(8); break;

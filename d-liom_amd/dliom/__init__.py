@@ -266,6 +266,7 @@ SYMBOLS = [
     ("dliom_imu_window_add_pose", C.c_int, [_vp, _f64p, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_imu_window_state", C.c_int, [_vp, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_imu_window_size", C.c_int, [_vp]),
+    ("dliom_imu_window_add_imu_batch", C.c_int, [_vp, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_imu_window_gravity_estimate", C.c_int, [_vp, _f64p, C.POINTER(C.c_int), _i64p]),
     ("dliom_gravity_estimate", C.c_int, [C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, _f64p, C.POINTER(C.c_int)]),
     ("dliom_imu_integrator_create", C.c_int, [_f64p, _f64p, C.POINTER(ImuNoise), C.POINTER(_vp)]),
@@ -1312,6 +1313,13 @@ class ImuWindow:
     def add_imu(self, acc, gyr, dt):
         _check(self._L.dliom_imu_window_add_imu(self.h, _p(_f64(acc), _f64p), _p(_f64(gyr), _f64p), float(dt)),
                "dliom_imu_window_add_imu")
+
+    def add_imu_batch(self, acc, gyr, dt):
+        """n samples in one call (acc, gyr: n x 3; dt: scalar or n)."""
+        acc, gyr = _f64(acc).reshape(-1, 3), _f64(gyr).reshape(-1, 3)
+        dts = np.ascontiguousarray(np.broadcast_to(np.asarray(dt, dtype=np.float64), (len(acc),)))
+        _check(self._L.dliom_imu_window_add_imu_batch(self.h, len(acc), _p(acc, _f64p), _p(gyr, _f64p), _p(dts, _f64p)),
+               "dliom_imu_window_add_imu_batch")
 
     def predict(self):
         pose, vel = np.zeros(7), np.zeros(3)

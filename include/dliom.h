@@ -595,6 +595,8 @@ int dliom_imu_window_initialize(dliom_imu_window* window, const double pose7[7],
                                 const double bias6[6]);
 /* imu_integrator_opt_->integrateMeasurement(acc, gyr, dt) (:188-196) */
 int dliom_imu_window_add_imu(dliom_imu_window* window, const double acc[3], const double gyr[3], double dt);
+/* the same for n samples (acc, gyr: n x 3; dt: n) in one call: for callers that buffer the IMU between two scans */
+int dliom_imu_window_add_imu_batch(dliom_imu_window* window, int n, const double* acc, const double* gyr, const double* dt);
 /* imu_integrator_opt_->predict(prev_state_, prev_bias_) (:198-199) */
 int dliom_imu_window_predict(const dliom_imu_window* window, double pose7[7], double velocity[3]);
 /* Pose3GravityFactor on the state `states_back` keys before the newest (:819-831); direction = estimated gravity */

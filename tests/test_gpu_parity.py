@@ -522,6 +522,52 @@ def test_set_values_and_set_probability(dl, ctx, orc):
     dg.close()
 
 
+def test_hybrid_grid_at_bits_8(dl, ctx, orc):
+    """DynamicGrid's own limit (hybrid_grid.h:387-405, CHECK_LE(new_bits, 8): +-8192 cells, +-819 m at 10 cm): the device
+    grid follows it all the way (a 2^33-entry leaf table, 64-bit index arithmetic) -- set / get, growth from a normal
+    submap, the correlative matcher (point-per-lane kernel with wide indices), the Ceres evaluation, download; one
+    cell further is DLIOM_ERR_GRID_EXTENT like the reference's CHECK."""
+    og = build_oracle_submap(orc, 0.1, num_scans=3, beams=16, azimuths=128)
+    dg = to_device_grid(dl, ctx, og)
+    assert dg.bits == og.bits <= 4
+    far = np.array([[8000, -8100, 5], [-8192, 8191, -8192], [4097, 0, 0]], dtype=np.int32)
+    vals = np.array([200, 300, 400], dtype=np.uint16)
+    og.set_values(far, vals)
+    dg.set_values(far, vals)
+    assert og.bits == 8 and dg.bits == 8
+    assert dg.cells() == oracle_cells_dict(og)
+    probe = np.concatenate([far, [[0, 0, 0], [8191, 8191, 8191], [8192, 0, 0], [-8193, 1, 1]]]).astype(np.int32)
+    assert np.array_equal(dg.values(probe), og.values(probe))  # outside the extent reads 0 on both sides
+    with pytest.raises(dl.DliomError) as e:
+        dg.set_values(np.array([[8192, 0, 0]], dtype=np.int32), np.array([5], dtype=np.uint16))
+    assert e.value.status == dl.ERR_GRID_EXTENT
+    from dliom import synth
+    truth = synth.trajectory_pose(0.3)
+    pts, _ = synth.scan(truth, 16, 64)
+    init = synth.perturb_pose(truth, 0.1, 0.5, seed=2)
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    got = rt.score_volume(init, pts, dg)
+    want = orc.rtcsm3d_value_sums(DEFAULT_RTCSM, init, pts, og)
+    assert np.array_equal(got.astype(np.uint64), want)
+    score, pose = rt.Match(init, pts, dg)
+    ref = orc.rtcsm3d_match(DEFAULT_RTCSM, init, pts, og)
+    assert rt.last_stats().score_kernel == 0  # the wide point-per-lane kernel
+    assert np.float32(score) == np.float32(ref["score"]) and np.array_equal(pose, ref["pose"])
+    og_lo = build_oracle_submap(orc, 0.45, num_scans=3, beams=16, azimuths=128)
+    dg_lo = to_device_grid(dl, ctx, og_lo)
+    p2, summary = dl.CeresScanMatcher3D(ctx, DEFAULT_CSM).Match(init[:3], pose, [(pts, dg), (pts, dg_lo)])
+    r2 = orc.csm3d_match(DEFAULT_CSM, init[:3], ref["pose"], [(pts, og), (pts, og_lo)])
+    assert np.linalg.norm(p2[:3] - r2["pose"][:3]) <= 1e-6
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE)
+    world = synth.transform_points(truth, pts)
+    origin = truth[:3].astype(np.float32)
+    og.insert_tables(origin, world, ins.hit_table, ins.miss_table, FREE)
+    ins.Insert(origin, world, dg)
+    assert dg.bits == 8 and dg.cells() == oracle_cells_dict(og)
+    dg.close()
+    dg_lo.close()
+
+
 FRONT_END_OPTS = dict(
     high_resolution_adaptive_voxel_filter=dict(max_length=2.0, min_num_points=150, max_range=15.0),
     low_resolution_adaptive_voxel_filter=dict(max_length=4.0, min_num_points=200, max_range=60.0),

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -50,7 +50,7 @@ if "FETCH_SIZE" in summary:
     out["write_bytes_raw"] = summary.get("WRITE_SIZE", {"mean": 0.0})["mean"] * 1024.0
     out["hbm_bytes_per_launch"] = 2.0 * out["fetch_bytes_raw"] + out["write_bytes_raw"]
 json.dump(out, open(os.path.join(dst, "%s_pmc_score_kernel.json" % tag), "w"), indent=1)
-for name, o in (("bench_full.json", "%s_bench.json"), ("wref.json", "%s_wref.json"),
+for name, o in (("bench_full.json", "%s_bench.json"), ("wref_full.json", "%s_wref_full.json"), ("wref.json", "%s_wref.json"),
                 ("wref_stages.json", "%s_wref_stages.json"), ("stream.json", "%s_stream_config3.json"),
                 ("stream_gentle.json", "%s_stream_config3_gentle.json")):
     f = os.path.join(src, name)

@@ -5,12 +5,12 @@
 #   never combined with tracing (gpurun refuses that)
 # Copy the summaries you want judged into profiles/ afterwards (tools/collect_profiles.py).
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-wref"
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-wref --no-pmc"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 grep '^{' $OUT/trace.log > $OUT/bench_under_trace.json
@@ -18,14 +18,15 @@ i=0
 for P in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
          "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
          "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES"; do
-  timeout 300 rocprofv3 --pmc $P --kernel-include-regex "rtcsm_score" --output-format csv -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $P --kernel-include-regex "rtcsm_score_box" --output-format csv -d $OUT/pmc$i -o p -- $CMD > $OUT/pmc$i.log 2>&1
   echo "pmc pass $i rc=$?"
   i=$((i+1))
 done
 cd $R
 timeout 600 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
 echo "bench rc=$?"
-timeout 200 python tools/wref.py > $OUT/wref.json 2> $OUT/wref.err
+timeout 300 python tools/wref_full.py > $OUT/wref_full.json 2> $OUT/wref.err
+timeout 200 python tools/wref.py > $OUT/wref.json 2>> $OUT/wref.err
 timeout 100 python tools/wref.py --stages > $OUT/wref_stages.json 2>> $OUT/wref.err
 timeout 200 python tools/stream.py > $OUT/stream.json 2> $OUT/stream.err
 timeout 200 python tools/stream.py --gentle --imu-noise > $OUT/stream_gentle.json 2>> $OUT/stream.err
