@@ -126,6 +126,74 @@ __global__ void gather_sorted_kernel(const float* __restrict__ x, const float* _
   }
 }
 
+// Cost class of every chunk of kCostChunk Morton-adjacent points (the unit of work of the LDS-box score kernel,
+// score_box.h): the box a chunk needs grows with the extent of its points and, through the rotations of the search
+// window, with their range.  Chunks that straddle a jump of the Morton curve need several boxes and take up to five
+// times as long as a compact one; the kernel's dispenser hands chunks out in the order built here -- most expensive
+// first -- so that the last tickets of a launch are short ones.  Only an ORDER of independent work items: results
+// never depend on it.  One half-wave per chunk.
+__global__ void chunk_cost_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+                                  int64_t n, int chunks, unsigned char* __restrict__ cls) {
+  const int lane = threadIdx.x & 63, l = lane & 31;
+  const int chunk = 2 * static_cast<int>((static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6) + (lane >> 5);
+  const int64_t i = static_cast<int64_t>(chunk) * kCostChunk + l;
+  const bool have = chunk < chunks && i < n;
+  const float x = have ? xs[i] : 0.f, y = have ? ys[i] : 0.f, z = have ? zs[i] : 0.f;
+  float lo[3] = {have ? x : 3.0e38f, have ? y : 3.0e38f, have ? z : 3.0e38f};
+  float hi[3] = {have ? x : -3.0e38f, have ? y : -3.0e38f, have ? z : -3.0e38f};
+  float r = fabsf(x) + fabsf(y) + fabsf(z);
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], m));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], m));
+    }
+    r = fmaxf(r, __shfl_xor(r, m));
+  }
+  if (l == 0 && chunk < chunks) {
+    float v = 1.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v *= fmaxf(hi[a] - lo[a], 0.f) + 0.05f * r + 0.6f;
+    cls[chunk] = static_cast<unsigned char>(min(max(static_cast<int>(4.f * log2f(v)) + 24, 0), 63));
+  }
+}
+// order[k] = the chunk handed out k-th: classes descending, chunk index ascending within a class (a stable counting
+// sort, deterministic).  One workgroup of 256 threads, each owning a contiguous range of chunks.
+__global__ __launch_bounds__(256) void chunk_order_kernel(const unsigned char* __restrict__ cls, int chunks,
+                                                          unsigned* __restrict__ order) {
+  __shared__ unsigned short hist[64][256];
+  __shared__ unsigned base[64];
+  const int t = threadIdx.x;
+  for (int c = 0; c < 64; ++c) hist[c][t] = 0;
+  const int per = (chunks + 255) / 256, first = t * per, last = min(first + per, chunks);
+  for (int c = first; c < last; ++c) ++hist[cls[c]][t];
+  __syncthreads();
+  if (t < 64) {  // exclusive scan over the threads, per class
+    unsigned run = 0;
+    for (int k = 0; k < 256; ++k) {
+      const unsigned v = hist[t][k];
+      hist[t][k] = static_cast<unsigned short>(run);
+      run += v;
+    }
+    base[t] = run;
+  }
+  __syncthreads();
+  if (t == 0) {
+    unsigned run = 0;
+    for (int c = 63; c >= 0; --c) {
+      const unsigned v = base[c];
+      base[c] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  for (int c = first; c < last; ++c) {
+    const int k = cls[c];
+    order[base[k] + hist[k][t]++] = static_cast<unsigned>(c);
+  }
+}
+
 // Device layout of a cloud inside one allocation:
 //   [aos staging | x y z (input order) | xs ys zs (Morton order) | keys, idx (in/out) ]
 static size_t cloud_bytes(int64_t n) {
@@ -199,6 +267,7 @@ static int finish_cloud(dliom_ctx* ctx, const CloudLayout& l, int64_t n, dliom_c
   out->d_ys = l.ys;
   out->d_zs = l.zs;
   out->morton_ready = false;
+  out->d_chunk_order = nullptr;
   return DLIOM_OK;
 }
 
@@ -226,6 +295,15 @@ int ensure_morton(dliom_ctx* ctx, const dliom_cloud* cloud) {
                                                        ctx->stream));
       hipLaunchKernelGGL(gather_sorted_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, l.x, l.y, l.z,
                          l.idx_out, n, np, l.xs, l.ys, l.zs);
+      // the sort's key buffers are free again: chunk classes in keys_out, the chunk order in keys_in
+      const int chunks = static_cast<int>((n + kCostChunk - 1) / kCostChunk);
+      if (chunks <= 65535) {  // 16-bit counters in chunk_order_kernel (2 M points)
+        unsigned char* cls = reinterpret_cast<unsigned char*>(l.keys_out);
+        hipLaunchKernelGGL(chunk_cost_kernel, dim3((chunks + 7) / 8), dim3(256), 0, ctx->stream, l.xs, l.ys, l.zs, n, chunks, cls);
+        DLIOM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(chunk_order_kernel, dim3(1), dim3(256), 0, ctx->stream, cls, chunks, l.keys_in);
+        c->d_chunk_order = l.keys_in;
+      }
     }
     DLIOM_HIP_TRY(hipGetLastError());
   }

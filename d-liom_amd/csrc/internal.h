@@ -152,6 +152,7 @@ struct dliom_cloud {
   size_t base_bytes = 0;   // its size class (cloud allocations are pooled per device)
   int device = 0;
   bool morton_ready = false;  // d_xs/d_ys/d_zs are built on first use (ensure_morton)
+  unsigned* d_chunk_order = nullptr;  // chunks of kCostChunk Morton-ordered points, most expensive first (or null)
 };
 
 struct dliom_inserter {
@@ -163,6 +164,7 @@ struct dliom_inserter {
 
 namespace dliom {
 // Coordinate of the padding points of the Morton-ordered arrays: far outside any grid extent.
+constexpr int kCostChunk = 32;  // points per chunk of dliom_cloud::d_chunk_order (= the box score kernel's chunk)
 constexpr float kPadCoordinate = 1.0e7f;  // cell index ~1e7/res: no int overflow for res >= 0.005 m
 // host-pointer cloud staged in ctx->points (valid until the next staging call)
 int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud* out,

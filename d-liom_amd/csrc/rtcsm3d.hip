@@ -1348,6 +1348,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   p.passes = passes;
   p.n = n;
   p.chunk = std::min(kMaxChunk, std::max(4, chunk_pts & ~3));
+  p.order = p.chunk == kCostChunk ? cloud.d_chunk_order : nullptr;
   p.point_chunks = (n + p.chunk - 1) / p.chunk;
   const int rot_groups = (r_last - r_first + 63) / 64;
   p.rot_groups = rot_groups;
@@ -1358,6 +1359,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
 #ifdef DLIOM_EXPERIMENTS
   static const int box_debug = env_int("DLIOM_BOX_DEBUG", 0);
   p.debug = box_debug;
+  if (box_debug & 512) p.order = nullptr;
 #else
   p.debug = 0;
 #endif
@@ -1440,9 +1442,14 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
     const double pairs = static_cast<double>(C) * static_cast<double>(n);
     int s3 = DLIOM_ERR_CAPACITY;
     if (T >= 8 && pairs >= std::ldexp(1.0, box_min_pairs_log2)) {
-      DLIOM_TRY(ctx->box_error.reserve(256));
+#ifdef DLIOM_EXPERIMENTS
+      constexpr size_t kBoxErrorBytes = 256 + 4096 * 32;  // + per-workgroup time stamps (Params::debug & 256)
+#else
+      constexpr size_t kBoxErrorBytes = 256;
+#endif
+      DLIOM_TRY(ctx->box_error.reserve(kBoxErrorBytes));
       if (!ctx->box_error_zeroed) {
-        DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_error.p, 0, 256, ctx->stream));
+        DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_error.p, 0, kBoxErrorBytes, ctx->stream));
         ctx->box_error_zeroed = true;
       }
       s3 = launch_score_box(ctx, cloud, g, c, *d, r_first, r_last, *d_sums, ctx->box_error.as<unsigned>());
@@ -2203,6 +2210,28 @@ int dliom_rtcsm3d_box_error(dliom_ctx* ctx, uint32_t* flags) {
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   return DLIOM_OK;
 }
+
+#ifdef DLIOM_EXPERIMENTS
+// experiments builds only (not in dliom.h): the box kernel's work counters (Params::debug & 128), read and cleared
+extern "C" int dliom_exp_box_stats(dliom_ctx* ctx, uint32_t out[8]) {
+  if (ctx == nullptr || out == nullptr || ctx->box_error.p == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipMemcpyAsync(out, static_cast<char*>(ctx->box_error.p) + 32, 32, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipMemsetAsync(static_cast<char*>(ctx->box_error.p) + 32, 0, 32, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+#endif
+
+#ifdef DLIOM_EXPERIMENTS
+// per-workgroup stamps of the last box-kernel launch: (start, end) in 10 ns ticks, tickets processed, XCC id
+extern "C" int dliom_exp_box_stamps(dliom_ctx* ctx, uint64_t* out, int workgroups) {
+  if (ctx == nullptr || out == nullptr || ctx->box_error.p == nullptr || workgroups > 4096) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipMemcpyAsync(out, static_cast<char*>(ctx->box_error.p) + 256, static_cast<size_t>(workgroups) * 32,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+#endif
 
 int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats) {
   if (ctx == nullptr || stats == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;

@@ -51,7 +51,11 @@ namespace dliom {
 namespace box {
 
 constexpr int kTC = 27;        // translations per pass (register accumulators)
-constexpr int kWaves = 4;      // waves per workgroup at most: consecutive rotation groups, the same point chunks
+#if !defined(DLIOM_EXPERIMENTS) || !defined(DLIOM_BOX_MAX_WAVES)
+#undef DLIOM_BOX_MAX_WAVES
+#define DLIOM_BOX_MAX_WAVES 4
+#endif
+constexpr int kWaves = DLIOM_BOX_MAX_WAVES;  // waves per workgroup at most: consecutive rotation groups, the same point chunks
 constexpr int kMaxDim = 120;   // box cells per axis (scaled coordinates stay below 256)
 constexpr int kMaxChunk = 64;  // points per chunk at most (one per lane in the bounding-box pass)
 constexpr int kBuckets = 8192; // fraction buckets per axis of the band bitmap
@@ -68,8 +72,14 @@ constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4
 #endif
 #ifdef DLIOM_EXPERIMENTS
 #define DLIOM_BOX_DBG(p, bit) (((p).debug & (bit)) != 0)
+// work counters (Params::debug & 128): error[8 + k] += v by the lanes for which cond holds
+#define DLIOM_BOX_STAT(p, cond, k, v)                                                                \
+  do {                                                                                                \
+    if (((p).debug & 128) && (cond)) atomicAdd((p).error + 8 + (k), static_cast<unsigned>(v));        \
+  } while (0)
 #else
 #define DLIOM_BOX_DBG(p, bit) false
+#define DLIOM_BOX_STAT(p, cond, k, v) do { } while (0)
 #endif
 #ifndef DLIOM_BOX_PIPE
 #define DLIOM_BOX_PIPE 1
@@ -108,6 +118,7 @@ struct Params {
   const float4* rot;       // candidate rotations (w, x, y, z)
   const Group* group;      // one per workgroup's rotations (nw * 64 from r_first on)
   unsigned long long* sums;
+  const unsigned* order;   // ticket -> chunk (most expensive chunks first, core.hip chunk_order_kernel) or null: identity
   unsigned* counters;      // one chunk dispenser per unit = (pass, rotation block), zeroed by the host before the launch
   unsigned* error;         // [0] sticky: an exact cell more than one cell from the fast one (cannot happen);
                            // [1] the same, cleared by the host when it reruns the match with the dense kernel
@@ -120,7 +131,9 @@ struct Params {
   unsigned thr;            // unresolved  <=>  (bits(w) & 0xffff) <= thr
   int cells;               // LDS box capacity per workgroup (cells)
   int debug;               // -DDLIOM_EXPERIMENTS builds only (wrong sums): 1 skip the lists, 2 skip staging, 4 skip the
-                           // lookups, 8 no work at all, 16 unconditional flush atomics, 32 no flush, 64 no stealing
+                           // lookups, 8 no work at all, 16 unconditional flush atomics, 32 no flush, 64 no stealing,
+                           // 128 work counters in error[8..15] (dliom_exp_box_stats), 256 per-workgroup stamps, 512 chunks in index
+                           // order, 1024 next ticket drawn with the first box
 };
 
 typedef __attribute__((address_space(3))) const unsigned short lds_cu16;
@@ -207,6 +220,7 @@ __device__ __forceinline__ void resolve_l2(const GridView& g, const Params& p, c
                                            const float* __restrict__ px, const float* __restrict__ py,
                                            const float* __restrict__ pz, const Lists& ls, int base1, int n2, int rot0,
                                            int lane) {
+  DLIOM_BOX_STAT(p, lane == 0, 6, n2);  // level-2 entries
   for (int e0 = 0; e0 < n2; e0 += 64) {
     const int e = e0 + lane;
     if (e < n2) {
@@ -252,6 +266,8 @@ __device__ __forceinline__ void resolve_l1(const GridView& g, const Params& p, c
                                            const float* __restrict__ pz, const Lists& ls, int base1, int count, int rot0,
                                            int lane) {
   const bool have = lane < count;
+  DLIOM_BOX_STAT(p, lane == 0, 4, 1);      // level-1 rounds (one wave each)
+  DLIOM_BOX_STAT(p, lane == 0, 5, count);  // level-1 entries
   float wx = 200.5f, wy = 200.5f, wz = 200.5f;  // idle lanes: a fraction of one half is never listed
   if (have) {
     const unsigned ent = ls.l1[base1 + lane];
@@ -541,8 +557,16 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
   // there (its accumulators are flushed per unit).  A ticket is ONE chunk: with tickets of four chunks a unit's 512
   // tickets over 170 workgroups left all but two of them idle for the length of a fourth ticket -- a quarter of the
   // kernel (profiles/r2_pmc_score_kernel.json: 2.7 of 4 resident waves per SIMD on average; round 3, same box:
-  // 0.871 ms with tickets of four, 0.797 with 4-2-1, 0.767 with single chunks).  The next ticket is drawn while the
-  // current one is processed.  Control flow below is uniform over the WORKGROUP (barriers).
+  // 0.871 ms with tickets of four, 0.797 with 4-2-1, 0.767 with single chunks).  Tickets map to chunks through
+  // Params::order, most expensive chunks first (a chunk across a jump of the Morton curve takes several boxes and up to
+  // five times the time of a compact one: handed out last it WAS the end of the launch), and the next ticket is drawn
+  // late (below); same box, 20 launches each: 0.794 ms index order + early draw, 0.784 / 0.779 with one of the two,
+  // 0.770 with both.  Control flow below is uniform over the WORKGROUP (barriers).
+#ifdef DLIOM_EXPERIMENTS
+  unsigned long long stamp_begin = 0ull;
+  unsigned stamp_tickets = 0u;
+  if (DLIOM_BOX_DBG(p, 256)) stamp_begin = wall_clock64();
+#endif
   const int home = static_cast<int>(blockIdx.x % static_cast<unsigned>(p.units));
   const int slot = static_cast<int>(blockIdx.x / static_cast<unsigned>(p.units));
   int parity = 0;
@@ -552,13 +576,19 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     int unit = home + hop;
     if (unit >= p.units) unit -= p.units;
     unsigned* counter = p.counters + unit;
-    int ticket;
+    int ticket, chunk_id;
     if (hop == 0) {
       ticket = DLIOM_BOX_DBG(p, 8) ? p.point_chunks : slot;
+      chunk_id = (p.order != nullptr && ticket < p.point_chunks) ? static_cast<int>(p.order[ticket]) : ticket;
     } else {
-      if (threadIdx.x == 0) tick[parity] = atomicAdd(counter, 1u);
+      if (threadIdx.x == 0) {
+        const int t = p.slots + static_cast<int>(atomicAdd(counter, 1u));
+        tick[parity] = static_cast<unsigned>(t);
+        tick[2 + parity] = (p.order != nullptr && t < p.point_chunks) ? p.order[t] : static_cast<unsigned>(t);
+      }
       __syncthreads();
-      ticket = p.slots + static_cast<int>(tick[parity]);
+      ticket = static_cast<int>(tick[parity]);
+      chunk_id = static_cast<int>(tick[2 + parity]);
       parity ^= 1;
     }
     if (ticket >= p.point_chunks) continue;  // nothing left here
@@ -598,10 +628,18 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     int n_guess = p.chunk;  // points per box that fitted last time
     int since_flush = 0;    // points added to the accumulators since they were last cleared (uniform)
     while (ticket < p.point_chunks) {
-      unsigned next_raw = 0u;
-      if (threadIdx.x == 0) next_raw = atomicAdd(counter, 1u);  // in flight while this ticket is processed
+      // The next ticket is drawn when the LAST box of this one is about to be staged (the atomic returns during the
+      // staging, the order table's entry during the lookups): a ticket drawn at the start of the current one is a
+      // chunk nobody else can take for a whole ticket's time, and at the end of the launch that left workgroups
+      // idle for up to two tickets while others still held one in reserve (round 3: workgroups ended between 627
+      // and 788 us of a 788 us launch).
+      unsigned next_raw = 0u, next_chunk = 0u;
+      bool drawn = false;
+#ifdef DLIOM_EXPERIMENTS
+      ++stamp_tickets;
+#endif
       {
-        const int c = ticket;
+        const int c = chunk_id;
         const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
         int lo = c_begin;
         while (lo < c_end) {
@@ -660,6 +698,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
             }
             fits = fits && static_cast<long long>(geo.sxy) * geo.dim[2] <= p.cells && geo.sxy <= 32767u;
             fits_out = fits;
+            DLIOM_BOX_STAT(p, threadIdx.x == 0, 7, 1);  // bounding boxes computed
             if (fits) break;
             if (n == 1) break;
             n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
@@ -682,8 +721,16 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
                                      cell_of(rz + tr[2], g.resolution));
             }
             lo += 1;
+            DLIOM_BOX_STAT(p, threadIdx.x == 0, 3, 1);  // points on the exact path
             continue;
           }
+          if (!drawn && (lo + n >= c_end || DLIOM_BOX_DBG(p, 1024))) {  // uniform: the last box of the ticket
+            if (threadIdx.x == 0) next_raw = atomicAdd(counter, 1u);
+            drawn = true;
+          }
+          DLIOM_BOX_STAT(p, threadIdx.x == 0, 0, 1);                                   // boxes
+          DLIOM_BOX_STAT(p, threadIdx.x == 0, 1, (geo.dim[0] >> 2) * geo.dim[1] * geo.dim[2]);  // staged quads
+          DLIOM_BOX_STAT(p, threadIdx.x == 0, 2, n);                                   // points in boxes
           __syncthreads();  // every wave is done with the previous box
           // ---- stage the box, all threads: 4-cell groups (8 bytes) of the bricked mirror, outside reads 1
           if (!DLIOM_BOX_DBG(p, 2)) {
@@ -712,6 +759,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
           if (lane < 4) ls.rec[4 * rec_id + lane] = lane < 3 ? geo.lo[lane] : lo;
           ++ls.seq;
           __syncthreads();  // the box is complete
+          if (drawn && threadIdx.x == 0) {  // in flight during the lookups
+            const int t = p.slots + static_cast<int>(next_raw);
+            next_chunk = (p.order != nullptr && t < p.point_chunks) ? p.order[t] : static_cast<unsigned>(t);
+          }
           // ---- all lookups of these points under this wave's rotations
           if (wave_active && !DLIOM_BOX_DBG(p, 4)) {
             int i = lo;
@@ -733,10 +784,19 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
           lo += n;
         }
       }
-      // the next ticket, through LDS (two words used alternately: one barrier per ticket)
-      if (threadIdx.x == 0) tick[parity] = next_raw;
+      // the next ticket, through LDS (two sets of words used alternately: one barrier per ticket)
+      if (threadIdx.x == 0) {
+        if (!drawn) {  // the ticket ended on the exact path (no box): draw now
+          const int t = p.slots + static_cast<int>(atomicAdd(counter, 1u));
+          next_raw = static_cast<unsigned>(t - p.slots);
+          next_chunk = (p.order != nullptr && t < p.point_chunks) ? p.order[t] : static_cast<unsigned>(t);
+        }
+        tick[parity] = static_cast<unsigned>(p.slots) + next_raw;
+        tick[2 + parity] = next_chunk;
+      }
       __syncthreads();
-      ticket = p.slots + static_cast<int>(tick[parity]);
+      ticket = static_cast<int>(tick[parity]);
+      chunk_id = static_cast<int>(tick[2 + parity]);
       parity ^= 1;
     }
     // leaving the unit: the lists refer to its rotations and pass, the accumulators to its candidates
@@ -753,6 +813,17 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
       flush_acc(p, ps, acc, rot0 + lane, lane_active);
     }
   }
+#ifdef DLIOM_EXPERIMENTS
+  if (DLIOM_BOX_DBG(p, 256) && threadIdx.x == 0 && blockIdx.x < 4096u) {
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(p.error + 64) + 4 * blockIdx.x;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    st[0] = stamp_begin;
+    st[1] = wall_clock64();
+    st[2] = stamp_tickets;
+    st[3] = xcc;
+  }
+#endif
 }
 
 }  // namespace box

@@ -70,7 +70,7 @@ def main():
                 buf = (ctypes.c_uint32 * 8)()
                 fn_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
                 fn_stats(ctx.h, buf)
-                names = ("boxes", "staged_quads", "box_points", "exact_points", "l1_rounds", "l1_entries", "l2_entries", "l2_rounds")
+                names = ("boxes", "staged_quads", "box_points", "exact_points", "l1_rounds", "l1_entries", "l2_entries", "bbox_tries")
                 print("        stats/launch: " + ", ".join("%s %.0f" % (k, v / (a.reps + 1.0)) for k, v in zip(names, buf)))
         if name == "ceres":
             print("        evals=%d iterations=%d" % (r[1]["num_residual_evaluations"], r[1]["num_iterations"]))
