@@ -24,7 +24,6 @@
 #include <functional>
 #include <limits>
 #include <memory>
-#include <unordered_map>
 #include <vector>
 
 #include "device_common.h"
@@ -148,6 +147,164 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(ScoreArgs a, cons
   if (threadIdx.x == 0) atomicAdd(&sums[c], static_cast<int>(wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3]));
 }
 
+
+// ---- device frontier -----------------------------------------------------------------------------
+// BranchAndBound (:439-492) asks for the scores of the children of every node whose score beats the best leaf found
+// so far.  Served one sibling group per launch that is ~110 launches + synchronisations for a whole-submap window
+// on a filtered scan (150 points): 3 ms, all of it latency.  Instead ONE chain of launches, no host in between:
+//   1. the lowest-resolution candidates (host list) are scored;
+//   2. one workgroup walks the branch the recursion walks first -- best candidate, best child, ... down to a leaf --
+//      whose score theta is (up to ties and the low-resolution check) the bound the recursion prunes with from its
+//      first leaf on;
+//   3. level by level, the children of every node with score >= max(theta, min_score) are scored and appended to
+//      that level's list: a superset of everything the recursion can ask for once it holds a leaf of score theta,
+//      and (>=, upper bounds) of the branch it walks before;
+//   4. all lists are packed into pinned host memory; one synchronisation.
+// The host then replays the reference's recursion -- same comparisons, same std::sort calls -- out of a hash table;
+// anything missing (a first leaf refused by the low-resolution matcher, a list that hit its capacity) is fetched
+// on demand as before.  Exactness is untouched: scores are functions of exact integer sums.
+constexpr int kMaxLevels = 16;
+struct FrontierRec {
+  int scan, ox, oy, oz, sum;
+};
+struct FrontierArgs {
+  LevelView level[kMaxLevels];
+  const int *cx, *cy, *cz;  // [scan][point] full-resolution cells
+  int n;                    // points per scan
+  int max_depth, full_resolution_depth;
+  int linear_xy, linear_z;
+  FrontierRec* pool;        // (max_depth + 1) lists of `cap` records, list d at pool + d * cap
+  int* counts;              // [kMaxLevels] records per list, [kMaxLevels] overflow flag, [kMaxLevels + 1] theta bits
+  int cap;
+  float min_score;
+};
+
+__device__ __forceinline__ float frontier_probability(int sum, int n) {  // ScoreCandidates' float (:407-411)
+  const float kMin = 0.1f, kMax = 1.f - 0.1f;
+  return kMin + (static_cast<float>(sum) / static_cast<float>(n)) * ((kMax - kMin) / 255.f);
+}
+
+// Integer sum of one candidate at `depth`, by one wavefront (every lane returns it).
+__device__ __forceinline__ int frontier_wave_sum(const FrontierArgs& a, int depth, int scan, int ox, int oy, int oz, int lane) {
+  const int e = max(0, depth - a.full_resolution_depth + 1);
+  const int sx = -a.linear_xy, sz = -a.linear_z;
+  const int lsx = sx >> e, lsz = sz >> e;
+  const LevelView& lv = a.level[depth];
+  const size_t base = static_cast<size_t>(scan) * a.n;
+  const int cox = ox >> e, coy = oy >> e, coz = oz >> e;
+  unsigned sum = 0;
+  for (int p = lane; p < a.n; p += 64) {
+    int x = a.cx[base + p], y = a.cy[base + p], z = a.cz[base + p];
+    if (e > 0) {  // low-resolution cells (:285-301)
+      x = ((x + sx) >> e) - lsx;
+      y = ((y + sx) >> e) - lsx;
+      z = ((z + sz) >> e) - lsz;
+    }
+    sum += level_value(lv, x + cox, y + coy, z + coz);
+  }
+  return __builtin_amdgcn_readlane(static_cast<int>(wave_sum_lane63(sum)), 63);
+}
+
+// 1. sums of the uploaded lowest-resolution list (list max_depth), one wavefront per candidate
+__global__ __launch_bounds__(256) void frontier_top_kernel(FrontierArgs a, int count) {
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (w >= count) return;
+  FrontierRec* r = a.pool + static_cast<size_t>(a.max_depth) * a.cap + w;
+  const int sum = frontier_wave_sum(a, a.max_depth, r->scan, r->ox, r->oy, r->oz, lane);
+  if (lane == 0) r->sum = sum;
+}
+
+// 2. the branch the recursion walks first; writes theta
+__global__ __launch_bounds__(512) void frontier_greedy_kernel(FrontierArgs a, int top_count) {
+  __shared__ unsigned long long best_key[8];
+  __shared__ int child_sum[8];
+  __shared__ int cur[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const FrontierRec* top = a.pool + static_cast<size_t>(a.max_depth) * a.cap;
+  unsigned long long key = 0ull;
+  for (int i = threadIdx.x; i < top_count; i += blockDim.x)
+    key = max(key, (static_cast<unsigned long long>(static_cast<unsigned>(top[i].sum)) << 32) | static_cast<unsigned>(0x7FFFFFFF - i));
+  for (int m = 32; m >= 1; m >>= 1) key = max(key, __shfl_xor(key, m));
+  if (lane == 0) best_key[wave] = key;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long k = 0ull;
+    for (int w = 0; w < 8; ++w) k = max(k, best_key[w]);
+    const int i = 0x7FFFFFFF - static_cast<int>(k & 0xFFFFFFFFull);
+    cur[0] = top[i].scan;
+    cur[1] = top[i].ox;
+    cur[2] = top[i].oy;
+    cur[3] = top[i].oz;
+    child_sum[0] = static_cast<int>(k >> 32);
+  }
+  __syncthreads();
+  int sum = child_sum[0];
+  __syncthreads();
+  for (int depth = a.max_depth; depth >= 1; --depth) {
+    const int hw = 1 << (depth - 1);
+    const int scan = cur[0], ox = cur[1] + ((wave & 1) ? hw : 0), oy = cur[2] + ((wave & 2) ? hw : 0), oz = cur[3] + ((wave & 4) ? hw : 0);
+    const bool valid = ox <= a.linear_xy && oy <= a.linear_xy && oz <= a.linear_z;  // children_of (:468-484)
+    const int s = valid ? frontier_wave_sum(a, depth - 1, scan, ox, oy, oz, lane) : -1;
+    if (lane == 0) child_sum[wave] = s;
+    __syncthreads();
+    int bw = 0;
+    for (int w = 1; w < 8; ++w)
+      if (child_sum[w] > child_sum[bw]) bw = w;
+    sum = child_sum[bw];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      cur[1] += (bw & 1) ? hw : 0;
+      cur[2] += (bw & 2) ? hw : 0;
+      cur[3] += (bw & 4) ? hw : 0;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float theta = fmaxf(frontier_probability(sum, a.n), a.min_score);
+    a.counts[kMaxLevels + 1] = __float_as_int(theta);
+  }
+}
+
+// 3. list `depth` -> list depth - 1: the children of every node with score >= theta, one wavefront per child
+__global__ __launch_bounds__(256) void frontier_level_kernel(FrontierArgs a, int depth) {
+  const int lane = threadIdx.x & 63;
+  const int waves = (gridDim.x * blockDim.x) >> 6;
+  const int parents = min(a.counts[depth], a.cap);
+  const float theta = __int_as_float(a.counts[kMaxLevels + 1]);
+  const FrontierRec* src = a.pool + static_cast<size_t>(depth) * a.cap;
+  FrontierRec* dst = a.pool + static_cast<size_t>(depth - 1) * a.cap;
+  const int hw = 1 << (depth - 1);
+  for (int item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < 8 * parents; item += waves) {
+    const FrontierRec pr = src[item >> 3];
+    if (!(frontier_probability(pr.sum, a.n) >= theta)) continue;
+    const int c = item & 7;
+    const int ox = pr.ox + ((c & 1) ? hw : 0), oy = pr.oy + ((c & 2) ? hw : 0), oz = pr.oz + ((c & 4) ? hw : 0);
+    if (ox > a.linear_xy || oy > a.linear_xy || oz > a.linear_z) continue;
+    const int sum = frontier_wave_sum(a, depth - 1, pr.scan, ox, oy, oz, lane);
+    if (lane == 0) {
+      const int at = atomicAdd(&a.counts[depth - 1], 1);
+      if (at < a.cap)
+        dst[at] = FrontierRec{pr.scan, ox, oy, oz, sum};
+      else
+        a.counts[kMaxLevels] = 1;  // overflow: the host fetches what is missing on demand
+    }
+  }
+}
+
+// 4. [counts | overflow | theta | records of list max_depth, ..., 0] -> pinned host memory
+__global__ __launch_bounds__(256) void frontier_pack_kernel(FrontierArgs a, int* __restrict__ out, int out_records) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+  if (tid < kMaxLevels + 2) out[tid] = a.counts[tid];
+  int first = 0;
+  for (int depth = a.max_depth; depth >= 0; --depth) {
+    const int cnt = min(a.counts[depth], a.cap);
+    const int* src = reinterpret_cast<const int*>(a.pool + static_cast<size_t>(depth) * a.cap);
+    for (int i = tid; i < 5 * cnt; i += nthreads)
+      if (first + i / 5 < out_records) out[kMaxLevels + 2 + 5 * first + i] = src[i];
+    first += cnt;
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 // rotate_histogram / match_histograms live in rotational_histogram.cc (host-only, CPU-testable).
 using Histogram = std::vector<float>;
@@ -224,8 +381,56 @@ struct Search {
   const std::vector<Candidate>* top = nullptr;  // the sorted lowest-resolution candidates
   float initial_min_score = 0.f;
   float frontier_threshold = std::numeric_limits<float>::infinity();  // last wavefront prefetch ran with this
-  // score cache: (depth, scan, offset) -> integer sum
-  std::unordered_map<uint64_t, int> cache;
+  // score cache: (depth, scan, offset) -> integer sum.  Open addressing, linear probing (a match looks up and inserts
+  // ~1e4 keys: std::unordered_map's node allocations were a third of the host time of a whole-submap match)
+  struct ScoreCache {
+    static constexpr uint64_t kEmpty = ~0ull;
+    std::vector<uint64_t> keys;
+    std::vector<int> vals;
+    size_t used = 0;
+    ScoreCache() { rehash(1u << 12); }
+    static size_t mix(uint64_t k) {
+      k ^= k >> 33;
+      k *= 0xff51afd7ed558ccdull;
+      k ^= k >> 33;
+      return static_cast<size_t>(k);
+    }
+    void rehash(size_t cap) {
+      std::vector<uint64_t> ok;
+      std::vector<int> ov;
+      ok.swap(keys);
+      ov.swap(vals);
+      keys.assign(cap, kEmpty);
+      vals.assign(cap, 0);
+      used = 0;
+      for (size_t i = 0; i < ok.size(); ++i)
+        if (ok[i] != kEmpty) put(ok[i], ov[i]);
+    }
+    const int* get(uint64_t k) const {
+      const size_t mask = keys.size() - 1;
+      for (size_t i = mix(k) & mask;; i = (i + 1) & mask) {
+        if (keys[i] == k) return &vals[i];
+        if (keys[i] == kEmpty) return nullptr;
+      }
+    }
+    bool has(uint64_t k) const { return get(k) != nullptr; }
+    void put(uint64_t k, int v) {
+      if (2 * (used + 1) > keys.size()) rehash(2 * keys.size());
+      const size_t mask = keys.size() - 1;
+      for (size_t i = mix(k) & mask;; i = (i + 1) & mask) {
+        if (keys[i] == k) {
+          vals[i] = v;
+          return;
+        }
+        if (keys[i] == kEmpty) {
+          keys[i] = k;
+          vals[i] = v;
+          ++used;
+          return;
+        }
+      }
+    }
+  } cache;
   static uint64_t key(int depth, int scan, const int* o) {
     // offsets fit 14 bits + sign for any window the 8-bit grid extent allows; scans < 2^16
     return (static_cast<uint64_t>(depth & 0xF) << 60) | (static_cast<uint64_t>(scan & 0xFFFF) << 44) |
@@ -293,14 +498,14 @@ inline float to_probability(float value) {  // precomputation_grid_3d.h:31-34
 int score_candidates(Search& s, int depth, std::vector<Candidate>* candidates) {
   std::vector<Candidate> missing;
   for (const Candidate& c : *candidates)
-    if (s.cache.find(Search::key(depth, c.scan_index, c.offset)) == s.cache.end()) missing.push_back(c);
+    if (!s.cache.has(Search::key(depth, c.scan_index, c.offset))) missing.push_back(c);
   if (!missing.empty()) {
     std::vector<int> sums;
     DLIOM_TRY(device_sums(s, depth, missing, &sums));
-    for (size_t i = 0; i < missing.size(); ++i) s.cache[Search::key(depth, missing[i].scan_index, missing[i].offset)] = sums[i];
+    for (size_t i = 0; i < missing.size(); ++i) s.cache.put(Search::key(depth, missing[i].scan_index, missing[i].offset), sums[i]);
   }
   for (Candidate& c : *candidates) {
-    const int sum = s.cache[Search::key(depth, c.scan_index, c.offset)];
+    const int sum = *s.cache.get(Search::key(depth, c.scan_index, c.offset));
     c.score = to_probability(sum / static_cast<float>(s.n_hi));
   }
   std::sort(candidates->begin(), candidates->end(), std::greater<Candidate>());
@@ -336,12 +541,12 @@ int prefetch_children(Search& s, const std::vector<Candidate>& siblings, size_t 
     std::vector<Candidate> ch;
     children_of(s, siblings[i], candidate_depth, &ch);
     for (const Candidate& c : ch)
-      if (s.cache.find(Search::key(candidate_depth - 1, c.scan_index, c.offset)) == s.cache.end()) batch.push_back(c);
+      if (!s.cache.has(Search::key(candidate_depth - 1, c.scan_index, c.offset))) batch.push_back(c);
   }
   if (batch.empty()) return DLIOM_OK;
   std::vector<int> sums;
   DLIOM_TRY(device_sums(s, candidate_depth - 1, batch, &sums));
-  for (size_t i = 0; i < batch.size(); ++i) s.cache[Search::key(candidate_depth - 1, batch[i].scan_index, batch[i].offset)] = sums[i];
+  for (size_t i = 0; i < batch.size(); ++i) s.cache.put(Search::key(candidate_depth - 1, batch[i].scan_index, batch[i].offset), sums[i]);
   return DLIOM_OK;
 }
 
@@ -359,20 +564,91 @@ int prefetch_frontier(Search& s, float threshold) {
     if (children.size() > (1u << 18)) break;  // a flat score landscape: stay with on-demand batches
     std::vector<Candidate> missing;
     for (const Candidate& c : children)
-      if (s.cache.find(Search::key(depth - 1, c.scan_index, c.offset)) == s.cache.end()) missing.push_back(c);
+      if (!s.cache.has(Search::key(depth - 1, c.scan_index, c.offset))) missing.push_back(c);
     if (!missing.empty()) {
       std::vector<int> sums;
       DLIOM_TRY(device_sums(s, depth - 1, missing, &sums));
       for (size_t i = 0; i < missing.size(); ++i)
-        s.cache[Search::key(depth - 1, missing[i].scan_index, missing[i].offset)] = sums[i];
+        s.cache.put(Search::key(depth - 1, missing[i].scan_index, missing[i].offset), sums[i]);
     }
     frontier.clear();
     for (Candidate& c : children) {
-      c.score = to_probability(s.cache[Search::key(depth - 1, c.scan_index, c.offset)] / static_cast<float>(s.n_hi));
+      c.score = to_probability(*s.cache.get(Search::key(depth - 1, c.scan_index, c.offset)) / static_cast<float>(s.n_hi));
       if (c.score > threshold) frontier.push_back(c);
     }
   }
   s.frontier_threshold = threshold;
+  return DLIOM_OK;
+}
+
+// The device frontier (kernels above): one chain of launches and one synchronisation that puts the lowest-resolution
+// candidates and everything the recursion can reach below them into the cache.  Does nothing (DLIOM_OK) for searches
+// it is not made for; the recursion then fetches scores on demand.
+int device_frontier(Search& s, const std::vector<Candidate>& lowest, float min_score) {
+  const dliom_fast_csm* m = s.m;
+  dliom_ctx* ctx = s.ctx;
+  const int max_depth = m->max_depth();
+  constexpr int kCap = 8192;
+  constexpr size_t kHead = 256, kUpload = 256 * 1024;
+  const size_t k = lowest.size();
+  // one wavefront per candidate: made for the clouds the reference matches (adaptive voxel filter, ~150-200 points);
+  // with every return of a scan (65 536 points) the single workgroup of step 2 alone takes 7 ms -- those searches keep
+  // the on-demand batches, whose block-per-chunk scoring kernel fills the chip
+  constexpr int kMaxPoints = 8192;
+  if (k == 0 || k > static_cast<size_t>(kCap) || max_depth + 1 > kMaxLevels || max_depth < 1 || ctx->pinned_bytes < (1u << 20) ||
+      s.n_hi > kMaxPoints)
+    return DLIOM_OK;
+  const size_t pool_bytes = static_cast<size_t>(max_depth + 1) * kCap * sizeof(FrontierRec);
+  DLIOM_TRY(ctx->cand.reserve(kHead + pool_bytes));
+  int* d_counts = ctx->cand.as<int>();
+  FrontierRec* d_pool = reinterpret_cast<FrontierRec*>(static_cast<char*>(ctx->cand.p) + kHead);
+  int* h = static_cast<int*>(ctx->pinned);
+  std::memset(h, 0, kHead);
+  h[max_depth] = static_cast<int>(k);
+  FrontierRec* h_top = reinterpret_cast<FrontierRec*>(static_cast<char*>(ctx->pinned) + kHead);
+  for (size_t i = 0; i < k; ++i) h_top[i] = FrontierRec{lowest[i].scan_index, lowest[i].offset[0], lowest[i].offset[1], lowest[i].offset[2], 0};
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_counts, h, kHead, hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_pool + static_cast<size_t>(max_depth) * kCap, h_top, k * sizeof(FrontierRec), hipMemcpyHostToDevice,
+                               ctx->stream));
+  FrontierArgs a;
+  for (int d = 0; d < kMaxLevels; ++d) a.level[d] = d <= max_depth ? m->levels[d].view() : LevelView{nullptr, {0, 0, 0}, {0, 0, 0}};
+  a.cx = s.d_cx;
+  a.cy = s.d_cy;
+  a.cz = s.d_cz;
+  a.n = s.n_hi;
+  a.max_depth = max_depth;
+  a.full_resolution_depth = m->options.full_resolution_depth;
+  a.linear_xy = s.linear_xy;
+  a.linear_z = s.linear_z;
+  a.pool = d_pool;
+  a.counts = d_counts;
+  a.cap = kCap;
+  a.min_score = min_score;
+  hipLaunchKernelGGL(frontier_top_kernel, dim3(static_cast<unsigned>((k + 3) / 4)), dim3(256), 0, ctx->stream, a, static_cast<int>(k));
+  hipLaunchKernelGGL(frontier_greedy_kernel, dim3(1), dim3(512), 0, ctx->stream, a, static_cast<int>(k));
+  for (int depth = max_depth; depth >= 1; --depth)
+    hipLaunchKernelGGL(frontier_level_kernel, dim3(256), dim3(256), 0, ctx->stream, a, depth);
+  int* out = reinterpret_cast<int*>(static_cast<char*>(ctx->pinned) + kUpload);
+  const int out_records = static_cast<int>((ctx->pinned_bytes - kUpload - 8192 - (kMaxLevels + 2) * 4) / sizeof(FrontierRec));
+  hipLaunchKernelGGL(frontier_pack_kernel, dim3(64), dim3(256), 0, ctx->stream, a, out, out_records);
+  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const FrontierRec* rec = reinterpret_cast<const FrontierRec*>(out + kMaxLevels + 2);
+  int at = 0;
+  for (int depth = max_depth; depth >= 0 && at < out_records; --depth) {
+    const int cnt = std::min(std::min(out[depth], kCap), out_records - at);
+    for (int i = 0; i < cnt; ++i) {
+      const FrontierRec& r = rec[at + i];
+      const int o[3] = {r.ox, r.oy, r.oz};
+      s.cache.put(Search::key(depth, r.scan, o), r.sum);
+    }
+    at += cnt;
+  }
+  s.scored += at;
+  s.launches += max_depth + 3;
+  float theta;
+  std::memcpy(&theta, &out[kMaxLevels + 1], 4);
+  s.frontier_threshold = theta;
   return DLIOM_OK;
 }
 
@@ -419,12 +695,12 @@ Candidate branch_and_bound(Search& s, const std::vector<Candidate>& candidates, 
     if (c.score <= min_score) break;
     std::vector<Candidate> higher;
     children_of(s, c, candidate_depth, &higher);
-    if (!higher.empty() && s.cache.find(Search::key(candidate_depth - 1, higher[0].scan_index, higher[0].offset)) == s.cache.end()) {
+    if (!higher.empty() && !s.cache.has(Search::key(candidate_depth - 1, higher[0].scan_index, higher[0].offset))) {
       if (best.score > s.initial_min_score && best.score < s.frontier_threshold) {
         *status = prefetch_frontier(s, best.score);  // a match exists: everything still reachable, per level
         if (*status != DLIOM_OK) return unsuccessful;
       }
-      if (s.cache.find(Search::key(candidate_depth - 1, higher[0].scan_index, higher[0].offset)) == s.cache.end()) {
+      if (!s.cache.has(Search::key(candidate_depth - 1, higher[0].scan_index, higher[0].offset))) {
         *status = prefetch_children(s, candidates, i, candidate_depth, best.score);
         if (*status != DLIOM_OK) return unsuccessful;
       }
@@ -459,11 +735,20 @@ int run_search(Search& s, const dliom_cloud& hi_cloud, float min_score, dliom_fa
     const float v[7] = {p.t.x, p.t.y, p.t.z, p.q.w, p.q.x, p.q.y, p.q.z};
     std::memcpy(&poses[7 * i], v, sizeof(v));
   }
-  DLIOM_HIP_TRY(hipMemcpyAsync(d_poses, poses.data(), poses.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  // through the pinned block when they fit (its first 208 KB belong to device_frontier's upload): no synchronisation
+  // here, the stream orders the kernels behind the copy
+  constexpr size_t kPosesAt = 208 * 1024, kPosesMax = 48 * 1024;
+  const bool poses_pinned = poses.size() * 4 <= kPosesMax && ctx->pinned_bytes >= (1u << 20);
+  const float* poses_src = poses.data();
+  if (poses_pinned) {
+    std::memcpy(static_cast<char*>(ctx->pinned) + kPosesAt, poses.data(), poses.size() * 4);
+    poses_src = reinterpret_cast<const float*>(static_cast<char*>(ctx->pinned) + kPosesAt);
+  }
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_poses, poses_src, poses.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(discretize_kernel, dim3((s.n_hi + 255) / 256, num_scans), dim3(256), 0, ctx->stream, hi_cloud.d_x,
                      hi_cloud.d_y, hi_cloud.d_z, s.n_hi, d_poses, m->resolution, s.d_cx, s.d_cy, s.d_cz);
   DLIOM_HIP_TRY(hipGetLastError());
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `poses` dies at scope exit
+  if (!poses_pinned) DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // pageable source
 
   // lowest-resolution candidates (:358-392, 419-429)
   const int step = 1 << m->max_depth();
@@ -487,6 +772,7 @@ int run_search(Search& s, const dliom_cloud& hi_cloud, float min_score, dliom_fa
           c.offset[2] = z;
           lowest.push_back(c);
         }
+  DLIOM_TRY(device_frontier(s, lowest, min_score));
   DLIOM_TRY(score_candidates(s, m->max_depth(), &lowest));
   s.top = &lowest;
   s.initial_min_score = min_score;
