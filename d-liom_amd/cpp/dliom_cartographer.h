@@ -500,7 +500,8 @@ class RangeDataSynchronizer {
 // proto::LocalTrajectoryBuilderOptions3D: the front end's options plus the AddRangeData / IMU fields
 struct LocalTrajectoryBuilderOptions3D {
   dliom_front_end_options front_end;     // adaptive filters, matchers, motion filter, submaps
-  dliom_imu_window_options imu;          // imu block + WindowOptimize
+  dliom_imu_window_options imu;          // imu block + WindowOptimize; imu.graph_reset_every < 0: follow
+                                         // front_end.num_range_data like the reference (.cc:750), 0: never reset
   float min_range = 1.f, max_range = 100.f;
   int num_accumulated_range_data = 1;
   float voxel_filter_size = 0.15f;
@@ -631,7 +632,9 @@ class LocalTrajectoryBuilder3D {
                            const std::vector<std::string>& expected_range_sensor_ids)
       : context_(context), options_(options), active_submaps_(context, options.front_end),
         synchronizer_(expected_range_sensor_ids) {
-    Check(dliom_imu_window_create(&options.imu, &window_), "dliom_imu_window_create");
+    dliom_imu_window_options imu = options.imu;
+    if (imu.graph_reset_every < 0) imu.graph_reset_every = options.front_end.num_range_data >= 2 ? options.front_end.num_range_data : 0;
+    Check(dliom_imu_window_create(&imu, &window_), "dliom_imu_window_create");
     Check(dliom_range_accumulator_create(context->get(), &accumulator_), "dliom_range_accumulator_create");
   }
   ~LocalTrajectoryBuilder3D() {

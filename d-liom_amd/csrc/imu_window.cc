@@ -470,6 +470,7 @@ struct dliom_imu_window {
   Preint current;  // since the newest state
   bool initialized = false;
   int64_t num_states = 0;
+  int key = 0;  // key_ of the next state: 1 after initialisation, 1 again after a graph reset (:792)
 };
 
 namespace {
@@ -899,13 +900,14 @@ int dliom_imu_window_default_options(dliom_imu_window_options* o) {
   o->enable_gravity_factor = 0;                // trajectory_builder_3d.lua:31 (dlio/config/basic_config_3d.lua:80 sets true)
   o->frames_for_online_gravity_estimate = 7;   // :29
   o->lidar_in_imu_translation[0] = o->lidar_in_imu_translation[1] = o->lidar_in_imu_translation[2] = 0.0;
+  o->graph_reset_every = 0;
   return DLIOM_OK;
 }
 
 int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out) {
   if (options == nullptr || out == nullptr || options->window_size < 2 || options->window_size > 16 ||
       options->iterations < 1 || !(options->acc_noise > 0) || !(options->gyr_noise > 0) || !(options->acc_bias_noise > 0) ||
-      !(options->gyr_bias_noise > 0))
+      !(options->gyr_bias_noise > 0) || options->graph_reset_every < 0 || options->graph_reset_every == 1)
     return DLIOM_ERR_INVALID_ARGUMENT;
   // the gravity factor goes on the state frames_for_online_gravity_estimate keys back (:828): it has to be in the window
   if (options->enable_gravity_factor != 0 &&
@@ -948,6 +950,7 @@ int dliom_imu_window_initialize(dliom_imu_window* w, const double pose7[7], cons
   w->current.reset(s.ba, s.bg);
   w->initialized = true;
   w->num_states = 1;
+  w->key = 1;
   return DLIOM_OK;
 }
 
@@ -986,12 +989,88 @@ int dliom_imu_window_add_gravity(dliom_imu_window* w, int states_back, const dou
   return DLIOM_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// "reset graph for speed" (:749-792): when key_ reaches num_range_data the reference throws its graph away and starts a
+// new one at the newest state, whose priors are the marginal covariances of X, V and B taken SEPARATELY -- whatever the
+// old graph knew about how pose, velocity and bias errors go together is dropped.  A fixed-lag window does not need
+// this (its marginal prior keeps the full 15 x 15 block); it is here so that the estimates follow the reference's
+// through its resets: tests/test_imu_window.py compares a 70-scan run against a batch solver with the same rule.
+bool reset_graph(dliom_imu_window& w) {
+  const int N = static_cast<int>(w.x.size()), n = N * kD;
+  std::vector<double> H, g;
+  if (!build(w, H, g)) return false;
+  for (int i = 0; i < n; ++i) H[static_cast<size_t>(i) * n + i] += 1e-12;
+  if (!cholesky_chain(H, n, kD)) return false;
+  double cov[kD][kD];  // marginal covariance of the newest state: the last block of H^-1
+  for (int c = 0; c < kD; ++c) {
+    std::vector<double> e(n, 0.0);
+    e[n - kD + c] = 1.0;
+    chol_solve_chain(H, n, kD, e.data());
+    for (int r = 0; r < kD; ++r) cov[r][c] = e[n - kD + r];
+  }
+  std::fill(w.H0, w.H0 + kD * kD, 0.0);
+  std::fill(w.b0, w.b0 + kD, 0.0);
+  const int first[3] = {0, 6, 9}, size[3] = {6, 3, 6};  // updatedPoseNoise, updatedVelNoise, updatedBiasNoise
+  for (int blk = 0; blk < 3; ++blk) {
+    const int f = first[blk], m = size[blk];
+    std::vector<double> C(static_cast<size_t>(m) * m);
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) C[static_cast<size_t>(i) * m + j] = 0.5 * (cov[f + i][f + j] + cov[f + j][f + i]);
+    if (!cholesky(C, m)) return false;
+    for (int c = 0; c < m; ++c) {  // information = C^-1, column by column
+      std::vector<double> e(m, 0.0);
+      e[c] = 1.0;
+      chol_solve(C, m, e.data());
+      for (int r = 0; r < m; ++r) w.H0[kD * (f + r) + f + c] = e[r];
+    }
+  }
+  for (int i = 0; i < kD; ++i)
+    for (int j = i + 1; j < kD; ++j) w.H0[kD * i + j] = w.H0[kD * j + i] = 0.5 * (w.H0[kD * i + j] + w.H0[kD * j + i]);
+  const State newest = w.x.back();
+  w.lin0 = newest;
+  w.x.assign(1, newest);
+  w.between.clear();
+  w.pose_priors.clear();
+  w.gravity.clear();
+  w.key = 1;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
 int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7], int degenerate, double pose7[7],
                               double velocity[3], double bias6[6]) {
   if (w == nullptr || matched_pose7 == nullptr || !w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
   if (!(w->current.dt > 0)) return DLIOM_ERR_INVALID_ARGUMENT;  // no IMU since the last pose
-  // new state at the IMU prediction (:833-838), IMU factor + bias random walk to it, pose prior on it
+  const dliom_imu_window saved = *w;  // a failed solve leaves the window exactly as it was
+  // prev_state_: the reference predicts from the estimate it read after the previous scan, also across a reset
   const State prev = w->x.back();
+  if (w->o.graph_reset_every > 0 && w->key == w->o.graph_reset_every) {
+    if (!reset_graph(*w)) {
+      *w = saved;
+      return DLIOM_ERR_SOLVER;
+    }
+    if (w->o.enable_gravity_factor != 0) {  // :772-782: EstimateGravity() here too (its deques get this frame twice)
+      w->g_est_valid = estimate_gravity(*w, prev, w->current);
+      if (w->g_est_valid) {
+        dliom_imu_window::Gravity gf;
+        gf.index = 0;
+        gf.nZ = (1.0 / norm(w->g_est_G)) * w->g_est_G;
+        gf.bRef = {0, 0, -1};
+        gf.sigma = w->o.prior_gravity_noise;
+        w->gravity.push_back(gf);
+        ++w->gravity_factors;
+        if (!gauss_newton(*w, 1)) {  // "optimize once" (:788)
+          *w = saved;
+          return DLIOM_ERR_SOLVER;
+        }
+      }
+    }
+  }
+  // new state at the IMU prediction (:833-838), IMU factor + bias random walk to it, pose prior on it
   State next = predicted(*w, prev, w->current);
   next.ba = prev.ba;
   next.bg = prev.bg;
@@ -1006,14 +1085,12 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
   f.sigma_trans = degenerate ? w->o.ceres_pose_noise_r_drift : w->o.ceres_pose_noise_r;
   w->pose_priors.push_back(f);
   // gravity factor for the state frames_for_online_gravity_estimate keys back (:819-831); key_ of the new state is
-  // num_states (1 for the first scan after initialisation; this window has no graph reset)
-  const std::deque<GFrame> g_frames_before = w->g_frames;
-  const std::deque<V3> g_vs_before = w->g_vs;
+  // w->key (1 for the first scan after initialisation or a reset)
   bool gravity_added = false;
   if (w->o.enable_gravity_factor != 0) {
     w->g_est_valid = estimate_gravity(*w, prev, w->current);
     const int win = w->o.frames_for_online_gravity_estimate;
-    if (w->g_est_valid && w->num_states - win >= 0 && static_cast<int>(w->x.size()) - 1 - win >= 0) {
+    if (w->g_est_valid && w->key - win >= 0 && static_cast<int>(w->x.size()) - 1 - win >= 0) {
       dliom_imu_window::Gravity gf;
       gf.index = static_cast<int>(w->x.size()) - 1 - win;
       gf.nZ = (1.0 / norm(w->g_est_G)) * w->g_est_G;
@@ -1023,17 +1100,11 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
       gravity_added = true;
     }
   }
-  const std::vector<State> backup = w->x;
   if (!gauss_newton(*w, w->o.iterations)) {
-    // nothing of this scan stays: the new key, its factors and the estimator's entry are taken back and the running
-    // preintegration is kept, so that the caller may try again (or re-initialise) without IMU samples counted twice
-    w->x = backup;
-    w->x.pop_back();
-    w->between.pop_back();
-    w->pose_priors.pop_back();
-    if (gravity_added) w->gravity.pop_back();
-    w->g_frames = g_frames_before;
-    w->g_vs = g_vs_before;
+    // nothing of this scan stays: the new key, its factors, the estimator's entry and a graph reset are taken back and
+    // the running preintegration is kept, so that the caller may try again (or re-initialise) without IMU samples
+    // counted twice
+    *w = saved;
     return DLIOM_ERR_SOLVER;
   }
   if (gravity_added) ++w->gravity_factors;
@@ -1042,6 +1113,7 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
   const State& s = w->x.back();
   w->current.reset(s.ba, s.bg);  // resetIntegrationAndSetBias(prev_bias_), :852
   ++w->num_states;
+  ++w->key;
   write_state(s, pose7, velocity, bias6);
   if (norm(s.v) > 30.0 || norm(s.ba) > 1.0 || norm(s.bg) > 1.0) {  // FailureDetection, :896-913
     w->initialized = false;                                          // ResetParams(): the caller re-initialises

@@ -139,7 +139,8 @@ class ImuWindowOptions(C.Structure):
         "prior_velocity_sigma", "prior_bias_sigma", "ceres_pose_noise_t", "ceres_pose_noise_r", "ceres_pose_noise_t_drift",
         "ceres_pose_noise_r_drift", "prior_gravity_noise")] + [
             ("window_size", C.c_int), ("iterations", C.c_int), ("enable_gravity_factor", C.c_int),
-            ("frames_for_online_gravity_estimate", C.c_int), ("lidar_in_imu_translation", C.c_double * 3)]
+            ("frames_for_online_gravity_estimate", C.c_int), ("lidar_in_imu_translation", C.c_double * 3),
+            ("graph_reset_every", C.c_int)]
 
 
 class ImuPreintegration(C.Structure):

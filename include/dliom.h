@@ -586,6 +586,10 @@ typedef struct dliom_imu_window_options {
   int frames_for_online_gravity_estimate;  /* lua :29 (7): estimator window, and the factor's key distance; needs
                                               window_size >= this + 1 */
   double lidar_in_imu_translation[3];      /* transform_lb_.translation() (.cc:1140), zero if the poses are the IMU's */
+  int graph_reset_every;                   /* submaps.num_range_data (.cc:749-792): when key_ reaches it the reference
+                                              replaces its graph by the newest state with the marginal covariances of
+                                              pose, velocity and bias taken separately; 0 = never (plain fixed-lag
+                                              smoothing, which keeps the cross-covariances that reset drops); >= 2 */
 } dliom_imu_window_options;
 int dliom_imu_window_default_options(dliom_imu_window_options* options);
 int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out);

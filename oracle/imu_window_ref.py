@@ -269,3 +269,103 @@ class BatchSmoother:
         s = self.x[-1]
         self.cur = Preintegration(s[3], s[4], self.o)
         return s
+
+
+class ReferenceRuleSmoother:
+    """What LocalTrajectoryBuilder3D::WindowOptimize keeps between scans (:693-863), with ISAM2 idealised as a batch
+    Gauss-Newton solve to convergence over every key since the last reset: the graph grows until key_ == num_range_data,
+    then it is reset to ONE state whose priors are the marginal covariances of X, V and B taken separately (:750-797;
+    the cross-covariances between pose, velocity and bias are dropped there).  Block-sparse numeric Jacobians (every
+    factor touches at most two states), so a run of a hundred scans stays within seconds.  No gravity factor."""
+
+    def __init__(self, opts, num_range_data):
+        self.o, self.n_reset = opts, int(num_range_data)
+
+    def initialize(self, pose7, vel, bias6):
+        s = (quat_to_matrix(pose7[3:]), np.array(pose7[:3], float), np.array(vel, float), np.array(bias6[:3], float),
+             np.array(bias6[3:], float))
+        o = self.o
+        self.x, self.pre, self.pose_priors = [s], [], []
+        # prior on state 0: mean and the inverse square roots of the three blocks (pose tangent = (rotation, translation
+        # in the body frame), like gtsam::Pose3::Logmap to first order)
+        self.prior = (s, np.eye(6) / o["prior_pose_noise"], np.eye(3) / o["prior_velocity_sigma"], np.eye(6) / o["prior_bias_sigma"])
+        self.cur = Preintegration(s[3], s[4], o)
+        self.resets = 0
+
+    def add_imu(self, acc, gyr, dt):
+        self.cur.add(acc, gyr, dt)
+
+    # ---- factors: (state indices, residual function of those states)
+    def _factors(self):
+        o = self.o
+        g = np.array([0, 0, -o["gravity"]])
+        s0, Wx, Wv, Wb = self.prior
+        fs = [((0,), lambda a: np.concatenate([Wx @ np.concatenate([log_so3(s0[0].T @ a[0]), s0[0].T @ (a[1] - s0[1])]),
+                                               Wv @ (a[2] - s0[2]), Wb @ np.concatenate([a[3] - s0[3], a[4] - s0[4]])]))]
+        for i, P in enumerate(self.pre):
+            L = np.linalg.cholesky(P.cov + 1e-18 * np.eye(9))
+
+            def imu(a, b, P=P, L=L):
+                dR, dp, dv = P.corrected(a[3], a[4])
+                raw = np.concatenate([log_so3(dR.T @ a[0].T @ b[0]),
+                                      a[0].T @ (b[1] - a[1] - P.dt * a[2] - 0.5 * P.dt ** 2 * g) - dp,
+                                      a[0].T @ (b[2] - a[2] - P.dt * g) - dv])
+                return np.concatenate([np.linalg.solve(L, raw), (b[3] - a[3]) / (np.sqrt(P.dt) * o["acc_bias_noise"]),
+                                       (b[4] - a[4]) / (np.sqrt(P.dt) * o["gyr_bias_noise"])])
+            fs.append(((i, i + 1), imu))
+        for idx, Rm, pm, s_rot, s_trans in self.pose_priors:
+            fs.append(((idx,), lambda a, Rm=Rm, pm=pm, s_rot=s_rot, s_trans=s_trans:
+                       np.concatenate([log_so3(Rm.T @ a[0]) / s_rot, Rm.T @ (a[1] - pm) / s_trans])))
+        return fs
+
+    def _normal_equations(self):
+        n = 15 * len(self.x)
+        H, b = np.zeros((n, n)), np.zeros(n)
+        for idx, f in self._factors():
+            st = [self.x[i] for i in idx]
+            r0 = f(*st)
+            J = np.zeros((len(r0), 15 * len(idx)))
+            for k in range(len(idx)):
+                for c in range(15):
+                    d = np.zeros(15)
+                    d[c] = 1e-6
+                    sp, sm = list(st), list(st)
+                    sp[k], sm[k] = retract(st[k], d), retract(st[k], -d)
+                    J[:, 15 * k + c] = (f(*sp) - f(*sm)) / 2e-6
+            cols = np.concatenate([np.arange(15 * i, 15 * i + 15) for i in idx])
+            H[np.ix_(cols, cols)] += J.T @ J
+            b[cols] += J.T @ r0
+        return H, b
+
+    def _solve(self, iterations):
+        for _ in range(iterations):
+            H, b = self._normal_equations()
+            step = np.linalg.solve(H, -b)
+            self.x = [retract(s, step[15 * i:15 * i + 15]) for i, s in enumerate(self.x)]
+            if np.linalg.norm(step) < 1e-10:
+                break
+
+    def add_pose(self, matched7, is_drift=False, iterations=6):
+        o = self.o
+        if len(self.x) == self.n_reset:  # key_ == num_range_data (:750): reset, keep the three marginals apart
+            H, _ = self._normal_equations()
+            cov = np.linalg.inv(H)[-15:, -15:]
+            s = self.x[-1]
+            T = np.eye(6)
+            T[3:6, 3:6] = s[0].T  # translation increment: world frame here, body frame in Pose3's tangent
+            cov_x = T @ cov[0:6, 0:6] @ T.T
+            sqrt_inv = lambda C: np.linalg.cholesky(np.linalg.inv(C)).T  # W with W^T W = C^-1
+            self.prior = (s, sqrt_inv(cov_x), sqrt_inv(cov[6:9, 6:9]), sqrt_inv(cov[9:15, 9:15]))
+            self.x, self.pre, self.pose_priors = [s], [], []
+            self.resets += 1
+            self._solve(2)  # "optimize once" (:788)
+        nxt = BatchSmoother._predict(self, self.x[-1], self.cur)
+        self.x.append(nxt)
+        self.pre.append(self.cur)
+        self.pose_priors.append((len(self.x) - 1, quat_to_matrix(matched7[3:]), np.array(matched7[:3], float),
+                                 o["ceres_pose_noise_t_drift"] if is_drift else o["ceres_pose_noise_t"],
+                                 o["ceres_pose_noise_r_drift"] if is_drift else o["ceres_pose_noise_r"]))
+        self._solve(iterations)
+        s = self.x[-1]
+        self.cur = Preintegration(s[3], s[4], o)
+        return s

@@ -307,3 +307,68 @@ def test_gravity_options_are_validated_and_failed_solves_roll_back(dl):
     pose, vel, bias, status = w.add_pose(st[:7])  # the same IMU samples, counted once
     assert status == 0 and len(w) == n_before + 1
     assert np.linalg.norm(pose[:3] - st[:3]) < 0.05
+
+
+def test_graph_reset_rule_follows_the_reference_through_its_resets(dl):
+    """50 scans with the reference's "reset graph for speed" (local_trajectory_builder_3d.cc:749-792) every 20 keys,
+    against a numpy solver that keeps EVERY key since the last reset in one converged batch problem (ISAM2 idealised) and
+    resets the way the reference does: marginal covariances of X, V and B taken separately.
+      * graph_reset_every = 20: the 8-state window (marginalising 12 states between resets) stays within 1e-6 m of it --
+        fixed-lag marginalisation costs ~1e-7 m against the growing graph, and the reset is reproduced;
+      * graph_reset_every = 0 (plain fixed-lag smoothing) agrees to 1e-6 m up to the first reset and is up to a few
+        millimetres / 1-2 cm/s away for the ~5 scans after one: that is the information the reference's reset drops
+        (the cross-covariances between pose, velocity and bias), not an error of the window."""
+    from dliom import synth
+    from oracle.imu_window_ref import ReferenceRuleSmoother
+    w_rule = dl.ImuWindow(window_size=8, iterations=2, graph_reset_every=20)
+    w_plain = dl.ImuWindow(window_size=8, iterations=2)
+    opts = {n: getattr(w_rule.options, n) for n in OPT_NAMES}
+    ref = ReferenceRuleSmoother(opts, num_range_data=20)
+    st = synth.trajectory_state(0.0)
+    for w in (w_rule, w_plain, ref):
+        w.initialize(st[:7], st[7:10], np.zeros(6))
+    T = 0.1
+    rule_dp, rule_dv, plain_dp = [], [], []
+    for k in range(1, 51):
+        dt, acc, gyr = synth.imu_samples(T * (k - 1), T * k, 200.0, (0.02, 0.002), seed=11 + k)
+        for a, g in zip(acc[:-1], gyr[:-1]):
+            for w in (w_rule, w_plain, ref):
+                w.add_imu(a, g, dt)
+        matched = synth.perturb_pose(synth.trajectory_pose(T * k), 0.02, 0.1, seed=70 + k)
+        pose, vel, bias, status = w_rule.add_pose(matched)
+        pose2, _, _, status2 = w_plain.add_pose(matched)
+        R, p, v, ba, bg = ref.add_pose(matched, iterations=4)
+        assert status == 0 and status2 == 0
+        rule_dp.append(np.linalg.norm(pose[:3] - p))
+        rule_dv.append(np.linalg.norm(vel - v))
+        plain_dp.append(np.linalg.norm(pose2[:3] - p))
+    assert ref.resets == 2
+    assert max(rule_dp) < 1e-6 and max(rule_dv) < 2e-5, (max(rule_dp), max(rule_dv))
+    assert max(plain_dp[:19]) < 1e-6                      # identical problems until the first reset
+    assert 2e-4 < max(plain_dp[19:26]) < 1e-2             # the reset's approximation, visible and bounded
+    assert plain_dp[-1] < 3e-4                            # and forgotten again some scans later
+
+
+def test_graph_reset_with_the_gravity_factor_runs_and_validates(dl):
+    """The reset path with enable_gravity_factor: EstimateGravity is called at the reset as well (.cc:772-782, a factor on
+    X(0) and one Gauss-Newton step), the key-distance gate restarts at the reset, option validation."""
+    with pytest.raises(Exception):
+        dl.ImuWindow(graph_reset_every=1)
+    with pytest.raises(Exception):
+        dl.ImuWindow(graph_reset_every=-3)
+    w = dl.ImuWindow(window_size=8, iterations=2, enable_gravity_factor=1, frames_for_online_gravity_estimate=3, graph_reset_every=6)
+    g = w.options.gravity
+    p0, v0, a0 = np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.8, 0.3, 0.0])
+    w.initialize(np.array([0, 0, 0, 1.0, 0, 0, 0]), v0, np.zeros(6))
+    T, h = 0.1, 0.005
+    factors = []
+    for k in range(1, 20):
+        for _ in range(int(round(T / h))):
+            w.add_imu(a0 + np.array([0, 0, g]), np.zeros(3), h)
+        t = T * k
+        pose = np.concatenate([p0 + v0 * t + 0.5 * a0 * t * t, [1.0, 0, 0, 0]])
+        out_pose, vel, bias, status = w.add_pose(pose)
+        assert status == 0 and len(w) <= 8
+        assert np.linalg.norm(out_pose[:3] - pose[:3]) < 5e-3
+        factors.append(w.gravity_estimate()[2])
+    assert factors[-1] > factors[5] > 0  # factors keep coming after the resets at keys 6, 12, 18
