@@ -579,54 +579,118 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
 // it did not use keep the bucket 255 the array was filled with): the order of the additions is the order of the array.
 // One wave per bucket: (1) scan the bucket bytes, 1024 entries per step, and queue the positions of its own entries in
 // order (wave prefix sums); (2) fetch their values, every lane busy; (3) one thread adds them one after the other.
-constexpr int kAccCap = 8192;
-__global__ __launch_bounds__(64) void accumulate_kernel(const unsigned char* __restrict__ c_bucket,
-                                                        const float* __restrict__ c_value, int n_padded, int histogram_size,
-                                                        float* __restrict__ histogram) {
-  __shared__ __attribute__((aligned(16))) float queue[kAccCap + 64];  // positions (as bits), then the values in place
-  const int bucket = blockIdx.x, lane = threadIdx.x;
-  if (bucket >= histogram_size) return;
-  float sum = 0.f;
-  unsigned queued = 0u;
-#ifdef DLIOM_EXPERIMENTS
-#define DLIOM_ASTAMP(k) if (lane == 0 && bucket < 128) dbg_acc[bucket * 8 + (k)] = __builtin_readcyclecounter()
-#else
-#define DLIOM_ASTAMP(k)
-#endif
-  DLIOM_ASTAMP(0);
-  auto drain = [&]() {
-    DLIOM_ASTAMP(1);
-#ifdef DLIOM_EXPERIMENTS
-    if (lane == 0 && bucket < 128) dbg_acc[bucket * 8 + 5] = queued;
-#endif
+constexpr int kAccCap = 24576;   // queue entries (dynamic LDS, 96 KB): a wall-dominated scan puts ~40 % of its points in one bucket
+constexpr int kAccWaves = 8;      // waves per bucket in the parallel scan
+constexpr int kAccHoldSteps = 8;  // steps of 1024 entries a wave keeps as one match bit per (lane, row): 2^16 entries per bucket
+
+// (2) + (3): values of the queued positions, every lane of the workgroup busy, then ONE thread adds them in order.
+__device__ __forceinline__ float fetch_and_sum(float* queue, unsigned queued, const float* __restrict__ c_value, float sum,
+                                               int tid, int nthreads, bool workgroup) {
+  if (workgroup) __syncthreads();
+  else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    for (unsigned e0 = 0; e0 < queued; e0 += 64 * 16) {  // sixteen gathers in flight per lane
-      float got[16];
+  }
+  for (unsigned e0 = 0; e0 < queued; e0 += static_cast<unsigned>(nthreads) * 16u) {  // sixteen gathers in flight per lane
+    float got[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const unsigned e = e0 + 64u * u + lane;
-        got[u] = e < queued ? c_value[__float_as_uint(queue[e])] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const unsigned e = e0 + 64u * u + lane;
-        if (e < queued) queue[e] = got[u];
-      }
+    for (int u = 0; u < 16; ++u) {
+      const unsigned e = e0 + static_cast<unsigned>(nthreads) * u + tid;
+      got[u] = e < queued ? c_value[__float_as_uint(queue[e])] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const unsigned e = e0 + static_cast<unsigned>(nthreads) * u + tid;
+      if (e < queued) queue[e] = got[u];
+    }
+  }
+  if (workgroup) __syncthreads();
+  else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    DLIOM_ASTAMP(2);
-    if (lane == 0) sum = thread_sequential_sum(queue, static_cast<int>(queued), sum);
-    __builtin_amdgcn_wave_barrier();
-    DLIOM_ASTAMP(3);
-    queued = 0u;
-  };
-  // 1024 entries per step as 16 rows of 64: lane l of row t looks at entry s * 1024 + t * 64 + l, so a row's matches are
-  // neighbours in the array AND in the queue (consecutive lanes -> consecutive LDS words).  With 16 consecutive entries
-  // per lane the queue writes of a hot bucket landed 16 words apart: 32-way bank conflicts, 5 us per step.
+  }
+  if (tid == 0) sum = thread_sequential_sum(queue, static_cast<int>(queued), sum);
+  if (workgroup) __syncthreads();
+  else __builtin_amdgcn_wave_barrier();
+  return sum;
+}
+
+// One WORKGROUP per bucket.  With one wave per bucket the scan of the ~46 steps was a chain of 46 dependent
+// load -> ballot -> queue rounds on 120 of the chip's 1024 SIMDs: 100 us, half of the whole histogram.  Now wave w scans
+// its contiguous eighth of the array keeping one match bit per (lane, row) in registers, the waves' counts are prefixed,
+// and every wave writes its positions where they belong -- the queue is in array order as before.  Arrays of more than
+// 2^16 entries, or more than kAccCap entries in one bucket, take the serial path (wave 0, queue drained as it fills).
+__global__ __launch_bounds__(64 * kAccWaves) void accumulate_kernel(const unsigned char* __restrict__ c_bucket,
+                                                                    const float* __restrict__ c_value, int n_padded,
+                                                                    int histogram_size, float* __restrict__ histogram) {
+  extern __shared__ __attribute__((aligned(16))) float queue[];  // kAccCap + 64: positions (as bits), then the values in place
+  __shared__ unsigned wave_count[kAccWaves];
+  const int bucket = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (bucket >= histogram_size) return;
   const int steps = n_padded / 1024;
   const unsigned char want8 = static_cast<unsigned char>(bucket);
+  const int per_wave = (steps + kAccWaves - 1) / kAccWaves;
+  bool parallel = per_wave <= kAccHoldSteps;
+  if (parallel) {
+    const int s_begin = wave * per_wave, s_end = min(steps, s_begin + per_wave);
+    unsigned bits[kAccHoldSteps / 2];  // 16 rows of step 2k in the low half, of step 2k + 1 in the high half
+#pragma unroll
+    for (int k = 0; k < kAccHoldSteps / 2; ++k) bits[k] = 0u;
+    unsigned mine = 0u;
+#pragma unroll
+    for (int k = 0; k < kAccHoldSteps; ++k) {
+      const int s = s_begin + k;
+      if (s < s_end) {
+        unsigned char row[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) row[t] = c_bucket[s * 1024 + t * 64 + lane];
+        unsigned b = 0u;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const bool hit = row[t] == want8;
+          b |= (hit ? 1u : 0u) << t;
+          mine += static_cast<unsigned>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit)));
+        }
+        bits[k >> 1] |= b << (16 * (k & 1));
+      }
+    }
+    if (lane == 0) wave_count[wave] = mine;
+    __syncthreads();
+    unsigned base = 0u, total = 0u;
+#pragma unroll
+    for (int w = 0; w < kAccWaves; ++w) {
+      if (w < wave) base += wave_count[w];
+      total += wave_count[w];
+    }
+    if (total <= static_cast<unsigned>(kAccCap)) {
+#pragma unroll
+      for (int k = 0; k < kAccHoldSteps; ++k) {
+        const int s = s_begin + k;
+        if (s < s_end) {
+          const unsigned b = bits[k >> 1] >> (16 * (k & 1));
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const bool hit = ((b >> t) & 1u) != 0u;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+            if (hit)
+              queue[base + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0u))] =
+                  __uint_as_float(static_cast<unsigned>(s) * 1024u + 64u * t + lane);
+            base += static_cast<unsigned>(__builtin_popcountll(mask));
+          }
+        }
+      }
+      const float sum = fetch_and_sum(queue, total, c_value, 0.f, static_cast<int>(threadIdx.x), 64 * kAccWaves, true);
+      if (threadIdx.x == 0) histogram[bucket] = sum;
+      return;
+    }
+    parallel = false;  // a bucket with more entries than the queue holds
+  }
+  if (wave != 0) return;
+  // ---- serial path: one wave, 1024 entries per step as 16 rows of 64 (lane l of row t looks at entry s * 1024 + t * 64 + l,
+  // so a row's matches are neighbours in the array AND in the queue: consecutive lanes -> consecutive LDS words)
+  float sum = 0.f;
+  unsigned queued = 0u;
   for (int s = 0; s < steps; ++s) {
     unsigned char row[16];
 #pragma unroll
@@ -639,7 +703,11 @@ __global__ __launch_bounds__(64) void accumulate_kernel(const unsigned char* __r
       step_total += static_cast<unsigned>(__builtin_popcountll(masks[t]));
     }
     if (step_total == 0u) continue;
-    if (queued + step_total > kAccCap) drain();
+    if (queued + step_total > kAccCap) {
+      sum = fetch_and_sum(queue, queued, c_value, sum, lane, 64, false);
+      sum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sum)));
+      queued = 0u;
+    }
     unsigned base = queued;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -651,7 +719,7 @@ __global__ __launch_bounds__(64) void accumulate_kernel(const unsigned char* __r
     }
     queued += step_total;
   }
-  drain();
+  sum = fetch_and_sum(queue, queued, c_value, sum, lane, 64, false);
   if (lane == 0) histogram[bucket] = sum;
 }
 
@@ -714,10 +782,13 @@ extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_clou
   hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, cloud->d_x, cloud->d_y, cloud->d_z, n, q,
                      rotation_wxyz != nullptr ? 1 : 0, rx, ry, rz, keys, bin_counts, flags);
   const size_t lds = static_cast<size_t>(kMaxSlice) * (8 + 12) + 1024;
+  const size_t acc_lds = static_cast<size_t>(kAccCap + 64) * 4;
   static thread_local bool attr_set = false;
   if (!attr_set) {
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds)));
+    DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(acc_lds)));
     attr_set = true;
   }
   // the smallest float s with fl(sqrt(s)) > kMaxDistance: `distance > kMaxDistance` as a comparison of squared lengths
@@ -729,7 +800,7 @@ extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_clou
   }();
   hipLaunchKernelGGL(slice_kernel, dim3(256), dim3(kThreads), lds, ctx->stream, rx, ry, rz, keys, n, bin_counts, histogram_size,
                      squared_jump, c_bucket, c_value, flags);
-  hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64), 0, ctx->stream, c_bucket, c_value,
+  hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64 * kAccWaves), acc_lds, ctx->stream, c_bucket, c_value,
                      static_cast<int>(n_padded), histogram_size, d_hist);
   DLIOM_HIP_TRY(hipGetLastError());
   // one read-back: [histogram | flags] through pinned memory
