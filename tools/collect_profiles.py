@@ -52,10 +52,16 @@ if "FETCH_SIZE" in summary:
 json.dump(out, open(os.path.join(dst, "%s_pmc_score_kernel.json" % tag), "w"), indent=1)
 for name, o in (("bench_full.json", "%s_bench.json"), ("wref_full.json", "%s_wref_full.json"), ("wref.json", "%s_wref.json"),
                 ("wref_stages.json", "%s_wref_stages.json"), ("stream.json", "%s_stream_config3.json"),
-                ("stream_gentle.json", "%s_stream_config3_gentle.json")):
+                ("stream_gentle.json", "%s_stream_config3_gentle.json"), ("config5_bench.json", "%s_config5_bench.json"),
+                ("bench_gloo2.json", "%s_bench_gloo2.json"), ("fast_csm.json", "%s_fast_csm.json"),
+                ("fast_csm_full.json", "%s_fast_csm_full.json"), ("fast_csm_dense.json", "%s_fast_csm_dense.json")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
         if lines:
             open(os.path.join(dst, o % tag), "w").write(lines[-1] + "\n")
+h = os.path.join(src, "histogram.txt")
+if os.path.exists(h):
+    keep = [l for l in open(h).read().splitlines() if "histogram" in l or "rothist" in l or l.startswith('"Name"')]
+    open(os.path.join(dst, "%s_histogram_kernels.txt" % tag), "w").write("\n".join(keep) + "\n")
 print(sorted(os.listdir(dst)))
