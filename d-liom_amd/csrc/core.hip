@@ -636,6 +636,7 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   ctx->box_tables.release();
   ctx->box_error.release();
   ctx->box_counters.release();
+  ctx->box_extents.release();
   if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

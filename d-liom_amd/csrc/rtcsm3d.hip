@@ -1397,6 +1397,12 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   DLIOM_TRY(ctx->box_counters.reserve(static_cast<size_t>(passes) * rot_blocks * 4 + 256));
   DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_counters.p, 0, static_cast<size_t>(passes) * rot_blocks * 4, ctx->stream));
   p.counters = ctx->box_counters.as<unsigned>();
+  // per-(rotation block, point) extents of the lookups: the boxes' bounding boxes are reductions over these
+  p.ext_stride = static_cast<int>(cloud.n_padded);
+  DLIOM_TRY(ctx->box_extents.reserve(static_cast<size_t>(rot_blocks) * 6 * static_cast<size_t>(cloud.n_padded) * 4));
+  p.ext = ctx->box_extents.as<float>();
+  hipLaunchKernelGGL(rtcsm_box_extent_kernel, dim3(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(rot_blocks)), dim3(256),
+                     0, ctx->stream, p, g.inv_resolution, cloud.d_xs, cloud.d_ys, cloud.d_zs, ctx->box_extents.as<float>());
   const unsigned blocks = static_cast<unsigned>(slot_quads) * passes * rot_blocks;
   hipLaunchKernelGGL(rtcsm_score_box_kernel, dim3(blocks), dim3(64 * nw), lds, ctx->stream, g, p, cloud.d_xs,
                      cloud.d_ys, cloud.d_zs);

@@ -117,6 +117,9 @@ struct Params {
   const float* trans;      // T x 3: the reference's float translations (exact path)
   const float4* rot;       // candidate rotations (w, x, y, z)
   const Group* group;      // one per workgroup's rotations (nw * 64 from r_first on)
+  const float* ext;        // [rot_blocks][6][ext_stride]: per point, lower / upper end per axis of its lookups under the
+                           // block's rotations, in cells, before the pass's translation (rtcsm_box_extent_kernel)
+  int ext_stride;
   unsigned long long* sums;
   const unsigned* order;   // ticket -> chunk (most expensive chunks first, core.hip chunk_order_kernel) or null: identity
   unsigned* counters;      // one chunk dispenser per unit = (pass, rotation block), zeroed by the host before the launch
@@ -526,6 +529,51 @@ __device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsig
   }
 }
 
+// Pre-pass of a launch: for every (rotation block, point) the interval per axis, in cells and before the pass's
+// translation, that contains the point's image under every rotation of the block:
+//   R_c (p + dc x p)  +-  |R_c| (hd (x) |p|)  +-  theta2 |p|      (metres)
+// around the centre rotation's image -- first-order spread of the rotations plus the second-order bound (Group, host,
+// double).  The score kernel used to compute this per box in every wave (~390 vector instructions an attempt, 10 % of
+// everything it issued, and on the critical path of a workgroup between two boxes); now a box's extent is six loads
+// and the reductions.  One thread per point, blockIdx.y = rotation block.
+__global__ __launch_bounds__(256) void rtcsm_box_extent_kernel(Params p, float inv, const float* __restrict__ px,
+                                                               const float* __restrict__ py, const float* __restrict__ pz,
+                                                               float* __restrict__ ext) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, rb = blockIdx.y;
+  if (i >= p.n) return;
+  const Group grp = p.group[rb];
+  const float4 qcc = p.rot[p.r_first + rb * p.nw * 64 + grp.c_lane];
+  const Quat4 qc{qcc.x, qcc.y, qcc.z, qcc.w};
+  float rabs[9];  // |R(qc)|, row major
+  {
+    const float w = qc.w, x = qc.x, y = qc.y, z = qc.z;
+    rabs[0] = fabsf(1.f - 2.f * (y * y + z * z));
+    rabs[1] = fabsf(2.f * (x * y - w * z));
+    rabs[2] = fabsf(2.f * (x * z + w * y));
+    rabs[3] = fabsf(2.f * (x * y + w * z));
+    rabs[4] = fabsf(1.f - 2.f * (x * x + z * z));
+    rabs[5] = fabsf(2.f * (y * z - w * x));
+    rabs[6] = fabsf(2.f * (x * z - w * y));
+    rabs[7] = fabsf(2.f * (y * z + w * x));
+    rabs[8] = fabsf(1.f - 2.f * (x * x + y * y));
+  }
+  const float x = px[i], y = py[i], z = pz[i];
+  const float sx_ = grp.dc[1] * z - grp.dc[2] * y, sy_ = grp.dc[2] * x - grp.dc[0] * z, sz_ = grp.dc[0] * y - grp.dc[1] * x;
+  float cx, cy, cz;
+  rotate_point(qc, x + sx_, y + sy_, z + sz_, cx, cy, cz);
+  const float fx = fabsf(x), fy = fabsf(y), fz = fabsf(z);
+  const float hx = grp.hd[1] * fz + grp.hd[2] * fy, hy = grp.hd[2] * fx + grp.hd[0] * fz, hz = grp.hd[0] * fy + grp.hd[1] * fx;
+  const float m2 = grp.theta2 * (fx + fy + fz) + 1.0e-5f * (fx + fy + fz);
+  const float c3[3] = {cx, cy, cz};
+  float* out = ext + static_cast<size_t>(rb) * 6 * p.ext_stride + i;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float he = rabs[3 * a] * hx + rabs[3 * a + 1] * hy + rabs[3 * a + 2] * hz + m2;
+    out[static_cast<size_t>(2 * a) * p.ext_stride] = (c3[a] - he) * inv;
+    out[static_cast<size_t>(2 * a + 1) * p.ext_stride] = (c3[a] + he) * inv;
+  }
+}
+
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rtcsm_score_box_kernel(
     GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
   extern __shared__ float4 lds_dyn4[];  // [kTC tau | band bitmap | ticket words | nw x lists | box]
@@ -546,7 +594,6 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
   ls.rec = reinterpret_cast<int*>(ls.l2 + kL2Cap);
   ls.n1 = 0;
   ls.seq = 0;
-  const float inv = g.inv_resolution;
   unsigned acc[kTC];
 #pragma unroll
   for (int j = 0; j < kTC; ++j) acc[j] = 0u;
@@ -609,22 +656,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     const bool lane_active = rot0 + lane < p.r_last;
     const float4 qq = p.rot[lane_active ? rot0 + lane : (wave_active ? rot0 : rot_b0)];  // idle lanes shadow a real rotation
     const Quat4 q{qq.x, qq.y, qq.z, qq.w};
-    const Group grp = p.group[rb];
-    const float4 qcc = p.rot[rot_b0 + grp.c_lane];
-    const Quat4 qc{qcc.x, qcc.y, qcc.z, qcc.w};
-    float rabs[9];  // |R(qc)|, row major
-    {
-      const float w = qc.w, x = qc.x, y = qc.y, z = qc.z;
-      rabs[0] = fabsf(1.f - 2.f * (y * y + z * z));
-      rabs[1] = fabsf(2.f * (x * y - w * z));
-      rabs[2] = fabsf(2.f * (x * z + w * y));
-      rabs[3] = fabsf(2.f * (x * y + w * z));
-      rabs[4] = fabsf(1.f - 2.f * (x * x + z * z));
-      rabs[5] = fabsf(2.f * (y * z - w * x));
-      rabs[6] = fabsf(2.f * (x * z - w * y));
-      rabs[7] = fabsf(2.f * (y * z + w * x));
-      rabs[8] = fabsf(1.f - 2.f * (x * x + y * y));
-    }
+    const float* ext_rb = p.ext + static_cast<size_t>(rb) * 6 * p.ext_stride;
     int n_guess = p.chunk;  // points per box that fitted last time
     int since_flush = 0;    // points added to the accumulators since they were last cleared (uniform)
     while (ticket < p.point_chunks) {
@@ -646,38 +678,28 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
           int n = min(c_end - lo, n_guess);
           Geometry geo;
           bool fits_out = false;
-          // ---- bounding box of every lookup of (these points) x (the workgroup's rotations) x (this pass);
-          //      every wave computes the same box from the same inputs
-          for (;;) {
-            // lanes = POINTS here: every lookup of point p under rotation q_lane lies within
-            //   R_c (p + dc x p)  +-  |R_c| (hd (x) |p|)  +-  theta2 |p|      (metres, before the translation)
-            // of the centre lane's image (first-order spread of the rotations plus the second-order bound)
-            float lo_f[3], hi_f[3];
-            {
-              const bool have = lane < n;
-              const int i = lo + (have ? lane : 0);
-              const float x = px[i], y = py[i], z = pz[i];
-              const float sx_ = grp.dc[1] * z - grp.dc[2] * y, sy_ = grp.dc[2] * x - grp.dc[0] * z, sz_ = grp.dc[0] * y - grp.dc[1] * x;
-              float cx, cy, cz;
-              rotate_point(qc, x + sx_, y + sy_, z + sz_, cx, cy, cz);
-              const float fx = fabsf(x), fy = fabsf(y), fz = fabsf(z);
-              const float hx = grp.hd[1] * fz + grp.hd[2] * fy, hy = grp.hd[2] * fx + grp.hd[0] * fz, hz = grp.hd[0] * fy + grp.hd[1] * fx;
-              const float m2 = grp.theta2 * (fx + fy + fz) + 1.0e-5f * (fx + fy + fz);
-              const float c3[3] = {cx, cy, cz};
+          // ---- bounding box of every lookup of (these points) x (the workgroup's rotations) x (this pass): the
+          //      per-point extents come from the pre-pass (lanes = POINTS here), every wave reduces the same values;
+          //      a box that does not fit is retried with fewer points -- only the reductions are redone
+          float l3[3], h3[3];
+          {
+            const int i = lo + (lane < n ? lane : 0);
 #pragma unroll
-              for (int a = 0; a < 3; ++a) {
-                const float he = rabs[3 * a] * hx + rabs[3 * a + 1] * hy + rabs[3 * a + 2] * hz + m2;
-                const float l = __builtin_fmaf(c3[a] - he, inv, ps.uc[a]) - 0.05f, h = __builtin_fmaf(c3[a] + he, inv, ps.uc[a]) + 0.05f;
-                lo_f[a] = wave_min_f(have ? l : 3.0e38f);
-                hi_f[a] = wave_max_f(have ? h : -3.0e38f);
-              }
+            for (int a = 0; a < 3; ++a) {
+              // 0.0502 instead of the 0.05 of the fused form fma(c -+ he, inv, uc): two more roundings of values < 1024
+              l3[a] = (ext_rb[static_cast<size_t>(2 * a) * p.ext_stride + i] + ps.uc[a]) - 0.0502f;
+              h3[a] = (ext_rb[static_cast<size_t>(2 * a + 1) * p.ext_stride + i] + ps.uc[a]) + 0.0502f;
             }
+          }
+          for (;;) {
+            const bool have = lane < n;
             bool fits = true;
             fits_out = false;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
               // clamp far outliers: a box that large is rejected below anyway
-              const float l = fmaxf(lo_f[a] - ps.reach[a], -1.0e6f), h = fminf(hi_f[a] + ps.reach[a], 1.0e6f);
+              const float l = fmaxf(wave_min_f(have ? l3[a] : 3.0e38f) - ps.reach[a], -1.0e6f);
+              const float h = fminf(wave_max_f(have ? h3[a] : -3.0e38f) + ps.reach[a], 1.0e6f);
               geo.lo[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(l)));
               geo.dim[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(h))) - geo.lo[a] + 1;
             }
