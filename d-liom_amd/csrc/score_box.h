@@ -756,24 +756,30 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
           __syncthreads();  // every wave is done with the previous box
           // ---- stage the box, all threads: 4-cell groups (8 bytes) of the bricked mirror, outside reads 1
           if (!DLIOM_BOX_DBG(p, 2)) {
-            const int quads = geo.dim[0] >> 2;
-            const int total = quads * geo.dim[1] * geo.dim[2];
-            const float inv_q = 1.0f / static_cast<float>(quads), inv_dy = 1.0f / static_cast<float>(geo.dim[1]);
+            // index arithmetic in 24-bit multiplies and one 32-bit byte offset: v_mul_lo_u32 and the 64-bit mads of
+            // the plain form are quarter-rate instructions, seven of them per 8-byte group were a tenth of the
+            // kernel's vector-ALU time (every factor here is below 2^24, the mirror below 4 GB)
+            const unsigned quads = static_cast<unsigned>(geo.dim[0]) >> 2, dim1 = static_cast<unsigned>(geo.dim[1]);
+            const unsigned total = __umul24(__umul24(quads, dim1), static_cast<unsigned>(geo.dim[2]));
+            const float inv_q = 1.0f / static_cast<float>(quads), inv_dy = 1.0f / static_cast<float>(dim1);
+            const int bx0 = geo.lo[0] + g.half + 1, by0 = geo.lo[1] + g.half + 1, bz0 = geo.lo[2] + g.half + 1;
+            const unsigned uB = static_cast<unsigned>(B), uBB = __umul24(uB, uB), uS = static_cast<unsigned>(S);
+            const char* dense_bytes = reinterpret_cast<const char*>(g.dense);
 #pragma unroll 4
-            for (int e = threadIdx.x; e < total; e += nthreads) {
-              const int row = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_q);  // exact: e < 2^21
-              const int xq = e - row * quads;
-              const int z = static_cast<int>((static_cast<float>(row) + 0.5f) * inv_dy);
-              const int y = row - z * geo.dim[1];
-              const int mx = geo.lo[0] + g.half + 1 + 4 * xq, my = geo.lo[1] + g.half + 1 + y, mz = geo.lo[2] + g.half + 1 + z;
+            for (unsigned e = threadIdx.x; e < total; e += static_cast<unsigned>(nthreads)) {
+              const unsigned row = static_cast<unsigned>((static_cast<float>(e) + 0.5f) * inv_q);  // exact: e < 2^21
+              const unsigned xq = e - __umul24(row, quads);
+              const unsigned z = static_cast<unsigned>((static_cast<float>(row) + 0.5f) * inv_dy);
+              const unsigned y = row - __umul24(z, dim1);
+              const int mx = bx0 + static_cast<int>(4u * xq), my = by0 + static_cast<int>(y), mz = bz0 + static_cast<int>(z);
               unsigned long long val = 0x0001000100010001ull;
-              if (mx >= 0 && mx < 4 * B && my >= 0 && my < S && mz >= 0 && mz < S) {
-                const size_t off = ((static_cast<size_t>(mz >> 2) * B + (my >> 2)) * B + (mx >> 2)) * 128u +
-                                   static_cast<size_t>(((mz & 3) << 5) | ((my & 3) << 3));
-                val = *reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(g.dense) + off);
+              if (static_cast<unsigned>(mx) < 4u * uB && static_cast<unsigned>(my) < uS && static_cast<unsigned>(mz) < uS) {
+                const unsigned umx = static_cast<unsigned>(mx), umy = static_cast<unsigned>(my), umz = static_cast<unsigned>(mz);
+                const unsigned off = ((__umul24(umz >> 2, uBB) + __umul24(umy >> 2, uB) + (umx >> 2)) << 7) |
+                                     (((umz & 3u) << 5) | ((umy & 3u) << 3));
+                val = *reinterpret_cast<const unsigned long long*>(dense_bytes + off);
               }
-              *reinterpret_cast<unsigned long long*>(box + (static_cast<unsigned>(z) * geo.sxy +
-                                                           static_cast<unsigned>(y) * geo.sx + 4u * static_cast<unsigned>(xq))) = val;
+              *reinterpret_cast<unsigned long long*>(box + (__umul24(z, geo.sxy) + __umul24(y, geo.sx) + 4u * xq)) = val;
             }
           }
           // chunk record for this wave's level-1 entries of these points
