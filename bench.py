@@ -442,6 +442,10 @@ def roofline_block(args, pairs, k_ms, launches, alg_bytes, score_kernel):
         # the same launch time against the cheapest instruction sequence known for a lookup: how much of the
         # kernel's issue slots do useful lookups (the headroom; `frac` counts every instruction the kernel issues)
         "frac_useful": (pairs / t) / USEFUL_PAIRS_PER_S if t > 0 else None,
+        # the hardware's own counter of the bounding pipe (SQ_ACTIVE_INST_VALU x 4 cycles over the launch's SIMD-cycles):
+        # `frac` prices every instruction at the 2-cycle rate of plain fp32 adds, this kernel's are mostly 4-cycle ones
+        # (v_mad_u32_u16, v_pk_add_f32, v_add3_u32), so frac <= 0.5 x valu_busy_frac-ish by construction
+        "valu_busy_frac": d.get("valu_busy_frac"),
         "valu_instructions_per_pair": valu_per_pair,
         "pairs_per_s": pairs / t if t > 0 else 0.0,
         "avg_launch_ms": k_ms,

@@ -81,6 +81,10 @@ def derive(counters, pairs, launch_seconds):
         d["resident_waves_per_simd"] = 4.0 * c["SQ_WAVE_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
     if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
         d["lds_bank_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+        # quad-cycles in which a SIMD's vector ALU executes an instruction, over the launch's SIMD-cycles: how busy the
+        # pipe that bounds the kernel is (every VALU instruction counted at 4 cycles -- most of this kernel's are)
+        d["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
     if "SQ_ACTIVE_INST_ANY" in c and c.get("SQ_WAVE_CYCLES", 0) > 0:
         d["wave_issue_frac"] = c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]
     return d
