@@ -93,6 +93,7 @@ struct dliom_ctx {
   int tuning[DLIOM_TUNE_COUNT] = {3, 4096, 0, 0};  // dliom_ctx_set_tuning (defaults: dliom.h)
   bool last_score_used_box = false;
   int last_score_mapping = -1;     // 3 box, 2 dense mirror, 1 / 0 leaf table kernels
+  int last_box_refusal = 0;        // DLIOM_BOX_* of the last score volume (dliom_rtcsm_stats.box_kernel_status)
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
   // profiling

@@ -1149,7 +1149,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   for (const F3& t : c.trans) tmax = std::max(tmax, static_cast<double>(std::max(std::fabs(t.x), std::max(std::fabs(t.y), std::fabs(t.z)))));
   const double rmax = static_cast<double>(cloud.max_norm) / res + 1.0;
   const double qmax = rmax + tmax / res + 1.0;
-  if (!std::isfinite(qmax) || qmax > 880.0) return DLIOM_ERR_CAPACITY;  // Kb must stay below 1024
+  if (!std::isfinite(qmax) || qmax > 880.0) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_RANGE, DLIOM_ERR_CAPACITY);  // Kb must stay below 1024
   std::vector<Pass> pass(static_cast<size_t>(passes));
   std::vector<float> tau(static_cast<size_t>(passes) * kTC * 4, 0.f);
   double taumax = 0.0;
@@ -1225,7 +1225,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
     const double a_lanes = (2.0 * c.w.angular_window_size + 1.0) * step;  // rotation-vector span of a workgroup (per axis, at most)
     const double spread = a_lanes * 0.6 * cloud.max_norm / res;                        // cells, at 60 % of the maximum range
     const double dim = spread + 2.0 * taumax + 8.0;
-    if (dim > kMaxDim || dim * dim * (dim * 0.25) > cells) return DLIOM_ERR_CAPACITY;
+    if (dim > kMaxDim || dim * dim * (dim * 0.25) > cells) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_WINDOW, DLIOM_ERR_CAPACITY);
   }
   // ---- spread of every wave's 64 rotations around its centre lane (window only: q_init cancels)
   const int rot_groups_all = (r_last - r_first + 63) / 64;
@@ -1238,7 +1238,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   const int rot_blocks = (rot_groups_all + nw - 1) / nw;
   if (kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 + static_cast<size_t>(cells) * 2 >
       160 * 1024)
-    return DLIOM_ERR_CAPACITY;  // LDS budget (checked again where the launch is sized)
+    return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_LDS, DLIOM_ERR_CAPACITY);  // LDS budget (checked again where the launch is sized)
   struct GroupCache {  // depends on the window and the shard only: cached per thread across matches
     int A = -1, r_first = -1, r_last = -1, nw = 0;
     float step = 0.f;
@@ -1289,7 +1289,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
         hi3[a] = std::max(hi3[a], dv[a]);
       }
     }
-    if (th > 0.3) return DLIOM_ERR_CAPACITY;  // the second-order bound below assumes small relative rotations
+    if (th > 0.3) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_WINDOW, DLIOM_ERR_CAPACITY);  // the second-order bound below assumes small relative rotations
     for (int a = 0; a < 3; ++a) {
       gr.dc[a] = static_cast<float>(0.5 * (lo3[a] + hi3[a]));
       gr.hd[a] = static_cast<float>(0.5 * (hi3[a] - lo3[a]) * 1.0001 + 1e-7);
@@ -1365,7 +1365,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
 #endif
   const size_t lds = kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 +
                      static_cast<size_t>(cells) * 2;
-  if (lds > 160 * 1024) return DLIOM_ERR_CAPACITY;
+  if (lds > 160 * 1024) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_LDS, DLIOM_ERR_CAPACITY);
   static thread_local bool attr_set = false;  // one context per thread: per-thread, not process-wide
   if (!attr_set) {
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rtcsm_score_box_kernel),
@@ -1434,20 +1434,32 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   // 2: rotation per lane over the dense mirror, 1: rotation per lane over the leaf table,
   // 0: point per lane over the leaf table
   int mapping = ctx->tuning[DLIOM_TUNE_SCORE_KERNEL];
-  if (ctx->force_dense_score && mapping > 2) mapping = 2;
+  ctx->last_box_refusal = mapping == 3 ? DLIOM_BOX_RAN : DLIOM_BOX_NOT_REQUESTED;
+  if (ctx->force_dense_score && mapping > 2) {
+    mapping = 2;
+    ctx->last_box_refusal = DLIOM_BOX_REFUSED_FLAGGED;  // the box kernel flagged an inconsistency: this is the rerun
+  }
   ctx->last_score_used_box = false;
   if (mapping >= 2) {
     // the mirror is a cache of the grid's contents: building it does not change the grid
-    if (const_cast<dliom_grid*>(grid)->ensure_dense() != DLIOM_OK) mapping = 1;  // too large: leaf path
+    if (const_cast<dliom_grid*>(grid)->ensure_dense() != DLIOM_OK) {
+      if (mapping == 3) ctx->last_box_refusal = DLIOM_BOX_REFUSED_NO_MIRROR;
+      mapping = 1;  // too large: leaf path
+    }
   }
   const GridView g = grid->view();
   DLIOM_TRY(ensure_morton(ctx, &cloud));
-  if (g.log2_leaves > 10 && mapping >= 1) mapping = 0;  // bits = 8: only the point-per-lane kernel has 64-bit table indices
+  if (g.log2_leaves > 10 && mapping >= 1) {  // bits = 8: only the point-per-lane kernel has 64-bit table indices
+    if (mapping == 3) ctx->last_box_refusal = DLIOM_BOX_REFUSED_NO_MIRROR;
+    mapping = 0;
+  }
   if (mapping == 3) {
     static const int box_min_pairs_log2 = env_int("DLIOM_BOX_MIN_LOG2", 24);  // small searches: launch-bound anyway
     const double pairs = static_cast<double>(C) * static_cast<double>(n);
     int s3 = DLIOM_ERR_CAPACITY;
+    ctx->last_box_refusal = DLIOM_BOX_REFUSED_SMALL;  // unless the launch below is reached
     if (T >= 8 && pairs >= std::ldexp(1.0, box_min_pairs_log2)) {
+      ctx->last_box_refusal = DLIOM_BOX_RAN;
 #ifdef DLIOM_EXPERIMENTS
       constexpr size_t kBoxErrorBytes = 256 + 4096 * 32;  // + per-workgroup time stamps (Params::debug & 256)
 #else
@@ -1946,6 +1958,7 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
   ctx->last_rtcsm.num_points = cloud.n;
   ctx->last_rtcsm.num_rescored = K;
   ctx->last_rtcsm.score_kernel = ctx->last_score_mapping;
+  ctx->last_rtcsm.box_kernel_status = ctx->last_box_refusal;
   ctx->last_rtcsm.best_index = st->best_c;
   if (local_best_packed != nullptr) {
     uint64_t packed = 0;  // a shard without a positive-score survivor contributes nothing

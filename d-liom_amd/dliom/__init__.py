@@ -67,7 +67,11 @@ class RtcsmWindow(C.Structure):
 
 class RtcsmStats(C.Structure):
     _fields_ = [("window", RtcsmWindow), ("num_points", C.c_int64), ("num_rescored", C.c_int64),
-                ("best_index", C.c_int64), ("score_kernel", C.c_int64)]
+                ("best_index", C.c_int64), ("score_kernel", C.c_int64), ("box_kernel_status", C.c_int64)]
+
+
+BOX_RAN, BOX_NOT_REQUESTED, BOX_REFUSED_SMALL, BOX_REFUSED_NO_MIRROR = 0, 1, 2, 3
+BOX_REFUSED_RANGE, BOX_REFUSED_WINDOW, BOX_REFUSED_LDS, BOX_REFUSED_FLAGGED = 4, 5, 6, 7
 
 
 MAX_CLOUDS = 8

@@ -223,7 +223,20 @@ typedef struct dliom_rtcsm_stats {
   int64_t best_index;     /* generation order: ((z,y,x) * R + (rz,ry,rx)) */
   int64_t score_kernel;   /* score-volume kernel that ran: 3 LDS-box, 2 dense mirror, 1 rotation per lane over the leaf
                              table, 0 point per lane over the leaf table */
+  int64_t box_kernel_status; /* why: DLIOM_BOX_* below (a refusal is not an error -- the other kernels give the same
+                                bits 1.9 to 4.4 times slower -- but it should not go unnoticed) */
 } dliom_rtcsm_stats;
+enum {
+  DLIOM_BOX_RAN = 0,               /* the LDS-box kernel scored the volume */
+  DLIOM_BOX_NOT_REQUESTED = 1,     /* DLIOM_TUNE_SCORE_KERNEL chose another kernel */
+  DLIOM_BOX_REFUSED_SMALL = 2,     /* fewer than 8 translations or 2^24 candidate-point pairs: launch-bound anyway */
+  DLIOM_BOX_REFUSED_NO_MIRROR = 3, /* the grid has no dense mirror (bits >= 5, or no memory for it) */
+  DLIOM_BOX_REFUSED_RANGE = 4,     /* scaled coordinates beyond the fast index's range (range / resolution > ~880 cells) */
+  DLIOM_BOX_REFUSED_WINDOW = 5,    /* angular window x range: a typical point's lookups do not fit a box */
+  DLIOM_BOX_REFUSED_LDS = 6,       /* the box + lists exceed the LDS budget */
+  DLIOM_BOX_REFUSED_FLAGGED = 7    /* the box kernel flagged an inconsistency ("cannot happen"): this match was redone
+                                      on the dense kernel (dliom_rtcsm3d_box_error holds the sticky flag) */
+};
 int dliom_rtcsm3d_last_stats(const dliom_ctx* ctx, dliom_rtcsm_stats* stats);
 /* BASELINE config 4 in one call: this rank scores rotations [shard R / num_shards, (shard + 1) R / num_shards), finds its
  * own winner exactly, and ONE max all-reduce of one uint64 (score_bits << 32 | ~candidate_index) yields the reference's

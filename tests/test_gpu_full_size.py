@@ -57,7 +57,7 @@ def test_config2_full_oracle_match(dl, ctx, orc, bench_scene):
     score, pose = rt.Match(sc["init"], sc["cloud"], s["g_hi"])
     st = rt.last_stats()
     assert st.window.num_candidates == 35937 == ref["num_candidates"] and st.num_points == 65536
-    assert st.score_kernel == 3  # the LDS-box kernel is what bench.py times
+    assert st.score_kernel == 3 and st.box_kernel_status == dl.BOX_RAN  # the LDS-box kernel is what bench.py times
     assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
     assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
     assert np.array_equal(pose, ref["pose"])
@@ -87,6 +87,7 @@ def test_config2_dense_rerun_after_box_fault(dl, ctx, orc, bench_scene):
     st = rt.last_stats()
     assert ctx.get_tuning(dl.TUNE_INJECT_BOX_FAULT) == 0  # consumed
     assert st.score_kernel == 2, st.score_kernel          # the rerun ran on the dense-mirror kernel
+    assert st.box_kernel_status == dl.BOX_REFUSED_FLAGGED  # ... and says why
     assert st.best_index == ref["best_index"]
     assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
     assert np.array_equal(pose, ref["pose"])
@@ -109,6 +110,7 @@ def test_config2_dense_rerun_after_box_fault(dl, ctx, orc, bench_scene):
     ctx.set_tuning(dl.TUNE_INJECT_BOX_FAULT, 0)
     score3, _ = rt.Match(sc["init"], sc["cloud"], s["g_hi"])
     assert rt.last_stats().score_kernel == 3 and np.float32(score3).tobytes() == np.float32(ref["score"]).tobytes()
+    assert rt.last_stats().box_kernel_status == dl.BOX_RAN
     assert rt.box_error() == 0
 
 

@@ -206,6 +206,9 @@ def test_rtcsm3d_match_equals_oracle(dl, ctx, orc, beams, azimuths, max_range, o
     assert np.float32(score) == np.float32(ref["score"])
     assert np.array_equal(pose, ref["pose"])
     assert 1 <= st.num_rescored <= st.window.num_candidates
+    # searches this small are launch-bound: the box kernel stands aside and says so
+    small = st.window.num_translations < 8 or st.window.num_candidates * st.num_points < 2 ** 24
+    assert (st.score_kernel, st.box_kernel_status) == ((2, dl.BOX_REFUSED_SMALL) if small else (3, dl.BOX_RAN))
     # the device-resident cloud entry point gives the same answer
     cloud = dl.PointCloud(ctx, pts)
     score2, pose2 = m.Match(init, cloud, dg)
@@ -552,6 +555,7 @@ def test_hybrid_grid_at_bits_8(dl, ctx, orc):
     score, pose = rt.Match(init, pts, dg)
     ref = orc.rtcsm3d_match(DEFAULT_RTCSM, init, pts, og)
     assert rt.last_stats().score_kernel == 0  # the wide point-per-lane kernel
+    assert rt.last_stats().box_kernel_status == dl.BOX_REFUSED_NO_MIRROR  # a refusal is reported, not silent
     assert np.float32(score) == np.float32(ref["score"]) and np.array_equal(pose, ref["pose"])
     og_lo = build_oracle_submap(orc, 0.45, num_scans=3, beams=16, azimuths=128)
     dg_lo = to_device_grid(dl, ctx, og_lo)
