@@ -746,6 +746,24 @@ class LocalTrajectoryBuilder3D {
     result->range_data_in_local.returns.resize(static_cast<size_t>(n));
     for (int64_t i = 0; i < n; ++i)
       result->range_data_in_local.returns[static_cast<size_t>(i)] = TransformPoint(pf, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    // ComputeHistogram (.cc:605-610) reads the same filtered cloud as the insertion and writes nothing the insertion
+    // reads: its kernels are started first, on the context's auxiliary stream, and run beside the insertion's
+    const float rot_wxyz[4] = {pf[3], pf[4], pf[5], pf[6]};
+    const bool histogram_on_device = options_.rotational_histogram_size > 0 && options_.rotational_histogram_size <= 255;
+    bool histogram_pending = false;
+    if (histogram_on_device) {
+      const int hb = dliom_cloud_rotational_histogram_begin(context_->get(), cloud, rot_wxyz, options_.rotational_histogram_size);
+      if (hb != DLIOM_ERR_CAPACITY) Check(hb, "RotationalScanMatcher::ComputeHistogram (begin)");
+      histogram_pending = hb == DLIOM_OK;
+    }
+    struct PendingHistogram {  // never leave one pending on the context, whatever path leaves this function
+      dliom_ctx* c;
+      bool* pending;
+      ~PendingHistogram() {
+        float discard[256];
+        if (*pending) (void)dliom_cloud_rotational_histogram_finish(c, discard);
+      }
+    } pending_guard{context_->get(), &histogram_pending};
     // InsertIntoSubmap (.cc:584-622): gravity_alignment = opt_pose.rotation()
     dliom_insertion_result ins;
     Check(dliom_front_end_insert(active_submaps_.get(), time, opt, opt + 3, &ins), "InsertIntoSubmap");
@@ -761,11 +779,11 @@ class LocalTrajectoryBuilder3D {
       // device one refuses (|z| beyond 409 m, more than 4096 points in one 0.2 m slice)
       if (options_.rotational_histogram_size > 0) {
         ir->rotational_scan_matcher_histogram.resize(static_cast<size_t>(options_.rotational_histogram_size));
-        const float rot_wxyz[4] = {pf[3], pf[4], pf[5], pf[6]};
-        int hs = options_.rotational_histogram_size <= 255
-                     ? dliom_cloud_rotational_histogram(context_->get(), cloud, rot_wxyz, options_.rotational_histogram_size,
-                                                        ir->rotational_scan_matcher_histogram.data())
-                     : DLIOM_ERR_CAPACITY;
+        int hs = DLIOM_ERR_CAPACITY;
+        if (histogram_pending) {
+          histogram_pending = false;
+          hs = dliom_cloud_rotational_histogram_finish(context_->get(), ir->rotational_scan_matcher_histogram.data());
+        }
         if (hs == DLIOM_ERR_CAPACITY) {
           const float rot[7] = {0.f, 0.f, 0.f, pf[3], pf[4], pf[5], pf[6]};
           std::vector<float> aligned(3 * static_cast<size_t>(n));

@@ -371,8 +371,9 @@ __global__ __launch_bounds__(256) void gather_to_pinned_kernel(GatherArgs a) {
 }
 }  // namespace
 
-int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs) {
+int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs, hipStream_t stream) {
   if (num_jobs <= 0) return DLIOM_OK;
+  if (stream == nullptr) stream = ctx->stream;
   if (num_jobs > 4) return DLIOM_ERR_INVALID_ARGUMENT;
   FillArgs a;
   unsigned long long most = 1;
@@ -384,7 +385,7 @@ int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs) {
     if ((reinterpret_cast<uintptr_t>(p) & 15u) != 0) {
       const unsigned char b = static_cast<unsigned char>(jobs[j].value & 0xFFu);
       if (jobs[j].value != 0x01010101u * b) return DLIOM_ERR_INVALID_ARGUMENT;
-      DLIOM_HIP_TRY(hipMemsetAsync(p, b, bytes, ctx->stream));
+      DLIOM_HIP_TRY(hipMemsetAsync(p, b, bytes, stream));
       bytes = 0;
     }
     a.p[j] = reinterpret_cast<uint4*>(p);
@@ -395,13 +396,14 @@ int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs) {
     most = std::max(most, a.vec[j]);
   }
   const unsigned blocks = static_cast<unsigned>(std::min<unsigned long long>((most + 255) / 256, 2048));
-  hipLaunchKernelGGL(fill_multi_kernel, dim3(blocks, num_jobs), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(fill_multi_kernel, dim3(blocks, num_jobs), dim3(256), 0, stream, a);
   DLIOM_HIP_TRY(hipGetLastError());
   return DLIOM_OK;
 }
 
-int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst) {
+int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst, hipStream_t stream) {
   if (num_jobs <= 0) return DLIOM_OK;
+  if (stream == nullptr) stream = ctx->stream;
   if (num_jobs > 6 || pinned_dst == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   GatherArgs a;
   unsigned off = 0;
@@ -418,7 +420,7 @@ int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* 
   }
   a.dst = static_cast<unsigned*>(pinned_dst);
   a.n = num_jobs;
-  hipLaunchKernelGGL(gather_to_pinned_kernel, dim3(1), dim3(256), 0, ctx->stream, a);
+  hipLaunchKernelGGL(gather_to_pinned_kernel, dim3(1), dim3(256), 0, stream, a);
   DLIOM_HIP_TRY(hipGetLastError());
   return DLIOM_OK;
 }
@@ -637,6 +639,10 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   ctx->box_error.release();
   ctx->box_counters.release();
   ctx->box_extents.release();
+  ctx->aux_scratch.release();
+  if (ctx->aux_pinned != nullptr) (void)hipHostFree(ctx->aux_pinned);
+  if (ctx->aux_fork != nullptr) (void)hipEventDestroy(ctx->aux_fork);
+  if (ctx->aux_stream != nullptr) (void)hipStreamDestroy(ctx->aux_stream);
   if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

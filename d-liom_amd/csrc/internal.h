@@ -96,6 +96,13 @@ struct dliom_ctx {
   int last_box_refusal = 0;        // DLIOM_BOX_* of the last score volume (dliom_rtcsm_stats.box_kernel_status)
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
+  // auxiliary stream (dliom_cloud_rotational_histogram_begin / _finish): work that only reads what is already on the
+  // context may run beside the main stream; own scratch and own pinned block, created on first use
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_fork = nullptr;
+  dliom::DevBuf aux_scratch;
+  void* aux_pinned = nullptr;  // 4 KB
+  int aux_histogram_size = 0;  // > 0: a histogram is pending on aux_stream
   // profiling
   bool profiling = false;
   unsigned profiling_mask = ~0u;  // kernel ids whose launches are timed
@@ -199,13 +206,13 @@ struct FillJob {
   size_t bytes;    // multiple of 4
   unsigned value;  // 32-bit pattern
 };
-int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs);  // num_jobs <= 4, on ctx->stream
+int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs, hipStream_t stream = nullptr);  // num_jobs <= 4, on ctx->stream unless given
 struct GatherJob {
   const void* src;  // device, 4-byte aligned
   unsigned words;
 };
 // Copies the jobs' words back to back into `pinned_dst` (device-visible pinned host memory, e.g. inside ctx->pinned).
-int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst);  // num_jobs <= 6, <= 1024 words each
+int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst, hipStream_t stream = nullptr);  // num_jobs <= 6, <= 1024 words each
 // rtcsm3d.hip: exact sequential float sums of LUT probabilities under explicit float poses
 int sequential_probability_sums(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid, const float* poses7,
                                 int k, float* sums);

@@ -11,9 +11,13 @@
 //     compact their contiguous 1/16 of the input (count, prefix over the waves, write): input order, no atomics.
 //   * ComputeCentroid (:52-59): a SEQUENTIAL float sum.  One thread per coordinate walks the slice in LDS.
 //   * SortSlice (:97-121): atan2f of the reference's libm (glibc 2.35 flt-32 = fdlibm, no FMA; restated below and
-//     pinned against the host's atan2f by tests/test_cpu_host.py), std::sort by angle.  Here: a bitonic sort of
-//     (angle, position in the slice) -- identical to any std::sort unless two DISTINCT points of a slice have
-//     bit-identical angles (std::sort's order of equal keys is unspecified; identical points commute).
+//     pinned against the host's atan2f by tests/test_cpu_host.py), then std::sort by angle ONLY.  Two returns of a slice
+//     share an angle in three scans out of four, and which of them comes first decides `last_point` below: the order
+//     libstdc++'s std::sort leaves equal keys in is part of the result.  A slice is first sorted by (angle, position)
+//     with a bitonic sort; if two equal angles end up next to each other, introsort itself is replayed on the slice
+//     (libstdcxx_sort_arrangement: median-of-three + unguarded partition of every segment above 16 elements as
+//     data-parallel rounds, heap sort where the depth limit 2 lg n is used up -- one slice in four, input order being
+//     close to a worst case of the median-of-three -- and a stable sort for the final insertion sort).
 //   * AddPointCloudSliceToHistogram (:61-92): `last_point` only moves when a point is more than 0.9 m from it -- a
 //     sequential state machine.  One wave evaluates 64 sorted points against the current anchor at once, takes the
 //     lanes before the first jump, moves the anchor and goes on.
@@ -23,6 +27,7 @@
 // Limits (DLIOM_ERR_CAPACITY, the host entry point has none): |z| < 409.6 m, at most 4096 points per slice.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #include "device_common.h"
@@ -234,10 +239,297 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+
+// ---- std::sort's order of EQUAL keys ---------------------------------------------------------------------------------
+// SortSlice sorts (angle, point) pairs by angle only (rotational_scan_matcher.cc:97-121); two returns of one slice share
+// an angle in three scans out of four, and the order libstdc++'s introsort leaves them in decides which one becomes
+// `last_point`.  So the algorithm is reproduced, not just a sorted order (tests/cpp/std_sort_model.cc is this
+// formulation in plain C++, checked against the real std::sort on arrays full of ties):
+//   __introsort_loop      = rounds of median-of-three + unguarded partition on every segment above 16 elements, all
+//                           segments of a round at once; a partition as data-parallel steps -- the k-th stop of the left
+//                           pointer swaps with the k-th stop of the right pointer while they have not crossed;
+//   __final_insertion_sort = a STABLE sort of what the rounds left (insertion never moves an element past an equal one).
+// Runs only for slices whose plain sort found two equal angles next to each other.  `a`: items (ordered angle bits << 32 |
+// position in the slice), [0, m); the arrays are kMaxSlice + 1 u16 each.  Where std::sort runs out of its depth limit it
+// heap-sorts the segment: restated too (heap_sort_keys).  Always returns true (the bool is kept for the callers' shape).
+struct SortScratch {
+  unsigned short *seg_first, *seg_last, *tmp_l, *tmp_r, *g, *l, *cut;
+};
+
+// exclusive prefix counts of 4 consecutive flags per thread (position 4 t + k) over the workgroup; out[p] for p in
+// [0, 4096], out[4096] = total
+__device__ __forceinline__ void blocked_prefix(const unsigned (&flag)[4], unsigned short* out, unsigned* wave_sums) {
+  const unsigned mine = flag[0] + flag[1] + flag[2] + flag[3];
+  unsigned total;
+  const unsigned base = block_exclusive_scan(mine, wave_sums, &total);
+  const int p0 = 4 * static_cast<int>(threadIdx.x);
+  unsigned run = base;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    out[p0 + k] = static_cast<unsigned short>(run);
+    run += flag[k];
+  }
+  if (threadIdx.x == kThreads - 1) out[kMaxSlice] = static_cast<unsigned short>(total);
+}
+
+// bits/stl_heap.h: __adjust_heap (with its __push_heap), __make_heap, __sort_heap on items compared by their high words
+__device__ inline void adjust_heap_keys(unsigned long long* first, int hole, int len, unsigned long long value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (static_cast<unsigned>(first[child] >> 32) < static_cast<unsigned>(first[child - 1] >> 32)) --child;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && static_cast<unsigned>(first[parent] >> 32) < static_cast<unsigned>(value >> 32)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+__device__ inline void heap_sort_keys(unsigned long long* first, int len) {
+  if (len >= 2)
+    for (int parent = (len - 2) / 2;; --parent) {
+      adjust_heap_keys(first, parent, len, first[parent]);
+      if (parent == 0) break;
+    }
+  for (int last = len; last > 1;) {
+    --last;
+    const unsigned long long value = first[last];
+    first[last] = first[0];
+    adjust_heap_keys(first, 0, last, value);
+  }
+}
+
+__device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const SortScratch& sc, unsigned* wave_sums) {
+  static_assert(kMaxSlice == 4 * kThreads, "four positions per thread");
+  const int p0 = 4 * static_cast<int>(threadIdx.x);
+  int depth = 0;
+  for (int v = m; v > 1; v >>= 1) ++depth;
+  depth *= 2;  // std::__lg(n) * 2
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sc.seg_first[p0 + k] = 0;
+    sc.seg_last[p0 + k] = static_cast<unsigned short>(m);
+  }
+  __syncthreads();
+  for (;;) {
+    // any segment above the threshold?
+    int large = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k;
+      if (p < m && sc.seg_first[p] == p && sc.seg_last[p] - p > 16) large = 1;
+    }
+    if (!__syncthreads_or(large)) return true;
+    if (depth == 0) {
+      // std::sort's depth limit (2 lg n partitions on one path): it heap-sorts what is left of such a segment --
+      // std::__partial_sort(first, last, last) = __make_heap + __sort_heap, restated; sequential, one thread per segment.
+      // Not rare: a slice in input order is close to a worst case of the median-of-three, one slice in four gets here.
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k;
+        if (p < m && sc.seg_first[p] == p && sc.seg_last[p] - p > 16) heap_sort_keys(a + p, sc.seg_last[p] - p);
+      }
+      __syncthreads();
+      return true;
+    }
+    --depth;
+    // (a) __move_median_to_first(first, first + 1, mid, last - 1): one thread per segment head
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k;
+      if (p < m && sc.seg_first[p] == p && sc.seg_last[p] - p > 16) {
+        const int first = p, last = sc.seg_last[p];
+        const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+        const unsigned ka = static_cast<unsigned>(a[ia] >> 32), kb = static_cast<unsigned>(a[ib] >> 32), kc = static_cast<unsigned>(a[ic] >> 32);
+        int md;
+        if (ka < kb) {
+          if (kb < kc) md = ib;
+          else if (ka < kc) md = ic;
+          else md = ia;
+        } else if (ka < kc) md = ia;
+        else if (kb < kc) md = ic;
+        else md = ib;
+        const unsigned long long t = a[first];
+        a[first] = a[md];
+        a[md] = t;
+      }
+    }
+    __syncthreads();
+    // (b) where the two pointers of __unguarded_partition(first + 1, last, first) stop: !(x < pivot) from the left,
+    //     !(pivot < x) from the right; prefix counts over the whole array, ranks relative to the segment
+    unsigned ge[4], le[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k;
+      ge[k] = le[k] = 0u;
+      if (p < m) {
+        const int first = sc.seg_first[p], last = sc.seg_last[p];
+        if (last - first > 16 && p != first) {
+          const unsigned pivot = static_cast<unsigned>(a[first] >> 32), x = static_cast<unsigned>(a[p] >> 32);
+          ge[k] = x < pivot ? 0u : 1u;
+          le[k] = pivot < x ? 0u : 1u;
+        }
+      }
+    }
+    blocked_prefix(ge, sc.g, wave_sums);
+    blocked_prefix(le, sc.l, wave_sums);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k;
+      if (p < m) {
+        const int first = sc.seg_first[p], last = sc.seg_last[p];
+        if (ge[k]) sc.tmp_l[first + 1 + (sc.g[p] - sc.g[first + 1])] = static_cast<unsigned short>(p);
+        if (le[k]) sc.tmp_r[first + 1 + (sc.l[last] - sc.l[p + 1])] = static_cast<unsigned short>(p);
+      }
+    }
+    __syncthreads();
+    // (c) the k-th pair swaps while the pointers have not crossed; the thread at the boundary knows the cut
+    unsigned long long keep_l[4], keep_r[4];
+    int at_l[4], at_r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = p0 + k;
+      at_l[k] = at_r[k] = -1;
+      if (q < m) {
+        const int first = sc.seg_first[q], last = sc.seg_last[q];
+        if (last - first > 16 && q != first) {
+          const int kk = q - (first + 1);
+          const int cnt_l = sc.g[last] - sc.g[first + 1], cnt_r = sc.l[last] - sc.l[first + 1];
+          auto valid = [&](int j) { return j < cnt_l && j < cnt_r && sc.tmp_l[first + 1 + j] < sc.tmp_r[first + 1 + j]; };
+          const bool v = valid(kk);
+          if (v) {
+            at_l[k] = sc.tmp_l[q];
+            at_r[k] = sc.tmp_r[q];
+            keep_l[k] = a[at_l[k]];
+            keep_r[k] = a[at_r[k]];
+          }
+          int K = -1;
+          if (kk == 0 && !v) K = 0;
+          else if (v && !valid(kk + 1)) K = kk + 1;
+          if (K >= 0) {  // where the left pointer stops next
+            int i = 1 << 30;
+            if (K < cnt_l) i = sc.tmp_l[first + 1 + K];
+            if (K > 0) i = min(i, static_cast<int>(sc.tmp_r[first + 1 + K - 1]));
+            sc.cut[first] = static_cast<unsigned short>(i);
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (at_l[k] >= 0) {
+        a[at_l[k]] = keep_r[k];
+        a[at_r[k]] = keep_l[k];
+      }
+    // (d) [first, cut) and [cut, last)
+    unsigned short nf[4], nl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = p0 + k;
+      nf[k] = sc.seg_first[p0 + k];
+      nl[k] = sc.seg_last[p0 + k];
+      if (p < m && nl[k] - nf[k] > 16) {
+        const int c = sc.cut[nf[k]];
+        if (p < c) nl[k] = static_cast<unsigned short>(c);
+        else nf[k] = static_cast<unsigned short>(c);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sc.seg_first[p0 + k] = nf[k];
+      sc.seg_last[p0 + k] = nl[k];
+    }
+    __syncthreads();
+  }
+}
+
 #ifdef DLIOM_EXPERIMENTS
 __device__ unsigned long long dbg_stamps[64 * 16];
 __device__ unsigned long long dbg_acc[128 * 8];
 #endif
+
+// Sorts skey[0, pow2) ascending (pow2 a power of two >= 64, <= kMaxSlice; unused entries hold ~0).
+__device__ __forceinline__ void bitonic_sort_keys(unsigned long long* skey, int pow2) {
+  // bitonic sort, up to four keys per thread in registers (key i = t + r * 1024): exchanges at distance < 64 are lane
+  // shuffles, at distance >= 1024 stay inside the thread, and only the distances 64 .. 512 go through LDS
+  constexpr int kR = kMaxSlice / kThreads;
+  const int rows = max(1, pow2 / kThreads);  // keys per thread in use
+  unsigned long long v[kR];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+    v[r] = i < pow2 ? skey[i] : ~0ull;
+  }
+  for (int k = 2; k <= pow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= kThreads) {  // partner key in the same thread: rows (0,1),(2,3) for j = 1024, (0,2),(1,3) for j = 2048
+        static_assert(kR == 4, "the in-thread exchanges below are written for four keys per thread");
+        auto exchange = [&](unsigned long long& a, unsigned long long& b, int row) {
+          const int i = static_cast<int>(threadIdx.x) + row * kThreads;
+          const bool up = (i & k) == 0;
+          const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+          a = up ? lo : hi;
+          b = up ? hi : lo;
+        };
+        if (j == kThreads) {
+          exchange(v[0], v[1], 0);
+          exchange(v[2], v[3], 2);
+        } else {
+          exchange(v[0], v[2], 0);
+          exchange(v[1], v[3], 1);
+        }
+      } else if (j >= 64) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+          const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+          if (r < rows && i < pow2) skey[i] = v[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+          const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+          if (r < rows && i < pow2) {
+            const unsigned long long other = skey[i ^ j];
+            const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+            v[r] = keep_min ? (v[r] < other ? v[r] : other) : (v[r] < other ? other : v[r]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+          if (r >= rows) break;  // uniform
+          const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+          const unsigned lo32 = static_cast<unsigned>(__shfl_xor(static_cast<int>(v[r] & 0xffffffffull), j, 64));
+          const unsigned hi32 = static_cast<unsigned>(__shfl_xor(static_cast<int>(v[r] >> 32), j, 64));
+          const unsigned long long other = (static_cast<unsigned long long>(hi32) << 32) | lo32;
+          const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+          v[r] = keep_min ? (v[r] < other ? v[r] : other) : (v[r] < other ? other : v[r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int i = static_cast<int>(threadIdx.x) + r * kThreads;
+    if (i < pow2) skey[i] = v[r];
+  }
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict__ rx, const float* __restrict__ ry,
                                                          const float* __restrict__ rz, const short* __restrict__ keys, int n,
@@ -249,6 +541,12 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
   float* sx = reinterpret_cast<float*>(skey + kMaxSlice);
   float* sy = sx + kMaxSlice;
   float* sz = sy + kMaxSlice;
+  // std::sort's order of equal keys (libstdcxx_sort_arrangement): eight arrays of kMaxSlice + 8 u16
+  unsigned short* u16_base = reinterpret_cast<unsigned short*>(sz + kMaxSlice);
+  constexpr int kU16 = kMaxSlice + 8;
+  const SortScratch sort_scratch{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
+                                 u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16};
+  unsigned short* idx_of = u16_base + 7 * kU16;  // arrangement position -> position in the slice
   __shared__ unsigned wave_sums[kThreads / 64];
   __shared__ unsigned sh_bin, sh_count, sh_begin, sh_valid, sh_written;
   __shared__ float sh_centroid[3];
@@ -381,75 +679,59 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     }
     __syncthreads();
     DLIOM_STAMP(3);
+    bitonic_sort_keys(skey, pow2);
+    const int m = static_cast<int>(sh_valid);
+    // equal angles next to each other: their order is std::sort's, not ours
+    bool tied = false;
     {
-      // bitonic sort, up to four keys per thread in registers (key i = t + r * 1024): exchanges at distance < 64 are lane
-      // shuffles, at distance >= 1024 stay inside the thread, and only the distances 64 .. 512 go through LDS
-      constexpr int kR = kMaxSlice / kThreads;
-      const int rows = max(1, pow2 / kThreads);  // keys per thread in use
-      unsigned long long v[kR];
+      int t = 0;
+      for (int j = threadIdx.x; j + 1 < m; j += kThreads) t |= (skey[j] >> 32) == (skey[j + 1] >> 32) ? 1 : 0;
+      tied = __syncthreads_or(t) != 0;
+    }
+    if (tied) {
+      // std::sort's input: the valid (angle, position) pairs in input order (blocked: thread t owns positions 4 t ...)
+      const float cx = sh_centroid[0], cy = sh_centroid[1];
+      const int p0 = 4 * static_cast<int>(threadIdx.x);
+      unsigned long long item[4];
+      unsigned ok[4];
 #pragma unroll
-      for (int r = 0; r < kR; ++r) {
-        const int i = static_cast<int>(threadIdx.x) + r * kThreads;
-        v[r] = i < pow2 ? skey[i] : ~0ull;
-      }
-      for (int k = 2; k <= pow2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          if (j >= kThreads) {  // partner key in the same thread: rows (0,1),(2,3) for j = 1024, (0,2),(1,3) for j = 2048
-            static_assert(kR == 4, "the in-thread exchanges below are written for four keys per thread");
-            auto exchange = [&](unsigned long long& a, unsigned long long& b, int row) {
-              const int i = static_cast<int>(threadIdx.x) + row * kThreads;
-              const bool up = (i & k) == 0;
-              const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
-              a = up ? lo : hi;
-              b = up ? hi : lo;
-            };
-            if (j == kThreads) {
-              exchange(v[0], v[1], 0);
-              exchange(v[2], v[3], 2);
-            } else {
-              exchange(v[0], v[2], 0);
-              exchange(v[1], v[3], 1);
-            }
-          } else if (j >= 64) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < kR; ++r) {
-              const int i = static_cast<int>(threadIdx.x) + r * kThreads;
-              if (r < rows && i < pow2) skey[i] = v[r];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < kR; ++r) {
-              const int i = static_cast<int>(threadIdx.x) + r * kThreads;
-              if (r < rows && i < pow2) {
-                const unsigned long long other = skey[i ^ j];
-                const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
-                v[r] = keep_min ? (v[r] < other ? v[r] : other) : (v[r] < other ? other : v[r]);
-              }
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < kR; ++r) {
-              if (r >= rows) break;  // uniform
-              const int i = static_cast<int>(threadIdx.x) + r * kThreads;
-              const unsigned lo32 = static_cast<unsigned>(__shfl_xor(static_cast<int>(v[r] & 0xffffffffull), j, 64));
-              const unsigned hi32 = static_cast<unsigned>(__shfl_xor(static_cast<int>(v[r] >> 32), j, 64));
-              const unsigned long long other = (static_cast<unsigned long long>(hi32) << 32) | lo32;
-              const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
-              v[r] = keep_min ? (v[r] < other ? v[r] : other) : (v[r] < other ? other : v[r]);
-            }
+      for (int k = 0; k < 4; ++k) {
+        const int i = p0 + k;
+        ok[k] = 0u;
+        item[k] = 0ull;
+        if (i < count) {
+          const float dx = sx[i] - cx, dy = sy[i] - cy;
+          if (!(norm2(dx, dy) < kMinDistance)) {
+            ok[k] = 1u;
+            item[k] = (static_cast<unsigned long long>(ordered_bits(fd_atan2f(dy, dx))) << 32) | static_cast<unsigned>(i);
           }
         }
       }
       __syncthreads();
+      blocked_prefix(ok, sort_scratch.g, wave_sums);
+      __syncthreads();
 #pragma unroll
-      for (int r = 0; r < kR; ++r) {
-        const int i = static_cast<int>(threadIdx.x) + r * kThreads;
-        if (i < pow2) skey[i] = v[r];
+      for (int k = 0; k < 4; ++k)
+        if (ok[k]) skey[sort_scratch.g[p0 + k]] = item[k];
+      __syncthreads();
+      const bool done = libstdcxx_sort_arrangement(skey, m, sort_scratch, wave_sums);
+      if (!done) {  // std::sort's depth limit: it heap-sorts from there, not reproduced -- refuse, the host path takes the cloud
+        if (threadIdx.x == 0) atomicOr(flags, 4u);
+        continue;
+      }
+      // the final insertion sort is a stable sort of this arrangement: sort (angle, arrangement position)
+      for (int q = threadIdx.x; q < pow2; q += kThreads) {
+        if (q < m) {
+          const unsigned long long it = skey[q];
+          idx_of[q] = static_cast<unsigned short>(it & 0xffffu);
+          skey[q] = (it & 0xffffffff00000000ull) | static_cast<unsigned>(q);
+        } else {
+          skey[q] = ~0ull;
+        }
       }
       __syncthreads();
+      bitonic_sort_keys(skey, pow2);
     }
-    const int m = static_cast<int>(sh_valid);
     DLIOM_STAMP(4);
     // ---- the sorted slice, contiguous (x into the z array -- z is not needed any more -- and y behind the sort keys'
     //      low words is not possible: y goes to a second pass over sy via registers)
@@ -460,7 +742,8 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
       const int j = threadIdx.x + r * kThreads;
       my_py[r] = 0.f;
       if (j < m) {
-        const unsigned idx = static_cast<unsigned>(skey[j]);
+        unsigned idx = static_cast<unsigned>(skey[j]);
+        if (tied) idx = idx_of[idx];
         px_sorted[j] = sx[idx];
         my_py[r] = sy[idx];
       }
@@ -740,18 +1023,78 @@ extern "C" int dliom_exp_rothist_acc_stamps(unsigned long long* out) {
 }
 #endif
 
-extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
-                                                int histogram_size, float* histogram) {
-  using namespace rothist;
-  if (ctx == nullptr || cloud == nullptr || histogram == nullptr || histogram_size <= 0 || histogram_size > 255)
-    return DLIOM_ERR_INVALID_ARGUMENT;
-  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  const int n = static_cast<int>(cloud->n);
-  if (n == 0) {
-    for (int i = 0; i < histogram_size; ++i) histogram[i] = 0.f;
-    return DLIOM_OK;
+namespace dliom {
+namespace rothist {
+// dliom_diag_std_sort_order: the slice kernel's sort (plain sort; on ties std::sort's partitions + stable sort) on bare keys
+__global__ __launch_bounds__(kThreads) void std_sort_order_kernel(const float* __restrict__ keys, int n, int* __restrict__ order,
+                                                                  int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds_dyn[];
+  unsigned long long* skey = lds_dyn;
+  unsigned short* u16_base = reinterpret_cast<unsigned short*>(skey + kMaxSlice);
+  constexpr int kU16 = kMaxSlice + 8;
+  const SortScratch sc{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
+                       u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16};
+  unsigned short* idx_of = u16_base + 7 * kU16;
+  __shared__ unsigned wave_sums[kThreads / 64];
+  int pow2 = 64;
+  while (pow2 < n) pow2 <<= 1;
+  for (int i = threadIdx.x; i < pow2; i += kThreads)
+    skey[i] = i < n ? (static_cast<unsigned long long>(ordered_bits(keys[i])) << 32) | static_cast<unsigned>(i) : ~0ull;
+  __syncthreads();
+  const bool done = libstdcxx_sort_arrangement(skey, n, sc, wave_sums);
+  if (!done) {
+    if (threadIdx.x == 0) *status = 1;
+    return;
   }
-  if (cloud->n > (int64_t{1} << 26)) return DLIOM_ERR_CAPACITY;
+  for (int q = threadIdx.x; q < pow2; q += kThreads) {
+    if (q < n) {
+      const unsigned long long it = skey[q];
+      idx_of[q] = static_cast<unsigned short>(it & 0xffffu);
+      skey[q] = (it & 0xffffffff00000000ull) | static_cast<unsigned>(q);
+    } else {
+      skey[q] = ~0ull;
+    }
+  }
+  __syncthreads();
+  bitonic_sort_keys(skey, pow2);
+  for (int j = threadIdx.x; j < n; j += kThreads) order[j] = idx_of[static_cast<unsigned>(skey[j]) & 0xffffu];
+  if (threadIdx.x == 0) *status = 0;
+}
+}  // namespace rothist
+}  // namespace dliom
+
+extern "C" int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int n, int32_t* order) {
+  using namespace rothist;
+  if (ctx == nullptr || (n > 0 && (keys == nullptr || order == nullptr)) || n < 0 || n > kMaxSlice) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DLIOM_OK;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_TRY(ctx->misc.reserve(static_cast<size_t>(kMaxSlice) * 8 + 256));
+  float* d_keys = ctx->misc.as<float>();
+  int* d_order = reinterpret_cast<int*>(d_keys + kMaxSlice);
+  int* d_status = d_order + kMaxSlice;
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_keys, keys, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, ctx->stream));
+  const size_t lds = static_cast<size_t>(kMaxSlice) * 8 + 8 * static_cast<size_t>(kMaxSlice + 8) * 2;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(std_sort_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(lds)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(std_sort_order_kernel, dim3(1), dim3(kThreads), lds, ctx->stream, d_keys, n, d_order, d_status);
+  DLIOM_HIP_TRY(hipGetLastError());
+  int status = 0;
+  DLIOM_HIP_TRY(hipMemcpyAsync(order, d_order, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return status == 0 ? DLIOM_OK : DLIOM_ERR_CAPACITY;  // std::sort's depth limit (heap sort from there): not reproduced
+}
+
+namespace {
+// Enqueues the three kernels and the read-back of [histogram | flags] into `pinned_dst` on `stream`; no synchronisation.
+int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch, void* pinned_dst, const dliom_cloud* cloud,
+                      const float rotation_wxyz[4], int histogram_size) {
+  using namespace rothist;
+  const int n = static_cast<int>(cloud->n);
   // scratch: [rx | ry | rz | c_value] floats, [keys] shorts (padded to 512), [c_bucket] bytes (padded to 1024),
   // [bin_counts | flags], [histogram]
   const size_t N = static_cast<size_t>(n);
@@ -761,8 +1104,8 @@ extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_clou
   const size_t b_bytes = n_padded;
   const size_t counts_bytes = (kBins + 64) * 4;
   const size_t hist_bytes = 1024;
-  DLIOM_TRY(ctx->misc.reserve(4 * f_bytes + k_bytes + b_bytes + counts_bytes + hist_bytes));
-  char* base = static_cast<char*>(ctx->misc.p);
+  DLIOM_TRY(scratch.reserve(4 * f_bytes + k_bytes + b_bytes + counts_bytes + hist_bytes));
+  char* base = static_cast<char*>(scratch.p);
   float* rx = reinterpret_cast<float*>(base);
   float* ry = reinterpret_cast<float*>(base + f_bytes);
   float* rz = reinterpret_cast<float*>(base + 2 * f_bytes);
@@ -774,14 +1117,14 @@ extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_clou
   float* d_hist = reinterpret_cast<float*>(base + 4 * f_bytes + k_bytes + b_bytes + counts_bytes);
   {
     const FillJob fills[2] = {{bin_counts, counts_bytes, 0u}, {c_bucket, b_bytes, 0xFFFFFFFFu}};  // bucket 255 = no entry
-    DLIOM_TRY(fill_multi(ctx, fills, 2));
+    DLIOM_TRY(fill_multi(ctx, fills, 2, stream));
   }
   Quat4 q{1.f, 0.f, 0.f, 0.f};
   if (rotation_wxyz != nullptr) q = Quat4{rotation_wxyz[0], rotation_wxyz[1], rotation_wxyz[2], rotation_wxyz[3]};
   const unsigned blocks = static_cast<unsigned>((N + kThreads - 1) / kThreads);
-  hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(kThreads), 0, ctx->stream, cloud->d_x, cloud->d_y, cloud->d_z, n, q,
+  hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(kThreads), 0, stream, cloud->d_x, cloud->d_y, cloud->d_z, n, q,
                      rotation_wxyz != nullptr ? 1 : 0, rx, ry, rz, keys, bin_counts, flags);
-  const size_t lds = static_cast<size_t>(kMaxSlice) * (8 + 12) + 1024;
+  const size_t lds = static_cast<size_t>(kMaxSlice) * (8 + 12) + 8 * static_cast<size_t>(kMaxSlice + 8) * 2 + 1024;
   const size_t acc_lds = static_cast<size_t>(kAccCap + 64) * 4;
   static thread_local bool attr_set = false;
   if (!attr_set) {
@@ -798,19 +1141,73 @@ extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_clou
     while (!(std::sqrt(s2) > kMaxDistance)) s2 = std::nextafter(s2, 2.f);
     return s2;
   }();
-  hipLaunchKernelGGL(slice_kernel, dim3(256), dim3(kThreads), lds, ctx->stream, rx, ry, rz, keys, n, bin_counts, histogram_size,
+  hipLaunchKernelGGL(slice_kernel, dim3(256), dim3(kThreads), lds, stream, rx, ry, rz, keys, n, bin_counts, histogram_size,
                      squared_jump, c_bucket, c_value, flags);
-  hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64 * kAccWaves), acc_lds, ctx->stream, c_bucket, c_value,
-                     static_cast<int>(n_padded), histogram_size, d_hist);
+  hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64 * kAccWaves), acc_lds, stream, c_bucket,
+                     c_value, static_cast<int>(n_padded), histogram_size, d_hist);
   DLIOM_HIP_TRY(hipGetLastError());
   // one read-back: [histogram | flags] through pinned memory
-  float* h = reinterpret_cast<float*>(static_cast<char*>(ctx->pinned) + 2048);
   const GatherJob back[2] = {{d_hist, static_cast<unsigned>(histogram_size)}, {flags, 1}};
-  DLIOM_TRY(gather_to_pinned(ctx, back, 2, h));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return gather_to_pinned(ctx, back, 2, pinned_dst, stream);
+}
+
+int read_histogram(const void* pinned_src, int histogram_size, float* histogram) {
+  const float* h = static_cast<const float*>(pinned_src);
   unsigned f;
   std::memcpy(&f, h + histogram_size, 4);
   if (f != 0u) return DLIOM_ERR_CAPACITY;  // |z| >= 409.6 m or a slice of more than 4096 points: use dliom_rotational_histogram
   std::memcpy(histogram, h, static_cast<size_t>(histogram_size) * 4);
   return DLIOM_OK;
+}
+}  // namespace
+
+extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
+                                                int histogram_size, float* histogram) {
+  if (ctx == nullptr || cloud == nullptr || histogram == nullptr || histogram_size <= 0 || histogram_size > 255)
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  if (cloud->n == 0) {
+    for (int i = 0; i < histogram_size; ++i) histogram[i] = 0.f;
+    return DLIOM_OK;
+  }
+  if (cloud->n > (int64_t{1} << 26)) return DLIOM_ERR_CAPACITY;
+  void* h = static_cast<char*>(ctx->pinned) + 2048;
+  DLIOM_TRY(enqueue_histogram(ctx, ctx->stream, ctx->misc, h, cloud, rotation_wxyz, histogram_size));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return read_histogram(h, histogram_size, histogram);
+}
+
+// The same in two halves on the context's auxiliary stream: everything enqueued on the context so far is waited for
+// (an event), then the histogram runs BESIDE whatever the caller puts on the context next -- the reference computes it
+// right after InsertIntoSubmap from the same filtered cloud (local_trajectory_builder_3d.cc:590-610); neither writes it.
+extern "C" int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
+                                                      int histogram_size) {
+  if (ctx == nullptr || cloud == nullptr || histogram_size <= 0 || histogram_size > 255) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (ctx->aux_histogram_size != 0) return DLIOM_ERR_INVALID_ARGUMENT;  // one pending histogram per context
+  if (cloud->n > (int64_t{1} << 26)) return DLIOM_ERR_CAPACITY;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->aux_stream == nullptr) {
+    DLIOM_HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    DLIOM_HIP_TRY(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+    DLIOM_HIP_TRY(hipHostMalloc(&ctx->aux_pinned, 4096, hipHostMallocDefault));
+  }
+  if (cloud->n == 0) {
+    std::memset(ctx->aux_pinned, 0, 4096);
+    ctx->aux_histogram_size = histogram_size;
+    return DLIOM_OK;
+  }
+  DLIOM_HIP_TRY(hipEventRecord(ctx->aux_fork, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+  DLIOM_TRY(enqueue_histogram(ctx, ctx->aux_stream, ctx->aux_scratch, ctx->aux_pinned, cloud, rotation_wxyz, histogram_size));
+  ctx->aux_histogram_size = histogram_size;
+  return DLIOM_OK;
+}
+
+extern "C" int dliom_cloud_rotational_histogram_finish(dliom_ctx* ctx, float* histogram) {
+  if (ctx == nullptr || histogram == nullptr || ctx->aux_histogram_size == 0) return DLIOM_ERR_INVALID_ARGUMENT;
+  const int size = ctx->aux_histogram_size;
+  ctx->aux_histogram_size = 0;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+  return read_histogram(ctx->aux_pinned, size, histogram);
 }

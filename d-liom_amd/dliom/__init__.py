@@ -285,6 +285,9 @@ SYMBOLS = [
     ("dliom_rotational_histogram", C.c_int, [_f32p, C.c_int64, C.c_int, _f32p]),
     ("dliom_rotational_histogram_mt", C.c_int, [_f32p, C.c_int64, C.c_int, C.c_int, _f32p]),
     ("dliom_cloud_rotational_histogram", C.c_int, [_vp, _vp, _f32p, C.c_int, _f32p]),
+    ("dliom_cloud_rotational_histogram_begin", C.c_int, [_vp, _vp, _f32p, C.c_int]),
+    ("dliom_cloud_rotational_histogram_finish", C.c_int, [_vp, _f32p]),
+    ("dliom_diag_std_sort_order", C.c_int, [_vp, _f32p, C.c_int, C.POINTER(C.c_int32)]),
     ("dliom_rotational_scan_match", C.c_int, [_f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
@@ -1232,6 +1235,29 @@ def cloud_rotational_histogram(ctx, cloud, histogram_size, rotation_wxyz=None):
     rot = None if rotation_wxyz is None else _p(_f32(rotation_wxyz), _f32p)
     _check(load_library().dliom_cloud_rotational_histogram(ctx.h, cloud.h, rot, int(histogram_size), _p(out, _f32p)),
            "dliom_cloud_rotational_histogram")
+    return out
+
+
+def cloud_rotational_histogram_begin(ctx, cloud, histogram_size, rotation_wxyz=None):
+    """First half of cloud_rotational_histogram: the kernels go onto the context's auxiliary stream and the call returns."""
+    rot = None if rotation_wxyz is None else _p(_f32(rotation_wxyz), _f32p)
+    _check(load_library().dliom_cloud_rotational_histogram_begin(ctx.h, cloud.h, rot, int(histogram_size)),
+           "dliom_cloud_rotational_histogram_begin")
+
+
+def cloud_rotational_histogram_finish(ctx, histogram_size):
+    """Second half: waits for the pending histogram of the context and returns it."""
+    out = np.zeros(histogram_size, dtype=np.float32)
+    _check(load_library().dliom_cloud_rotational_histogram_finish(ctx.h, _p(out, _f32p)), "dliom_cloud_rotational_histogram_finish")
+    return out
+
+
+def diag_std_sort_order(ctx, keys):
+    """dliom_diag_std_sort_order: the device's restatement of std::sort's order (ties included) for <= 4096 keys."""
+    keys = _f32(keys).reshape(-1)
+    out = np.zeros(len(keys), dtype=np.int32)
+    _check(load_library().dliom_diag_std_sort_order(ctx.h, _p(keys, _f32p), len(keys), out.ctypes.data_as(C.POINTER(C.c_int32))),
+           "dliom_diag_std_sort_order")
     return out
 
 

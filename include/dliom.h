@@ -527,6 +527,18 @@ int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram
  * DLIOM_ERR_CAPACITY: |z| >= 409.6 m or more than 4096 points in one slice -- use the host function. */
 int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
                                      int histogram_size, float* histogram);
+/* The same in two halves: _begin enqueues the kernels on an auxiliary stream of the context, behind everything the
+ * context has been given so far, and returns; the caller may then put other work on the context (the adapter inserts
+ * the scan into the submaps, local_trajectory_builder_3d.cc:590-604 -- neither step writes the filtered cloud);
+ * _finish waits for the histogram only.  One histogram may be pending per context; the cloud must stay alive until
+ * _finish.  Status of the limits (DLIOM_ERR_CAPACITY, see above) comes from _finish. */
+int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
+                                           int histogram_size);
+int dliom_cloud_rotational_histogram_finish(dliom_ctx* ctx, float* histogram);
+/* Diagnostic: indices of n <= 4096 float keys in the order the device's SortSlice leaves them -- libstdc++'s std::sort
+ * on (key, index) pairs compared by key only, EQUAL keys included (introsort's partitions restated as data-parallel
+ * rounds, its heap sort at the depth limit, and a stable sort for the final insertion sort). */
+int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int n, int32_t* order);
 /* The same with an explicit number of host threads (0 = as many as pay, at most 8; the bits do not depend on it). */
 int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n, int histogram_size, int num_threads, float* histogram);
 /* RotationalScanMatcher(histograms_at_angles).Match(histogram, initial_angle, angles)

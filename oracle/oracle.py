@@ -132,6 +132,7 @@ def _declare(L):
     sig("orc_fast_csm_match_3dof", None, vp, _f64p, _f64p, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_float,
         _f64p, _f64p)
     sig("orc_compute_histogram", None, _f32p, C.c_int, C.c_int, _f32p)
+    sig("orc_std_sort_order", None, _f32p, C.c_int, C.POINTER(C.c_int))
     sig("orc_accumulator_new", C.c_void_p)
     sig("orc_accumulator_free", None, C.c_void_p)
     sig("orc_accumulator_add", None, C.c_void_p, _f64p, _f64p, _f64p, _f32p, C.c_int, _i32p, _f32p, C.c_int, _f32p)
@@ -739,6 +740,14 @@ def compute_histogram(pts, histogram_size):
     pts = _f32(pts).reshape(-1, 3)
     out = np.zeros(histogram_size, dtype=np.float32)
     lib().orc_compute_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p))
+    return out
+
+
+def std_sort_order(keys):
+    """Indices in the order std::sort (this machine's libstdc++) leaves (key, index) pairs compared by key only."""
+    keys = _f32(keys).reshape(-1)
+    out = np.zeros(len(keys), dtype=np.int32)
+    lib().orc_std_sort_order(_p(keys, _f32p), len(keys), out.ctypes.data_as(C.POINTER(C.c_int)))
     return out
 
 

@@ -722,6 +722,19 @@ void orc_compute_histogram(const float* pts, int n, int histogram_size, float* o
   const Histogram h = ComputeHistogram(ToCloud(pts, n), histogram_size);
   std::memcpy(out, h.data(), sizeof(float) * histogram_size);
 }
+// The order this machine's std::sort leaves (key, index) pairs in when compared by key only -- SortSlice's comparison
+// (rotational_scan_matcher.cc:97-121); what the device's restatement of introsort is checked against.
+void orc_std_sort_order(const float* keys, int n, int* order) {
+  struct Pair {
+    float key;
+    int id;
+    bool operator<(const Pair& o) const { return key < o.key; }
+  };
+  std::vector<Pair> v(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) v[static_cast<size_t>(i)] = Pair{keys[i], i};
+  std::sort(v.begin(), v.end());
+  for (int i = 0; i < n; ++i) order[i] = v[static_cast<size_t>(i)].id;
+}
 // MotionFilter (mapping/internal/motion_filter.cc:40-58) as an object, for motion_filter_test.cc.
 void* orc_motion_filter_create(double max_time_seconds, double max_distance_meters, double max_angle_radians) {
   return new MotionFilter(MotionFilterOptions{max_time_seconds, max_distance_meters, max_angle_radians});

@@ -102,3 +102,25 @@ def oracle_cells_sorted(og):
     key = ((xyz[:, 0] + (1 << 20)) << 42) | ((xyz[:, 1] + (1 << 20)) << 21) | (xyz[:, 2] + (1 << 20))
     order = np.argsort(key)
     return key[order], np.asarray(v)[order]
+
+
+def slice_angle_arrays(pts):
+    """The angle arrays SortSlice hands to std::sort for a cloud (rotational_scan_matcher.cc:97-121,159-165), in exact
+    float32 arithmetic: slices by lround(z / 0.2f) in input order, sequential float centroid, points closer than 0.2 m
+    to it skipped, atan2f of this machine's libm."""
+    pts = np.asarray(pts, np.float32)
+    q = (pts[:, 2] / np.float32(0.2)).astype(np.float64)
+    keys = np.where(q >= 0, np.floor(q + 0.5), -np.floor(-q + 0.5)).astype(int)
+    out = []
+    for key in np.unique(keys):
+        s = pts[keys == key]
+        c = np.zeros(3, np.float32)
+        for p in s:
+            c = (c + p).astype(np.float32)
+        c = (c / np.float32(len(s))).astype(np.float32)
+        d = (s[:, :2] - c[:2]).astype(np.float32)
+        nrm = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
+        ang = np.arctan2(d[~(nrm < np.float32(0.2)), 1], d[~(nrm < np.float32(0.2)), 0]).astype(np.float32)
+        if len(ang) > 1:
+            out.append(ang)
+    return out

@@ -4,6 +4,7 @@ fail loudly (no silent fallback) when there is no device."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -305,6 +306,30 @@ def test_device_atan2f_restatement_equals_this_machines_libm(tmp_path):
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(root, "tests", "cpp", "atan2f_pin.c"), "-lm"])
     out = subprocess.run([exe, "3000000"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "mismatches: 0 of 3000000" in out.stdout, out.stdout
+
+
+def test_std_sort_as_data_parallel_rounds_equals_this_machines_std_sort(tmp_path):
+    """tests/cpp/std_sort_model.cc: the formulation rotational_histogram.hip uses for the order std::sort leaves equal
+    keys in (introsort's partitions as rounds of data-parallel steps + a stable sort) against the real std::sort of this
+    libstdc++, 3 000 arrays of 0 ... 4 096 elements full of ties."""
+    exe = tmp_path / "std_sort_model"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "std_sort_model.cc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), src], check=True)
+    # ... and the slices of two synthetic scans: in input order they are close to a worst case of the median-of-three,
+    # std::sort runs into its depth limit on about one in four and heap-sorts there (restated as well)
+    from dliom import synth
+    from helpers import slice_angle_arrays
+    from oracle import oracle as orc
+    slices = tmp_path / "slices.txt"
+    with open(slices, "w") as f:
+        for k in range(2):
+            raw, _ = synth.scan(synth.trajectory_pose(0.4 + 0.3 * k), 64, 1024)
+            for a in slice_angle_arrays(raw[orc.voxel_filter(0.15, raw)]):
+                f.write("%d\n%s\n" % (len(a), " ".join("%08x" % b for b in a.view(np.uint32))))
+    out = subprocess.run([str(exe), "3000", str(slices)], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches: 0 of 3000" in out.stdout, out.stdout
+    reached = int(re.search(r"depth limit reached in (\d+)", out.stdout).group(1))
+    assert reached >= 5, out.stdout  # the heap-sort path is exercised
 
 
 def test_rotational_scan_match_equals_oracle(orc):

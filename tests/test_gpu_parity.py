@@ -1353,3 +1353,117 @@ def test_device_rotational_histogram_limits(dl, ctx):
     empty = dl.PointCloud(ctx, np.zeros((0, 3), np.float32))
     assert np.array_equal(dl.cloud_rotational_histogram(ctx, empty, 16), np.zeros(16, np.float32))
     empty.close()
+
+
+def test_device_std_sort_order_equals_libstdcxx(dl, ctx, orc):
+    """dliom_diag_std_sort_order against the real std::sort (oracle, this machine's libstdc++) on arrays full of ties."""
+    rng = np.random.RandomState(17)
+    sizes = [1, 2, 15, 16, 17, 18, 33, 64, 65, 100, 257, 700, 1000, 2047, 2048, 2049, 4095, 4096]
+    for trial in range(72):
+        n = sizes[trial % len(sizes)]
+        kind = trial % 6
+        if kind == 0:
+            keys = rng.randint(0, 3, n)
+        elif kind == 1:
+            keys = rng.randint(0, 50, n)
+        elif kind == 2:
+            keys = rng.randint(0, n // 2 + 1, n)
+        elif kind == 3:
+            keys = rng.uniform(-3.2, 3.2, n)
+        elif kind == 4:
+            keys = np.arange(n) // 7
+        else:
+            keys = (n - np.arange(n)) // 3
+        keys = keys.astype(np.float32)
+        if kind == 3 and n > 4:
+            keys[rng.randint(0, n, n // 4)] = keys[rng.randint(0, n, n // 4)]  # some exact duplicates among distinct values
+            keys[0] = -0.0
+            keys[1] = 0.0
+        got = dl.diag_std_sort_order(ctx, keys)
+        want = orc.std_sort_order(keys)
+        assert np.array_equal(got, want), (trial, n, kind, int((got != want).sum()))
+    # the slices of a real scan (one in four runs std::sort into its depth limit: heap sort)
+    from dliom import synth
+    from helpers import slice_angle_arrays
+    raw, _ = synth.scan(synth.trajectory_pose(0.7), 64, 1024)
+    arrays = slice_angle_arrays(raw[orc.voxel_filter(0.15, raw)])
+    assert len(arrays) > 30
+    for a in arrays:
+        assert np.array_equal(dl.diag_std_sort_order(ctx, a), orc.std_sort_order(a)), len(a)
+
+
+def test_device_rotational_histogram_reproduces_std_sorts_order_of_equal_angles(dl, ctx, orc):
+    """SortSlice sorts by angle only, and the order std::sort leaves EQUAL angles in decides `last_point`
+    (rotational_scan_matcher.cc:97-121,61-92).  Three scans out of four hold a slice with two returns at the same angle;
+    sorted by (angle, position) instead of by libstdc++'s introsort the histogram of about one scan in ten is off by a
+    whole contribution in some bucket (found in round 3 with the first rotation below).  The device replays introsort's
+    partitions (tests/cpp/std_sort_model.cc is the same formulation on the CPU): 14 scans x rotations, bit for bit."""
+    from dliom import synth
+    first = np.array([0.998, 0.02, -0.03, 0.05], np.float32)
+    first /= np.linalg.norm(first)
+    checked = 0
+    for k in range(14):
+        raw, _ = synth.scan(synth.trajectory_pose(0.4 + 0.1 * (k % 7)), 64, 1024)
+        pts = raw[orc.voxel_filter(0.15, raw)]
+        rot = first if k == 0 else synth.perturb_pose(np.array([0, 0, 0, 1, 0, 0, 0], float), 0.0, 3.0, seed=300 + k)[3:].astype(np.float32)
+        cloud = dl.PointCloud(ctx, pts)
+        got = dl.cloud_rotational_histogram(ctx, cloud, 120, rotation_wxyz=rot)
+        aligned = orc.transform_points(np.concatenate([np.zeros(3, np.float32), rot]), pts)
+        want = np.asarray(orc.compute_histogram(aligned, 120), np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, int((got != want).sum()), float(np.abs(got - want).max()))
+        cloud.close()
+        checked += 1
+    assert checked == 14
+    # a cloud made of ties: returns on 90 rays from the origin, four ranges each, a symmetric set (centroid = origin up to
+    # rounding) -- every slice is full of equal angles
+    ang = np.repeat(np.arange(90) * (2 * np.pi / 90), 8)
+    rad = np.tile(np.array([4.0, 6.0, 8.0, 10.0, 4.0, 6.0, 8.0, 10.0]), 90)
+    z = np.tile(np.array([0.01, 0.01, 0.01, 0.01, 0.25, 0.25, 0.25, 0.25]), 90)
+    rays = np.stack([rad * np.cos(ang), rad * np.sin(ang), z], axis=1).astype(np.float32)
+    rays = rays[np.random.RandomState(8).permutation(len(rays))]
+    cloud = dl.PointCloud(ctx, rays)
+    got = dl.cloud_rotational_histogram(ctx, cloud, 120)
+    want = np.asarray(orc.compute_histogram(rays, 120), np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    cloud.close()
+
+
+@pytest.mark.gpu
+def test_device_rotational_histogram_in_two_halves(dl, ctx, orc):
+    """dliom_cloud_rotational_histogram_begin / _finish: the histogram runs on the context's auxiliary stream beside
+    whatever the context is given meanwhile (here: insertions into two grids and a voxel filter of the same cloud) and
+    equals the blocking call bit for bit; one pending histogram per context; the limits report at _finish."""
+    from dliom import synth
+    raw, _ = synth.scan(synth.trajectory_pose(0.4), 64, 1024)
+    pts = raw[orc.voxel_filter(0.15, raw)]
+    cloud = dl.PointCloud(ctx, pts)
+    rot = synth.perturb_pose(np.array([0, 0, 0, 1, 0, 0, 0], float), 0.0, 3.0, seed=4)[3:].astype(np.float32)
+    want = dl.cloud_rotational_histogram(ctx, cloud, 120, rotation_wxyz=rot)  # == oracle: the test above
+    assert want.sum() > 0
+    ins = dl.RangeDataInserter3D(0.55, 0.49, 2, ctx=ctx)
+    g_hi, g_lo = dl.HybridGrid(ctx, 0.1), dl.HybridGrid(ctx, 0.45)
+    pose = synth.trajectory_pose(0.4).astype(np.float32)
+    for rep in range(3):
+        dl.cloud_rotational_histogram_begin(ctx, cloud, 120, rotation_wxyz=rot)
+        with pytest.raises(dl.DliomError):  # one pending histogram per context
+            dl.cloud_rotational_histogram_begin(ctx, cloud, 120, rotation_wxyz=rot)
+        dl.insert_cloud_multi(ins, cloud, [(g_hi, [pose], 20.0), (g_lo, [pose], 0.0)])
+        filtered = dl.voxel_filter_cloud(ctx, cloud, 0.3) if hasattr(dl, "voxel_filter_cloud") else None
+        got = dl.cloud_rotational_histogram_finish(ctx, 120)
+        assert np.array_equal(got, want), rep
+        if filtered is not None:
+            filtered.close()
+    with pytest.raises(dl.DliomError):  # nothing pending
+        dl.cloud_rotational_histogram_finish(ctx, 120)
+    high = dl.PointCloud(ctx, np.array([[1, 0, 500.0], [2, 0, 0]], dtype=np.float32))
+    dl.cloud_rotational_histogram_begin(ctx, high, 120)
+    with pytest.raises(dl.DliomError) as e:
+        dl.cloud_rotational_histogram_finish(ctx, 120)
+    assert e.value.status == dl.ERR_CAPACITY
+    empty = dl.PointCloud(ctx, np.zeros((0, 3), np.float32))
+    dl.cloud_rotational_histogram_begin(ctx, empty, 16)
+    assert np.array_equal(dl.cloud_rotational_histogram_finish(ctx, 16), np.zeros(16, np.float32))
+    for c in (cloud, high, empty):
+        c.close()
+    g_hi.close()
+    g_lo.close()

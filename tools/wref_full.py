@@ -96,15 +96,21 @@ def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, hist
             window.initialize(matched, pv, np.zeros(6))
             est, vel, bias = matched, pv, np.zeros(6)
         t4 = time.perf_counter()
+        if device:  # the histogram's kernels run beside the insertion (both only read the filtered cloud): begin / finish
+            dl.cloud_rotational_histogram_begin(ctx, cloud, histogram_size, rotation_wxyz=est[3:].astype(np.float32))
         ins = fe.insert(int(k * 1e6), est, est[3:])
         if device:
             ctx.synchronize()
         t5 = time.perf_counter()
         hist = None
         inserted = bool(ins["inserted"]) if isinstance(ins, dict) else bool(ins)  # the oracle's insert returns the flag itself
+        if device:
+            hist = dl.cloud_rotational_histogram_finish(ctx, histogram_size)
+            if not inserted:
+                hist = None
         if inserted:  # the histogram belongs to the TrajectoryNode of an inserted scan (:605-610)
             if device:
-                hist = dl.cloud_rotational_histogram(ctx, cloud, histogram_size, rotation_wxyz=est[3:].astype(np.float32))
+                pass
             else:
                 rot = np.concatenate([np.zeros(3), est[3:]]).astype(np.float32)
                 hist = orc.compute_histogram(orc.transform_points(rot, ref["returns_in_tracking"]), histogram_size)
