@@ -309,6 +309,61 @@ __device__ inline void heap_sort_keys(unsigned long long* first, int len) {
   }
 }
 
+// std::__introsort_loop as written (bits/stl_algo.h), one thread on its own segment: used for the tail of the rounds
+// below, when only a few small segments are left above the threshold (an unlucky path of the recursion can go on for
+// 2 lg n partitions while everything else has long been done).  The recursion on [cut, last) is an explicit stack; the
+// two halves are disjoint, so the order they are worked in does not matter.
+__device__ inline void introsort_loop_sequential(unsigned long long* a, int first, int last, int depth) {
+  int st_first[40], st_last[40], st_depth[40];
+  int sp = 0;
+  for (;;) {
+    while (last - first > 16) {
+      if (depth == 0) {
+        heap_sort_keys(a + first, last - first);
+        break;
+      }
+      --depth;
+      {
+        const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+        const unsigned ka = static_cast<unsigned>(a[ia] >> 32), kb = static_cast<unsigned>(a[ib] >> 32), kc = static_cast<unsigned>(a[ic] >> 32);
+        int md;
+        if (ka < kb) {
+          if (kb < kc) md = ib;
+          else if (ka < kc) md = ic;
+          else md = ia;
+        } else if (ka < kc) md = ia;
+        else if (kb < kc) md = ic;
+        else md = ib;
+        const unsigned long long t = a[first];
+        a[first] = a[md];
+        a[md] = t;
+      }
+      const unsigned pivot = static_cast<unsigned>(a[first] >> 32);
+      int f = first + 1, l = last;
+      for (;;) {
+        while (static_cast<unsigned>(a[f] >> 32) < pivot) ++f;
+        --l;
+        while (pivot < static_cast<unsigned>(a[l] >> 32)) --l;
+        if (!(f < l)) break;
+        const unsigned long long t = a[f];
+        a[f] = a[l];
+        a[l] = t;
+        ++f;
+      }
+      st_first[sp] = f;  // std::__introsort_loop(cut, last, depth_limit) ...
+      st_last[sp] = last;
+      st_depth[sp] = depth;
+      ++sp;
+      last = f;          // ... and last = cut
+    }
+    if (sp == 0) return;
+    --sp;
+    first = st_first[sp];
+    last = st_last[sp];
+    depth = st_depth[sp];
+  }
+}
+
 __device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const SortScratch& sc, unsigned* wave_sums) {
   static_assert(kMaxSlice == 4 * kThreads, "four positions per thread");
   const int p0 = 4 * static_cast<int>(threadIdx.x);
@@ -322,14 +377,24 @@ __device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const S
   }
   __syncthreads();
   for (;;) {
-    // any segment above the threshold?
-    int large = 0;
+    // threads that own a position inside a segment above the threshold (<= 4 positions each)
+    int inside = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int p = p0 + k;
-      if (p < m && sc.seg_first[p] == p && sc.seg_last[p] - p > 16) large = 1;
+      if (p < m && sc.seg_last[p] - sc.seg_first[p] > 16) inside = 1;
     }
-    if (!__syncthreads_or(large)) return true;
+    const int busy_threads = __syncthreads_count(inside);
+    if (busy_threads == 0) return true;
+    if (busy_threads <= 96 && depth > 0) {  // <= 384 elements left: the rest of the recursion sequentially, a thread per segment
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k;
+        if (p < m && sc.seg_first[p] == p && sc.seg_last[p] - p > 16) introsort_loop_sequential(a, p, sc.seg_last[p], depth);
+      }
+      __syncthreads();
+      return true;
+    }
     if (depth == 0) {
       // std::sort's depth limit (2 lg n partitions on one path): it heap-sorts what is left of such a segment --
       // std::__partial_sort(first, last, last) = __make_heap + __sort_heap, restated; sequential, one thread per segment.
