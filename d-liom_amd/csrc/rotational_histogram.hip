@@ -1251,10 +1251,22 @@ extern "C" int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dlio
   if (ctx->aux_histogram_size != 0) return DLIOM_ERR_INVALID_ARGUMENT;  // one pending histogram per context
   if (cloud->n > (int64_t{1} << 26)) return DLIOM_ERR_CAPACITY;
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  if (ctx->aux_stream == nullptr) {
-    DLIOM_HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    DLIOM_HIP_TRY(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
-    DLIOM_HIP_TRY(hipHostMalloc(&ctx->aux_pinned, 4096, hipHostMallocDefault));
+  if (ctx->aux_stream == nullptr) {  // all three or none
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    void* pin = nullptr;
+    const bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess &&
+                    hipHostMalloc(&pin, 4096, hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+      if (pin != nullptr) (void)hipHostFree(pin);
+      if (ev != nullptr) (void)hipEventDestroy(ev);
+      if (st != nullptr) (void)hipStreamDestroy(st);
+      return DLIOM_ERR_HIP;
+    }
+    ctx->aux_stream = st;
+    ctx->aux_fork = ev;
+    ctx->aux_pinned = pin;
   }
   if (cloud->n == 0) {
     std::memset(ctx->aux_pinned, 0, 4096);
