@@ -271,6 +271,7 @@ SYMBOLS = [
     ("dliom_imu_window_add_pose", C.c_int, [_vp, _f64p, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_imu_window_state", C.c_int, [_vp, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_imu_window_size", C.c_int, [_vp]),
+    ("dliom_diag_imu_factor_jacobians", C.c_int, [_vp, _f64p, _f64p]),
     ("dliom_imu_window_add_imu_batch", C.c_int, [_vp, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_imu_window_gravity_estimate", C.c_int, [_vp, _f64p, C.POINTER(C.c_int), _i64p]),
     ("dliom_gravity_estimate", C.c_int, [C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_double, _f64p, C.POINTER(C.c_int)]),
@@ -1385,6 +1386,12 @@ class ImuWindow:
         _check(self._L.dliom_imu_window_gravity_estimate(self.h, _p(g, _f64p), C.byref(ok), C.byref(n)),
                "dliom_imu_window_gravity_estimate")
         return g, bool(ok.value), int(n.value)
+
+    def diag_imu_factor_jacobians(self):
+        """(analytic, numeric) 15 x 30 Jacobians of the IMU factor between the two newest states."""
+        a, b = np.zeros((15, 30)), np.zeros((15, 30))
+        _check(self._L.dliom_diag_imu_factor_jacobians(self.h, _p(a, _f64p), _p(b, _f64p)), "dliom_diag_imu_factor_jacobians")
+        return a, b
 
 
 def gravity_estimate(poses7, delta_t, delta_p, delta_v, velocities, gravity_norm, lidar_in_imu_translation=(0.0, 0.0, 0.0)):

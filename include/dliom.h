@@ -637,6 +637,9 @@ int dliom_imu_window_add_pose(dliom_imu_window* window, const double matched_pos
 int dliom_imu_window_state(const dliom_imu_window* window, int states_back, double pose7[7], double velocity[3],
                            double bias6[6]);
 int dliom_imu_window_size(const dliom_imu_window* window);
+/* Diagnostic: Jacobian (15 x 30, row major) of the IMU factor + bias random walk between the window's two newest
+ * states -- the closed form the solver uses and central differences of its residual.  Needs >= 2 states. */
+int dliom_diag_imu_factor_jacobians(dliom_imu_window* window, double* analytic, double* numeric);
 /* g_vec_est_G_ of the last EstimateGravity() (local_trajectory_builder_3d.cc:1106-1154), whether that call passed the
  * reference's gates, and how many gravity factors add_pose has added so far */
 int dliom_imu_window_gravity_estimate(const dliom_imu_window* window, double gravity_in_global[3], int* valid,

@@ -372,3 +372,25 @@ def test_graph_reset_with_the_gravity_factor_runs_and_validates(dl):
         assert np.linalg.norm(out_pose[:3] - pose[:3]) < 5e-3
         factors.append(w.gravity_estimate()[2])
     assert factors[-1] > factors[5] > 0  # factors keep coming after the resets at keys 6, 12, 18
+
+
+def test_analytic_imu_factor_jacobian_equals_central_differences(dl):
+    """The solver's closed-form Jacobian of the IMU factor (+ bias random walk) against central differences of its own
+    residual, on states away from the linearisation point (large rotation residual, bias offsets): every block."""
+    from dliom import synth
+    worst = 0.0
+    for seed in range(6):
+        rng = np.random.RandomState(40 + seed)
+        w = dl.ImuWindow(window_size=6, iterations=1)
+        st = synth.trajectory_state(0.0)
+        w.initialize(st[:7], st[7:10], rng.normal(0, [0.05] * 3 + [0.01] * 3))
+        for k in (1, 2):
+            _feed(w, None, k, 0.1, synth, bias=(rng.normal(0, 0.05, 3), rng.normal(0, 0.01, 3)), noise=(0.05, 0.005))
+            matched = synth.perturb_pose(synth.trajectory_pose(0.1 * k), 0.3, 8.0, seed=seed * 10 + k)  # far off: big residuals
+            _, _, _, status = w.add_pose(matched)
+            assert status == 0
+        a, n = w.diag_imu_factor_jacobians()
+        scale = np.maximum(np.abs(n).max(axis=1, keepdims=True), 1.0)
+        worst = max(worst, float((np.abs(a - n) / scale).max()))
+        assert np.abs(a).max() > 1.0
+    assert worst < 2e-6, worst
