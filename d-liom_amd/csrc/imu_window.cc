@@ -709,23 +709,54 @@ void pose_prior_jacobian(const dliom_imu_window::PosePrior& f, const State& s, d
     }
 }
 
-// J^T J and J^T r of a factor on states ia, ib (ib may be -1) from its residual and its rows x (15 or 30) Jacobian.
-void accumulate_factor(int ia, int ib, int rows, const double* r0, const double* J, std::vector<double>& H, std::vector<double>& g,
-                       int n) {
-  const int cols = ib >= 0 ? 2 * kD : kD;
-  for (int c1 = 0; c1 < cols; ++c1) {
-    const int g1 = (c1 < kD ? ia : ib) * kD + c1 % kD;
+// J^T J and J^T r of the two factor shapes that make up almost all of a window, without the structural zeros: the IMU
+// factor's nine whitened rows do not touch the second state's biases and its six bias rows have two entries each; the
+// pose prior is two 3 x 3 blocks.  Same products, same order within every sum that is not a structural zero.
+void accumulate_imu_factor(int ia, const double* r0, const double* J /* 15 x 30 */, std::vector<double>& H, std::vector<double>& g,
+                           int n) {
+  const int base_a = ia * kD, base_b = (ia + 1) * kD;
+  auto gi = [&](int c) { return c < kD ? base_a + c : base_b + (c - kD); };
+  for (int c1 = 0; c1 < 24; ++c1) {  // columns 24 .. 29 (ba_b, bg_b) are zero in rows 0 .. 8
+    const int g1 = gi(c1);
     double s = 0;
-    for (int i = 0; i < rows; ++i) s += J[static_cast<size_t>(i) * cols + c1] * r0[i];
+    for (int i = 0; i < 9; ++i) s += J[30 * i + c1] * r0[i];
     g[g1] += s;
-    for (int c2 = c1; c2 < cols; ++c2) {
-      const int g2 = (c2 < kD ? ia : ib) * kD + c2 % kD;
+    for (int c2 = c1; c2 < 24; ++c2) {
+      const int g2 = gi(c2);
       double h = 0;
-      for (int i = 0; i < rows; ++i) h += J[static_cast<size_t>(i) * cols + c1] * J[static_cast<size_t>(i) * cols + c2];
+      for (int i = 0; i < 9; ++i) h += J[30 * i + c1] * J[30 * i + c2];
       H[static_cast<size_t>(g1) * n + g2] += h;
       if (c2 != c1) H[static_cast<size_t>(g2) * n + g1] += h;
     }
   }
+  for (int i = 9; i < 15; ++i) {  // bias random walk: row i has -1/s at column i (state a) and +1/s at column 15 + i (state b)
+    const int ca = i, cb = kD + i;
+    const double ja = J[30 * i + ca], jb = J[30 * i + cb];
+    const int ga = gi(ca), gb = gi(cb);
+    g[ga] += ja * r0[i];
+    g[gb] += jb * r0[i];
+    H[static_cast<size_t>(ga) * n + ga] += ja * ja;
+    H[static_cast<size_t>(gb) * n + gb] += jb * jb;
+    H[static_cast<size_t>(ga) * n + gb] += ja * jb;
+    H[static_cast<size_t>(gb) * n + ga] += ja * jb;
+  }
+}
+void accumulate_pose_prior(int ia, const double* r0, const double* J /* 6 x 15 */, std::vector<double>& H, std::vector<double>& g, int n) {
+  const int base = ia * kD;
+  for (int blk = 0; blk < 2; ++blk)
+    for (int c1 = 0; c1 < 3; ++c1) {
+      const int g1 = base + 3 * blk + c1;
+      double s = 0;
+      for (int i = 0; i < 3; ++i) s += J[kD * (3 * blk + i) + 3 * blk + c1] * r0[3 * blk + i];
+      g[g1] += s;
+      for (int c2 = c1; c2 < 3; ++c2) {
+        const int g2 = base + 3 * blk + c2;
+        double h = 0;
+        for (int i = 0; i < 3; ++i) h += J[kD * (3 * blk + i) + 3 * blk + c1] * J[kD * (3 * blk + i) + 3 * blk + c2];
+        H[static_cast<size_t>(g1) * n + g2] += h;
+        if (c2 != c1) H[static_cast<size_t>(g2) * n + g1] += h;
+      }
+    }
 }
 
 // Normal equations of every factor in the window at the current estimate.
@@ -750,12 +781,12 @@ bool build(dliom_imu_window& w, std::vector<double>& H, std::vector<double>& g) 
     const Preint& P = w.between[i];
     double r[15], J[15 * 30];
     imu_factor_jacobian(w, P, Linv, w.x[i], w.x[i + 1], r, J);
-    accumulate_factor(i, i + 1, 15, r, J, H, g, n);
+    accumulate_imu_factor(i, r, J, H, g, n);
   }
   for (const auto& f : w.pose_priors) {
     double r[6], J[6 * kD];
     pose_prior_jacobian(f, w.x[f.index], r, J);
-    accumulate_factor(f.index, -1, 6, r, J, H, g, n);
+    accumulate_pose_prior(f.index, r, J, H, g, n);
   }
   for (const auto& f : w.gravity) {
     double r[2], J[2 * kD];
@@ -804,13 +835,13 @@ bool marginalize_oldest(dliom_imu_window& w) {
   {
     double r[15], J[15 * 30];
     imu_factor_jacobian(w, P, Linv, x2[0], x2[1], r, J);
-    accumulate_factor(0, 1, 15, r, J, H, g, n);
+    accumulate_imu_factor(0, r, J, H, g, n);
   }
   for (const auto& f : w.pose_priors)
     if (f.index == 0) {
       double r[6], J[6 * kD];
       pose_prior_jacobian(f, x2[0], r, J);
-      accumulate_factor(0, -1, 6, r, J, H, g, n);
+      accumulate_pose_prior(0, r, J, H, g, n);
     }
   for (const auto& f : w.gravity)
     if (f.index == 0) {
