@@ -114,6 +114,28 @@ def test_config2_dense_rerun_after_box_fault(dl, ctx, orc, bench_scene):
     assert rt.box_error() == 0
 
 
+@pytest.mark.parametrize("n", [50017, 36001, 4129])
+def test_config2_ragged_clouds_through_the_box_kernel(dl, ctx, orc, bench_scene, n):
+    """Cloud sizes that are no multiple of the 32-point chunks the box kernel's dispenser hands out (most expensive first,
+    a permutation built per cloud) nor of anything else: a last partial chunk, an odd number of chunks.  2 000 random
+    candidates' integer sums against the oracle, and the winner."""
+    s = bench_scene
+    sc = s["sc"]
+    pts = sc["pts"][np.sort(np.random.RandomState(n).choice(len(sc["pts"]), n, replace=False))]
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, DEFAULT_RTCSM)
+    sums = rt.score_volume(sc["init"], pts, s["g_hi"])
+    idx = np.random.RandomState(n + 1).randint(0, len(sums), size=2000)
+    want, _ = orc.rtcsm3d_at(DEFAULT_RTCSM, sc["init"], pts, s["og_hi"], idx, threads=THREADS)
+    assert np.array_equal(sums[idx].astype(np.uint64), want)
+    score, pose = rt.Match(sc["init"], pts, s["g_hi"])
+    ref = orc.rtcsm3d_match_parallel(DEFAULT_RTCSM, sc["init"], pts, s["og_hi"], threads=THREADS)
+    st = rt.last_stats()
+    assert st.score_kernel == 3 and st.box_kernel_status == dl.BOX_RAN and st.num_points == n
+    assert st.best_index == ref["best_index"]
+    assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes() and np.array_equal(pose, ref["pose"])
+    assert rt.box_error() == 0
+
+
 def test_config2_every_score_kernel_gives_the_same_volume(dl, ctx, orc, bench_scene):
     """The fallback kernels (dense mirror, leaf table by rotation, leaf table by point: what runs when the search does
     not suit the box kernel or the grid has no mirror) produce the box kernel's volume bit for bit at the bench size."""
