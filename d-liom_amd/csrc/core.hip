@@ -1,6 +1,7 @@
 // Context, scratch memory, status strings, probability-value tables and the
 // device-resident point cloud of libdliom.so.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -362,12 +363,23 @@ struct GatherArgs {
   const unsigned* src[6];
   unsigned words[6];
   unsigned offset[6];
+  unsigned stride[6];
   unsigned* dst;
+  unsigned* done_word;
+  unsigned done_seq;
   int n;
 };
 __global__ __launch_bounds__(256) void gather_to_pinned_kernel(GatherArgs a) {
   for (int j = 0; j < a.n; ++j)
-    for (unsigned i = threadIdx.x; i < a.words[j]; i += 256u) a.dst[a.offset[j] + i] = a.src[j][i];
+    for (unsigned i = threadIdx.x; i < a.words[j]; i += 256u) a.dst[a.offset[j] + i] = a.src[j][static_cast<size_t>(i) * a.stride[j]];
+  if (a.done_word != nullptr) {  // every writer releases its own copies system-wide, then the word
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned*>(a.done_word) = a.done_seq;
+    }
+  }
 }
 }  // namespace
 
@@ -401,7 +413,8 @@ int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs, hipStream_t st
   return DLIOM_OK;
 }
 
-int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst, hipStream_t stream) {
+int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst, hipStream_t stream, unsigned* done_word,
+                     unsigned done_seq) {
   if (num_jobs <= 0) return DLIOM_OK;
   if (stream == nullptr) stream = ctx->stream;
   if (num_jobs > 6 || pinned_dst == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
@@ -410,19 +423,46 @@ int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* 
   for (int j = 0; j < 6; ++j) {
     a.src[j] = nullptr;
     a.words[j] = a.offset[j] = 0;
+    a.stride[j] = 1;
   }
   for (int j = 0; j < num_jobs; ++j) {
     if (jobs[j].words > 1024u) return DLIOM_ERR_INVALID_ARGUMENT;
     a.src[j] = static_cast<const unsigned*>(jobs[j].src);
     a.words[j] = jobs[j].words;
+    a.stride[j] = jobs[j].stride == 0 ? 1 : jobs[j].stride;
     a.offset[j] = off;
     off += jobs[j].words;
   }
   a.dst = static_cast<unsigned*>(pinned_dst);
+  a.done_word = done_word;
+  a.done_seq = done_seq;
   a.n = num_jobs;
   hipLaunchKernelGGL(gather_to_pinned_kernel, dim3(1), dim3(256), 0, stream, a);
   DLIOM_HIP_TRY(hipGetLastError());
   return DLIOM_OK;
+}
+
+int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq) {
+  (void)ctx;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n(done_word, __ATOMIC_ACQUIRE) == done_seq) return DLIOM_OK;
+    if ((spins & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
+  }
+  DLIOM_HIP_TRY(hipStreamSynchronize(stream));
+  return __atomic_load_n(done_word, __ATOMIC_ACQUIRE) == done_seq ? DLIOM_OK : DLIOM_ERR_HIP;
+}
+
+int gather_and_wait(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst) {
+  if (num_jobs <= 0) return DLIOM_OK;
+  if (ctx->done_word == nullptr) {  // no completion word (allocation failed at creation): the plain way
+    DLIOM_TRY(gather_to_pinned(ctx, jobs, num_jobs, pinned_dst));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DLIOM_OK;
+  }
+  const unsigned seq = ++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq;
+  DLIOM_TRY(gather_to_pinned(ctx, jobs, num_jobs, pinned_dst, ctx->stream, ctx->done_word, seq));
+  return wait_done(ctx, ctx->stream, ctx->done_word, seq);
 }
 
 // Cloud allocations are pooled per device: a scan makes four clouds (raw, filtered, high, low) and
@@ -604,6 +644,13 @@ static int ctx_create_common(int device_id, hipStream_t stream, bool owns, dliom
     delete ctx;
     return DLIOM_ERR_HIP;
   }
+  {
+    void* w = nullptr;
+    if (hipHostMalloc(&w, 64, hipHostMallocDefault) == hipSuccess) {  // optional: without it read-backs synchronise fully
+      ctx->done_word = static_cast<unsigned*>(w);
+      *ctx->done_word = 0u;
+    }
+  }
   *out = ctx;
   return DLIOM_OK;
 }
@@ -644,6 +691,7 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   if (ctx->aux_fork != nullptr) (void)hipEventDestroy(ctx->aux_fork);
   if (ctx->aux_stream != nullptr) (void)hipStreamDestroy(ctx->aux_stream);
   if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
+  if (ctx->done_word != nullptr) (void)hipHostFree(ctx->done_word);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return DLIOM_OK;

@@ -183,7 +183,8 @@ __device__ __forceinline__ void csm_point(const CsmPose& a, const CsmCloudArg& c
 __global__ __launch_bounds__(kCsmBlock) void csm_eval_kernel(CsmArgs a, float k_scale, float k_offset,
                                                              float k_unknown,
                                                              double* __restrict__ partials,
-                                                             double* __restrict__ final_out) {
+                                                             double* __restrict__ final_out, unsigned* done_word,
+                                                             unsigned done_seq) {
   double acc[kAcc];
 #pragma unroll
   for (int k = 0; k < kAcc; ++k) acc[k] = 0.;
@@ -219,19 +220,37 @@ __global__ __launch_bounds__(kCsmBlock) void csm_eval_kernel(CsmArgs a, float k_
       if (gridDim.x == 1) final_out[k] = v;  // small problems: this block's sums ARE the result
     }
   }
+  if (gridDim.x == 1 && done_word != nullptr) {  // completion word for the host's poll (internal.h, wait_done)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned*>(done_word) = done_seq;
+    }
+  }
 }
 
 // One wave per accumulated quantity: lane l sums blocks l, l+64, ... then a fixed butterfly --
 // the summation order never changes from run to run.
 __global__ void csm_final_reduce_kernel(const double* __restrict__ partials, int num_blocks,
-                                        double* __restrict__ out) {
+                                        double* __restrict__ out, unsigned* arrivals, unsigned* done_word, unsigned done_seq) {
   const int k = blockIdx.x;
   const int lane = threadIdx.x;
   double s = 0.;
   for (int b = lane; b < num_blocks; b += 64) s += partials[b * kAcc + k];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) out[k] = s;
+  if (lane == 0) {
+    out[k] = s;
+    if (done_word != nullptr) {  // the last of the kAcc waves to get here tells the host (and re-arms the counter)
+      __threadfence_system();
+      if (atomicAdd(arrivals, 1u) == static_cast<unsigned>(kAcc) - 1u) {
+        *arrivals = 0u;
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned*>(done_word) = done_seq;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------- host side
@@ -251,6 +270,7 @@ struct CsmProblem {
   int num_blocks;
   double* d_partials;
   double* d_out;
+  unsigned* d_arrivals;  // zeroed word: csm_final_reduce_kernel's last-wave detection (null: full synchronise)
   int evaluations;
 };
 
@@ -367,14 +387,20 @@ static int evaluate(CsmProblem* p, const double x[7], Normal* out) {
   const int span = ctx->begin_span(DLIOM_KERNEL_CSM_EVAL);
   // the 28 results go straight into pinned host memory (device-visible): no copy command
   double* host = static_cast<double*>(ctx->pinned);
+  // ... and a completion word behind them, which the host polls: ten evaluations a match, 5 us of synchronise each
+  unsigned* done = p->d_arrivals != nullptr ? ctx->done_word : nullptr;
+  const unsigned seq = done != nullptr ? (++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq) : 0u;
   hipLaunchKernelGGL(csm_eval_kernel, dim3(p->num_blocks), dim3(kCsmBlock), 0, ctx->stream, a, k_scale,
-                     k_offset, kMin, p->d_partials, host);
+                     k_offset, kMin, p->d_partials, host, done, seq);
   if (p->num_blocks > 1)
     hipLaunchKernelGGL(csm_final_reduce_kernel, dim3(kAcc), dim3(64), 0, ctx->stream, p->d_partials,
-                       p->num_blocks, host);
+                       p->num_blocks, host, p->d_arrivals, done, seq);
   ctx->end_span(span);
   DLIOM_HIP_TRY(hipGetLastError());
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (done != nullptr)
+    DLIOM_TRY(wait_done(ctx, ctx->stream, done, seq));
+  else
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   ++p->evaluations;
   if (p->nloc == 3)
     finish_normal<3>(host, x, a.pose.plus, p->o->translation_weight, p->o->rotation_weight, p->target_t, p->init_q, out);
@@ -637,6 +663,8 @@ struct LmKernelParams {
   double init_q[4];
   double x0[7];
   float k_scale, k_offset, k_unknown;
+  unsigned* done_word;  // csm_lm_kernel: completion word the host polls (null: full synchronise)
+  unsigned done_seq;
 };
 struct LmKernelOut {
   double x[7];
@@ -752,6 +780,10 @@ __global__ __launch_bounds__(kCsmBlock) void csm_lm_kernel(CsmArgs a, LmKernelPa
     for (int i = 0; i < 7; ++i) out->x[i] = x[i];
     out->summary = sum;
     out->status = status;
+    if (prm.done_word != nullptr) {
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned*>(prm.done_word) = prm.done_seq;
+    }
   }
 }
 
@@ -899,9 +931,12 @@ static int setup_problem(dliom_ctx* ctx, const dliom_csm_options* o, const doubl
   for (int i = 0; i < 3; ++i) p->target_t[i] = target_t[i];
   for (int i = 0; i < 4; ++i) p->init_q[i] = init7[3 + i];
   p->num_blocks = std::max(1, std::min(512, (total + 2 * kCsmBlock - 1) / (2 * kCsmBlock)));
-  DLIOM_TRY(ctx->partials.reserve(static_cast<size_t>(p->num_blocks + 1) * kAcc * sizeof(double)));
+  DLIOM_TRY(ctx->partials.reserve(static_cast<size_t>(p->num_blocks + 1) * kAcc * sizeof(double) + 256));
   p->d_partials = ctx->partials.as<double>();
   p->d_out = p->d_partials + static_cast<size_t>(p->num_blocks) * kAcc;
+  // the word csm_final_reduce_kernel counts its waves in: zero before the first evaluation, re-armed by the kernel itself
+  p->d_arrivals = reinterpret_cast<unsigned*>(p->d_out + kAcc);
+  DLIOM_HIP_TRY(hipMemsetAsync(p->d_arrivals, 0, 4, ctx->stream));
   return DLIOM_OK;
 }
 
@@ -960,6 +995,8 @@ int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* o, const do
     prm.k_offset = kMin - prm.k_scale;
     prm.k_unknown = kMin;
     LmKernelOut* host = reinterpret_cast<LmKernelOut*>(static_cast<char*>(ctx->pinned) + 1024);  // device-visible
+    prm.done_word = ctx->done_word;
+    prm.done_seq = ctx->done_word != nullptr ? (++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq) : 0u;
     const int span = ctx->begin_span(DLIOM_KERNEL_CSM_EVAL);
     if (p.nloc == 3)
       hipLaunchKernelGGL(csm_lm_kernel<3>, dim3(1), dim3(kCsmBlock), 0, ctx->stream, p.args, prm, host);
@@ -967,7 +1004,10 @@ int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* o, const do
       hipLaunchKernelGGL(csm_lm_kernel<1>, dim3(1), dim3(kCsmBlock), 0, ctx->stream, p.args, prm, host);
     ctx->end_span(span);
     DLIOM_HIP_TRY(hipGetLastError());
-    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (prm.done_word != nullptr)
+      DLIOM_TRY(wait_done(ctx, ctx->stream, prm.done_word, prm.done_seq));
+    else
+      DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::memcpy(out7, host->x, sizeof(x));
     *sum = host->summary;
     return host->status;
@@ -992,6 +1032,8 @@ int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* o, const do
     prm.k_scale = (kMax - kMin) / 32766.f;
     prm.k_offset = kMin - prm.k_scale;
     prm.k_unknown = kMin;
+    prm.done_word = nullptr;
+    prm.done_seq = 0u;
     const size_t part_bytes = (2 * static_cast<size_t>(p.num_blocks) * kAcc * sizeof(double) + 255) & ~static_cast<size_t>(255);
     DLIOM_TRY(ctx->partials.reserve(part_bytes + 256));
     double* partials = ctx->partials.as<double>();

@@ -347,6 +347,8 @@ struct MultiInsertArgs {
   const uint16_t* miss;
   int* status;  // per target: [needed bits, ray too long]
   int* host_status;  // pinned host copy of `status`, written by pass 1 (null: not wanted) -- saves a copy dispatch
+  unsigned* done_word;  // ... followed by this completion word (pinned; null: none), which the host polls
+  unsigned done_seq;
 };
 
 // Transformed + range-filtered hit of point i for target tg; false if filtered out.
@@ -382,9 +384,17 @@ __global__ void multi_insert_kernel(MultiInsertArgs a) {
   if (!((a.run_mask >> tgi) & 1u)) return;
   const InsertTarget& tg = a.tg[tgi];
   // pass 0 has finished: its verdict goes to the host from here (the passes that follow are skipped per target)
-  if (PASS == 1 && a.host_status != nullptr && blockIdx.x == 0 && tgi == __ffs(a.run_mask) - 1 &&
-      threadIdx.x < 2 * kMaxInsertTargets)
-    a.host_status[threadIdx.x] = a.status[threadIdx.x];
+  if (PASS == 1 && a.host_status != nullptr && blockIdx.x == 0 && tgi == __ffs(a.run_mask) - 1) {  // uniform over the block
+    if (threadIdx.x < 2 * kMaxInsertTargets) {
+      a.host_status[threadIdx.x] = a.status[threadIdx.x];
+      __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && a.done_word != nullptr) {
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned*>(a.done_word) = a.done_seq;
+    }
+  }
   if (PASS > 0 && (a.status[2 * tgi] > tg.bits || a.status[2 * tgi + 1] != 0)) return;  // host first
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int hx = 0, hy = 0, hz = 0;
@@ -1037,7 +1047,12 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
   a.miss = ins->d_tables + 32768;
   a.run_mask = (1u << num_targets) - 1u;
   DLIOM_HIP_TRY(hipMemsetAsync(a.status, 0, 8 * kMaxInsertTargets, ctx->stream));
-  a.host_status = static_cast<int*>(ctx->pinned);  // device-visible; this call owns the block until it returns
+  a.host_status = static_cast<int*>(ctx->pinned);  // device-visible; written by pass 1 only
+  // The host needs pass 0's verdict, not the end of the update passes: everything that follows on this context is
+  // ordered behind them by the stream.  Pass 1 ends its copy of the verdict with a completion word; the call returns
+  // when that arrives (the update passes may still be running -- 50 us the caller's next step no longer waits for).
+  a.done_word = ctx->done_word;
+  a.done_seq = ctx->done_word != nullptr ? (++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq) : 0u;
   const dim3 grid_dim(blocks_for(n, 256), num_targets), block(256);
   const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
   hipLaunchKernelGGL(multi_insert_kernel<0>, grid_dim, block, 0, ctx->stream, a);
@@ -1049,9 +1064,13 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
     hipLaunchKernelGGL(multi_insert_kernel<4>, grid_dim, block, 0, ctx->stream, a);
     DLIOM_HIP_TRY(hipGetLastError());
     if (attempt == 0) {
-      DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (a.done_word != nullptr)
+        DLIOM_TRY(wait_done(ctx, ctx->stream, a.done_word, a.done_seq));
+      else
+        DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
       std::memcpy(status, a.host_status, sizeof(status));
       a.host_status = nullptr;
+      a.done_word = nullptr;
       unsigned redo = 0;
       for (int k = 0; k < num_targets; ++k) {
         if (status[2 * k + 1] != 0) {
@@ -1063,6 +1082,7 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
           return DLIOM_ERR_GRID_EXTENT;
         }
         if (status[2 * k] > grids[k]->bits) {  // skipped on the device: grow, then run it alone
+          DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // (the other targets' passes are done before anything is reallocated)
           DLIOM_TRY(grids[k]->ensure_bits(status[2 * k]));
           refresh_target(&a.tg[k], grids[k]);
           redo |= 1u << k;

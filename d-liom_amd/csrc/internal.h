@@ -96,6 +96,8 @@ struct dliom_ctx {
   int last_box_refusal = 0;        // DLIOM_BOX_* of the last score volume (dliom_rtcsm_stats.box_kernel_status)
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
+  unsigned* done_word = nullptr;  // pinned, own allocation: completion word of the main stream's read-back kernels
+  unsigned done_seq = 0;
   // auxiliary stream (dliom_cloud_rotational_histogram_begin / _finish): work that only reads what is already on the
   // context may run beside the main stream; own scratch and own pinned block, created on first use
   hipStream_t aux_stream = nullptr;
@@ -103,6 +105,8 @@ struct dliom_ctx {
   dliom::DevBuf aux_scratch;
   void* aux_pinned = nullptr;  // 4 KB
   int aux_histogram_size = 0;  // > 0: a histogram is pending on aux_stream
+  unsigned aux_seq = 0;        // its completion word is the one at aux_pinned + 4032
+  bool aux_enqueued = false;   // false: the pending histogram is the empty cloud's (nothing on the stream)
   // profiling
   bool profiling = false;
   unsigned profiling_mask = ~0u;  // kernel ids whose launches are timed
@@ -197,7 +201,9 @@ int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, fl
                         int64_t* n_out);
 // Order-preserving compaction of the points with kinds[i] == want; synchronises once.
 int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
-                         float* oy, float* oz, int64_t* n_out);
+                         float* oy, float* oz, int64_t* n_out,
+                         const void* also_src = nullptr, unsigned also_words = 0, void* also_dst = nullptr);  // also_*: a few
+                         // more device words read back in the same round trip
 int needed_bits_for_cell_range(int min_index, int max_index);
 // core.hip: several small device fills / read-backs in ONE dispatch each (a hipMemsetAsync or hipMemcpyAsync is a
 // dispatch of its own: ~3 us of GPU time plus the gap to its neighbours, and the filtered-cloud chain issued ~25 per scan)
@@ -210,9 +216,20 @@ int fill_multi(dliom_ctx* ctx, const FillJob* jobs, int num_jobs, hipStream_t st
 struct GatherJob {
   const void* src;  // device, 4-byte aligned
   unsigned words;
+  unsigned stride = 1;  // in words: word i comes from src[i * stride]
 };
 // Copies the jobs' words back to back into `pinned_dst` (device-visible pinned host memory, e.g. inside ctx->pinned).
-int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst, hipStream_t stream = nullptr);  // num_jobs <= 6, <= 1024 words each
+// done_word / done_seq: when given, the kernel writes done_seq to *done_word (pinned) after its copies are visible
+// system-wide -- what wait_done() polls.
+int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst, hipStream_t stream = nullptr,
+                     unsigned* done_word = nullptr, unsigned done_seq = 0);  // num_jobs <= 6, <= 1024 words each
+// Waiting for a kernel that ends in a completion word (measured on the MI355X boxes, tools/ubench/sync_latency.hip:
+// launch + hipStreamSynchronize 11.8 us, launch + polling a pinned word 6.5 us, and a 4-byte hipMemcpyAsync D2H in
+// front of the synchronise 22.3 us): polls for a short while, then falls back to hipStreamSynchronize (long kernels
+// in front, or an error that keeps the word from ever arriving).
+int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq);
+// gather_to_pinned on ctx->stream + wait_done: the read-back of a few words without a memcpy and without a full synchronise
+int gather_and_wait(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst);
 // rtcsm3d.hip: exact sequential float sums of LUT probabilities under explicit float poses
 int sequential_probability_sums(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid, const float* poses7,
                                 int k, float* sums);

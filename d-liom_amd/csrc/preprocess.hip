@@ -266,9 +266,10 @@ static int add_range_data_stage_a(dliom_ctx* ctx, const double prev_pose[7], con
                      ctx->stream, a, c, c + nn, c + 2 * nn, c + 3 * nn, multi ? oi_f : static_cast<const float*>(nullptr),
                      1, static_cast<int>(n1), d, d + nn, d + 2 * nn, 1, kind, d_pose);
   DLIOM_HIP_TRY(hipGetLastError());
-  DLIOM_HIP_TRY(hipMemcpyAsync(current_pose, d_pose, 28, hipMemcpyDeviceToHost, ctx->stream));
-  // returns (kind 1), in hit order; misses (kind 2) are not used by the 3D path (compaction synchronises)
-  DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, num_returns));
+  // returns (kind 1), in hit order; misses (kind 2) are not used by the 3D path.  The compaction's read-back brings the
+  // last hit's pose along (one round trip, no memcpy)
+  DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, num_returns, d_pose, 7,
+                                 current_pose));
   *returns = e;
   *stride = nn;
   return DLIOM_OK;
@@ -306,9 +307,10 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
                        ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y, ti.z, f, f + fs, f + 2 * fs,
                        static_cast<int>(n3), ox, oy, oz, d_max_sq);
     unsigned* host = static_cast<unsigned*>(ctx->pinned);
-    if (st == DLIOM_OK && (hipMemcpyAsync(host, d_max_sq, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                           hipStreamSynchronize(ctx->stream) != hipSuccess))
-      st = DLIOM_ERR_HIP;
+    if (st == DLIOM_OK) {
+      const GatherJob job{d_max_sq, 1};
+      st = gather_and_wait(ctx, &job, 1, host);
+    }
     float sq;
     std::memcpy(&sq, host, 4);
     max_norm = std::sqrt(sq);

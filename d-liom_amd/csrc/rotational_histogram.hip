@@ -1157,7 +1157,7 @@ extern "C" int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int 
 namespace {
 // Enqueues the three kernels and the read-back of [histogram | flags] into `pinned_dst` on `stream`; no synchronisation.
 int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch, void* pinned_dst, const dliom_cloud* cloud,
-                      const float rotation_wxyz[4], int histogram_size) {
+                      const float rotation_wxyz[4], int histogram_size, unsigned* done_word = nullptr, unsigned done_seq = 0) {
   using namespace rothist;
   const int n = static_cast<int>(cloud->n);
   // scratch: [rx | ry | rz | c_value] floats, [keys] shorts (padded to 512), [c_bucket] bytes (padded to 1024),
@@ -1213,7 +1213,7 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
   DLIOM_HIP_TRY(hipGetLastError());
   // one read-back: [histogram | flags] through pinned memory
   const GatherJob back[2] = {{d_hist, static_cast<unsigned>(histogram_size)}, {flags, 1}};
-  return gather_to_pinned(ctx, back, 2, pinned_dst, stream);
+  return gather_to_pinned(ctx, back, 2, pinned_dst, stream, done_word, done_seq);
 }
 
 int read_histogram(const void* pinned_src, int histogram_size, float* histogram) {
@@ -1237,8 +1237,14 @@ extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_clou
   }
   if (cloud->n > (int64_t{1} << 26)) return DLIOM_ERR_CAPACITY;
   void* h = static_cast<char*>(ctx->pinned) + 2048;
-  DLIOM_TRY(enqueue_histogram(ctx, ctx->stream, ctx->misc, h, cloud, rotation_wxyz, histogram_size));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->done_word != nullptr) {
+    const unsigned seq = ++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq;
+    DLIOM_TRY(enqueue_histogram(ctx, ctx->stream, ctx->misc, h, cloud, rotation_wxyz, histogram_size, ctx->done_word, seq));
+    DLIOM_TRY(wait_done(ctx, ctx->stream, ctx->done_word, seq));
+  } else {
+    DLIOM_TRY(enqueue_histogram(ctx, ctx->stream, ctx->misc, h, cloud, rotation_wxyz, histogram_size));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
   return read_histogram(h, histogram_size, histogram);
 }
 
@@ -1264,19 +1270,24 @@ extern "C" int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dlio
       if (st != nullptr) (void)hipStreamDestroy(st);
       return DLIOM_ERR_HIP;
     }
+    std::memset(pin, 0, 4096);
     ctx->aux_stream = st;
     ctx->aux_fork = ev;
     ctx->aux_pinned = pin;
   }
   if (cloud->n == 0) {
-    std::memset(ctx->aux_pinned, 0, 4096);
+    std::memset(ctx->aux_pinned, 0, 4032);
     ctx->aux_histogram_size = histogram_size;
+    ctx->aux_enqueued = false;
     return DLIOM_OK;
   }
   DLIOM_HIP_TRY(hipEventRecord(ctx->aux_fork, ctx->stream));
   DLIOM_HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
-  DLIOM_TRY(enqueue_histogram(ctx, ctx->aux_stream, ctx->aux_scratch, ctx->aux_pinned, cloud, rotation_wxyz, histogram_size));
+  ctx->aux_seq = ++ctx->aux_seq == 0u ? 1u : ctx->aux_seq;
+  DLIOM_TRY(enqueue_histogram(ctx, ctx->aux_stream, ctx->aux_scratch, ctx->aux_pinned, cloud, rotation_wxyz, histogram_size,
+                              reinterpret_cast<unsigned*>(static_cast<char*>(ctx->aux_pinned) + 4032), ctx->aux_seq));
   ctx->aux_histogram_size = histogram_size;
+  ctx->aux_enqueued = true;
   return DLIOM_OK;
 }
 
@@ -1285,6 +1296,7 @@ extern "C" int dliom_cloud_rotational_histogram_finish(dliom_ctx* ctx, float* hi
   const int size = ctx->aux_histogram_size;
   ctx->aux_histogram_size = 0;
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
+  if (ctx->aux_enqueued)
+    DLIOM_TRY(wait_done(ctx, ctx->aux_stream, reinterpret_cast<const unsigned*>(static_cast<const char*>(ctx->aux_pinned) + 4032), ctx->aux_seq));
   return read_histogram(ctx->aux_pinned, size, histogram);
 }

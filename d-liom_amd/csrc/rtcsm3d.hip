@@ -1904,8 +1904,7 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
     const bool want_err = st->used_box && global_best_lo_bits == nullptr;
     const GatherJob back[4] = {{st->d_ctrs, 2}, {st->d_list, kSpecK}, {ctx->rescore.p, kSpecK},
                                {static_cast<char*>(ctx->box_error.p) + 4, 1}};
-    DLIOM_TRY(gather_to_pinned(ctx, back, want_err ? 4 : 3, h_ctrs));
-    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    DLIOM_TRY(gather_and_wait(ctx, back, want_err ? 4 : 3, h_ctrs));
     {
       bool overflow = false;
       DLIOM_TRY(box_overflowed(ctx, *h_err, &overflow));
@@ -2047,6 +2046,13 @@ int sequential_probability_sums(dliom_ctx* ctx, const dliom_cloud& cloud, const 
   float* d_ksums = ctx->rescore.as<float>();
   DLIOM_TRY(launch_sequential_sums(ctx, rescore_method_default(), grid->view(), cloud, d_rot, k, d_trans, d_list, nullptr,
                                    static_cast<unsigned>(k), &ctx->misc, d_ksums));
+  if (K <= 1024) {  // a few sums (the loop-closure matcher asks for one at a time): packed by a kernel, polled
+    const GatherJob job{d_ksums, static_cast<unsigned>(K)};
+    float* h = reinterpret_cast<float*>(static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 8192);
+    DLIOM_TRY(gather_and_wait(ctx, &job, 1, h));  // also keeps `host` alive long enough: the upload is in front of it
+    std::memcpy(sums, h, K * 4);
+    return DLIOM_OK;
+  }
   DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_ksums, K * 4, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `host` alive long enough
   return DLIOM_OK;

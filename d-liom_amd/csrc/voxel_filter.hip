@@ -288,15 +288,17 @@ static int run_insert(dliom_ctx* ctx, const Soa& in, const std::vector<float>& s
   const dim3 grid((n + kVfInsertBlock - 1) / kVfInsertBlock, num);
   hipLaunchKernelGGL(voxel_insert_kernel, grid, dim3(kVfInsertBlock), 0, ctx->stream, in.x, in.y, in.z, n, lengths, *t);
   DLIOM_HIP_TRY(hipGetLastError());
+  // the 2 num + 1 counters (kVfCounterStride words apart) packed into pinned memory by a kernel that ends in a completion
+  // word: no memcpy, no full synchronise (internal.h, wait_done)
   unsigned* host = static_cast<unsigned*>(ctx->pinned);
-  DLIOM_HIP_TRY(hipMemcpyAsync(host, t->counters, counter_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (host[kVfCounterStride * 2 * num] != 0) return DLIOM_ERR_INVALID_ARGUMENT;  // voxel index outside 21 bits
+  const GatherJob job{t->counters, static_cast<unsigned>(2 * num + 1), static_cast<unsigned>(kVfCounterStride)};
+  DLIOM_TRY(gather_and_wait(ctx, &job, 1, host));
+  if (host[2 * num] != 0) return DLIOM_ERR_INVALID_ARGUMENT;  // voxel index outside 21 bits
   counts->resize(num);
   in_range->resize(num);
   for (int k = 0; k < num; ++k) {
-    (*counts)[k] = host[kVfCounterStride * k];
-    (*in_range)[k] = host[kVfCounterStride * (num + k)];
+    (*counts)[k] = host[k];
+    (*in_range)[k] = host[num + k];
   }
   for (int k = 0; k < num; ++k)
     if (ranges[k] < 0.f) (*in_range)[k] = n;
@@ -367,9 +369,16 @@ int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, fl
 }
 
 int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
-                         float* oy, float* oz, int64_t* n_out) {
+                         float* oy, float* oz, int64_t* n_out, const void* also_src, unsigned also_words, void* also_dst) {
   *n_out = 0;
-  if (in.n == 0) return DLIOM_OK;
+  if (in.n == 0) {
+    if (also_src != nullptr && also_words > 0) {
+      const GatherJob job{also_src, also_words};
+      DLIOM_TRY(gather_and_wait(ctx, &job, 1, ctx->pinned));
+      std::memcpy(also_dst, ctx->pinned, static_cast<size_t>(also_words) * 4);
+    }
+    return DLIOM_OK;
+  }
   VfScratch s;
   DLIOM_TRY(carve_scratch(ctx, in.n, 1, &s));
   const unsigned n = static_cast<unsigned>(in.n);
@@ -382,16 +391,17 @@ int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kin
                      static_cast<float*>(nullptr), static_cast<unsigned*>(nullptr), static_cast<unsigned*>(nullptr));
   DLIOM_HIP_TRY(hipGetLastError());
   unsigned* host = static_cast<unsigned*>(ctx->pinned);
-  DLIOM_HIP_TRY(hipMemcpyAsync(host, s.max_sq, 4, hipMemcpyDeviceToHost, ctx->stream));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const GatherJob jobs[2] = {{s.max_sq, 1}, {also_src, also_words}};
+  DLIOM_TRY(gather_and_wait(ctx, jobs, also_src != nullptr && also_words > 0 ? 2 : 1, host));
   *n_out = host[0];
+  if (also_src != nullptr && also_words > 0) std::memcpy(also_dst, host + 1, static_cast<size_t>(also_words) * 4);
   return DLIOM_OK;
 }
 
 int read_max_norm(dliom_ctx* ctx, const unsigned* d_max_sq, float* max_norm) {
   unsigned* host = static_cast<unsigned*>(ctx->pinned);
-  DLIOM_HIP_TRY(hipMemcpyAsync(host, d_max_sq, 4, hipMemcpyDeviceToHost, ctx->stream));
-  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const GatherJob job{d_max_sq, 1};
+  DLIOM_TRY(gather_and_wait(ctx, &job, 1, host));
   float sq;
   std::memcpy(&sq, host, 4);
   *max_norm = std::sqrt(sq);  // sqrt is monotone and correctly rounded: == max of the norms
@@ -610,9 +620,8 @@ int adaptive_voxel_filter_clouds(dliom_ctx* ctx, const dliom_cloud& in, const dl
   if (any) {
     unsigned* host = static_cast<unsigned*>(ctx->pinned);
     int st = DLIOM_OK;
-    if (hipMemcpyAsync(host, s.max_sq, 4 * num_filters, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess)
-      st = DLIOM_ERR_HIP;
+    const GatherJob job{s.max_sq, static_cast<unsigned>(num_filters)};
+    st = gather_and_wait(ctx, &job, 1, host);
     if (st != DLIOM_OK) return fail(st);
     std::memcpy(max_sq, host, 4 * num_filters);
   }
