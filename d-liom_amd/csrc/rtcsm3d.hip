@@ -18,6 +18,7 @@
 //   host   score = sum / N * exp(-(|t| wt + angle wr)^2) as the reference computes it; first
 //          strictly greater score in generation order wins.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1999,10 +2000,29 @@ static int match_decode(dliom_ctx* ctx, uint64_t best_packed, double out7[7], fl
 static int match_impl(dliom_ctx* ctx, const dliom_rtcsm_options* o, const double init7[7],
                       const dliom_cloud& cloud, const dliom_grid* grid, double out7[7],
                       float* out_score) {
+#ifdef DLIOM_EXPERIMENTS
+  static const int timing = env_int("DLIOM_TIMING", 0);
+  const auto t0 = std::chrono::steady_clock::now();
+#endif
   DLIOM_TRY(match_begin(ctx, o, init7, cloud, grid, 0, 1, nullptr));
+#ifdef DLIOM_EXPERIMENTS
+  const auto t1 = std::chrono::steady_clock::now();
+#endif
   uint64_t packed = 0;
   DLIOM_TRY(match_finish(ctx, nullptr, &packed));
-  return match_decode(ctx, packed, out7, out_score);
+#ifdef DLIOM_EXPERIMENTS
+  const auto t2 = std::chrono::steady_clock::now();
+#endif
+  const int s = match_decode(ctx, packed, out7, out_score);
+#ifdef DLIOM_EXPERIMENTS
+  if (timing) {
+    const auto t3 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    std::fprintf(stderr, "TIMING match: begin (host prep + enqueue) %.1f us, finish (enqueue + wait) %.1f us, decode %.1f us\n", us(t0, t1),
+                 us(t1, t2), us(t2, t3));
+  }
+#endif
+  return s;
 }
 
 }  // namespace dliom
