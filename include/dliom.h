@@ -147,9 +147,15 @@ int dliom_inserter_insert_cloud(const dliom_inserter* inserter, dliom_grid* grid
                                 const float* poses7, int num_poses, const float origin[3],
                                 const dliom_cloud* cloud, float max_range);
 
-/* The same for up to 4 grids in one set of launches and one synchronisation -- the four
- * insertions of ActiveSubmaps3D::InsertRangeData (both grids of both active submaps,
- * submap_3d.cc:303-309).  Target k uses poses7[14*k .. 14*k + 7*num_poses[k]) and max_range[k]. */
+/* The same for up to 4 grids in one set of launches -- the four insertions of
+ * ActiveSubmaps3D::InsertRangeData (both grids of both active submaps, submap_3d.cc:303-309).
+ * Target k uses poses7[14*k .. 14*k + 7*num_poses[k]) and max_range[k].
+ * The insertion calls (this one, _insert_cloud, dliom_front_end_insert*) return as soon as the device has told the
+ * host whether the grids can hold the scan (status, growth); the update passes themselves are still on the context's
+ * stream then.  Every later call ON THE SAME CONTEXT is ordered behind them; the cloud may be destroyed right away
+ * (dliom_cloud_destroy waits for the device).  Code that reads a grid through ANOTHER context (a loop-closure thread
+ * building a matcher on an active submap) calls dliom_ctx_synchronize on the inserting context first -- finished
+ * submaps handed out by dliom_front_end_take_finished_submap need nothing, they have been synchronised. */
 int dliom_inserter_insert_cloud_multi(const dliom_inserter* inserter, int num_targets,
                                       dliom_grid* const* grids, const float* poses7, const int* num_poses,
                                       const float origin[3], const dliom_cloud* cloud,
