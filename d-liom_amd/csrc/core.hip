@@ -686,6 +686,7 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   ctx->box_error.release();
   ctx->box_counters.release();
   ctx->box_extents.release();
+  ctx->csm_arrivals.release();
   ctx->aux_scratch.release();
   if (ctx->aux_pinned != nullptr) (void)hipHostFree(ctx->aux_pinned);
   if (ctx->aux_fork != nullptr) (void)hipEventDestroy(ctx->aux_fork);

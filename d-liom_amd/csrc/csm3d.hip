@@ -931,12 +931,15 @@ static int setup_problem(dliom_ctx* ctx, const dliom_csm_options* o, const doubl
   for (int i = 0; i < 3; ++i) p->target_t[i] = target_t[i];
   for (int i = 0; i < 4; ++i) p->init_q[i] = init7[3 + i];
   p->num_blocks = std::max(1, std::min(512, (total + 2 * kCsmBlock - 1) / (2 * kCsmBlock)));
-  DLIOM_TRY(ctx->partials.reserve(static_cast<size_t>(p->num_blocks + 1) * kAcc * sizeof(double) + 256));
+  DLIOM_TRY(ctx->partials.reserve(static_cast<size_t>(p->num_blocks + 1) * kAcc * sizeof(double)));
   p->d_partials = ctx->partials.as<double>();
   p->d_out = p->d_partials + static_cast<size_t>(p->num_blocks) * kAcc;
-  // the word csm_final_reduce_kernel counts its waves in: zero before the first evaluation, re-armed by the kernel itself
-  p->d_arrivals = reinterpret_cast<unsigned*>(p->d_out + kAcc);
-  DLIOM_HIP_TRY(hipMemsetAsync(p->d_arrivals, 0, 4, ctx->stream));
+  // the word csm_final_reduce_kernel counts its waves in: zeroed once when it is allocated, re-armed by the kernel itself
+  if (ctx->csm_arrivals.p == nullptr) {
+    DLIOM_TRY(ctx->csm_arrivals.reserve(256));
+    DLIOM_HIP_TRY(hipMemsetAsync(ctx->csm_arrivals.p, 0, 256, ctx->stream));
+  }
+  p->d_arrivals = ctx->csm_arrivals.as<unsigned>();
   return DLIOM_OK;
 }
 

@@ -87,6 +87,7 @@ struct dliom_ctx {
   dliom::DevBuf box_tables; // per-pass constants of the LDS-box score kernel (rtcsm3d.hip)
   dliom::DevBuf box_counters; // its chunk dispensers
   dliom::DevBuf box_extents;  // per (rotation block, point) extents of its lookups (rtcsm_box_extent_kernel)
+  dliom::DevBuf csm_arrivals; // csm_final_reduce_kernel's wave counter (zero between evaluations)
   dliom::DevBuf box_error;  // its 'cannot happen' flag word, read by dliom_rtcsm3d_box_error
   bool box_error_zeroed = false;
   bool force_dense_score = false;  // rerun after the LDS-box kernel flagged an inconsistency
