@@ -1,4 +1,5 @@
-// RTCSM3D score volume, LDS-box kernel (round 2).  Included by rtcsm3d.hip only.
+// RTCSM3D score volume, LDS-box kernel (round 2; work distribution, extent pre-pass and staging arithmetic round 3).
+// Included by rtcsm3d.hip only.
 //
 // Same exact integer sums as rtcsm_score_dense_kernel (sum_i max(v_i & 0x7fff, 1) per candidate,
 // real_time_correlative_scan_matcher_3d.cc:97-104), restructured around what the gfx950 pipes
@@ -18,7 +19,10 @@
 //     size keep 32-bit accumulators;
 //   * per iteration of kHotP points the next points are already in registers (fetched during the previous
 //     iteration's 27 steps), the 3 kHotP band-bitmap words are fetched together and the list append is branch-free;
-//     the values gathered in one step are accumulated after the next step's address arithmetic (kPipe, kLateAcc).
+//     the values gathered in one step are accumulated after the next step's address arithmetic (kPipe, kLateAcc);
+//   * (round 3) work units are (pass, rotation block) with single-chunk tickets, handed out most expensive first, and
+//     workgroups move on to other units when theirs is empty; the per-point part of the boxes' bounding boxes comes from
+//     a pre-pass (rtcsm_box_extent_kernel); the staging loop's index arithmetic avoids quarter-rate 32-bit multiplies.
 // What bounds it and what was tried: DESIGN.md 3.1.  The timing experiments quoted there (DLIOM_BOX_EXP,
 // Params::debug) produce wrong sums by design: they exist only in builds made with -DDLIOM_EXPERIMENTS
 // (`make experiments` -> ab/libdliom_exp.so); the library that ships contains neither them nor any switch that
