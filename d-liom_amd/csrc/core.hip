@@ -443,12 +443,12 @@ int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* 
 }
 
 int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq) {
-  (void)ctx;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n(done_word, __ATOMIC_ACQUIRE) == done_seq) return DLIOM_OK;
     if ((spins & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
   }
+  if (ctx != nullptr) ++ctx->poll_fallbacks;  // long kernels in front are expected; a count that grows with every call is not
   DLIOM_HIP_TRY(hipStreamSynchronize(stream));
   return __atomic_load_n(done_word, __ATOMIC_ACQUIRE) == done_seq ? DLIOM_OK : DLIOM_ERR_HIP;
 }
@@ -636,8 +636,12 @@ static int ctx_create_common(int device_id, hipStream_t stream, bool owns, dliom
   } else {
     ctx->stream = stream;
   }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
+  }
   ctx->pinned_bytes = 1 << 20;
-  hipError_t e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocCoherent | hipHostMallocMapped);
   if (e != hipSuccess) {
     set_last_error("hipHostMalloc", e, __FILE__, __LINE__);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
@@ -646,7 +650,7 @@ static int ctx_create_common(int device_id, hipStream_t stream, bool owns, dliom
   }
   {
     void* w = nullptr;
-    if (hipHostMalloc(&w, 64, hipHostMallocDefault) == hipSuccess) {  // optional: without it read-backs synchronise fully
+    if (hipHostMalloc(&w, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {  // optional: without it read-backs synchronise fully
       ctx->done_word = static_cast<unsigned*>(w);
       *ctx->done_word = 0u;
     }
@@ -703,6 +707,12 @@ int dliom_ctx_device(const dliom_ctx* ctx) { return ctx == nullptr ? -1 : ctx->d
 int dliom_ctx_synchronize(dliom_ctx* ctx) {
   if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
+int dliom_ctx_poll_fallbacks(const dliom_ctx* ctx, int64_t* count) {
+  if (ctx == nullptr || count == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *count = ctx->poll_fallbacks;
   return DLIOM_OK;
 }
 

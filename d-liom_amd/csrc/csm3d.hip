@@ -1015,12 +1015,7 @@ int dliom_csm3d_match_cloud(dliom_ctx* ctx, const dliom_csm_options* o, const do
     *sum = host->summary;
     return host->status;
   }
-  static const int num_cus = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
-  }();
+  const int num_cus = ctx->num_cus;
   // large clouds: the loop in one launch with grid barriers when every workgroup of the evaluation grid is resident at
   // once (256 threads and 57 KB of LDS each: two per CU)
   if (ctx->tuning[DLIOM_TUNE_CSM_GRID_SYNC] != 0 && p.num_blocks > 1 && p.num_blocks <= 2 * num_cus) {

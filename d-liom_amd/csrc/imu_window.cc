@@ -27,8 +27,8 @@
 // :750-797,841-842) becomes: Gauss-Newton (two iterations per scan) over the last `window_size` states, older states
 // marginalised into a Gaussian prior on the oldest kept one (Schur complement).  For a linear problem both give the
 // same estimate; the difference is where the old factors are linearised.
-// Jacobians are taken numerically on the manifold (central differences in double): 15 or 30 columns of at most 15
-// rows per factor -- microseconds per scan on the host, and one code path shared by every factor.
+// Jacobians are closed-form (IMU factor + bias random walk, pose prior, gravity factor); dliom_diag_imu_factor_jacobians
+// compares the IMU factor's with central differences of its own residual.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -814,7 +814,15 @@ bool gauss_newton(dliom_imu_window& w, int iterations) {
 
 // Marginalises x[0]: the factors touching it (its prior, the IMU factor to x[1], pose priors / gravity factors on
 // it) become a Gaussian prior on x[1], linearised at the current estimate.
+#ifdef DLIOM_TEST_HOOKS
+// tests/cpp/imu_window_marginalize_fail.cc compiles this file by itself with the hook; libdliom.so never has it
+int dliom_test_fail_marginalize = 0;
+#endif
+
 bool marginalize_oldest(dliom_imu_window& w) {
+#ifdef DLIOM_TEST_HOOKS
+  if (dliom_test_fail_marginalize != 0) return false;
+#endif
   // sub-problem of x[0], x[1] with only those factors
   std::vector<State> x2 = {w.x[0], w.x[1]};
   const int n = 2 * kD;
@@ -1222,7 +1230,10 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
   }
   if (gravity_added) ++w->gravity_factors;
   while (static_cast<int>(w->x.size()) > w->o.window_size)
-    if (!marginalize_oldest(*w)) return DLIOM_ERR_INVALID_ARGUMENT;
+    if (!marginalize_oldest(*w)) {  // a failed Schur complement is a failed solve: nothing of this scan stays either
+      *w = saved;
+      return DLIOM_ERR_SOLVER;
+    }
   const State& s = w->x.back();
   w->current.reset(s.ba, s.bg);  // resetIntegrationAndSetBias(prev_bias_), :852
   ++w->num_states;

@@ -99,6 +99,9 @@ struct dliom_ctx {
   size_t pinned_bytes = 0;
   unsigned* done_word = nullptr;  // pinned, own allocation: completion word of the main stream's read-back kernels
   unsigned done_seq = 0;
+  int64_t poll_fallbacks = 0;     // wait_done() calls that ran out of their polling time (dliom_ctx_poll_fallbacks)
+  int num_cus = 256;              // of ctx->device (set at creation)
+  unsigned func_attr_set = 0;     // kFuncAttr* bits: hipFuncSetAttribute done for this context's device
   // auxiliary stream (dliom_cloud_rotational_histogram_begin / _finish): work that only reads what is already on the
   // context may run beside the main stream; own scratch and own pinned block, created on first use
   hipStream_t aux_stream = nullptr;
@@ -177,6 +180,8 @@ struct dliom_inserter {
 };
 
 namespace dliom {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per context, not per thread or process
+enum : unsigned { kFuncAttrScoreBox = 1u, kFuncAttrHistogram = 2u, kFuncAttrStdSortDiag = 4u, kFuncAttrHistogramBig = 8u };
 // Coordinate of the padding points of the Morton-ordered arrays: far outside any grid extent.
 constexpr int kCostChunk = 32;  // points per chunk of dliom_cloud::d_chunk_order (= the box score kernel's chunk)
 constexpr float kPadCoordinate = 1.0e7f;  // cell index ~1e7/res: no int overflow for res >= 0.005 m

@@ -1263,7 +1263,7 @@ extern "C" int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dlio
     void* pin = nullptr;
     const bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
                     hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess &&
-                    hipHostMalloc(&pin, 4096, hipHostMallocDefault) == hipSuccess;
+                    hipHostMalloc(&pin, 4096, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess;
     if (!ok) {
       if (pin != nullptr) (void)hipHostFree(pin);
       if (ev != nullptr) (void)hipEventDestroy(ev);

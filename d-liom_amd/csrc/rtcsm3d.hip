@@ -1367,11 +1367,10 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   const size_t lds = kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 +
                      static_cast<size_t>(cells) * 2;
   if (lds > 160 * 1024) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_LDS, DLIOM_ERR_CAPACITY);
-  static thread_local bool attr_set = false;  // one context per thread: per-thread, not process-wide
-  if (!attr_set) {
+  if ((ctx->func_attr_set & kFuncAttrScoreBox) == 0u) {
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rtcsm_score_box_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    ctx->func_attr_set |= kFuncAttrScoreBox;
   }
   // workgroups: one round of residents (every wave walks an equal share of the point chunks, so a second,
   // partly filled round would only idle); `target_waves` overrides
@@ -1383,12 +1382,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
                                                                 64 * nw, lds));
     resident_lds = lds;
   }
-  static const int num_cus = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
-  }();
+  const int num_cus = ctx->num_cus;
   const int want_blocks = target_waves > 0 ? target_waves / nw : std::max(1, resident) * num_cus;
   int slot_quads = std::max(1, want_blocks / std::max(1, rot_blocks * passes));
   slot_quads = std::min(slot_quads, p.point_chunks);

@@ -300,6 +300,7 @@ SYMBOLS = [
     ("dliom_csm3d_evaluate", C.c_int, [_vp, C.POINTER(CsmOptions), _f64p, _f64p, _f64p, C.c_int, C.POINTER(_f32p),
                                        _i64p, C.POINTER(_vp), _f64p, _f64p, _f64p]),
     ("dliom_ctx_set_tuning", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("dliom_ctx_poll_fallbacks", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("dliom_ctx_get_tuning", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("dliom_ctx_set_profiling", C.c_int, [_vp, C.c_int]),
     ("dliom_ctx_reset_profiling", C.c_int, [_vp]),
@@ -390,6 +391,12 @@ class Context:
 
     def synchronize(self):
         _check(self._L.dliom_ctx_synchronize(self.h), "synchronize")
+
+    def poll_fallbacks(self):
+        """dliom_ctx_poll_fallbacks: read-backs that ran out of polling time and synchronised the stream instead."""
+        n = C.c_int64(0)
+        _check(self._L.dliom_ctx_poll_fallbacks(self.h, C.byref(n)), "poll_fallbacks")
+        return int(n.value)
 
     def set_tuning(self, knob, value):
         """dliom_ctx_set_tuning: TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_INJECT_BOX_FAULT, TUNE_CSM_GRID_SYNC."""

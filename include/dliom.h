@@ -522,8 +522,8 @@ int dliom_fast_csm_level(const dliom_fast_csm* matcher, int depth, int32_t lo[3]
 
 /* RotationalScanMatcher::ComputeHistogram (rotational_scan_matcher.cc:159-170; called per inserted
  * scan, local_trajectory_builder_3d.cc:605-610) on the host: histogram_size floats.  Clouds of 8192 points and more
- * are processed on up to 8 host threads (same bits at any thread count; DLIOM_HISTOGRAM_THREADS=1 keeps the call on
- * the caller's thread). */
+ * are processed on up to 8 host threads (same bits at any thread count; dliom_rotational_histogram_mt(..., forced_threads = 1, ...)
+ * keeps the call on the caller's thread -- the library reads no environment variable). */
 int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram_size, float* histogram);
 /* The same on the device, on a cloud that is already in HBM (the filtered cloud of the front end), fused with the
  * gravity alignment of local_trajectory_builder_3d.cc:605-610: histogram of Rigid3f::Rotation(rotation_wxyz) * point
@@ -708,7 +708,9 @@ enum {
   DLIOM_TUNE_CSM_ONE_LAUNCH_MAX = 1,  /* CeresScanMatcher3D: clouds up to this many points (sum over grids) run the whole
                                          trust-region loop in one launch (default 4096, 0 = never) */
   DLIOM_TUNE_INJECT_BOX_FAULT = 2,    /* test hook: the next match treats the box kernel's consistency word as set, i.e.
-                                         takes the "redo on the dense kernel" path once (same result by construction) */
+                                         takes the "redo on the dense kernel" path once (same result by construction);
+                                         it sets only the per-match word, never the sticky flags that
+                                         dliom_rtcsm3d_box_error reports */
   DLIOM_TUNE_CSM_GRID_SYNC = 3,       /* CeresScanMatcher3D on large clouds: 1 = the whole loop in one launch with grid
                                          barriers, 0 = one launch per evaluation (default: measured 0.27 ms against
                                          0.35 ms per 131 072-point match -- the barrier, the final reduction and the
@@ -718,6 +720,11 @@ enum {
 };
 int dliom_ctx_set_tuning(dliom_ctx* ctx, int knob, int value);
 int dliom_ctx_get_tuning(const dliom_ctx* ctx, int knob, int* value);
+/* Read-backs end in a completion word in coherent pinned host memory that the host polls (150 us), falling back to
+ * hipStreamSynchronize: *count = how often that fallback was taken on this context.  A long kernel in front of a
+ * read-back takes it legitimately; a count that grows with every call means the polling is not seeing the device's
+ * writes (10x the latency, same results). */
+int dliom_ctx_poll_fallbacks(const dliom_ctx* ctx, int64_t* count);
 
 /* Kernel timing (HIP events on the context's stream). */
 enum {

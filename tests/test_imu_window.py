@@ -394,3 +394,21 @@ def test_analytic_imu_factor_jacobian_equals_central_differences(dl):
         worst = max(worst, float((np.abs(a - n) / scale).max()))
         assert np.abs(a).max() > 1.0
     assert worst < 2e-6, worst
+
+
+def test_failed_marginalisation_rolls_the_window_back(tmp_path):
+    """a failed Schur complement in add_pose must restore the window like a failed solve does --
+    DLIOM_ERR_SOLVER, same size, same newest state, and a retry that equals a window that never failed.  The failure
+    cannot be provoked through the C ABI, so tests/cpp/imu_window_marginalize_fail.cc compiles imu_window.cc by itself
+    with a test-only seam (DLIOM_TEST_HOOKS; the shipped library is built without it)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "imu_window_marginalize_fail")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-subobject-linkage", "-o", exe,
+                           os.path.join(root, "tests", "cpp", "imu_window_marginalize_fail.cc")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+    so = os.path.join(root, "d-liom_amd", "libdliom.so")
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+    assert "dliom_test_fail_marginalize" not in syms
