@@ -775,8 +775,9 @@ class LocalTrajectoryBuilder3D {
       for (int i = 0; i < ins.num_insertion_submaps; ++i) ir->insertion_submap_indices.push_back(ins.insertion_submap_index[i]);
       ir->submap_finished = ins.submap_finished != 0;
       // ComputeHistogram(TransformPointCloud(filtered_range_data_in_tracking.returns, Rotation(gravity_alignment.cast<float>())), size)
-      // on the device, where the filtered cloud already is (rotation fused); the host version only for the two cases the
-      // device one refuses (|z| beyond 409 m, more than 4096 points in one 0.2 m slice)
+      // on the device, where the filtered cloud already is (rotation fused; slices of any size -- the floor of a real scan
+      // puts 15 000 returns into one 0.2 m slice); the host version only for what the device one refuses (|z| beyond
+      // 409 m, non-finite coordinates, more than 63 slices above 4096 points): histogram_host_fallbacks() counts them
       if (options_.rotational_histogram_size > 0) {
         ir->rotational_scan_matcher_histogram.resize(static_cast<size_t>(options_.rotational_histogram_size));
         int hs = DLIOM_ERR_CAPACITY;
@@ -785,6 +786,7 @@ class LocalTrajectoryBuilder3D {
           hs = dliom_cloud_rotational_histogram_finish(context_->get(), ir->rotational_scan_matcher_histogram.data());
         }
         if (hs == DLIOM_ERR_CAPACITY) {
+          ++histogram_host_fallbacks_;
           const float rot[7] = {0.f, 0.f, 0.f, pf[3], pf[4], pf[5], pf[6]};
           std::vector<float> aligned(3 * static_cast<size_t>(n));
           for (int64_t i = 0; i < n; ++i) {
@@ -832,6 +834,11 @@ class LocalTrajectoryBuilder3D {
   int64_t last_imu_time_ = -1;
   bool imu_initialized_ = false;
   bool have_prediction_ = false;
+  int64_t histogram_host_fallbacks_ = 0;
+
+ public:
+  // ComputeHistogram calls that the device entry point refused and the host one served
+  int64_t histogram_host_fallbacks() const { return histogram_host_fallbacks_; }
 };
 
 }  // namespace mapping

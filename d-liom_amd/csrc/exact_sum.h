@@ -1,0 +1,261 @@
+// Exact PARALLEL replay of a SEQUENTIAL float sum  acc = ((acc0 + v[0]) + v[1]) + ...  for one workgroup of 1024
+// threads; addends of either sign.  Used where the reference's result depends on the order of float additions:
+// ComputeCentroid (rotational_scan_matcher.cc:52-59) and histogram(bucket) += value (:49).
+// tests/cpp/exact_sum_model.h is this algorithm in plain C++ (pinned against the plain loop on 4000 random arrays:
+// signed, monotone, hovering around zero and around powers of two, wild magnitudes, ties everywhere); the comments there
+// carry the error bound.  In short: while the accumulator stays in one binade it is an integer counter and every addend
+// a function {parity} -> {increment, parity} (ParityFn) that composes associatively; the real (double) prefix sums prove,
+// per chunk of 32 addends, in which binade the accumulator is while it crosses the chunk ("safe" chunks, 94-98 % on
+// LiDAR slices); a wave then walks the chunk functions 64 at a time with a scan and adds the values of the other chunks
+// one after the other.  Anything not proven falls back to those sequential additions, which are right by definition.
+#ifndef DLIOM_CSRC_EXACT_SUM_H_
+#define DLIOM_CSRC_EXACT_SUM_H_
+
+#include <hip/hip_runtime.h>
+
+namespace dliom {
+namespace exact_sum {
+
+constexpr int kThreads = 1024;          // the workgroup size the block scans below are written for
+constexpr int kChunk = 32;              // addends per chunk
+constexpr int kChunksPerBlock = 1024;   // chunks per super-block (one per thread); longer arrays are streamed
+constexpr int kNoCode = 0x7fffffff;
+
+struct Fn {
+  int s0, s1;       // increment of the counter for parity-in 0 / 1
+  unsigned p0, p1;  // parity out
+};
+__device__ __forceinline__ Fn identity_fn() { return Fn{0, 0, 0u, 1u}; }
+__device__ __forceinline__ Fn compose(const Fn& a, const Fn& b) {  // a first, then b
+  Fn r;
+  r.s0 = a.s0 + (a.p0 ? b.s1 : b.s0);
+  r.p0 = a.p0 ? b.p1 : b.p0;
+  r.s1 = a.s1 + (a.p1 ? b.s1 : b.s0);
+  r.p1 = a.p1 ? b.p1 : b.p0;
+  return r;
+}
+__device__ __forceinline__ Fn shfl_up_fn(const Fn& f, int off) {
+  Fn r;
+  r.s0 = __shfl_up(f.s0, off, 64);
+  r.s1 = __shfl_up(f.s1, off, 64);
+  r.p0 = __shfl_up(f.p0, off, 64);
+  r.p1 = __shfl_up(f.p1, off, 64);
+  return r;
+}
+__device__ __forceinline__ Fn wave_inclusive_scan_fn(Fn f, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const Fn o = shfl_up_fn(f, off);
+    if (lane >= off) f = compose(o, f);
+  }
+  return f;
+}
+
+// binade of a float: sign << 16 | biased exponent; kNoCode for zero, denormals, inf, nan
+__device__ __forceinline__ int code_of(float a) {
+  const unsigned u = __float_as_uint(a);
+  const int be = static_cast<int>((u >> 23) & 0xffu);
+  if (be == 0 || be == 255) return kNoCode;
+  return static_cast<int>((u >> 31) << 16) | be;
+}
+
+// The Fn of adding x to an accumulator of binade `code`; *ok = false when x does not fit the model (never in a safe chunk)
+__device__ __forceinline__ Fn element_fn(float x, int code, bool* ok) {
+  const unsigned u = __float_as_uint(x);
+  const unsigned mant = u & 0x7fffffu;
+  const int bex = static_cast<int>((u >> 23) & 0xffu);
+  if (bex == 255) {
+    *ok = false;
+    return identity_fn();
+  }
+  if (bex == 0 && mant == 0u) return identity_fn();
+  const unsigned mx = bex == 0 ? mant : (mant | 0x800000u);
+  const int ex = bex == 0 ? 1 : bex;
+  const int sh = (code & 0xff) - ex;  // x / ulp = +-mx 2^-sh
+  if (sh <= 0) {
+    *ok = false;
+    return identity_fn();
+  }
+  if (sh >= 25) return identity_fn();
+  const bool negative = (u >> 31) != static_cast<unsigned>(code >> 16);  // sign of x relative to the accumulator's
+  const unsigned q = mx >> sh, rem = mx & ((1u << sh) - 1u), half = 1u << (sh - 1);
+  if (rem == half) {  // tie: of base and its neighbour away from zero the one that makes the counter even
+    const int base = negative ? -static_cast<int>(q) : static_cast<int>(q);
+    const int other = negative ? base - 1 : base + 1;
+    Fn f;
+    f.s0 = (base & 1) == 0 ? base : other;
+    f.s1 = (base & 1) != 0 ? base : other;
+    f.p0 = f.p1 = 0u;
+    return f;
+  }
+  const int c = static_cast<int>(q + (rem > half ? 1u : 0u));
+  const int inc = negative ? -c : c;
+  return Fn{inc, inc, static_cast<unsigned>(c & 1), static_cast<unsigned>((c & 1) ^ 1)};
+}
+
+// LDS scratch of one call: chunk descriptors of a super-block for K arrays + the block scans' wave partials
+template <int K>
+struct Scratch {
+  int code[K][kChunksPerBlock];
+  int s0[K][kChunksPerBlock], s1[K][kChunksPerBlock];
+  unsigned char pp[K][kChunksPerBlock];  // p0 | p1 << 1
+  double wave_part[K][kThreads / 64];
+  float result[K];
+};
+
+__device__ __forceinline__ double shfl_up_double(double v, int off) {
+  const unsigned long long u = static_cast<unsigned long long>(__double_as_longlong(v));
+  const unsigned lo = __shfl_up(static_cast<unsigned>(u), off, 64), hi = __shfl_up(static_cast<unsigned>(u >> 32), off, 64);
+  return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+// Inclusive block scans of one double per thread (1024 threads): sum / maximum.  `part`: 16 doubles of LDS.
+template <bool kMax>
+__device__ __forceinline__ double block_inclusive_scan(double v, double* part, double* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = shfl_up_double(v, off);
+    if (lane >= off) v = kMax ? fmax(v, o) : v + o;
+  }
+  __syncthreads();  // `part` may still be read from an earlier scan
+  if (lane == 63) part[wave] = v;
+  __syncthreads();
+  double before = kMax ? 0.0 : 0.0, all = 0.0;
+  for (int w = 0; w < kThreads / 64; ++w) {
+    const double s = part[w];
+    if (w < wave) before = kMax ? fmax(before, s) : before + s;
+    all = kMax ? fmax(all, s) : all + s;
+  }
+  *total = all;
+  return kMax ? fmax(before, v) : before + v;
+}
+
+// All 1024 threads call this; every thread returns with out[k] = the sequential float sum of v[k][0 .. n) started at acc0[k].
+// v[k] may point to LDS or global memory (generic pointers); it must stay unchanged during the call.
+template <int K>
+__device__ void block_sequential_sums(const float* const (&v)[K], int n, const float (&acc0)[K], float (&out)[K], Scratch<K>& S) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double P[K], Mx[K];
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    acc[k] = acc0[k];
+    P[k] = static_cast<double>(acc0[k]);
+    Mx[k] = fabs(P[k]);
+  }
+  const int num_chunks = (n + kChunk - 1) / kChunk;
+  for (int cb = 0; cb < num_chunks; cb += kChunksPerBlock) {  // uniform
+    const int chunks_here = min(kChunksPerBlock, num_chunks - cb);
+    const int c = cb + tid;
+    const int i0 = c * kChunk, i1 = min(n, i0 + kChunk);
+    double sum[K], lo[K], hi[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double p = 0.0, l = 0.0, h = 0.0;
+      if (tid < chunks_here)
+        for (int i = i0; i < i1; ++i) {
+          p += static_cast<double>(v[k][i]);
+          l = fmin(l, p);
+          h = fmax(h, p);
+        }
+      sum[k] = p;
+      lo[k] = l;
+      hi[k] = h;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double total, mtotal;
+      const double incl = block_inclusive_scan<false>(sum[k], S.wave_part[k], &total);
+      const double Pc = P[k] + (incl - sum[k]);  // real prefix in front of this thread's chunk
+      const double mine = tid < chunks_here ? fmax(fabs(Pc + lo[k]), fabs(Pc + hi[k])) : 0.0;
+      const double mx = fmax(Mx[k], block_inclusive_scan<true>(mine, S.wave_part[k], &mtotal));
+      int code = kNoCode;
+      Fn f = identity_fn();
+      if (tid < chunks_here) {
+        const double count = static_cast<double>(i1);
+        const double E = 1.1 * count * 5.9604644775390625e-8 * mx + 1e-300;
+        const double a = Pc + lo[k] - E, b = Pc + hi[k] + E;
+        if (count <= 1048576.0 && ((a > 0.0 && b > 0.0) || (a < 0.0 && b < 0.0))) {
+          const double m0 = fmin(fabs(a), fabs(b)), m1 = fmax(fabs(a), fabs(b));
+          // binade exponents from the doubles' own exponent fields (both are normal, far from the double range's ends)
+          const long long u0 = __double_as_longlong(m0), u1 = __double_as_longlong(m1);
+          const int e0 = static_cast<int>((u0 >> 52) & 0x7ff) - 1023, e1 = static_cast<int>((u1 >> 52) & 0x7ff) - 1023;
+          const bool power_of_two = (u0 & 0xfffffffffffffll) == 0ll;  // m0 == 2^e0: not strictly inside
+          const int be = e0 + 127;
+          if (e0 == e1 && !power_of_two && be >= 30 && be <= 250) {
+            const int cd = ((a < 0.0 ? 1 : 0) << 16) | be;
+            bool ok = true;
+            for (int i = i0; i < i1; ++i) f = compose(f, element_fn(v[k][i], cd, &ok));
+            if (ok) code = cd;
+          }
+        }
+        S.code[k][tid] = code;
+        S.s0[k][tid] = f.s0;
+        S.s1[k][tid] = f.s1;
+        S.pp[k][tid] = static_cast<unsigned char>(f.p0 | (f.p1 << 1));
+      }
+      P[k] += total;
+      Mx[k] = fmax(Mx[k], mtotal);
+    }
+    __syncthreads();
+    // the walk: wave k takes array k
+    if (wave < K) {
+      float a = acc[0];
+#pragma unroll
+      for (int k = 1; k < K; ++k)
+        if (wave == k) a = acc[k];
+      const int kk = wave;
+      int cc = 0;
+      while (cc < chunks_here) {  // uniform within the wave
+        const int code = code_of(a);
+        const int my = cc + lane;
+        const bool usable = my < chunks_here && code != kNoCode && S.code[kk][my] == code;
+        const unsigned long long ball = __builtin_amdgcn_ballot_w64(usable);
+        const int u = ball == ~0ull ? 64 : __builtin_ctzll(~ball);
+        bool applied = false;
+        if (u > 0) {
+          Fn f = identity_fn();
+          if (lane < u) {
+            const unsigned pp = S.pp[kk][my];
+            f = Fn{S.s0[kk][my], S.s1[kk][my], pp & 1u, pp >> 1};
+          }
+          f = wave_inclusive_scan_fn(f, lane);
+          const int t0 = __shfl(f.s0, u - 1, 64), t1 = __shfl(f.s1, u - 1, 64);
+          const unsigned bits = __float_as_uint(a);
+          const int kcount = static_cast<int>((bits & 0x7fffffu) | 0x800000u);
+          const int k2 = kcount + ((kcount & 1) ? t1 : t0);
+          if (k2 >= (1 << 23) && k2 < (1 << 24)) {
+            a = __uint_as_float((bits & 0xff800000u) | (static_cast<unsigned>(k2) & 0x7fffffu));
+            cc += u;
+            applied = true;
+          }
+        }
+        if (!applied) {  // this chunk's values one after the other
+          if (lane == 0) {
+            const int j0 = (cb + cc) * kChunk, j1 = min(n, j0 + kChunk);
+            float x[kChunk];
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) x[j] = j0 + j < j1 ? v[kk][j0 + j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j)
+              if (j0 + j < j1) a += x[j];  // (a padding +0 would turn an accumulator of -0 into +0)
+          }
+          a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a)));
+          cc += 1;
+        }
+      }
+      if (lane == 0) S.result[kk] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = S.result[k];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = acc[k];
+}
+
+}  // namespace exact_sum
+}  // namespace dliom
+
+#endif  // DLIOM_CSRC_EXACT_SUM_H_

@@ -111,6 +111,10 @@ struct dliom_ctx {
   int aux_histogram_size = 0;  // > 0: a histogram is pending on aux_stream
   unsigned aux_seq = 0;        // its completion word is the one at aux_pinned + 4032
   bool aux_enqueued = false;   // false: the pending histogram is the empty cloud's (nothing on the stream)
+  const dliom_cloud* aux_cloud = nullptr;  // the pending histogram's input, should _finish have to run it again
+  float aux_rotation[4] = {1.f, 0.f, 0.f, 0.f};
+  bool aux_has_rotation = false;
+  bool hist_expect_big = true;  // the previous cloud had height slices above 4096 points (rotational_histogram.hip)
   // profiling
   bool profiling = false;
   unsigned profiling_mask = ~0u;  // kernel ids whose launches are timed

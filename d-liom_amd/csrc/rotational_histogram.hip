@@ -24,13 +24,21 @@
 //   * histogram(bucket) += value (:49): float additions in slice order, then point order.  The slices' contribution
 //     lists lie back to back in slice order; kernel 3: one wave per bucket queues the positions of its entries in
 //     order, fetches the values and one thread adds them one after the other.
-// Limits (DLIOM_ERR_CAPACITY, the host entry point has none): |z| < 409.6 m, at most 4096 points per slice.
+// Slices of more than 4096 points (the floor of every real scan) take the path of rothist_big.h: the same steps on arrays
+// in HBM, a radix sort, std::sort's order of equal angles restricted to the segments that hold ties, and the `last_point`
+// chain by pointer doubling.  The sequential float sums (centroids, bucket additions) are replayed in parallel, exactly
+// (exact_sum.h).  Whether a cloud has such slices is only known on the device: the context remembers what the previous
+// cloud needed and enqueues the big path (or not) accordingly; a cloud that needed it without having it is run again.
+// Limits (DLIOM_ERR_CAPACITY, the host entry point has none): |z| < 409.6 m, at most 63 slices above 4096 points.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 
+#include <hipcub/hipcub.hpp>
+
 #include "device_common.h"
+#include "exact_sum.h"
 
 namespace dliom {
 namespace rothist {
@@ -39,6 +47,7 @@ constexpr int kBins = 4096;
 constexpr int kBinOrigin = 2048;
 constexpr int kMaxSlice = 4096;
 constexpr int kThreads = 1024;
+constexpr int kExactSumFrom = 1024;  // sequential float sums of this many addends and more are replayed in parallel
 constexpr float kMinDistance = 0.2f;
 constexpr float kMaxDistance = 0.9f;
 constexpr float kSliceHeight = 0.2f;
@@ -165,8 +174,8 @@ __global__ __launch_bounds__(kThreads) void prepare_kernel(const float* __restri
     ry[i] = py;
     rz[i] = pz;
     const float kf = pz / kSliceHeight;
-    int key = 0;
-    if (!(fabsf(kf) < 2047.f)) {  // also NaN
+    int key = 0x7fff;  // no slice has this key (the padding's): a rejected point is in nobody's compaction
+    if (!(fabsf(kf) < 2047.f) || !(fabsf(px) < 3.0e38f) || !(fabsf(py) < 3.0e38f)) {  // also NaN / inf
       atomicOr(flags, 1u);
     } else {
       key = lround_away(kf);
@@ -596,11 +605,13 @@ __device__ __forceinline__ void bitonic_sort_keys(unsigned long long* skey, int 
   __syncthreads();
 }
 
+#include "rothist_big.h"
+
 __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict__ rx, const float* __restrict__ ry,
                                                          const float* __restrict__ rz, const short* __restrict__ keys, int n,
                                                          const unsigned* __restrict__ bin_counts, int histogram_size,
                                                          float squared_jump, unsigned char* __restrict__ c_bucket,
-                                                         float* __restrict__ c_value, unsigned* __restrict__ flags) {
+                                                         float* __restrict__ c_value, unsigned* __restrict__ flags, int with_big) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lds_dyn[];  // [sort keys kMaxSlice | sx | sy | sz]; later [.. | px py of the sorted points]
   unsigned long long* skey = lds_dyn;
   float* sx = reinterpret_cast<float*>(skey + kMaxSlice);
@@ -612,21 +623,36 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
   const SortScratch sort_scratch{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
                                  u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16};
   unsigned short* idx_of = u16_base + 7 * kU16;  // arrangement position -> position in the slice
+  // the centroids' exact sums (slices of kExactSumFrom points and more) borrow the sort's scratch: neither centroid is
+  // computed while a sort is under way
+  static_assert(sizeof(exact_sum::Scratch<2>) <= 8 * static_cast<size_t>(kMaxSlice + 8) * 2, "the sort scratch holds it");
+  exact_sum::Scratch<2>& es = *reinterpret_cast<exact_sum::Scratch<2>*>(u16_base);
   __shared__ unsigned wave_sums[kThreads / 64];
   __shared__ unsigned sh_bin, sh_count, sh_begin, sh_valid, sh_written;
   __shared__ float sh_centroid[3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // ---- which slice: the (blockIdx.x)-th non-empty bin, then every gridDim.x-th; offsets = prefix of the counts
   unsigned my_counts[kBins / kThreads], my_sum = 0u, my_nonempty = 0u;
+  int my_big = 0;
 #pragma unroll
   for (int k = 0; k < kBins / kThreads; ++k) {
     my_counts[k] = bin_counts[threadIdx.x * (kBins / kThreads) + k];
     my_sum += my_counts[k];
     my_nonempty += my_counts[k] != 0u ? 1u : 0u;
+    my_big |= my_counts[k] > static_cast<unsigned>(kMaxSlice) ? 1 : 0;
   }
   unsigned total_points, total_slices;
   const unsigned points_before = block_exclusive_scan(my_sum, wave_sums, &total_points);
   const unsigned slices_before = block_exclusive_scan(my_nonempty, wave_sums, &total_slices);
+  {
+    // slices above kMaxSlice belong to the kernels of rothist_big.h.  flags[1] tells the host whether the cloud had any
+    // (what the next cloud's launch plan is made from); flags[0] bit 3: it had, and those kernels were not enqueued
+    const int any_big = __syncthreads_or(my_big);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && any_big) {
+      flags[1] = 1u;
+      if (!with_big) atomicOr(flags, 8u);
+    }
+  }
 #ifdef DLIOM_EXPERIMENTS
 #define DLIOM_STAMP(k) if (threadIdx.x == 0 && blockIdx.x < 64) dbg_stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter()
 #else
@@ -654,10 +680,7 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     const int key = static_cast<int>(sh_bin) - kBinOrigin;
     const int count = static_cast<int>(sh_count);
     const unsigned begin = sh_begin;
-    if (count > kMaxSlice) {
-      if (threadIdx.x == 0) atomicOr(flags, 2u);
-      continue;
-    }
+    if (count > kMaxSlice) continue;  // big_prepare_kernel / big_slice_kernel
     // ---- the slice's points in input order: wave w compacts its contiguous share of the input, 512 keys (8 per lane,
     //      one 16-byte load) per step; a lane's keys are consecutive, so input order = (step, lane, position in lane)
     const int blocks512 = (n + 511) / 512;
@@ -718,8 +741,18 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     __syncthreads();
     DLIOM_STAMP(1);
     // ---- SortSlice: centroid (sequential float sums), angles, sort by angle
-    if (lane == 0 && wave < 3)  // one thread per coordinate (on three different SIMDs)
-      sh_centroid[wave] = thread_sequential_sum(wave == 0 ? sx : (wave == 1 ? sy : sz), count, 0.f) / static_cast<float>(count);
+    if (count >= kExactSumFrom) {  // the same sums as parity functions (exact_sum.h); z's is never read
+      const float* const arrays[2] = {sx, sy};
+      const float zero[2] = {0.f, 0.f};
+      float sums[2];
+      exact_sum::block_sequential_sums<2>(arrays, count, zero, sums, es);
+      if (threadIdx.x == 0) {
+        sh_centroid[0] = sums[0] / static_cast<float>(count);
+        sh_centroid[1] = sums[1] / static_cast<float>(count);
+      }
+    } else if (lane == 0 && wave < 2) {  // one thread per coordinate (on different SIMDs)
+      sh_centroid[wave] = thread_sequential_sum(wave == 0 ? sx : sy, count, 0.f) / static_cast<float>(count);
+    }
     __syncthreads();
     DLIOM_STAMP(2);
     int pow2 = 64;
@@ -822,8 +855,18 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     }
     __syncthreads();
     // ---- AddPointCloudSliceToHistogram: centroid of the SORTED points (sequential again; z is not used below)
-    if (lane == 0 && wave < 2)
+    if (m >= kExactSumFrom) {
+      const float* const arrays[2] = {px_sorted, py_sorted};
+      const float zero[2] = {0.f, 0.f};
+      float sums[2];
+      exact_sum::block_sequential_sums<2>(arrays, m, zero, sums, es);
+      if (threadIdx.x == 0) {
+        sh_centroid[0] = sums[0] / static_cast<float>(m);
+        sh_centroid[1] = sums[1] / static_cast<float>(m);
+      }
+    } else if (lane == 0 && wave < 2) {
       sh_centroid[wave] = thread_sequential_sum(wave == 0 ? px_sorted : py_sorted, m, 0.f) / static_cast<float>(m);
+    }
     __syncthreads();
     DLIOM_STAMP(5);
     // (a) which points can never contribute: closer than kMinDistance to the centroid (:73-75)
@@ -928,12 +971,12 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
 // One wave per bucket: (1) scan the bucket bytes, 1024 entries per step, and queue the positions of its own entries in
 // order (wave prefix sums); (2) fetch their values, every lane busy; (3) one thread adds them one after the other.
 constexpr int kAccCap = 24576;   // queue entries (dynamic LDS, 96 KB): a wall-dominated scan puts ~40 % of its points in one bucket
-constexpr int kAccWaves = 8;      // waves per bucket in the parallel scan
-constexpr int kAccHoldSteps = 8;  // steps of 1024 entries a wave keeps as one match bit per (lane, row): 2^16 entries per bucket
+constexpr int kAccWaves = kThreads / 64;  // waves per bucket in the parallel scan (the exact sum is written for 1024 threads)
+constexpr int kAccHoldSteps = 16;  // steps of 1024 entries a wave keeps as one match bit per (lane, row): 2^18 entries per bucket
 
 // (2) + (3): values of the queued positions, every lane of the workgroup busy, then ONE thread adds them in order.
 __device__ __forceinline__ float fetch_and_sum(float* queue, unsigned queued, const float* __restrict__ c_value, float sum,
-                                               int tid, int nthreads, bool workgroup) {
+                                               int tid, int nthreads, bool workgroup, exact_sum::Scratch<1>* es) {
   if (workgroup) __syncthreads();
   else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -957,6 +1000,15 @@ __device__ __forceinline__ float fetch_and_sum(float* queue, unsigned queued, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
+  if (workgroup && queued >= static_cast<unsigned>(kExactSumFrom)) {
+    // histogram(bucket) += value, one after the other (:49): a wall-dominated scan puts 18 000 of them into one bucket.
+    // The same float is reached by composing the additions as parity functions (exact_sum.h); every thread gets it.
+    const float* const arrays[1] = {queue};
+    const float start[1] = {sum};
+    float out[1];
+    exact_sum::block_sequential_sums<1>(arrays, static_cast<int>(queued), start, out, *es);
+    return out[0];
+  }
   if (tid == 0) sum = thread_sequential_sum(queue, static_cast<int>(queued), sum);
   if (workgroup) __syncthreads();
   else __builtin_amdgcn_wave_barrier();
@@ -973,6 +1025,7 @@ __global__ __launch_bounds__(64 * kAccWaves) void accumulate_kernel(const unsign
                                                                     int histogram_size, float* __restrict__ histogram) {
   extern __shared__ __attribute__((aligned(16))) float queue[];  // kAccCap + 64: positions (as bits), then the values in place
   __shared__ unsigned wave_count[kAccWaves];
+  __shared__ exact_sum::Scratch<1> es;
   const int bucket = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (bucket >= histogram_size) return;
   const int steps = n_padded / 1024;
@@ -1028,7 +1081,7 @@ __global__ __launch_bounds__(64 * kAccWaves) void accumulate_kernel(const unsign
           }
         }
       }
-      const float sum = fetch_and_sum(queue, total, c_value, 0.f, static_cast<int>(threadIdx.x), 64 * kAccWaves, true);
+      const float sum = fetch_and_sum(queue, total, c_value, 0.f, static_cast<int>(threadIdx.x), 64 * kAccWaves, true, &es);
       if (threadIdx.x == 0) histogram[bucket] = sum;
       return;
     }
@@ -1052,7 +1105,7 @@ __global__ __launch_bounds__(64 * kAccWaves) void accumulate_kernel(const unsign
     }
     if (step_total == 0u) continue;
     if (queued + step_total > kAccCap) {
-      sum = fetch_and_sum(queue, queued, c_value, sum, lane, 64, false);
+      sum = fetch_and_sum(queue, queued, c_value, sum, lane, 64, false, nullptr);
       sum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sum)));
       queued = 0u;
     }
@@ -1067,7 +1120,7 @@ __global__ __launch_bounds__(64 * kAccWaves) void accumulate_kernel(const unsign
     }
     queued += step_total;
   }
-  sum = fetch_and_sum(queue, queued, c_value, sum, lane, 64, false);
+  sum = fetch_and_sum(queue, queued, c_value, sum, lane, 64, false, nullptr);
   if (lane == 0) histogram[bucket] = sum;
 }
 
@@ -1128,22 +1181,79 @@ __global__ __launch_bounds__(kThreads) void std_sort_order_kernel(const float* _
 }  // namespace rothist
 }  // namespace dliom
 
+namespace {
+// Carves the arrays of rothist_big.h out of `base` (returns the bytes used); `entries` = points + 64 (every slice works at
+// offset begin + ordinal and keeps one sentinel behind its last entry)
+size_t carve_big_arrays(char* base, size_t entries, dliom::rothist::BigArrays* A) {
+  size_t at = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base == nullptr ? nullptr : base + at;
+    at += (bytes + 255) & ~static_cast<size_t>(255);
+    return p;
+  };
+  const size_t e = entries + 64;
+  A->key_in = reinterpret_cast<unsigned long long*>(take(e * 8));
+  A->key_out = reinterpret_cast<unsigned long long*>(take(e * 8));
+  A->arr = reinterpret_cast<unsigned long long*>(take(e * 8));
+  A->bx = reinterpret_cast<float*>(take(e * 4));
+  A->by = reinterpret_cast<float*>(take(e * 4));
+  A->spx = reinterpret_cast<float*>(take(e * 4));
+  A->spy = reinterpret_cast<float*>(take(e * 4));
+  A->val_in = reinterpret_cast<unsigned*>(take(e * 4));
+  A->val_out = reinterpret_cast<unsigned*>(take(e * 4));
+  unsigned** u32s[] = {&A->seg_first, &A->seg_last, &A->g, &A->l, &A->tmp_l, &A->tmp_r, &A->cut, &A->tpre, &A->pos_of, &A->sorted_id,
+                       &A->jump_a, &A->jump_b};
+  for (unsigned** q : u32s) *q = reinterpret_cast<unsigned*>(take(e * 4));
+  unsigned char** u8s[] = {&A->act, &A->fl, &A->tied, &A->dead, &A->mark};
+  for (unsigned char** q : u8s) *q = reinterpret_cast<unsigned char*>(take(e));
+  A->valid = reinterpret_cast<unsigned*>(take(256));
+  return at;
+}
+}  // namespace
+
 extern "C" int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int n, int32_t* order) {
   using namespace rothist;
-  if (ctx == nullptr || (n > 0 && (keys == nullptr || order == nullptr)) || n < 0 || n > kMaxSlice) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (ctx == nullptr || (n > 0 && (keys == nullptr || order == nullptr)) || n < 0 || n > (1 << 22)) return DLIOM_ERR_INVALID_ARGUMENT;
   if (n == 0) return DLIOM_OK;
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  if (n > kMaxSlice) {
+    // the path of slices above kMaxSlice (rothist_big.h): radix sort + the order of equal keys from introsort's partitions
+    BigArrays A;
+    const size_t entries = static_cast<size_t>(n);
+    const size_t big_bytes = carve_big_arrays(nullptr, entries, &A);
+    size_t temp_bytes = 0;
+    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, n, 0, 32, ctx->stream));
+    const size_t keys_at = (big_bytes + 255) & ~static_cast<size_t>(255);
+    const size_t order_at = keys_at + ((static_cast<size_t>(n) * 4 + 255) & ~static_cast<size_t>(255));
+    const size_t temp_at = order_at + ((static_cast<size_t>(n) * 4 + 256 + 255) & ~static_cast<size_t>(255));
+    DLIOM_TRY(ctx->misc.reserve(temp_at + temp_bytes + 256));
+    char* base = static_cast<char*>(ctx->misc.p);
+    carve_big_arrays(base, entries, &A);
+    float* d_keys = reinterpret_cast<float*>(base + keys_at);
+    int* d_order = reinterpret_cast<int*>(base + order_at);
+    int* d_status = d_order + n;
+    DLIOM_HIP_TRY(hipMemcpyAsync(d_keys, keys, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(big_sort_items_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_keys, n, A.key_in, A.val_in);
+    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(base + temp_at, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, n, 0, 32,
+                                                     ctx->stream));
+    hipLaunchKernelGGL(big_sort_order_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, n, A, d_order, d_status);
+    DLIOM_HIP_TRY(hipGetLastError());
+    int status = 0;
+    DLIOM_HIP_TRY(hipMemcpyAsync(order, d_order, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DLIOM_HIP_TRY(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return status == 0 ? DLIOM_OK : DLIOM_ERR_CAPACITY;
+  }
   DLIOM_TRY(ctx->misc.reserve(static_cast<size_t>(kMaxSlice) * 8 + 256));
   float* d_keys = ctx->misc.as<float>();
   int* d_order = reinterpret_cast<int*>(d_keys + kMaxSlice);
   int* d_status = d_order + kMaxSlice;
   DLIOM_HIP_TRY(hipMemcpyAsync(d_keys, keys, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, ctx->stream));
   const size_t lds = static_cast<size_t>(kMaxSlice) * 8 + 8 * static_cast<size_t>(kMaxSlice + 8) * 2;
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
+  if ((ctx->func_attr_set & kFuncAttrStdSortDiag) == 0u) {
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(std_sort_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds)));
-    attr_set = true;
+    ctx->func_attr_set |= kFuncAttrStdSortDiag;
   }
   hipLaunchKernelGGL(std_sort_order_kernel, dim3(1), dim3(kThreads), lds, ctx->stream, d_keys, n, d_order, d_status);
   DLIOM_HIP_TRY(hipGetLastError());
@@ -1154,14 +1264,53 @@ extern "C" int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int 
   return status == 0 ? DLIOM_OK : DLIOM_ERR_CAPACITY;  // std::sort's depth limit (heap sort from there): not reproduced
 }
 
+// The exact parallel replay of a sequential float sum (exact_sum.h) on bare values, for the tests: k arrays of n floats
+// (values: k x n row major), each started at acc0[k] -> sums[k].
+namespace dliom {
+namespace rothist {
+__global__ __launch_bounds__(kThreads) void sequential_sums_kernel(const float* __restrict__ values, int n, const float* __restrict__ acc0,
+                                                                   float* __restrict__ sums) {
+  __shared__ exact_sum::Scratch<1> es;
+  const float* const arrays[1] = {values + static_cast<size_t>(blockIdx.x) * n};
+  const float start[1] = {acc0[blockIdx.x]};
+  float out[1];
+  exact_sum::block_sequential_sums<1>(arrays, n, start, out, es);
+  if (threadIdx.x == 0) sums[blockIdx.x] = out[0];
+}
+}  // namespace rothist
+}  // namespace dliom
+
+extern "C" int dliom_diag_sequential_sums(dliom_ctx* ctx, const float* values, int k, int n, const float* acc0, float* sums) {
+  if (ctx == nullptr || values == nullptr || acc0 == nullptr || sums == nullptr || k <= 0 || k > 65535 || n < 0 ||
+      static_cast<int64_t>(k) * n > (int64_t{1} << 28))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t v_bytes = (static_cast<size_t>(k) * n * 4 + 255) & ~static_cast<size_t>(255);
+  DLIOM_TRY(ctx->misc.reserve(v_bytes + static_cast<size_t>(k) * 8 + 256));
+  float* d_v = ctx->misc.as<float>();
+  float* d_a = reinterpret_cast<float*>(static_cast<char*>(ctx->misc.p) + v_bytes);
+  float* d_s = d_a + k;
+  if (n > 0) DLIOM_HIP_TRY(hipMemcpyAsync(d_v, values, static_cast<size_t>(k) * n * 4, hipMemcpyHostToDevice, ctx->stream));
+  DLIOM_HIP_TRY(hipMemcpyAsync(d_a, acc0, static_cast<size_t>(k) * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(rothist::sequential_sums_kernel, dim3(static_cast<unsigned>(k)), dim3(rothist::kThreads), 0, ctx->stream, d_v, n, d_a, d_s);
+  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_HIP_TRY(hipMemcpyAsync(sums, d_s, static_cast<size_t>(k) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
 namespace {
-// Enqueues the three kernels and the read-back of [histogram | flags] into `pinned_dst` on `stream`; no synchronisation.
+constexpr int kRetryWithBigPath = 1000;  // read_histogram: the cloud has slices above kMaxSlice and their kernels were not enqueued
+
+// Enqueues the kernels and the read-back of [histogram | flags | had-big-slices] into `pinned_dst` on `stream`; no
+// synchronisation.  with_big: the kernels of rothist_big.h are part of the chain.
 int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch, void* pinned_dst, const dliom_cloud* cloud,
-                      const float rotation_wxyz[4], int histogram_size, unsigned* done_word = nullptr, unsigned done_seq = 0) {
+                      const float rotation_wxyz[4], int histogram_size, bool with_big, unsigned* done_word = nullptr,
+                      unsigned done_seq = 0) {
   using namespace rothist;
   const int n = static_cast<int>(cloud->n);
   // scratch: [rx | ry | rz | c_value] floats, [keys] shorts (padded to 512), [c_bucket] bytes (padded to 1024),
-  // [bin_counts | flags], [histogram]
+  // [bin_counts | flags], [histogram], then the arrays of the big path and the radix sort's temporary storage
   const size_t N = static_cast<size_t>(n);
   const size_t n_padded = (N + 1023) & ~static_cast<size_t>(1023);
   const size_t f_bytes = n_padded * 4;
@@ -1169,7 +1318,16 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
   const size_t b_bytes = n_padded;
   const size_t counts_bytes = (kBins + 64) * 4;
   const size_t hist_bytes = 1024;
-  DLIOM_TRY(scratch.reserve(4 * f_bytes + k_bytes + b_bytes + counts_bytes + hist_bytes));
+  const size_t small_bytes = 4 * f_bytes + k_bytes + b_bytes + counts_bytes + hist_bytes;
+  BigArrays A{};
+  size_t big_bytes = 0, temp_bytes = 0;
+  const int sort_items = n + 64;
+  if (with_big) {
+    big_bytes = carve_big_arrays(nullptr, N, &A);
+    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, sort_items, 0,
+                                                     kBigKeyBits, stream));
+  }
+  DLIOM_TRY(scratch.reserve(small_bytes + big_bytes + temp_bytes + 512));
   char* base = static_cast<char*>(scratch.p);
   float* rx = reinterpret_cast<float*>(base);
   float* ry = reinterpret_cast<float*>(base + f_bytes);
@@ -1178,11 +1336,15 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
   short* keys = reinterpret_cast<short*>(base + 4 * f_bytes);
   unsigned char* c_bucket = reinterpret_cast<unsigned char*>(base + 4 * f_bytes + k_bytes);
   unsigned* bin_counts = reinterpret_cast<unsigned*>(base + 4 * f_bytes + k_bytes + b_bytes);
-  unsigned* flags = bin_counts + kBins;
+  unsigned* flags = bin_counts + kBins;  // [0] refusals, [1] the cloud has slices above kMaxSlice
   float* d_hist = reinterpret_cast<float*>(base + 4 * f_bytes + k_bytes + b_bytes + counts_bytes);
+  char* big_base = base + small_bytes;
+  void* sort_temp = big_base + big_bytes;
+  if (with_big) carve_big_arrays(big_base, N, &A);
   {
-    const FillJob fills[2] = {{bin_counts, counts_bytes, 0u}, {c_bucket, b_bytes, 0xFFFFFFFFu}};  // bucket 255 = no entry
-    DLIOM_TRY(fill_multi(ctx, fills, 2, stream));
+    FillJob fills[3] = {{bin_counts, counts_bytes, 0u}, {c_bucket, b_bytes, 0xFFFFFFFFu}, {nullptr, 0, 0u}};  // bucket 255 = no entry
+    if (with_big) fills[2] = FillJob{A.key_in, (static_cast<size_t>(sort_items) * 8 + 3) & ~static_cast<size_t>(3), 0xFFFFFFFFu};  // padding keys sort last
+    DLIOM_TRY(fill_multi(ctx, fills, with_big ? 3 : 2, stream));
   }
   Quat4 q{1.f, 0.f, 0.f, 0.f};
   if (rotation_wxyz != nullptr) q = Quat4{rotation_wxyz[0], rotation_wxyz[1], rotation_wxyz[2], rotation_wxyz[3]};
@@ -1191,13 +1353,12 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
                      rotation_wxyz != nullptr ? 1 : 0, rx, ry, rz, keys, bin_counts, flags);
   const size_t lds = static_cast<size_t>(kMaxSlice) * (8 + 12) + 8 * static_cast<size_t>(kMaxSlice + 8) * 2 + 1024;
   const size_t acc_lds = static_cast<size_t>(kAccCap + 64) * 4;
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
+  if ((ctx->func_attr_set & kFuncAttrHistogram) == 0u) {
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds)));
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(acc_lds)));
-    attr_set = true;
+    ctx->func_attr_set |= kFuncAttrHistogram;
   }
   // the smallest float s with fl(sqrt(s)) > kMaxDistance: `distance > kMaxDistance` as a comparison of squared lengths
   static const float squared_jump = [] {
@@ -1206,23 +1367,59 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
     while (!(std::sqrt(s2) > kMaxDistance)) s2 = std::nextafter(s2, 2.f);
     return s2;
   }();
+  if (with_big) {  // first: the small slices' workgroups then run beside the sort
+    hipLaunchKernelGGL(big_prepare_kernel, dim3(kMaxBig), dim3(kThreads), 0, stream, rx, ry, keys, n, bin_counts, A, flags);
+    DLIOM_HIP_TRY(hipGetLastError());
+  }
   hipLaunchKernelGGL(slice_kernel, dim3(256), dim3(kThreads), lds, stream, rx, ry, rz, keys, n, bin_counts, histogram_size,
-                     squared_jump, c_bucket, c_value, flags);
+                     squared_jump, c_bucket, c_value, flags, with_big ? 1 : 0);
+  if (with_big) {
+    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_temp, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, sort_items, 0,
+                                                     kBigKeyBits, stream));
+    hipLaunchKernelGGL(big_slice_kernel, dim3(kMaxBig), dim3(kThreads), 0, stream, bin_counts, histogram_size, squared_jump, A, c_bucket,
+                       c_value, flags);
+  }
   hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64 * kAccWaves), acc_lds, stream, c_bucket,
                      c_value, static_cast<int>(n_padded), histogram_size, d_hist);
   DLIOM_HIP_TRY(hipGetLastError());
-  // one read-back: [histogram | flags] through pinned memory
-  const GatherJob back[2] = {{d_hist, static_cast<unsigned>(histogram_size)}, {flags, 1}};
+  // one read-back: [histogram | flags | had-big] through pinned memory
+  const GatherJob back[2] = {{d_hist, static_cast<unsigned>(histogram_size)}, {flags, 2}};
   return gather_to_pinned(ctx, back, 2, pinned_dst, stream, done_word, done_seq);
 }
 
-int read_histogram(const void* pinned_src, int histogram_size, float* histogram) {
+// DLIOM_OK, DLIOM_ERR_CAPACITY (use dliom_rotational_histogram) or kRetryWithBigPath; *had_big: the cloud had slices
+// above kMaxSlice
+int read_histogram(const void* pinned_src, int histogram_size, float* histogram, bool* had_big) {
   const float* h = static_cast<const float*>(pinned_src);
-  unsigned f;
-  std::memcpy(&f, h + histogram_size, 4);
-  if (f != 0u) return DLIOM_ERR_CAPACITY;  // |z| >= 409.6 m or a slice of more than 4096 points: use dliom_rotational_histogram
+  unsigned f[2];
+  std::memcpy(f, h + histogram_size, 8);
+  *had_big = f[1] != 0u;
+  if ((f[0] & ~8u) != 0u) return DLIOM_ERR_CAPACITY;  // |z| >= 409.6 m, non-finite coordinates, more than 63 big slices, ...
+  if ((f[0] & 8u) != 0u) return kRetryWithBigPath;
   std::memcpy(histogram, h, static_cast<size_t>(histogram_size) * 4);
   return DLIOM_OK;
+}
+
+// One complete histogram on `stream`, waiting for it; runs the cloud a second time when it turns out to need the big
+// path that was not enqueued (the context then expects big slices from the next cloud on).
+int run_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch, void* pinned, unsigned* done_word, unsigned* seq_counter,
+                  const dliom_cloud* cloud, const float rotation_wxyz[4], int histogram_size, float* histogram) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool with_big = ctx->hist_expect_big || attempt == 1;
+    if (done_word != nullptr) {
+      const unsigned seq = ++*seq_counter == 0u ? ++*seq_counter : *seq_counter;
+      DLIOM_TRY(enqueue_histogram(ctx, stream, scratch, pinned, cloud, rotation_wxyz, histogram_size, with_big, done_word, seq));
+      DLIOM_TRY(wait_done(ctx, stream, done_word, seq));
+    } else {
+      DLIOM_TRY(enqueue_histogram(ctx, stream, scratch, pinned, cloud, rotation_wxyz, histogram_size, with_big));
+      DLIOM_HIP_TRY(hipStreamSynchronize(stream));
+    }
+    bool had_big = false;
+    const int status = read_histogram(pinned, histogram_size, histogram, &had_big);
+    ctx->hist_expect_big = had_big;
+    if (status != kRetryWithBigPath) return status;
+  }
+  return DLIOM_ERR_CAPACITY;
 }
 }  // namespace
 
@@ -1237,20 +1434,14 @@ extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_clou
   }
   if (cloud->n > (int64_t{1} << 26)) return DLIOM_ERR_CAPACITY;
   void* h = static_cast<char*>(ctx->pinned) + 2048;
-  if (ctx->done_word != nullptr) {
-    const unsigned seq = ++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq;
-    DLIOM_TRY(enqueue_histogram(ctx, ctx->stream, ctx->misc, h, cloud, rotation_wxyz, histogram_size, ctx->done_word, seq));
-    DLIOM_TRY(wait_done(ctx, ctx->stream, ctx->done_word, seq));
-  } else {
-    DLIOM_TRY(enqueue_histogram(ctx, ctx->stream, ctx->misc, h, cloud, rotation_wxyz, histogram_size));
-    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  }
-  return read_histogram(h, histogram_size, histogram);
+  return run_histogram(ctx, ctx->stream, ctx->misc, h, ctx->done_word, &ctx->done_seq, cloud, rotation_wxyz, histogram_size, histogram);
 }
 
 // The same in two halves on the context's auxiliary stream: everything enqueued on the context so far is waited for
 // (an event), then the histogram runs BESIDE whatever the caller puts on the context next -- the reference computes it
 // right after InsertIntoSubmap from the same filtered cloud (local_trajectory_builder_3d.cc:590-610); neither writes it.
+// The cloud must stay alive and unchanged until _finish returns (a cloud that turns out to have slices above 4096 points
+// when the context did not expect any is run again there).
 extern "C" int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
                                                       int histogram_size) {
   if (ctx == nullptr || cloud == nullptr || histogram_size <= 0 || histogram_size > 255) return DLIOM_ERR_INVALID_ARGUMENT;
@@ -1285,9 +1476,12 @@ extern "C" int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dlio
   DLIOM_HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
   ctx->aux_seq = ++ctx->aux_seq == 0u ? 1u : ctx->aux_seq;
   DLIOM_TRY(enqueue_histogram(ctx, ctx->aux_stream, ctx->aux_scratch, ctx->aux_pinned, cloud, rotation_wxyz, histogram_size,
-                              reinterpret_cast<unsigned*>(static_cast<char*>(ctx->aux_pinned) + 4032), ctx->aux_seq));
+                              ctx->hist_expect_big, reinterpret_cast<unsigned*>(static_cast<char*>(ctx->aux_pinned) + 4032), ctx->aux_seq));
   ctx->aux_histogram_size = histogram_size;
   ctx->aux_enqueued = true;
+  ctx->aux_cloud = cloud;
+  ctx->aux_has_rotation = rotation_wxyz != nullptr;
+  if (rotation_wxyz != nullptr) std::memcpy(ctx->aux_rotation, rotation_wxyz, sizeof(ctx->aux_rotation));
   return DLIOM_OK;
 }
 
@@ -1296,7 +1490,13 @@ extern "C" int dliom_cloud_rotational_histogram_finish(dliom_ctx* ctx, float* hi
   const int size = ctx->aux_histogram_size;
   ctx->aux_histogram_size = 0;
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  if (ctx->aux_enqueued)
-    DLIOM_TRY(wait_done(ctx, ctx->aux_stream, reinterpret_cast<const unsigned*>(static_cast<const char*>(ctx->aux_pinned) + 4032), ctx->aux_seq));
-  return read_histogram(ctx->aux_pinned, size, histogram);
+  unsigned* word = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->aux_pinned) + 4032);
+  if (ctx->aux_enqueued) DLIOM_TRY(wait_done(ctx, ctx->aux_stream, word, ctx->aux_seq));
+  bool had_big = false;
+  const int status = read_histogram(ctx->aux_pinned, size, histogram, &had_big);
+  if (ctx->aux_enqueued) ctx->hist_expect_big = had_big;
+  if (status != kRetryWithBigPath) return status;
+  ctx->hist_expect_big = true;  // the first cloud with a floor after clouds without one: once more, with the big path
+  return run_histogram(ctx, ctx->aux_stream, ctx->aux_scratch, ctx->aux_pinned, word, &ctx->aux_seq, ctx->aux_cloud,
+                       ctx->aux_has_rotation ? ctx->aux_rotation : nullptr, size, histogram);
 }

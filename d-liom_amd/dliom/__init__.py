@@ -289,6 +289,7 @@ SYMBOLS = [
     ("dliom_cloud_rotational_histogram_begin", C.c_int, [_vp, _vp, _f32p, C.c_int]),
     ("dliom_cloud_rotational_histogram_finish", C.c_int, [_vp, _f32p]),
     ("dliom_diag_std_sort_order", C.c_int, [_vp, _f32p, C.c_int, C.POINTER(C.c_int32)]),
+    ("dliom_diag_sequential_sums", C.c_int, [_vp, _f32p, C.c_int, C.c_int, _f32p, _f32p]),
     ("dliom_rotational_scan_match", C.c_int, [_f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
@@ -1260,8 +1261,22 @@ def cloud_rotational_histogram_finish(ctx, histogram_size):
     return out
 
 
+def diag_sequential_sums(ctx, values, acc0=None):
+    """dliom_diag_sequential_sums: the device's exact parallel replay of sequential float sums; values (k, n)."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    if v.ndim == 1:
+        v = v.reshape(1, -1)
+    k, n = v.shape
+    a = np.zeros(k, dtype=np.float32) if acc0 is None else np.ascontiguousarray(acc0, dtype=np.float32).reshape(k)
+    out = np.zeros(k, dtype=np.float32)
+    _check(load_library().dliom_diag_sequential_sums(ctx.h, _p(v, _f32p), k, n, _p(a, _f32p), _p(out, _f32p)),
+           "dliom_diag_sequential_sums")
+    return out
+
+
 def diag_std_sort_order(ctx, keys):
-    """dliom_diag_std_sort_order: the device's restatement of std::sort's order (ties included) for <= 4096 keys."""
+    """dliom_diag_std_sort_order: the device's restatement of std::sort's order (ties included); <= 4096 keys through the
+    LDS path of the small slices, more through the HBM path."""
     keys = _f32(keys).reshape(-1)
     out = np.zeros(len(keys), dtype=np.int32)
     _check(load_library().dliom_diag_std_sort_order(ctx.h, _p(keys, _f32p), len(keys), out.ctypes.data_as(C.POINTER(C.c_int32))),

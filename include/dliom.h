@@ -528,9 +528,13 @@ int dliom_rotational_histogram(const float* points_xyz, int64_t n, int histogram
 /* The same on the device, on a cloud that is already in HBM (the filtered cloud of the front end), fused with the
  * gravity alignment of local_trajectory_builder_3d.cc:605-610: histogram of Rigid3f::Rotation(rotation_wxyz) * point
  * (rotation_wxyz == NULL: the points as they are).  Bit-identical to the host function (additions in the reference's
- * order; atan2f is glibc 2.35's float algorithm) unless two DISTINCT points of one 0.2 m slice have bit-identical
- * angles around the slice's centroid (the reference's std::sort leaves their order unspecified).  histogram_size <= 255.
- * DLIOM_ERR_CAPACITY: |z| >= 409.6 m or more than 4096 points in one slice -- use the host function. */
+ * order -- the sequential float sums are replayed in parallel, exactly; atan2f is glibc 2.35's float algorithm; equal
+ * angles of one slice come out in the order libstdc++'s std::sort leaves them in).  histogram_size <= 255.  Slices of
+ * any size: up to 4096 points of one 0.2 m slice are processed in LDS, larger ones (the floor of every real scan: 15 000
+ * returns of a filtered 64-beam scan) in HBM.  Whether a cloud has such slices is only known on the device; the context
+ * enqueues their kernels when the previous cloud had any, and runs a cloud again that needed them without having them.
+ * DLIOM_ERR_CAPACITY: |z| >= 409.6 m, non-finite coordinates, more than 63 slices above 4096 points, or std::sort's
+ * heap-sort fallback on a segment of more than 8192 elements of such a slice -- use the host function. */
 int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
                                      int histogram_size, float* histogram);
 /* The same in two halves: _begin enqueues the kernels on an auxiliary stream of the context, behind everything the
@@ -541,10 +545,15 @@ int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_cloud* cloud, c
 int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
                                            int histogram_size);
 int dliom_cloud_rotational_histogram_finish(dliom_ctx* ctx, float* histogram);
-/* Diagnostic: indices of n <= 4096 float keys in the order the device's SortSlice leaves them -- libstdc++'s std::sort
+/* Diagnostic: indices of n float keys in the order the device's SortSlice leaves them -- libstdc++'s std::sort
  * on (key, index) pairs compared by key only, EQUAL keys included (introsort's partitions restated as data-parallel
- * rounds, its heap sort at the depth limit, and a stable sort for the final insertion sort). */
+ * rounds, its heap sort at the depth limit, and a stable sort for the final insertion sort).  n <= 4096: the LDS path of
+ * the small slices; above: the HBM path (radix sort + the partition rounds on the segments that hold ties). */
 int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int n, int32_t* order);
+/* Diagnostic: the exact parallel replay of sequential float sums the histogram uses for ComputeCentroid and
+ * histogram(bucket) += value (rotational_scan_matcher.cc:49,52-59): k arrays of n floats (values: k x n, row major),
+ * sums[i] = (((acc0[i] + v[0]) + v[1]) + ...) in exactly that order, computed by one workgroup per array. */
+int dliom_diag_sequential_sums(dliom_ctx* ctx, const float* values, int k, int n, const float* acc0, float* sums);
 /* The same with an explicit number of host threads (0 = as many as pay, at most 8; the bits do not depend on it). */
 int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n, int histogram_size, int num_threads, float* histogram);
 /* RotationalScanMatcher(histograms_at_angles).Match(histogram, initial_angle, angles)

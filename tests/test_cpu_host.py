@@ -588,3 +588,46 @@ def test_cpp_range_data_synchronizer_on_the_cpu(tmp_path):
             assert a[0] == b[0] and np.array_equal(np.array(a[1:], np.float32).view(np.uint32), np.array(b[1:], np.float32).view(np.uint32)), (a, b)
         merged_calls += g[1] == 2
     assert merged_calls == 3
+
+
+def test_exact_parallel_replay_of_sequential_float_sums_model(tmp_path):
+    """tests/cpp/exact_sum_model.h is the algorithm of d-liom_amd/csrc/exact_sum.h in plain C++ (parity functions per
+    binade, chunks proven safe by the real prefix sums within a rigorous error bound, sequential additions for the
+    rest): 4 000 random arrays of up to 200 000 addends against the plain float loop, bit for bit."""
+    exe = str(tmp_path / "exact_sum_model_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "exact_sum_model_test.cc")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "mismatches: 0 of 4000" in out.stdout, out.stdout
+
+
+def test_big_slice_histogram_formulation_equals_the_reference_restated(tmp_path, orc):
+    """tests/cpp/hist_big_model.cc: the formulation rothist_big.h uses for height slices above 4096 points (exact replay
+    of the centroid / bucket sums, stable sort + std::sort's order of equal angles from introsort's partitions on the
+    segments that hold ties, `last_point` by pointer doubling) against a direct restatement of
+    rotational_scan_matcher.cc:29-123,159-170 with this machine's std::sort and atan2f -- on yard scans (a floor: slices
+    of 14 000 ... 35 000 points), a cube scan, a cloud full of ties and the empty cloud."""
+    import struct
+    from dliom import synth
+    exe = str(tmp_path / "hist_big_model")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "hist_big_model.cc")])
+    path = str(tmp_path / "clouds.bin")
+    with open(path, "wb") as f:
+        def put(p):
+            p = np.ascontiguousarray(p, np.float32)
+            f.write(struct.pack("i", len(p)))
+            f.write(p.tobytes())
+        with synth.scene("ground"):
+            for k, (beams, azimuths, size, noise) in enumerate([(64, 1024, 0.15, 0.0), (64, 1024, 0.15, 0.02), (64, 1024, 0.0, 0.0),
+                                                               (16, 512, 0.0, 0.0)]):
+                pose = synth.trajectory_pose(0.4 + 0.3 * k)
+                raw, _ = synth.scan(pose, beams, azimuths, noise_sigma=noise)
+                pts = raw[orc.voxel_filter(size, raw)] if size > 0 else raw
+                put(synth.transform_points(np.concatenate([[0, 0, 0], pose[3:]]), pts))
+        raw, _ = synth.scan(synth.trajectory_pose(0.4), 64, 1024)
+        put(raw[orc.voxel_filter(0.15, raw)])
+        put(np.round(np.random.RandomState(3).uniform(-3, 3, (20000, 3)) * 4) / 4)
+        put(np.zeros((0, 3)))
+    out = subprocess.run([exe, path, "120"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mismatches: 0 of 7 clouds" in out.stdout, out.stdout

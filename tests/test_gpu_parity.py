@@ -1343,9 +1343,8 @@ def test_device_rotational_histogram_limits(dl, ctx):
         dl.cloud_rotational_histogram(ctx, c, 120)
     assert e.value.status == dl.ERR_CAPACITY
     c.close()
-    rng = np.random.RandomState(1)
-    flat = np.concatenate([rng.uniform(-20, 20, (5000, 2)), np.full((5000, 1), 0.03)], axis=1).astype(np.float32)  # one slice, 5000 points
-    c = dl.PointCloud(ctx, flat)
+    bad = np.array([[1, 0, 0.1], [np.inf, 0, 0.1], [2, 1, 0.1]], dtype=np.float32)  # non-finite coordinates
+    c = dl.PointCloud(ctx, bad)
     with pytest.raises(dl.DliomError) as e:
         dl.cloud_rotational_histogram(ctx, c, 120)
     assert e.value.status == dl.ERR_CAPACITY
@@ -1426,6 +1425,157 @@ def test_device_rotational_histogram_reproduces_std_sorts_order_of_equal_angles(
     want = np.asarray(orc.compute_histogram(rays, 120), np.float32)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     cloud.close()
+
+
+@pytest.mark.gpu
+def test_device_sequential_sums_equal_the_loop(dl, ctx):
+    """exact_sum.h: the parallel replay of  acc = ((acc0 + v0) + v1) + ...  (parity functions per binade, chunks proven
+    safe by the real prefix sums, a wave walking the chunk functions) against the loop itself (numpy's float32 cumsum is
+    that loop), bit for bit: signed coordinates, histogram values, an azimuth sweep, sums hovering around zero and around
+    powers of two, wild magnitudes, ties everywhere, zeros, 0 ... 150 000 addends, several arrays per launch."""
+    rng = np.random.RandomState(23)
+    cases = 0
+    for n in (0, 1, 2, 31, 32, 33, 1000, 1024, 4096, 14460, 32768, 32769, 65536, 150000):
+        rows, starts = [], []
+        for kind in range(10):
+            i = np.arange(n)
+            if kind == 0:
+                v = 30.0 * rng.uniform(-1, 1, n)
+            elif kind == 1:
+                v = np.abs(rng.uniform(-1, 1, n))
+            elif kind == 2:
+                v = 20.0 * np.cos(2 * np.pi * i / (n + 1)) + 0.01 * rng.normal(size=n)
+            elif kind == 3:
+                v = np.where(i % 2 == 1, 1.0, -1.0) * (1.0 + 1e-3 * rng.uniform(-1, 1, n))
+            elif kind == 4:
+                v = np.ldexp(rng.uniform(-1, 1, n), rng.randint(-20, 20, n))
+            elif kind == 5:
+                v = -np.abs(rng.uniform(-1, 1, n)) - 1.8
+            elif kind == 6:
+                v = np.where(rng.randint(0, 4, n) == 0, 0.0, 0.5)
+            elif kind == 7:
+                v = np.ldexp(1.0, -rng.randint(0, 30, n))
+            elif kind == 8:
+                v = np.where(rng.randint(0, 3, n) == 0, -1.0, 1.0) * np.ldexp(1.0, -rng.randint(0, 26, n))
+            else:
+                v = 1024.0 + rng.uniform(-1, 1, n)
+            rows.append(np.asarray(v, np.float32))
+            starts.append(np.float32(0.0 if kind % 3 == 0 else 100.0 * rng.uniform(-1, 1)))
+        values = np.stack(rows) if n > 0 else np.zeros((10, 0), np.float32)
+        starts = np.asarray(starts, np.float32)
+        got = dl.diag_sequential_sums(ctx, values, starts)
+        want = np.array([np.cumsum(np.concatenate([[a], r]).astype(np.float32), dtype=np.float32)[-1] for a, r in zip(starts, rows)],
+                        np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, np.nonzero(got.view(np.uint32) != want.view(np.uint32)))
+        cases += len(rows)
+    assert cases == 140
+    # numpy's cumsum really is the plain loop (not a pairwise sum)
+    v = rng.uniform(-1, 1, 5000).astype(np.float32)
+    acc = np.float32(0)
+    for x in v:
+        acc = np.float32(acc + x)
+    assert acc == np.cumsum(v, dtype=np.float32)[-1]
+
+
+@pytest.mark.gpu
+def test_device_std_sort_order_above_4096_keys(dl, ctx, orc):
+    """dliom_diag_std_sort_order on more than 4096 keys: the HBM path of the big slices (radix sort, introsort's partition
+    rounds only on the segments that hold ties, tie groups ordered by arrangement position) against the real std::sort of
+    this libstdc++: random keys with a handful of ties, many ties, runs of ties, and the angle arrays of floor slices."""
+    rng = np.random.RandomState(29)
+    for trial, n in enumerate([4097, 5000, 8192, 14460, 20000, 40000, 100000, 4100, 9000]):
+        kind = trial % 5
+        if kind == 0:
+            keys = rng.uniform(-3.2, 3.2, n).astype(np.float32)
+            dup = rng.randint(0, n, 6)
+            keys[dup[:3]] = keys[dup[3:]]  # three tied pairs
+        elif kind == 1:
+            keys = rng.uniform(-3.2, 3.2, n).astype(np.float32)
+            keys[rng.randint(0, n, n // 50)] = keys[rng.randint(0, n, n // 50)]
+        elif kind == 2:
+            keys = rng.randint(0, n // 3 + 1, n).astype(np.float32)  # ties everywhere
+        elif kind == 3:
+            keys = (np.arange(n) // 7).astype(np.float32)
+        else:
+            keys = np.round(rng.uniform(-3.2, 3.2, n) * 2000.0).astype(np.float32) / np.float32(2000.0)
+        got = dl.diag_std_sort_order(ctx, keys)
+        want = orc.std_sort_order(keys)
+        assert np.array_equal(got, want), (trial, n, kind, int((got != want).sum()))
+    from dliom import synth
+    from helpers import slice_angle_arrays
+    with synth.scene("ground"):
+        raw, _ = synth.scan(synth.trajectory_pose(0.4), 64, 1024)
+    big = [a for a in slice_angle_arrays(raw[orc.voxel_filter(0.15, raw)]) if len(a) > 4096]
+    big += [a for a in slice_angle_arrays(raw) if len(a) > 4096]
+    assert len(big) >= 2 and max(len(a) for a in big) > 30000
+    for a in big:
+        assert np.array_equal(dl.diag_std_sort_order(ctx, a), orc.std_sort_order(a)), len(a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["64x1024", "64x1024_noise_rotated", "64x1024_raw", "128x2048", "flat_5000", "two_floors"])
+def test_device_rotational_histogram_on_scans_with_a_floor(dl, ctx, orc, case):
+    """every real scan has a floor, and a floor puts 15 000 (64 x 1024, 0.15 m filter) to 60 000
+    (128 x 2048) returns into ONE 0.2 m height slice.  The device histogram processes such slices in HBM (rothist_big.h)
+    and still equals the oracle's ComputeHistogram bit for bit -- on the yard scene of dliom.synth (ground plane, walls,
+    boxes, -25..+15 degree beams, returns to 80 m), filtered and raw, with range noise and a gravity alignment, on one
+    flat random slice of 5 000 points, and on a cloud with two floors."""
+    from dliom import synth
+    rng = np.random.RandomState(31)
+    rot = None
+    with synth.scene("ground"):
+        pose = synth.trajectory_pose(0.5)
+        if case in ("64x1024", "64x1024_noise_rotated", "64x1024_raw"):
+            raw, _ = synth.scan(pose, 64, 1024, noise_sigma=0.02 if "noise" in case else 0.0)
+            pts = raw if case.endswith("raw") else raw[orc.voxel_filter(0.15, raw)]
+            if "rotated" in case:
+                rot = synth.perturb_pose(np.array([0, 0, 0, 1, 0, 0, 0], float), 0.0, 2.0, seed=5)[3:].astype(np.float32)
+        elif case == "128x2048":
+            raw, _ = synth.scan(pose, 128, 2048, noise_sigma=0.02)
+            pts = raw[orc.voxel_filter(0.15, raw)]
+        elif case == "flat_5000":
+            pts = np.concatenate([rng.uniform(-20, 20, (5000, 2)), np.full((5000, 1), 0.03)], axis=1).astype(np.float32)
+        else:
+            raw, _ = synth.scan(pose, 64, 1024)
+            low = raw[orc.voxel_filter(0.15, raw)]
+            pts = np.concatenate([low, low + np.array([0.3, -0.2, 3.0], np.float32)]).astype(np.float32)  # a second floor 3 m up
+    aligned = pts if rot is None else orc.transform_points(np.concatenate([np.zeros(3, np.float32), rot]), pts)
+    keys = np.round(aligned[:, 2].astype(np.float64) / 0.2)
+    largest = int(np.unique(keys, return_counts=True)[1].max())
+    assert largest > 4096, largest
+    cloud = dl.PointCloud(ctx, pts)
+    got = dl.cloud_rotational_histogram(ctx, cloud, 120, rotation_wxyz=rot)
+    want = np.asarray(orc.compute_histogram(aligned, 120), np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), \
+        (case, largest, int((got != want).sum()), float(np.abs(got - want).max()))
+    if case == "64x1024":
+        for size in (1, 37, 255):
+            assert np.array_equal(dl.cloud_rotational_histogram(ctx, cloud, size), np.asarray(orc.compute_histogram(pts, size), np.float32))
+    cloud.close()
+
+
+@pytest.mark.gpu
+def test_device_rotational_histogram_switches_between_scenes(dl, ctx, orc):
+    """Whether a cloud has slices above 4096 points is only known on the device: the context enqueues the big path when
+    the PREVIOUS cloud had such slices, and runs a cloud again that needed it without having it.  Cube scene (no floor)
+    and yard scene alternating, blocking call and the two halves: always the oracle's histogram."""
+    from dliom import synth
+    raw, _ = synth.scan(synth.trajectory_pose(0.4), 64, 1024)
+    cube = raw[orc.voxel_filter(0.15, raw)]
+    with synth.scene("ground"):
+        raw, _ = synth.scan(synth.trajectory_pose(0.4), 64, 1024)
+    yard = raw[orc.voxel_filter(0.15, raw)]
+    want = {"cube": np.asarray(orc.compute_histogram(cube, 120), np.float32), "yard": np.asarray(orc.compute_histogram(yard, 120), np.float32)}
+    clouds = {"cube": dl.PointCloud(ctx, cube), "yard": dl.PointCloud(ctx, yard)}
+    for name in ("cube", "yard", "yard", "cube", "cube", "yard", "cube"):
+        got = dl.cloud_rotational_histogram(ctx, clouds[name], 120)
+        assert np.array_equal(got.view(np.uint32), want[name].view(np.uint32)), name
+    for name in ("yard", "cube", "cube", "yard", "yard", "cube", "yard"):
+        dl.cloud_rotational_histogram_begin(ctx, clouds[name], 120)
+        got = dl.cloud_rotational_histogram_finish(ctx, 120)
+        assert np.array_equal(got.view(np.uint32), want[name].view(np.uint32)), name
+    for c in clouds.values():
+        c.close()
 
 
 @pytest.mark.gpu
