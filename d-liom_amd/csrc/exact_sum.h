@@ -93,13 +93,43 @@ __device__ __forceinline__ Fn element_fn(float x, int code, bool* ok) {
   return Fn{inc, inc, static_cast<unsigned>(c & 1), static_cast<unsigned>((c & 1) ^ 1)};
 }
 
-// LDS scratch of one call: chunk descriptors of a super-block for K arrays + the block scans' wave partials
+// compose(f, element_fn(x, code)) in straight-line code (32 of these per chunk are unrolled; branches cost registers):
+// f = (s0, s1, p0, p1) is updated in place.  *ok = false when x does not fit the model (never in a safe chunk).
+__device__ __forceinline__ void append_element(float x, int biased_exponent, unsigned sign, int& s0, int& s1, unsigned& p0,
+                                               unsigned& p1, bool& ok) {
+  const unsigned u = __float_as_uint(x);
+  const unsigned mant = u & 0x7fffffu;
+  const int bex = static_cast<int>((u >> 23) & 0xffu);
+  const unsigned mx = bex == 0 ? mant : (mant | 0x800000u);
+  const int sh = biased_exponent - max(bex, 1);  // x / ulp = +-mx 2^-sh
+  ok = ok && bex != 255 && (sh > 0 || mx == 0u);
+  const int shc = min(max(sh, 1), 25);  // from 25 on the counter does not move: q = 0 and rem = mx < half
+  const unsigned q = mx >> shc, rem = mx & ((1u << shc) - 1u), half = 1u << (shc - 1);
+  const bool tie = rem == half;
+  const bool negative = (u >> 31) != sign;
+  const unsigned c = q + (rem > half ? 1u : 0u);
+  const int inc = negative ? -static_cast<int>(c) : static_cast<int>(c);
+  const int base = negative ? -static_cast<int>(q) : static_cast<int>(q);
+  const int other = negative ? base - 1 : base + 1;
+  const int even = (base & 1) ? other : base, odd = (base & 1) ? base : other;  // increment for an even / odd counter at a tie
+  s0 += tie ? (p0 ? odd : even) : inc;
+  s1 += tie ? (p1 ? odd : even) : inc;
+  const unsigned b = c & 1u;
+  p0 = tie ? 0u : (p0 ^ b);
+  p1 = tie ? 0u : (p1 ^ b);
+}
+
+// LDS scratch of one call: the chunk descriptors of a super-block for K arrays, the values of the chunks that will be
+// added one by one, the scans' wave partials
+constexpr int kStageSlots = 64;  // unsafe chunks per super-block whose values wait in LDS for the walk (others: from v)
 template <int K>
 struct Scratch {
-  int code[K][kChunksPerBlock];
-  int s0[K][kChunksPerBlock], s1[K][kChunksPerBlock];
-  unsigned char pp[K][kChunksPerBlock];  // p0 | p1 << 1
+  int4 desc[K][kChunksPerBlock];  // x: binade code, y / z: increment of the run from this chunk to its end for parity 0 / 1,
+                                  // w: parity out (bits 0, 1) | last chunk of the run << 2 | (stage slot + 1) << 16
+  float stage[K][kStageSlots][kChunk];
   double wave_part[K][kThreads / 64];
+  int4 wave_agg[K][kThreads / 64];
+  unsigned stage_count[K];
   float result[K];
 };
 
@@ -108,7 +138,7 @@ __device__ __forceinline__ double shfl_up_double(double v, int off) {
   const unsigned lo = __shfl_up(static_cast<unsigned>(u), off, 64), hi = __shfl_up(static_cast<unsigned>(u >> 32), off, 64);
   return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
 }
-// Inclusive block scans of one double per thread (1024 threads): sum / maximum.  `part`: 16 doubles of LDS.
+// Inclusive block scans of one double per thread (1024 threads): sum / maximum of non-negative values.  `part`: 16 doubles of LDS.
 template <bool kMax>
 __device__ __forceinline__ double block_inclusive_scan(double v, double* part, double* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,7 +150,7 @@ __device__ __forceinline__ double block_inclusive_scan(double v, double* part, d
   __syncthreads();  // `part` may still be read from an earlier scan
   if (lane == 63) part[wave] = v;
   __syncthreads();
-  double before = kMax ? 0.0 : 0.0, all = 0.0;
+  double before = 0.0, all = 0.0;
   for (int w = 0; w < kThreads / 64; ++w) {
     const double s = part[w];
     if (w < wave) before = kMax ? fmax(before, s) : before + s;
@@ -128,6 +158,30 @@ __device__ __forceinline__ double block_inclusive_scan(double v, double* part, d
   }
   *total = all;
   return kMax ? fmax(before, v) : before + v;
+}
+
+// A run of safe chunks as seen from its first chunk: the composed function, where the run ends, and whether it ends
+// inside the range this value covers (the segmented scan's flag)
+struct Run {
+  Fn f;
+  int end;
+  int closed;
+};
+__device__ __forceinline__ Run join(const Run& x, const Run& y) {  // x in front of y
+  if (x.closed) return x;
+  return Run{compose(x.f, y.f), y.end, y.closed};
+}
+__device__ __forceinline__ Run shfl_down_run(const Run& r, int off) {
+  Run o;
+  o.f.s0 = __shfl_down(r.f.s0, off, 64);
+  o.f.s1 = __shfl_down(r.f.s1, off, 64);
+  const unsigned packed = __shfl_down(static_cast<unsigned>(r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.closed) << 2) |
+                                                            (static_cast<unsigned>(r.end) << 3)), off, 64);
+  o.f.p0 = packed & 1u;
+  o.f.p1 = (packed >> 1) & 1u;
+  o.closed = static_cast<int>((packed >> 2) & 1u);
+  o.end = static_cast<int>(packed >> 3);
+  return o;
 }
 
 // All 1024 threads call this; every thread returns with out[k] = the sequential float sum of v[k][0 .. n) started at acc0[k].
@@ -146,35 +200,34 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
   const int num_chunks = (n + kChunk - 1) / kChunk;
   for (int cb = 0; cb < num_chunks; cb += kChunksPerBlock) {  // uniform
     const int chunks_here = min(kChunksPerBlock, num_chunks - cb);
+    const bool mine = tid < chunks_here;
     const int c = cb + tid;
     const int i0 = c * kChunk, i1 = min(n, i0 + kChunk);
-    double sum[K], lo[K], hi[K];
+    if (tid < K) S.stage_count[tid] = 0u;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      double p = 0.0, l = 0.0, h = 0.0;
-      if (tid < chunks_here)
-        for (int i = i0; i < i1; ++i) {
-          p += static_cast<double>(v[k][i]);
-          l = fmin(l, p);
-          h = fmax(h, p);
-        }
-      sum[k] = p;
-      lo[k] = l;
-      hi[k] = h;
-    }
+      // the chunk's 32 addends, all loads in flight at once (a loop of load -> add pays the memory latency 32 times)
+      float x[kChunk];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
+      for (int j = 0; j < kChunk; ++j) x[j] = (mine && i0 + j < i1) ? v[k][i0 + j] : 0.f;
+      double p = 0.0, lo = 0.0, hi = 0.0;
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        p += static_cast<double>(x[j]);
+        lo = fmin(lo, p);
+        hi = fmax(hi, p);
+      }
       double total, mtotal;
-      const double incl = block_inclusive_scan<false>(sum[k], S.wave_part[k], &total);
-      const double Pc = P[k] + (incl - sum[k]);  // real prefix in front of this thread's chunk
-      const double mine = tid < chunks_here ? fmax(fabs(Pc + lo[k]), fabs(Pc + hi[k])) : 0.0;
-      const double mx = fmax(Mx[k], block_inclusive_scan<true>(mine, S.wave_part[k], &mtotal));
+      const double incl = block_inclusive_scan<false>(p, S.wave_part[k], &total);
+      const double Pc = P[k] + (incl - p);  // real prefix in front of this thread's chunk
+      const double reach = mine ? fmax(fabs(Pc + lo), fabs(Pc + hi)) : 0.0;
+      const double mx = fmax(Mx[k], block_inclusive_scan<true>(reach, S.wave_part[k], &mtotal));
       int code = kNoCode;
       Fn f = identity_fn();
-      if (tid < chunks_here) {
+      if (mine) {
         const double count = static_cast<double>(i1);
         const double E = 1.1 * count * 5.9604644775390625e-8 * mx + 1e-300;
-        const double a = Pc + lo[k] - E, b = Pc + hi[k] + E;
+        const double a = Pc + lo - E, b = Pc + hi + E;
         if (count <= 1048576.0 && ((a > 0.0 && b > 0.0) || (a < 0.0 && b < 0.0))) {
           const double m0 = fmin(fabs(a), fabs(b)), m1 = fmax(fabs(a), fabs(b));
           // binade exponents from the doubles' own exponent fields (both are normal, far from the double range's ends)
@@ -185,66 +238,97 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
           if (e0 == e1 && !power_of_two && be >= 30 && be <= 250) {
             const int cd = ((a < 0.0 ? 1 : 0) << 16) | be;
             bool ok = true;
-            for (int i = i0; i < i1; ++i) f = compose(f, element_fn(v[k][i], cd, &ok));
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j)  // (padding zeros are the identity)
+              append_element(x[j], be, a < 0.0 ? 1u : 0u, f.s0, f.s1, f.p0, f.p1, ok);
             if (ok) code = cd;
           }
         }
-        S.code[k][tid] = code;
-        S.s0[k][tid] = f.s0;
-        S.s1[k][tid] = f.s1;
-        S.pp[k][tid] = static_cast<unsigned char>(f.p0 | (f.p1 << 1));
       }
       P[k] += total;
       Mx[k] = fmax(Mx[k], mtotal);
-    }
-    __syncthreads();
-    // the walk: wave k takes array k
-    if (wave < K) {
-      float a = acc[0];
+      // chunks that will be added one value after the other: their values wait in LDS
+      int slot = -1;
+      if (mine && code == kNoCode) {
+        const unsigned s = atomicAdd(&S.stage_count[k], 1u);
+        if (s < static_cast<unsigned>(kStageSlots)) {
+          slot = static_cast<int>(s);
 #pragma unroll
-      for (int k = 1; k < K; ++k)
-        if (wave == k) a = acc[k];
-      const int kk = wave;
-      int cc = 0;
-      while (cc < chunks_here) {  // uniform within the wave
-        const int code = code_of(a);
-        const int my = cc + lane;
-        const bool usable = my < chunks_here && code != kNoCode && S.code[kk][my] == code;
-        const unsigned long long ball = __builtin_amdgcn_ballot_w64(usable);
-        const int u = ball == ~0ull ? 64 : __builtin_ctzll(~ball);
-        bool applied = false;
-        if (u > 0) {
-          Fn f = identity_fn();
-          if (lane < u) {
-            const unsigned pp = S.pp[kk][my];
-            f = Fn{S.s0[kk][my], S.s1[kk][my], pp & 1u, pp >> 1};
-          }
-          f = wave_inclusive_scan_fn(f, lane);
-          const int t0 = __shfl(f.s0, u - 1, 64), t1 = __shfl(f.s1, u - 1, 64);
-          const unsigned bits = __float_as_uint(a);
-          const int kcount = static_cast<int>((bits & 0x7fffffu) | 0x800000u);
-          const int k2 = kcount + ((kcount & 1) ? t1 : t0);
-          if (k2 >= (1 << 23) && k2 < (1 << 24)) {
-            a = __uint_as_float((bits & 0xff800000u) | (static_cast<unsigned>(k2) & 0x7fffffu));
-            cc += u;
-            applied = true;
-          }
-        }
-        if (!applied) {  // this chunk's values one after the other
-          if (lane == 0) {
-            const int j0 = (cb + cc) * kChunk, j1 = min(n, j0 + kChunk);
-            float x[kChunk];
-#pragma unroll
-            for (int j = 0; j < kChunk; ++j) x[j] = j0 + j < j1 ? v[kk][j0 + j] : 0.f;
-#pragma unroll
-            for (int j = 0; j < kChunk; ++j)
-              if (j0 + j < j1) a += x[j];  // (a padding +0 would turn an accumulator of -0 into +0)
-          }
-          a = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a)));
-          cc += 1;
+          for (int j = 0; j < kChunk; j += 4)
+            *reinterpret_cast<float4*>(&S.stage[k][slot][j]) = make_float4(x[j], x[j + 1], x[j + 2], x[j + 3]);
         }
       }
-      if (lane == 0) S.result[kk] = a;
+      // runs of consecutive chunks of one binade: a segmented suffix scan gives every chunk the composition from itself
+      // to the end of its run, so that the walk below crosses a run in one step wherever it enters it
+      S.desc[k][tid].x = mine ? code : kNoCode;
+      __syncthreads();
+      const int next_code = (tid + 1 < chunks_here) ? S.desc[k][tid + 1].x : kNoCode;
+      Run r{f, tid, (code == kNoCode || next_code != code) ? 1 : 0};
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const Run o = shfl_down_run(r, off);
+        if (lane + off < 64) r = join(r, o);
+      }
+      if (lane == 0) {
+        S.wave_agg[k][wave] = make_int4(r.f.s0, r.f.s1, static_cast<int>(r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.closed) << 2)), r.end);
+      }
+      __syncthreads();
+      for (int w = wave + 1; w < kThreads / 64 && !r.closed; ++w) {
+        const int4 g = S.wave_agg[k][w];
+        r = join(r, Run{Fn{g.x, g.y, static_cast<unsigned>(g.z) & 1u, (static_cast<unsigned>(g.z) >> 1) & 1u}, g.w, (g.z >> 2) & 1});
+      }
+      if (mine)
+        S.desc[k][tid] = make_int4(code, r.f.s0, r.f.s1,
+                                   static_cast<int>(r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.end) << 2) |
+                                                    (static_cast<unsigned>(slot + 1) << 16)));
+    }
+    __syncthreads();
+    // the walk: lane 0 of wave k takes array k
+    if (wave < K && lane == 0) {
+      float a = acc[0];
+      const float* vp = v[0];
+#pragma unroll
+      for (int k = 1; k < K; ++k)
+        if (wave == k) {
+          a = acc[k];
+          vp = v[k];
+        }
+      int cc = 0;
+      while (cc < chunks_here) {
+        const int4 d = S.desc[wave][cc];
+        const unsigned bits = __float_as_uint(a);
+        if (d.x != kNoCode && d.x == code_of(a)) {
+          const int kcount = static_cast<int>((bits & 0x7fffffu) | 0x800000u);
+          const int k2 = kcount + ((kcount & 1) ? d.z : d.y);
+          if (k2 >= (1 << 23) && k2 < (1 << 24)) {
+            a = __uint_as_float((bits & 0xff800000u) | (static_cast<unsigned>(k2) & 0x7fffffu));
+            cc = static_cast<int>((static_cast<unsigned>(d.w) >> 2) & 0x3fffu) + 1;
+            continue;
+          }
+        }
+        // this chunk's values one after the other
+        const int j0 = (cb + cc) * kChunk, j1 = min(n, j0 + kChunk);
+        const int slot = static_cast<int>(static_cast<unsigned>(d.w) >> 16) - 1;
+        float x[kChunk];
+        if (slot >= 0) {
+#pragma unroll
+          for (int j = 0; j < kChunk; j += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(&S.stage[wave][slot][j]);
+            x[j] = q.x;
+            x[j + 1] = q.y;
+            x[j + 2] = q.z;
+            x[j + 3] = q.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < kChunk; ++j) x[j] = j0 + j < j1 ? vp[j0 + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+          if (j0 + j < j1) a += x[j];  // (a padding +0 would turn an accumulator of -0 into +0)
+        cc += 1;
+      }
+      S.result[wave] = a;
     }
     __syncthreads();
 #pragma unroll

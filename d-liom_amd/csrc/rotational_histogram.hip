@@ -47,7 +47,7 @@ constexpr int kBins = 4096;
 constexpr int kBinOrigin = 2048;
 constexpr int kMaxSlice = 4096;
 constexpr int kThreads = 1024;
-constexpr int kExactSumFrom = 1024;  // sequential float sums of this many addends and more are replayed in parallel
+constexpr int kExactSumFrom = 2048;  // bucket additions: this many and more are replayed in parallel (exact_sum.h)
 constexpr float kMinDistance = 0.2f;
 constexpr float kMaxDistance = 0.9f;
 constexpr float kSliceHeight = 0.2f;
@@ -263,6 +263,11 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {
 // heap-sorts the segment: restated too (heap_sort_keys).  Always returns true (the bool is kept for the callers' shape).
 struct SortScratch {
   unsigned short *seg_first, *seg_last, *tmp_l, *tmp_r, *g, *l, *cut;
+  // Only segments that still hold two TIED elements (elements whose key occurs more than once) are partitioned: equal keys
+  // can only be told apart by where the partitions put them, a segment without two of them has a unique sorted order,
+  // and the final insertion sort is stable -- what the rounds leave of the other segments does not matter.
+  const unsigned char* tied;  // by position in the slice (the items' low words); null: every element counts as tied
+  unsigned char* act;         // by arrangement position: the position lies in a segment that is still partitioned
 };
 
 // exclusive prefix counts of 4 consecutive flags per thread (position 4 t + k) over the workgroup; out[p] for p in
@@ -386,20 +391,39 @@ __device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const S
   }
   __syncthreads();
   for (;;) {
-    // threads that own a position inside a segment above the threshold (<= 4 positions each)
+    // which segments are still partitioned: above the threshold and holding at least two tied elements
+    {
+      unsigned t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k;
+        t[k] = p < m ? (sc.tied != nullptr ? sc.tied[static_cast<unsigned>(a[p]) & 0xffffu] : 1u) : 0u;
+      }
+      blocked_prefix(t, sc.tmp_l, wave_sums);  // tmp_l is free until (b)
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = p0 + k;
+        unsigned char on = 0;
+        if (p < m) {
+          const int first = sc.seg_first[p], last = sc.seg_last[p];
+          on = (last - first > 16 && sc.tmp_l[last] - sc.tmp_l[first] >= 2) ? 1 : 0;
+        }
+        sc.act[p] = on;
+      }
+      __syncthreads();
+    }
+    // threads that own a position inside such a segment (<= 4 positions each)
     int inside = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = p0 + k;
-      if (p < m && sc.seg_last[p] - sc.seg_first[p] > 16) inside = 1;
-    }
+    for (int k = 0; k < 4; ++k) inside |= sc.act[p0 + k];
     const int busy_threads = __syncthreads_count(inside);
     if (busy_threads == 0) return true;
     if (busy_threads <= 96 && depth > 0) {  // <= 384 elements left: the rest of the recursion sequentially, a thread per segment
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int p = p0 + k;
-        if (p < m && sc.seg_first[p] == p && sc.seg_last[p] - p > 16) introsort_loop_sequential(a, p, sc.seg_last[p], depth);
+        if (sc.act[p] && sc.seg_first[p] == p) introsort_loop_sequential(a, p, sc.seg_last[p], depth);
       }
       __syncthreads();
       return true;
@@ -411,7 +435,7 @@ __device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const S
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int p = p0 + k;
-        if (p < m && sc.seg_first[p] == p && sc.seg_last[p] - p > 16) heap_sort_keys(a + p, sc.seg_last[p] - p);
+        if (sc.act[p] && sc.seg_first[p] == p) heap_sort_keys(a + p, sc.seg_last[p] - p);
       }
       __syncthreads();
       return true;
@@ -421,7 +445,7 @@ __device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const S
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int p = p0 + k;
-      if (p < m && sc.seg_first[p] == p && sc.seg_last[p] - p > 16) {
+      if (sc.act[p] && sc.seg_first[p] == p) {
         const int first = p, last = sc.seg_last[p];
         const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
         const unsigned ka = static_cast<unsigned>(a[ia] >> 32), kb = static_cast<unsigned>(a[ib] >> 32), kc = static_cast<unsigned>(a[ic] >> 32);
@@ -448,7 +472,7 @@ __device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const S
       ge[k] = le[k] = 0u;
       if (p < m) {
         const int first = sc.seg_first[p], last = sc.seg_last[p];
-        if (last - first > 16 && p != first) {
+        if (sc.act[p] && p != first) {
           const unsigned pivot = static_cast<unsigned>(a[first] >> 32), x = static_cast<unsigned>(a[p] >> 32);
           ge[k] = x < pivot ? 0u : 1u;
           le[k] = pivot < x ? 0u : 1u;
@@ -477,7 +501,7 @@ __device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const S
       at_l[k] = at_r[k] = -1;
       if (q < m) {
         const int first = sc.seg_first[q], last = sc.seg_last[q];
-        if (last - first > 16 && q != first) {
+        if (sc.act[q] && q != first) {
           const int kk = q - (first + 1);
           const int cnt_l = sc.g[last] - sc.g[first + 1], cnt_r = sc.l[last] - sc.l[first + 1];
           auto valid = [&](int j) { return j < cnt_l && j < cnt_r && sc.tmp_l[first + 1 + j] < sc.tmp_r[first + 1 + j]; };
@@ -514,7 +538,7 @@ __device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const S
       const int p = p0 + k;
       nf[k] = sc.seg_first[p0 + k];
       nl[k] = sc.seg_last[p0 + k];
-      if (p < m && nl[k] - nf[k] > 16) {
+      if (sc.act[p]) {
         const int c = sc.cut[nf[k]];
         if (p < c) nl[k] = static_cast<unsigned short>(c);
         else nf[k] = static_cast<unsigned short>(c);
@@ -620,14 +644,13 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
   // std::sort's order of equal keys (libstdcxx_sort_arrangement): eight arrays of kMaxSlice + 8 u16
   unsigned short* u16_base = reinterpret_cast<unsigned short*>(sz + kMaxSlice);
   constexpr int kU16 = kMaxSlice + 8;
-  const SortScratch sort_scratch{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
-                                 u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16};
   unsigned short* idx_of = u16_base + 7 * kU16;  // arrangement position -> position in the slice
-  // the centroids' exact sums (slices of kExactSumFrom points and more) borrow the sort's scratch: neither centroid is
-  // computed while a sort is under way
-  static_assert(sizeof(exact_sum::Scratch<2>) <= 8 * static_cast<size_t>(kMaxSlice + 8) * 2, "the sort scratch holds it");
-  exact_sum::Scratch<2>& es = *reinterpret_cast<exact_sum::Scratch<2>*>(u16_base);
+  unsigned char* tied_flags = reinterpret_cast<unsigned char*>(idx_of);  // by position in the slice; dead once idx_of is written
+  unsigned char* act_flags = reinterpret_cast<unsigned char*>(u16_base + 8 * kU16);  // [kMaxSlice]; later the chain's marks
+  const SortScratch sort_scratch{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
+                                 u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16, tied_flags, act_flags};
   __shared__ unsigned wave_sums[kThreads / 64];
+  __shared__ int wave_max[kThreads / 64];
   __shared__ unsigned sh_bin, sh_count, sh_begin, sh_valid, sh_written;
   __shared__ float sh_centroid[3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -741,18 +764,9 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     __syncthreads();
     DLIOM_STAMP(1);
     // ---- SortSlice: centroid (sequential float sums), angles, sort by angle
-    if (count >= kExactSumFrom) {  // the same sums as parity functions (exact_sum.h); z's is never read
-      const float* const arrays[2] = {sx, sy};
-      const float zero[2] = {0.f, 0.f};
-      float sums[2];
-      exact_sum::block_sequential_sums<2>(arrays, count, zero, sums, es);
-      if (threadIdx.x == 0) {
-        sh_centroid[0] = sums[0] / static_cast<float>(count);
-        sh_centroid[1] = sums[1] / static_cast<float>(count);
-      }
-    } else if (lane == 0 && wave < 2) {  // one thread per coordinate (on different SIMDs)
+    if (lane == 0 && wave < 2)  // one thread per coordinate (on different SIMDs); z's sum is never read.  At most 4096
+      // additions (14 us): the parallel replay of exact_sum.h pays from about that size on and is used by the big slices
       sh_centroid[wave] = thread_sequential_sum(wave == 0 ? sx : sy, count, 0.f) / static_cast<float>(count);
-    }
     __syncthreads();
     DLIOM_STAMP(2);
     int pow2 = 64;
@@ -782,8 +796,15 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     // equal angles next to each other: their order is std::sort's, not ours
     bool tied = false;
     {
+      for (int i = threadIdx.x; i < count; i += kThreads) tied_flags[i] = 0;
+      __syncthreads();
       int t = 0;
-      for (int j = threadIdx.x; j + 1 < m; j += kThreads) t |= (skey[j] >> 32) == (skey[j + 1] >> 32) ? 1 : 0;
+      for (int j = threadIdx.x; j + 1 < m; j += kThreads)
+        if ((skey[j] >> 32) == (skey[j + 1] >> 32)) {
+          tied_flags[static_cast<unsigned>(skey[j]) & 0xffffu] = 1;
+          tied_flags[static_cast<unsigned>(skey[j + 1]) & 0xffffu] = 1;
+          t = 1;
+        }
       tied = __syncthreads_or(t) != 0;
     }
     if (tied) {
@@ -855,18 +876,8 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     }
     __syncthreads();
     // ---- AddPointCloudSliceToHistogram: centroid of the SORTED points (sequential again; z is not used below)
-    if (m >= kExactSumFrom) {
-      const float* const arrays[2] = {px_sorted, py_sorted};
-      const float zero[2] = {0.f, 0.f};
-      float sums[2];
-      exact_sum::block_sequential_sums<2>(arrays, m, zero, sums, es);
-      if (threadIdx.x == 0) {
-        sh_centroid[0] = sums[0] / static_cast<float>(m);
-        sh_centroid[1] = sums[1] / static_cast<float>(m);
-      }
-    } else if (lane == 0 && wave < 2) {
+    if (lane == 0 && wave < 2)
       sh_centroid[wave] = thread_sequential_sum(wave == 0 ? px_sorted : py_sorted, m, 0.f) / static_cast<float>(m);
-    }
     __syncthreads();
     DLIOM_STAMP(5);
     // (a) which points can never contribute: closer than kMinDistance to the centroid (:73-75)
@@ -879,34 +890,66 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
       for (int j = threadIdx.x; j < m; j += kThreads) dead[j] = norm2(px_sorted[j] - cx, py_sorted[j] - cy) < kMinDistance ? 1 : 0;
     }
     __syncthreads();
-    // (b) the chain of `last_point`s (:70-80), one wave: last_point moves to the first live point farther than
-    //     kMaxDistance from it.  fl(sqrt(s)) > kMaxDistance is a threshold on s itself (sqrt is monotone and correctly
-    //     rounded): the comparison needs no square root.
-    if (wave == 0) {
-      int anchor = 0;
-      float ax = m > 0 ? px_sorted[0] : 0.f, ay = m > 0 ? py_sorted[0] : 0.f;
-      for (int j0 = 0; j0 < m; j0 += 64) {  // a window of 64 points in the lanes; several jumps may fall into it
-        const int j = j0 + lane;
-        const bool have = j < m;
-        const float px = have ? px_sorted[j] : 0.f, py = have ? py_sorted[j] : 0.f;
-        const bool live = have && dead[j] == 0;
-        int from = 0;  // lanes below `from` are settled
-        unsigned short mine = 0;
-        for (;;) {
-          const float dx = px - ax, dy = py - ay;
-          const float s2 = dx * dx + dy * dy;
-          const bool jump = live && lane >= from && s2 >= squared_jump;
-          const unsigned long long jumps = __builtin_amdgcn_ballot_w64(jump);
-          const int first_jump = jumps != 0ull ? __builtin_ctzll(jumps) : 64;
-          if (lane >= from && lane < first_jump) mine = static_cast<unsigned short>(anchor);
-          if (first_jump == 64) break;
-          if (lane == first_jump) mine = 0xFFFFu;
-          anchor = j0 + first_jump;
-          ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), first_jump));
-          ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), first_jump));
-          from = first_jump + 1;
+    // (b) the chain of `last_point`s (:70-80): last_point moves to the first live point farther than kMaxDistance from
+    //     it.  fl(sqrt(s)) > kMaxDistance is a threshold on s itself (sqrt is monotone and correctly rounded): the
+    //     comparison needs no square root.  Walking the chain costs a step per jump, and on a floor-like slice nearly
+    //     every point is one; instead next(i) for every i at once, then the nodes on the path 0 -> next(0) -> ... by
+    //     pointer doubling (marks spread along next^(2^d) while the pointers are squared; rothist_big.h).
+    {
+      unsigned short* ja = sort_scratch.g;  // the sort's scratch is free
+      unsigned short* jb = sort_scratch.l;
+      unsigned char* mark = act_flags;
+      const int p0 = 4 * static_cast<int>(threadIdx.x);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = p0 + k;
+        if (i < m) {
+          const float ax = px_sorted[i], ay = py_sorted[i];
+          int j = i + 1;
+          for (; j < m; ++j) {
+            if (dead[j]) continue;
+            const float dx = px_sorted[j] - ax, dy = py_sorted[j] - ay;
+            if (dx * dx + dy * dy >= squared_jump) break;
+          }
+          ja[i] = static_cast<unsigned short>(j);
+          mark[i] = i == 0 ? 1 : 0;
         }
-        if (have) anchor_of[j] = mine;
+      }
+      if (threadIdx.x == 0) {
+        ja[m] = static_cast<unsigned short>(m);
+        jb[m] = static_cast<unsigned short>(m);
+        mark[m] = 0;  // (m <= kMaxSlice: the arrays have kMaxSlice + 8 entries, act_flags kMaxSlice + 8 bytes)
+      }
+      __syncthreads();
+      for (int d = 0; (1 << d) < 2 * m; ++d) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = p0 + k;
+          if (i < m) {
+            const unsigned short t = ja[i];
+            if (mark[i]) mark[t] = 1;
+            jb[i] = ja[t];
+          }
+        }
+        __syncthreads();
+        unsigned short* t = ja;
+        ja = jb;
+        jb = t;
+      }
+      // last_point of point j = the last marked position before it; a marked point (a jump) contributes nothing
+      int last_marked = -1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (p0 + k < m && mark[p0 + k]) last_marked = p0 + k;
+      int anchor = max(0, block_exclusive_max(last_marked, -1, wave_max));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = p0 + k;
+        if (j < m) {
+          const bool jump = mark[j] != 0 && j != 0;
+          anchor_of[j] = jump ? 0xFFFFu : static_cast<unsigned short>(anchor);
+          if (mark[j]) anchor = j;
+        }
       }
     }
     __syncthreads();
@@ -1136,6 +1179,12 @@ extern "C" int dliom_exp_rothist_stamps(unsigned long long* out) {
 #endif
 
 #ifdef DLIOM_EXPERIMENTS
+extern "C" int dliom_exp_rothist_big_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rothist::dbg_big), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : -2;
+}
+#endif
+
+#ifdef DLIOM_EXPERIMENTS
 extern "C" int dliom_exp_rothist_acc_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rothist::dbg_acc), sizeof(unsigned long long) * 128 * 8) == hipSuccess ? 0 : -2;
 }
@@ -1150,12 +1199,28 @@ __global__ __launch_bounds__(kThreads) void std_sort_order_kernel(const float* _
   unsigned long long* skey = lds_dyn;
   unsigned short* u16_base = reinterpret_cast<unsigned short*>(skey + kMaxSlice);
   constexpr int kU16 = kMaxSlice + 8;
-  const SortScratch sc{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
-                       u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16};
   unsigned short* idx_of = u16_base + 7 * kU16;
+  unsigned char* tied_flags = reinterpret_cast<unsigned char*>(idx_of);
+  unsigned char* act_flags = reinterpret_cast<unsigned char*>(u16_base + 8 * kU16);
+  const SortScratch sc{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
+                       u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16, tied_flags, act_flags};
   __shared__ unsigned wave_sums[kThreads / 64];
   int pow2 = 64;
   while (pow2 < n) pow2 <<= 1;
+  // as in slice_kernel: a plain sort finds the elements whose key occurs more than once ...
+  for (int i = threadIdx.x; i < pow2; i += kThreads)
+    skey[i] = i < n ? (static_cast<unsigned long long>(ordered_bits(keys[i])) << 32) | static_cast<unsigned>(i) : ~0ull;
+  __syncthreads();
+  bitonic_sort_keys(skey, pow2);
+  for (int i = threadIdx.x; i < n; i += kThreads) tied_flags[i] = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j + 1 < n; j += kThreads)
+    if ((skey[j] >> 32) == (skey[j + 1] >> 32)) {
+      tied_flags[static_cast<unsigned>(skey[j]) & 0xffffu] = 1;
+      tied_flags[static_cast<unsigned>(skey[j + 1]) & 0xffffu] = 1;
+    }
+  __syncthreads();
+  // ... then std::sort's input again, its partitions on the segments that hold ties, and the stable sort
   for (int i = threadIdx.x; i < pow2; i += kThreads)
     skey[i] = i < n ? (static_cast<unsigned long long>(ordered_bits(keys[i])) << 32) | static_cast<unsigned>(i) : ~0ull;
   __syncthreads();
@@ -1249,7 +1314,7 @@ extern "C" int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int 
   int* d_order = reinterpret_cast<int*>(d_keys + kMaxSlice);
   int* d_status = d_order + kMaxSlice;
   DLIOM_HIP_TRY(hipMemcpyAsync(d_keys, keys, static_cast<size_t>(n) * 4, hipMemcpyHostToDevice, ctx->stream));
-  const size_t lds = static_cast<size_t>(kMaxSlice) * 8 + 8 * static_cast<size_t>(kMaxSlice + 8) * 2;
+  const size_t lds = static_cast<size_t>(kMaxSlice) * 8 + 8 * static_cast<size_t>(kMaxSlice + 8) * 2 + kMaxSlice + 64;
   if ((ctx->func_attr_set & kFuncAttrStdSortDiag) == 0u) {
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(std_sort_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(lds)));
@@ -1351,7 +1416,7 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
   const unsigned blocks = static_cast<unsigned>((N + kThreads - 1) / kThreads);
   hipLaunchKernelGGL(prepare_kernel, dim3(blocks), dim3(kThreads), 0, stream, cloud->d_x, cloud->d_y, cloud->d_z, n, q,
                      rotation_wxyz != nullptr ? 1 : 0, rx, ry, rz, keys, bin_counts, flags);
-  const size_t lds = static_cast<size_t>(kMaxSlice) * (8 + 12) + 8 * static_cast<size_t>(kMaxSlice + 8) * 2 + 1024;
+  const size_t lds = static_cast<size_t>(kMaxSlice) * (8 + 12) + 8 * static_cast<size_t>(kMaxSlice + 8) * 2 + kMaxSlice + 64 + 1024;
   const size_t acc_lds = static_cast<size_t>(kAccCap + 64) * 4;
   if ((ctx->func_attr_set & kFuncAttrHistogram) == 0u) {
     DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

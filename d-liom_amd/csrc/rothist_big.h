@@ -23,6 +23,13 @@
 // next^(2^d) while the pointers are squared (marked nodes are path nodes at every moment, so the passes need no
 // snapshot).  A point's last_point is the last marked position before it; a marked point contributes nothing.
 
+#ifdef DLIOM_EXPERIMENTS
+__device__ unsigned long long dbg_big[64 * 16];
+#define DLIOM_BSTAMP(k) if (threadIdx.x == 0 && blockIdx.x < 4) dbg_big[(blockIdx.x + 4 * (kernel_id)) * 16 + (k)] = __builtin_readcyclecounter()
+#else
+#define DLIOM_BSTAMP(k)
+#endif
+
 constexpr int kMaxBig = 63;         // big slices per cloud (slice ordinal 63 is the sort's padding key)
 constexpr int kBigKeyBits = 38;     // 32 angle bits + 6 slice bits
 
@@ -317,11 +324,16 @@ __global__ __launch_bounds__(kThreads) void big_prepare_kernel(const float* __re
   __shared__ unsigned sh4[4];
   __shared__ exact_sum::Scratch<2> es;
   BigSlice s;
+#ifdef DLIOM_EXPERIMENTS
+  constexpr int kernel_id = 0;
+#endif
+  DLIOM_BSTAMP(0);
   if (!find_big_slice(bin_counts, wave_sums, &s, sh4)) return;
   if (s.n_big > static_cast<unsigned>(kMaxBig)) {
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(flags, 16u);
     return;
   }
+  DLIOM_BSTAMP(1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int key = s.bin - kBinOrigin;
   const int count = static_cast<int>(s.count);
@@ -385,12 +397,14 @@ __global__ __launch_bounds__(kThreads) void big_prepare_kernel(const float* __re
     }
     __syncthreads();
   }
+  DLIOM_BSTAMP(2);
   // ComputeCentroid (:52-59), x and y (the z sum is never read)
   const float* const arrays[2] = {bx, by};
   const float zero[2] = {0.f, 0.f};
   float sums[2];
   exact_sum::block_sequential_sums<2>(arrays, count, zero, sums, es);
   const float cx = sums[0] / static_cast<float>(count), cy = sums[1] / static_cast<float>(count);
+  DLIOM_BSTAMP(3);
   // SortSlice's (angle, point) pairs in input order; points closer than kMinDistance to the centroid are skipped (:111-113)
   int lo, hi;
   owned_range(count, &lo, &hi);
@@ -407,6 +421,7 @@ __global__ __launch_bounds__(kThreads) void big_prepare_kernel(const float* __re
     }
   }
   if (threadIdx.x == 0) A.valid[s.ordinal] = total_valid;
+  DLIOM_BSTAMP(4);
 }
 
 // ---- kernel B2: everything behind the sort -------------------------------------------------------------------------
@@ -418,6 +433,10 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
   __shared__ unsigned sh4[4];
   __shared__ exact_sum::Scratch<2> es;
   BigSlice s;
+#ifdef DLIOM_EXPERIMENTS
+  constexpr int kernel_id = 1;
+#endif
+  DLIOM_BSTAMP(0);
   if (!find_big_slice(bin_counts, wave_sums, &s, sh4)) return;
   if (s.n_big > static_cast<unsigned>(kMaxBig)) return;  // flagged by big_prepare_kernel
   const unsigned off = s.begin + static_cast<unsigned>(s.ordinal);
@@ -431,6 +450,7 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
     if (threadIdx.x == 0) atomicOr(flags, 4u);
     return;
   }
+  DLIOM_BSTAMP(1);
   const unsigned* sorted_id = A.sorted_id + off;
   const float* bx = A.bx + off;
   const float* by = A.by + off;
@@ -444,12 +464,14 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
     py[j] = by[id];
   }
   __syncthreads();
+  DLIOM_BSTAMP(2);
   // AddPointCloudSliceToHistogram: centroid of the SORTED points (:68)
   const float* const arrays[2] = {px, py};
   const float zero[2] = {0.f, 0.f};
   float sums[2];
   exact_sum::block_sequential_sums<2>(arrays, m, zero, sums, es);
   const float cx = sums[0] / static_cast<float>(m), cy = sums[1] / static_cast<float>(m);
+  DLIOM_BSTAMP(3);
   unsigned char* dead = A.dead + off;
   unsigned char* mark = A.mark + off;
   unsigned* ja = A.jump_a + off;
@@ -476,6 +498,7 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
     ja[i] = static_cast<unsigned>(j);
   }
   __syncthreads();
+  DLIOM_BSTAMP(4);
   for (int d = 0; (1 << d) < 2 * m; ++d) {
     for (int i = lo; i < hi; ++i)
       if (mark[i]) mark[ja[i]] = 1;
@@ -485,6 +508,7 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
     ja = jb;
     jb = t;
   }
+  DLIOM_BSTAMP(5);
   // last_point of point j = the last marked position before it (position 0 to begin with)
   int last_marked = -1;
   for (int j = lo; j < hi; ++j)
@@ -520,6 +544,13 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
       ++at;
     }
   }
+  DLIOM_BSTAMP(6);
+#ifdef DLIOM_EXPERIMENTS
+  if (threadIdx.x == 0 && blockIdx.x < 4) {
+    dbg_big[(blockIdx.x + 4) * 16 + 10] = s.count;
+    dbg_big[(blockIdx.x + 4) * 16 + 11] = static_cast<unsigned long long>(m);
+  }
+#endif
 }
 
 // dliom_diag_std_sort_order for more than kMaxSlice keys: the sorted (key, position) pairs come from the radix sort

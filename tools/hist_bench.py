@@ -1,0 +1,62 @@
+"""ComputeHistogram on the device: time per call on the cube scene (no floor: every slice in LDS) and on the yard scene
+(a floor: slices of 15 000 ... 60 000 points, the HBM path), against the host entry point (8 threads) and, with --check,
+bit for bit against the oracle.  python tools/hist_bench.py [--check] [--reps 200]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "d-liom_amd")]
+import numpy as np  # noqa: E402
+
+import dliom as dl  # noqa: E402
+from dliom import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    ctx = dl.Context(0)
+    rot = np.array([0.999, 0.01, -0.02, 0.03], np.float32)
+    rot /= np.linalg.norm(rot)
+    out = {}
+    cases = [("cube_64x1024", "cube", 64, 1024, 0.15, 0.7), ("yard_64x1024", "ground", 64, 1024, 0.15, 0.5),
+             ("yard_64x1024_raw", "ground", 64, 1024, 0.0, 0.5), ("yard_128x2048", "ground", 128, 2048, 0.15, 0.5)]
+    for name, scene, beams, azimuths, size, t in cases:
+        if args.only and args.only not in name:
+            continue
+        with synth.scene(scene):
+            raw, _ = synth.scan(synth.trajectory_pose(t), beams, azimuths)
+        pts = raw[orc.voxel_filter(size, raw)] if size > 0 else raw
+        aligned = orc.transform_points(np.concatenate([np.zeros(3, np.float32), rot]), pts)
+        keys = np.round(aligned[:, 2].astype(np.float64) / 0.2)
+        cloud = dl.PointCloud(ctx, pts)
+        for _ in range(5):
+            got = dl.cloud_rotational_histogram(ctx, cloud, 120, rot)
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            dl.cloud_rotational_histogram(ctx, cloud, 120, rot)
+        dev_us = (time.perf_counter() - t0) / args.reps * 1e6
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dl.rotational_histogram(aligned, 120)
+        host_us = (time.perf_counter() - t0) / 10 * 1e6
+        rec = {"points": int(len(pts)), "largest_slice": int(np.unique(keys, return_counts=True)[1].max()),
+               "device_us": round(dev_us, 1), "host_8_threads_us": round(host_us, 1)}
+        if args.check:
+            want = np.asarray(orc.compute_histogram(aligned, 120), np.float32)
+            rec["equals_oracle"] = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+        out[name] = rec
+        cloud.close()
+    out["poll_fallbacks"] = ctx.poll_fallbacks()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

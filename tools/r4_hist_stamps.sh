@@ -1,0 +1,36 @@
+#!/bin/bash
+# experiments build (make -C d-liom_amd experiments, locally): where the histogram kernels spend their time
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+cat > /tmp/hist_dbg.py <<'PY'
+import sys, time, ctypes
+sys.path.insert(0, "/root/repo/d-liom_amd"); sys.path.insert(0, "/root/repo")
+import numpy as np, dliom as dl
+from dliom import synth
+from oracle import oracle as orc
+ctx = dl.Context(0)
+L = dl.load_library()
+for scene, size in (("cube", 0.15), ("ground", 0.15), ("ground", 0.0)):
+    with synth.scene(scene):
+        raw, _ = synth.scan(synth.trajectory_pose(0.5), 64, 1024)
+    pts = raw[orc.voxel_filter(size, raw)] if size > 0 else raw
+    cloud = dl.PointCloud(ctx, pts)
+    for _ in range(3): h = dl.cloud_rotational_histogram(ctx, cloud, 120)
+    t = time.perf_counter()
+    for _ in range(20): h = dl.cloud_rotational_histogram(ctx, cloud, 120)
+    print(scene, size, len(pts), "us per call", (time.perf_counter() - t) / 20 * 1e6)
+    buf = (ctypes.c_ulonglong * (64 * 16))()
+    L.dliom_exp_rothist_stamps(buf)
+    a = np.array(buf, dtype=np.uint64).reshape(64, 16).astype(np.int64)
+    total = a[:, 7] - a[:, 0]
+    for b in np.argsort(-total)[:4]:
+        s = a[b]
+        print("  wg", b, "count/m/E", s[10], s[11], s[12], "phases(x10ns):", [int(s[k + 1] - s[k]) for k in range(7)])
+    L.dliom_exp_rothist_big_stamps(buf)
+    a = np.array(buf, dtype=np.uint64).reshape(64, 16).astype(np.int64)
+    for b in range(2):
+        print("  big prepare wg", b, [int(a[b, k + 1] - a[b, k]) for k in range(4)])
+        print("  big slice   wg", b, "count/m", a[4 + b, 10], a[4 + b, 11], [int(a[4 + b, k + 1] - a[4 + b, k]) for k in range(6)])
+    cloud.close()
+PY
+DLIOM_LIB=$R/d-liom_amd/ab/libdliom_exp.so timeout 300 python /tmp/hist_dbg.py
