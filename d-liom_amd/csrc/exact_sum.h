@@ -323,9 +323,14 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
 #pragma unroll
           for (int j = 0; j < kChunk; ++j) x[j] = j0 + j < j1 ? vp[j0 + j] : 0.f;
         }
+        if (j1 - j0 == kChunk) {
 #pragma unroll
-        for (int j = 0; j < kChunk; ++j)
-          if (j0 + j < j1) a += x[j];  // (a padding +0 would turn an accumulator of -0 into +0)
+          for (int j = 0; j < kChunk; ++j) a += x[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < kChunk; ++j)
+            if (j0 + j < j1) a += x[j];  // (a padding +0 would turn an accumulator of -0 into +0)
+        }
         cc += 1;
       }
       S.result[wave] = a;

@@ -15,7 +15,7 @@
 //     share an angle in three scans out of four, and which of them comes first decides `last_point` below: the order
 //     libstdc++'s std::sort leaves equal keys in is part of the result.  A slice is first sorted by (angle, position)
 //     with a bitonic sort; if two equal angles end up next to each other, introsort itself is replayed on the slice
-//     (libstdcxx_sort_arrangement: median-of-three + unguarded partition of every segment above 16 elements as
+//     (wave_sort_arrangement: median-of-three + unguarded partition of every segment above 16 elements as
 //     data-parallel rounds, heap sort where the depth limit 2 lg n is used up -- one slice in four, input order being
 //     close to a worst case of the median-of-three -- and a stable sort for the final insertion sort).
 //   * AddPointCloudSliceToHistogram (:61-92): `last_point` only moves when a point is more than 0.9 m from it -- a
@@ -251,23 +251,30 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {
 
 // ---- std::sort's order of EQUAL keys ---------------------------------------------------------------------------------
 // SortSlice sorts (angle, point) pairs by angle only (rotational_scan_matcher.cc:97-121); two returns of one slice share
-// an angle in three scans out of four, and the order libstdc++'s introsort leaves them in decides which one becomes
-// `last_point`.  So the algorithm is reproduced, not just a sorted order (tests/cpp/std_sort_model.cc is this
-// formulation in plain C++, checked against the real std::sort on arrays full of ties):
-//   __introsort_loop      = rounds of median-of-three + unguarded partition on every segment above 16 elements, all
-//                           segments of a round at once; a partition as data-parallel steps -- the k-th stop of the left
-//                           pointer swaps with the k-th stop of the right pointer while they have not crossed;
-//   __final_insertion_sort = a STABLE sort of what the rounds left (insertion never moves an element past an equal one).
-// Runs only for slices whose plain sort found two equal angles next to each other.  `a`: items (ordered angle bits << 32 |
-// position in the slice), [0, m); the arrays are kMaxSlice + 1 u16 each.  Where std::sort runs out of its depth limit it
-// heap-sorts the segment: restated too (heap_sort_keys).  Always returns true (the bool is kept for the callers' shape).
+// an angle in three scans out of four (on walls, where two returns of one 0.2 m slice stand above each other, in every
+// slice), and the order libstdc++'s introsort leaves them in decides which one becomes `last_point`.  So the algorithm is
+// reproduced, not just a sorted order (tests/cpp/std_sort_model.cc is the formulation in plain C++, checked against the
+// real std::sort on arrays full of ties):
+//   __introsort_loop      = median-of-three + unguarded partition of every segment above 16 elements; a partition as
+//                           data-parallel steps -- the k-th stop of the left pointer swaps with the k-th stop of the
+//                           right pointer while they have not crossed; heap sort where the depth limit 2 lg n is used up;
+//   __final_insertion_sort = a STABLE sort of what the partitions left (insertion never moves an element past an equal one).
+// Only segments that still hold two TIED elements (elements whose key occurs more than once) are partitioned: equal keys can
+// only be told apart by where the partitions put them, a segment without two of them has a unique sorted order, and the
+// final sort is stable -- what is left of the other segments does not matter.
+// Round 4: a segment is partitioned by ONE WAVE (ballots and lane ranks, no workgroup barrier), the segments wait in a
+// queue in LDS that the workgroup's 16 waves serve.  The block-wide rounds this replaces cost ~30 000 cycles each (fifteen
+// barriers) however little was left to do: 100 us for the one tied pair of a wall slice, 230 us on slices full of ties.
+// `a`: items (ordered angle bits << 32 | position in the slice).
 struct SortScratch {
-  unsigned short *seg_first, *seg_last, *tmp_l, *tmp_r, *g, *l, *cut;
-  // Only segments that still hold two TIED elements (elements whose key occurs more than once) are partitioned: equal keys
-  // can only be told apart by where the partitions put them, a segment without two of them has a unique sorted order,
-  // and the final insertion sort is stable -- what the rounds leave of the other segments does not matter.
-  const unsigned char* tied;  // by position in the slice (the items' low words); null: every element counts as tied
-  unsigned char* act;         // by arrangement position: the position lies in a segment that is still partitioned
+  unsigned short *tmp_l, *tmp_r;  // [kMaxSlice + 8] each: the stops of the two pointers of the partition in progress
+  const unsigned char* tied;      // by position in the slice (the items' low 16 bits)
+  struct Queue* queue;
+};
+constexpr int kQueueCap = 1024;  // segments ever queued: every one has > 16 elements and they nest, so <= 2 m / 17
+struct Queue {
+  unsigned reserved, head, pending, overflow;
+  uint2 seg[kQueueCap];  // x = first | last << 16, y = partitions left on this path; y = 0xFFFFFFFF: not written yet
 };
 
 // exclusive prefix counts of 4 consecutive flags per thread (position 4 t + k) over the workgroup; out[p] for p in
@@ -323,235 +330,129 @@ __device__ inline void heap_sort_keys(unsigned long long* first, int len) {
   }
 }
 
-// std::__introsort_loop as written (bits/stl_algo.h), one thread on its own segment: used for the tail of the rounds
-// below, when only a few small segments are left above the threshold (an unlucky path of the recursion can go on for
-// 2 lg n partitions while everything else has long been done).  The recursion on [cut, last) is an explicit stack; the
-// two halves are disjoint, so the order they are worked in does not matter.
-__device__ inline void introsort_loop_sequential(unsigned long long* a, int first, int last, int depth) {
-  int st_first[40], st_last[40], st_depth[40];
-  int sp = 0;
-  for (;;) {
-    while (last - first > 16) {
-      if (depth == 0) {
-        heap_sort_keys(a + first, last - first);
-        break;
-      }
-      --depth;
-      {
-        const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
-        const unsigned ka = static_cast<unsigned>(a[ia] >> 32), kb = static_cast<unsigned>(a[ib] >> 32), kc = static_cast<unsigned>(a[ic] >> 32);
-        int md;
-        if (ka < kb) {
-          if (kb < kc) md = ib;
-          else if (ka < kc) md = ic;
-          else md = ia;
-        } else if (ka < kc) md = ia;
-        else if (kb < kc) md = ic;
-        else md = ib;
-        const unsigned long long t = a[first];
-        a[first] = a[md];
-        a[md] = t;
-      }
-      const unsigned pivot = static_cast<unsigned>(a[first] >> 32);
-      int f = first + 1, l = last;
-      for (;;) {
-        while (static_cast<unsigned>(a[f] >> 32) < pivot) ++f;
-        --l;
-        while (pivot < static_cast<unsigned>(a[l] >> 32)) --l;
-        if (!(f < l)) break;
-        const unsigned long long t = a[f];
-        a[f] = a[l];
-        a[l] = t;
-        ++f;
-      }
-      st_first[sp] = f;  // std::__introsort_loop(cut, last, depth_limit) ...
-      st_last[sp] = last;
-      st_depth[sp] = depth;
-      ++sp;
-      last = f;          // ... and last = cut
-    }
-    if (sp == 0) return;
-    --sp;
-    first = st_first[sp];
-    last = st_last[sp];
-    depth = st_depth[sp];
+// The queue is served level by level: the segments queued so far are partitioned, one wave each, their children are
+// appended (one atomic counter), a barrier, and the appended ones are the next level.  (A first version let idle waves
+// spin on their next entry instead of meeting at a barrier; it hung on the device and was not worth the minutes.)
+__device__ __forceinline__ void queue_init(Queue* q) {  // all threads; a barrier must follow
+  if (threadIdx.x == 0) {
+    q->reserved = 0u;
+    q->head = 0u;
+    q->pending = 0u;
+    q->overflow = 0u;
   }
 }
+__device__ __forceinline__ void queue_push(Queue* q, int first, int last, int depth) {  // one lane
+  const unsigned slot = atomicAdd(&q->reserved, 1u);
+  if (slot < static_cast<unsigned>(kQueueCap))
+    q->seg[slot] = make_uint2(static_cast<unsigned>(first) | (static_cast<unsigned>(last) << 16), static_cast<unsigned>(depth));
+  else
+    atomicExch(&q->overflow, 1u);
+}
 
-__device__ bool libstdcxx_sort_arrangement(unsigned long long* a, int m, const SortScratch& sc, unsigned* wave_sums) {
-  static_assert(kMaxSlice == 4 * kThreads, "four positions per thread");
-  const int p0 = 4 * static_cast<int>(threadIdx.x);
-  int depth = 0;
-  for (int v = m; v > 1; v >>= 1) ++depth;
-  depth *= 2;  // std::__lg(n) * 2
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    sc.seg_first[p0 + k] = 0;
-    sc.seg_last[p0 + k] = static_cast<unsigned short>(m);
-  }
-  __syncthreads();
-  for (;;) {
-    // which segments are still partitioned: above the threshold and holding at least two tied elements
-    {
-      unsigned t[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int p = p0 + k;
-        t[k] = p < m ? (sc.tied != nullptr ? sc.tied[static_cast<unsigned>(a[p]) & 0xffffu] : 1u) : 0u;
-      }
-      blocked_prefix(t, sc.tmp_l, wave_sums);  // tmp_l is free until (b)
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int p = p0 + k;
-        unsigned char on = 0;
-        if (p < m) {
-          const int first = sc.seg_first[p], last = sc.seg_last[p];
-          on = (last - first > 16 && sc.tmp_l[last] - sc.tmp_l[first] >= 2) ? 1 : 0;
-        }
-        sc.act[p] = on;
-      }
-      __syncthreads();
-    }
-    // threads that own a position inside such a segment (<= 4 positions each)
-    int inside = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) inside |= sc.act[p0 + k];
-    const int busy_threads = __syncthreads_count(inside);
-    if (busy_threads == 0) return true;
-    if (busy_threads <= 96 && depth > 0) {  // <= 384 elements left: the rest of the recursion sequentially, a thread per segment
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int p = p0 + k;
-        if (sc.act[p] && sc.seg_first[p] == p) introsort_loop_sequential(a, p, sc.seg_last[p], depth);
-      }
-      __syncthreads();
-      return true;
-    }
+// std::__introsort_loop on the queued segments (see above).  All threads of the workgroup call this after the queue has
+// been filled and a barrier; returns after a barrier, false if the queue overflowed (cannot happen for m <= kMaxSlice).
+__device__ bool wave_sort_arrangement(unsigned long long* a, const SortScratch& sc) {
+  Queue* q = sc.queue;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned level_begin = 0u;
+  for (int level = 0; level < 4 * 64; ++level) {  // (a path has at most 2 lg n partitions; the bound only guards the loop)
+    const unsigned level_end = min(q->reserved, static_cast<unsigned>(kQueueCap));
+    __syncthreads();  // everybody has read the level's end before anybody appends to the queue
+    if (level_begin >= level_end) break;
+    for (unsigned e = level_begin + static_cast<unsigned>(wave); e < level_end; e += kThreads / 64) {
+    const uint2 entry = q->seg[e];
+    const int first = static_cast<int>(entry.x & 0xffffu), last = static_cast<int>(entry.x >> 16);
+    const int depth = static_cast<int>(entry.y);
     if (depth == 0) {
       // std::sort's depth limit (2 lg n partitions on one path): it heap-sorts what is left of such a segment --
-      // std::__partial_sort(first, last, last) = __make_heap + __sort_heap, restated; sequential, one thread per segment.
-      // Not rare: a slice in input order is close to a worst case of the median-of-three, one slice in four gets here.
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int p = p0 + k;
-        if (sc.act[p] && sc.seg_first[p] == p) heap_sort_keys(a + p, sc.seg_last[p] - p);
-      }
-      __syncthreads();
-      return true;
+      // std::__partial_sort(first, last, last) = __make_heap + __sort_heap, restated; sequential
+      if (lane == 0) heap_sort_keys(a + first, last - first);
+      continue;
     }
-    --depth;
-    // (a) __move_median_to_first(first, first + 1, mid, last - 1): one thread per segment head
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = p0 + k;
-      if (sc.act[p] && sc.seg_first[p] == p) {
-        const int first = p, last = sc.seg_last[p];
-        const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
-        const unsigned ka = static_cast<unsigned>(a[ia] >> 32), kb = static_cast<unsigned>(a[ib] >> 32), kc = static_cast<unsigned>(a[ic] >> 32);
-        int md;
-        if (ka < kb) {
-          if (kb < kc) md = ib;
-          else if (ka < kc) md = ic;
-          else md = ia;
-        } else if (ka < kc) md = ia;
-        else if (kb < kc) md = ic;
-        else md = ib;
-        const unsigned long long t = a[first];
-        a[first] = a[md];
-        a[md] = t;
-      }
+    // (a) __move_median_to_first(first, first + 1, mid, last - 1)
+    if (lane == 0) {
+      const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+      const unsigned ka = static_cast<unsigned>(a[ia] >> 32), kb = static_cast<unsigned>(a[ib] >> 32), kc = static_cast<unsigned>(a[ic] >> 32);
+      int md;
+      if (ka < kb) {
+        if (kb < kc) md = ib;
+        else if (ka < kc) md = ic;
+        else md = ia;
+      } else if (ka < kc) md = ia;
+      else if (kb < kc) md = ic;
+      else md = ib;
+      const unsigned long long t = a[first];
+      a[first] = a[md];
+      a[md] = t;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned pivot = static_cast<unsigned>(a[first] >> 32);
     // (b) where the two pointers of __unguarded_partition(first + 1, last, first) stop: !(x < pivot) from the left,
-    //     !(pivot < x) from the right; prefix counts over the whole array, ranks relative to the segment
-    unsigned ge[4], le[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = p0 + k;
-      ge[k] = le[k] = 0u;
-      if (p < m) {
-        const int first = sc.seg_first[p], last = sc.seg_last[p];
-        if (sc.act[p] && p != first) {
-          const unsigned pivot = static_cast<unsigned>(a[first] >> 32), x = static_cast<unsigned>(a[p] >> 32);
-          ge[k] = x < pivot ? 0u : 1u;
-          le[k] = pivot < x ? 0u : 1u;
-        }
+    //     !(pivot < x) from the right; both lists in ascending order of position
+    unsigned short* stops_l = sc.tmp_l + first + 1;
+    unsigned short* stops_r = sc.tmp_r + first + 1;
+    int cnt_l = 0, cnt_r = 0;
+    for (int base = first + 1; base < last; base += 64) {
+      const int p = base + lane;
+      const bool in = p < last;
+      const unsigned x = in ? static_cast<unsigned>(a[p] >> 32) : 0u;
+      const bool ge = in && !(x < pivot), le = in && !(pivot < x);
+      const unsigned long long ml = __builtin_amdgcn_ballot_w64(ge), mr = __builtin_amdgcn_ballot_w64(le);
+      if (ge) stops_l[cnt_l + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(ml >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(ml), 0u))] =
+          static_cast<unsigned short>(p);
+      if (le) stops_r[cnt_r + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mr >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mr), 0u))] =
+          static_cast<unsigned short>(p);
+      cnt_l += __builtin_popcountll(ml);
+      cnt_r += __builtin_popcountll(mr);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // (c) the k-th stop from the left swaps with the k-th stop from the right while the pointers have not crossed
+    //     (positions from the left grow with k, from the right they fall: the valid k are 0 .. K - 1)
+    const int lim = min(cnt_l, cnt_r);
+    int K = lim;
+    for (int k0 = 0; k0 < lim; k0 += 64) {
+      const int k = k0 + lane;
+      const bool v = k < lim && stops_l[k] < stops_r[cnt_r - 1 - k];
+      const unsigned long long mv = __builtin_amdgcn_ballot_w64(v);
+      if (mv != ~0ull) {
+        K = k0 + __builtin_ctzll(~mv);
+        break;
       }
     }
-    blocked_prefix(ge, sc.g, wave_sums);
-    blocked_prefix(le, sc.l, wave_sums);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = p0 + k;
-      if (p < m) {
-        const int first = sc.seg_first[p], last = sc.seg_last[p];
-        if (ge[k]) sc.tmp_l[first + 1 + (sc.g[p] - sc.g[first + 1])] = static_cast<unsigned short>(p);
-        if (le[k]) sc.tmp_r[first + 1 + (sc.l[last] - sc.l[p + 1])] = static_cast<unsigned short>(p);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + lane;
+      if (k < K) {
+        const int il = stops_l[k], ir = stops_r[cnt_r - 1 - k];
+        const unsigned long long xl = a[il], xr = a[ir];
+        a[il] = xr;
+        a[ir] = xl;
       }
     }
-    __syncthreads();
-    // (c) the k-th pair swaps while the pointers have not crossed; the thread at the boundary knows the cut
-    unsigned long long keep_l[4], keep_r[4];
-    int at_l[4], at_r[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int q = p0 + k;
-      at_l[k] = at_r[k] = -1;
-      if (q < m) {
-        const int first = sc.seg_first[q], last = sc.seg_last[q];
-        if (sc.act[q] && q != first) {
-          const int kk = q - (first + 1);
-          const int cnt_l = sc.g[last] - sc.g[first + 1], cnt_r = sc.l[last] - sc.l[first + 1];
-          auto valid = [&](int j) { return j < cnt_l && j < cnt_r && sc.tmp_l[first + 1 + j] < sc.tmp_r[first + 1 + j]; };
-          const bool v = valid(kk);
-          if (v) {
-            at_l[k] = sc.tmp_l[q];
-            at_r[k] = sc.tmp_r[q];
-            keep_l[k] = a[at_l[k]];
-            keep_r[k] = a[at_r[k]];
-          }
-          int K = -1;
-          if (kk == 0 && !v) K = 0;
-          else if (v && !valid(kk + 1)) K = kk + 1;
-          if (K >= 0) {  // where the left pointer stops next
-            int i = 1 << 30;
-            if (K < cnt_l) i = sc.tmp_l[first + 1 + K];
-            if (K > 0) i = min(i, static_cast<int>(sc.tmp_r[first + 1 + K - 1]));
-            sc.cut[first] = static_cast<unsigned short>(i);
-          }
-        }
-      }
+    int cut = 1 << 30;  // where the left pointer stops next
+    if (K < cnt_l) cut = stops_l[K];
+    if (K > 0) cut = min(cut, static_cast<int>(stops_r[cnt_r - K]));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // (d) [first, cut) and [cut, last): queued if they are above the threshold and hold two tied elements
+    int tied_l = 0, tied_r = 0;
+    for (int base = first; base < last; base += 64) {
+      const int p = base + lane;
+      const bool t = p < last && sc.tied[static_cast<unsigned>(a[p]) & 0xffffu] != 0;
+      tied_l += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t && p < cut));
+      tied_r += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t && p >= cut));
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (at_l[k] >= 0) {
-        a[at_l[k]] = keep_r[k];
-        a[at_r[k]] = keep_l[k];
-      }
-    // (d) [first, cut) and [cut, last)
-    unsigned short nf[4], nl[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = p0 + k;
-      nf[k] = sc.seg_first[p0 + k];
-      nl[k] = sc.seg_last[p0 + k];
-      if (sc.act[p]) {
-        const int c = sc.cut[nf[k]];
-        if (p < c) nl[k] = static_cast<unsigned short>(c);
-        else nf[k] = static_cast<unsigned short>(c);
-      }
+    if (lane == 0) {
+      if (cut - first > 16 && tied_l >= 2) queue_push(q, first, cut, depth - 1);
+      if (last - cut > 16 && tied_r >= 2) queue_push(q, cut, last, depth - 1);
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      sc.seg_first[p0 + k] = nf[k];
-      sc.seg_last[p0 + k] = nl[k];
     }
-    __syncthreads();
+    __syncthreads();  // the level's partitions and appended entries are done
+    level_begin = level_end;
   }
+  __syncthreads();
+  return q->overflow == 0u;
 }
 
 #ifdef DLIOM_EXPERIMENTS
@@ -641,14 +542,19 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
   float* sx = reinterpret_cast<float*>(skey + kMaxSlice);
   float* sy = sx + kMaxSlice;
   float* sz = sy + kMaxSlice;
-  // std::sort's order of equal keys (libstdcxx_sort_arrangement): eight arrays of kMaxSlice + 8 u16
+  // std::sort's order of equal keys (wave_sort_arrangement) and later steps: eight arrays of kMaxSlice + 8 u16
   unsigned short* u16_base = reinterpret_cast<unsigned short*>(sz + kMaxSlice);
   constexpr int kU16 = kMaxSlice + 8;
   unsigned short* idx_of = u16_base + 7 * kU16;  // arrangement position -> position in the slice
   unsigned char* tied_flags = reinterpret_cast<unsigned char*>(idx_of);  // by position in the slice; dead once idx_of is written
   unsigned char* act_flags = reinterpret_cast<unsigned char*>(u16_base + 8 * kU16);  // [kMaxSlice]; later the chain's marks
-  const SortScratch sort_scratch{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
-                                 u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16, tied_flags, act_flags};
+  static_assert(sizeof(Queue) <= static_cast<size_t>(kU16) * 2, "the queue fits one of the arrays");
+  const SortScratch sort_scratch{u16_base, u16_base + kU16, tied_flags, reinterpret_cast<Queue*>(u16_base + 2 * kU16)};
+  // std::sort's input and arrangement (the plainly sorted keys stay in skey): arrays 3 .. 6
+  static_assert(4 * static_cast<size_t>(kU16) * 2 >= static_cast<size_t>(kMaxSlice) * 8, "four of the arrays hold the replay's items");
+  unsigned long long* replay = reinterpret_cast<unsigned long long*>(u16_base + 3 * kU16 + 4);  // (+ 4: 8-byte aligned)
+  unsigned short* scratch_g = u16_base;         // prefix counts of the valid points (before the replay); later the chain's pointers
+  unsigned short* scratch_l = u16_base + kU16;  // ... and, between them, the tied elements' places and the final order
   __shared__ unsigned wave_sums[kThreads / 64];
   __shared__ int wave_max[kThreads / 64];
   __shared__ unsigned sh_bin, sh_count, sh_begin, sh_valid, sh_written;
@@ -754,8 +660,7 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
       while (hits != 0u) {
         const int t = __builtin_ctz(hits);
         sx[slot] = rx[i0 + t];
-        sy[slot] = ry[i0 + t];
-        sz[slot] = rz[i0 + t];
+        sy[slot] = ry[i0 + t];  // (z decided the slice and is not read again)
         ++slot;
         hits &= hits - 1u;
       }
@@ -827,29 +732,51 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
         }
       }
       __syncthreads();
-      blocked_prefix(ok, sort_scratch.g, wave_sums);
+      blocked_prefix(ok, scratch_g, wave_sums);
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (ok[k]) skey[sort_scratch.g[p0 + k]] = item[k];
+        if (ok[k]) replay[scratch_g[p0 + k]] = item[k];
       __syncthreads();
-      const bool done = libstdcxx_sort_arrangement(skey, m, sort_scratch, wave_sums);
-      if (!done) {  // std::sort's depth limit: it heap-sorts from there, not reproduced -- refuse, the host path takes the cloud
+      queue_init(sort_scratch.queue);
+      __syncthreads();
+      if (threadIdx.x == 0 && m > 16) {
+        int depth = 0;
+        for (int v = m; v > 1; v >>= 1) ++depth;
+        queue_push(sort_scratch.queue, 0, m, 2 * depth);  // std::__lg(n) * 2
+      }
+      __syncthreads();
+      const bool done = wave_sort_arrangement(replay, sort_scratch);
+      if (!done) {  // the queue overflowed (cannot happen for m <= kMaxSlice): refuse, the host path takes the cloud
         if (threadIdx.x == 0) atomicOr(flags, 4u);
         continue;
       }
-      // the final insertion sort is a stable sort of this arrangement: sort (angle, arrangement position)
-      for (int q = threadIdx.x; q < pow2; q += kThreads) {
-        if (q < m) {
-          const unsigned long long it = skey[q];
-          idx_of[q] = static_cast<unsigned short>(it & 0xffffu);
-          skey[q] = (it & 0xffffffff00000000ull) | static_cast<unsigned>(q);
-        } else {
-          skey[q] = ~0ull;
-        }
+      // the final insertion sort is stable: among equal angles the arrangement's order stays.  skey is sorted by (angle,
+      // position); every group of equal angles is put into the order of its members' places in the arrangement.
+      unsigned short* pos_of = scratch_g;  // by position in the slice (tied elements only)
+      unsigned short* order = scratch_l;   // j-th element of std::sort's result -> position in the slice
+      for (int q = threadIdx.x; q < m; q += kThreads) {
+        const unsigned id = static_cast<unsigned>(replay[q]) & 0xffffu;
+        if (tied_flags[id]) pos_of[id] = static_cast<unsigned short>(q);
       }
       __syncthreads();
-      bitonic_sort_keys(skey, pow2);
+      for (int j = threadIdx.x; j < m; j += kThreads) {
+        const unsigned long long it = skey[j];
+        const unsigned id = static_cast<unsigned>(it) & 0xffffu;
+        int dst = j;
+        if (tied_flags[id]) {
+          const unsigned key = static_cast<unsigned>(it >> 32);
+          int gs = j, ge = j + 1;
+          while (gs > 0 && static_cast<unsigned>(skey[gs - 1] >> 32) == key) --gs;
+          while (ge < m && static_cast<unsigned>(skey[ge] >> 32) == key) ++ge;
+          const unsigned mine = pos_of[id];
+          int r = 0;
+          for (int u = gs; u < ge; ++u) r += pos_of[static_cast<unsigned>(skey[u]) & 0xffffu] < mine ? 1 : 0;
+          dst = gs + r;
+        }
+        order[dst] = static_cast<unsigned short>(id);
+      }
+      __syncthreads();
     }
     DLIOM_STAMP(4);
     // ---- the sorted slice, contiguous (x into the z array -- z is not needed any more -- and y behind the sort keys'
@@ -861,8 +788,8 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
       const int j = threadIdx.x + r * kThreads;
       my_py[r] = 0.f;
       if (j < m) {
-        unsigned idx = static_cast<unsigned>(skey[j]);
-        if (tied) idx = idx_of[idx];
+        unsigned idx = static_cast<unsigned>(skey[j]) & 0xffffu;
+        if (tied) idx = scratch_l[j];  // `order` of the branch above
         px_sorted[j] = sx[idx];
         my_py[r] = sy[idx];
       }
@@ -896,8 +823,8 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     //     every point is one; instead next(i) for every i at once, then the nodes on the path 0 -> next(0) -> ... by
     //     pointer doubling (marks spread along next^(2^d) while the pointers are squared; rothist_big.h).
     {
-      unsigned short* ja = sort_scratch.g;  // the sort's scratch is free
-      unsigned short* jb = sort_scratch.l;
+      unsigned short* ja = scratch_g;  // the sort's scratch is free
+      unsigned short* jb = scratch_l;
       unsigned char* mark = act_flags;
       const int p0 = 4 * static_cast<int>(threadIdx.x);
 #pragma unroll
@@ -1201,10 +1128,7 @@ __global__ __launch_bounds__(kThreads) void std_sort_order_kernel(const float* _
   constexpr int kU16 = kMaxSlice + 8;
   unsigned short* idx_of = u16_base + 7 * kU16;
   unsigned char* tied_flags = reinterpret_cast<unsigned char*>(idx_of);
-  unsigned char* act_flags = reinterpret_cast<unsigned char*>(u16_base + 8 * kU16);
-  const SortScratch sc{u16_base,           u16_base + kU16,     u16_base + 2 * kU16, u16_base + 3 * kU16,
-                       u16_base + 4 * kU16, u16_base + 5 * kU16, u16_base + 6 * kU16, tied_flags, act_flags};
-  __shared__ unsigned wave_sums[kThreads / 64];
+  const SortScratch sc{u16_base, u16_base + kU16, tied_flags, reinterpret_cast<Queue*>(u16_base + 2 * kU16)};
   int pow2 = 64;
   while (pow2 < n) pow2 <<= 1;
   // as in slice_kernel: a plain sort finds the elements whose key occurs more than once ...
@@ -1224,7 +1148,15 @@ __global__ __launch_bounds__(kThreads) void std_sort_order_kernel(const float* _
   for (int i = threadIdx.x; i < pow2; i += kThreads)
     skey[i] = i < n ? (static_cast<unsigned long long>(ordered_bits(keys[i])) << 32) | static_cast<unsigned>(i) : ~0ull;
   __syncthreads();
-  const bool done = libstdcxx_sort_arrangement(skey, n, sc, wave_sums);
+  queue_init(sc.queue);
+  __syncthreads();
+  if (threadIdx.x == 0 && n > 16) {
+    int depth = 0;
+    for (int v = n; v > 1; v >>= 1) ++depth;
+    queue_push(sc.queue, 0, n, 2 * depth);
+  }
+  __syncthreads();
+  const bool done = wave_sort_arrangement(skey, sc);
   if (!done) {
     if (threadIdx.x == 0) *status = 1;
     return;
@@ -1301,7 +1233,14 @@ extern "C" int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int 
     hipLaunchKernelGGL(big_sort_items_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_keys, n, A.key_in, A.val_in);
     DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(base + temp_at, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, n, 0, 32,
                                                      ctx->stream));
-    hipLaunchKernelGGL(big_sort_order_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, n, A, d_order, d_status);
+    if ((ctx->func_attr_set & kFuncAttrHistogramBig) == 0u) {
+      DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(big_sort_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(kBigLdsBytes)));
+      DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(big_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(kBigLdsBytes)));
+      ctx->func_attr_set |= kFuncAttrHistogramBig;
+    }
+    hipLaunchKernelGGL(big_sort_order_kernel, dim3(1), dim3(kThreads), kBigLdsBytes, ctx->stream, n, A, d_order, d_status);
     DLIOM_HIP_TRY(hipGetLastError());
     int status = 0;
     DLIOM_HIP_TRY(hipMemcpyAsync(order, d_order, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1441,8 +1380,15 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
   if (with_big) {
     DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_temp, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, sort_items, 0,
                                                      kBigKeyBits, stream));
-    hipLaunchKernelGGL(big_slice_kernel, dim3(kMaxBig), dim3(kThreads), 0, stream, bin_counts, histogram_size, squared_jump, A, c_bucket,
-                       c_value, flags);
+    if ((ctx->func_attr_set & kFuncAttrHistogramBig) == 0u) {
+      DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(big_sort_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(kBigLdsBytes)));
+      DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(big_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(kBigLdsBytes)));
+      ctx->func_attr_set |= kFuncAttrHistogramBig;
+    }
+    hipLaunchKernelGGL(big_slice_kernel, dim3(kMaxBig), dim3(kThreads), kBigLdsBytes, stream, bin_counts, histogram_size, squared_jump, A,
+                       c_bucket, c_value, flags);
   }
   hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64 * kAccWaves), acc_lds, stream, c_bucket,
                      c_value, static_cast<int>(n_padded), histogram_size, d_hist);

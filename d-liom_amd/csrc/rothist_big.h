@@ -30,6 +30,7 @@ __device__ unsigned long long dbg_big[64 * 16];
 #define DLIOM_BSTAMP(k)
 #endif
 
+constexpr size_t kBigLdsBytes = static_cast<size_t>(kMaxSlice) * 8 + 2 * static_cast<size_t>(kMaxSlice + 8) * 2 + sizeof(Queue) + kMaxSlice + 64;
 constexpr int kMaxBig = 63;         // big slices per cloud (slice ordinal 63 is the sort's padding key)
 constexpr int kBigKeyBits = 38;     // 32 angle bits + 6 slice bits
 
@@ -125,18 +126,60 @@ __device__ __forceinline__ int block_exclusive_max(int v, int identity, int* wav
 __device__ __forceinline__ unsigned key_of(unsigned long long item) { return static_cast<unsigned>(item >> 32); }
 
 // ---- std::sort's order of equal keys on a slice of any size --------------------------------------------------------
+// Thread t owns the positions [lo, hi) in every pass; they are visited four at a time with the loads of all four issued
+// before anything depends on them: a plain loop of load -> use -> store pays the memory latency once per position, and
+// with ~15 positions per thread and a dozen passes per partition round that was 1.3 ms for a floor slice of 14 500
+// returns (round 4's first version).
+template <class Stage1, class Stage2, class Use>
+__device__ __forceinline__ void for_owned4(int lo, int hi, Stage1 stage1, Stage2 stage2, Use use) {
+  for (int p0 = lo; p0 < hi; p0 += 4) {
+    const int q0 = p0, q1 = min(p0 + 1, hi - 1), q2 = min(p0 + 2, hi - 1), q3 = min(p0 + 3, hi - 1);
+    const auto a0 = stage1(q0);
+    const auto a1 = stage1(q1);
+    const auto a2 = stage1(q2);
+    const auto a3 = stage1(q3);
+    const auto b0 = stage2(q0, a0);
+    const auto b1 = stage2(q1, a1);
+    const auto b2 = stage2(q2, a2);
+    const auto b3 = stage2(q3, a3);
+    use(q0, a0, b0);
+    if (p0 + 1 < hi) use(q1, a1, b1);
+    if (p0 + 2 < hi) use(q2, a2, b2);
+    if (p0 + 3 < hi) use(q3, a3, b3);
+  }
+}
+struct U2 {
+  unsigned a, b;
+};
+struct U4 {
+  unsigned a, b, c, d;
+};
+
 // in:  sk/sv   the m items sorted by (key, input position): key in the low 32 bits of sk, position in sv (< count)
 //      ik/iv   the same items in input order
 // out: sorted_id[j] = position (in the slice) of the j-th element of std::sort's result
-// Scratch arrays have m + 1 entries.  Returns false when the depth limit's heap sort would have to run on a segment too
-// large to do by one thread in global memory (flags |= 4: the host entry point takes the cloud).
+// Scratch arrays have m + 1 entries.  The partition rounds run on arrays in HBM while more than kMaxSlice elements lie in
+// segments that still hold ties, then in LDS (lds_a / lds_sc: wave_sort_arrangement, the replay of the small slices).  Returns false when
+// the depth limit's heap sort would have to run on a segment too large to do by one thread in global memory (flags |= 4:
+// the host entry point takes the cloud).
 __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const unsigned* __restrict__ sv,
                                const unsigned long long* __restrict__ ik, const unsigned* __restrict__ iv, int m, int count,
-                               const BigArrays& A, unsigned off, unsigned* wave_sums) {
-  unsigned long long* arr = A.arr + off;
-  unsigned *seg_first = A.seg_first + off, *seg_last = A.seg_last + off, *g = A.g + off, *l = A.l + off, *tmp_l = A.tmp_l + off,
-           *tmp_r = A.tmp_r + off, *cut = A.cut + off, *tpre = A.tpre + off, *pos_of = A.pos_of + off, *sorted_id = A.sorted_id + off;
-  unsigned char *act = A.act + off, *fl = A.fl + off, *tied = A.tied + off;
+                               const BigArrays& A, unsigned off, unsigned* wave_sums, unsigned long long* lds_a,
+                               const SortScratch& lds_sc) {
+  unsigned long long* __restrict__ arr = A.arr + off;
+  unsigned* __restrict__ seg_first = A.seg_first + off;
+  unsigned* __restrict__ seg_last = A.seg_last + off;
+  unsigned* __restrict__ g = A.g + off;
+  unsigned* __restrict__ l = A.l + off;
+  unsigned* __restrict__ tmp_l = A.tmp_l + off;
+  unsigned* __restrict__ tmp_r = A.tmp_r + off;
+  unsigned* __restrict__ cut = A.cut + off;
+  unsigned* __restrict__ tpre = A.tpre + off;
+  unsigned* __restrict__ pos_of = A.pos_of + off;
+  unsigned* __restrict__ sorted_id = A.sorted_id + off;
+  unsigned char* __restrict__ act = A.act + off;
+  unsigned char* __restrict__ fl = A.fl + off;
+  unsigned char* __restrict__ tied = A.tied + off;
   int lo, hi;
   {  // positions in the slice run over [0, count); m <= count of them are items
     int clo, chi;
@@ -146,23 +189,29 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
   owned_range(m, &lo, &hi);
   __syncthreads();
   int t = 0;
-  for (int j = lo; j < hi; ++j)
-    if (j + 1 < m && static_cast<unsigned>(sk[j]) == static_cast<unsigned>(sk[j + 1])) {
-      tied[sv[j]] = 1;
-      tied[sv[j + 1]] = 1;
-      t = 1;
-    }
+  for_owned4(
+      lo, hi, [&](int j) { return U2{static_cast<unsigned>(sk[j]), static_cast<unsigned>(sk[min(j + 1, m - 1)])}; },
+      [&](int j, U2) { return U2{sv[j], sv[min(j + 1, m - 1)]}; },
+      [&](int j, U2 k, U2 v) {
+        if (j + 1 < m && k.a == k.b) {
+          tied[v.a] = 1;
+          tied[v.b] = 1;
+          t = 1;
+        }
+      });
   const bool any_tie = __syncthreads_or(t) != 0;
   if (!any_tie) {
-    for (int j = lo; j < hi; ++j) sorted_id[j] = sv[j];
+    for_owned4(lo, hi, [&](int j) { return sv[j]; }, [](int, unsigned) { return 0; }, [&](int j, unsigned v, int) { sorted_id[j] = v; });
     __syncthreads();
     return true;
   }
-  for (int p = lo; p < hi; ++p) {
-    arr[p] = (static_cast<unsigned long long>(static_cast<unsigned>(ik[p])) << 32) | iv[p];
-    seg_first[p] = 0u;
-    seg_last[p] = static_cast<unsigned>(m);
-  }
+  for_owned4(
+      lo, hi, [&](int p) { return U2{static_cast<unsigned>(ik[p]), iv[p]}; }, [](int, U2) { return 0; },
+      [&](int p, U2 x, int) {
+        arr[p] = (static_cast<unsigned long long>(x.a) << 32) | x.b;
+        seg_first[p] = 0u;
+        seg_last[p] = static_cast<unsigned>(m);
+      });
   int depth = 0;
   for (int v = m; v > 1; v >>= 1) ++depth;
   depth *= 2;
@@ -171,24 +220,77 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
   for (;;) {
     // which segments still matter: above the threshold and holding at least two tied elements
     unsigned cnt = 0u;
-    for (int p = lo; p < hi; ++p) cnt += tied[static_cast<unsigned>(arr[p])];
+    for_owned4(
+        lo, hi, [&](int p) { return static_cast<unsigned>(arr[p]); }, [&](int, unsigned id) { return static_cast<unsigned>(tied[id]); },
+        [&](int p, unsigned, unsigned f) {
+          fl[p] = static_cast<unsigned char>(f);
+          cnt += f;
+        });
     unsigned total;
     unsigned run = block_exclusive_scan(cnt, wave_sums, &total);
-    for (int p = lo; p < hi; ++p) {
-      tpre[p] = run;
-      run += tied[static_cast<unsigned>(arr[p])];
-    }
+    for_owned4(
+        lo, hi, [&](int p) { return static_cast<unsigned>(fl[p]); }, [](int, unsigned) { return 0; },
+        [&](int p, unsigned f, int) {
+          tpre[p] = run;
+          run += f;
+        });
     if (threadIdx.x == 0) tpre[m] = total;
     __syncthreads();
     int any = 0, heap_too_large = 0;
-    for (int p = lo; p < hi; ++p) {
-      const unsigned f = seg_first[p], s = seg_last[p];
-      const int a = (s - f > 16u && tpre[s] - tpre[f] >= 2u) ? 1 : 0;
-      act[p] = static_cast<unsigned char>(a);
-      any |= a;
-      if (a && depth == 0 && s - f > 8192u) heap_too_large = 1;
-    }
+    unsigned active = 0u;
+    for_owned4(
+        lo, hi, [&](int p) { return U2{seg_first[p], seg_last[p]}; }, [&](int, U2 s) { return U2{tpre[s.a], tpre[s.b]}; },
+        [&](int p, U2 s, U2 c) {
+          const int a = (s.b - s.a > 16u && c.b - c.a >= 2u) ? 1 : 0;
+          act[p] = static_cast<unsigned char>(a);
+          any |= a;
+          active += static_cast<unsigned>(a);
+          if (a && depth == 0 && s.b - s.a > 8192u) heap_too_large = 1;
+        });
     if (__syncthreads_or(any) == 0) break;
+    unsigned active_total;
+    const unsigned compact_at = block_exclusive_scan(active, wave_sums, &active_total);
+    if (active_total <= static_cast<unsigned>(kMaxSlice)) {
+      // ---- the rest in LDS: the active segments, packed in order (a segment is active as a whole, so segments stay
+      //      contiguous), under the replay of the small slices; identities are the packed indices at this moment
+      unsigned* __restrict__ cpos = g;  // packed index -> position; g, l, tpre are free from here on
+      unsigned* __restrict__ cid = l;   // packed index -> position in the slice (the item's low word)
+      unsigned* __restrict__ cidx = tpre;  // position -> packed index (active positions)
+      {
+        unsigned c = compact_at;
+        for_owned4(
+            lo, hi, [&](int p) { return static_cast<unsigned>(act[p]); }, [](int, unsigned) { return 0; },
+            [&](int p, unsigned a, int) {
+              if (a) cidx[p] = c++;
+            });
+      }
+      __syncthreads();
+      queue_init(lds_sc.queue);
+      __syncthreads();
+      for_owned4(
+          lo, hi, [&](int p) { return U4{static_cast<unsigned>(act[p]), seg_first[p], seg_last[p], cidx[p]}; },
+          [&](int p, U4 x) { return x.a ? U2{cidx[x.b], cidx[x.c - 1u]} : U2{0u, 0u}; },
+          [&](int p, U4 x, U2 sfl) {
+            if (x.a) {
+              const unsigned long long item = arr[p];
+              const unsigned c = x.d;
+              lds_a[c] = (item & 0xffffffff00000000ull) | c;
+              const_cast<unsigned char*>(lds_sc.tied)[c] = tied[static_cast<unsigned>(item)];
+              cpos[c] = static_cast<unsigned>(p);
+              cid[c] = static_cast<unsigned>(item);
+              if (x.b == static_cast<unsigned>(p)) queue_push(lds_sc.queue, static_cast<int>(sfl.a), static_cast<int>(sfl.b) + 1, depth);
+            }
+          });
+      const int T = static_cast<int>(active_total);
+      __syncthreads();
+      if (!wave_sort_arrangement(lds_a, lds_sc)) ok = false;
+      for (int q = threadIdx.x; q < T; q += kThreads) {
+        const unsigned long long item = lds_a[q];
+        arr[cpos[q]] = (item & 0xffffffff00000000ull) | cid[static_cast<unsigned>(item) & 0xffffu];
+      }
+      __syncthreads();
+      break;
+    }
     if (depth == 0) {
       // std::sort's depth limit: heap sort (restated in rotational_histogram.hip) of what is left, one thread per segment
       if (__syncthreads_or(heap_too_large) != 0) {
@@ -222,95 +324,109 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
     __syncthreads();
     // (b) where the two pointers of __unguarded_partition stop
     unsigned gc = 0u, lc = 0u;
-    for (int p = lo; p < hi; ++p) {
-      unsigned ge = 0u, le = 0u;
-      if (act[p] && seg_first[p] != static_cast<unsigned>(p)) {
-        const unsigned pivot = key_of(arr[seg_first[p]]), x = key_of(arr[p]);
-        ge = x < pivot ? 0u : 1u;
-        le = pivot < x ? 0u : 1u;
-      }
-      fl[p] = static_cast<unsigned char>(ge | (le << 1));
-      gc += ge;
-      lc += le;
-    }
+    for_owned4(
+        lo, hi, [&](int p) { return U4{static_cast<unsigned>(act[p]), seg_first[p], key_of(arr[p]), 0u}; },
+        [&](int, U4 x) { return x.a ? key_of(arr[x.b]) : 0u; },
+        [&](int p, U4 x, unsigned pivot) {
+          unsigned ge = 0u, le = 0u;
+          if (x.a && x.b != static_cast<unsigned>(p)) {
+            ge = x.c < pivot ? 0u : 1u;
+            le = pivot < x.c ? 0u : 1u;
+          }
+          fl[p] = static_cast<unsigned char>(ge | (le << 1));
+          gc += ge;
+          lc += le;
+        });
     unsigned gtotal, ltotal;
     unsigned gb = block_exclusive_scan(gc, wave_sums, &gtotal);
     unsigned lb = block_exclusive_scan(lc, wave_sums, &ltotal);
-    for (int p = lo; p < hi; ++p) {
-      g[p] = gb;
-      l[p] = lb;
-      gb += fl[p] & 1u;
-      lb += fl[p] >> 1;
-    }
+    for_owned4(
+        lo, hi, [&](int p) { return static_cast<unsigned>(fl[p]); }, [](int, unsigned) { return 0; },
+        [&](int p, unsigned f, int) {
+          g[p] = gb;
+          l[p] = lb;
+          gb += f & 1u;
+          lb += f >> 1;
+        });
     if (threadIdx.x == 0) {
       g[m] = gtotal;
       l[m] = ltotal;
     }
     __syncthreads();
-    for (int p = lo; p < hi; ++p)
-      if (act[p] && seg_first[p] != static_cast<unsigned>(p)) {
-        const unsigned first = seg_first[p], last = seg_last[p];
-        if (fl[p] & 1u) tmp_l[first + 1u + (g[p] - g[first + 1u])] = static_cast<unsigned>(p);
-        if (fl[p] & 2u) tmp_r[first + 1u + (l[last] - l[p + 1])] = static_cast<unsigned>(p);
-      }
+    for_owned4(
+        lo, hi, [&](int p) { return U4{static_cast<unsigned>(act[p]) != 0u ? static_cast<unsigned>(fl[p]) : 0u, seg_first[p], seg_last[p], g[p]}; },
+        [&](int p, U4 x) { return x.a != 0u ? U4{g[x.b + 1u], l[x.c], l[p + 1], 0u} : U4{0u, 0u, 0u, 0u}; },
+        [&](int p, U4 x, U4 y) {
+          if (x.b == static_cast<unsigned>(p)) return;  // the pivot
+          if (x.a & 1u) tmp_l[x.b + 1u + (x.d - y.a)] = static_cast<unsigned>(p);
+          if (x.a & 2u) tmp_r[x.b + 1u + (y.b - y.c)] = static_cast<unsigned>(p);
+        });
     __syncthreads();
     // (c) the k-th pair swaps while the pointers have not crossed; the thread at the boundary knows the cut
-    for (int q = lo; q < hi; ++q)
-      if (act[q] && seg_first[q] != static_cast<unsigned>(q)) {
-        const unsigned first = seg_first[q], last = seg_last[q];
-        const unsigned kk = static_cast<unsigned>(q) - (first + 1u);
-        const unsigned cnt_l = g[last] - g[first + 1u], cnt_r = l[last] - l[first + 1u];
-        auto valid = [&](unsigned j) { return j < cnt_l && j < cnt_r && tmp_l[first + 1u + j] < tmp_r[first + 1u + j]; };
-        const bool v = valid(kk);
-        if (v) {
-          const unsigned il = tmp_l[q], ir = tmp_r[q];
-          const unsigned long long xl = arr[il], xr = arr[ir];
-          arr[il] = xr;
-          arr[ir] = xl;
-        }
-        int K = -1;
-        if (kk == 0u && !v) K = 0;
-        else if (v && !valid(kk + 1u)) K = static_cast<int>(kk) + 1;
-        if (K >= 0) {
-          unsigned i = 0x7fffffffu;
-          if (static_cast<unsigned>(K) < cnt_l) i = tmp_l[first + 1u + static_cast<unsigned>(K)];
-          if (K > 0) i = min(i, tmp_r[first + 1u + static_cast<unsigned>(K) - 1u]);
-          cut[first] = i;
-        }
-      }
+    for_owned4(
+        lo, hi, [&](int q) { return U4{static_cast<unsigned>(act[q]), seg_first[q], seg_last[q], 0u}; },
+        [&](int q, U4 x) {
+          if (x.a == 0u || x.b == static_cast<unsigned>(q)) return U4{0u, 0u, 0u, 0u};
+          return U4{g[x.c] - g[x.b + 1u], l[x.c] - l[x.b + 1u], tmp_l[q], tmp_r[q]};
+        },
+        [&](int q, U4 x, U4 y) {
+          if (x.a == 0u || x.b == static_cast<unsigned>(q)) return;
+          const unsigned first = x.b, kk = static_cast<unsigned>(q) - (first + 1u);
+          const unsigned cnt_l = y.a, cnt_r = y.b;
+          const bool v = kk < cnt_l && kk < cnt_r && y.c < y.d;
+          if (v) {
+            const unsigned long long xl = arr[y.c], xr = arr[y.d];
+            arr[y.c] = xr;
+            arr[y.d] = xl;
+          }
+          auto valid = [&](unsigned j) { return j < cnt_l && j < cnt_r && tmp_l[first + 1u + j] < tmp_r[first + 1u + j]; };
+          int K = -1;
+          if (kk == 0u && !v) K = 0;
+          else if (v && !valid(kk + 1u)) K = static_cast<int>(kk) + 1;
+          if (K >= 0) {
+            unsigned i = 0x7fffffffu;
+            if (static_cast<unsigned>(K) < cnt_l) i = tmp_l[first + 1u + static_cast<unsigned>(K)];
+            if (K > 0) i = min(i, tmp_r[first + 1u + static_cast<unsigned>(K) - 1u]);
+            cut[first] = i;
+          }
+        });
     __syncthreads();
     // (d) [first, cut) and [cut, last)
-    for (int p = lo; p < hi; ++p)
-      if (act[p]) {
-        const unsigned c = cut[seg_first[p]];
-        if (static_cast<unsigned>(p) < c) seg_last[p] = c;
-        else seg_first[p] = c;
-      }
+    for_owned4(
+        lo, hi, [&](int p) { return U2{static_cast<unsigned>(act[p]), seg_first[p]}; }, [&](int, U2 x) { return x.a ? cut[x.b] : 0u; },
+        [&](int p, U2 x, unsigned c) {
+          if (x.a) {
+            if (static_cast<unsigned>(p) < c) seg_last[p] = c;
+            else seg_first[p] = c;
+          }
+        });
     __syncthreads();
   }
   if (!ok) return false;
   // where the tied elements are in the arrangement
-  for (int q = lo; q < hi; ++q) {
-    const unsigned id = static_cast<unsigned>(arr[q]);
-    if (tied[id]) pos_of[id] = static_cast<unsigned>(q);
-  }
+  for_owned4(
+      lo, hi, [&](int q) { return static_cast<unsigned>(arr[q]); }, [&](int, unsigned id) { return static_cast<unsigned>(tied[id]); },
+      [&](int q, unsigned id, unsigned f) {
+        if (f) pos_of[id] = static_cast<unsigned>(q);
+      });
   __syncthreads();
   // the final insertion sort is stable: a group of equal keys ends up in arrangement order
-  for (int j = lo; j < hi; ++j) {
-    const unsigned id = sv[j];
-    unsigned dst = static_cast<unsigned>(j);
-    if (tied[id]) {
-      const unsigned key = static_cast<unsigned>(sk[j]);
-      int gs = j, ge = j + 1;
-      while (gs > 0 && static_cast<unsigned>(sk[gs - 1]) == key) --gs;
-      while (ge < m && static_cast<unsigned>(sk[ge]) == key) ++ge;
-      const unsigned mine = pos_of[id];
-      unsigned r = 0u;
-      for (int u = gs; u < ge; ++u) r += pos_of[sv[u]] < mine ? 1u : 0u;
-      dst = static_cast<unsigned>(gs) + r;
-    }
-    sorted_id[dst] = id;
-  }
+  for_owned4(
+      lo, hi, [&](int j) { return sv[j]; }, [&](int, unsigned id) { return static_cast<unsigned>(tied[id]); },
+      [&](int j, unsigned id, unsigned f) {
+        unsigned dst = static_cast<unsigned>(j);
+        if (f) {
+          const unsigned key = static_cast<unsigned>(sk[j]);
+          int gs = j, ge = j + 1;
+          while (gs > 0 && static_cast<unsigned>(sk[gs - 1]) == key) --gs;
+          while (ge < m && static_cast<unsigned>(sk[ge]) == key) ++ge;
+          const unsigned mine = pos_of[id];
+          unsigned r = 0u;
+          for (int u = gs; u < ge; ++u) r += pos_of[sv[u]] < mine ? 1u : 0u;
+          dst = static_cast<unsigned>(gs) + r;
+        }
+        sorted_id[dst] = id;
+      });
   __syncthreads();
   return true;
 }
@@ -428,10 +544,20 @@ __global__ __launch_bounds__(kThreads) void big_prepare_kernel(const float* __re
 __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __restrict__ bin_counts, int histogram_size,
                                                              float squared_jump, BigArrays A, unsigned char* __restrict__ c_bucket,
                                                              float* __restrict__ c_value, unsigned* __restrict__ flags) {
+  // dynamic LDS: the arrays of the small slices' replay (libstdcxx_sort_arrangement) for the rounds that fit; the exact
+  // sums' scratch lies over them (never in use at the same time)
+  extern __shared__ __attribute__((aligned(16))) unsigned long long big_lds[];
+  unsigned long long* lds_a = big_lds;
+  unsigned short* u16_base = reinterpret_cast<unsigned short*>(lds_a + kMaxSlice);
+  constexpr int kU16 = kMaxSlice + 8;
+  const SortScratch lds_sc{u16_base, u16_base + kU16,
+                           reinterpret_cast<unsigned char*>(u16_base + 2 * kU16) + sizeof(Queue),
+                           reinterpret_cast<Queue*>(u16_base + 2 * kU16)};
+  static_assert(sizeof(exact_sum::Scratch<2>) <= kBigLdsBytes, "the exact sums' scratch fits the replay's arrays");
+  exact_sum::Scratch<2>& es = *reinterpret_cast<exact_sum::Scratch<2>*>(big_lds);
   __shared__ unsigned wave_sums[kThreads / 64];
   __shared__ int wave_max[kThreads / 64];
   __shared__ unsigned sh4[4];
-  __shared__ exact_sum::Scratch<2> es;
   BigSlice s;
 #ifdef DLIOM_EXPERIMENTS
   constexpr int kernel_id = 1;
@@ -446,7 +572,7 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
   for (int b = 0; b < s.ordinal; ++b) sorted_at += A.valid[b];
   const unsigned long long* sk = A.key_out + sorted_at;
   const unsigned* sv = A.val_out + sorted_at;
-  if (!big_sort_order(sk, sv, A.key_in + off, A.val_in + off, m, static_cast<int>(s.count), A, off, wave_sums)) {
+  if (!big_sort_order(sk, sv, A.key_in + off, A.val_in + off, m, static_cast<int>(s.count), A, off, wave_sums, lds_a, lds_sc)) {
     if (threadIdx.x == 0) atomicOr(flags, 4u);
     return;
   }
@@ -499,10 +625,29 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
   }
   __syncthreads();
   DLIOM_BSTAMP(4);
+  // (positions i = tid, tid + 1024, ... here: the levels need no prefix over positions, and consecutive lanes on
+  // consecutive entries with eight independent loads in flight hide the latency of the dependent gathers)
   for (int d = 0; (1 << d) < 2 * m; ++d) {
-    for (int i = lo; i < hi; ++i)
-      if (mark[i]) mark[ja[i]] = 1;
-    for (int i = lo; i < hi; ++i) jb[i] = ja[ja[i]];
+    for (int i0 = static_cast<int>(threadIdx.x); i0 < m; i0 += 8 * kThreads) {
+      unsigned t[8], t2[8];
+      unsigned char mk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * kThreads;
+        t[u] = i < m ? ja[i] : static_cast<unsigned>(m);
+        mk[u] = i < m ? mark[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t2[u] = ja[t[u]];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * kThreads;
+        if (i < m) {
+          if (mk[u]) mark[t[u]] = 1;
+          jb[i] = t2[u];
+        }
+      }
+    }
     __syncthreads();
     unsigned* t = ja;
     ja = jb;
@@ -555,8 +700,15 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
 
 // dliom_diag_std_sort_order for more than kMaxSlice keys: the sorted (key, position) pairs come from the radix sort
 __global__ __launch_bounds__(kThreads) void big_sort_order_kernel(int n, BigArrays A, int* __restrict__ order, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long big_lds[];
+  unsigned long long* lds_a = big_lds;
+  unsigned short* u16_base = reinterpret_cast<unsigned short*>(lds_a + kMaxSlice);
+  constexpr int kU16 = kMaxSlice + 8;
+  const SortScratch lds_sc{u16_base, u16_base + kU16,
+                           reinterpret_cast<unsigned char*>(u16_base + 2 * kU16) + sizeof(Queue),
+                           reinterpret_cast<Queue*>(u16_base + 2 * kU16)};
   __shared__ unsigned wave_sums[kThreads / 64];
-  const bool ok = big_sort_order(A.key_out, A.val_out, A.key_in, A.val_in, n, n, A, 0u, wave_sums);
+  const bool ok = big_sort_order(A.key_out, A.val_out, A.key_in, A.val_in, n, n, A, 0u, wave_sums, lds_a, lds_sc);
   int lo, hi;
   owned_range(n, &lo, &hi);
   if (ok)

@@ -631,3 +631,24 @@ def test_big_slice_histogram_formulation_equals_the_reference_restated(tmp_path,
         put(np.zeros((0, 3)))
     out = subprocess.run([exe, path, "120"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "mismatches: 0 of 7 clouds" in out.stdout, out.stdout
+
+
+def test_wave_per_segment_replay_of_std_sort_model(tmp_path, orc):
+    """tests/cpp/wave_sort_model.cc: wave_sort_arrangement's formulation (one 64-lane wave partitions one segment with
+    ballots and lane ranks; only segments that hold two tied elements; the queue served level by level; heap sort at the
+    depth limit; a stable sort at the end) against this machine's std::sort: 3 000 arrays full of ties + the slices of a
+    cube scan and a yard scan."""
+    from dliom import synth
+    from helpers import slice_angle_arrays
+    exe = str(tmp_path / "wave_sort_model")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "wave_sort_model.cc")])
+    slices = tmp_path / "slices.txt"
+    with open(slices, "w") as f:
+        for scene in ("cube", "ground"):
+            with synth.scene(scene):
+                raw, _ = synth.scan(synth.trajectory_pose(0.4), 64, 1024)
+            for a in slice_angle_arrays(raw[orc.voxel_filter(0.15, raw)]):
+                f.write("%d\n%s\n" % (len(a), " ".join("%08x" % b for b in a.view(np.uint32))))
+    out = subprocess.run([exe, "3000", str(slices)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "mismatches: 0 of 3000" in out.stdout, out.stdout
+    assert int(re.search(r"heap sorts (\d+)", out.stdout).group(1)) >= 5, out.stdout  # the depth limit is exercised
