@@ -68,6 +68,7 @@ def parse():
                     help="5 = BASELINE config 5 (128 x 2048 returns, 5 cm voxels, 3 map scans); 2 = the headline config")
     ap.add_argument("--no-pmc", action="store_true", help="skips the rocprofv3 --pmc child runs (roofline counters)")
     ap.add_argument("--no-config5", action="store_true", help="N > 1: skips the sharded config-5 line")
+    ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skips the one-rank run of the library's RCCL entry point")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: scene + 3 matches, no timing
     a = ap.parse_args()
     if a.config == 5:
@@ -168,7 +169,15 @@ def main():
     ctx = dl.Context(local_rank)
 
     # ---------------------------------------------------------------- scene (per rank: own time offset)
-    sharded_mode = args.shard_candidates and world > 1
+    # the sharded lines go through the library's own RCCL entry point (dliom_rtcsm3d_match_sharded_rccl, an ncclComm_t of
+    # this process) when the backend is nccl -- also on ONE rank (--gpus 1 --shard-candidates: a one-rank communicator,
+    # same winner as the unsharded line); DLIOM_BENCH_BACKEND=gloo keeps the callback entry point over host collectives
+    rccl_comm = None
+    if backend == "nccl" and (world > 1 or args.shard_candidates):
+        from dliom import sharded as _sh
+        rccl_comm = _sh.RcclCommunicator(rank, world, dist)
+        assert rccl_comm.ranks_seen == world, (rccl_comm.ranks_seen, world)
+    sharded_mode = args.shard_candidates and (world > 1 or rccl_comm is not None)
     # replicas: every rank runs the SAME scan stream on its own submap copy, so that the per-GPU work
     # (N, C, evaluations) is identical and the max-over-ranks time measures scaling, not scene
     # differences; sharded: all ranks share one stream by construction
@@ -178,10 +187,14 @@ def main():
 
     rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_OPTS)
     cs = dl.CeresScanMatcher3D(ctx, CSM_OPTS)
-    shard = dl.RtcsmShard(ctx, RTCSM_OPTS, rank, world) if world > 1 else None
-    if world > 1:
-        from dliom import sharded
-        dev = coll_device
+    shard = dl.RtcsmShard(ctx, RTCSM_OPTS, rank, world) if (world > 1 or rccl_comm is not None) else None
+    from dliom import sharded
+    dev = coll_device
+
+    def sharded_rtcsm(shard_, sc_, grid_):
+        if rccl_comm is not None:  # ncclAllReduce(max, uint64, count 1) on the context's stream, inside the library
+            return shard_.match_rccl(sc_["init"], sc_["cloud"], grid_, rccl_comm.handle)
+        return sharded.sharded_match(shard_, sc_["init"], sc_["cloud"], grid_, dist=dist, device=dev)
     stage = {"rtcsm": 0.0, "ceres": 0.0, "insert": 0.0}
     evals = []
     use_shards = [sharded_mode]  # flipped for the second (config 4) line of an N > 1 replica run
@@ -191,7 +204,7 @@ def main():
         a = time.perf_counter()
         if use_shards[0]:
             # dliom_rtcsm3d_match_sharded: own rotations, own exact winner, ONE 8-byte max all-reduce (RCCL)
-            _, p1 = sharded.sharded_match(shard, sc["init"], sc["cloud"], g_hi, dist=dist, device=dev)
+            _, p1 = sharded_rtcsm(shard, sc, g_hi)
         else:
             _, p1 = rt.Match(sc["init"], sc["cloud"], g_hi)
         b = time.perf_counter()
@@ -265,6 +278,9 @@ def main():
         use_shards[0] = False
         sharded_line = {"workload": "config4: ONE scan stream, RTCSM3D search window sharded over %d ranks (one 8-byte RCCL "
                                     "max all-reduce per scan), Ceres + insertion replicated" % world,
+                        "collective": ("dliom_rtcsm3d_match_sharded_rccl (ncclAllReduce inside the library)" if rccl_comm is not None
+                                       else "dliom_rtcsm3d_match_sharded + torch.distributed callback (%s)" % backend),
+                        "ranks_seen": rccl_comm.ranks_seen if rccl_comm is not None else world,
                         "value": args.steps / float(tt.item()), "unit": "scans/s", "scaling": "strong",
                         "ms_per_step": 1e3 * float(tt.item()) / args.steps,
                         "note": "Amdahl: only the score volume (~60 % of a 1-GPU step) shards; Ceres, insertion, the "
@@ -274,7 +290,7 @@ def main():
     # is 98 % score volume -- every rank builds the same small submap and takes its share of the rotations
     config5_line = None
     if world > 1 and not sharded_mode and args.config == 2 and not args.no_config5:
-        config5_line = config5_sharded_line(args, dl, synth, ctx, rank, world, dist, coll_device, torch, sharded)
+        config5_line = config5_sharded_line(args, dl, synth, ctx, rank, world, dist, coll_device, torch, sharded, rccl_comm)
 
     extra = max(1, min(5, args.steps))
     ctx.set_profiling(1)
@@ -290,6 +306,33 @@ def main():
     st = rt.last_stats()
     n_pts = int(st.num_points)
     C = int(st.window.num_candidates)
+
+    # N = 1: the library's RCCL entry point on a one-rank communicator (ncclAllReduce really runs), so that every driver
+    # line shows it alive: same winner as the unsharded match, and what the collective costs when there is nobody to wait for
+    rccl_one_rank = None
+    if world == 1 and backend == "nccl" and not args.no_rccl_check and not sharded_mode:
+        try:
+            comm1 = sharded.RcclCommunicator(0, 1)
+            sh1 = dl.RtcsmShard(ctx, RTCSM_OPTS, 0, 1)
+            sc = scans[0]
+            s_ref, p_ref = rt.Match(sc["init"], sc["cloud"], g_hi)
+            s_got, p_got = sh1.match_rccl(sc["init"], sc["cloud"], g_hi, comm1.handle)
+            ctx.synchronize()
+            t_r = time.perf_counter()
+            for _ in range(5):
+                sh1.match_rccl(sc["init"], sc["cloud"], g_hi, comm1.handle)
+            ctx.synchronize()
+            ms_rccl = 1e3 * (time.perf_counter() - t_r) / 5
+            t_r = time.perf_counter()
+            for _ in range(5):
+                rt.Match(sc["init"], sc["cloud"], g_hi)
+            ctx.synchronize()
+            rccl_one_rank = {"entry_point": "dliom_rtcsm3d_match_sharded_rccl", "ranks_seen": comm1.ranks_seen,
+                             "same_winner": bool(np.array_equal(p_ref, p_got) and np.float32(s_ref) == np.float32(s_got)),
+                             "ms_per_match": ms_rccl, "unsharded_ms_per_match": 1e3 * (time.perf_counter() - t_r) / 5}
+            comm1.close()
+        except Exception as e:  # RCCL's bootstrap is the environment's, not the product's
+            rccl_one_rank = {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
 
     out = None
     if rank == 0:
@@ -334,6 +377,8 @@ def main():
             "kernel_ms_per_scan": breakdown,
             "roofline": roofline_block(args, pairs, k_ms, int(score_n), alg_bytes, int(st.score_kernel)),
         }
+        if rccl_one_rank is not None:
+            out["sharded_rccl_one_rank"] = rccl_one_rank
         if sharded_line is not None:
             out["sharded"] = sharded_line
         if config5_line is not None:
@@ -355,7 +400,7 @@ def main():
         dist.destroy_process_group()
 
 
-def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sharded):
+def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sharded, rccl_comm=None):
     """BASELINE config 5 with the search window sharded over the ranks (config 4's protocol): one 128 x 2048 scan
     stream, every rank scores its own rotations of the ~3e6-candidate window, one 8-byte max all-reduce per scan,
     Ceres + insertion replicated."""
@@ -368,7 +413,10 @@ def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sh
     sc = scans[0]
 
     def one():
-        _, p1 = sharded.sharded_match(shard, sc["init"], sc["cloud"], g_hi, dist=dist, device=dev)
+        if rccl_comm is not None:
+            _, p1 = shard.match_rccl(sc["init"], sc["cloud"], g_hi, rccl_comm.handle)
+        else:
+            _, p1 = sharded.sharded_match(shard, sc["init"], sc["cloud"], g_hi, dist=dist, device=dev)
         p2, _ = cs.Match(sc["init"][:3], p1, [(sc["cloud"], g_hi), (sc["cloud"], g_lo)])
         pf = p2.astype(np.float32)
         dl.insert_cloud_multi(ins, sc["cloud"], [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)])
@@ -394,6 +442,7 @@ def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sh
     g_lo.close()
     return {"workload": "config5 W-dense: ONE 128x2048 scan stream @ 5 cm, RTCSM3D window sharded over %d ranks (one 8-byte "
                         "RCCL max all-reduce per scan), Ceres + insertion replicated" % world,
+            "collective": "dliom_rtcsm3d_match_sharded_rccl" if rccl_comm is not None else "callback",
             "value": steps / float(tt.item()), "unit": "scans/s", "scaling": "strong", "steps": steps,
             "ms_per_step": 1e3 * float(tt.item()) / steps, "C": int(st.window.num_candidates), "N": int(st.num_points)}
 

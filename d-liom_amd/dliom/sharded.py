@@ -47,3 +47,44 @@ def pack_winner(score, index):
 def unpack_winner(packed):
     bits = np.uint32(packed >> 32)
     return float(bits.view(np.float32)), 0xFFFFFFFF - (packed & 0xFFFFFFFF)
+
+
+class RcclCommunicator:
+    """An ncclComm_t of this process's own for dliom_rtcsm3d_match_sharded_rccl -- the entry point INTEGRATION.md offers a
+    cartographer maintainer: RCCL through ctypes, ncclGetUniqueId on rank 0, the id handed to the other ranks through
+    torch.distributed (its store / its own collective; any side channel would do), ncclCommInitRank on the CURRENT HIP
+    device.  world == 1 needs no torch.distributed at all."""
+
+    def __init__(self, rank, world, dist=None):
+        import ctypes as C
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        self._C = C
+        self.lib = C.CDLL("librccl.so.1")
+        uid = UniqueId()
+        if rank == 0:
+            rc = self.lib.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError("ncclGetUniqueId -> %d" % rc)
+        if world > 1:
+            box = [C.string_at(C.addressof(uid), 128) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(C.addressof(uid), box[0], 128)
+        comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rc = self.lib.ncclCommInitRank(C.byref(comm), int(world), uid, int(rank))
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank -> %d" % rc)
+        self.handle = comm.value
+        n = C.c_int(0)
+        self.lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        rc = self.lib.ncclCommCount(C.c_void_p(self.handle), C.byref(n))
+        self.ranks_seen = int(n.value) if rc == 0 else -1
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ncclCommDestroy.argtypes = [self._C.c_void_p]
+            self.lib.ncclCommDestroy(self._C.c_void_p(self.handle))
+            self.handle = None

@@ -1,0 +1,47 @@
+"""A slice of the randomised differential testers of tools/ inside `pytest -m gpu`: fixed seeds,
+both scene families, device vs CPU oracle bit for bit -- so that the driver's GPU test record, not a tool log, says so."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _run(module, argv, capsys):
+    import importlib
+    from dliom import synth
+    mod = importlib.import_module("tools." + module)
+    try:
+        status = mod.main(argv)
+    finally:
+        synth.set_scene("cube")
+        synth.set_trajectory()
+    out = capsys.readouterr().out
+    assert status == 0, out
+    return out
+
+
+def test_fuzz_parity_300_cases(capsys):
+    """Insertion, score volumes, RTCSM3D matches, voxel filters, adaptive filters, CeresScanMatcher3D on random grids,
+    clouds, poses and options (tools/fuzz_parity.py)."""
+    out = _run("fuzz_parity", ["--cases", "300", "--seed", "91000", "--seconds", "240"], capsys)
+    assert "fuzz ok" in out
+
+
+def test_fuzz_fast_csm_300_cases(capsys):
+    """FastCorrelativeScanMatcher3D Match / MatchWith3DofInitial on random submaps (cube and yard scenes), pyramid depths,
+    windows and thresholds (tools/fuzz_fast_csm.py)."""
+    out = _run("fuzz_fast_csm", ["--cases", "300", "--seed", "92000", "--seconds", "240"], capsys)
+    assert "fast csm fuzz ok" in out
+
+
+def test_fuzz_round3_300_cases(capsys):
+    """ComputeHistogram (cube and yard scans incl. slices above 4096 points, crops, duplicates, returns on common rays),
+    std::sort's order of equal keys up to 30 000 keys, AddRangeData under random motion (tools/fuzz_round3.py)."""
+    out = _run("fuzz_round3", ["--cases", "300", "--seed", "93000", "--seconds", "240"], capsys)
+    assert "round-3 fuzz ok" in out

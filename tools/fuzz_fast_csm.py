@@ -15,12 +15,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=4321)
     ap.add_argument("--seconds", type=float, default=120.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     import dliom as dl
     from dliom import synth
     from helpers import build_oracle_submap, to_device_grid
@@ -36,6 +36,7 @@ def main():
         rng = np.random.RandomState(seed)
         res = float(rng.choice([0.1, 0.2, 0.3]))
         scans = int(rng.randint(2, 6))
+        synth.set_scene("ground" if rng.rand() < 0.35 else "cube")  # round 4: also the yard scene (reset at the end of the case)
         og_hi = build_oracle_submap(orc, res, num_scans=scans, beams=8, azimuths=128, max_range=30.0)
         og_lo = build_oracle_submap(orc, 0.5, num_scans=scans, beams=8, azimuths=128)
         g_hi, g_lo = to_device_grid(dl, ctx, og_hi), to_device_grid(dl, ctx, og_lo)
@@ -60,6 +61,7 @@ def main():
         if per_xy * per_xy * per_z * max_scans > 2e6:
             g_hi.close()
             g_lo.close()
+            synth.set_scene("cube")
             continue
         om = orc.FastCorrelativeScanMatcher3D(og_hi, og_lo, np.array(hists), yaws, opts)
         dm = dl.FastCorrelativeScanMatcher3D(ctx, g_hi, g_lo, np.array(hists), yaws, opts)
@@ -84,10 +86,12 @@ def main():
                         np.float32(rd["rotational_score"]) == np.float32(ro["rotational_score"]))
             if not same:
                 print("MISMATCH", what, "seed", seed, opts, rd, ro)
+                synth.set_scene("cube")
                 return 1
         dm.close()
         g_hi.close()
         g_lo.close()
+        synth.set_scene("cube")
         done += 1
     print("fast csm fuzz ok: %d cases in %.1f s" % (done, time.time() - t0))
     return 0

@@ -14,12 +14,12 @@ sys.path.insert(0, os.path.join(ROOT, "d-liom_amd"))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--seconds", type=float, default=150.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     import dliom as dl
     from dliom import synth
     from oracle import oracle as orc
