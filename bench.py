@@ -134,6 +134,12 @@ def main():
         return pmc_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)  # does not return
+    # ONE JSON line on stdout is the contract; RCCL prints a version banner on stdout when its first communicator comes
+    # up (the one-rank check at N = 1, torch's and the library's at N > 1): from here on file descriptor 1 IS stderr, and
+    # the JSON line goes to the real stdout kept aside
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -392,7 +398,8 @@ def main():
             out["parity"] = parity
             out["cpu_baseline"] = cpu_baseline(args, dl, scans[0], g_hi, g_lo, ins, C, n_pts)
     if out is not None:
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     for sc in scans:
         sc["cloud"].close()
     if dist is not None:
