@@ -86,16 +86,20 @@ struct InsertArgs {
   unsigned gsize;
   unsigned L;
   uint16_t* dense;  // write-through dense mirror of the grid (may be null), see ensure_dense()
-  int dense_stride; // cells per axis of the mirror = grid_size + 2 (one guard cell each side)
+  int dense_stride; // cells per axis of the mirror
+  int dense_off[3]; // mirror coordinate = cell index + dense_off (a windowed mirror does not hold every cell)
 };
 
-// Index into the dense mirror: every axis shifted by half + 1 (guard cell); 4 x 4 x 4 bricks of
-// 64 cells (one 128-byte cache line), bricks z-major with B = ceil(stride / 4) per axis.
-__device__ __forceinline__ size_t dense_index(int ix, int iy, int iz, int half, int stride) {
-  const unsigned x = static_cast<unsigned>(ix + half + 1), y = static_cast<unsigned>(iy + half + 1),
-                 z = static_cast<unsigned>(iz + half + 1);
+// Index into the dense mirror: mirror coordinate = cell index + off per axis (the whole-grid mirror: half + 1, one guard
+// cell); 4 x 4 x 4 bricks of 64 cells (one 128-byte cache line), bricks z-major with B = ceil(stride / 4) per axis.
+// false: the cell lies outside the mirror (a windowed mirror; the matcher never reads there).
+__device__ __forceinline__ bool dense_index(int ix, int iy, int iz, const int (&off)[3], int stride, size_t* index) {
+  const unsigned x = static_cast<unsigned>(ix + off[0]), y = static_cast<unsigned>(iy + off[1]), z = static_cast<unsigned>(iz + off[2]);
+  const unsigned S = static_cast<unsigned>(stride);
+  if (x >= S || y >= S || z >= S) return false;
   const size_t B = static_cast<size_t>((stride + 3) >> 2);
-  return (((z >> 2) * B + (y >> 2)) * B + (x >> 2)) * 64 + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
+  *index = (((z >> 2) * B + (y >> 2)) * B + (x >> 2)) * 64 + (((z & 3u) << 4) | ((y & 3u) << 2) | (x & 3u));
+  return true;
 }
 
 // range_data_inserter_3d.cc:36-50: the k-th sample on the ray origin->hit in
@@ -176,8 +180,10 @@ __global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ t
       if (MODE == 0) {
         const uint32_t nv = apply_table(pool32, vi, lut);
         // each cell is written at most once per Insert: the mirror takes the final value
-        if (nv != 0u && a.dense != nullptr)
-          a.dense[dense_index(hx, hy, hz, a.half, a.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
+        if (nv != 0u && a.dense != nullptr) {
+            size_t di;
+            if (dense_index(hx, hy, hz, a.dense_off, a.dense_stride, &di)) a.dense[di] = static_cast<uint16_t>(nv & 0x7FFFu);
+          }
       } else {
         clear_marker(pool32, vi);
       }
@@ -195,8 +201,10 @@ __global__ void insert_apply_kernel(InsertArgs a, const uint32_t* __restrict__ t
       const size_t vi = static_cast<size_t>(table[tidx]) * 512u + cell;
       if (MODE == 1) {
         const uint32_t nv = apply_table(pool32, vi, lut);
-        if (nv != 0u && a.dense != nullptr)
-          a.dense[dense_index(mx, my, mz, a.half, a.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
+        if (nv != 0u && a.dense != nullptr) {
+            size_t di;
+            if (dense_index(mx, my, mz, a.dense_off, a.dense_stride, &di)) a.dense[di] = static_cast<uint16_t>(nv & 0x7FFFu);
+          }
       } else {
         clear_marker(pool32, vi);
       }
@@ -217,13 +225,17 @@ __global__ void rebuild_table_kernel(const int32_t* __restrict__ slot_coord, uin
 }
 
 // Dense mirror (re)build: one workgroup per allocated leaf copies its 512 cells.
+struct DenseOff {
+  int v[3];
+};
 __global__ void dense_fill_kernel(const int32_t* __restrict__ slot_coord, const uint16_t* __restrict__ pool,
-                                  uint16_t* __restrict__ dense, int half, int stride) {
+                                  uint16_t* __restrict__ dense, DenseOff off, int stride) {
   const size_t s = static_cast<size_t>(blockIdx.x) + 1;  // slot 0 is the null leaf
   const int bx = slot_coord[3 * s] * 8, by = slot_coord[3 * s + 1] * 8, bz = slot_coord[3 * s + 2] * 8;
   for (int c = threadIdx.x; c < 512; c += blockDim.x) {
     const uint16_t v = pool[s * 512 + c] & 0x7FFFu;
-    dense[dense_index(bx + (c & 7), by + ((c >> 3) & 7), bz + (c >> 6), half, stride)] = v > 0 ? v : 1;
+    size_t di;
+    if (dense_index(bx + (c & 7), by + ((c >> 3) & 7), bz + (c >> 6), off.v, stride, &di)) dense[di] = v > 0 ? v : 1;
   }
 }
 
@@ -335,6 +347,7 @@ struct InsertTarget {
   uint32_t* pool32;
   uint16_t* dense;
   int dense_stride;
+  int dense_off[3];
 };
 struct MultiInsertArgs {
   InsertTarget tg[kMaxInsertTargets];
@@ -442,8 +455,10 @@ __global__ void multi_insert_kernel(MultiInsertArgs a) {
       const size_t vi = static_cast<size_t>(tg.table[tidx]) * 512u + cell;
       if (PASS == 2) {
         const uint32_t nv = apply_table(tg.pool32, vi, a.hit);
-        if (nv != 0u && tg.dense != nullptr)
-          tg.dense[dense_index(hx, hy, hz, tg.half, tg.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
+        if (nv != 0u && tg.dense != nullptr) {
+            size_t di;
+            if (dense_index(hx, hy, hz, tg.dense_off, tg.dense_stride, &di)) tg.dense[di] = static_cast<uint16_t>(nv & 0x7FFFu);
+          }
       } else {
         clear_marker(tg.pool32, vi);
       }
@@ -457,8 +472,10 @@ __global__ void multi_insert_kernel(MultiInsertArgs a) {
       const size_t vi = static_cast<size_t>(tg.table[tidx]) * 512u + cell;
       if (PASS == 3) {
         const uint32_t nv = apply_table(tg.pool32, vi, a.miss);
-        if (nv != 0u && tg.dense != nullptr)
-          tg.dense[dense_index(mx, my, mz, tg.half, tg.dense_stride)] = static_cast<uint16_t>(nv & 0x7FFFu);
+        if (nv != 0u && tg.dense != nullptr) {
+            size_t di;
+            if (dense_index(mx, my, mz, tg.dense_off, tg.dense_stride, &di)) tg.dense[di] = static_cast<uint16_t>(nv & 0x7FFFu);
+          }
       } else {
         clear_marker(tg.pool32, vi);
       }
@@ -487,6 +504,7 @@ GridView dliom_grid::view() const {
   v.dense = d_dense;
   v.dense_stride = dense_stride;
   v.dense_bricks = dense_bricks;
+  for (int a = 0; a < 3; ++a) v.dense_off[a] = dense_off[a];
   return v;
 }
 
@@ -535,6 +553,7 @@ void dliom_grid::drop_dense() {
   d_dense = nullptr;
   dense_stride = 0;
   dense_bricks = 0;
+  dense_windowed = false;
 }
 
 // Dense mirror of the grid for the correlative matcher: (grid_size + 2)^3 uint16 in 4x4x4 bricks
@@ -544,24 +563,59 @@ void dliom_grid::drop_dense() {
 // bits = 3, 2.0 GiB at bits = 4) to make a voxel lookup ONE load at a linear address instead of
 // leaf-table load + leaf load; kept in sync by the insertion kernels (write-through) and rebuilt
 // from the leaf pool after uploads or growth.  Grids beyond bits = 4 stay on the leaf path.
-int dliom_grid::ensure_dense() {
-  if (d_dense != nullptr) return DLIOM_OK;
-  if (bits > kMaxDenseBits) return DLIOM_ERR_GRID_EXTENT;
-  const int stride = (64 << bits) + 2;
+static int build_mirror(dliom_grid* g, const int off[3], int stride, bool windowed) {
   const size_t bricks = static_cast<size_t>((stride + 3) >> 2);
   const size_t cells = bricks * bricks * bricks * 64;
-  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_dense), cells * sizeof(uint16_t)));
-  DLIOM_HIP_TRY(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(d_dense), 1, cells, ctx->stream));
+  if (g->d_dense != nullptr) g->drop_dense();
+  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->d_dense), cells * sizeof(uint16_t)));
+  DLIOM_HIP_TRY(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(g->d_dense), 1, cells, g->ctx->stream));
   int64_t count = 0;
-  DLIOM_TRY(refresh_count(&count));
+  DLIOM_TRY(g->refresh_count(&count));
+  DenseOff o{{off[0], off[1], off[2]}};
   if (count > 1) {
-    hipLaunchKernelGGL(dense_fill_kernel, dim3(static_cast<unsigned>(count - 1)), dim3(256), 0, ctx->stream,
-                       d_slot_coord, d_pool, d_dense, 32 << bits, stride);
+    hipLaunchKernelGGL(dense_fill_kernel, dim3(static_cast<unsigned>(count - 1)), dim3(256), 0, g->ctx->stream,
+                       g->d_slot_coord, g->d_pool, g->d_dense, o, stride);
     DLIOM_HIP_TRY(hipGetLastError());
   }
-  dense_stride = stride;
-  dense_bricks = static_cast<int>(bricks);
+  g->dense_stride = stride;
+  g->dense_bricks = static_cast<int>(bricks);
+  for (int a = 0; a < 3; ++a) g->dense_off[a] = off[a];
+  g->dense_windowed = windowed;
   return DLIOM_OK;
+}
+
+int dliom_grid::ensure_dense() {
+  if (d_dense != nullptr && !dense_windowed) return DLIOM_OK;
+  if (bits > kMaxDenseBits) return DLIOM_ERR_GRID_EXTENT;
+  const int h1 = (32 << bits) + 1;
+  const int off[3] = {h1, h1, h1};
+  return build_mirror(this, off, (64 << bits) + 2, false);
+}
+
+// Grids beyond bits = 4 (a 10 cm grid with more than 51 m of extent: every outdoor submap whose high-resolution range
+// is not cut at 20 m) cannot be mirrored whole -- 17.6 GB at bits = 5, and the LDS-box kernel addresses the mirror with
+// 32-bit byte offsets.  The matcher only ever reads within (farthest point + search window) of its initial pose:
+// a WINDOW of the grid around that pose is mirrored instead, at most 1264 cells a side (4.04 GB).  The insertion kernels
+// write through to the cells that lie inside it; the window is kept while the next match still fits and rebuilt around
+// the new pose, with a margin of 48 cells, when it does not (memset + one pass over the leaves: about a millisecond per
+// gigabyte, once every few metres of travel).
+int dliom_grid::ensure_dense_for(const int centre[3], int radius_cells) {
+  if (bits <= kMaxDenseBits) return ensure_dense();
+  constexpr int kMaxSide = 1264, kMargin = 48;
+  if (radius_cells < 1 || 2 * (radius_cells + 2) + 4 > kMaxSide) return DLIOM_ERR_GRID_EXTENT;
+  if (d_dense != nullptr && dense_windowed) {
+    bool inside = true;
+    for (int a = 0; a < 3; ++a) {
+      const int lo = centre[a] - radius_cells + dense_off[a], hi = centre[a] + radius_cells + dense_off[a];
+      inside = inside && lo >= 1 && hi <= dense_stride - 2;  // one guard cell per side, like the whole-grid mirror
+    }
+    if (inside) return DLIOM_OK;
+  }
+  const int r = std::min(radius_cells + kMargin, (kMaxSide - 8) / 2);
+  const int stride = (2 * r + 2 + 3) & ~3;
+  int off[3];
+  for (int a = 0; a < 3; ++a) off[a] = -(centre[a] - r) + 1;  // cell centre - r -> mirror coordinate 1
+  return build_mirror(this, off, stride, true);
 }
 
 int dliom_grid::ensure_capacity(int64_t additional_slots) {
@@ -853,6 +907,7 @@ static int insert_device(dliom_grid* g, const float origin[3], const float* d_re
   a.L = static_cast<unsigned>(v.leaves_per_axis);
   a.dense = g->d_dense;  // write-through when the mirror exists
   a.dense_stride = g->dense_stride;
+  for (int k = 0; k < 3; ++k) a.dense_off[k] = g->dense_off[k];
   uint32_t* pool32 = reinterpret_cast<uint32_t*>(g->d_pool);
   hipLaunchKernelGGL(insert_alloc_kernel, grid, block, 0, ctx->stream, a, g->d_table, g->d_slot_coord,
                      g->d_count);
@@ -998,6 +1053,7 @@ static void refresh_target(InsertTarget* tg, dliom_grid* g) {
   tg->pool32 = reinterpret_cast<uint32_t*>(g->d_pool);
   tg->dense = g->d_dense;
   tg->dense_stride = g->dense_stride;
+  for (int k = 0; k < 3; ++k) tg->dense_off[k] = g->dense_off[k];
 }
 
 int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets, dliom_grid* const* grids,

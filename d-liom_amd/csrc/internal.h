@@ -63,9 +63,10 @@ struct GridView {
   float resolution;
   float inv_resolution;   // fl(1 / resolution): fast path of the score kernel only
   int log2_leaves;        // log2(leaves_per_axis) = bits + 3
-  const uint16_t* dense;  // dense mirror (grid_size + 2)^3, null when absent
-  int dense_stride;       // S = grid_size + 2 cells per axis
+  const uint16_t* dense;  // dense mirror, S^3 cells, null when absent
+  int dense_stride;       // S: grid_size + 2 cells per axis (whole grid), or the side of the window (bits >= 5)
   int dense_bricks;       // B = ceil(S / 4): the mirror is B^3 bricks of 4x4x4 cells (128 B)
+  int dense_off[3];       // mirror coordinate = cell index + dense_off (whole grid: half + 1 on every axis)
 };
 
 }  // namespace dliom
@@ -148,7 +149,12 @@ struct dliom_grid {
   uint16_t* d_dense = nullptr;  // optional dense mirror for the correlative matcher (grid.hip)
   int dense_stride = 0;
   int dense_bricks = 0;
-  int ensure_dense();
+  int dense_off[3] = {0, 0, 0};  // mirror coordinate = cell index + dense_off
+  bool dense_windowed = false;   // the mirror covers a cube around a match's initial pose, not the whole grid (bits >= 5)
+  int ensure_dense();            // the whole grid (bits <= 4), else DLIOM_ERR_GRID_EXTENT
+  // the whole grid if it is small enough, else a window that holds the cells [centre - radius, centre + radius] on every
+  // axis (kept while the next request still fits; rebuilt around the new centre with a margin otherwise)
+  int ensure_dense_for(const int centre[3], int radius_cells);
   void drop_dense();
   dliom::GridView view() const;
   int ensure_bits(int needed_bits);

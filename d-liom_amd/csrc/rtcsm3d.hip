@@ -1436,12 +1436,22 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
   }
   ctx->last_score_used_box = false;
   if (mapping >= 2) {
-    // the mirror is a cache of the grid's contents: building it does not change the grid
-    if (const_cast<dliom_grid*>(grid)->ensure_dense() != DLIOM_OK) {
+    // the mirror is a cache of the grid's contents: building it does not change the grid.  Grids beyond bits = 4 get a
+    // WINDOW around this match's initial pose that holds every cell the search can read: a rotated point lies within
+    // max ||p|| of the candidate's translation, and that within (L + 1) res sqrt(3) of the initial one
+    const float res = grid->resolution;
+    const int centre[3] = {static_cast<int>(std::lround(c.init.t.x / res)), static_cast<int>(std::lround(c.init.t.y / res)),
+                           static_cast<int>(std::lround(c.init.t.z / res))};
+    const double reach_cells = static_cast<double>(cloud.max_norm) / res + (c.w.linear_window_size + 1) * 1.7321 + 4.0;
+    const int radius = reach_cells < 1.0e6 ? static_cast<int>(std::ceil(reach_cells)) : (1 << 20);
+    if (const_cast<dliom_grid*>(grid)->ensure_dense_for(centre, radius) != DLIOM_OK) {
       if (mapping == 3) ctx->last_box_refusal = DLIOM_BOX_REFUSED_NO_MIRROR;
       mapping = 1;  // too large: leaf path
     }
   }
+  // a windowed mirror has its own offset per axis: only the box kernel reads it, everything else takes the leaf table
+  const bool windowed = grid->dense_windowed;
+  if (windowed && mapping == 2) mapping = 1;
   const GridView g = grid->view();
   DLIOM_TRY(ensure_morton(ctx, &cloud));
   if (g.log2_leaves > 10 && mapping >= 1) {  // bits = 8: only the point-per-lane kernel has 64-bit table indices
@@ -1474,7 +1484,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
       return DLIOM_OK;
     }
     if (s3 != DLIOM_ERR_CAPACITY) return s3;
-    mapping = 2;
+    mapping = windowed ? 1 : 2;
   }
   static const int forced_ppt = env_int("DLIOM_SCORE_PPT", 0);   // tuning knobs
   static const int target_blocks = env_int("DLIOM_SCORE_BLOCKS", 8192);

@@ -207,7 +207,7 @@ struct Geometry {   // wave-uniform description of the current box
 // value the matcher sums at reference cell (ix, iy, iz), straight from the mirror in HBM (outside: 1)
 __device__ __forceinline__ unsigned mirror_value(const GridView& g, int ix, int iy, int iz) {
   const int S = g.dense_stride, B = g.dense_bricks;
-  const int mx = ix + g.half + 1, my = iy + g.half + 1, mz = iz + g.half + 1;
+  const int mx = ix + g.dense_off[0], my = iy + g.dense_off[1], mz = iz + g.dense_off[2];
   if (mx < 0 || mx >= S || my < 0 || my >= S || mz < 0 || mz >= S) return 1u;
   return g.dense[((static_cast<size_t>(mz >> 2) * B + (my >> 2)) * B + (mx >> 2)) * 64u +
                  static_cast<size_t>(((mz & 3) << 4) | ((my & 3) << 2) | (mx & 3))];
@@ -707,10 +707,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
               geo.lo[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(l)));
               geo.dim[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(h))) - geo.lo[a] + 1;
             }
-            {  // x: whole 4-cell groups of the bricked mirror (mirror coordinate = index + half + 1)
-              const int m_lo = (geo.lo[0] + g.half + 1) & ~3;
-              const int m_hi = geo.lo[0] + g.half + 1 + geo.dim[0];  // exclusive
-              geo.lo[0] = m_lo - g.half - 1;
+            {  // x: whole 4-cell groups of the bricked mirror (mirror coordinate = index + dense_off)
+              const int m_lo = (geo.lo[0] + g.dense_off[0]) & ~3;
+              const int m_hi = geo.lo[0] + g.dense_off[0] + geo.dim[0];  // exclusive
+              geo.lo[0] = m_lo - g.dense_off[0];
               geo.dim[0] = ((m_hi - m_lo) + 3) & ~3;
             }
             geo.sx = static_cast<unsigned>(geo.dim[0]);
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
             const unsigned quads = static_cast<unsigned>(geo.dim[0]) >> 2, dim1 = static_cast<unsigned>(geo.dim[1]);
             const unsigned total = __umul24(__umul24(quads, dim1), static_cast<unsigned>(geo.dim[2]));
             const float inv_q = 1.0f / static_cast<float>(quads), inv_dy = 1.0f / static_cast<float>(dim1);
-            const int bx0 = geo.lo[0] + g.half + 1, by0 = geo.lo[1] + g.half + 1, bz0 = geo.lo[2] + g.half + 1;
+            const int bx0 = geo.lo[0] + g.dense_off[0], by0 = geo.lo[1] + g.dense_off[1], bz0 = geo.lo[2] + g.dense_off[2];
             const unsigned uB = static_cast<unsigned>(B), uBB = __umul24(uB, uB), uS = static_cast<unsigned>(S);
             const char* dense_bytes = reinterpret_cast<const char*>(g.dense);
 #pragma unroll 4
