@@ -299,7 +299,9 @@ def test_windowed_mirror_runs_the_box_kernel_on_large_grids(dl, ctx, orc, case):
             ins.InsertCloud(grid, cloud, poses=[pose.astype(np.float32)])  # no range cut: the grid reaches 80 m
             cloud.close()
         scans = []
-        for t in (1.0, 1.6, 9.0):  # 4 m/s: 2.4 m on, then 30 m on
+        # 4 m/s: 2.4 m on, then far enough for a new window (the box kernel itself refuses lookups beyond ~880 cells of
+        # the grid's origin -- its scaled coordinates must stay below 1024 --, 44 m at 5 cm: the third pose respects that)
+        for t in (1.0, 1.6, 9.0 if case == "bits5_10cm" else 3.0):
             truth = synth.trajectory_pose(t)
             pts, _ = synth.scan(truth, 32, 512)
             pts = pts[np.linalg.norm(pts.astype(np.float64), axis=1) <= cut]
@@ -326,9 +328,31 @@ def test_windowed_mirror_runs_the_box_kernel_on_large_grids(dl, ctx, orc, case):
         ctx.set_tuning(dl.TUNE_SCORE_KERNEL, 1)  # the rotation-per-lane kernel over the leaf table
         try:
             leaf = rt.score_volume(init, pts, grid)
+            score1, pose1 = rt.Match(init, pts, grid)
             assert rt.last_stats().score_kernel == 1
+            assert np.float32(score1).tobytes() == np.float32(score).tobytes() and np.array_equal(pose1, pose)
         finally:
             ctx.set_tuning(dl.TUNE_SCORE_KERNEL, 3)
         assert np.array_equal(got, leaf), (k, int((got != leaf).sum()))
         assert rt.box_error() == 0
+    # what the window buys (the matched scan resident; the first box match of a pose may build the window)
+    import sys
+    import time
+    truth, pts, init = scans[0]
+    cloud = dl.PointCloud(ctx, pts)
+    times = {}
+    for kernel in (3, 1):
+        ctx.set_tuning(dl.TUNE_SCORE_KERNEL, kernel)
+        rt.Match(init, cloud, grid)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            rt.Match(init, cloud, grid)
+        ctx.synchronize()
+        times[kernel] = (time.perf_counter() - t0) / 5
+    ctx.set_tuning(dl.TUNE_SCORE_KERNEL, 3)
+    sys.stderr.write("windowed mirror %s: RTCSM3D match %.3f ms on the box kernel, %.3f ms on the leaf-table kernel (C = %d, N = %d)\n" %
+                     (case, 1e3 * times[3], 1e3 * times[1], rt.last_stats().window.num_candidates, len(pts)))
+    assert times[3] < times[1]
+    cloud.close()
     grid.close()
