@@ -10,7 +10,7 @@ p = (sin 4t, 1 - cos 4t, t), rotation 0.3 t about (1,-1,2)/sqrt(6).
 
 Second scene family (round 4, VERDICT r3: "a world with a floor"): `with scene("ground"):` switches every function of
 this module to an outdoor yard -- a ground plane 1.8 m below the sensor's start height, a 120 m x 90 m walled yard
-(walls 12 m high, open sky above), 40 axis-aligned boxes (cars to buildings) and 12 spheres, scanned with elevations
+(walls 12 m high, open sky above), 40 axis-aligned boxes (cars to buildings), 90 posts and low walls near the path and 12 spheres, scanned with elevations
 -25..+15 degrees and a 100 m range limit.  Rays into the sky or past the range limit do NOT return: a scan has fewer
 points than beams x azimuths (ragged), the floor puts > 15 000 returns of a 64 x 1024 scan into one 0.2 m height slice,
 and returns reach 60-100 m (HybridGrid bits 5 at 10 cm).  The default trajectory there is a level arc
@@ -77,6 +77,21 @@ def ground_boxes(seed=43):
         h = rng.uniform(1.4, 8.0)
         if np.hypot(c[0], c[1] - 10.0) < 16.0 + 0.5 * np.hypot(*size) and np.hypot(c[0], c[1] - 10.0) > 4.0 - 0.5 * np.hypot(*size):
             continue  # the arc of radius 10 around (0, 10) +- 6 m stays free
+        lo.append([c[0] - 0.5 * size[0], c[1] - 0.5 * size[1], GROUND_Z])
+        hi.append([c[0] + 0.5 * size[0], c[1] + 0.5 * size[1], GROUND_Z + h])
+    # ... and 90 posts, bollards and low walls 2.5 - 14 m from the arc: what a street offers the matchers within the 15 - 20 m
+    # of the high-resolution filters (a bare floor does not constrain x and y: the correlative matcher then picks the first
+    # of many equal scores and the chain drifts by its window per scan -- the reference's behaviour, not a useful benchmark)
+    while len(lo) < 130:
+        ang = rng.uniform(0, 2 * np.pi)
+        rad = 10.0 + rng.choice([-1.0, 1.0]) * rng.uniform(2.5, 14.0)
+        if rad < 0.5:
+            continue
+        c = np.array([rad * np.sin(ang), 10.0 - rad * np.cos(ang)])
+        if np.any(np.abs(c) > YARD_HALF - 2.0):
+            continue
+        size = rng.uniform(0.25, 0.7, 2) if rng.rand() < 0.7 else np.array([rng.uniform(1.5, 4.0), 0.3])[::rng.choice([1, -1])]
+        h = rng.uniform(0.8, 4.0)
         lo.append([c[0] - 0.5 * size[0], c[1] - 0.5 * size[1], GROUND_Z])
         hi.append([c[0] + 0.5 * size[0], c[1] + 0.5 * size[1], GROUND_Z + h])
     return np.array(lo), np.array(hi)

@@ -433,6 +433,34 @@ def rtcsm3d_match_range(opts, init7, pts, grid, first, count):
     return s, best.value
 
 
+class FlatGridIndex:
+    """orc_flat_grid_new: the flat leaf table of BASELINE.md section 2's "fair-CPU" variant, built once per grid state."""
+
+    def __init__(self, grid):
+        self._L = lib()
+        self._L.orc_flat_grid_new.restype = C.c_void_p
+        self.grid = grid
+        self.h = C.c_void_p(self._L.orc_flat_grid_new(grid.h))
+
+    def __del__(self):
+        try:
+            self._L.orc_flat_grid_free(self.h)
+        except Exception:
+            pass
+
+
+def rtcsm3d_match_range_fair(opts, init7, pts, flat, first, count):
+    """The reference's Match loop on candidates [first, first + count) in the fair-CPU variant (flat leaf table, no
+    per-candidate allocation; same arithmetic, hence the same scores).  Returns (best score of the range, its index)."""
+    pts = _f32(pts).reshape(-1, 3)
+    best = C.c_int64(-1)
+    L = lib()
+    L.orc_rtcsm3d_match_range_fair.restype = C.c_float
+    s = L.orc_rtcsm3d_match_range_fair(_p(_opts4(opts), _f64p), _p(_f64(init7), _f64p), _p(pts, _f32p), len(pts), flat.grid.h,
+                                       flat.h, C.c_int64(first), C.c_int64(count), C.byref(best))
+    return s, best.value
+
+
 def _ranges(total, parts):
     step = (total + parts - 1) // parts
     return [(f, min(step, total - f)) for f in range(0, total, step)]
@@ -642,6 +670,10 @@ class FrontEnd:
             self._L.orc_front_end_free(self.h)
         except Exception:
             pass
+
+    def set_threads(self, threads):
+        """The RTCSM3D candidate loop on `threads` host threads (a CPU baseline variant: the reference's loop is serial)."""
+        self._L.orc_front_end_set_threads(self.h, int(threads))
 
     def match(self, pose_prediction, origin, returns):
         returns = _f32(returns).reshape(-1, 3)

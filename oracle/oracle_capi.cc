@@ -340,6 +340,66 @@ float orc_rtcsm3d_match_range(const double* opts, const double* init7, const flo
   if (best_index != nullptr) *best_index = best_c;
   return best;
 }
+// BASELINE.md section 2, variant (ii) "fair-CPU": the same arithmetic as orc_rtcsm3d_match_range -- Rigid3f * point, true
+// division + lround for the cell, the LUT probability, the sequential float sum, first strictly greater score -- but a
+// FLAT leaf table instead of the two pointer levels (orc_flat_grid_new, built once per grid like an index a CPU
+// implementation would maintain beside the tree) and no TransformPointCloud allocation per candidate.
+struct FlatGridView {
+  float resolution;
+  int half, leaves;  // voxel shift, leaves per axis
+  std::vector<const uint16*> table;
+};
+void* orc_flat_grid_new(void* grid) {
+  const HybridGrid& g = *G(grid);
+  FlatGridView* f = new FlatGridView;
+  f->resolution = g.resolution();
+  f->half = g.grid_size() >> 1;
+  f->leaves = g.grid_size() >> 3;
+  f->table.assign(static_cast<size_t>(f->leaves) * f->leaves * f->leaves, nullptr);
+  g.ForEachLeaf([&](const Vec3i& origin, const uint16* cells) {
+    const int lx = (origin.x + f->half) >> 3, ly = (origin.y + f->half) >> 3, lz = (origin.z + f->half) >> 3;
+    f->table[(static_cast<size_t>(lz) * f->leaves + ly) * f->leaves + lx] = cells;
+  });
+  return f;
+}
+void orc_flat_grid_free(void* flat) { delete static_cast<FlatGridView*>(flat); }
+float orc_rtcsm3d_match_range_fair(const double* opts, const double* init7, const float* pts, int n, void* grid, void* flat,
+                                   int64_t first, int64_t count, int64_t* best_index) {
+  const RealTimeCorrelativeScanMatcherOptions o{opts[0], opts[1], opts[2], opts[3]};
+  const RealTimeCorrelativeScanMatcher3D m(o);
+  const PointCloud cloud = ToCloud(pts, n);
+  const HybridGrid& g = *G(grid);
+  const FlatGridView& f = *static_cast<FlatGridView*>(flat);
+  const std::vector<Rigid3f> ts = m.GenerateExhaustiveSearchTransforms(g.resolution(), cloud);
+  const Rigid3f init = ToRigid(init7).cast<float>();
+  const int64_t end = std::min<int64_t>(first + count, static_cast<int64_t>(ts.size()));
+  const unsigned gsize = static_cast<unsigned>(2 * f.half);
+  float best = -1.f;
+  int64_t best_c = -1;
+  for (int64_t c = first; c < end; ++c) {
+    const Rigid3f candidate = init * ts[c];
+    float score = 0.f;
+    for (const Vec3f& p : cloud) {
+      const Vec3i i = g.GetCellIndex(candidate * p);
+      const unsigned sx = static_cast<unsigned>(i.x + f.half), sy = static_cast<unsigned>(i.y + f.half), sz = static_cast<unsigned>(i.z + f.half);
+      uint16 v = 0;
+      if (sx < gsize && sy < gsize && sz < gsize) {
+        const uint16* leaf = f.table[(static_cast<size_t>(sz >> 3) * f.leaves + (sy >> 3)) * f.leaves + (sx >> 3)];
+        if (leaf != nullptr) v = leaf[((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u)];
+      }
+      score += ValueToProbability(v);
+    }
+    score /= static_cast<float>(cloud.size());
+    const float angle = GetAngle(ts[c]);
+    score *= std::exp(-Pow2(ts[c].translation.norm() * o.translation_delta_cost_weight + angle * o.rotation_delta_cost_weight));
+    if (score > best) {
+      best = score;
+      best_c = c;
+    }
+  }
+  if (best_index != nullptr) *best_index = best_c;
+  return best;
+}
 // Per candidate: sum over points of max(value & 0x7fff, 1) (exact integers),
 // the order-independent quantity the HIP score-volume kernel accumulates.
 // Candidates [first, first+count) only (count<0: all).
@@ -497,6 +557,7 @@ void* orc_front_end_new(const double* o) {
   return new FrontEnd(f);
 }
 void orc_front_end_free(void* fe) { delete static_cast<FrontEnd*>(fe); }
+void orc_front_end_set_threads(void* fe, int threads) { static_cast<FrontEnd*>(fe)->rtcsm_threads = threads; }
 // out[0] dropped, out[1..7] pose_estimate, out[8..14] observation, out[15..21] initial ceres pose,
 // out[22] rtcsm score, out[23] final cost, out[24] iterations, out[25] n_hi, out[26] n_lo
 void orc_front_end_match(void* fe, const double* pose_prediction7, const float* origin3, const float* returns,

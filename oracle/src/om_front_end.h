@@ -168,8 +168,10 @@ class FrontEnd {
     }
     if (options_.use_online_correlative_scan_matching) {
       const Rigid3d initial_pose = initial_ceres_pose;
-      r.rtcsm_score = rtcsm_.Match(initial_pose, hi, matching_submap->high_resolution_hybrid_grid(),
-                                   &initial_ceres_pose);
+      r.rtcsm_score = rtcsm_threads > 1
+                          ? rtcsm_.MatchThreaded(initial_pose, hi, matching_submap->high_resolution_hybrid_grid(),
+                                                 &initial_ceres_pose, rtcsm_threads)
+                          : rtcsm_.Match(initial_pose, hi, matching_submap->high_resolution_hybrid_grid(), &initial_ceres_pose);
     }
     const PointCloud lo = AdaptiveVoxelFilter(options_.low_resolution_adaptive_voxel_filter,
                                               filtered_range_data_in_tracking.returns);
@@ -201,6 +203,9 @@ class FrontEnd {
   ActiveSubmaps3D active_submaps_;
   MotionFilter motion_filter_;
   RealTimeCorrelativeScanMatcher3D rtcsm_;
+ public:
+  int rtcsm_threads = 1;  // > 1: the candidate loop on this many threads (a CPU baseline variant)
+ private:
   CeresScanMatcher3D csm_;
   RangeData range_data_;
 };

@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "om_sensor.h"
@@ -118,6 +119,43 @@ class RealTimeCorrelativeScanMatcher3D {
       ++index;
     }
     return best_score;
+  }
+
+  // BASELINE.md section 2, "8 threads": the same loop with the candidates cut into contiguous ranges, one per thread; a
+  // range keeps its first strictly greater score and the ranges are combined in generation order with the same strict
+  // `>`, so the winner is the serial loop's.  Not what the reference does (its loop is serial): a CPU baseline variant.
+  float MatchThreaded(const Rigid3d& initial_pose_estimate, const PointCloud& cloud, const HybridGrid& grid,
+                      Rigid3d* pose_estimate, int num_threads) const {
+    const std::vector<Rigid3f> ts = GenerateExhaustiveSearchTransforms(grid.resolution(), cloud);
+    const Rigid3f init = initial_pose_estimate.cast<float>();
+    const int n = static_cast<int>(ts.size());
+    const int parts = std::max(1, std::min(num_threads, n));
+    std::vector<float> best(static_cast<size_t>(parts), -1.f);
+    std::vector<int> best_c(static_cast<size_t>(parts), -1);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < parts; ++t)
+      pool.emplace_back([&, t] {
+        const int lo = static_cast<int>(static_cast<long long>(n) * t / parts);
+        const int hi = static_cast<int>(static_cast<long long>(n) * (t + 1) / parts);
+        for (int c = lo; c < hi; ++c) {
+          const Rigid3f candidate = init * ts[c];
+          const float score = ScoreCandidate(grid, TransformPointCloud(cloud, candidate), ts[c]);
+          if (score > best[t]) {
+            best[t] = score;
+            best_c[t] = c;
+          }
+        }
+      });
+    for (std::thread& th : pool) th.join();
+    float s = -1.f;
+    int at = -1;
+    for (int t = 0; t < parts; ++t)
+      if (best[t] > s) {
+        s = best[t];
+        at = best_c[t];
+      }
+    if (at >= 0) *pose_estimate = (init * ts[at]).cast<double>();
+    return s;
   }
 
  private:

@@ -60,7 +60,17 @@ def option_sets():
     }
 
 
+_STREAMS = {}
+
+
 def make_stream(synth, scans, beams, azimuths):
+    key = (synth.SCENE["name"], tuple(sorted((k, str(v)) for k, v in synth.TRAJ.items())), scans, beams, azimuths)
+    if key not in _STREAMS:  # ray casting the yard's 140 boxes costs a second per scan: both option sets share a stream
+        _STREAMS[key] = _make_stream(synth, scans, beams, azimuths)
+    return _STREAMS[key]
+
+
+def _make_stream(synth, scans, beams, azimuths):
     T = 0.1
     centers = synth.bubbles()
     clouds = [synth.moving_scan(T * k, beams, azimuths, centers) for k in range(1, scans + 1)]
@@ -68,11 +78,13 @@ def make_stream(synth, scans, beams, azimuths):
     return T, clouds, imus, synth.trajectory_state(0.0)
 
 
-def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, histogram_size=120):
+def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, histogram_size=120, cpu_threads=1):
     """One pass over the stream; returns (per-scan stage seconds [n x 6], poses [n x 7], histograms, gravity factors)."""
     window = dl.ImuWindow(acc_noise=NOISE[0], gyr_noise=NOISE[1], acc_bias_noise=NOISE[2], gyr_bias_noise=NOISE[3], **cfg["window"])
     window.initialize(state0[:7], state0[7:10], np.zeros(6))
     fe = dl.LocalTrajectoryBuilder3D(ctx, cfg["front_end"]) if device else orc.FrontEnd(cfg["front_end"])
+    if not device and cpu_threads > 1:
+        fe.set_threads(cpu_threads)  # BASELINE.md section 2: the candidate loop on 8 threads (the reference's is serial)
     vfs, rmin, rmax = cfg["voxel_filter_size"], cfg["min_range"], cfg["max_range"]
     state = state0.copy()
     rows, poses, hists = [], [], []
@@ -127,14 +139,15 @@ def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, hist
 STAGES = ("imu", "add_range_data", "match", "window_optimize", "insert", "histogram")
 
 
-def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=6, beams=64, azimuths=1024, cpu=True):
+def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=20, beams=64, azimuths=1024, cpu=True, scene="cube"):
+    """scene: "cube" (the reference test's closed room) or "ground" (the yard of dliom.synth: a floor 1.8 m below
+    the sensor, walls, boxes, -25..+15 degree beams, returns to 80 m, rays that do not return)."""
     from dliom import synth
     cfg = option_sets()[name]
-    synth.set_trajectory(10.0, 0.4)  # a vehicle-like arc: 4 m/s on a 10 m radius
-    try:
+    with synth.scene(scene):
+        if scene == "cube":
+            synth.set_trajectory(10.0, 0.4)  # a vehicle-like arc: 4 m/s on a 10 m radius (the yard's own is level)
         T, clouds, imus, state0 = make_stream(synth, scans, beams, azimuths)
-    finally:
-        synth.set_trajectory()
     import gc
     gc.collect()
     gc.disable()  # harness only: a full collection of CPython's cyclic collector is ~35 ms with torch imported
@@ -143,7 +156,7 @@ def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=6, beams=64, azimuths=1024
     finally:
         gc.enable()
     rows = rows[warmup:]
-    out = {"options": name,
+    out = {"options": name, "scene": scene, "returns_per_scan": int(np.mean([len(c) for c in clouds])),
            "workload": "W-ref complete chain (%s): %dx%d motion-distorted scans at 10 Hz + 200 Hz IMU: AddImuData, AddRangeData, "
                        "adaptive filters + %sCeres, WindowOptimize%s, InsertIntoSubmap, ComputeHistogram; raw scans cross "
                        "PCIe inside AddRangeData" % (name, beams, azimuths,
@@ -170,6 +183,15 @@ def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=6, beams=64, azimuths=1024
                                "sample": "the same stream through the CPU oracle (C++ restatement, 1 thread), %d scans after one "
                                          "warm-up; WindowOptimize is the same host code in both legs" % len(crows)}
         out["speedup_vs_cpu"] = out["scans_per_s"] * per_scan
+        if cfg["front_end"]["use_online_correlative_scan_matching"]:
+            threads = min(8, os.cpu_count() or 1)
+            mrows, _, _, _ = run_chain(dl, cfg, T, clouds[:n], imus[:n], state0, False, orc=orc, cpu_threads=threads)
+            per_scan_mt = float(np.mean(mrows[1:].sum(axis=1)))
+            out["cpu_baseline_%d_threads" % threads] = {
+                "value": 1.0 / per_scan_mt, "unit": "scans/s", "cores": threads, "kind": "port",
+                "what": "the same chain with the RTCSM3D candidate loop on %d threads (BASELINE.md section 2; everything else "
+                        "is serial in the reference and stays so)" % threads}
+            out["speedup_vs_best_cpu"] = out["scans_per_s"] * min(per_scan, per_scan_mt)
         out["parity"] = {"scans_compared": n, "max_translation_difference_m": dpos, "max_rotation_difference_rad": dang,
                          "tolerance_m": 1e-4, "ok": bool(dpos <= 1e-4 and dang <= 1e-4),
                          "histograms_same_scans": bool(same_presence), "histograms_max_abs_difference": hdiff,
@@ -183,14 +205,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--cpu-scans", type=int, default=6)
+    ap.add_argument("--cpu-scans", type=int, default=20)
+    ap.add_argument("--scene", default="cube", choices=("cube", "ground"))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--options", default="both", choices=("both", "trajectory_builder_3d", "basic_config_3d"))
     a = ap.parse_args()
     import dliom as dl
     ctx = dl.Context(0)
     names = ("trajectory_builder_3d", "basic_config_3d") if a.options == "both" else (a.options,)
-    print(json.dumps({n: line(dl, ctx, n, a.scans, a.warmup, a.cpu_scans, cpu=not a.no_cpu) for n in names}))
+    print(json.dumps({n: line(dl, ctx, n, a.scans, a.warmup, a.cpu_scans, cpu=not a.no_cpu, scene=a.scene) for n in names}))
 
 
 if __name__ == "__main__":
