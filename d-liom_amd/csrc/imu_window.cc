@@ -5,11 +5,23 @@
 // integrateMeasurement / predict) and gravity_factor/gravity_factor.cc:10-33.  GTSAM 4.0.2 is not in the tree
 // (README.MD:12): its factors are restated from their published definitions, PARITY UNPINNED (the reference
 // has no test at this boundary):
-//   preintegration   PreintegratedImuMeasurements on the manifold (Forster et al.): Delta R, Delta p, Delta v, their
-//                    bias Jacobians and the 9 x 9 covariance (rotation, position, velocity), integration covariance
-//                    (1e-4)^2 dt on the position block (:79-82)
-//   ImuFactor        r_R = Log(DR(bg)^T Ri^T Rj), r_p = Ri^T (pj - pi - vi dt - g dt^2 / 2) - Dp(b),
-//                    r_v = Ri^T (vj - vi - g dt) - Dv(b), whitened with the preintegrated covariance, n_gravity = (0,0,-g)
+//   preintegration   TWO forms behind dliom_imu_window_options::tangent_preintegration:
+//                    1 (default) TangentPreintegration -- what the reference's binary holds: README.MD:13-15 builds GTSAM
+//                      4.0.2 without -DGTSAM_TANGENT_PREINTEGRATION=OFF and 4.0.x defaults to ON, so
+//                      PreintegratedImuMeasurements (local_trajectory_builder_3d.cc:76-104,188-199) integrates the vector
+//                      [theta, p, v] in the tangent space of the first NavState: theta += Jr(theta)^-1 w dt,
+//                      p += v dt + R(theta) a dt^2 / 2, v += R(theta) a dt, bias Jacobians H <- A H - [B | C], covariance
+//                      A S A^T + B (Sa / dt) B^T + C (Sw / dt) C^T + (1e-4)^2 dt on the position block (:79-82), and the
+//                      factor's error is the NavState local coordinates of the predicted state at state j:
+//                      [Log(Rj^T R*), Rj^T (p* - pj), Rj^T (v* - vj)], R* = Ri Exp(theta(b)), p* = pi + vi dt + g dt^2/2 +
+//                      Ri P(b), v* = vi + g dt + Ri V(b);
+//                    0 the manifold form (Forster et al.; GTSAM with the flag OFF): Delta R, Delta p, Delta v, error
+//                      r_R = Log(DR(bg)^T Ri^T Rj), r_p = Ri^T (pj - pi - vi dt - g dt^2 / 2) - Dp(b),
+//                      r_v = Ri^T (vj - vi - g dt) - Dv(b).
+//                    Both whitened with the preintegrated 9 x 9 covariance, n_gravity = (0,0,-g).  DESIGN 3.8 quantifies
+//                    the difference between the two on tools/stream.py's run (it is small: they differ in second order
+//                    of the rotation within one scan interval and in the frame the residual is expressed in).
+//   ImuFactor        see above
 //   BetweenFactor    bias_j - bias_i with sigma = sqrt(dt) (acc_bias_noise x3, gyr_bias_noise x3)        (:808-812)
 //   PriorFactor      Pose3 local coordinates [Log(R0^T R), R0^T (p - p0)] with the sigmas IN THE ORDER THE REFERENCE
 //                    FILLS THEM, (t, t, t, r, r, r) (:94-101): the rotation rows get ceres_pose_noise_t -- kept
@@ -192,23 +204,132 @@ struct Preint {
   double dt = 0.0;
   M3 dR = identity();
   V3 dp{0, 0, 0}, dv{0, 0, 0};
+  // manifold form: d(Delta R)/d(bg) as a right perturbation; tangent form: d(theta)/d(bg) (the same slot: dR_dbg)
   M3 dR_dbg{}, dp_dba{}, dp_dbg{}, dv_dba{}, dv_dbg{};
   double cov[81];  // rotation, position, velocity
   V3 ba_lin{0, 0, 0}, bg_lin{0, 0, 0};
+  bool tangent = false;  // GTSAM's TangentPreintegration: `th` is the integrated quantity, dR = Exp(th) is kept beside it
+  V3 th{0, 0, 0};
+  M3 dth_dba{};          // tangent form only (zero in exact arithmetic: kept because GTSAM carries the block)
   Preint() { reset({0, 0, 0}, {0, 0, 0}); }
   void reset(V3 ba, V3 bg) {
     dt = 0.0;
     dR = identity();
     dp = dv = V3{0, 0, 0};
+    th = V3{0, 0, 0};
     std::memset(&dR_dbg, 0, sizeof(M3));
-    dp_dba = dp_dbg = dv_dba = dv_dbg = dR_dbg;
+    dp_dba = dp_dbg = dv_dba = dv_dbg = dth_dba = dR_dbg;
     std::memset(cov, 0, sizeof cov);
     ba_lin = ba;
     bg_lin = bg;
   }
 };
 
+// d(Jr(theta) c)/d(theta) for a fixed c (GTSAM so3::DexpFunctor::applyDexp's H1):
+//   Jr(theta) c = c - alpha theta x c + beta theta x (theta x c),  alpha = (1 - cos t) / t^2,  beta = (t - sin t) / t^3
+M3 DexpDerivative(V3 theta, V3 c) {
+  const double t2 = dot(theta, theta), t = std::sqrt(t2);
+  if (t2 <= 2.220446049250313e-16) return scaled(skew(c), 0.5);  // Jr ~ I - [theta]x / 2
+  const double alpha = (1.0 - std::cos(t)) / t2, beta = (t - std::sin(t)) / (t2 * t);
+  const double dalpha = (t * std::sin(t) - 2.0 * (1.0 - std::cos(t))) / (t2 * t);       // d alpha / dt
+  const double dbeta = (t * (1.0 - std::cos(t)) - 3.0 * (t - std::sin(t))) / (t2 * t2);  // d beta / dt
+  const V3 txc = cross(theta, c), ttc = cross(theta, txc);
+  const double tc = dot(theta, c);
+  M3 D = scaled(skew(c), alpha);
+  auto outer_add = [&D](V3 a, V3 b, double s) {  // D += s a b^T
+    const double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) D.m[3 * i + j] += s * av[i] * bv[j];
+  };
+  outer_add(txc, theta, -dalpha / t);
+  for (int i = 0; i < 3; ++i) D.m[4 * i] += beta * tc;
+  outer_add(theta, c, beta);
+  outer_add(c, theta, -2.0 * beta);
+  outer_add(ttc, theta, dbeta / t);
+  return D;
+}
+
+// gtsam::TangentPreintegration::update + PreintegratedImuMeasurements::integrateMeasurement (GTSAM 4.0.2,
+// navigation/TangentPreintegration.cpp, ImuFactor.cpp), restated from their published definitions.
+void integrate_tangent(Preint& P, V3 acc_meas, V3 gyr_meas, double h, double acc_sigma, double gyr_sigma, double int_sigma) {
+  const V3 a = acc_meas - P.ba_lin, w = gyr_meas - P.bg_lin;
+  const M3 Jr = RightJacobian(P.th), invJ = RightJacobianInverse(P.th);
+  const V3 w_tangent = invJ * w;
+  const M3 R = Exp(P.th);
+  const V3 a_nav = R * a;
+  const double h22 = 0.5 * h * h;
+  // A = d(new)/d(old), B = d(new)/d(acc), C = d(new)/d(omega)
+  const M3 w_tangent_H_theta = scaled(invJ * DexpDerivative(P.th, w_tangent), -1.0);
+  const M3 a_nav_H_theta = (R * skew(-1.0 * a)) * Jr;
+  double A[81] = {0}, Bm[27] = {0}, Cm[27] = {0};
+  for (int i = 0; i < 9; ++i) A[10 * i] = 1.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      A[9 * i + j] += h * w_tangent_H_theta.m[3 * i + j];
+      A[9 * (3 + i) + j] = h22 * a_nav_H_theta.m[3 * i + j];
+      A[9 * (6 + i) + j] = h * a_nav_H_theta.m[3 * i + j];
+      Bm[3 * (3 + i) + j] = h22 * R.m[3 * i + j];
+      Bm[3 * (6 + i) + j] = h * R.m[3 * i + j];
+      Cm[3 * i + j] = h * invJ.m[3 * i + j];
+    }
+  for (int i = 0; i < 3; ++i) A[9 * (3 + i) + 6 + i] = h;
+  double tmp[81], next[81];
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double s = 0;
+      for (int k = 0; k < 9; ++k) s += A[9 * i + k] * P.cov[9 * k + j];
+      tmp[9 * i + j] = s;
+    }
+  const double qa = acc_sigma * acc_sigma / h, qg = gyr_sigma * gyr_sigma / h;
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double s = 0;
+      for (int k = 0; k < 9; ++k) s += tmp[9 * i + k] * A[9 * j + k];
+      for (int k = 0; k < 3; ++k) s += qa * Bm[3 * i + k] * Bm[3 * j + k] + qg * Cm[3 * i + k] * Cm[3 * j + k];
+      next[9 * i + j] = s;
+    }
+  for (int i = 0; i < 3; ++i) next[9 * (3 + i) + 3 + i] += int_sigma * int_sigma * h;
+  std::memcpy(P.cov, next, sizeof next);
+  // preintegrated_H_biasAcc = A H_a - B, preintegrated_H_biasOmega = A H_g - C (9 x 3 each, kept as three 3 x 3 blocks)
+  double Ha[27], Hg[27], Ha2[27], Hg2[27];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Ha[3 * i + j] = P.dth_dba.m[3 * i + j];
+      Ha[3 * (3 + i) + j] = P.dp_dba.m[3 * i + j];
+      Ha[3 * (6 + i) + j] = P.dv_dba.m[3 * i + j];
+      Hg[3 * i + j] = P.dR_dbg.m[3 * i + j];
+      Hg[3 * (3 + i) + j] = P.dp_dbg.m[3 * i + j];
+      Hg[3 * (6 + i) + j] = P.dv_dbg.m[3 * i + j];
+    }
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double sa = -Bm[3 * i + j], sg = -Cm[3 * i + j];
+      for (int k = 0; k < 9; ++k) {
+        sa += A[9 * i + k] * Ha[3 * k + j];
+        sg += A[9 * i + k] * Hg[3 * k + j];
+      }
+      Ha2[3 * i + j] = sa;
+      Hg2[3 * i + j] = sg;
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      P.dth_dba.m[3 * i + j] = Ha2[3 * i + j];
+      P.dp_dba.m[3 * i + j] = Ha2[3 * (3 + i) + j];
+      P.dv_dba.m[3 * i + j] = Ha2[3 * (6 + i) + j];
+      P.dR_dbg.m[3 * i + j] = Hg2[3 * i + j];
+      P.dp_dbg.m[3 * i + j] = Hg2[3 * (3 + i) + j];
+      P.dv_dbg.m[3 * i + j] = Hg2[3 * (6 + i) + j];
+    }
+  // the mean
+  P.dp = P.dp + h * P.dv + h22 * a_nav;
+  P.dv = P.dv + h * a_nav;
+  P.th = P.th + h * w_tangent;
+  P.dR = Exp(P.th);  // deltaRij() for EstimateGravity and the prediction
+  P.dt += h;
+}
+
 void integrate(Preint& P, V3 acc_meas, V3 gyr_meas, double h, double acc_sigma, double gyr_sigma, double int_sigma) {
+  if (P.tangent) return integrate_tangent(P, acc_meas, gyr_meas, h, acc_sigma, gyr_sigma, int_sigma);
   const V3 a = acc_meas - P.ba_lin, w = gyr_meas - P.bg_lin;
   const V3 wh = h * w;
   const M3 dRk = Exp(wh), Jr = RightJacobian(wh);
@@ -263,8 +384,16 @@ void integrate(Preint& P, V3 acc_meas, V3 gyr_meas, double h, double acc_sigma, 
   P.dt += h;
 }
 
-void corrected(const Preint& P, V3 ba, V3 bg, M3* dR, V3* dp, V3* dv) {
+void corrected(const Preint& P, V3 ba, V3 bg, M3* dR, V3* dp, V3* dv, V3* theta = nullptr) {
   const V3 da = ba - P.ba_lin, dg = bg - P.bg_lin;
+  if (P.tangent) {  // biasCorrectedDelta: a linear correction of the tangent vector
+    const V3 th = P.th + P.dth_dba * da + P.dR_dbg * dg;
+    if (theta != nullptr) *theta = th;
+    *dR = Exp(th);
+    *dp = P.dp + P.dp_dba * da + P.dp_dbg * dg;
+    *dv = P.dv + P.dv_dba * da + P.dv_dbg * dg;
+    return;
+  }
   *dR = P.dR * Exp(P.dR_dbg * dg);
   *dp = P.dp + P.dp_dba * da + P.dp_dbg * dg;
   *dv = P.dv + P.dv_dba * da + P.dv_dbg * dg;
@@ -516,9 +645,18 @@ void imu_residual(const dliom_imu_window& w, const Preint& P, const std::vector<
   }
   const V3 g{0, 0, -w.o.gravity};
   const M3 RiT = transpose(a.R);
-  const V3 rR = Log(transpose(dR) * (RiT * b.R));
-  const V3 rp = RiT * (b.p - a.p - P.dt * a.v - (0.5 * P.dt * P.dt) * g) - dp;
-  const V3 rv = RiT * (b.v - a.v - P.dt * g) - dv;
+  V3 rR, rp, rv;
+  if (P.tangent) {
+    // PreintegrationBase::computeError (GTSAM 4.0.2): state_j.localCoordinates(predict(state_i, bias_i))
+    const M3 RjT = transpose(b.R);
+    rR = Log(RjT * (a.R * dR));
+    rp = RjT * ((a.p + P.dt * a.v + (0.5 * P.dt * P.dt) * g + a.R * dp) - b.p);
+    rv = RjT * ((a.v + P.dt * g + a.R * dv) - b.v);
+  } else {
+    rR = Log(transpose(dR) * (RiT * b.R));
+    rp = RiT * (b.p - a.p - P.dt * a.v - (0.5 * P.dt * P.dt) * g) - dp;
+    rv = RiT * (b.v - a.v - P.dt * g) - dv;
+  }
   const double raw[9] = {rR.x, rR.y, rR.z, rp.x, rp.y, rp.z, rv.x, rv.y, rv.z};
   for (int i = 0; i < 9; ++i) {  // r = L^-1 raw (L lower Cholesky factor of the covariance)
     double s = 0;
@@ -643,15 +781,10 @@ void imu_factor_jacobian(const dliom_imu_window& w, const Preint& P, const std::
                          double* r, double* J /* 15 x 30, row major */) {
   imu_residual(w, P, Linv, a, b, r, nullptr);
   M3 dR;
-  V3 dp, dv;
-  corrected(P, a.ba, a.bg, &dR, &dp, &dv);
+  V3 dp, dv, theta{0, 0, 0};
+  corrected(P, a.ba, a.bg, &dR, &dp, &dv, &theta);
   const V3 g{0, 0, -w.o.gravity};
   const M3 RaT = transpose(a.R);
-  const M3 E = transpose(dR) * (RaT * b.R);
-  const V3 rR = Log(E);
-  const M3 Jri = RightJacobianInverse(rR);
-  const V3 xp = RaT * (b.p - a.p - P.dt * a.v - (0.5 * P.dt * P.dt) * g);
-  const V3 xv = RaT * (b.v - a.v - P.dt * g);
   double raw[9][30];
   for (auto& row : raw)
     for (double& v : row) v = 0.0;
@@ -659,6 +792,44 @@ void imu_factor_jacobian(const dliom_imu_window& w, const Preint& P, const std::
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) raw[r0 + i][c0 + j] = scale * m.m[3 * i + j];
   };
+  if (P.tangent) {
+    // e_R = Log(Rb^T Ra Exp(theta)),  e_p = Rb^T (p* - pb),  e_v = Rb^T (v* - vb)   (imu_residual); on this
+    // parametrisation (R <- R Exp(d), p <- p + d, v <- v + d, biases additive):
+    //   e_R: d/dtheta_a = Jr^-1(e_R) Exp(theta)^T,  d/dtheta_b = -Jr^-1(e_R) E^T (E = Rb^T Ra Exp(theta)),
+    //        d/db = Jr^-1(e_R) Jr(theta) dtheta/db
+    //   e_p: d/dtheta_b = [e_p]x, d/dpb = -Rb^T, d/dpa = Rb^T, d/dva = dt Rb^T, d/dtheta_a = -Rb^T Ra [P]x, d/db = Rb^T Ra dP/db
+    //   e_v: d/dtheta_b = [e_v]x, d/dvb = -Rb^T, d/dva = Rb^T, d/dtheta_a = -Rb^T Ra [V]x, d/db = Rb^T Ra dV/db
+    const M3 RbT = transpose(b.R);
+    const M3 RbTRa = RbT * a.R;
+    const M3 E = RbTRa * dR;
+    const V3 eR = Log(E);
+    const M3 Jri = RightJacobianInverse(eR);
+    const V3 ep = RbT * ((a.p + P.dt * a.v + (0.5 * P.dt * P.dt) * g + a.R * dp) - b.p);
+    const V3 ev = RbT * ((a.v + P.dt * g + a.R * dv) - b.v);
+    const M3 JrTheta = RightJacobian(theta);
+    put(0, 0, Jri * transpose(dR), 1.0);
+    put(0, 15, Jri * transpose(E), -1.0);
+    put(0, 9, Jri * (JrTheta * P.dth_dba), 1.0);
+    put(0, 12, Jri * (JrTheta * P.dR_dbg), 1.0);
+    put(3, 15, skew(ep), 1.0);
+    put(3, 18, RbT, -1.0);
+    put(3, 3, RbT, 1.0);
+    put(3, 6, RbT, P.dt);
+    put(3, 0, RbTRa * skew(dp), -1.0);
+    put(3, 9, RbTRa * P.dp_dba, 1.0);
+    put(3, 12, RbTRa * P.dp_dbg, 1.0);
+    put(6, 15, skew(ev), 1.0);
+    put(6, 21, RbT, -1.0);
+    put(6, 6, RbT, 1.0);
+    put(6, 0, RbTRa * skew(dv), -1.0);
+    put(6, 9, RbTRa * P.dv_dba, 1.0);
+    put(6, 12, RbTRa * P.dv_dbg, 1.0);
+  } else {
+  const M3 E = transpose(dR) * (RaT * b.R);
+  const V3 rR = Log(E);
+  const M3 Jri = RightJacobianInverse(rR);
+  const V3 xp = RaT * (b.p - a.p - P.dt * a.v - (0.5 * P.dt * P.dt) * g);
+  const V3 xv = RaT * (b.v - a.v - P.dt * g);
   // rR
   put(0, 0, Jri * (transpose(b.R) * a.R), -1.0);
   put(0, 15, Jri, 1.0);
@@ -679,6 +850,7 @@ void imu_factor_jacobian(const dliom_imu_window& w, const Preint& P, const std::
   put(6, 9, P.dv_dba, -1.0);
   put(6, 12, P.dv_dbg, -1.0);
   put(6, 21, RaT, 1.0);
+  }
   for (int i = 0; i < 9; ++i)
     for (int c = 0; c < 30; ++c) {
       double s = 0;
@@ -1022,6 +1194,7 @@ int dliom_imu_window_default_options(dliom_imu_window_options* o) {
   o->frames_for_online_gravity_estimate = 7;   // :29
   o->lidar_in_imu_translation[0] = o->lidar_in_imu_translation[1] = o->lidar_in_imu_translation[2] = 0.0;
   o->graph_reset_every = 0;
+  o->tangent_preintegration = 1;  // what the reference's GTSAM 4.0.2 build integrates (README.MD:13-15: no flag, default ON)
   return DLIOM_OK;
 }
 
@@ -1036,6 +1209,7 @@ int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_w
     return DLIOM_ERR_INVALID_ARGUMENT;
   dliom_imu_window* w = new dliom_imu_window;
   w->o = *options;
+  w->current.tangent = options->tangent_preintegration != 0;
   *out = w;
   return DLIOM_OK;
 }

@@ -144,7 +144,7 @@ class ImuWindowOptions(C.Structure):
         "ceres_pose_noise_r_drift", "prior_gravity_noise")] + [
             ("window_size", C.c_int), ("iterations", C.c_int), ("enable_gravity_factor", C.c_int),
             ("frames_for_online_gravity_estimate", C.c_int), ("lidar_in_imu_translation", C.c_double * 3),
-            ("graph_reset_every", C.c_int)]
+            ("graph_reset_every", C.c_int), ("tangent_preintegration", C.c_int)]
 
 
 class ImuPreintegration(C.Structure):

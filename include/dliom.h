@@ -600,7 +600,8 @@ int dliom_imu_integrator_predict(const dliom_imu_integrator* integrator, const d
 /* ---- LocalTrajectoryBuilder3D::WindowOptimize: IMU-preintegration cost in the optimisation ----------
  * (host; PARITY UNPINNED: GTSAM 4.0.2 is not in the reference tree and the reference has no
  * test at this boundary).  Replaces mapping/internal/3d/local_trajectory_builder_3d.cc:693-863 and the
- * gtsam::PreintegratedImuMeasurements calls of AddImuData (:179-199): manifold preintegration, ImuFactor +
+ * gtsam::PreintegratedImuMeasurements calls of AddImuData (:179-199): IMU preintegration (tangent form like the
+ * reference's GTSAM build, or the manifold form: options.tangent_preintegration), ImuFactor +
  * bias BetweenFactor + PriorFactor<Pose3> on the matched pose + Pose3GravityFactor
  * (gravity_factor/gravity_factor.cc:10-33), solved as a fixed-lag Gauss-Newton smoother with marginalisation
  * in place of ISAM2.  Poses are [x, y, z, qw, qx, qy, qz], biases [ax, ay, az, gx, gy, gz].
@@ -631,6 +632,12 @@ typedef struct dliom_imu_window_options {
                                               replaces its graph by the newest state with the marginal covariances of
                                               pose, velocity and bias taken separately; 0 = never (plain fixed-lag
                                               smoothing, which keeps the cross-covariances that reset drops); >= 2 */
+  int tangent_preintegration;              /* 1 (default): gtsam::TangentPreintegration, what PreintegratedImuMeasurements
+                                              IS in the reference's build (README.MD:13-15 builds GTSAM 4.0.2 without
+                                              -DGTSAM_TANGENT_PREINTEGRATION=OFF; 4.0.x defaults to ON): [theta, p, v]
+                                              integrated in the tangent space of the first state, error = local
+                                              coordinates of the predicted state at state j.  0: the manifold form of
+                                              Forster et al. (GTSAM with the flag OFF).  Still PARITY UNPINNED either way */
 } dliom_imu_window_options;
 int dliom_imu_window_default_options(dliom_imu_window_options* options);
 int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out);

@@ -37,7 +37,89 @@ def quat_to_matrix(q):
     return Rot.from_quat([x, y, z, w]).as_matrix()
 
 
+def right_jacobian_inverse(w):
+    return np.linalg.inv(right_jacobian(w))
+
+
+class TangentPreintegration:
+    """gtsam::TangentPreintegration + PreintegratedImuMeasurements (GTSAM 4.0.2, what the reference links: README.MD:13-15
+    sets no GTSAM_TANGENT_PREINTEGRATION flag and 4.0.x defaults to ON), restated independently of imu_window.cc: the
+    vector [theta, p, v]; A = d(new)/d(old) by CENTRAL DIFFERENCES of the update itself (imu_window.cc has it in closed form),
+    B and C in closed form; bias Jacobians H <- A H - [B | C]; covariance A S A^T + B Sa/dt B^T + C Sw/dt C^T + position block."""
+
+    tangent = True
+
+    def __init__(self, ba, bg, opts):
+        self.ba, self.bg, self.o = np.array(ba, float), np.array(bg, float), opts
+        self.dt = 0.0
+        self.x = np.zeros(9)
+        self.H_a, self.H_g = np.zeros((9, 3)), np.zeros((9, 3))
+        self.cov = np.zeros((9, 9))
+
+    @staticmethod
+    def _update(x, a, w, h):
+        th, p, v = x[0:3], x[3:6], x[6:9]
+        R = exp_so3(th)
+        wt = right_jacobian_inverse(th) @ w
+        an = R @ a
+        return np.concatenate([th + wt * h, p + v * h + 0.5 * h * h * an, v + an * h])
+
+    def add(self, acc, gyr, h):
+        a, w = np.asarray(acc, float) - self.ba, np.asarray(gyr, float) - self.bg
+        A = np.zeros((9, 9))
+        for c in range(9):
+            d = np.zeros(9)
+            d[c] = 1e-6
+            A[:, c] = (self._update(self.x + d, a, w, h) - self._update(self.x - d, a, w, h)) / 2e-6
+        R = exp_so3(self.x[0:3])
+        B = np.zeros((9, 3))
+        B[3:6] = 0.5 * h * h * R
+        B[6:9] = h * R
+        Cg = np.zeros((9, 3))
+        Cg[0:3] = h * right_jacobian_inverse(self.x[0:3])
+        self.cov = A @ self.cov @ A.T + B @ B.T * (self.o["acc_noise"] ** 2 / h) + Cg @ Cg.T * (self.o["gyr_noise"] ** 2 / h)
+        self.cov[3:6, 3:6] += np.eye(3) * self.o["integration_sigma"] ** 2 * h
+        self.H_a = A @ self.H_a - B
+        self.H_g = A @ self.H_g - Cg
+        self.x = self._update(self.x, a, w, h)
+        self.dt += h
+
+    @property
+    def dR(self):
+        return exp_so3(self.x[0:3])
+
+    @property
+    def dp(self):
+        return self.x[3:6]
+
+    @property
+    def dv(self):
+        return self.x[6:9]
+
+    def corrected(self, ba, bg):
+        x = self.x + self.H_a @ (ba - self.ba) + self.H_g @ (bg - self.bg)
+        return exp_so3(x[0:3]), x[3:6], x[6:9]
+
+
+def make_preintegration(ba, bg, opts):
+    return TangentPreintegration(ba, bg, opts) if opts.get("tangent_preintegration", 0) else Preintegration(ba, bg, opts)
+
+
+def imu_raw_residual(P, a, b, g):
+    """The 9 unwhitened residuals of the IMU factor between states a and b (R, p, v, ba, bg)."""
+    dR, dp, dv = P.corrected(a[3], a[4])
+    if getattr(P, "tangent", False):  # NavState::localCoordinates of the predicted state at state b
+        return np.concatenate([log_so3(b[0].T @ a[0] @ dR),
+                               b[0].T @ (a[1] + P.dt * a[2] + 0.5 * P.dt ** 2 * g + a[0] @ dp - b[1]),
+                               b[0].T @ (a[2] + P.dt * g + a[0] @ dv - b[2])])
+    return np.concatenate([log_so3(dR.T @ a[0].T @ b[0]),
+                           a[0].T @ (b[1] - a[1] - P.dt * a[2] - 0.5 * P.dt ** 2 * g) - dp,
+                           a[0].T @ (b[2] - a[2] - P.dt * g) - dv])
+
+
 class Preintegration:
+    tangent = False
+
     def __init__(self, ba, bg, opts):
         self.ba, self.bg, self.o = np.array(ba, float), np.array(bg, float), opts
         self.dt = 0.0
@@ -194,7 +276,7 @@ class BatchSmoother:
         self.x, self.pre, self.pose_priors = [s], [], []
         self.gravity, self.g_frames, self.g_vs, self.g_valid = [], [], [], False
         self.prior0 = s
-        self.cur = Preintegration(s[3], s[4], self.o)
+        self.cur = make_preintegration(s[3], s[4], self.o)
 
     def add_imu(self, acc, gyr, dt):
         self.cur.add(acc, gyr, dt)
@@ -215,10 +297,7 @@ class BatchSmoother:
         g = np.array([0, 0, -o["gravity"]])
         for i, P in enumerate(self.pre):
             a, b = x[i], x[i + 1]
-            dR, dp, dv = P.corrected(a[3], a[4])
-            raw = np.concatenate([log_so3(dR.T @ a[0].T @ b[0]),
-                                  a[0].T @ (b[1] - a[1] - P.dt * a[2] - 0.5 * P.dt ** 2 * g) - dp,
-                                  a[0].T @ (b[2] - a[2] - P.dt * g) - dv])
+            raw = imu_raw_residual(P, a, b, g)
             L = np.linalg.cholesky(P.cov + 1e-18 * np.eye(9))
             r.append(np.linalg.solve(L, raw))
             r.append((b[3] - a[3]) / (np.sqrt(P.dt) * o["acc_bias_noise"]))
@@ -267,7 +346,7 @@ class BatchSmoother:
             step = np.linalg.solve(J.T @ J + 1e-12 * np.eye(n), -J.T @ r0)
             self.x = [retract(s, step[15 * i:15 * i + 15]) for i, s in enumerate(self.x)]
         s = self.x[-1]
-        self.cur = Preintegration(s[3], s[4], self.o)
+        self.cur = make_preintegration(s[3], s[4], self.o)
         return s
 
 
@@ -289,7 +368,7 @@ class ReferenceRuleSmoother:
         # prior on state 0: mean and the inverse square roots of the three blocks (pose tangent = (rotation, translation
         # in the body frame), like gtsam::Pose3::Logmap to first order)
         self.prior = (s, np.eye(6) / o["prior_pose_noise"], np.eye(3) / o["prior_velocity_sigma"], np.eye(6) / o["prior_bias_sigma"])
-        self.cur = Preintegration(s[3], s[4], o)
+        self.cur = make_preintegration(s[3], s[4], o)
         self.resets = 0
 
     def add_imu(self, acc, gyr, dt):
@@ -306,10 +385,7 @@ class ReferenceRuleSmoother:
             L = np.linalg.cholesky(P.cov + 1e-18 * np.eye(9))
 
             def imu(a, b, P=P, L=L):
-                dR, dp, dv = P.corrected(a[3], a[4])
-                raw = np.concatenate([log_so3(dR.T @ a[0].T @ b[0]),
-                                      a[0].T @ (b[1] - a[1] - P.dt * a[2] - 0.5 * P.dt ** 2 * g) - dp,
-                                      a[0].T @ (b[2] - a[2] - P.dt * g) - dv])
+                raw = imu_raw_residual(P, a, b, g)
                 return np.concatenate([np.linalg.solve(L, raw), (b[3] - a[3]) / (np.sqrt(P.dt) * o["acc_bias_noise"]),
                                        (b[4] - a[4]) / (np.sqrt(P.dt) * o["gyr_bias_noise"])])
             fs.append(((i, i + 1), imu))
@@ -367,5 +443,5 @@ class ReferenceRuleSmoother:
                                  o["ceres_pose_noise_r_drift"] if is_drift else o["ceres_pose_noise_r"]))
         self._solve(iterations)
         s = self.x[-1]
-        self.cur = Preintegration(s[3], s[4], o)
+        self.cur = make_preintegration(s[3], s[4], o)
         return s
