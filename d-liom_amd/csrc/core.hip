@@ -695,6 +695,9 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   if (ctx->aux_pinned != nullptr) (void)hipHostFree(ctx->aux_pinned);
   if (ctx->aux_fork != nullptr) (void)hipEventDestroy(ctx->aux_fork);
   if (ctx->aux_stream != nullptr) (void)hipStreamDestroy(ctx->aux_stream);
+  if (ctx->hist_fork != nullptr) (void)hipEventDestroy(ctx->hist_fork);
+  if (ctx->hist_join != nullptr) (void)hipEventDestroy(ctx->hist_join);
+  if (ctx->hist_big_stream != nullptr) (void)hipStreamDestroy(ctx->hist_big_stream);
   if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
   if (ctx->done_word != nullptr) (void)hipHostFree(ctx->done_word);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

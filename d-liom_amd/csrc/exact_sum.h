@@ -5,7 +5,7 @@
 // signed, monotone, hovering around zero and around powers of two, wild magnitudes, ties everywhere); the comments there
 // carry the error bound.  In short: while the accumulator stays in one binade it is an integer counter and every addend
 // a function {parity} -> {increment, parity} (ParityFn) that composes associatively; the real (double) prefix sums prove,
-// per chunk of 32 addends, in which binade the accumulator is while it crosses the chunk ("safe" chunks, 94-98 % on
+// per chunk of 16 addends, in which binade the accumulator is while it crosses the chunk ("safe" chunks, 94-98 % on
 // LiDAR slices); a wave then walks the chunk functions 64 at a time with a scan and adds the values of the other chunks
 // one after the other.  Anything not proven falls back to those sequential additions, which are right by definition.
 #ifndef DLIOM_CSRC_EXACT_SUM_H_
@@ -17,7 +17,7 @@ namespace dliom {
 namespace exact_sum {
 
 constexpr int kThreads = 1024;          // the workgroup size the block scans below are written for
-constexpr int kChunk = 32;              // addends per chunk
+constexpr int kChunk = 16;              // addends per chunk (32 needed more registers than a 1024-thread workgroup has: spills)
 constexpr int kChunksPerBlock = 1024;   // chunks per super-block (one per thread); longer arrays are streamed
 constexpr int kNoCode = 0x7fffffff;
 

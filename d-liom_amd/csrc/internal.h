@@ -116,6 +116,10 @@ struct dliom_ctx {
   float aux_rotation[4] = {1.f, 0.f, 0.f, 0.f};
   bool aux_has_rotation = false;
   bool hist_expect_big = true;  // the previous cloud had height slices above 4096 points (rotational_histogram.hip)
+  // the big slices' kernels (one workgroup per slice, a few hundred microseconds) run on a stream of their own beside the
+  // small slices' kernel (256 workgroups): created with the first histogram that needs them
+  hipStream_t hist_big_stream = nullptr;
+  hipEvent_t hist_fork = nullptr, hist_join = nullptr;
   // profiling
   bool profiling = false;
   unsigned profiling_mask = ~0u;  // kernel ids whose launches are timed

@@ -1371,15 +1371,33 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
     while (!(std::sqrt(s2) > kMaxDistance)) s2 = std::nextafter(s2, 2.f);
     return s2;
   }();
-  if (with_big) {  // first: the small slices' workgroups then run beside the sort
-    hipLaunchKernelGGL(big_prepare_kernel, dim3(kMaxBig), dim3(kThreads), 0, stream, rx, ry, keys, n, bin_counts, A, flags);
-    DLIOM_HIP_TRY(hipGetLastError());
-  }
-  hipLaunchKernelGGL(slice_kernel, dim3(256), dim3(kThreads), lds, stream, rx, ry, rz, keys, n, bin_counts, histogram_size,
-                     squared_jump, c_bucket, c_value, flags, with_big ? 1 : 0);
+  hipStream_t big_stream = stream;
   if (with_big) {
+    // the big slices' chain (prepare, radix sort, one workgroup per slice) beside the small slices' kernel: both only
+    // read what prepare_kernel wrote and write disjoint regions of the contribution arrays
+    if (ctx->hist_big_stream == nullptr) {
+      hipStream_t st = nullptr;
+      hipEvent_t e1 = nullptr, e2 = nullptr;
+      const bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        if (e2 != nullptr) (void)hipEventDestroy(e2);
+        if (e1 != nullptr) (void)hipEventDestroy(e1);
+        if (st != nullptr) (void)hipStreamDestroy(st);
+        return DLIOM_ERR_HIP;
+      }
+      ctx->hist_big_stream = st;
+      ctx->hist_fork = e1;
+      ctx->hist_join = e2;
+    }
+    big_stream = ctx->hist_big_stream;
+    DLIOM_HIP_TRY(hipEventRecord(ctx->hist_fork, stream));
+    DLIOM_HIP_TRY(hipStreamWaitEvent(big_stream, ctx->hist_fork, 0));
+    hipLaunchKernelGGL(big_prepare_kernel, dim3(kMaxBig), dim3(kThreads), 0, big_stream, rx, ry, keys, n, bin_counts, A, flags);
+    DLIOM_HIP_TRY(hipGetLastError());
     DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_temp, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, sort_items, 0,
-                                                     kBigKeyBits, stream));
+                                                     kBigKeyBits, big_stream));
     if ((ctx->func_attr_set & kFuncAttrHistogramBig) == 0u) {
       DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(big_sort_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(kBigLdsBytes)));
@@ -1387,9 +1405,14 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
                                         static_cast<int>(kBigLdsBytes)));
       ctx->func_attr_set |= kFuncAttrHistogramBig;
     }
-    hipLaunchKernelGGL(big_slice_kernel, dim3(kMaxBig), dim3(kThreads), kBigLdsBytes, stream, bin_counts, histogram_size, squared_jump, A,
+    hipLaunchKernelGGL(big_slice_kernel, dim3(kMaxBig), dim3(kThreads), kBigLdsBytes, big_stream, bin_counts, histogram_size, squared_jump, A,
                        c_bucket, c_value, flags);
+    DLIOM_HIP_TRY(hipGetLastError());
+    DLIOM_HIP_TRY(hipEventRecord(ctx->hist_join, big_stream));
   }
+  hipLaunchKernelGGL(slice_kernel, dim3(256), dim3(kThreads), lds, stream, rx, ry, rz, keys, n, bin_counts, histogram_size,
+                     squared_jump, c_bucket, c_value, flags, with_big ? 1 : 0);
+  if (with_big) DLIOM_HIP_TRY(hipStreamWaitEvent(stream, ctx->hist_join, 0));
   hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64 * kAccWaves), acc_lds, stream, c_bucket,
                      c_value, static_cast<int>(n_padded), histogram_size, d_hist);
   DLIOM_HIP_TRY(hipGetLastError());

@@ -30,7 +30,12 @@ __device__ unsigned long long dbg_big[64 * 16];
 #define DLIOM_BSTAMP(k)
 #endif
 
-constexpr size_t kBigLdsBytes = static_cast<size_t>(kMaxSlice) * 8 + 2 * static_cast<size_t>(kMaxSlice + 8) * 2 + sizeof(Queue) + kMaxSlice + 64;
+// dynamic LDS of big_slice_kernel: the replay's arrays (61 KB) or the exact sums' scratch (50 KB) or the chain's arrays
+// (10 bytes per point) -- one after the other; one workgroup of 1024 threads per CU anyway
+constexpr size_t kBigReplayBytes = static_cast<size_t>(kMaxSlice) * 8 + 2 * static_cast<size_t>(kMaxSlice + 8) * 2 + sizeof(Queue) + kMaxSlice + 64;
+constexpr size_t kBigLdsBytes = 150 * 1024;
+static_assert(kBigReplayBytes <= kBigLdsBytes, "the replay's arrays fit");
+constexpr int kWorkListCap = 256;    // segments of a big slice's replay that still hold ties, before they fit LDS together
 constexpr int kMaxBig = 63;         // big slices per cloud (slice ordinal 63 is the sort's padding key)
 constexpr int kBigKeyBits = 38;     // 32 angle bits + 6 slice bits
 
@@ -167,18 +172,11 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
                                const BigArrays& A, unsigned off, unsigned* wave_sums, unsigned long long* lds_a,
                                const SortScratch& lds_sc) {
   unsigned long long* __restrict__ arr = A.arr + off;
-  unsigned* __restrict__ seg_first = A.seg_first + off;
-  unsigned* __restrict__ seg_last = A.seg_last + off;
-  unsigned* __restrict__ g = A.g + off;
   unsigned* __restrict__ l = A.l + off;
   unsigned* __restrict__ tmp_l = A.tmp_l + off;
   unsigned* __restrict__ tmp_r = A.tmp_r + off;
-  unsigned* __restrict__ cut = A.cut + off;
-  unsigned* __restrict__ tpre = A.tpre + off;
   unsigned* __restrict__ pos_of = A.pos_of + off;
   unsigned* __restrict__ sorted_id = A.sorted_id + off;
-  unsigned char* __restrict__ act = A.act + off;
-  unsigned char* __restrict__ fl = A.fl + off;
   unsigned char* __restrict__ tied = A.tied + off;
   int lo, hi;
   {  // positions in the slice run over [0, count); m <= count of them are items
@@ -189,245 +187,403 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
   owned_range(m, &lo, &hi);
   __syncthreads();
   int t = 0;
-  for_owned4(
-      lo, hi, [&](int j) { return U2{static_cast<unsigned>(sk[j]), static_cast<unsigned>(sk[min(j + 1, m - 1)])}; },
-      [&](int j, U2) { return U2{sv[j], sv[min(j + 1, m - 1)]}; },
-      [&](int j, U2 k, U2 v) {
-        if (j + 1 < m && k.a == k.b) {
-          tied[v.a] = 1;
-          tied[v.b] = 1;
-          t = 1;
-        }
-      });
+  for (int j0 = static_cast<int>(threadIdx.x); j0 < m; j0 += 8 * kThreads) {  // (coalesced, eight loads in flight)
+    unsigned ka[8], kb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = min(j0 + u * kThreads, m - 1);
+      ka[u] = static_cast<unsigned>(sk[j]);
+      kb[u] = static_cast<unsigned>(sk[min(j + 1, m - 1)]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * kThreads;
+      if (j + 1 < m && ka[u] == kb[u]) {
+        tied[sv[j]] = 1;
+        tied[sv[j + 1]] = 1;
+        t = 1;
+      }
+    }
+  }
   const bool any_tie = __syncthreads_or(t) != 0;
+#ifdef DLIOM_EXPERIMENTS
+#define DLIOM_SSTAMP(k) if (threadIdx.x == 0 && blockIdx.x < 4) dbg_big[(blockIdx.x + 8) * 16 + (k)] = __builtin_readcyclecounter()
+  int dbg_round = 0;
+#else
+#define DLIOM_SSTAMP(k)
+#endif
+  DLIOM_SSTAMP(0);
   if (!any_tie) {
-    for_owned4(lo, hi, [&](int j) { return sv[j]; }, [](int, unsigned) { return 0; }, [&](int j, unsigned v, int) { sorted_id[j] = v; });
+    for (int j = threadIdx.x; j < m; j += kThreads) sorted_id[j] = sv[j];
     __syncthreads();
     return true;
   }
-  for_owned4(
-      lo, hi, [&](int p) { return U2{static_cast<unsigned>(ik[p]), iv[p]}; }, [](int, U2) { return 0; },
-      [&](int p, U2 x, int) {
-        arr[p] = (static_cast<unsigned long long>(x.a) << 32) | x.b;
-        seg_first[p] = 0u;
-        seg_last[p] = static_cast<unsigned>(m);
-      });
-  int depth = 0;
-  for (int v = m; v > 1; v >>= 1) ++depth;
-  depth *= 2;
+  for (int p0 = static_cast<int>(threadIdx.x); p0 < m; p0 += 8 * kThreads) {
+    unsigned k8[8], v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = min(p0 + u * kThreads, m - 1);
+      k8[u] = static_cast<unsigned>(ik[p]);
+      v8[u] = iv[p];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + u * kThreads < m) arr[p0 + u * kThreads] = (static_cast<unsigned long long>(k8[u]) << 32) | v8[u];
+  }
+  int depth0 = 0;
+  for (int v = m; v > 1; v >>= 1) ++depth0;
+  depth0 *= 2;
   bool ok = true;
+  // ---- introsort's partitions, only where two tied elements still share a segment.  A work list of such segments
+  //      (disjoint, in HBM coordinates); while they hold more than kMaxSlice elements together the LARGEST one is
+  //      partitioned by the whole workgroup (coop_partition: four coalesced passes), then everything left moves to LDS
+  //      and wave_sort_arrangement finishes it.  (Round 4's first version ran all segments through block-wide rounds over
+  //      thread-owned positions: ~90 us per round for a floor slice of 10 000 returns, four or five rounds.)
+  __shared__ int wl_first[kWorkListCap], wl_last[kWorkListCap], wl_depth[kWorkListCap];
+  __shared__ int wl_n, wl_pick, wl_total, wl_overflow, wl_mode;
+  __shared__ int wl_base[kWorkListCap + 1];
+  __shared__ unsigned co_cnt[2][kThreads / 64];
+  __shared__ unsigned co_k, co_tied[2];
+  __shared__ int co_cut;
+  if (threadIdx.x == 0) {
+    wl_first[0] = 0;
+    wl_last[0] = m;
+    wl_depth[0] = depth0;
+    wl_n = m > 16 ? 1 : 0;
+    wl_overflow = 0;
+  }
   __syncthreads();
-  for (;;) {
-    // which segments still matter: above the threshold and holding at least two tied elements
-    unsigned cnt = 0u;
-    for_owned4(
-        lo, hi, [&](int p) { return static_cast<unsigned>(arr[p]); }, [&](int, unsigned id) { return static_cast<unsigned>(tied[id]); },
-        [&](int p, unsigned, unsigned f) {
-          fl[p] = static_cast<unsigned char>(f);
-          cnt += f;
-        });
-    unsigned total;
-    unsigned run = block_exclusive_scan(cnt, wave_sums, &total);
-    for_owned4(
-        lo, hi, [&](int p) { return static_cast<unsigned>(fl[p]); }, [](int, unsigned) { return 0; },
-        [&](int p, unsigned f, int) {
-          tpre[p] = run;
-          run += f;
-        });
-    if (threadIdx.x == 0) tpre[m] = total;
-    __syncthreads();
-    int any = 0, heap_too_large = 0;
-    unsigned active = 0u;
-    for_owned4(
-        lo, hi, [&](int p) { return U2{seg_first[p], seg_last[p]}; }, [&](int, U2 s) { return U2{tpre[s.a], tpre[s.b]}; },
-        [&](int p, U2 s, U2 c) {
-          const int a = (s.b - s.a > 16u && c.b - c.a >= 2u) ? 1 : 0;
-          act[p] = static_cast<unsigned char>(a);
-          any |= a;
-          active += static_cast<unsigned>(a);
-          if (a && depth == 0 && s.b - s.a > 8192u) heap_too_large = 1;
-        });
-    if (__syncthreads_or(any) == 0) break;
-    unsigned active_total;
-    const unsigned compact_at = block_exclusive_scan(active, wave_sums, &active_total);
-    if (active_total <= static_cast<unsigned>(kMaxSlice)) {
-      // ---- the rest in LDS: the active segments, packed in order (a segment is active as a whole, so segments stay
-      //      contiguous), under the replay of the small slices; identities are the packed indices at this moment
-      unsigned* __restrict__ cpos = g;  // packed index -> position; g, l, tpre are free from here on
-      unsigned* __restrict__ cid = l;   // packed index -> position in the slice (the item's low word)
-      unsigned* __restrict__ cidx = tpre;  // position -> packed index (active positions)
-      {
-        unsigned c = compact_at;
-        for_owned4(
-            lo, hi, [&](int p) { return static_cast<unsigned>(act[p]); }, [](int, unsigned) { return 0; },
-            [&](int p, unsigned a, int) {
-              if (a) cidx[p] = c++;
-            });
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int guard = 0; guard < (1 << 20); ++guard) {
+    // What next (thread 0 decides, everybody follows): the largest segment is partitioned by the whole workgroup in HBM,
+    // or as many segments as fit LDS together are finished there (wave_sort_arrangement) and leave the list.
+    if (threadIdx.x == 0) {
+      int pick = -1, best = 0, total = 0;
+      for (int e = 0; e < wl_n; ++e) {
+        const int len = wl_last[e] - wl_first[e];
+        total += len;
+        if (len > best) {
+          best = len;
+          pick = e;
+        }
       }
-      __syncthreads();
+      wl_pick = pick;
+      // With a handful of tied pairs the segments that matter halve with every partition: a few workgroup-wide
+      // partitions (~9 us each) until everything left fits LDS at once beat several LDS batches (~40 us each).  With ties
+      // everywhere nothing shrinks: then the segments go through LDS in batches as soon as they are small enough.
+      int mode = 0;
+      if (wl_n > 0)
+        mode = ((best > kMaxSlice || (total > kMaxSlice && best > kMaxSlice / 4)) && wl_n < kWorkListCap - 2) ? 1 : 2;
+      if (mode == 2) {  // the batch: entries in list order while they fit; the chosen ones move to the END of the list
+        int at = 0, taken = 0, n = wl_n;
+        for (int e = 0; e < n - taken;) {
+          const int len = wl_last[e] - wl_first[e];
+          if (len <= kMaxSlice && at + len <= kMaxSlice && taken < kWorkListCap) {
+            const int last_free = n - taken - 1;
+            const int f = wl_first[e], l2 = wl_last[e], d = wl_depth[e];
+            wl_first[e] = wl_first[last_free];
+            wl_last[e] = wl_last[last_free];
+            wl_depth[e] = wl_depth[last_free];
+            wl_first[last_free] = f;
+            wl_last[last_free] = l2;
+            wl_depth[last_free] = d;
+            at += len;
+            ++taken;
+          } else {
+            ++e;
+          }
+        }
+        wl_total = taken;  // the batch is the last `taken` entries of the list
+        if (taken == 0) wl_overflow = 1;  // a list full of segments above kMaxSlice: cannot happen below 2^18 elements
+      }
+      wl_mode = mode;
+    }
+    __syncthreads();
+    if (wl_mode == 0 || wl_overflow != 0) break;
+    if (wl_mode == 2) {
+      // ---- a batch in LDS: the chosen segments packed one behind the other; an item's identity there is its packed index
+      const int n_batch = wl_total, e0 = wl_n - n_batch;
+      if (threadIdx.x == 0) {
+        int at = 0;
+        for (int e = 0; e < n_batch; ++e) {
+          wl_base[e] = at;
+          at += wl_last[e0 + e] - wl_first[e0 + e];
+        }
+        wl_base[n_batch] = at;
+      }
       queue_init(lds_sc.queue);
       __syncthreads();
-      for_owned4(
-          lo, hi, [&](int p) { return U4{static_cast<unsigned>(act[p]), seg_first[p], seg_last[p], cidx[p]}; },
-          [&](int p, U4 x) { return x.a ? U2{cidx[x.b], cidx[x.c - 1u]} : U2{0u, 0u}; },
-          [&](int p, U4 x, U2 sfl) {
-            if (x.a) {
-              const unsigned long long item = arr[p];
-              const unsigned c = x.d;
-              lds_a[c] = (item & 0xffffffff00000000ull) | c;
-              const_cast<unsigned char*>(lds_sc.tied)[c] = tied[static_cast<unsigned>(item)];
-              cpos[c] = static_cast<unsigned>(p);
-              cid[c] = static_cast<unsigned>(item);
-              if (x.b == static_cast<unsigned>(p)) queue_push(lds_sc.queue, static_cast<int>(sfl.a), static_cast<int>(sfl.b) + 1, depth);
-            }
-          });
-      const int T = static_cast<int>(active_total);
+      const int T = wl_base[n_batch];
+      unsigned* __restrict__ cid = l;  // packed index -> position in the slice (the item's low word)
+      for (int c = threadIdx.x; c < T; c += kThreads) {
+        int e = 0;
+        while (c >= wl_base[e + 1]) ++e;
+        const int p = wl_first[e0 + e] + (c - wl_base[e]);
+        const unsigned long long item = arr[p];
+        lds_a[c] = (item & 0xffffffff00000000ull) | static_cast<unsigned>(c);
+        const_cast<unsigned char*>(lds_sc.tied)[c] = tied[static_cast<unsigned>(item)];
+        cid[c] = static_cast<unsigned>(item);
+      }
+      if (static_cast<int>(threadIdx.x) < n_batch)
+        queue_push(lds_sc.queue, wl_base[threadIdx.x], wl_base[threadIdx.x + 1], wl_depth[e0 + threadIdx.x]);
       __syncthreads();
+      DLIOM_SSTAMP(11);
       if (!wave_sort_arrangement(lds_a, lds_sc)) ok = false;
+      DLIOM_SSTAMP(12);
+#ifdef DLIOM_EXPERIMENTS
+      if (threadIdx.x == 0 && blockIdx.x < 4) dbg_big[(blockIdx.x + 8) * 16 + 15] = static_cast<unsigned long long>(T) | (static_cast<unsigned long long>(dbg_round) << 32);
+#endif
       for (int q = threadIdx.x; q < T; q += kThreads) {
+        int e = 0;
+        while (q >= wl_base[e + 1]) ++e;
         const unsigned long long item = lds_a[q];
-        arr[cpos[q]] = (item & 0xffffffff00000000ull) | cid[static_cast<unsigned>(item) & 0xffffu];
+        arr[wl_first[e0 + e] + (q - wl_base[e])] = (item & 0xffffffff00000000ull) | cid[static_cast<unsigned>(item) & 0xffffu];
       }
       __syncthreads();
-      break;
+      if (threadIdx.x == 0) wl_n = e0;
+      __syncthreads();
+      if (!ok) break;
+      continue;
     }
+#ifdef DLIOM_EXPERIMENTS
+    if (dbg_round < 9) DLIOM_SSTAMP(1 + dbg_round);
+    ++dbg_round;
+#endif
+    const int first = wl_first[wl_pick], last = wl_last[wl_pick], depth = wl_depth[wl_pick];
     if (depth == 0) {
-      // std::sort's depth limit: heap sort (restated in rotational_histogram.hip) of what is left, one thread per segment
-      if (__syncthreads_or(heap_too_large) != 0) {
-        ok = false;
-        break;
-      }
-      for (int p = lo; p < hi; ++p)
-        if (act[p] && seg_first[p] == static_cast<unsigned>(p)) heap_sort_keys(arr + p, static_cast<int>(seg_last[p]) - p);
-      __syncthreads();
+      // std::sort's depth limit on a segment that large: its heap sort, sequential in HBM -- refused (the host takes the cloud)
+      ok = false;
       break;
     }
-    --depth;
     // (a) __move_median_to_first(first, first + 1, mid, last - 1)
-    for (int p = lo; p < hi; ++p)
-      if (act[p] && seg_first[p] == static_cast<unsigned>(p)) {
-        const int first = p, last = static_cast<int>(seg_last[p]);
-        const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
-        const unsigned ka = key_of(arr[ia]), kb = key_of(arr[ib]), kc = key_of(arr[ic]);
-        int md;
-        if (ka < kb) {
-          if (kb < kc) md = ib;
-          else if (ka < kc) md = ic;
-          else md = ia;
-        } else if (ka < kc) md = ia;
-        else if (kb < kc) md = ic;
-        else md = ib;
-        const unsigned long long tmp = arr[first];
-        arr[first] = arr[md];
-        arr[md] = tmp;
-      }
-    __syncthreads();
-    // (b) where the two pointers of __unguarded_partition stop
-    unsigned gc = 0u, lc = 0u;
-    for_owned4(
-        lo, hi, [&](int p) { return U4{static_cast<unsigned>(act[p]), seg_first[p], key_of(arr[p]), 0u}; },
-        [&](int, U4 x) { return x.a ? key_of(arr[x.b]) : 0u; },
-        [&](int p, U4 x, unsigned pivot) {
-          unsigned ge = 0u, le = 0u;
-          if (x.a && x.b != static_cast<unsigned>(p)) {
-            ge = x.c < pivot ? 0u : 1u;
-            le = pivot < x.c ? 0u : 1u;
-          }
-          fl[p] = static_cast<unsigned char>(ge | (le << 1));
-          gc += ge;
-          lc += le;
-        });
-    unsigned gtotal, ltotal;
-    unsigned gb = block_exclusive_scan(gc, wave_sums, &gtotal);
-    unsigned lb = block_exclusive_scan(lc, wave_sums, &ltotal);
-    for_owned4(
-        lo, hi, [&](int p) { return static_cast<unsigned>(fl[p]); }, [](int, unsigned) { return 0; },
-        [&](int p, unsigned f, int) {
-          g[p] = gb;
-          l[p] = lb;
-          gb += f & 1u;
-          lb += f >> 1;
-        });
     if (threadIdx.x == 0) {
-      g[m] = gtotal;
-      l[m] = ltotal;
+      const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+      const unsigned ka = key_of(arr[ia]), kb = key_of(arr[ib]), kc = key_of(arr[ic]);
+      int md;
+      if (ka < kb) {
+        if (kb < kc) md = ib;
+        else if (ka < kc) md = ic;
+        else md = ia;
+      } else if (ka < kc) md = ia;
+      else if (kb < kc) md = ic;
+      else md = ib;
+      const unsigned long long tmp = arr[first];
+      arr[first] = arr[md];
+      arr[md] = tmp;
     }
     __syncthreads();
-    for_owned4(
-        lo, hi, [&](int p) { return U4{static_cast<unsigned>(act[p]) != 0u ? static_cast<unsigned>(fl[p]) : 0u, seg_first[p], seg_last[p], g[p]}; },
-        [&](int p, U4 x) { return x.a != 0u ? U4{g[x.b + 1u], l[x.c], l[p + 1], 0u} : U4{0u, 0u, 0u, 0u}; },
-        [&](int p, U4 x, U4 y) {
-          if (x.b == static_cast<unsigned>(p)) return;  // the pivot
-          if (x.a & 1u) tmp_l[x.b + 1u + (x.d - y.a)] = static_cast<unsigned>(p);
-          if (x.a & 2u) tmp_r[x.b + 1u + (y.b - y.c)] = static_cast<unsigned>(p);
-        });
+    const unsigned pivot = key_of(arr[first]);
+    // (b) the stops of the two pointers, both lists in ascending order of position: wave w takes a contiguous share of
+    //     (first, last) in steps of 64 positions, four steps' loads in flight
+    const int n_in = last - (first + 1);
+    const int per_wave = ((n_in + (kThreads / 64) * 64 - 1) / ((kThreads / 64) * 64)) * 64;
+    const int w_lo = first + 1 + wave * per_wave, w_hi = min(last, w_lo + per_wave);
+    unsigned cl = 0u, cr = 0u;
+    for (int base = w_lo; base < w_hi; base += 256) {
+      unsigned x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = base + 64 * u + lane;
+        x[u] = p < w_hi ? key_of(arr[p]) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = base + 64 * u + lane < w_hi;
+        cl += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in && !(x[u] < pivot)));
+        cr += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in && !(pivot < x[u])));
+      }
+    }
+    if (lane == 0) {
+      co_cnt[0][wave] = cl;
+      co_cnt[1][wave] = cr;
+    }
     __syncthreads();
-    // (c) the k-th pair swaps while the pointers have not crossed; the thread at the boundary knows the cut
-    for_owned4(
-        lo, hi, [&](int q) { return U4{static_cast<unsigned>(act[q]), seg_first[q], seg_last[q], 0u}; },
-        [&](int q, U4 x) {
-          if (x.a == 0u || x.b == static_cast<unsigned>(q)) return U4{0u, 0u, 0u, 0u};
-          return U4{g[x.c] - g[x.b + 1u], l[x.c] - l[x.b + 1u], tmp_l[q], tmp_r[q]};
-        },
-        [&](int q, U4 x, U4 y) {
-          if (x.a == 0u || x.b == static_cast<unsigned>(q)) return;
-          const unsigned first = x.b, kk = static_cast<unsigned>(q) - (first + 1u);
-          const unsigned cnt_l = y.a, cnt_r = y.b;
-          const bool v = kk < cnt_l && kk < cnt_r && y.c < y.d;
-          if (v) {
-            const unsigned long long xl = arr[y.c], xr = arr[y.d];
-            arr[y.c] = xr;
-            arr[y.d] = xl;
-          }
-          auto valid = [&](unsigned j) { return j < cnt_l && j < cnt_r && tmp_l[first + 1u + j] < tmp_r[first + 1u + j]; };
-          int K = -1;
-          if (kk == 0u && !v) K = 0;
-          else if (v && !valid(kk + 1u)) K = static_cast<int>(kk) + 1;
-          if (K >= 0) {
-            unsigned i = 0x7fffffffu;
-            if (static_cast<unsigned>(K) < cnt_l) i = tmp_l[first + 1u + static_cast<unsigned>(K)];
-            if (K > 0) i = min(i, tmp_r[first + 1u + static_cast<unsigned>(K) - 1u]);
-            cut[first] = i;
-          }
-        });
+    unsigned at_l = 0u, at_r = 0u, cnt_l = 0u, cnt_r = 0u;
+    for (int w = 0; w < kThreads / 64; ++w) {
+      if (w < wave) {
+        at_l += co_cnt[0][w];
+        at_r += co_cnt[1][w];
+      }
+      cnt_l += co_cnt[0][w];
+      cnt_r += co_cnt[1][w];
+    }
+    unsigned* stops_l = tmp_l + first + 1;
+    unsigned* stops_r = tmp_r + first + 1;
+    for (int base = w_lo; base < w_hi; base += 256) {
+      unsigned x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = base + 64 * u + lane;
+        x[u] = p < w_hi ? key_of(arr[p]) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = base + 64 * u + lane;
+        const bool in = p < w_hi;
+        const bool ge = in && !(x[u] < pivot), le = in && !(pivot < x[u]);
+        const unsigned long long ml = __builtin_amdgcn_ballot_w64(ge), mr = __builtin_amdgcn_ballot_w64(le);
+        if (ge) stops_l[at_l + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(ml >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(ml), 0u))] = static_cast<unsigned>(p);
+        if (le) stops_r[at_r + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mr >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mr), 0u))] = static_cast<unsigned>(p);
+        at_l += __builtin_popcountll(ml);
+        at_r += __builtin_popcountll(mr);
+      }
+    }
+    if (threadIdx.x == 0) {
+      co_k = min(cnt_l, cnt_r);
+      co_tied[0] = co_tied[1] = 0u;
+    }
     __syncthreads();
-    // (d) [first, cut) and [cut, last)
-    for_owned4(
-        lo, hi, [&](int p) { return U2{static_cast<unsigned>(act[p]), seg_first[p]}; }, [&](int, U2 x) { return x.a ? cut[x.b] : 0u; },
-        [&](int p, U2 x, unsigned c) {
-          if (x.a) {
-            if (static_cast<unsigned>(p) < c) seg_last[p] = c;
-            else seg_first[p] = c;
+    // (c) the k-th stop from the left swaps with the k-th from the right while they have not crossed: K = the first k
+    //     that does not (the valid k are 0 .. K - 1: positions from the left grow with k, from the right they fall)
+    const unsigned lim = min(cnt_l, cnt_r);
+    {
+      unsigned first_invalid = lim;
+      for (unsigned k0 = threadIdx.x; k0 < lim; k0 += 4 * kThreads) {
+        unsigned a4[4], b4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned k = k0 + u * kThreads;
+          a4[u] = k < lim ? stops_l[k] : 0u;
+          b4[u] = k < lim ? stops_r[cnt_r - 1u - k] : 1u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned k = k0 + u * kThreads;
+          if (k < lim && !(a4[u] < b4[u])) first_invalid = min(first_invalid, k);
+        }
+      }
+      if (first_invalid < lim) atomicMin(&co_k, first_invalid);
+    }
+    __syncthreads();
+    const unsigned K = co_k;
+    for (unsigned k0 = threadIdx.x; k0 < K; k0 += 4 * kThreads) {
+      unsigned il[4], ir[4];
+      unsigned long long xl[4], xr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned k = k0 + u * kThreads;
+        il[u] = k < K ? stops_l[k] : 0u;
+        ir[u] = k < K ? stops_r[cnt_r - 1u - k] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xl[u] = arr[il[u]];
+        xr[u] = arr[ir[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + u * kThreads < K) {
+          arr[il[u]] = xr[u];
+          arr[ir[u]] = xl[u];
+        }
+    }
+    if (threadIdx.x == 0) {
+      unsigned c = 0x7fffffffu;  // where the left pointer stops next
+      if (K < cnt_l) c = stops_l[K];
+      if (K > 0u) c = min(c, stops_r[cnt_r - K]);
+      co_cut = static_cast<int>(c);
+    }
+    __syncthreads();
+    const int cut = co_cut;
+    // (d) [first, cut) and [cut, last): on the list if they are above the threshold and hold two tied elements
+    {
+      const int n_all = last - first;
+      const int pw = ((n_all + (kThreads / 64) * 64 - 1) / ((kThreads / 64) * 64)) * 64;
+      const int lo_w = first + wave * pw, hi_w = min(last, lo_w + pw);
+      unsigned tl = 0u, tr = 0u;
+      for (int base = lo_w; base < hi_w; base += 256) {
+        unsigned id4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = base + 64 * u + lane;
+          id4[u] = p < hi_w ? static_cast<unsigned>(arr[p]) : 0u;
+        }
+        unsigned char t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t4[u] = base + 64 * u + lane < hi_w ? tied[id4[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = base + 64 * u + lane;
+          tl += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t4[u] != 0 && p < cut));
+          tr += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t4[u] != 0 && p >= cut));
+        }
+      }
+      if (lane == 0) {
+        atomicAdd(&co_tied[0], tl);
+        atomicAdd(&co_tied[1], tr);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // replace the entry by its children that still matter
+      int n = wl_n;
+      wl_first[wl_pick] = wl_first[n - 1];
+      wl_last[wl_pick] = wl_last[n - 1];
+      wl_depth[wl_pick] = wl_depth[n - 1];
+      --n;
+      const int cf[2] = {first, cut}, cl2[2] = {cut, last};
+      for (int c = 0; c < 2; ++c)
+        if (cl2[c] - cf[c] > 16 && co_tied[c] >= 2u) {
+          if (n < kWorkListCap) {
+            wl_first[n] = cf[c];
+            wl_last[n] = cl2[c];
+            wl_depth[n] = depth - 1;
+            ++n;
+          } else {
+            wl_overflow = 1;
           }
-        });
+        }
+      wl_n = n;
+    }
     __syncthreads();
   }
+  if (wl_overflow != 0) ok = false;
   if (!ok) return false;
+  DLIOM_SSTAMP(13);
   // where the tied elements are in the arrangement
-  for_owned4(
-      lo, hi, [&](int q) { return static_cast<unsigned>(arr[q]); }, [&](int, unsigned id) { return static_cast<unsigned>(tied[id]); },
-      [&](int q, unsigned id, unsigned f) {
-        if (f) pos_of[id] = static_cast<unsigned>(q);
-      });
+  for (int q0 = static_cast<int>(threadIdx.x); q0 < m; q0 += 8 * kThreads) {
+    unsigned id8[8];
+    unsigned char f8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) id8[u] = static_cast<unsigned>(arr[min(q0 + u * kThreads, m - 1)]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f8[u] = tied[id8[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (q0 + u * kThreads < m && f8[u]) pos_of[id8[u]] = static_cast<unsigned>(q0 + u * kThreads);
+  }
   __syncthreads();
   // the final insertion sort is stable: a group of equal keys ends up in arrangement order
-  for_owned4(
-      lo, hi, [&](int j) { return sv[j]; }, [&](int, unsigned id) { return static_cast<unsigned>(tied[id]); },
-      [&](int j, unsigned id, unsigned f) {
+  for (int j0 = static_cast<int>(threadIdx.x); j0 < m; j0 += 8 * kThreads) {
+    unsigned id8[8];
+    unsigned char f8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) id8[u] = sv[min(j0 + u * kThreads, m - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f8[u] = tied[id8[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * kThreads;
+      if (j >= m) continue;
+      const unsigned id = id8[u];
+      {
         unsigned dst = static_cast<unsigned>(j);
-        if (f) {
+        if (f8[u]) {
           const unsigned key = static_cast<unsigned>(sk[j]);
           int gs = j, ge = j + 1;
           while (gs > 0 && static_cast<unsigned>(sk[gs - 1]) == key) --gs;
           while (ge < m && static_cast<unsigned>(sk[ge]) == key) ++ge;
           const unsigned mine = pos_of[id];
           unsigned r = 0u;
-          for (int u = gs; u < ge; ++u) r += pos_of[sv[u]] < mine ? 1u : 0u;
+          for (int w2 = gs; w2 < ge; ++w2) r += pos_of[sv[w2]] < mine ? 1u : 0u;
           dst = static_cast<unsigned>(gs) + r;
         }
         sorted_id[dst] = id;
-      });
+      }
+    }
+  }
   __syncthreads();
+  DLIOM_SSTAMP(14);
   return true;
 }
 
@@ -584,10 +740,24 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
   float* py = A.spy + off;
   int lo, hi;
   owned_range(m, &lo, &hi);
-  for (int j = lo; j < hi; ++j) {
-    const unsigned id = sorted_id[j];
-    px[j] = bx[id];
-    py[j] = by[id];
+  // (eight positions per thread at a time, position = tid + 1024 u: consecutive lanes on consecutive entries and all loads
+  // of a stage in flight together -- a plain loop over the thread's positions pays the memory latency once per position)
+  for (int j0 = static_cast<int>(threadIdx.x); j0 < m; j0 += 8 * kThreads) {
+    unsigned id[8];
+    float x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) id[u] = j0 + u * kThreads < m ? sorted_id[j0 + u * kThreads] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      x[u] = bx[id[u]];
+      y[u] = by[id[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u * kThreads < m) {
+        px[j0 + u * kThreads] = x[u];
+        py[j0 + u * kThreads] = y[u];
+      }
   }
   __syncthreads();
   DLIOM_BSTAMP(2);
@@ -598,13 +768,32 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
   exact_sum::block_sequential_sums<2>(arrays, m, zero, sums, es);
   const float cx = sums[0] / static_cast<float>(m), cy = sums[1] / static_cast<float>(m);
   DLIOM_BSTAMP(3);
-  unsigned char* dead = A.dead + off;
-  unsigned char* mark = A.mark + off;
-  unsigned* ja = A.jump_a + off;
-  unsigned* jb = A.jump_b + off;
-  for (int j = lo; j < hi; ++j) {
-    dead[j] = norm2(px[j] - cx, py[j] - cy) < kMinDistance ? 1 : 0;
-    mark[j] = j == 0 ? 1 : 0;
+  // the chain's arrays (next pointers twice, dead and mark bytes) live in LDS when the slice is small enough for that
+  // (15 000 points: the floor of a filtered 64-beam scan), else in HBM
+  const size_t chain_bytes = (static_cast<size_t>(m) + 4) * 10;
+  const bool chain_in_lds = chain_bytes <= kBigLdsBytes;
+  const int m4 = (m + 4) & ~3;
+  unsigned* ja = chain_in_lds ? reinterpret_cast<unsigned*>(big_lds) : A.jump_a + off;
+  unsigned* jb = chain_in_lds ? ja + m4 : A.jump_b + off;
+  unsigned char* dead = chain_in_lds ? reinterpret_cast<unsigned char*>(jb + m4) : A.dead + off;
+  unsigned char* mark = chain_in_lds ? dead + m4 : A.mark + off;
+  __syncthreads();  // (the exact sums' scratch lies under these arrays)
+  for (int j0 = static_cast<int>(threadIdx.x); j0 < m; j0 += 8 * kThreads) {
+    float x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = min(j0 + u * kThreads, m - 1);
+      x[u] = px[j];
+      y[u] = py[j];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * kThreads;
+      if (j < m) {
+        dead[j] = norm2(x[u] - cx, y[u] - cy) < kMinDistance ? 1 : 0;
+        mark[j] = j == 0 ? 1 : 0;
+      }
+    }
   }
   if (threadIdx.x == 0) {
     mark[m] = 0;
@@ -612,21 +801,41 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
     jb[m] = static_cast<unsigned>(m);
   }
   __syncthreads();
-  // next(i): the first live point farther than kMaxDistance from point i (squared lengths: rotational_histogram.hip)
-  for (int i = lo; i < hi; ++i) {
-    const float ax = px[i], ay = py[i];
-    int j = i + 1;
-    for (; j < m; ++j) {
-      if (dead[j]) continue;
-      const float dx = px[j] - ax, dy = py[j] - ay;
-      if (dx * dx + dy * dy >= squared_jump) break;
+  // next(i): the first live point farther than kMaxDistance from point i (squared lengths: rotational_histogram.hip).
+  // On a floor nearly every point's answer is i + 1: that candidate is tested for eight positions at once, the others
+  // walk on alone.
+  for (int i0 = static_cast<int>(threadIdx.x); i0 < m; i0 += 8 * kThreads) {
+    float ax[8], ay[8], nx[8], ny[8];
+    unsigned char nd[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + u * kThreads, m - 1), j = min(i + 1, m - 1);
+      ax[u] = px[i];
+      ay[u] = py[i];
+      nx[u] = px[j];
+      ny[u] = py[j];
+      nd[u] = dead[j];
     }
-    ja[i] = static_cast<unsigned>(j);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * kThreads;
+      if (i < m) {
+        int j = i + 1;
+        const float dx0 = nx[u] - ax[u], dy0 = ny[u] - ay[u];
+        if (!(j < m && nd[u] == 0 && dx0 * dx0 + dy0 * dy0 >= squared_jump)) {
+          for (j = min(i + 1, m); j < m; ++j) {
+            if (dead[j]) continue;
+            const float dx = px[j] - ax[u], dy = py[j] - ay[u];
+            if (dx * dx + dy * dy >= squared_jump) break;
+          }
+        }
+        ja[i] = static_cast<unsigned>(j);
+      }
+    }
   }
   __syncthreads();
   DLIOM_BSTAMP(4);
-  // (positions i = tid, tid + 1024, ... here: the levels need no prefix over positions, and consecutive lanes on
-  // consecutive entries with eight independent loads in flight hide the latency of the dependent gathers)
+  // marks spread along next^(2^d) while the pointers are squared
   for (int d = 0; (1 << d) < 2 * m; ++d) {
     for (int i0 = static_cast<int>(threadIdx.x); i0 < m; i0 += 8 * kThreads) {
       unsigned t[8], t2[8];
@@ -654,39 +863,89 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
     jb = t;
   }
   DLIOM_BSTAMP(5);
-  // last_point of point j = the last marked position before it (position 0 to begin with)
+  // last_point of point j = the last marked position before it (position 0 to begin with); thread t owns [lo, hi) here:
+  // the contributions keep the order of the points
   int last_marked = -1;
   for (int j = lo; j < hi; ++j)
     if (mark[j]) last_marked = j;
-  int anchor = max(0, block_exclusive_max(last_marked, -1, wave_max));
+  const int anchor0 = max(0, block_exclusive_max(last_marked, -1, wave_max));
+  constexpr int kOwn = 16;  // owned positions handled in registers (slices up to 16 384 points); more: the plain loop
   unsigned emitted = 0u;
-  // two passes over the owned points: count, then write in order
-  for (int pass = 0; pass < 2; ++pass) {
-    int a = anchor;
-    unsigned at = 0u;
-    if (pass == 1) {
-      unsigned total;
-      at = s.begin + block_exclusive_scan(emitted, wave_sums, &total);
-    }
-    for (int j = lo; j < hi; ++j) {
-      const int last_point = a;
-      const bool jump = mark[j] != 0 && j != 0;
-      if (mark[j]) a = j;
-      if (dead[j] || jump) continue;
-      const float pxj = px[j], pyj = py[j];
-      const float dx = pxj - px[last_point], dy = pyj - py[last_point];
-      const float distance = norm2(dx, dy);
-      if (distance < kMinDistance) continue;
-      if (pass == 0) {
-        ++emitted;
-        continue;
+  if (hi - lo <= kOwn) {
+    int anchor_of[kOwn];
+    bool live[kOwn];
+    {
+      int a = anchor0;
+#pragma unroll
+      for (int u = 0; u < kOwn; ++u) {
+        const int j = lo + u;
+        anchor_of[u] = a;
+        live[u] = false;
+        if (j < hi) {
+          const bool mk = mark[j] != 0;
+          live[u] = dead[j] == 0 && !(mk && j != 0);
+          if (mk) a = j;
+        }
       }
-      const float ex = pxj - cx, ey = pyj - cy;
-      const float direction_norm = norm2(ex, ey);
-      const float dot = (dx / distance) * (ex / direction_norm) + (dy / distance) * (ey / direction_norm);
-      c_bucket[at] = static_cast<unsigned char>(bucket_of(fd_atan2f(dy, dx), histogram_size));
-      c_value[at] = fmaxf(0.f, 1.f - fabsf(dot));
-      ++at;
+    }
+    float xj[kOwn], yj[kOwn], xa[kOwn], ya[kOwn];
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) {
+      const int j = min(lo + u, m - 1);
+      xj[u] = px[j];
+      yj[u] = py[j];
+      xa[u] = px[anchor_of[u]];
+      ya[u] = py[anchor_of[u]];
+    }
+    float dist[kOwn];
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) {
+      dist[u] = norm2(xj[u] - xa[u], yj[u] - ya[u]);
+      live[u] = live[u] && !(dist[u] < kMinDistance);
+      emitted += live[u] ? 1u : 0u;
+    }
+    unsigned total;
+    unsigned at = s.begin + block_exclusive_scan(emitted, wave_sums, &total);
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u)
+      if (live[u]) {
+        const float dx = xj[u] - xa[u], dy = yj[u] - ya[u];
+        const float ex = xj[u] - cx, ey = yj[u] - cy;
+        const float direction_norm = norm2(ex, ey);
+        const float dot = (dx / dist[u]) * (ex / direction_norm) + (dy / dist[u]) * (ey / direction_norm);
+        c_bucket[at] = static_cast<unsigned char>(bucket_of(fd_atan2f(dy, dx), histogram_size));
+        c_value[at] = fmaxf(0.f, 1.f - fabsf(dot));
+        ++at;
+      }
+  } else {
+    // two passes over the owned points: count, then write in order
+    for (int pass = 0; pass < 2; ++pass) {
+      int a = anchor0;
+      unsigned at = 0u;
+      if (pass == 1) {
+        unsigned total;
+        at = s.begin + block_exclusive_scan(emitted, wave_sums, &total);
+      }
+      for (int j = lo; j < hi; ++j) {
+        const int last_point = a;
+        const bool jump = mark[j] != 0 && j != 0;
+        if (mark[j]) a = j;
+        if (dead[j] || jump) continue;
+        const float pxj = px[j], pyj = py[j];
+        const float dx = pxj - px[last_point], dy = pyj - py[last_point];
+        const float distance = norm2(dx, dy);
+        if (distance < kMinDistance) continue;
+        if (pass == 0) {
+          ++emitted;
+          continue;
+        }
+        const float ex = pxj - cx, ey = pyj - cy;
+        const float direction_norm = norm2(ex, ey);
+        const float dot = (dx / distance) * (ex / direction_norm) + (dy / distance) * (ey / direction_norm);
+        c_bucket[at] = static_cast<unsigned char>(bucket_of(fd_atan2f(dy, dx), histogram_size));
+        c_value[at] = fmaxf(0.f, 1.f - fabsf(dot));
+        ++at;
+      }
     }
   }
   DLIOM_BSTAMP(6);

@@ -4,7 +4,7 @@
 // (sign s, exponent e: |acc| in [2^e, 2^(e+1)), ulp U = 2^(e-23)) it is an integer counter k = |acc| / U, and adding x
 // changes it by round(s x / U) with ties to even -- a function {parity of k} -> {increment, parity out} (ParityFn),
 // which composes associatively.  The real (double) prefix sums locate the accumulator within a rigorous error bound:
-//   chunk c (32 addends) is SAFE in binade (s, e) when [P_c + lo_c - E_c, P_c + hi_c + E_c] lies strictly inside it, where
+//   chunk c (16 addends) is SAFE in binade (s, e) when [P_c + lo_c - E_c, P_c + hi_c + E_c] lies strictly inside it, where
 //   P_c is the real prefix, lo/hi the extremes of the partial sums inside the chunk and
 //   E_c >= |float accumulator - real prefix| anywhere up to the end of chunk c: every addition rounds by at most half an
 //   ulp of its result, i.e. 2^-24 (|S_i| + err), so err <= i 2^-24 Mx / (1 - i 2^-24) with Mx the largest |real prefix|
@@ -37,7 +37,7 @@ inline ParityFn compose(const ParityFn& a, const ParityFn& b) {  // a first, the
 inline uint32_t bits_of(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float float_of(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
-constexpr int kChunk = 32;
+constexpr int kChunk = 16;
 constexpr int kNoCode = 0x7fffffff;
 // binade code of a float: sign << 16 | (biased exponent); kNoCode for 0, denormals, inf, nan
 inline int code_of(float a) {

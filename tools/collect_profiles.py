@@ -54,7 +54,8 @@ for name, o in (("bench_full.json", "%s_bench.json"), ("wref_full.json", "%s_wre
                 ("wref_stages.json", "%s_wref_stages.json"), ("stream.json", "%s_stream_config3.json"),
                 ("stream_gentle.json", "%s_stream_config3_gentle.json"), ("config5_bench.json", "%s_config5_bench.json"),
                 ("bench_gloo2.json", "%s_bench_gloo2.json"), ("fast_csm.json", "%s_fast_csm.json"),
-                ("fast_csm_full.json", "%s_fast_csm_full.json"), ("fast_csm_dense.json", "%s_fast_csm_dense.json")):
+                ("fast_csm_full.json", "%s_fast_csm_full.json"), ("fast_csm_dense.json", "%s_fast_csm_dense.json"),
+                ("hist_bench.json", "%s_hist_bench.json"), ("bench_rccl_1rank.json", "%s_bench_rccl_1rank.json")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
@@ -62,6 +63,15 @@ for name, o in (("bench_full.json", "%s_bench.json"), ("wref_full.json", "%s_wre
             open(os.path.join(dst, o % tag), "w").write(lines[-1] + "\n")
 h = os.path.join(src, "histogram.txt")
 if os.path.exists(h):
-    keep = [l for l in open(h).read().splitlines() if "histogram" in l or "rothist" in l or l.startswith('"Name"')]
+    keep = [l for l in open(h).read().splitlines() if "histogram" in l or "rothist" in l or l.startswith('"Name"') or l.startswith("==")
+            or l.startswith("{") or "rocprim" in l or "fill_multi" in l or "gather_to_pinned" in l]
     open(os.path.join(dst, "%s_histogram_kernels.txt" % tag), "w").write("\n".join(keep) + "\n")
+for name, o in (("wref_trace", "%s_wref_full_rocprofv3_kernel_stats.csv"), ("wref_trace_yard", "%s_wref_full_yard_rocprofv3_kernel_stats.csv")):
+    for f in glob.glob(os.path.join(src, name, "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, o % tag))
+g = os.path.join(src, "gputest.log")
+if os.path.exists(g):
+    lines = [l for l in open(g).read().splitlines() if l.strip()]
+    keep = [l for l in lines if "passed" in l or "failed" in l or "fuzz ok" in l or "windowed mirror" in l or "manifold vs tangent" in l]
+    open(os.path.join(dst, "%s_gputest_summary.txt" % tag), "w").write("\n".join(keep) + "\n")
 print(sorted(os.listdir(dst)))

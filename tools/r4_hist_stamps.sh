@@ -31,6 +31,11 @@ for scene, size in (("cube", 0.15), ("ground", 0.15), ("ground", 0.0)):
     for b in range(2):
         print("  big prepare wg", b, [int(a[b, k + 1] - a[b, k]) for k in range(4)])
         print("  big slice   wg", b, "count/m", a[4 + b, 10], a[4 + b, 11], [int(a[4 + b, k + 1] - a[4 + b, k]) for k in range(6)])
+    so = a[8]
+    rounds = int(so[15] >> 32)
+    print("  big sort order: tie detect + init", int(so[1] - so[0]), "global rounds", [int(so[k + 1] - so[k]) for k in range(1, min(rounds, 8))],
+          "handover T", int(so[15] & 0xffffffff), "prep", int(so[11] - so[min(rounds, 9)]), "LDS replay", int(so[12] - so[11]),
+          "write back", int(so[13] - so[12]), "tie groups", int(so[14] - so[13]))
     cloud.close()
 PY
 DLIOM_LIB=$R/d-liom_amd/ab/libdliom_exp.so timeout 300 python /tmp/hist_dbg.py
