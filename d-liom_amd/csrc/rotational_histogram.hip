@@ -1471,6 +1471,39 @@ extern "C" int dliom_cloud_rotational_histogram(dliom_ctx* ctx, const dliom_clou
   return run_histogram(ctx, ctx->stream, ctx->misc, h, ctx->done_word, &ctx->done_seq, cloud, rotation_wxyz, histogram_size, histogram);
 }
 
+// Test hook: the (bucket, value) pairs the histogram is summed from, in the order of the additions (slice order, then the
+// order of the sorted points) -- the arrays accumulate_kernel reads, compacted.  A histogram of sums in the hundreds cannot
+// tell whether a contribution of 1e-5 went into the right bucket; this can.  Blocking; up to `capacity` entries stored.
+extern "C" int dliom_diag_histogram_contributions(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
+                                                  int histogram_size, int32_t* buckets, float* values, int64_t capacity,
+                                                  int64_t* count) {
+  if (ctx == nullptr || cloud == nullptr || count == nullptr || capacity < 0 || (capacity > 0 && (buckets == nullptr || values == nullptr)))
+    return DLIOM_ERR_INVALID_ARGUMENT;
+  *count = 0;
+  if (cloud->n == 0) return DLIOM_OK;
+  std::vector<float> histogram(static_cast<size_t>(histogram_size > 0 ? histogram_size : 1));
+  DLIOM_TRY(dliom_cloud_rotational_histogram(ctx, cloud, rotation_wxyz, histogram_size, histogram.data()));
+  // the layout of enqueue_histogram's scratch (ctx->misc, untouched since the call above returned)
+  const size_t N = static_cast<size_t>(cloud->n);
+  const size_t n_padded = (N + 1023) & ~static_cast<size_t>(1023);
+  const char* base = static_cast<const char*>(ctx->misc.p);
+  std::vector<float> v(n_padded);
+  std::vector<unsigned char> b(n_padded);
+  DLIOM_HIP_TRY(hipMemcpy(v.data(), base + 3 * n_padded * 4, n_padded * 4, hipMemcpyDeviceToHost));
+  DLIOM_HIP_TRY(hipMemcpy(b.data(), base + 4 * n_padded * 4 + n_padded * 2, n_padded, hipMemcpyDeviceToHost));
+  int64_t at = 0;
+  for (size_t i = 0; i < n_padded; ++i) {
+    if (b[i] == 0xFFu) continue;
+    if (at < capacity) {
+      buckets[at] = b[i];
+      values[at] = v[i];
+    }
+    ++at;
+  }
+  *count = at;
+  return DLIOM_OK;
+}
+
 // The same in two halves on the context's auxiliary stream: everything enqueued on the context so far is waited for
 // (an event), then the histogram runs BESIDE whatever the caller puts on the context next -- the reference computes it
 // right after InsertIntoSubmap from the same filtered cloud (local_trajectory_builder_3d.cc:590-610); neither writes it.

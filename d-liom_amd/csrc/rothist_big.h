@@ -871,7 +871,11 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
   const int anchor0 = max(0, block_exclusive_max(last_marked, -1, wave_max));
   constexpr int kOwn = 16;  // owned positions handled in registers (slices up to 16 384 points); more: the plain loop
   unsigned emitted = 0u;
-  if (hi - lo <= kOwn) {
+  // (the choice must be the same for every thread: both branches hold the workgroup's prefix scan, and the last thread
+  // with points owns fewer than the others -- chosen per thread, its wave ran both branches, barriers and all, one after
+  // the other and that thread's contributions landed on top of its wave's first ones: slices above 16 384 points whose
+  // last owner had any, found in round 4 on the 20 090-point floor of a noise-free 128 x 2048 scan)
+  if ((m + kThreads - 1) / kThreads <= kOwn) {
     int anchor_of[kOwn];
     bool live[kOwn];
     {

@@ -290,6 +290,8 @@ SYMBOLS = [
     ("dliom_cloud_rotational_histogram_finish", C.c_int, [_vp, _f32p]),
     ("dliom_diag_std_sort_order", C.c_int, [_vp, _f32p, C.c_int, C.POINTER(C.c_int32)]),
     ("dliom_diag_sequential_sums", C.c_int, [_vp, _f32p, C.c_int, C.c_int, _f32p, _f32p]),
+    ("dliom_diag_histogram_contributions", C.c_int, [_vp, _vp, _f32p, C.c_int, C.POINTER(C.c_int32), _f32p, C.c_int64,
+                                                      C.POINTER(C.c_int64)]),
     ("dliom_rotational_scan_match", C.c_int, [_f32p, _f32p, C.c_int, C.c_int, _f32p, C.c_float, _f32p, C.c_int, _f32p]),
     ("dliom_rtcsm2d_match", C.c_int, [C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _u16p, C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_double, _f64p, _f64p]),
@@ -1272,6 +1274,19 @@ def diag_sequential_sums(ctx, values, acc0=None):
     _check(load_library().dliom_diag_sequential_sums(ctx.h, _p(v, _f32p), k, n, _p(a, _f32p), _p(out, _f32p)),
            "dliom_diag_sequential_sums")
     return out
+
+
+def diag_histogram_contributions(ctx, cloud, histogram_size, rotation_wxyz=None):
+    """dliom_diag_histogram_contributions: (buckets, values) of every addition the device histogram is made of, in order."""
+    cap = int(cloud.n) + 1
+    buckets = np.zeros(cap, dtype=np.int32)
+    values = np.zeros(cap, dtype=np.float32)
+    count = C.c_int64(0)
+    rot = None if rotation_wxyz is None else _p(_f32(rotation_wxyz), _f32p)
+    _check(load_library().dliom_diag_histogram_contributions(ctx.h, cloud.h, rot, int(histogram_size),
+                                                             buckets.ctypes.data_as(C.POINTER(C.c_int32)), _p(values, _f32p), cap,
+                                                             C.byref(count)), "dliom_diag_histogram_contributions")
+    return buckets[:count.value].copy(), values[:count.value].copy()
 
 
 def diag_std_sort_order(ctx, keys):

@@ -554,6 +554,12 @@ int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int n, int32_t*
  * histogram(bucket) += value (rotational_scan_matcher.cc:49,52-59): k arrays of n floats (values: k x n, row major),
  * sums[i] = (((acc0[i] + v[0]) + v[1]) + ...) in exactly that order, computed by one workgroup per array. */
 int dliom_diag_sequential_sums(dliom_ctx* ctx, const float* values, int k, int n, const float* acc0, float* sums);
+/* Diagnostic: every `histogram(bucket) += value` of dliom_cloud_rotational_histogram as (bucket, value) in the order of
+ * the additions (AddValueToHistogram, rotational_scan_matcher.cc:35-50: slices in key order, points in SortSlice's
+ * order).  Stronger than comparing histograms: a bucket whose sum is in the hundreds hides a contribution of 1e-5 that
+ * went elsewhere.  Blocking; stores the first `capacity` pairs, *count = how many there are. */
+int dliom_diag_histogram_contributions(dliom_ctx* ctx, const dliom_cloud* cloud, const float rotation_wxyz[4],
+                                       int histogram_size, int32_t* buckets, float* values, int64_t capacity, int64_t* count);
 /* The same with an explicit number of host threads (0 = as many as pay, at most 8; the bits do not depend on it). */
 int dliom_rotational_histogram_mt(const float* points_xyz, int64_t n, int histogram_size, int num_threads, float* histogram);
 /* RotationalScanMatcher(histograms_at_angles).Match(histogram, initial_angle, angles)

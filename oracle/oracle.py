@@ -132,6 +132,7 @@ def _declare(L):
     sig("orc_fast_csm_match_3dof", None, vp, _f64p, _f64p, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_float,
         _f64p, _f64p)
     sig("orc_compute_histogram", None, _f32p, C.c_int, C.c_int, _f32p)
+    sig("orc_histogram_contributions", C.c_int, _f32p, C.c_int, C.c_int, C.POINTER(C.c_int), _f32p, C.c_int)
     sig("orc_std_sort_order", None, _f32p, C.c_int, C.POINTER(C.c_int))
     sig("orc_accumulator_new", C.c_void_p)
     sig("orc_accumulator_free", None, C.c_void_p)
@@ -773,6 +774,17 @@ def compute_histogram(pts, histogram_size):
     out = np.zeros(histogram_size, dtype=np.float32)
     lib().orc_compute_histogram(_p(pts, _f32p), len(pts), histogram_size, _p(out, _f32p))
     return out
+
+
+def histogram_contributions(pts, histogram_size):
+    """(buckets, values) of every `histogram(bucket) += value` of ComputeHistogram, in the order they happen."""
+    pts = _f32(pts).reshape(-1, 3)
+    cap = len(pts) + 1
+    buckets = np.zeros(cap, dtype=np.int32)
+    values = np.zeros(cap, dtype=np.float32)
+    total = lib().orc_histogram_contributions(_p(pts, _f32p), len(pts), histogram_size,
+                                              buckets.ctypes.data_as(C.POINTER(C.c_int)), _p(values, _f32p), cap)
+    return buckets[:total].copy(), values[:total].copy()
 
 
 def std_sort_order(keys):

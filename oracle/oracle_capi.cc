@@ -783,6 +783,20 @@ void orc_compute_histogram(const float* pts, int n, int histogram_size, float* o
   const Histogram h = ComputeHistogram(ToCloud(pts, n), histogram_size);
   std::memcpy(out, h.data(), sizeof(float) * histogram_size);
 }
+// ComputeHistogram's additions one by one: (bucket, value) in the order `histogram(bucket) += value` happens; returns how
+// many there were (the first `capacity` are stored).
+int orc_histogram_contributions(const float* pts, int n, int histogram_size, int* buckets, float* values, int capacity) {
+  std::vector<std::pair<int, float>> trace;
+  rsm_detail::ContributionTrace() = &trace;
+  (void)ComputeHistogram(ToCloud(pts, n), histogram_size);
+  rsm_detail::ContributionTrace() = nullptr;
+  const int total = static_cast<int>(trace.size());
+  for (int i = 0; i < total && i < capacity; ++i) {
+    buckets[i] = trace[static_cast<size_t>(i)].first;
+    values[i] = trace[static_cast<size_t>(i)].second;
+  }
+  return total;
+}
 // The order this machine's std::sort leaves (key, index) pairs in when compared by key only -- SortSlice's comparison
 // (rotational_scan_matcher.cc:97-121); what the device's restatement of introsort is checked against.
 void orc_std_sort_order(const float* keys, int n, int* order) {

@@ -209,6 +209,13 @@ constexpr float kMaxDistance = 0.9f;
 constexpr float kSliceHeight = 0.2f;
 inline float Norm2(float x, float y) { return std::sqrt(x * x + y * y); }
 
+// Test instrumentation (not in the reference): when set, every (bucket, value) AddValueToHistogram adds is appended here
+// in the order of the additions -- the histogram alone cannot tell whether a contribution of 1e-5 went into the right
+// bucket once that bucket's sum is in the hundreds.
+inline std::vector<std::pair<int, float>>*& ContributionTrace() {
+  static thread_local std::vector<std::pair<int, float>>* trace = nullptr;
+  return trace;
+}
 // rotational_scan_matcher.cc:35-50
 inline void AddValueToHistogram(float angle, float value, Histogram* histogram) {
   while (angle > static_cast<float>(M_PI)) angle -= static_cast<float>(M_PI);
@@ -217,6 +224,7 @@ inline void AddValueToHistogram(float angle, float value, Histogram* histogram) 
   const int size = static_cast<int>(histogram->size());
   int bucket = RoundToInt(static_cast<float>(size) * zero_to_one - 0.5f);
   bucket = std::min(std::max(bucket, 0), size - 1);
+  if (ContributionTrace() != nullptr) ContributionTrace()->emplace_back(bucket, value);
   (*histogram)[bucket] += value;
 }
 // :52-59

@@ -72,6 +72,12 @@ def main(argv=None):
             if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
                 print("MISMATCH histogram seed %d mode %d n %d size %d: %d buckets, max %g" % (seed, mode, len(pts), hsize, int((got != want).sum()), float(np.abs(got - want).max())))
                 return 1
+            # ... and addition by addition: a bucket whose sum is in the hundreds hides a contribution of 1e-5 gone astray
+            gb, gv = dl.diag_histogram_contributions(ctx, cloud, hsize, rotation_wxyz=rot)
+            wb, wv = orc.histogram_contributions(aligned, hsize)
+            if len(gb) != len(wb) or not np.array_equal(gb, wb) or not np.array_equal(gv.view(np.uint32), wv.view(np.uint32)):
+                print("MISMATCH contributions seed %d mode %d n %d size %d: %d on the device, %d in the oracle" % (seed, mode, len(pts), hsize, len(gb), len(wb)))
+                return 1
             cloud.close()
             counts["histogram"] += 1
         elif kind == 1:  # std::sort's order

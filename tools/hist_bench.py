@@ -55,6 +55,10 @@ def main():
         if args.check:
             want = np.asarray(orc.compute_histogram(aligned, 120), np.float32)
             rec["equals_oracle"] = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+            gb, gv = dl.diag_histogram_contributions(ctx, cloud, 120, use_rot)  # addition by addition
+            wb, wv = orc.histogram_contributions(aligned, 120)
+            rec["additions"] = int(len(wb))
+            rec["additions_equal"] = bool(len(gb) == len(wb) and np.array_equal(gb, wb) and np.array_equal(gv.view(np.uint32), wv.view(np.uint32)))
         out[name] = rec
         cloud.close()
     out["poll_fallbacks"] = ctx.poll_fallbacks()
