@@ -57,20 +57,84 @@ __device__ __forceinline__ double lut_probability(unsigned v, float k_scale, flo
   return static_cast<double>(p);
 }
 
+// The eight voxels around (ix, iy, iz): ix / ix + 1 etc.  The index arithmetic per axis is done once (two values each)
+// and combined with ORs -- eight calls of grid_value() were eight times the whole sequence, with 64-bit
+// multiply-adds (quarter rate) in it; csm_lm_kernel is bound by instruction issue.  32-bit offsets: bits <= 7
+// (table and pool below 4 GiB); bits = 8 grids take grid_value().
+__device__ __forceinline__ void grid_corner_values(const GridView& g, int ix, int iy, int iz, unsigned (&v)[8]) {
+  if (g.log2_leaves > 10) {  // uniform
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = grid_value(g, ix + (k >> 2), iy + ((k >> 1) & 1), iz + (k & 1));
+    return;
+  }
+  const unsigned lb = static_cast<unsigned>(g.log2_leaves);
+  unsigned tx[2], ty[2], tz[2], cx[2], cy[2], cz[2];
+  bool in_x[2], in_y[2], in_z[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const unsigned sx = static_cast<unsigned>(ix + k + g.half), sy = static_cast<unsigned>(iy + k + g.half),
+                   sz = static_cast<unsigned>(iz + k + g.half);
+    in_x[k] = sx < g.grid_size;
+    in_y[k] = sy < g.grid_size;
+    in_z[k] = sz < g.grid_size;
+    tx[k] = sx >> 3;
+    ty[k] = (sy >> 3) << lb;
+    tz[k] = (sz >> 3) << (2u * lb);
+    cx[k] = (sx & 7u) << 1;
+    cy[k] = (sy & 7u) << 4;
+    cz[k] = (sz & 7u) << 7;
+  }
+  unsigned slot[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {  // k = x << 2 | y << 1 | z
+    const int kx = k >> 2, ky = (k >> 1) & 1, kz = k & 1;
+    const bool inside = in_x[kx] && in_y[ky] && in_z[kz];
+    const unsigned tidx = inside ? (tz[kz] | ty[ky] | tx[kx]) : 0u;
+    slot[k] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(g.table) + (tidx << 2));
+    slot[k] = inside ? slot[k] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int kx = k >> 2, ky = (k >> 1) & 1, kz = k & 1;
+    v[k] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.pool) + ((slot[k] << 10) | cz[kz] | cy[ky] | cx[kx]));
+  }
+}
+
+// 1 / d for d near the grid resolution: a float seed (IEEE float division) and two Newton steps -- a double division
+// is a dependent sequence of ~35 instructions, three of them per point.  (Within an ulp of the correctly rounded
+// reciprocal; the cost functor's parity bar is 1e-9.)
+__device__ __forceinline__ double fast_reciprocal(double d) {
+  double y = static_cast<double>(1.0f / static_cast<float>(d));
+  y = fma(y, fma(-d, y, 1.0), y);
+  y = fma(y, fma(-d, y, 1.0), y);
+  return y;
+}
+
 // One point: residual r = s (1 - P(T p)) and its 6 tangent-space derivatives.
+// The double-precision arithmetic is written in explicit fused multiply-adds (round 4: a third fewer instructions --
+// csm_lm_kernel is bound by instruction issue; the values differ from the reference's separately rounded operations in
+// the last bits, far inside the 1e-9 bar against the oracle's Jets).  Explicit, not `#pragma clang fp contract`: which
+// products a contracting compiler fuses depends on what the function is inlined into, and the one-launch kernel, the
+// evaluation kernel and the grid-barrier kernel must produce the same bits.  The float block in between -- which cell,
+// which side of its centre: interpolated_grid.h:123-139 -- is the reference's arithmetic to the bit.
+__device__ __forceinline__ double cross_term(double a, double b, double c, double d) { return fma(a, b, -(c * d)); }  // a b - c d
+// interpolated_grid.h:88-102, one axis: (a - b) n^3 2 + (b - a) n^2 3 + a, with c3 = 2 n^3 and c2 = 3 n^2
+__device__ __forceinline__ double smooth_mix(double a, double b, double c3, double c2) { return fma(a - b, c3, fma(b - a, c2, a)); }
+// ... and its derivative by n: (a - b) n^2 6 + (b - a) n 6, with e2 = 6 n^2 and e1 = 6 n
+__device__ __forceinline__ double smooth_mix_dn(double a, double b, double e2, double e1) { return fma(a - b, e2, (b - a) * e1); }
+
 __device__ __forceinline__ void csm_point_v(const CsmPose& a, const CsmCloudArg& c, double vx, double vy, double vz,
                                             float k_scale, float k_offset, float k_unknown,
                                             double* r_out, double jrow[6]) {
   const double qw = a.q[0], ux = a.q[1], uy = a.q[2], uz = a.q[3];
   // Eigen _transformVector on doubles: uv = 2 (u x v); world = (v + w uv) + u x uv, then + t
-  double uvx = uy * vz - uz * vy, uvy = uz * vx - ux * vz, uvz = ux * vy - uy * vx;
+  double uvx = cross_term(uy, vz, uz, vy), uvy = cross_term(uz, vx, ux, vz), uvz = cross_term(ux, vy, uy, vx);
   uvx = uvx + uvx;
   uvy = uvy + uvy;
   uvz = uvz + uvz;
-  const double cx = uy * uvz - uz * uvy, cy = uz * uvx - ux * uvz, cz = ux * uvy - uy * uvx;
-  const double wx = ((vx + qw * uvx) + cx) + a.t[0];
-  const double wy = ((vy + qw * uvy) + cy) + a.t[1];
-  const double wz = ((vz + qw * uvz) + cz) + a.t[2];
+  const double wx = (fma(qw, uvx, vx) + cross_term(uy, uvz, uz, uvy)) + a.t[0];
+  const double wy = (fma(qw, uvy, vy) + cross_term(uz, uvx, ux, uvz)) + a.t[1];
+  const double wz = (fma(qw, uvz, vz) + cross_term(ux, uvy, uy, uvx)) + a.t[2];
 
   // interpolated_grid.h:123-139: cell of the point (double -> float), centre in float, step down
   // where the float centre exceeds the double coordinate; x2 = x1 + resolution in float.
@@ -87,40 +151,36 @@ __device__ __forceinline__ void csm_point_v(const CsmPose& a, const CsmCloudArg&
   const double x2 = static_cast<double>(lx + res), y2 = static_cast<double>(ly + res),
                z2 = static_cast<double>(lz + res);
   const int ix = cell_of(lx, res), iy = cell_of(ly, res), iz = cell_of(lz, res);
-  const double q111 = lut_probability(grid_value(c.g, ix, iy, iz), k_scale, k_offset, k_unknown);
-  const double q112 = lut_probability(grid_value(c.g, ix, iy, iz + 1), k_scale, k_offset, k_unknown);
-  const double q121 = lut_probability(grid_value(c.g, ix, iy + 1, iz), k_scale, k_offset, k_unknown);
-  const double q122 = lut_probability(grid_value(c.g, ix, iy + 1, iz + 1), k_scale, k_offset, k_unknown);
-  const double q211 = lut_probability(grid_value(c.g, ix + 1, iy, iz), k_scale, k_offset, k_unknown);
-  const double q212 = lut_probability(grid_value(c.g, ix + 1, iy, iz + 1), k_scale, k_offset, k_unknown);
-  const double q221 = lut_probability(grid_value(c.g, ix + 1, iy + 1, iz), k_scale, k_offset, k_unknown);
-  const double q222 = lut_probability(grid_value(c.g, ix + 1, iy + 1, iz + 1), k_scale, k_offset, k_unknown);
+  unsigned corner[8];
+  grid_corner_values(c.g, ix, iy, iz, corner);
+  const double q111 = lut_probability(corner[0], k_scale, k_offset, k_unknown);
+  const double q112 = lut_probability(corner[1], k_scale, k_offset, k_unknown);
+  const double q121 = lut_probability(corner[2], k_scale, k_offset, k_unknown);
+  const double q122 = lut_probability(corner[3], k_scale, k_offset, k_unknown);
+  const double q211 = lut_probability(corner[4], k_scale, k_offset, k_unknown);
+  const double q212 = lut_probability(corner[5], k_scale, k_offset, k_unknown);
+  const double q221 = lut_probability(corner[6], k_scale, k_offset, k_unknown);
+  const double q222 = lut_probability(corner[7], k_scale, k_offset, k_unknown);
 
   // Jet / scalar multiplies by the reciprocal (ceres/jet.h operator/(Jet, T)).
-  const double inv_dx = 1.0 / (x2 - x1), inv_dy = 1.0 / (y2 - y1), inv_dz = 1.0 / (z2 - z1);
+  const double inv_dx = fast_reciprocal(x2 - x1), inv_dy = fast_reciprocal(y2 - y1), inv_dz = fast_reciprocal(z2 - z1);
   const double nx = (wx - x1) * inv_dx, ny = (wy - y1) * inv_dy, nz = (wz - z1) * inv_dz;
-  const double nxx = nx * nx, nxxx = nx * nxx;
-  const double nyy = ny * ny, nyyy = ny * nyy;
-  const double nzz = nz * nz, nzzz = nz * nzz;
+  const double nxx = nx * nx, nyy = ny * ny, nzz = nz * nz;
+  const double x3 = 2. * (nx * nxx), x2c = 3. * nxx, xe2 = 6. * nxx, xe1 = 6. * nx;
+  const double y3 = 2. * (ny * nyy), y2c = 3. * nyy, ye2 = 6. * nyy, ye1 = 6. * ny;
+  const double z3 = 2. * (nz * nzz), z2c = 3. * nzz, ze2 = 6. * nzz, ze1 = 6. * nz;
   // interpolated_grid.h:88-102, z then y then x; d(.)/dn alongside.
-  const double q11 = (q111 - q112) * nzzz * 2. + (q112 - q111) * nzz * 3. + q111;
-  const double q12 = (q121 - q122) * nzzz * 2. + (q122 - q121) * nzz * 3. + q121;
-  const double q21 = (q211 - q212) * nzzz * 2. + (q212 - q211) * nzz * 3. + q211;
-  const double q22 = (q221 - q222) * nzzz * 2. + (q222 - q221) * nzz * 3. + q221;
-  const double d11 = (q111 - q112) * nzz * 6. + (q112 - q111) * nz * 6.;
-  const double d12 = (q121 - q122) * nzz * 6. + (q122 - q121) * nz * 6.;
-  const double d21 = (q211 - q212) * nzz * 6. + (q212 - q211) * nz * 6.;
-  const double d22 = (q221 - q222) * nzz * 6. + (q222 - q221) * nz * 6.;
-  const double q1 = (q11 - q12) * nyyy * 2. + (q12 - q11) * nyy * 3. + q11;
-  const double q2 = (q21 - q22) * nyyy * 2. + (q22 - q21) * nyy * 3. + q21;
-  const double q1_z = (d11 - d12) * nyyy * 2. + (d12 - d11) * nyy * 3. + d11;
-  const double q2_z = (d21 - d22) * nyyy * 2. + (d22 - d21) * nyy * 3. + d21;
-  const double q1_y = (q11 - q12) * nyy * 6. + (q12 - q11) * ny * 6.;
-  const double q2_y = (q21 - q22) * nyy * 6. + (q22 - q21) * ny * 6.;
-  const double P = (q1 - q2) * nxxx * 2. + (q2 - q1) * nxx * 3. + q1;
-  const double P_nx = (q1 - q2) * nxx * 6. + (q2 - q1) * nx * 6.;
-  const double P_ny = (q1_y - q2_y) * nxxx * 2. + (q2_y - q1_y) * nxx * 3. + q1_y;
-  const double P_nz = (q1_z - q2_z) * nxxx * 2. + (q2_z - q1_z) * nxx * 3. + q1_z;
+  const double q11 = smooth_mix(q111, q112, z3, z2c), q12 = smooth_mix(q121, q122, z3, z2c);
+  const double q21 = smooth_mix(q211, q212, z3, z2c), q22 = smooth_mix(q221, q222, z3, z2c);
+  const double d11 = smooth_mix_dn(q111, q112, ze2, ze1), d12 = smooth_mix_dn(q121, q122, ze2, ze1);
+  const double d21 = smooth_mix_dn(q211, q212, ze2, ze1), d22 = smooth_mix_dn(q221, q222, ze2, ze1);
+  const double q1 = smooth_mix(q11, q12, y3, y2c), q2 = smooth_mix(q21, q22, y3, y2c);
+  const double q1_z = smooth_mix(d11, d12, y3, y2c), q2_z = smooth_mix(d21, d22, y3, y2c);
+  const double q1_y = smooth_mix_dn(q11, q12, ye2, ye1), q2_y = smooth_mix_dn(q21, q22, ye2, ye1);
+  const double P = smooth_mix(q1, q2, x3, x2c);
+  const double P_nx = smooth_mix_dn(q1, q2, xe2, xe1);
+  const double P_ny = smooth_mix(q1_y, q2_y, x3, x2c);
+  const double P_nz = smooth_mix(q1_z, q2_z, x3, x2c);
   const double gx = P_nx * inv_dx, gy = P_ny * inv_dy, gz = P_nz * inv_dz;  // dP/dworld
 
   const double s = c.scale;
@@ -134,39 +194,33 @@ __device__ __forceinline__ void csm_point_v(const CsmPose& a, const CsmCloudArg&
   //   d/dw   = 2 (u x v) = uv
   //   d/du_k = 2 w (e_k x v) + 2 e_k x (u x v) + 2 u x (e_k x v)
   const double hx = 0.5 * uvx, hy = 0.5 * uvy, hz = 0.5 * uvz;  // u x v (exact halving)
+  auto dot3 = [](double p0, double p1, double p2, double q0, double q1v, double q2v) { return fma(p2, q2v, fma(p1, q1v, p0 * q0)); };
   double dq[4];
-  dq[0] = ax * uvx + ay * uvy + az * uvz;
+  dq[0] = dot3(ax, ay, az, uvx, uvy, uvz);
   {
-    // e_x x v = (0, -vz, vy); e_x x h = (0, -hz, hy); u x (e_x x v)
-    const double ex = 0., ey = -vz, ez = vy;
-    const double fx = 0., fy = -hz, fz = hy;
-    const double gxv = uy * ez - uz * ey, gyv = uz * ex - ux * ez, gzv = ux * ey - uy * ex;
-    const double dxw = 2. * (qw * ex + fx + gxv), dyw = 2. * (qw * ey + fy + gyv),
-                 dzw = 2. * (qw * ez + fz + gzv);
-    dq[1] = ax * dxw + ay * dyw + az * dzw;
+    // e_x x v = (0, -vz, vy); e_x x h = (0, -hz, hy); u x (e_x x v) = (uy vy + uz vz, -ux vy, -ux vz)
+    const double gxv = fma(uy, vy, uz * vz), gyv = -(ux * vy), gzv = -(ux * vz);
+    const double dxw = 2. * gxv, dyw = 2. * (fma(qw, -vz, -hz) + gyv), dzw = 2. * (fma(qw, vy, hy) + gzv);
+    dq[1] = dot3(ax, ay, az, dxw, dyw, dzw);
   }
   {
-    const double ex = vz, ey = 0., ez = -vx;
-    const double fx = hz, fy = 0., fz = -hx;
-    const double gxv = uy * ez - uz * ey, gyv = uz * ex - ux * ez, gzv = ux * ey - uy * ex;
-    const double dxw = 2. * (qw * ex + fx + gxv), dyw = 2. * (qw * ey + fy + gyv),
-                 dzw = 2. * (qw * ez + fz + gzv);
-    dq[2] = ax * dxw + ay * dyw + az * dzw;
+    // e_y x v = (vz, 0, -vx); e_y x h = (hz, 0, -hx); u x (e_y x v) = (-uy vx, ux vx + uz vz, -uy vz)
+    const double gxv = -(uy * vx), gyv = fma(ux, vx, uz * vz), gzv = -(uy * vz);
+    const double dxw = 2. * (fma(qw, vz, hz) + gxv), dyw = 2. * gyv, dzw = 2. * (fma(qw, -vx, -hx) + gzv);
+    dq[2] = dot3(ax, ay, az, dxw, dyw, dzw);
   }
   {
-    const double ex = -vy, ey = vx, ez = 0.;
-    const double fx = -hy, fy = hx, fz = 0.;
-    const double gxv = uy * ez - uz * ey, gyv = uz * ex - ux * ez, gzv = ux * ey - uy * ex;
-    const double dxw = 2. * (qw * ex + fx + gxv), dyw = 2. * (qw * ey + fy + gyv),
-                 dzw = 2. * (qw * ez + fz + gzv);
-    dq[3] = ax * dxw + ay * dyw + az * dzw;
+    // e_z x v = (-vy, vx, 0); e_z x h = (-hy, hx, 0); u x (e_z x v) = (-uz vx, -uz vy, ux vx + uy vy)
+    const double gxv = -(uz * vx), gyv = -(uz * vy), gzv = fma(ux, vx, uy * vy);
+    const double dxw = 2. * (fma(qw, -vy, -hy) + gxv), dyw = 2. * (fma(qw, vx, hx) + gyv), dzw = 2. * gzv;
+    dq[3] = dot3(ax, ay, az, dxw, dyw, dzw);
   }
   // tangent space: J_local = J_ambient(1x4) * plus(4 x nloc)
   jrow[3] = jrow[4] = jrow[5] = 0.;
   for (int c2 = 0; c2 < a.nloc; ++c2) {
     double acc = 0.;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc += dq[k] * a.plus[k * a.nloc + c2];
+    for (int k = 0; k < 4; ++k) acc = fma(dq[k], a.plus[k * a.nloc + c2], acc);
     jrow[3 + c2] = acc;
   }
 }
@@ -254,8 +308,12 @@ __global__ void csm_final_reduce_kernel(const double* __restrict__ partials, int
 }
 
 // ---------------------------------------------------------------------------------- host side
+// index of (r, c) = (c, r) in the upper triangle of a symmetric 6 x 6 matrix stored row by row (0 .. 20: the order of the
+// 21 J^T J sums of the evaluation kernels)
+__host__ __device__ constexpr int tri(int r, int c) { return r <= c ? r * 6 - r * (r - 1) / 2 + (c - r) : c * 6 - c * (c - 1) / 2 + (r - c); }
 struct Normal {
-  double H[36];  // J^T J, full symmetric, row-major
+  double H[21];  // J^T J, upper triangle row-major (tri(r, c)): the trust-region loop of csm_lm_kernel keeps two of these
+                 // and a scaled copy in registers, and the full 6 x 6 form did not fit the 256 it can address directly
   double g[6];   // J^T r
   double cost;   // 1/2 sum r^2
 };
@@ -299,10 +357,24 @@ __host__ __device__ static void plus(const double x[7], const double* delta, int
   for (int i = 0; i < 3; ++i) out[i] = x[i] + delta[i];
   const double* d = delta + 3;
   if (nloc == 3) {
-    const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    if (n > 0.0) {
-      const double s = sin(n) / n;
-      const double qd[4] = {cos(n), s * d[0], s * d[1], s * d[2]};
+    const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (n2 > 0.0) {
+      // q_delta = [cos |d|, sin |d| / |d| d] (QuaternionParameterization::Plus).  An LM step turns by a fraction of a
+      // degree: both factors are series in |d|^2 there (to 1e-17 below |d| = 0.25) -- no square root, no division, no
+      // sin / cos, which were a dependent chain of ~2 000 cycles on the critical path of every iteration of
+      // csm_lm_kernel, twice (candidate and gradient projection).  Host and device run this same code.
+      double sn, cs;
+      if (n2 < 0.0625) {
+        sn = 1.0 + n2 * (-1.0 / 6.0 + n2 * (1.0 / 120.0 + n2 * (-1.0 / 5040.0 + n2 * (1.0 / 362880.0 + n2 * (-1.0 / 39916800.0 +
+             n2 * (1.0 / 6227020800.0 + n2 * (-1.0 / 1307674368000.0 + n2 * (1.0 / 355687428096000.0))))))));
+        cs = 1.0 + n2 * (-0.5 + n2 * (1.0 / 24.0 + n2 * (-1.0 / 720.0 + n2 * (1.0 / 40320.0 + n2 * (-1.0 / 3628800.0 +
+             n2 * (1.0 / 479001600.0 + n2 * (-1.0 / 87178291200.0 + n2 * (1.0 / 20922789888000.0))))))));
+      } else {
+        const double n = sqrt(n2);
+        sn = sin(n) / n;
+        cs = cos(n);
+      }
+      const double qd[4] = {cs, sn * d[0], sn * d[1], sn * d[2]};
       quat_product(qd, x + 3, out + 3);
     } else {
       for (int i = 0; i < 4; ++i) out[3 + i] = x[3 + i];
@@ -326,8 +398,7 @@ __host__ __device__ static void finish_normal(const double* sums28, const double
   for (int r = 0; r < 6; ++r)
 #pragma unroll
     for (int c = r; c < 6; ++c) {
-      out->H[r * 6 + c] = sums28[idx];
-      out->H[c * 6 + r] = sums28[idx];
+      out->H[tri(r, c)] = sums28[idx];
       ++idx;
     }
 #pragma unroll
@@ -338,7 +409,7 @@ __host__ __device__ static void finish_normal(const double* sums28, const double
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const double r = wt * (x[i] - target_t[i]);
-      out->H[i * 6 + i] += wt * wt;
+      out->H[tri(i, i)] += wt * wt;
       out->g[i] += wt * r;
       sumsq += r * r;
     }
@@ -365,7 +436,7 @@ __host__ __device__ static void finish_normal(const double* sums28, const double
       for (int c1 = 0; c1 < nloc; ++c1) {
         out->g[3 + c1] += jl[c1] * r;
 #pragma unroll
-        for (int c2 = 0; c2 < nloc; ++c2) out->H[(3 + c1) * 6 + 3 + c2] += jl[c1] * jl[c2];
+        for (int c2 = c1; c2 < nloc; ++c2) out->H[tri(3 + c1, 3 + c2)] += jl[c1] * jl[c2];
       }
       sumsq += r * r;
     }
@@ -409,26 +480,47 @@ static int evaluate(CsmProblem* p, const double x[7], Normal* out) {
   return DLIOM_OK;
 }
 
+// 1 / sqrt(s) to double precision without a double square root or division (each a dependent sequence of ~30
+// instructions on the device, and a pivot of the Cholesky factorisation below waits for it): a seed from the exponent
+// bits (the classic shift-and-subtract, 3.4 % off at worst) and five Newton steps in fused multiply-adds -- only
+// integer operations and IEEE multiply-adds, so host and device get the same bits.
+__host__ __device__ static inline double inv_sqrt(double s) {
+  if (!(s > 1e-300 && s < 1e300)) return 1.0 / sqrt(s);
+  long long bits;
+  memcpy(&bits, &s, sizeof(bits));
+  bits = 0x5FE6EB50C7B537A9ll - (bits >> 1);
+  double y;
+  memcpy(&y, &bits, sizeof(y));
+  const double h = 0.5 * s;
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {  // relative error 3.4e-2 -> 1.8e-3 -> 4.6e-6 -> 3.2e-11 -> 1.5e-21 (-> rounding)
+    const double e = fma(-(h * y), y, 0.5);  // 1/2 - s y^2 / 2
+    y = fma(y, e, y);
+  }
+  return y;
+}
+
 // (A + diag(d2)) y = b for the leading n x n block, Cholesky; false if not positive definite.
 // (n is a template argument and every loop is unrolled: in csm_lm_kernel the matrices must live in registers, a
 // dynamically indexed local array would sit in scratch memory at ~1 us per dependent access.)
 template <int n>
 __host__ __device__ static bool solve_spd(const double* A, const double* d2, const double* b, double* y) {
-  // One IEEE division per pivot (its reciprocal), multiplications elsewhere: a double division is a ~30-instruction
-  // dependent sequence on the device, and this solve runs on the critical path of every LM iteration (csm_lm_kernel).
+  // One reciprocal square root per pivot (inv_sqrt), multiplications elsewhere: a double division or square root is a
+  // ~30-instruction dependent sequence on the device, and this solve runs on the critical path of every LM iteration
+  // (csm_lm_kernel).
   // Host and device run this same code, so the launch-per-evaluation loop and the one-launch kernel stay identical.
   double Lm[36], rd[6];
 #pragma unroll
   for (int i = 0; i < n; ++i) {
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
-      double s = A[i * 6 + j] + (i == j ? d2[i] : 0.0);
+      double s = A[tri(i, j)] + (i == j ? d2[i] : 0.0);
 #pragma unroll
       for (int k = 0; k < j; ++k) s -= Lm[i * 6 + k] * Lm[j * 6 + k];
       if (i == j) {
         if (!(s > 0.0)) return false;
-        Lm[i * 6 + i] = sqrt(s);
-        rd[i] = 1.0 / Lm[i * 6 + i];
+        rd[i] = inv_sqrt(s);
+        Lm[i * 6 + i] = s * rd[i];
       } else {
         Lm[i * 6 + j] = s * rd[j];
       }
@@ -455,6 +547,14 @@ __host__ __device__ static bool solve_spd(const double* A, const double* d2, con
   return true;
 }
 
+#ifdef DLIOM_EXPERIMENTS
+__device__ unsigned long long dbg_lm2[256];
+#endif
+#if defined(DLIOM_EXPERIMENTS) && defined(__HIP_DEVICE_COMPILE__)
+#define DLIOM_LM2_STAMP(i) if (threadIdx.x == 0 && blockIdx.x == 0 && iteration < 30) dbg_lm2[8 * iteration + (i)] = __builtin_readcyclecounter()
+#else
+#define DLIOM_LM2_STAMP(i)
+#endif
 // Ceres 1.13 trust-region minimizer (LEVENBERG_MARQUARDT) on the normal equations.
 // `ev(x, &normal)` evaluates the normal equations at x (0 = ok) and counts in ev.evaluations; on the host it launches
 // the evaluation kernel per call, inside csm_lm_kernel it is the workgroup's own reduction -- the SAME loop either way.
@@ -495,6 +595,7 @@ __host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7]
     const int es = ev(x, &cur);
     if (es != DLIOM_OK) return es;
   }
+
   double x_cost = cur.cost, minimum_cost = cur.cost;
   double best_x[7];
 #pragma unroll
@@ -504,7 +605,7 @@ __host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7]
   int num_iter_records = 1;
   double scale[6] = {1, 1, 1, 1, 1, 1};
 #pragma unroll
-  for (int i = 0; i < ne; ++i) scale[i] = 1.0 / (1.0 + sqrt(cur.H[i * 6 + i]));
+  for (int i = 0; i < ne; ++i) scale[i] = 1.0 / (1.0 + sqrt(cur.H[tri(i, i)]));
   double x_norm = norm7(x);
   double gmax = grad_max_norm(x, cur);
   auto finish = [&](int type) {
@@ -539,24 +640,35 @@ __host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7]
       ++sum->num_unsuccessful_steps;
     }
     if (iteration >= o.max_num_iterations) return finish(1);
-    if (last_ok && gmax <= kGradientTol) return finish(0);
     if (radius <= kMinRadius) return finish(0);
+    // The gradient test of an accepted step (max |x - Plus(x, -g)| <= tolerance -> converged, like the radius test above)
+    // is evaluated BELOW, behind the solve: its projection and the factorisation are two independent dependent chains and
+    // the device, which issues in order, interleaves them only inside one block.  A converged run discards the solve.
+    const bool accepted_step = last_ok;
     ++iteration;
     last_ok = false;
+    DLIOM_LM2_STAMP(0);
+    if (accepted_step) gmax = grad_max_norm(x, cur);
 
     // scaled normal equations Hs = S H S, gs = S g; LM diagonal from diag(Hs)
-    double Hs[36], gs[6], d2[6], y[6], step[6];
+    double Hs[21], gs[6], d2[6], y[6], step[6];  // (Hs: upper triangle like Normal::H)
 #pragma unroll
     for (int r = 0; r < ne; ++r) {
       gs[r] = cur.g[r] * scale[r];
 #pragma unroll
-      for (int c = 0; c < ne; ++c) Hs[r * 6 + c] = cur.H[r * 6 + c] * scale[r] * scale[c];
+      for (int c = r; c < ne; ++c) Hs[tri(r, c)] = cur.H[tri(r, c)] * scale[r] * scale[c];
     }
     const double inv_radius = 1.0 / radius;
 #pragma unroll
     for (int r = 0; r < ne; ++r)
-      d2[r] = fmin(fmax(Hs[r * 6 + r], kMinDiag), kMaxDiag) * inv_radius;
+      d2[r] = fmin(fmax(Hs[tri(r, r)], kMinDiag), kMaxDiag) * inv_radius;
+    DLIOM_LM2_STAMP(1);
     bool valid = solve_spd<ne>(Hs, d2, gs, y);
+    DLIOM_LM2_STAMP(2);
+    if (accepted_step && gmax <= kGradientTol) {
+      --iteration;  // (the test belongs in front of this iteration)
+      return finish(0);
+    }
     double model_cost_change = 0.0;
     if (valid) {
 #pragma unroll
@@ -568,7 +680,7 @@ __host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7]
         sg += step[r] * gs[r];
         double t = 0.0;
 #pragma unroll
-        for (int c = 0; c < ne; ++c) t += Hs[r * 6 + c] * step[c];
+        for (int c = 0; c < ne; ++c) t += Hs[tri(r, c)] * step[c];
         shs += step[r] * t;
       }
       model_cost_change = -sg - 0.5 * shs;
@@ -586,11 +698,13 @@ __host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7]
 #pragma unroll
     for (int r = 0; r < ne; ++r) delta[r] = step[r] * scale[r];
     plus(x, delta, nloc, cand);
+    DLIOM_LM2_STAMP(3);
     Normal cn;
     {
       const int es = ev(cand, &cn);
       if (es != DLIOM_OK) return es;
     }
+    DLIOM_LM2_STAMP(4);
     const double cand_cost = cn.cost;
     double step_norm = 0;
 #pragma unroll
@@ -601,15 +715,16 @@ __host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7]
     const double rel = (ev_cur - cand_cost) / model_cost_change;
     const double hist = (ev_ref - cand_cost) / (acc_ref + model_cost_change);
     const double quality = fmax(rel, hist);
+    DLIOM_LM2_STAMP(5);
     if (quality > kMinRelDecrease) {
 #pragma unroll
       for (int i = 0; i < 7; ++i) x[i] = cand[i];
       x_norm = norm7(x);
       cur = cn;
       x_cost = cand_cost;
-      gmax = grad_max_norm(x, cur);
       last_ok = true;
-      radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * quality - 1.0, 3));
+      const double tq = 2.0 * quality - 1.0;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);  // (pow(., 3) is a few hundred instructions on the device)
       radius = fmin(kMaxRadius, radius);
       decrease_factor = 2.0;
       ev_cur = cand_cost;
@@ -637,6 +752,7 @@ __host__ __device__ static int minimize(Eval& ev, const LmConfig& o, double x[7]
       decrease_factor *= 2.0;
       min_iter_cost = fmin(min_iter_cost, cand_cost);
     }
+    DLIOM_LM2_STAMP(6);
     ++num_iter_records;
   }
 }
@@ -672,6 +788,18 @@ struct LmKernelOut {
   int status;
 };
 
+#ifdef DLIOM_EXPERIMENTS
+__device__ unsigned long long dbg_lm[128];
+#define DLIOM_LM_STAMP(i) if (threadIdx.x == 0 && evaluations < 24) dbg_lm[5 * evaluations + (i)] = __builtin_readcyclecounter()
+#else
+#define DLIOM_LM_STAMP(i)
+#endif
+// (Round 4 tried two and three groups of 256 threads, one point per thread, the products handed to group 0 through LDS
+// in the evaluation kernel's order of additions: NOT faster.  An evaluation is bound by instruction issue -- ~750 vector
+// instructions per point without contraction, 4 cycles each, on the four SIMDs of the ONE compute unit a workgroup
+// lives on -- so eight waves with one point each issue what four waves with two points did, the exchange costs three
+// more barriers, and the trust-region step, which every wave runs redundantly, has to share its SIMD: 414 000 cycles
+// per match against 325 000.  What did help: fewer instructions, see plus(), inv_sqrt() and csm_point_v.)
 template <int NLOC>
 struct DeviceEval {
   const CsmArgs* a;  // clouds (kernel argument)
@@ -681,6 +809,7 @@ struct DeviceEval {
   double pts[6];             // two-cloud fast path: this thread's point of cloud 0 and of cloud 1 (index clamped)
   int evaluations = 0;
   __device__ int operator()(const double x[7], Normal* out) {
+    DLIOM_LM_STAMP(0);
     CsmPose pose;
     for (int i = 0; i < 3; ++i) pose.t[i] = x[i];
     for (int i = 0; i < 4; ++i) pose.q[i] = x[3 + i];
@@ -721,6 +850,7 @@ struct DeviceEval {
         }
       }
     }
+    DLIOM_LM_STAMP(1);
     __syncthreads();  // the previous evaluation's totals have been read by everyone
 #pragma unroll
     for (int k = 0; k < kAcc; ++k) red[k][threadIdx.x] = acc[k];
@@ -742,10 +872,12 @@ struct DeviceEval {
 #pragma unroll
       for (int m = 0; m < kAcc / 4; ++m) tot[wave + 4 * m] = v[m];
     __syncthreads();
+    DLIOM_LM_STAMP(2);
     double sums[kAcc];
 #pragma unroll
     for (int k = 0; k < kAcc; ++k) sums[k] = tot[k];
     finish_normal<NLOC>(sums, x, pose.plus, prm->translation_weight, prm->rotation_weight, prm->target_t, prm->init_q, out);
+    DLIOM_LM_STAMP(3);
     ++evaluations;
     return DLIOM_OK;
   }
@@ -776,6 +908,12 @@ __global__ __launch_bounds__(kCsmBlock) void csm_lm_kernel(CsmArgs a, LmKernelPa
   for (int i = 0; i < 7; ++i) x[i] = prm.x0[i];
   dliom_csm_summary sum;
   const int status = minimize<NLOC>(ev, prm.cfg, x, &sum);
+#ifdef DLIOM_EXPERIMENTS
+  if (threadIdx.x == 0) {
+    dbg_lm[126] = __builtin_readcyclecounter();
+    dbg_lm[127] = static_cast<unsigned long long>(ev.evaluations);
+  }
+#endif
   if (threadIdx.x == 0) {
     for (int i = 0; i < 7; ++i) out->x[i] = x[i];
     out->summary = sum;
@@ -786,6 +924,17 @@ __global__ __launch_bounds__(kCsmBlock) void csm_lm_kernel(CsmArgs a, LmKernelPa
     }
   }
 }
+
+#ifdef DLIOM_EXPERIMENTS
+}  // namespace dliom
+extern "C" int dliom_exp_lm2_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dliom::dbg_lm2), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -2;
+}
+extern "C" int dliom_exp_lm_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dliom::dbg_lm), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -2;
+}
+namespace dliom {
+#endif
 
 // ---- the whole Levenberg-Marquardt loop in ONE launch for LARGE clouds: the same grid as csm_eval_kernel (every
 // workgroup resident), every thread of every workgroup runs the same minimize<> loop on the same numbers, and an
@@ -1085,7 +1234,9 @@ int dliom_csm3d_evaluate(dliom_ctx* ctx, const dliom_csm_options* o, const doubl
   DLIOM_TRY(evaluate(&p, pose, &nrm));
   if (cost != nullptr) *cost = nrm.cost;
   if (gradient != nullptr) std::memcpy(gradient, nrm.g, sizeof(nrm.g));
-  if (jtj != nullptr) std::memcpy(jtj, nrm.H, sizeof(nrm.H));
+  if (jtj != nullptr)
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) jtj[r * 6 + c] = nrm.H[tri(r, c)];
   return DLIOM_OK;
 }
 

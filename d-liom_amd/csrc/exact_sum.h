@@ -130,7 +130,9 @@ struct Scratch {
   double wave_part[K][kThreads / 64];
   int4 wave_agg[K][kThreads / 64];
   unsigned stage_count[K];
-  float result[K];
+  float result[K];      // the float accumulators
+  double carry_p[K];    // real prefix sums so far
+  double carry_mx[K];   // largest |real prefix| so far
 };
 
 __device__ __forceinline__ double shfl_up_double(double v, int off) {
@@ -186,16 +188,29 @@ __device__ __forceinline__ Run shfl_down_run(const Run& r, int off) {
 
 // All 1024 threads call this; every thread returns with out[k] = the sequential float sum of v[k][0 .. n) started at acc0[k].
 // v[k] may point to LDS or global memory (generic pointers); it must stay unchanged during the call.
+#ifdef DLIOM_EXPERIMENTS
+__device__ unsigned long long dbg_es[16];
+#define DLIOM_ES_STAMP(i) if (threadIdx.x == 0 && blockIdx.x == 0) dbg_es[(i)] = __builtin_readcyclecounter()
+#else
+#define DLIOM_ES_STAMP(i)
+#endif
 template <int K>
 __device__ void block_sequential_sums(const float* const (&v)[K], int n, const float (&acc0)[K], float (&out)[K], Scratch<K>& S) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double P[K], Mx[K];
-  float acc[K];
+  // Per-array state (real prefix, largest |prefix| so far, the float accumulator) lives in LDS and the arrays are
+  // classified one after the other by the SAME code (a loop that is not unrolled): unrolled over K the two copies'
+  // live ranges overlapped and a 1024-thread workgroup has 128 registers per thread -- 400 to 650 bytes of scratch per
+  // lane, and the centroid of a 10 000-point floor slice took 46 us (round 4's first version; 10 us of work).
+  __syncthreads();  // (S may lie over arrays the caller was still reading)
+  DLIOM_ES_STAMP(0);
+  if (tid < K) {
+    float a0 = acc0[0];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    acc[k] = acc0[k];
-    P[k] = static_cast<double>(acc0[k]);
-    Mx[k] = fabs(P[k]);
+    for (int k = 1; k < K; ++k)
+      if (tid == k) a0 = acc0[k];
+    S.result[tid] = a0;
+    S.carry_p[tid] = static_cast<double>(a0);
+    S.carry_mx[tid] = fabs(static_cast<double>(a0));
   }
   const int num_chunks = (n + kChunk - 1) / kChunk;
   for (int cb = 0; cb < num_chunks; cb += kChunksPerBlock) {  // uniform
@@ -204,12 +219,18 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
     const int c = cb + tid;
     const int i0 = c * kChunk, i1 = min(n, i0 + kChunk);
     if (tid < K) S.stage_count[tid] = 0u;
-#pragma unroll
+    __syncthreads();
+#pragma unroll 1
     for (int k = 0; k < K; ++k) {
-      // the chunk's 32 addends, all loads in flight at once (a loop of load -> add pays the memory latency 32 times)
+      const float* vk = v[0];
+#pragma unroll
+      for (int kk = 1; kk < K; ++kk)
+        if (k == kk) vk = v[kk];
+      const double P = S.carry_p[k], Mx = S.carry_mx[k];
+      // the chunk's addends, all loads in flight at once (a loop of load -> add pays the memory latency once per addend)
       float x[kChunk];
 #pragma unroll
-      for (int j = 0; j < kChunk; ++j) x[j] = (mine && i0 + j < i1) ? v[k][i0 + j] : 0.f;
+      for (int j = 0; j < kChunk; ++j) x[j] = (mine && i0 + j < i1) ? vk[i0 + j] : 0.f;
       double p = 0.0, lo = 0.0, hi = 0.0;
 #pragma unroll
       for (int j = 0; j < kChunk; ++j) {
@@ -217,11 +238,17 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
         lo = fmin(lo, p);
         hi = fmax(hi, p);
       }
+      DLIOM_ES_STAMP(10);
       double total, mtotal;
-      const double incl = block_inclusive_scan<false>(p, S.wave_part[k], &total);
-      const double Pc = P[k] + (incl - p);  // real prefix in front of this thread's chunk
+      const double incl = block_inclusive_scan<false>(p, S.wave_part[0], &total);
+      const double Pc = P + (incl - p);  // real prefix in front of this thread's chunk
       const double reach = mine ? fmax(fabs(Pc + lo), fabs(Pc + hi)) : 0.0;
-      const double mx = fmax(Mx[k], block_inclusive_scan<true>(reach, S.wave_part[k], &mtotal));
+      const double mx = fmax(Mx, block_inclusive_scan<true>(reach, S.wave_part[0], &mtotal));
+      if (tid == 0) {  // (everybody has read the old values: two barriers ago at the latest)
+        S.carry_p[k] = P + total;
+        S.carry_mx[k] = fmax(Mx, mtotal);
+      }
+      DLIOM_ES_STAMP(11);
       int code = kNoCode;
       Fn f = identity_fn();
       if (mine) {
@@ -245,8 +272,7 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
           }
         }
       }
-      P[k] += total;
-      Mx[k] = fmax(Mx[k], mtotal);
+      DLIOM_ES_STAMP(12);
       // chunks that will be added one value after the other: their values wait in LDS
       int slot = -1;
       if (mine && code == kNoCode) {
@@ -270,29 +296,28 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
         if (lane + off < 64) r = join(r, o);
       }
       if (lane == 0) {
-        S.wave_agg[k][wave] = make_int4(r.f.s0, r.f.s1, static_cast<int>(r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.closed) << 2)), r.end);
+        S.wave_agg[0][wave] = make_int4(r.f.s0, r.f.s1, static_cast<int>(r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.closed) << 2)), r.end);
       }
       __syncthreads();
       for (int w = wave + 1; w < kThreads / 64 && !r.closed; ++w) {
-        const int4 g = S.wave_agg[k][w];
+        const int4 g = S.wave_agg[0][w];
         r = join(r, Run{Fn{g.x, g.y, static_cast<unsigned>(g.z) & 1u, (static_cast<unsigned>(g.z) >> 1) & 1u}, g.w, (g.z >> 2) & 1});
       }
       if (mine)
         S.desc[k][tid] = make_int4(code, r.f.s0, r.f.s1,
                                    static_cast<int>(r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.end) << 2) |
                                                     (static_cast<unsigned>(slot + 1) << 16)));
+      __syncthreads();  // (wave_agg and wave_part are shared by the arrays)
+      DLIOM_ES_STAMP(1 + k);
     }
     __syncthreads();
     // the walk: lane 0 of wave k takes array k
     if (wave < K && lane == 0) {
-      float a = acc[0];
+      float a = S.result[wave];
       const float* vp = v[0];
 #pragma unroll
       for (int k = 1; k < K; ++k)
-        if (wave == k) {
-          a = acc[k];
-          vp = v[k];
-        }
+        if (wave == k) vp = v[k];
       int cc = 0;
       while (cc < chunks_here) {
         const int4 d = S.desc[wave][cc];
@@ -336,12 +361,11 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
       S.result[wave] = a;
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = S.result[k];
-    __syncthreads();
+    DLIOM_ES_STAMP(8);
   }
 #pragma unroll
-  for (int k = 0; k < K; ++k) out[k] = acc[k];
+  for (int k = 0; k < K; ++k) out[k] = S.result[k];
+  __syncthreads();  // (the caller may reuse S)
 }
 
 }  // namespace exact_sum

@@ -697,6 +697,7 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     __syncthreads();
     DLIOM_STAMP(3);
     bitonic_sort_keys(skey, pow2);
+    DLIOM_STAMP(13);
     const int m = static_cast<int>(sh_valid);
     // equal angles next to each other: their order is std::sort's, not ours
     bool tied = false;
@@ -746,7 +747,9 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
         queue_push(sort_scratch.queue, 0, m, 2 * depth);  // std::__lg(n) * 2
       }
       __syncthreads();
+      DLIOM_STAMP(14);
       const bool done = wave_sort_arrangement(replay, sort_scratch);
+      DLIOM_STAMP(15);
       if (!done) {  // the queue overflowed (cannot happen for m <= kMaxSlice): refuse, the host path takes the cloud
         if (threadIdx.x == 0) atomicOr(flags, 4u);
         continue;
@@ -1108,6 +1111,12 @@ extern "C" int dliom_exp_rothist_stamps(unsigned long long* out) {
 #ifdef DLIOM_EXPERIMENTS
 extern "C" int dliom_exp_rothist_big_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rothist::dbg_big), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : -2;
+}
+#endif
+
+#ifdef DLIOM_EXPERIMENTS
+extern "C" int dliom_exp_exact_sum_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(exact_sum::dbg_es), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
 }
 #endif
 

@@ -25,7 +25,8 @@ for scene, size in (("cube", 0.15), ("ground", 0.15), ("ground", 0.0)):
     total = a[:, 7] - a[:, 0]
     for b in np.argsort(-total)[:4]:
         s = a[b]
-        print("  wg", b, "count/m/E", s[10], s[11], s[12], "phases(x10ns):", [int(s[k + 1] - s[k]) for k in range(7)])
+        print("  wg", b, "count/m/E", s[10], s[11], s[12], "phases(cycles):", [int(s[k + 1] - s[k]) for k in range(7)],
+              "sort", int(s[13] - s[3]), "ties+items", int(s[14] - s[13]), "replay", int(s[15] - s[14]), "order", int(s[4] - s[15]))
     L.dliom_exp_rothist_big_stamps(buf)
     a = np.array(buf, dtype=np.uint64).reshape(64, 16).astype(np.int64)
     for b in range(2):
@@ -36,6 +37,11 @@ for scene, size in (("cube", 0.15), ("ground", 0.15), ("ground", 0.0)):
     print("  big sort order: tie detect + init", int(so[1] - so[0]), "global rounds", [int(so[k + 1] - so[k]) for k in range(1, min(rounds, 8))],
           "handover T", int(so[15] & 0xffffffff), "prep", int(so[11] - so[min(rounds, 9)]), "LDS replay", int(so[12] - so[11]),
           "write back", int(so[13] - so[12]), "tie groups", int(so[14] - so[13]))
+    es = (ctypes.c_ulonglong * 16)()
+    L.dliom_exp_exact_sum_stamps(es)
+    e = [int(v) for v in es]
+    print("  exact sums (last call of block 0): k=0", e[1] - e[0], "k=1", e[2] - e[1], "walk", e[8] - e[2], "| last k: loads+prefix", e[10] - e[1],
+          "scans", e[11] - e[10], "functions", e[12] - e[11], "runs", e[2] - e[12])
     cloud.close()
 PY
 DLIOM_LIB=$R/d-liom_amd/ab/libdliom_exp.so timeout 300 python /tmp/hist_dbg.py
