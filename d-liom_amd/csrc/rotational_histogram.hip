@@ -273,8 +273,8 @@ struct SortScratch {
 };
 constexpr int kQueueCap = 1024;  // segments ever queued: every one has > 16 elements and they nest, so <= 2 m / 17
 struct Queue {
-  unsigned reserved, head, pending, overflow;
-  uint2 seg[kQueueCap];  // x = first | last << 16, y = partitions left on this path; y = 0xFFFFFFFF: not written yet
+  unsigned reserved, capacity, pending, overflow;  // capacity: entries of seg[] in use (kQueueCap unless the owner has more room)
+  uint2 seg[kQueueCap];  // x = first | last << 16, y = partitions left on this path
 };
 
 // exclusive prefix counts of 4 consecutive flags per thread (position 4 t + k) over the workgroup; out[p] for p in
@@ -293,13 +293,22 @@ __device__ __forceinline__ void blocked_prefix(const unsigned (&flag)[4], unsign
   if (threadIdx.x == kThreads - 1) out[kMaxSlice] = static_cast<unsigned short>(total);
 }
 
-// bits/stl_heap.h: __adjust_heap (with its __push_heap), __make_heap, __sort_heap on items compared by their high words
-__device__ inline void adjust_heap_keys(unsigned long long* first, int hole, int len, unsigned long long value) {
+// An item of the replay: (key, position in the slice), compared by key only.  64 bits (ordered angle bits << 32 | position)
+// for the slices that fit LDS anyway; 32 bits (dense rank of the angle << 16 | position) for the floor slices of
+// rothist_big.h, which fit LDS only that way.
+__device__ __forceinline__ unsigned item_key(unsigned long long x) { return static_cast<unsigned>(x >> 32); }
+__device__ __forceinline__ unsigned item_id(unsigned long long x) { return static_cast<unsigned>(x) & 0xffffu; }
+__device__ __forceinline__ unsigned item_key(unsigned x) { return x >> 16; }
+__device__ __forceinline__ unsigned item_id(unsigned x) { return x & 0xffffu; }
+
+// bits/stl_heap.h: __adjust_heap (with its __push_heap), __make_heap, __sort_heap on items compared by their keys
+template <class Item>
+__device__ inline void adjust_heap_keys(Item* first, int hole, int len, Item value) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    if (static_cast<unsigned>(first[child] >> 32) < static_cast<unsigned>(first[child - 1] >> 32)) --child;
+    if (item_key(first[child]) < item_key(first[child - 1])) --child;
     first[hole] = first[child];
     hole = child;
   }
@@ -309,14 +318,15 @@ __device__ inline void adjust_heap_keys(unsigned long long* first, int hole, int
     hole = child - 1;
   }
   int parent = (hole - 1) / 2;
-  while (hole > top && static_cast<unsigned>(first[parent] >> 32) < static_cast<unsigned>(value >> 32)) {
+  while (hole > top && item_key(first[parent]) < item_key(value)) {
     first[hole] = first[parent];
     hole = parent;
     parent = (hole - 1) / 2;
   }
   first[hole] = value;
 }
-__device__ inline void heap_sort_keys(unsigned long long* first, int len) {
+template <class Item>
+__device__ inline void heap_sort_keys(Item* first, int len) {
   if (len >= 2)
     for (int parent = (len - 2) / 2;; --parent) {
       adjust_heap_keys(first, parent, len, first[parent]);
@@ -324,7 +334,7 @@ __device__ inline void heap_sort_keys(unsigned long long* first, int len) {
     }
   for (int last = len; last > 1;) {
     --last;
-    const unsigned long long value = first[last];
+    const Item value = first[last];
     first[last] = first[0];
     adjust_heap_keys(first, 0, last, value);
   }
@@ -333,17 +343,17 @@ __device__ inline void heap_sort_keys(unsigned long long* first, int len) {
 // The queue is served level by level: the segments queued so far are partitioned, one wave each, their children are
 // appended (one atomic counter), a barrier, and the appended ones are the next level.  (A first version let idle waves
 // spin on their next entry instead of meeting at a barrier; it hung on the device and was not worth the minutes.)
-__device__ __forceinline__ void queue_init(Queue* q) {  // all threads; a barrier must follow
+__device__ __forceinline__ void queue_init(Queue* q, unsigned capacity = kQueueCap) {  // all threads; a barrier must follow
   if (threadIdx.x == 0) {
     q->reserved = 0u;
-    q->head = 0u;
+    q->capacity = capacity;
     q->pending = 0u;
     q->overflow = 0u;
   }
 }
 __device__ __forceinline__ void queue_push(Queue* q, int first, int last, int depth) {  // one lane
   const unsigned slot = atomicAdd(&q->reserved, 1u);
-  if (slot < static_cast<unsigned>(kQueueCap))
+  if (slot < q->capacity)
     q->seg[slot] = make_uint2(static_cast<unsigned>(first) | (static_cast<unsigned>(last) << 16), static_cast<unsigned>(depth));
   else
     atomicExch(&q->overflow, 1u);
@@ -351,12 +361,13 @@ __device__ __forceinline__ void queue_push(Queue* q, int first, int last, int de
 
 // std::__introsort_loop on the queued segments (see above).  All threads of the workgroup call this after the queue has
 // been filled and a barrier; returns after a barrier, false if the queue overflowed (cannot happen for m <= kMaxSlice).
-__device__ bool wave_sort_arrangement(unsigned long long* a, const SortScratch& sc) {
+template <class Item>
+__device__ bool wave_sort_arrangement(Item* a, const SortScratch& sc) {
   Queue* q = sc.queue;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned level_begin = 0u;
   for (int level = 0; level < 4 * 64; ++level) {  // (a path has at most 2 lg n partitions; the bound only guards the loop)
-    const unsigned level_end = min(q->reserved, static_cast<unsigned>(kQueueCap));
+    const unsigned level_end = min(q->reserved, q->capacity);
     __syncthreads();  // everybody has read the level's end before anybody appends to the queue
     if (level_begin >= level_end) break;
     for (unsigned e = level_begin + static_cast<unsigned>(wave); e < level_end; e += kThreads / 64) {
@@ -372,7 +383,7 @@ __device__ bool wave_sort_arrangement(unsigned long long* a, const SortScratch& 
     // (a) __move_median_to_first(first, first + 1, mid, last - 1)
     if (lane == 0) {
       const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
-      const unsigned ka = static_cast<unsigned>(a[ia] >> 32), kb = static_cast<unsigned>(a[ib] >> 32), kc = static_cast<unsigned>(a[ic] >> 32);
+      const unsigned ka = item_key(a[ia]), kb = item_key(a[ib]), kc = item_key(a[ic]);
       int md;
       if (ka < kb) {
         if (kb < kc) md = ib;
@@ -381,13 +392,13 @@ __device__ bool wave_sort_arrangement(unsigned long long* a, const SortScratch& 
       } else if (ka < kc) md = ia;
       else if (kb < kc) md = ic;
       else md = ib;
-      const unsigned long long t = a[first];
+      const Item t = a[first];
       a[first] = a[md];
       a[md] = t;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const unsigned pivot = static_cast<unsigned>(a[first] >> 32);
+    const unsigned pivot = item_key(a[first]);
     // (b) where the two pointers of __unguarded_partition(first + 1, last, first) stop: !(x < pivot) from the left,
     //     !(pivot < x) from the right; both lists in ascending order of position
     unsigned short* stops_l = sc.tmp_l + first + 1;
@@ -396,7 +407,7 @@ __device__ bool wave_sort_arrangement(unsigned long long* a, const SortScratch& 
     for (int base = first + 1; base < last; base += 64) {
       const int p = base + lane;
       const bool in = p < last;
-      const unsigned x = in ? static_cast<unsigned>(a[p] >> 32) : 0u;
+      const unsigned x = in ? item_key(a[p]) : 0u;
       const bool ge = in && !(x < pivot), le = in && !(pivot < x);
       const unsigned long long ml = __builtin_amdgcn_ballot_w64(ge), mr = __builtin_amdgcn_ballot_w64(le);
       if (ge) stops_l[cnt_l + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(ml >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(ml), 0u))] =
@@ -425,7 +436,7 @@ __device__ bool wave_sort_arrangement(unsigned long long* a, const SortScratch& 
       const int k = k0 + lane;
       if (k < K) {
         const int il = stops_l[k], ir = stops_r[cnt_r - 1 - k];
-        const unsigned long long xl = a[il], xr = a[ir];
+        const Item xl = a[il], xr = a[ir];
         a[il] = xr;
         a[ir] = xl;
       }
@@ -439,7 +450,7 @@ __device__ bool wave_sort_arrangement(unsigned long long* a, const SortScratch& 
     int tied_l = 0, tied_r = 0;
     for (int base = first; base < last; base += 64) {
       const int p = base + lane;
-      const bool t = p < last && sc.tied[static_cast<unsigned>(a[p]) & 0xffffu] != 0;
+      const bool t = p < last && sc.tied[item_id(a[p])] != 0;
       tied_l += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t && p < cut));
       tied_r += __builtin_popcountll(__builtin_amdgcn_ballot_w64(t && p >= cut));
     }
@@ -1111,6 +1122,12 @@ extern "C" int dliom_exp_rothist_stamps(unsigned long long* out) {
 #ifdef DLIOM_EXPERIMENTS
 extern "C" int dliom_exp_rothist_big_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(rothist::dbg_big), sizeof(unsigned long long) * 64 * 16) == hipSuccess ? 0 : -2;
+}
+#endif
+
+#ifdef DLIOM_EXPERIMENTS
+extern "C" int dliom_exp_set_coop_min(int v) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(rothist::dbg_coop_min), &v, sizeof(v)) == hipSuccess ? 0 : -2;
 }
 #endif
 

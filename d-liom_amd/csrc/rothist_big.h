@@ -39,6 +39,9 @@ constexpr int kWorkListCap = 256;    // segments of a big slice's replay that st
 constexpr int kMaxBig = 63;         // big slices per cloud (slice ordinal 63 is the sort's padding key)
 constexpr int kBigKeyBits = 38;     // 32 angle bits + 6 slice bits
 
+#ifdef DLIOM_EXPERIMENTS
+__device__ int dbg_coop_min = 4096;
+#endif
 struct BigArrays {
   // per point of the cloud (n_padded + 64 entries each; slice b works at offset begin_b + b, so that every slice has
   // room for one sentinel behind its last entry)
@@ -171,6 +174,330 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
                                const unsigned long long* __restrict__ ik, const unsigned* __restrict__ iv, int m, int count,
                                const BigArrays& A, unsigned off, unsigned* wave_sums, unsigned long long* lds_a,
                                const SortScratch& lds_sc) {
+#ifdef DLIOM_EXPERIMENTS
+#define DLIOM_SSTAMP(k) if (threadIdx.x == 0 && blockIdx.x < 4) dbg_big[(blockIdx.x + 8) * 16 + (k)] = __builtin_readcyclecounter()
+#else
+#define DLIOM_SSTAMP(k)
+#endif
+  __shared__ int wl_first[kWorkListCap], wl_last[kWorkListCap], wl_depth[kWorkListCap];
+  __shared__ int wl_n, wl_pick, wl_total, wl_overflow, wl_mode;
+  __shared__ int wl_base[kWorkListCap + 1];
+  __shared__ unsigned co_cnt[2][kThreads / 64];
+  __shared__ unsigned co_k, co_tied[2];
+  __shared__ int co_cut;
+  // ---- slices up to ~16 000 points (the floor of a filtered 64- or 128-beam scan): the whole replay in LDS.  An item is
+  //      32 bits there -- the angle's dense RANK among the slice's angles (the radix sort's order gives it; equal angles
+  //      share it, so comparisons come out as on the angles) and the position in the slice, 16 bits each -- and the two
+  //      pointers' stops are 16-bit positions: 9 bytes per point with the tie flags.  (Until this, seven workgroup-wide
+  //      partitions on arrays in HBM at ~9.5 us each -- nine dependent L2 round trips a round -- then a copy into LDS
+  //      for the rest: 150 us of a 10 000-point floor slice's 300.)
+  {
+    const size_t arr_bytes = (static_cast<size_t>(m) + 2) / 2 * 8;               // u32 [m + 1], 8-byte aligned end
+    const size_t stop_bytes = (static_cast<size_t>(m) + 8 + 3) / 4 * 8;          // u16 [m + 8]
+    const size_t tied_bytes = (static_cast<size_t>(count) + 8 + 15) / 16 * 16;   // u8 [count + 8]
+    // the queue of the wave-per-segment stage: every queued segment has more than 16 elements and they nest
+    const size_t queue_entries = 2 * static_cast<size_t>(m) / 17 + 64;
+    const size_t need = arr_bytes + 2 * stop_bytes + tied_bytes + 16 + queue_entries * sizeof(uint2) + 16;
+    if (need <= kBigLdsBytes && count < 65536 && 2 * stop_bytes >= 2 * static_cast<size_t>(count)) {
+      char* base = reinterpret_cast<char*>(lds_a);
+      unsigned* arr = reinterpret_cast<unsigned*>(base);
+      unsigned short* tl = reinterpret_cast<unsigned short*>(base + arr_bytes);
+      unsigned short* tr = reinterpret_cast<unsigned short*>(base + arr_bytes + stop_bytes);
+      unsigned char* tied = reinterpret_cast<unsigned char*>(base + arr_bytes + 2 * stop_bytes);
+      Queue* queue = reinterpret_cast<Queue*>(base + arr_bytes + 2 * stop_bytes + tied_bytes);
+      unsigned short* rank_by_pos = tl;  // [count], before the partitions need the stops' arrays
+      unsigned* __restrict__ sorted_id = A.sorted_id + off;
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      DLIOM_SSTAMP(0);
+      for (int p = threadIdx.x; p < count + 8; p += kThreads) tied[p] = 0;
+      __syncthreads();
+      int t = 0;
+      for (int j0 = static_cast<int>(threadIdx.x); j0 < m; j0 += 8 * kThreads) {  // (coalesced, eight loads in flight)
+        unsigned ka[8], kb[8], ia[8], ib[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = min(j0 + u * kThreads, m - 1), j1 = min(j + 1, m - 1);
+          ka[u] = static_cast<unsigned>(sk[j]);
+          kb[u] = static_cast<unsigned>(sk[j1]);
+          ia[u] = sv[j];
+          ib[u] = sv[j1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * kThreads;
+          if (j + 1 < m && ka[u] == kb[u]) {
+            tied[ia[u]] = 1;
+            tied[ib[u]] = 1;
+            t = 1;
+          }
+        }
+      }
+      const bool any_tie = __syncthreads_or(t) != 0;
+      if (!any_tie) {
+        for (int j = threadIdx.x; j < m; j += kThreads) sorted_id[j] = sv[j];
+        __syncthreads();
+        return true;
+      }
+      DLIOM_SSTAMP(1);
+      // the angles' dense ranks: thread t owns the sorted positions [lo, hi)
+      int lo, hi;
+      owned_range(m, &lo, &hi);
+      {
+        constexpr int kOwnMax = 16;  // (m <= 16 384 here)
+        unsigned kk[kOwnMax + 1], vv[kOwnMax];
+#pragma unroll
+        for (int u = 0; u <= kOwnMax; ++u) kk[u] = static_cast<unsigned>(sk[min(max(lo - 1 + u, 0), m - 1)]);
+#pragma unroll
+        for (int u = 0; u < kOwnMax; ++u) vv[u] = sv[min(lo + u, m - 1)];
+        unsigned mine = 0u;
+#pragma unroll
+        for (int u = 0; u < kOwnMax; ++u)
+          if (lo + u < hi && lo + u > 0 && kk[u + 1] != kk[u]) ++mine;
+        unsigned total;
+        unsigned rank = block_exclusive_scan(mine, wave_sums, &total);
+#pragma unroll
+        for (int u = 0; u < kOwnMax; ++u)
+          if (lo + u < hi) {
+            if (lo + u > 0 && kk[u + 1] != kk[u]) ++rank;
+            rank_by_pos[vv[u]] = static_cast<unsigned short>(rank);
+          }
+      }
+      __syncthreads();
+      for (int q0 = static_cast<int>(threadIdx.x); q0 < m; q0 += 8 * kThreads) {  // std::sort's input: the items in input order
+        unsigned v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = iv[min(q0 + u * kThreads, m - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (q0 + u * kThreads < m) arr[q0 + u * kThreads] = (static_cast<unsigned>(rank_by_pos[v8[u]]) << 16) | v8[u];
+      }
+      int depth0 = 0;
+      for (int v = m; v > 1; v >>= 1) ++depth0;
+      depth0 *= 2;
+      if (threadIdx.x == 0) {
+        wl_first[0] = 0;
+        wl_last[0] = m;
+        wl_depth[0] = depth0;
+        wl_n = m > 16 ? 1 : 0;
+        wl_overflow = 0;
+      }
+      queue_init(queue, static_cast<unsigned>(queue_entries));
+      __syncthreads();  // (rank_by_pos is dead: the stops' arrays are free)
+      DLIOM_SSTAMP(2);
+#ifdef DLIOM_EXPERIMENTS
+      int dbg_rounds_lds = 0;
+#endif
+      bool ok = true;
+#ifdef DLIOM_EXPERIMENTS
+      const int kCoopMin = dbg_coop_min;
+#else
+      // larger segments are partitioned by the whole workgroup, smaller ones by a wave each (a workgroup-wide partition
+      // costs ~18 000 cycles whatever the size -- nine barriers --, a wave takes ~30 cycles per element but sixteen of
+      // them work side by side; measured on a 10 462-point floor slice: 239 000 cycles with 1024, 206 000 with 2048,
+      // 175 000 with 4096, 230 000 with 8192)
+      constexpr int kCoopMin = 4096;
+#endif
+      for (int guard = 0; guard < (1 << 16); ++guard) {
+        if (threadIdx.x == 0) {
+          int pick = -1, best = kCoopMin;
+          for (int e = 0; e < wl_n; ++e) {
+            const int len = wl_last[e] - wl_first[e];
+            if (len > best) {
+              best = len;
+              pick = e;
+            }
+          }
+          wl_pick = pick;
+        }
+        __syncthreads();
+        if (wl_pick < 0 || wl_overflow != 0) break;
+#ifdef DLIOM_EXPERIMENTS
+        ++dbg_rounds_lds;
+#endif
+        const int first = wl_first[wl_pick], last = wl_last[wl_pick], depth = wl_depth[wl_pick];
+        if (depth == 0) {  // std::sort's depth limit on a segment that large: its heap sort, sequential -- refused
+          ok = false;
+          break;
+        }
+        // (a) __move_median_to_first(first, first + 1, mid, last - 1)
+        if (threadIdx.x == 0) {
+          const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+          const unsigned ka = item_key(arr[ia]), kb = item_key(arr[ib]), kc = item_key(arr[ic]);
+          int md;
+          if (ka < kb) {
+            if (kb < kc) md = ib;
+            else if (ka < kc) md = ic;
+            else md = ia;
+          } else if (ka < kc) md = ia;
+          else if (kb < kc) md = ic;
+          else md = ib;
+          const unsigned tmp = arr[first];
+          arr[first] = arr[md];
+          arr[md] = tmp;
+        }
+        __syncthreads();
+        const unsigned pivot = item_key(arr[first]);
+        // (b) the stops of the two pointers, both lists in ascending order of position: wave w takes a contiguous share
+        const int n_in = last - (first + 1);
+        const int per_wave = ((n_in + (kThreads / 64) * 64 - 1) / ((kThreads / 64) * 64)) * 64;
+        const int w_lo = first + 1 + wave * per_wave, w_hi = min(last, w_lo + per_wave);
+        unsigned cl = 0u, cr = 0u;
+        for (int base2 = w_lo; base2 < w_hi; base2 += 64) {
+          const int p = base2 + lane;
+          const bool in = p < w_hi;
+          const unsigned x = in ? item_key(arr[p]) : 0u;
+          cl += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in && !(x < pivot)));
+          cr += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in && !(pivot < x)));
+        }
+        if (lane == 0) {
+          co_cnt[0][wave] = cl;
+          co_cnt[1][wave] = cr;
+        }
+        __syncthreads();
+        unsigned at_l = 0u, at_r = 0u, cnt_l = 0u, cnt_r = 0u;
+        for (int w = 0; w < kThreads / 64; ++w) {
+          if (w < wave) {
+            at_l += co_cnt[0][w];
+            at_r += co_cnt[1][w];
+          }
+          cnt_l += co_cnt[0][w];
+          cnt_r += co_cnt[1][w];
+        }
+        unsigned short* stops_l = tl + first + 1;
+        unsigned short* stops_r = tr + first + 1;
+        for (int base2 = w_lo; base2 < w_hi; base2 += 64) {
+          const int p = base2 + lane;
+          const bool in = p < w_hi;
+          const unsigned x = in ? item_key(arr[p]) : 0u;
+          const bool ge = in && !(x < pivot), le = in && !(pivot < x);
+          const unsigned long long ml = __builtin_amdgcn_ballot_w64(ge), mr = __builtin_amdgcn_ballot_w64(le);
+          if (ge) stops_l[at_l + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(ml >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(ml), 0u))] = static_cast<unsigned short>(p);
+          if (le) stops_r[at_r + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mr >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mr), 0u))] = static_cast<unsigned short>(p);
+          at_l += __builtin_popcountll(ml);
+          at_r += __builtin_popcountll(mr);
+        }
+        if (threadIdx.x == 0) {
+          co_k = min(cnt_l, cnt_r);
+          co_tied[0] = co_tied[1] = 0u;
+        }
+        __syncthreads();
+        // (c) the k-th stop from the left swaps with the k-th from the right while they have not crossed
+        const unsigned lim = min(cnt_l, cnt_r);
+        {
+          unsigned first_invalid = lim;
+          for (unsigned k = threadIdx.x; k < lim; k += kThreads)
+            if (!(stops_l[k] < stops_r[cnt_r - 1u - k])) {
+              first_invalid = k;
+              break;  // (the valid k are a prefix: this thread's later ones are invalid as well)
+            }
+          if (first_invalid < lim) atomicMin(&co_k, first_invalid);
+        }
+        __syncthreads();
+        const unsigned K = co_k;
+        for (unsigned k = threadIdx.x; k < K; k += kThreads) {
+          const unsigned il = stops_l[k], ir = stops_r[cnt_r - 1u - k];
+          const unsigned xl = arr[il], xr = arr[ir];
+          arr[il] = xr;
+          arr[ir] = xl;
+        }
+        if (threadIdx.x == 0) {
+          unsigned c = 0x7fffffffu;  // where the left pointer stops next
+          if (K < cnt_l) c = stops_l[K];
+          if (K > 0u) c = min(c, static_cast<unsigned>(stops_r[cnt_r - K]));
+          co_cut = static_cast<int>(c);
+        }
+        __syncthreads();
+        const int cut = co_cut;
+        // (d) [first, cut) and [cut, last): on the list if they are above the threshold and hold two tied elements
+        {
+          unsigned tl2 = 0u, tr2 = 0u;
+          for (int p = first + static_cast<int>(threadIdx.x); p < last; p += kThreads) {
+            const bool td = tied[item_id(arr[p])] != 0;
+            tl2 += (td && p < cut) ? 1u : 0u;
+            tr2 += (td && p >= cut) ? 1u : 0u;
+          }
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            tl2 += __shfl_xor(tl2, d, 64);
+            tr2 += __shfl_xor(tr2, d, 64);
+          }
+          if (lane == 0) {
+            if (tl2 != 0u) atomicAdd(&co_tied[0], tl2);
+            if (tr2 != 0u) atomicAdd(&co_tied[1], tr2);
+          }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          int n = wl_n;
+          wl_first[wl_pick] = wl_first[n - 1];
+          wl_last[wl_pick] = wl_last[n - 1];
+          wl_depth[wl_pick] = wl_depth[n - 1];
+          --n;
+          const int cf[2] = {first, cut}, cl2[2] = {cut, last};
+          for (int c = 0; c < 2; ++c)
+            if (cl2[c] - cf[c] > 16 && co_tied[c] >= 2u) {
+              if (n < kWorkListCap) {
+                wl_first[n] = cf[c];
+                wl_last[n] = cl2[c];
+                wl_depth[n] = depth - 1;
+                ++n;
+              } else {
+                wl_overflow = 1;
+              }
+            }
+          wl_n = n;
+        }
+        __syncthreads();
+      }
+      if (!ok || wl_overflow != 0) return false;
+      DLIOM_SSTAMP(3);
+#ifdef DLIOM_EXPERIMENTS
+      if (threadIdx.x == 0 && blockIdx.x < 4) dbg_big[(blockIdx.x + 8) * 16 + 15] = static_cast<unsigned long long>(dbg_rounds_lds) | (static_cast<unsigned long long>(wl_n) << 32);
+#endif
+      // what is left: one wave per segment, level by level (wave_sort_arrangement), in place
+      if (static_cast<int>(threadIdx.x) < wl_n) queue_push(queue, wl_first[threadIdx.x], wl_last[threadIdx.x], wl_depth[threadIdx.x]);
+      __syncthreads();
+      {
+        const SortScratch sc{tl, tr, tied, queue};
+        if (!wave_sort_arrangement(arr, sc)) return false;
+      }
+      DLIOM_SSTAMP(4);
+      // where the tied elements are in the arrangement; a group of equal keys ends up in arrangement order (the final
+      // insertion sort is stable)
+      unsigned short* pos_of = tl;  // by position in the slice (the stops' arrays are free again)
+      for (int q = threadIdx.x; q < m; q += kThreads) {
+        const unsigned id = item_id(arr[q]);
+        if (tied[id]) pos_of[id] = static_cast<unsigned short>(q);
+      }
+      __syncthreads();
+      for (int j0 = static_cast<int>(threadIdx.x); j0 < m; j0 += 8 * kThreads) {
+        unsigned id8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) id8[u] = sv[min(j0 + u * kThreads, m - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * kThreads;
+          if (j >= m) continue;
+          const unsigned id = id8[u];
+          unsigned dst = static_cast<unsigned>(j);
+          if (tied[id]) {
+            const unsigned key = static_cast<unsigned>(sk[j]);
+            int gs = j, ge = j + 1;
+            while (gs > 0 && static_cast<unsigned>(sk[gs - 1]) == key) --gs;
+            while (ge < m && static_cast<unsigned>(sk[ge]) == key) ++ge;
+            const unsigned mine = pos_of[id];
+            unsigned r = 0u;
+            for (int w2 = gs; w2 < ge; ++w2) r += pos_of[sv[w2]] < mine ? 1u : 0u;
+            dst = static_cast<unsigned>(gs) + r;
+          }
+          sorted_id[dst] = id;
+        }
+      }
+      __syncthreads();
+      DLIOM_SSTAMP(5);
+      return true;
+    }
+  }
   unsigned long long* __restrict__ arr = A.arr + off;
   unsigned* __restrict__ l = A.l + off;
   unsigned* __restrict__ tmp_l = A.tmp_l + off;
@@ -207,10 +534,7 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
   }
   const bool any_tie = __syncthreads_or(t) != 0;
 #ifdef DLIOM_EXPERIMENTS
-#define DLIOM_SSTAMP(k) if (threadIdx.x == 0 && blockIdx.x < 4) dbg_big[(blockIdx.x + 8) * 16 + (k)] = __builtin_readcyclecounter()
   int dbg_round = 0;
-#else
-#define DLIOM_SSTAMP(k)
 #endif
   DLIOM_SSTAMP(0);
   if (!any_tie) {
@@ -239,12 +563,6 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
   //      partitioned by the whole workgroup (coop_partition: four coalesced passes), then everything left moves to LDS
   //      and wave_sort_arrangement finishes it.  (Round 4's first version ran all segments through block-wide rounds over
   //      thread-owned positions: ~90 us per round for a floor slice of 10 000 returns, four or five rounds.)
-  __shared__ int wl_first[kWorkListCap], wl_last[kWorkListCap], wl_depth[kWorkListCap];
-  __shared__ int wl_n, wl_pick, wl_total, wl_overflow, wl_mode;
-  __shared__ int wl_base[kWorkListCap + 1];
-  __shared__ unsigned co_cnt[2][kThreads / 64];
-  __shared__ unsigned co_k, co_tied[2];
-  __shared__ int co_cut;
   if (threadIdx.x == 0) {
     wl_first[0] = 0;
     wl_last[0] = m;

@@ -10,6 +10,10 @@ from dliom import synth
 from oracle import oracle as orc
 ctx = dl.Context(0)
 L = dl.load_library()
+import os
+if os.environ.get("COOP_MIN"):
+    L.dliom_exp_set_coop_min(int(os.environ["COOP_MIN"]))
+    print("coop min", os.environ["COOP_MIN"])
 for scene, size in (("cube", 0.15), ("ground", 0.15), ("ground", 0.0)):
     with synth.scene(scene):
         raw, _ = synth.scan(synth.trajectory_pose(0.5), 64, 1024)
@@ -33,6 +37,8 @@ for scene, size in (("cube", 0.15), ("ground", 0.15), ("ground", 0.0)):
         print("  big prepare wg", b, [int(a[b, k + 1] - a[b, k]) for k in range(4)])
         print("  big slice   wg", b, "count/m", a[4 + b, 10], a[4 + b, 11], [int(a[4 + b, k + 1] - a[4 + b, k]) for k in range(6)])
     so = a[8]
+    print("  LDS sort order: ties", int(so[1] - so[0]), "ranks+items", int(so[2] - so[1]), "workgroup partitions", int(so[3] - so[2]), "(%d rounds, %d segments left)" % (int(so[15] & 0xffffffff), int(so[15] >> 32)),
+          "wave stage", int(so[4] - so[3]), "tie groups", int(so[5] - so[4]))
     rounds = int(so[15] >> 32)
     print("  big sort order: tie detect + init", int(so[1] - so[0]), "global rounds", [int(so[k + 1] - so[k]) for k in range(1, min(rounds, 8))],
           "handover T", int(so[15] & 0xffffffff), "prep", int(so[11] - so[min(rounds, 9)]), "LDS replay", int(so[12] - so[11]),
