@@ -62,6 +62,35 @@ __device__ __forceinline__ double lut_probability(unsigned v, float k_scale, flo
 // multiply-adds (quarter rate) in it; csm_lm_kernel is bound by instruction issue.  32-bit offsets: bits <= 7
 // (table and pool below 4 GiB); bits = 8 grids take grid_value().
 __device__ __forceinline__ void grid_corner_values(const GridView& g, int ix, int iy, int iz, unsigned (&v)[8]) {
+  if (g.dense != nullptr) {  // uniform
+    // The dense mirror of the matcher (grid.hip: the same values with the update marker stripped and 1 for "unknown")
+    // where it covers the eight cells: ONE load per voxel instead of leaf table -> leaf, and the eight of them in one or
+    // two 128-byte bricks.  "Unknown" reads 1 there instead of 0; lut_probability() gives both the same float (0.1f:
+    // kMinProbability is what value 1 stands for, and 1 * k_scale + k_offset rounds to it -- checked on the host where
+    // the constants are made, setup_problem()).
+    const int mx = ix + g.dense_off[0], my = iy + g.dense_off[1], mz = iz + g.dense_off[2];
+    const int S = g.dense_stride;
+    if (mx >= 0 && my >= 0 && mz >= 0 && mx + 1 < S && my + 1 < S && mz + 1 < S) {
+      const unsigned B = static_cast<unsigned>(g.dense_bricks);
+      unsigned bx[2], by[2], bz[2], cx[2], cy[2], cz[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const unsigned ux = static_cast<unsigned>(mx + k), uy = static_cast<unsigned>(my + k), uz = static_cast<unsigned>(mz + k);
+        bx[k] = (ux >> 2) << 7;
+        by[k] = ((uy >> 2) * B) << 7;
+        bz[k] = ((uz >> 2) * B * B) << 7;
+        cx[k] = (ux & 3u) << 1;
+        cy[k] = (uy & 3u) << 3;
+        cz[k] = (uz & 3u) << 5;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {  // k = x << 2 | y << 1 | z
+        const int kx = k >> 2, ky = (k >> 1) & 1, kz = k & 1;
+        v[k] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(g.dense) + ((bz[kz] + by[ky] + bx[kx]) | cz[kz] | cy[ky] | cx[kx]));
+      }
+      return;
+    }
+  }
   if (g.log2_leaves > 10) {  // uniform
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = grid_value(g, ix + (k >> 2), iy + ((k >> 1) & 1), iz + (k & 1));
@@ -1067,6 +1096,12 @@ static int setup_problem(dliom_ctx* ctx, const dliom_csm_options* o, const doubl
     if (clouds[i]->n <= 0) return DLIOM_ERR_EMPTY_CLOUD;
     CsmCloudArg& c = p->args.cloud[i];
     c.g = grids[i]->view();
+    {
+      // the mirror stands in for the leaf table only if "unknown" (0) and the mirror's 1 mean the same probability
+      const float kMin = 0.1f, kMax = 1.f - 0.1f;
+      const float k_scale = (kMax - kMin) / 32766.f, k_offset = kMin - k_scale;
+      if (!(1.f * k_scale + k_offset == kMin)) c.g.dense = nullptr;
+    }
     DLIOM_TRY(ensure_morton(ctx, clouds[i]));
     c.x = clouds[i]->d_xs;  // Morton order: neighbouring lanes read neighbouring voxels; the
     c.y = clouds[i]->d_ys;  // reduction order is still fixed, so results stay reproducible

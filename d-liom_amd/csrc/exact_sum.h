@@ -93,7 +93,7 @@ __device__ __forceinline__ Fn element_fn(float x, int code, bool* ok) {
   return Fn{inc, inc, static_cast<unsigned>(c & 1), static_cast<unsigned>((c & 1) ^ 1)};
 }
 
-// compose(f, element_fn(x, code)) in straight-line code (32 of these per chunk are unrolled; branches cost registers):
+// compose(f, element_fn(x, code)) in straight-line code (16 of these per chunk are unrolled; branches cost registers):
 // f = (s0, s1, p0, p1) is updated in place.  *ok = false when x does not fit the model (never in a safe chunk).
 __device__ __forceinline__ void append_element(float x, int biased_exponent, unsigned sign, int& s0, int& s1, unsigned& p0,
                                                unsigned& p1, bool& ok) {

@@ -162,6 +162,27 @@ def test_rotational_histogram_equals_oracle(orc):
     assert np.array_equal(dl.rotational_histogram(sparse, 16).view(np.uint32), orc.compute_histogram(sparse, 16).view(np.uint32))
 
 
+def test_oracle_histogram_contributions_are_the_histograms_additions(orc):
+    """The oracle's trace of AddValueToHistogram (what dliom_diag_histogram_contributions is compared with on the GPU)
+    replayed one float addition after the other gives the oracle's histogram to the bit -- on both scene families, and the
+    reference's own fixture: one point per slice contributes nothing (rotational_scan_matcher_test.cc's histograms are
+    built from whole scans, a lone point has no neighbour to form a direction with)."""
+    from dliom import synth
+    for scene, beams, az in (("cube", 16, 256), ("ground", 32, 512)):
+        with synth.scene(scene):
+            pts, _ = synth.scan(synth.trajectory_pose(0.3), beams, az)
+        for size in (120, 17):
+            buckets, values = orc.histogram_contributions(pts, size)
+            assert len(buckets) == len(values) and len(buckets) > 100
+            assert buckets.min() >= 0 and buckets.max() < size and values.min() >= 0.0 and values.max() <= 1.0
+            h = np.zeros(size, np.float32)
+            for b, v in zip(buckets, values):
+                h[b] = np.float32(h[b] + v)
+            assert np.array_equal(h.view(np.uint32), np.asarray(orc.compute_histogram(pts, size), np.float32).view(np.uint32))
+    lone = np.array([[1.0, 0.0, 0.0], [0.0, 2.0, 1.0], [3.0, 1.0, 2.0]], np.float32)
+    assert len(orc.histogram_contributions(lone, 8)[0]) == 0
+
+
 def _imu_stream(seed, n=40, dt=0.005):
     rng = np.random.RandomState(seed)
     acc = np.array([0.3, -0.2, 9.7]) + 0.5 * rng.normal(size=(n, 3))
