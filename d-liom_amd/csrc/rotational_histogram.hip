@@ -627,16 +627,23 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     const int per_wave = (blocks512 + kThreads / 64 - 1) / (kThreads / 64);
     const int blk_lo = wave * per_wave, blk_hi = min(blocks512, blk_lo + per_wave);
     unsigned mine = 0u;
+    // (up to eight steps per wave -- clouds of 65 536 points -- the lane's eight match bits of every step stay in a
+    // register: the second pass then reads no keys and compares nothing)
+    unsigned long long kept_hits = 0ull;
+    const bool keep_hits = per_wave <= 8;
     for (int blk = blk_lo; blk < blk_hi; ++blk) {
       const int i0 = blk * 512 + lane * 8;
       uint4 kk = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);  // no key is 0x7fff
       if (i0 < n) kk = *reinterpret_cast<const uint4*>(keys + i0);                 // the key array is padded to 512
       const unsigned w4[4] = {kk.x, kk.y, kk.z, kk.w};
+      unsigned h8 = 0u;
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const short kv = static_cast<short>((w4[t >> 1] >> ((t & 1) * 16)) & 0xffffu);
-        mine += (i0 + t < n && kv == key) ? 1u : 0u;
+        h8 |= (i0 + t < n && kv == key) ? (1u << t) : 0u;
       }
+      mine += static_cast<unsigned>(__builtin_popcount(h8));
+      if (keep_hits) kept_hits |= static_cast<unsigned long long>(h8) << (8 * (blk - blk_lo));
     }
     // per-wave totals -> where this wave's points start
     unsigned wave_total = mine;
@@ -649,18 +656,20 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     for (int w = 0; w < wave; ++w) at += wave_sums[w];
     for (int blk = blk_lo; blk < blk_hi; ++blk) {
       const int i0 = blk * 512 + lane * 8;
-      uint4 kk = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
-      if (i0 < n) kk = *reinterpret_cast<const uint4*>(keys + i0);
-      const unsigned w4[4] = {kk.x, kk.y, kk.z, kk.w};
-      unsigned hits = 0u, cnt = 0u;
+      unsigned hits = 0u;
+      if (keep_hits) {
+        hits = static_cast<unsigned>(kept_hits >> (8 * (blk - blk_lo))) & 0xffu;
+      } else {
+        uint4 kk = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+        if (i0 < n) kk = *reinterpret_cast<const uint4*>(keys + i0);
+        const unsigned w4[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const short kv = static_cast<short>((w4[t >> 1] >> ((t & 1) * 16)) & 0xffffu);
-        if (i0 + t < n && kv == key) {
-          hits |= 1u << t;
-          ++cnt;
+        for (int t = 0; t < 8; ++t) {
+          const short kv = static_cast<short>((w4[t >> 1] >> ((t & 1) * 16)) & 0xffffu);
+          if (i0 + t < n && kv == key) hits |= 1u << t;
         }
       }
+      const unsigned cnt = static_cast<unsigned>(__builtin_popcount(hits));
       unsigned incl = cnt;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -863,16 +872,23 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
       }
       __syncthreads();
       for (int d = 0; (1 << d) < 2 * m; ++d) {
+        // (a level in which no marked node has a successor 2^d steps on has run off the end of the path -- after d
+        // levels the first 2^d nodes are marked, so that is all of them: on a wall the anchor moves every fifth to tenth
+        // point, the path has m / 6 nodes and the last three or four levels would only square pointers)
+        int reached = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int i = p0 + k;
           if (i < m) {
             const unsigned short t = ja[i];
-            if (mark[i]) mark[t] = 1;
+            if (mark[i]) {
+              mark[t] = 1;
+              reached |= t < m ? 1 : 0;
+            }
             jb[i] = ja[t];
           }
         }
-        __syncthreads();
+        if (__syncthreads_or(reached) == 0) break;
         unsigned short* t = ja;
         ja = jb;
         jb = t;
