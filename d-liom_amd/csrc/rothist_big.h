@@ -1088,13 +1088,17 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
   DLIOM_BSTAMP(3);
   // the chain's arrays (next pointers twice, dead and mark bytes) live in LDS when the slice is small enough for that
   // (15 000 points: the floor of a filtered 64-beam scan), else in HBM
-  const size_t chain_bytes = (static_cast<size_t>(m) + 4) * 10;
-  const bool chain_in_lds = chain_bytes <= kBigLdsBytes;
+  // (19 000 points: next and x1 of the blocked walk below as 16-bit positions, dead and mark bytes -- 6 bytes a point,
+  // 8 reserved)
+  const bool chain_in_lds = (static_cast<size_t>(m) + 4) * 8 + 64 <= kBigLdsBytes;
   const int m4 = (m + 4) & ~3;
-  unsigned* ja = chain_in_lds ? reinterpret_cast<unsigned*>(big_lds) : A.jump_a + off;
-  unsigned* jb = chain_in_lds ? ja + m4 : A.jump_b + off;
-  unsigned char* dead = chain_in_lds ? reinterpret_cast<unsigned char*>(jb + m4) : A.dead + off;
+  unsigned short* nx16 = reinterpret_cast<unsigned short*>(big_lds);  // LDS: next(i)
+  unsigned short* x1 = nx16 + m4;
+  unsigned* ja = A.jump_a + off;  // HBM: next(i), squared level by level
+  unsigned* jb = A.jump_b + off;
+  unsigned char* dead = chain_in_lds ? reinterpret_cast<unsigned char*>(x1 + m4) : A.dead + off;
   unsigned char* mark = chain_in_lds ? dead + m4 : A.mark + off;
+  __shared__ unsigned short walk_entry_t[kThreads];  // where the path enters a block of the walk (m: it does not)
   __syncthreads();  // (the exact sums' scratch lies under these arrays)
   for (int j0 = static_cast<int>(threadIdx.x); j0 < m; j0 += 8 * kThreads) {
     float x[8], y[8];
@@ -1109,15 +1113,21 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
       const int j = j0 + u * kThreads;
       if (j < m) {
         dead[j] = norm2(x[u] - cx, y[u] - cy) < kMinDistance ? 1 : 0;
-        mark[j] = j == 0 ? 1 : 0;
+        mark[j] = (j == 0 && !chain_in_lds) ? 1 : 0;
       }
     }
   }
   if (threadIdx.x == 0) {
     mark[m] = 0;
-    ja[m] = static_cast<unsigned>(m);
-    jb[m] = static_cast<unsigned>(m);
+    if (chain_in_lds) {
+      nx16[m] = static_cast<unsigned short>(m);
+      x1[m] = static_cast<unsigned short>(m);
+    } else {
+      ja[m] = static_cast<unsigned>(m);
+      jb[m] = static_cast<unsigned>(m);
+    }
   }
+  walk_entry_t[threadIdx.x] = static_cast<unsigned short>(m);
   __syncthreads();
   // next(i): the first live point farther than kMaxDistance from point i (squared lengths: rotational_histogram.hip).
   // On a floor nearly every point's answer is i + 1: that candidate is tested for eight positions at once, the others
@@ -1147,14 +1157,41 @@ __global__ __launch_bounds__(kThreads) void big_slice_kernel(const unsigned* __r
             if (dx * dx + dy * dy >= squared_jump) break;
           }
         }
-        ja[i] = static_cast<unsigned>(j);
+        if (chain_in_lds) nx16[i] = static_cast<unsigned short>(j);
+        else ja[i] = static_cast<unsigned>(j);
       }
     }
   }
   __syncthreads();
   DLIOM_BSTAMP(4);
-  // marks spread along next^(2^d) while the pointers are squared
-  for (int d = 0; (1 << d) < 2 * m; ++d) {
+  if (chain_in_lds) {
+    // ---- the nodes of the path 0 -> next(0) -> ... by a BLOCKED WALK (tests/cpp/chain_walk_model.cc is this in plain
+    //      C++ against the plain walk).  next(i) > i: the path only moves forward.  Squaring all m pointers
+    //      ceil(lg m) times (pointer doubling, below: what the arrays in HBM still get) was 50 us of a 10 000-point floor
+    //      slice -- fifteen passes over every position, bound by instruction issue.  Here the positions are cut into
+    //      blocks of kWalkBlock; (1) one thread per block, positions from the last to the first: x1(i) = the first path
+    //      node at or behind the block's end (next(i) if that already is, else x1(next(i))); (2) ONE thread hops from
+    //      block to block with x1 and notes where the path enters each; (3) one thread per block marks from there with
+    //      next.  ~2 * 64 + m / 64 dependent LDS accesses instead of 15 passes.  (A wave level in between -- x2(i), the
+    //      first node behind the WAVE's 64 blocks, thread blocks of ceil(m / 1024) positions -- was built first and was
+    //      slower than the doubling: its sweep has one lane of every wave active per step, and sixteen waves issuing
+    //      64 * 11 predicated steps are 90 000 cycles of a compute unit's instruction issue.)
+    constexpr int kWalkBlock = 64;
+    static_assert(kThreads * kWalkBlock >= 19200, "one thread per block");
+    const int b_lo = min(m, static_cast<int>(threadIdx.x) * kWalkBlock), b_hi = min(m, b_lo + kWalkBlock);
+    for (int i = b_hi - 1; i >= b_lo; --i) {
+      const unsigned v = nx16[i];
+      x1[i] = static_cast<unsigned short>(static_cast<int>(v) >= b_hi ? v : x1[v]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int e = 0; e < m; e = x1[e]) walk_entry_t[e / kWalkBlock] = static_cast<unsigned short>(e);
+    __syncthreads();
+    for (int i = walk_entry_t[threadIdx.x]; i < b_hi; i = nx16[i]) mark[i] = 1;
+    __syncthreads();
+  }
+  // marks spread along next^(2^d) while the pointers are squared (arrays in HBM)
+  for (int d = 0; !chain_in_lds && (1 << d) < 2 * m; ++d) {
     for (int i0 = static_cast<int>(threadIdx.x); i0 < m; i0 += 8 * kThreads) {
       unsigned t[8], t2[8];
       unsigned char mk[8];

@@ -675,3 +675,14 @@ def test_wave_per_segment_replay_of_std_sort_model(tmp_path, orc):
     out = subprocess.run([exe, "3000", str(slices)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "mismatches: 0 of 3000" in out.stdout, out.stdout
     assert int(re.search(r"heap sorts (\d+)", out.stdout).group(1)) >= 1, out.stdout  # the depth limit is exercised
+
+
+def test_blocked_chain_walk_model(tmp_path):
+    """tests/cpp/chain_walk_model.cc: the blocked walk that marks the nodes of the `last_point` chain 0 -> next(0) -> ...
+    in rothist_big.h (per-thread exits, per-wave exits from the last block to the first, the waves' entries, the blocks'
+    entries, the marks) against the plain walk, on 2 000 forward-pointing arrays: steps of one, short and long jumps,
+    jumps past the end, sizes around every block boundary."""
+    exe = str(tmp_path / "chain_walk_model")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "chain_walk_model.cc")])
+    out = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "mismatches: 0 of 2000" in out.stdout, out.stdout
