@@ -261,8 +261,96 @@ __device__ __forceinline__ void csm_point(const CsmPose& a, const CsmCloudArg& c
               k_offset, k_unknown, r_out, jrow);
 }
 
+// ---- the workgroup's 28 sums: a reduce-scatter over the lanes, then the four waves' results (round 4) ----------------
+// Until round 4 all 28 x 256 partial sums went to LDS (57 KB), wave w folded sums w, w + 4, ... with a six-step butterfly
+// each (84 cross-lane exchanges per lane), three barriers: 3 700 cycles per evaluation of csm_lm_kernel.  Now every wave
+// halves its 28 (padded to 32) values per step -- lanes l and l ^ 32 exchange 16 of them and keep the sums of the other
+// 16, then l ^ 16 with 8, ... -- so that after five steps lane l holds ONE quantity (number l >> 1) summed over half the
+// wave and the sixth step completes it: 32 additions and 32 exchanges instead of 168 and 84, v_permlane32/16_swap and
+// DPP instead of ds_bpermute.  The waves' 4 x 28 results meet in LDS (2 KB, double-buffered: ONE barrier per call) and
+// every thread adds them.  The order of the additions is fixed, and the same in csm_eval_kernel, csm_lm_kernel and
+// csm_lm_grid_kernel: they still produce the same bits (tested).
+struct Halves {
+  unsigned lo, hi;
+};
+__device__ __forceinline__ Halves split_double(double v) {
+  const unsigned long long u = static_cast<unsigned long long>(__double_as_longlong(v));
+  return Halves{static_cast<unsigned>(u), static_cast<unsigned>(u >> 32)};
+}
+__device__ __forceinline__ double join_double(unsigned lo, unsigned hi) {
+  return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+// lanes 32..63 of x <-> lanes 0..31 of y (v_permlane32_swap): afterwards x + y is, in lanes 0..31, x's pair sum (lane l
+// and l + 32) and in lanes 32..63 y's
+__device__ __forceinline__ void swap_halves32(double& x, double& y) {
+  const Halves a = split_double(x), b = split_double(y);
+  const auto lo = __builtin_amdgcn_permlane32_swap(a.lo, b.lo, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(a.hi, b.hi, false, false);
+  x = join_double(lo[0], hi[0]);
+  y = join_double(lo[1], hi[1]);
+}
+// odd rows of x <-> even rows of y (rows of 16 lanes; v_permlane16_swap): x + y is x's pair sum (lane l and l ^ 16) in
+// the even rows and y's in the odd rows
+__device__ __forceinline__ void swap_rows16(double& x, double& y) {
+  const Halves a = split_double(x), b = split_double(y);
+  const auto lo = __builtin_amdgcn_permlane16_swap(a.lo, b.lo, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(a.hi, b.hi, false, false);
+  x = join_double(lo[0], hi[0]);
+  y = join_double(lo[1], hi[1]);
+}
+template <int kDppCtrl>
+__device__ __forceinline__ double dpp_move_double(double v) {
+  const Halves h = split_double(v);
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(h.lo), kDppCtrl, 0xf, 0xf, false));
+  const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(h.hi), kDppCtrl, 0xf, 0xf, false));
+  return join_double(lo, hi);
+}
+__device__ __forceinline__ double from_lane_xor8(double v) { return dpp_move_double<0x128>(v); }  // row_ror:8
+__device__ __forceinline__ double from_lane_xor2(double v) { return dpp_move_double<0x4E>(v); }   // quad_perm:[2,3,0,1]
+__device__ __forceinline__ double from_lane_xor1(double v) { return dpp_move_double<0xB1>(v); }   // quad_perm:[1,0,3,2]
+__device__ __forceinline__ double from_lane_xor4(double v) {                                      // ds_swizzle, xor mask 4
+  const Halves h = split_double(v);
+  return join_double(static_cast<unsigned>(__builtin_amdgcn_ds_swizzle(static_cast<int>(h.lo), 0x101F)),
+                     static_cast<unsigned>(__builtin_amdgcn_ds_swizzle(static_cast<int>(h.hi), 0x101F)));
+}
+// keeps a (lanes whose `bit` is clear) or b (set), adds the partner's contribution to the kept one
+template <class Exchange>
+__device__ __forceinline__ double keep_and_add(double a, double b, bool bit_set, Exchange from_partner) {
+  const double send = bit_set ? a : b, keep = bit_set ? b : a;
+  return keep + from_partner(send);
+}
+// part: [2][kCsmBlock / 64][32] doubles of LDS; parity: 0 / 1 alternating from call to call (0 for a single call)
+__device__ __forceinline__ void block_reduce28(const double (&acc)[kAcc], double* part, int parity, double (&sums)[kAcc]) {
+  static_assert(kAcc == 28 && kCsmBlock == 256, "written for 28 sums and four waves");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double r1[16], r2[8], r3[4], r4[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double a = acc[i], b = i + 16 < kAcc ? acc[i + 16] : 0.;
+    swap_halves32(a, b);
+    r1[i] = a + b;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    double a = r1[i], b = r1[i + 8];
+    swap_rows16(a, b);
+    r2[i] = a + b;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r3[i] = keep_and_add(r2[i], r2[i + 4], (lane & 8) != 0, from_lane_xor8);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) r4[i] = keep_and_add(r3[i], r3[i + 2], (lane & 4) != 0, from_lane_xor4);
+  const double r5 = keep_and_add(r4[0], r4[1], (lane & 2) != 0, from_lane_xor2);
+  const double total = r5 + from_lane_xor1(r5);  // quantity number lane >> 1, over the wave's 64 lanes
+  double* mine = part + (parity & 1) * (kCsmBlock / 64) * 32;
+  if ((lane & 1) == 0) mine[wave * 32 + (lane >> 1)] = total;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kAcc; ++k) sums[k] = (mine[k] + mine[32 + k]) + (mine[64 + k] + mine[96 + k]);
+}
+
 // Every thread strides over the stacked clouds, accumulates its 28 sums in registers, then the
-// block reduces them through LDS in a FIXED order (deterministic run to run).
+// block reduces them in a FIXED order (block_reduce28; deterministic run to run).
 __global__ __launch_bounds__(kCsmBlock) void csm_eval_kernel(CsmArgs a, float k_scale, float k_offset,
                                                              float k_unknown,
                                                              double* __restrict__ partials,
@@ -287,21 +375,16 @@ __global__ __launch_bounds__(kCsmBlock) void csm_eval_kernel(CsmArgs a, float k_
       acc[27] += r * r;
     }
   }
-  // Block reduction in a fixed order: all 28 x 256 partials go to LDS once, then wave w folds
-  // values w, w+4, ... (4 LDS reads per lane + a 6-step butterfly), lane 0 writes the result.
-  __shared__ double red[kAcc][kCsmBlock];
+  __shared__ double part[2 * (kCsmBlock / 64) * 32];
+  double sums[kAcc];
+  block_reduce28(acc, part, 0, sums);
+  if (threadIdx.x < kAcc) {
+    double mine = sums[0];
 #pragma unroll
-  for (int k = 0; k < kAcc; ++k) red[k][threadIdx.x] = acc[k];
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int k = wave; k < kAcc; k += kCsmBlock / 64) {
-    double v = (red[k][lane] + red[k][lane + 64]) + (red[k][lane + 128] + red[k][lane + 192]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) {
-      partials[blockIdx.x * kAcc + k] = v;
-      if (gridDim.x == 1) final_out[k] = v;  // small problems: this block's sums ARE the result
-    }
+    for (int k = 1; k < kAcc; ++k)
+      if (static_cast<int>(threadIdx.x) == k) mine = sums[k];
+    partials[blockIdx.x * kAcc + threadIdx.x] = mine;
+    if (gridDim.x == 1) final_out[threadIdx.x] = mine;  // small problems: this block's sums ARE the result
   }
   if (gridDim.x == 1 && done_word != nullptr) {  // completion word for the host's poll (internal.h, wait_done)
     __threadfence_system();
@@ -833,8 +916,7 @@ template <int NLOC>
 struct DeviceEval {
   const CsmArgs* a;  // clouds (kernel argument)
   const LmKernelParams* prm;
-  double (*red)[kCsmBlock];  // [kAcc][kCsmBlock]
-  double* tot;               // [kAcc]
+  double* part;              // block_reduce28's LDS: [2][4][32]
   double pts[6];             // two-cloud fast path: this thread's point of cloud 0 and of cloud 1 (index clamped)
   int evaluations = 0;
   __device__ int operator()(const double x[7], Normal* out) {
@@ -880,31 +962,9 @@ struct DeviceEval {
       }
     }
     DLIOM_LM_STAMP(1);
-    __syncthreads();  // the previous evaluation's totals have been read by everyone
-#pragma unroll
-    for (int k = 0; k < kAcc; ++k) red[k][threadIdx.x] = acc[k];
-    __syncthreads();
-    // wave w folds sums w, w+4, ..., w+24 -- the seven butterflies are independent, so they are unrolled side by side
-    // (one after the other they cost seven times the cross-lane latency); same order of additions as csm_eval_kernel
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double v[kAcc / 4];
-#pragma unroll
-    for (int m = 0; m < kAcc / 4; ++m) {
-      const int k = wave + 4 * m;
-      v[m] = (red[k][lane] + red[k][lane + 64]) + (red[k][lane + 128] + red[k][lane + 192]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int m = 0; m < kAcc / 4; ++m) v[m] += __shfl_xor(v[m], off, 64);
-    if (lane == 0)
-#pragma unroll
-      for (int m = 0; m < kAcc / 4; ++m) tot[wave + 4 * m] = v[m];
-    __syncthreads();
-    DLIOM_LM_STAMP(2);
     double sums[kAcc];
-#pragma unroll
-    for (int k = 0; k < kAcc; ++k) sums[k] = tot[k];
+    block_reduce28(acc, part, evaluations, sums);  // (csm_eval_kernel's order of additions)
+    DLIOM_LM_STAMP(2);
     finish_normal<NLOC>(sums, x, pose.plus, prm->translation_weight, prm->rotation_weight, prm->target_t, prm->init_q, out);
     DLIOM_LM_STAMP(3);
     ++evaluations;
@@ -914,13 +974,11 @@ struct DeviceEval {
 
 template <int NLOC>
 __global__ __launch_bounds__(kCsmBlock) void csm_lm_kernel(CsmArgs a, LmKernelParams prm, LmKernelOut* out) {
-  __shared__ double red[kAcc][kCsmBlock];
-  __shared__ double tot[kAcc];
+  __shared__ double part[2 * (kCsmBlock / 64) * 32];
   DeviceEval<NLOC> ev;
   ev.a = &a;
   ev.prm = &prm;
-  ev.red = red;
-  ev.tot = tot;
+  ev.part = part;
   {
     const int n0 = a.cloud[0].n, n1 = a.cloud[1].n;
     const bool pair = a.num_clouds == 2 && n0 > 0 && n1 > 0 && n0 <= kCsmBlock && n1 <= kCsmBlock;
@@ -996,7 +1054,7 @@ template <int NLOC>
 struct DeviceGridEval {
   const CsmArgs* a;
   const LmKernelParams* prm;
-  double (*red)[kCsmBlock];  // [kAcc][kCsmBlock]
+  double* part;              // block_reduce28's LDS: [2][4][32]
   double* tot;               // [kAcc]
   double* partials;          // 2 x gridDim.x x kAcc
   GridSync gs;
@@ -1026,17 +1084,18 @@ struct DeviceGridEval {
         acc[27] += r * r;
       }
     }
-    __syncthreads();  // the previous evaluation's LDS values have been read by everyone
-#pragma unroll
-    for (int k = 0; k < kAcc; ++k) red[k][threadIdx.x] = acc[k];
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* mine = partials + static_cast<size_t>(evaluations & 1) * gridDim.x * kAcc;
-    for (int k = wave; k < kAcc; k += kCsmBlock / 64) {  // csm_eval_kernel's block reduction
-      double v = (red[k][lane] + red[k][lane + 64]) + (red[k][lane + 128] + red[k][lane + 192]);
+    {
+      double block_sums[kAcc];
+      block_reduce28(acc, part, evaluations, block_sums);  // csm_eval_kernel's block reduction
+      if (threadIdx.x < kAcc) {
+        double v = block_sums[0];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) mine[blockIdx.x * kAcc + k] = v;
+        for (int k = 1; k < kAcc; ++k)
+          if (static_cast<int>(threadIdx.x) == k) v = block_sums[k];
+        mine[blockIdx.x * kAcc + threadIdx.x] = v;
+      }
     }
     grid_barrier(gs);
     for (int k = wave; k < kAcc; k += kCsmBlock / 64) {  // csm_final_reduce_kernel's reduction
@@ -1059,12 +1118,12 @@ struct DeviceGridEval {
 template <int NLOC>
 __global__ __launch_bounds__(kCsmBlock) void csm_lm_grid_kernel(CsmArgs a, LmKernelParams prm, double* partials,
                                                                 unsigned* counter, LmKernelOut* out) {
-  __shared__ double red[kAcc][kCsmBlock];
+  __shared__ double part[2 * (kCsmBlock / 64) * 32];
   __shared__ double tot[kAcc];
   DeviceGridEval<NLOC> ev;
   ev.a = &a;
   ev.prm = &prm;
-  ev.red = red;
+  ev.part = part;
   ev.tot = tot;
   ev.partials = partials;
   ev.gs = GridSync{counter, 0u, false};
