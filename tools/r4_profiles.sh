@@ -28,5 +28,9 @@ PY
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wref_trace -o w -- python $R/tools/wref_full.py --no-cpu --options trajectory_builder_3d --scans 24 > $OUT/wref_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wref_trace_yard -o w -- python $R/tools/wref_full.py --no-cpu --options trajectory_builder_3d --scans 24 --scene ground > $OUT/wref_trace_yard.log 2>&1
 cd $R
-timeout 900 python -m pytest tests -q -m gpu --timeout 600 -s > $OUT/gputest.log 2>&1; tail -3 $OUT/gputest.log
+if [ -n "$R4_TEST_SUBSET" ]; then  # (a refresh of the numbers after a small change: the tests that cover it)
+  timeout 600 python -m pytest tests -q -m gpu --timeout 600 -k "$R4_TEST_SUBSET" > $OUT/gputest_subset.log 2>&1; tail -3 $OUT/gputest_subset.log
+else
+  timeout 900 python -m pytest tests -q -m gpu --timeout 600 -s > $OUT/gputest.log 2>&1; tail -3 $OUT/gputest.log
+fi
 ls $OUT | head -60
