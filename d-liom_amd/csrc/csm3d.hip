@@ -882,8 +882,8 @@ struct HostEval {
 // ---- the whole Levenberg-Marquardt loop in ONE launch (small clouds: the reference's own configuration matches
 // ~170 + ~210 points after the adaptive voxel filters, where ten launch + synchronise round trips of ~25 us each
 // were 90 % of CeresScanMatcher3D's time).  One workgroup: every thread runs the same minimize<> loop on the same
-// numbers (uniform control flow); an evaluation is the workgroup's strided accumulation + the fixed-order LDS
-// reduction of csm_eval_kernel, so for clouds that fit one workgroup of that kernel the sums are bit-identical.
+// numbers (uniform control flow); an evaluation is the workgroup's strided accumulation + the fixed-order
+// reduction of csm_eval_kernel (block_reduce28), so for clouds that fit one workgroup of that kernel the sums are bit-identical.
 struct LmKernelParams {
   LmConfig cfg;
   double translation_weight, rotation_weight;
