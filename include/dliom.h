@@ -548,7 +548,8 @@ int dliom_cloud_rotational_histogram_finish(dliom_ctx* ctx, float* histogram);
 /* Diagnostic: indices of n float keys in the order the device's SortSlice leaves them -- libstdc++'s std::sort
  * on (key, index) pairs compared by key only, EQUAL keys included (introsort's partitions restated as data-parallel
  * rounds, its heap sort at the depth limit, and a stable sort for the final insertion sort).  n <= 4096: the LDS path of
- * the small slices; above: the HBM path (radix sort + the partition rounds on the segments that hold ties). */
+ * the small slices; above: the path of the floor slices (radix sort + the partitions of the segments that hold ties --
+ * in LDS on 32-bit (rank, position) items up to ~16 000 keys, on arrays in HBM beyond). */
 int dliom_diag_std_sort_order(dliom_ctx* ctx, const float* keys, int n, int32_t* order);
 /* Diagnostic: the exact parallel replay of sequential float sums the histogram uses for ComputeCentroid and
  * histogram(bucket) += value (rotational_scan_matcher.cc:49,52-59): k arrays of n floats (values: k x n, row major),
