@@ -329,6 +329,17 @@ static int fill_cloud(dliom_ctx* ctx, char* base, const float* points_xyz, int64
   DLIOM_TRY(finish_cloud(ctx, l, n, out));
   out->base = base;
   out->max_norm = cloud_max_norm(points_xyz, n);
+  {
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int64_t i = 0; i < n; ++i) {
+      ax = std::max(ax, std::fabs(points_xyz[3 * i]));
+      ay = std::max(ay, std::fabs(points_xyz[3 * i + 1]));
+      az = std::max(az, std::fabs(points_xyz[3 * i + 2]));
+    }
+    out->abs_max[0] = ax;
+    out->abs_max[1] = ay;
+    out->abs_max[2] = az;
+  }
   return DLIOM_OK;
 }
 
@@ -463,6 +474,16 @@ int gather_and_wait(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* p
   const unsigned seq = ++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq;
   DLIOM_TRY(gather_to_pinned(ctx, jobs, num_jobs, pinned_dst, ctx->stream, ctx->done_word, seq));
   return wait_done(ctx, ctx->stream, ctx->done_word, seq);
+}
+
+int zero_words(dliom_ctx* ctx, unsigned** out) {
+  if (!ctx->zero_words_ready) {
+    DLIOM_TRY(ctx->zero_words.reserve(256));
+    DLIOM_HIP_TRY(hipMemsetAsync(ctx->zero_words.p, 0, 256, ctx->stream));
+    ctx->zero_words_ready = true;
+  }
+  *out = ctx->zero_words.as<unsigned>();
+  return DLIOM_OK;
 }
 
 // Cloud allocations are pooled per device: a scan makes four clouds (raw, filtered, high, low) and
@@ -688,6 +709,7 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   ctx->voxel.release();
   ctx->box_tables.release();
   ctx->box_error.release();
+  ctx->zero_words.release();
   ctx->box_counters.release();
   ctx->box_extents.release();
   ctx->csm_arrivals.release();
@@ -728,6 +750,13 @@ int dliom_ctx_set_tuning(dliom_ctx* ctx, int knob, int value) {
     case DLIOM_TUNE_CSM_ONE_LAUNCH_MAX:
       if (value < 0 || value > 4096) return DLIOM_ERR_INVALID_ARGUMENT;
       break;
+    case DLIOM_TUNE_RESERVED_TEST_HOOK:
+#ifdef DLIOM_TEST_HOOKS  // libdliom_hooks.so (make hooks): inject the box kernel's inconsistency word once
+      if (value != 0 && value != 1) return DLIOM_ERR_INVALID_ARGUMENT;
+      break;
+#else
+      return DLIOM_ERR_INVALID_ARGUMENT;  // the shipped library has no fault injection
+#endif
     default:
       if (value != 0 && value != 1) return DLIOM_ERR_INVALID_ARGUMENT;
   }

@@ -112,6 +112,39 @@ __device__ __forceinline__ unsigned wave_sum_lane63(unsigned v) {
   return v;
 }
 
+// ---- small copies and fills that ride along in another kernel's launch (round 5) ------------------------------------
+// A Match used to put six operations on the stream before its score kernel could start -- candidate tables H2D, fill of
+// the score volume, box tables H2D, counter memset, extent pre-pass, score kernel -- each a packet of its own with ~5 us
+// of launch / dependency latency while the device idles.  The tables are staged in device-visible pinned host memory
+// anyway: a few surplus workgroups of the FIRST kernel of the chain read them from there (PCIe, ~40 KB) and do the fills.
+// Everything is 4-byte granular; dst/src 16-byte aligned.
+struct PrepJob {
+  uint4* dst;
+  const uint4* src;     // device-visible (pinned host or device) source; null: fill with `value`
+  unsigned vec;         // whole 16-byte units
+  unsigned tail_words;  // 0..3 words behind them
+  unsigned value;
+};
+constexpr int kMaxPrepJobs = 6;
+struct PrepArgs {
+  PrepJob job[kMaxPrepJobs];
+  int n;
+};
+// executed by `nblocks` workgroups of `nthreads` threads (block = this workgroup's index among them)
+__device__ __forceinline__ void prep_block(const PrepArgs& a, unsigned block, unsigned nblocks, unsigned tid, unsigned nthreads) {
+#pragma unroll
+  for (int j = 0; j < kMaxPrepJobs; ++j) {  // static indices: the argument stays in SGPRs (no scratch copy)
+    if (j >= a.n) break;
+    const PrepJob& jb = a.job[j];
+    const uint4 v4 = make_uint4(jb.value, jb.value, jb.value, jb.value);
+    for (unsigned i = block * nthreads + tid; i < jb.vec; i += nblocks * nthreads) jb.dst[i] = jb.src != nullptr ? jb.src[i] : v4;
+    if (block == 0 && tid < jb.tail_words) {
+      unsigned* dt = reinterpret_cast<unsigned*>(jb.dst + jb.vec);
+      dt[tid] = jb.src != nullptr ? reinterpret_cast<const unsigned*>(jb.src + jb.vec)[tid] : jb.value;
+    }
+  }
+}
+
 }  // namespace dliom
 
 #endif  // DLIOM_CSRC_DEVICE_COMMON_H_

@@ -1041,6 +1041,61 @@ static void transform_origin(const float* poses7, int num_poses, const float ori
   out[2] = o[2];
 }
 
+// Host-side proof that pass 0 (the extent scan) of an insertion would report nothing for this target -- no cell beyond
+// the grid's current extent, no ray of 2^15 cells.  Every hit is the image of a cloud point under the target's rigid
+// chain: it lies in the image of the cloud's bounding box [-e, e] (e = max |x|, |y|, |z| where the cloud's producer
+// recorded them, max ||p|| per axis otherwise) -- centre c <- R c + t, half extents e <- |R| e per pose -- and, when the
+// range filter is on, within max_range of the chain's image of the origin; every miss cell lies in the box spanned by
+// the origin's cell and a hit's cell (range_data_inserter_3d.cc:36-50).  Float rounding of the chains and quaternions a
+// few 1e-7 off unit norm are covered by the relative slack; anything else (non-finite input, quaternions far from unit)
+// is "not proven" and the caller runs the scan as before.
+static bool insertion_provably_inside(const InsertTarget& tg, const float origin_local[3], const dliom_cloud& cloud) {
+  if (!(cloud.max_norm >= 0.f) || !std::isfinite(cloud.max_norm)) return false;
+  double c[3] = {0.0, 0.0, 0.0}, e[3];
+  for (int a = 0; a < 3; ++a) {
+    e[a] = cloud.abs_max[a] >= 0.f ? std::min<double>(cloud.abs_max[a], cloud.max_norm) : static_cast<double>(cloud.max_norm);
+    if (!std::isfinite(e[a])) return false;
+  }
+  for (int j = 0; j < tg.num_poses; ++j) {
+    const Quat4& q = tg.q[j];
+    const double w = q.w, x = q.x, y = q.y, z = q.z;
+    const double n2 = w * w + x * x + y * y + z * z;
+    if (!(n2 > 0.999 && n2 < 1.001)) return false;
+    // v + 2 w (u x v) + 2 u x (u x v) as a matrix (what rotate_point computes, for any q)
+    const double M[3][3] = {{1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y - w * z), 2.0 * (x * z + w * y)},
+                            {2.0 * (x * y + w * z), 1.0 - 2.0 * (x * x + z * z), 2.0 * (y * z - w * x)},
+                            {2.0 * (x * z - w * y), 2.0 * (y * z + w * x), 1.0 - 2.0 * (x * x + y * y)}};
+    double nc[3], ne[3];
+    for (int a = 0; a < 3; ++a) {
+      nc[a] = M[a][0] * c[0] + M[a][1] * c[1] + M[a][2] * c[2] + tg.t[j][a];
+      ne[a] = std::fabs(M[a][0]) * e[0] + std::fabs(M[a][1]) * e[1] + std::fabs(M[a][2]) * e[2];
+    }
+    for (int a = 0; a < 3; ++a) {
+      c[a] = nc[a];
+      e[a] = ne[a];
+    }
+  }
+  const double on = std::sqrt(double(origin_local[0]) * origin_local[0] + double(origin_local[1]) * origin_local[1] +
+                              double(origin_local[2]) * origin_local[2]);
+  double reach = (static_cast<double>(cloud.max_norm) + on) * 1.001;  // |hit - origin| in the world frame
+  if (tg.max_range > 0.f) reach = std::min(reach, static_cast<double>(tg.max_range));
+  reach = reach * (1.0 + 1e-4) + 1e-3;
+  const double res = tg.resolution;
+  if (!std::isfinite(reach) || !(res > 0.0)) return false;
+  if (reach / res + 4.0 >= 32768.0) return false;  // num_samples < 1 << 15
+  const double half = static_cast<double>(tg.half);
+  const float o[3] = {tg.ox, tg.oy, tg.oz};
+  for (int a = 0; a < 3; ++a) {
+    if (!std::isfinite(o[a]) || !std::isfinite(c[a]) || !std::isfinite(e[a])) return false;
+    const double ao = std::fabs(static_cast<double>(o[a]));
+    const double by_box = std::fabs(c[a]) + e[a] * (1.0 + 1e-4) + 1e-3;  // |hit coordinate|, from the cloud's box
+    const double by_range = ao + reach;                                   // ... from the distance to the origin
+    const double far = std::max(ao, std::min(by_box, by_range));          // hits and the origin itself
+    if (far / res + 3.0 >= half) return false;  // cells in [-half, half)
+  }
+  return true;
+}
+
 static void refresh_target(InsertTarget* tg, dliom_grid* g) {
   const GridView v = g->view();
   tg->bits = g->bits;
@@ -1093,8 +1148,6 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
     DLIOM_TRY(grids[k]->ensure_capacity(n * (1 + static_cast<int64_t>(F))));
     refresh_target(&tg, grids[k]);
   }
-  DLIOM_TRY(ctx->misc.reserve(256));
-  a.status = ctx->misc.as<int>();
   a.px = cloud->d_x;
   a.py = cloud->d_y;
   a.pz = cloud->d_z;
@@ -1102,6 +1155,32 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
   a.hit = ins->d_tables;
   a.miss = ins->d_tables + 32768;
   a.run_mask = (1u << num_targets) - 1u;
+  const dim3 grid_dim(blocks_for(n, 256), num_targets), block(256);
+  // Steady state (round 5): the scan's range is known on the host (max ||p|| travels with the cloud), so "no target
+  // needs more bits, no ray is too long" is usually PROVEN before anything is launched -- then there is no extent scan,
+  // no status fill and, above all, no verdict to wait for: the four update passes are enqueued and the call returns
+  // (the caller's next step is ordered behind them by the stream).  The wait was a polled round trip in the middle of
+  // the chain -- fill, pass 0, [host], passes 1-4 -- that kept host and device idle in turn.
+  bool proven = true;
+  for (int k = 0; k < num_targets && proven; ++k) proven = insertion_provably_inside(a.tg[k], origin, *cloud);
+  if (proven) {
+    unsigned* zeros = nullptr;
+    DLIOM_TRY(zero_words(ctx, &zeros));
+    a.status = reinterpret_cast<int*>(zeros);  // read only: "nothing to report" for every target
+    a.host_status = nullptr;
+    a.done_word = nullptr;
+    const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
+    hipLaunchKernelGGL(multi_insert_kernel<1>, grid_dim, block, 0, ctx->stream, a);
+    hipLaunchKernelGGL(multi_insert_kernel<2>, grid_dim, block, 0, ctx->stream, a);
+    if (F > 0) hipLaunchKernelGGL(multi_insert_kernel<3>, grid_dim, block, 0, ctx->stream, a);
+    hipLaunchKernelGGL(multi_insert_kernel<4>, grid_dim, block, 0, ctx->stream, a);
+    ctx->end_span(span);
+    DLIOM_HIP_TRY(hipGetLastError());
+    for (int k = 0; k < num_targets; ++k) grids[k]->used_upper += n * (1 + static_cast<int64_t>(F));
+    return DLIOM_OK;
+  }
+  DLIOM_TRY(ctx->misc.reserve(256));
+  a.status = ctx->misc.as<int>();
   DLIOM_HIP_TRY(hipMemsetAsync(a.status, 0, 8 * kMaxInsertTargets, ctx->stream));
   a.host_status = static_cast<int*>(ctx->pinned);  // device-visible; written by pass 1 only
   // The host needs pass 0's verdict, not the end of the update passes: everything that follows on this context is
@@ -1109,7 +1188,6 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
   // when that arrives (the update passes may still be running -- 50 us the caller's next step no longer waits for).
   a.done_word = ctx->done_word;
   a.done_seq = ctx->done_word != nullptr ? (++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq) : 0u;
-  const dim3 grid_dim(blocks_for(n, 256), num_targets), block(256);
   const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
   hipLaunchKernelGGL(multi_insert_kernel<0>, grid_dim, block, 0, ctx->stream, a);
   int status[2 * kMaxInsertTargets];

@@ -90,6 +90,8 @@ struct dliom_ctx {
   dliom::DevBuf box_extents;  // per (rotation block, point) extents of its lookups (rtcsm_box_extent_kernel)
   dliom::DevBuf csm_arrivals; // csm_final_reduce_kernel's wave counter (zero between evaluations)
   dliom::DevBuf box_error;  // its 'cannot happen' flag word, read by dliom_rtcsm3d_box_error
+  dliom::DevBuf zero_words; // 256 bytes that stay zero (zeroed once): status words of kernels whose checking pass was
+  bool zero_words_ready = false;  // proven unnecessary on the host (grid.hip: insertion without the extent scan)
   bool box_error_zeroed = false;
   bool force_dense_score = false;  // rerun after the LDS-box kernel flagged an inconsistency
   int tuning[DLIOM_TUNE_COUNT] = {3, 4096, 0, 0};  // dliom_ctx_set_tuning (defaults: dliom.h)
@@ -178,6 +180,8 @@ struct dliom_cloud {
   float* d_ys = nullptr;
   float* d_zs = nullptr;
   float max_norm = 0.f;    // max_i ||p_i|| (float, Eigen order), host computed
+  float abs_max[3] = {-1.f, -1.f, -1.f};  // max_i |x_i|, |y_i|, |z_i| where a producer knows them (host uploads); < 0: unknown,
+                                          // max_norm bounds every axis.  Only bounds are derived from these (grid.hip).
   bool owned_by_ctx_scratch = false;
   void* base = nullptr;    // the allocation everything above lives in
   size_t base_bytes = 0;   // its size class (cloud allocations are pooled per device)
@@ -250,6 +254,8 @@ int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* 
 int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq);
 // gather_to_pinned on ctx->stream + wait_done: the read-back of a few words without a memcpy and without a full synchronise
 int gather_and_wait(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst);
+// 64 device words that are zero and that nobody writes (zeroed on ctx->stream at first use)
+int zero_words(dliom_ctx* ctx, unsigned** out);
 // rtcsm3d.hip: exact sequential float sums of LUT probabilities under explicit float poses
 int sequential_probability_sums(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid, const float* poses7,
                                 int k, float* sums);

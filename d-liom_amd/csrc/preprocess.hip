@@ -164,16 +164,29 @@ __global__ void transform_kernel(Quat4 q, float tx, float ty, float tz, const fl
                                  float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
                                  unsigned* __restrict__ max_sq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float rx, ry, rz;
-  rotate_point(q, x[i], y[i], z[i], rx, ry, rz);
-  rx += tx;
-  ry += ty;
-  rz += tz;
-  ox[i] = rx;
-  oy[i] = ry;
-  oz[i] = rz;
-  atomicMax(max_sq, __float_as_uint(rx * rx + (ry * ry + rz * rz)));
+  const bool have = i < n;  // no early return: the wave reductions below need every lane
+  float rx = 0.f, ry = 0.f, rz = 0.f;
+  if (have) {
+    rotate_point(q, x[i], y[i], z[i], rx, ry, rz);
+    rx += tx;
+    ry += ty;
+    rz += tz;
+    ox[i] = rx;
+    oy[i] = ry;
+    oz[i] = rz;
+  }
+  // max_sq[0]: largest squared norm (the cloud's max ||p||); [1..3]: largest |x|, |y|, |z| (bounds only: grid.hip proves
+  // "this insertion cannot leave the grid's extent" from them).  One atomic per wavefront and word, not one per point.
+  float m[4] = {rx * rx + (ry * ry + rz * rz), fabsf(rx), fabsf(ry), fabsf(rz)};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicMax(max_sq + k, __float_as_uint(m[k]));
+  }
 }
 
 static int make_deskew_args(const double prev_pose[7], const double predicted_pose[7], double scan_period,
@@ -298,24 +311,27 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
   origin_in_tracking[2] = o.z;
   float *ox, *oy, *oz;
   DLIOM_TRY(alloc_device_cloud(ctx, n3, returns_in_tracking, &ox, &oy, &oz));
-  float max_norm = 0.f;
+  float max_norm = 0.f, abs_max[3] = {0.f, 0.f, 0.f};
   int st = DLIOM_OK;
   const int threads = 256;
   if (n3 > 0) {
-    if (hipMemsetAsync(d_max_sq, 0, 4, ctx->stream) != hipSuccess) st = DLIOM_ERR_HIP;
+    if (hipMemsetAsync(d_max_sq, 0, 16, ctx->stream) != hipSuccess) st = DLIOM_ERR_HIP;
     hipLaunchKernelGGL(transform_kernel, dim3(static_cast<unsigned>((n3 + threads - 1) / threads)), dim3(threads), 0,
                        ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y, ti.z, f, f + fs, f + 2 * fs,
                        static_cast<int>(n3), ox, oy, oz, d_max_sq);
     unsigned* host = static_cast<unsigned*>(ctx->pinned);
     if (st == DLIOM_OK) {
-      const GatherJob job{d_max_sq, 1};
+      const GatherJob job{d_max_sq, 4};
       st = gather_and_wait(ctx, &job, 1, host);
     }
     float sq;
     std::memcpy(&sq, host, 4);
     max_norm = std::sqrt(sq);
+    if (st == DLIOM_OK) std::memcpy(abs_max, host + 1, 12);
   }
   if (st == DLIOM_OK) st = finish_device_cloud(ctx, *returns_in_tracking, max_norm);
+  if (st == DLIOM_OK && n3 > 0)
+    for (int a = 0; a < 3; ++a) (*returns_in_tracking)->abs_max[a] = abs_max[a];
   if (st != DLIOM_OK) {
     dliom_cloud_destroy(*returns_in_tracking);
     *returns_in_tracking = nullptr;

@@ -836,40 +836,96 @@ __global__ __launch_bounds__(256) void rtcsm_rescore_chunk_fns_kernel(
   if (lane == 63) fns[static_cast<size_t>(blockIdx.y) * num_chunks + c] = out;
 }
 
+// ParityFn in two words (increment in bits 0..30, parity out in bit 31): a composition is and / select / add per word,
+// and the scans below move it with DPP (row shifts and the two row broadcasts) instead of ds_bpermute -- the scan
+// kernel is ONE workgroup per survivor and nothing but dependent latency: ~45 wave scans and ~60 barriers a survivor
+// made it 53 us for the one survivor a match usually has (round 4 profile).  Increments inside a pass's window stay
+// below 2^28 (at most 2^24 / c_min elements of at most 10 c_min each), so bit 31 is free.
+struct PFn2 {
+  unsigned a, b;  // a: parity in 0, b: parity in 1
+};
+__device__ __forceinline__ PFn2 pfn2_identity() { return PFn2{0u, 0x80000000u}; }
+__device__ __forceinline__ PFn2 pack_fn(const ParityFn& f) { return PFn2{f.s0 | (f.p0 << 31), f.s1 | (f.p1 << 31)}; }
+__device__ __forceinline__ PFn2 compose2(const PFn2& x, const PFn2& y) {  // x first, then y
+  PFn2 r;
+  r.a = (x.a & 0x7FFFFFFFu) + (static_cast<int>(x.a) < 0 ? y.b : y.a);
+  r.b = (x.b & 0x7FFFFFFFu) + (static_cast<int>(x.b) < 0 ? y.b : y.a);
+  return r;
+}
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ PFn2 dpp_fn(const PFn2& f) {  // lanes without a source (or outside the row mask) get the identity
+  PFn2 r;
+  r.a = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(f.a), kCtrl, kRowMask, 0xf, false));
+  r.b = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(0x80000000u), static_cast<int>(f.b), kCtrl, kRowMask, 0xf, false));
+  return r;
+}
+__device__ __forceinline__ PFn2 wave_inclusive_scan2(PFn2 f) {
+  f = compose2(dpp_fn<0x111, 0xf>(f), f);  // row_shr:1
+  f = compose2(dpp_fn<0x112, 0xf>(f), f);  // row_shr:2
+  f = compose2(dpp_fn<0x114, 0xf>(f), f);  // row_shr:4
+  f = compose2(dpp_fn<0x118, 0xf>(f), f);  // row_shr:8
+  f = compose2(dpp_fn<0x142, 0xa>(f), f);  // row_bcast:15 into rows 1 and 3
+  f = compose2(dpp_fn<0x143, 0xc>(f), f);  // row_bcast:31 into rows 2 and 3
+  return f;
+}
+__device__ __forceinline__ PFn2 wave_shift_right1(const PFn2& f) { return dpp_fn<0x138, 0xf>(f); }  // wave_shr:1, lane 0: identity
+__device__ __forceinline__ PFn2 lane_of(const PFn2& f, int l) {  // l uniform
+  return PFn2{static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(f.a), l)),
+              static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(f.b), l))};
+}
+__device__ __forceinline__ unsigned apply2(const PFn2& f, unsigned parity) { return (parity ? f.b : f.a) & 0x7FFFFFFFu; }
+
+// Round 5 form: thread t <-> chunk t for the whole kernel (its ChunkFns are loaded ONCE, beside the copy of the values
+// into LDS, instead of a dependent 32-byte global load per pass), the first 256 additions replayed by wave 0 out of
+// registers with v_readlane (one thread chasing 256 dependent LDS reads was a fifth of the kernel), the partial chunk a
+// pass resumes in and the chunk the sum leaves the binade in opened by the WAVE that owns them (no hand-over through
+// LDS), three barriers a pass.  Same arithmetic, same result bits as before (test_sequential_sum_kernels_bit_exact
+// compares it with the element scan and the serial replay).
 __global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_chunk_scan_kernel(
     const unsigned short* __restrict__ values, int n, int n_stride, float k_scale, float k_offset, float k_unknown,
     const unsigned* __restrict__ count, const ChunkFns* __restrict__ fns, int num_chunks, float* __restrict__ sums) {
   extern __shared__ unsigned short lds_value[];  // n_stride grid values (15 bit), input order
   if (count != nullptr && blockIdx.x >= *count) return;
-  __shared__ ParityFn wave_total[kScanThreads / 64];
-  __shared__ unsigned sh_m, sh_e, sh_i0, sh_cross_t, sh_cross_begin, sh_cross_end, sh_cross_m, sh_total, sh_cross_i, sh_cross_before,
-      sh_mismatch_t, sh_force_serial;
+  __shared__ PFn2 wave_total[kScanThreads / 64];
+  __shared__ unsigned sh_m, sh_e, sh_i0, sh_cross_t, sh_total, sh_mismatch_t, sh_force_serial;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const ChunkFns none{0xFFFFFFFFu, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u};
+  const ChunkFns cf = tid < num_chunks ? fns[static_cast<size_t>(blockIdx.x) * num_chunks + tid] : none;  // in flight during the copy
   {
     const uint4* src = reinterpret_cast<const uint4*>(values + static_cast<size_t>(blockIdx.x) * n_stride);
     uint4* dst = reinterpret_cast<uint4*>(lds_value);
     for (int i = tid; i < n_stride / 8; i += kScanThreads) dst[i] = src[i];
   }
   __syncthreads();
+  auto prob = [&](unsigned v) { return v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset; };
   auto fixed = [&](unsigned i) { return fixed_of_value(lds_value[i], k_scale, k_offset, k_unknown); };
-  if (tid == 0) {
+  const int n0 = min(n, kSerialPrefix);
+  if (wave == 0) {
     float s = 0.f;
-    const int n0 = min(n, kSerialPrefix);
-    for (int i = 0; i < n0; ++i) {
-      const unsigned v = lds_value[i];
-      s += v == 0u ? k_unknown : static_cast<float>(static_cast<int>(v)) * k_scale + k_offset;
+    if (n0 == kSerialPrefix) {
+      // element k * 64 + l sits in lane l's register k: the 256 sequential additions read them with v_readlane
+      float pv[kSerialPrefix / 64];
+#pragma unroll
+      for (int k = 0; k < kSerialPrefix / 64; ++k) pv[k] = prob(lds_value[k * 64 + lane]);
+#pragma unroll
+      for (int k = 0; k < kSerialPrefix / 64; ++k)
+#pragma unroll
+        for (int l = 0; l < 64; ++l) s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv[k]), l));
+    } else {
+      for (int i = 0; i < n0; ++i) s += prob(lds_value[i]);
     }
-    const unsigned b = __float_as_uint(s);
-    sh_m = (b & 0x7FFFFFu) | 0x800000u;
-    sh_e = (b >> 23) - 123u;
-    sh_i0 = static_cast<unsigned>(n0);
-    sh_force_serial = 0u;
+    if (lane == 0) {
+      const unsigned b = __float_as_uint(s);
+      sh_m = (b & 0x7FFFFFu) | 0x800000u;
+      sh_e = (b >> 23) - 123u;
+      sh_i0 = static_cast<unsigned>(n0);
+      sh_force_serial = 0u;
+    }
   }
   __syncthreads();
-  const ChunkFns* my_fns = fns + static_cast<size_t>(blockIdx.x) * num_chunks;
-  const ParityFn id{0u, 0u, 0u, 1u};
+  const PFn2 id = pfn2_identity();
   while (sh_i0 < static_cast<unsigned>(n)) {  // uniform: one pass per binade
-    const unsigned m = sh_m, e = sh_e, i0 = sh_i0;
+    const unsigned m = sh_m, e = sh_e, i0 = sh_i0, force_serial = sh_force_serial;
     // window that must contain the crossing (every addend >= 0.1 > 13421772 * 2^-27), rounded up to
     // a chunk boundary: elements behind the crossing are never looked at
     const unsigned c_min = max(13421772u >> e, 1u);
@@ -877,102 +933,92 @@ __global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_chunk_scan_kernel(
     const unsigned window = min(remaining, ((1u << 24) - m) / c_min + 2u);
     const unsigned c0 = i0 / kChunk;
     const unsigned i_lim = min(static_cast<unsigned>(n), ((i0 + window + kChunk - 1u) / kChunk) * kChunk);
-    // thread t <-> chunk c0 + t, clipped to [i0, i_lim)
-    const unsigned c = c0 + static_cast<unsigned>(tid);
+    // thread t <-> chunk t, clipped to [i0, i_lim): chunks before the one the walk resumes in and behind the window
+    // are the identity
+    const unsigned c = static_cast<unsigned>(tid);
     const unsigned begin = max(i0, c * kChunk), end = min(i_lim, (c + 1u) * kChunk);
-    ParityFn f = id;
+    const bool in_window = begin < end && c >= c0;
+    PFn2 f = id;
     bool mismatch = false;
-    if (tid != 0 && begin < end) {
-      const ChunkFns cf = my_fns[c];
-      if (cf.e0 == e) f = ParityFn{cf.s00, cf.s01, cf.pp0 & 1u, cf.pp0 >> 1};
-      else if (cf.e1 == e) f = ParityFn{cf.s10, cf.s11, cf.pp1 & 1u, cf.pp1 >> 1};
+    if (in_window && c != c0) {
+      if (cf.e0 == e) f = PFn2{cf.s00 | ((cf.pp0 & 1u) << 31), cf.s01 | ((cf.pp0 >> 1) << 31)};
+      else if (cf.e1 == e) f = PFn2{cf.s10 | ((cf.pp1 & 1u) << 31), cf.s11 | ((cf.pp1 >> 1) << 31)};
       else mismatch = true;
     }
     // A chunk without a function for this binade lies BEHIND the crossing (the window bound is loose
     // by up to 9x, and the real prefix proves the sum has left the binade by then): it stays the
     // identity and is never selected.  Should one ever sit before the crossing -- a violated bound --
     // the pass is repeated with such chunks opened element by element (sh_force_serial).
-    if (mismatch && sh_force_serial) {
-      for (unsigned i = begin; i < end; ++i) f = compose(f, element_fn(fixed(i), e));
+    if (mismatch && force_serial) {
+      ParityFn g = ParityFn{0u, 0u, 0u, 1u};
+      for (unsigned i = begin; i < end; ++i) g = compose(g, element_fn(fixed(i), e));
+      f = pack_fn(g);
       mismatch = false;
     }
-    if (wave == 0) {  // the chunk the walk resumes in is partial: lane per element
-      const unsigned hb = i0, he = min(i_lim, (c0 + 1u) * kChunk);
-      const unsigned i = hb + static_cast<unsigned>(lane);
-      ParityFn h = wave_inclusive_scan(i < he ? element_fn(fixed(i), e) : id, lane);
-      h.s0 = __shfl(h.s0, 63, 64);
-      h.s1 = __shfl(h.s1, 63, 64);
-      h.p0 = __shfl(h.p0, 63, 64);
-      h.p1 = __shfl(h.p1, 63, 64);
-      if (lane == 0) f = h;
+    if (static_cast<unsigned>(wave) == (c0 >> 6)) {  // the chunk the walk resumes in is partial: lane per element, by its wave
+      const unsigned he = min(i_lim, (c0 + 1u) * kChunk);
+      const unsigned i = i0 + static_cast<unsigned>(lane);
+      const PFn2 h = wave_inclusive_scan2(i < he ? pack_fn(element_fn(fixed(i), e)) : id);
+      const PFn2 whole = lane_of(h, 63);
+      if (static_cast<unsigned>(lane) == (c0 & 63u)) f = whole;
     }
     // block-wide inclusive scan over the chunk functions
-    ParityFn inc = wave_inclusive_scan(f, lane);
+    const PFn2 inc = wave_inclusive_scan2(f);
     if (lane == 63) wave_total[wave] = inc;
     if (tid == 0) {
       sh_cross_t = 0xFFFFFFFFu;
       sh_mismatch_t = 0xFFFFFFFFu;
     }
-    __syncthreads();
+    __syncthreads();  // (1) wave totals, reset words
     if (mismatch) atomicMin(&sh_mismatch_t, static_cast<unsigned>(tid));
-    ParityFn before = id;
-    for (int w = 0; w < wave; ++w) before = compose(before, wave_total[w]);
-    ParityFn excl = shfl_up_fn(inc, 1);
-    if (lane == 0) excl = id;
-    excl = compose(before, excl);
-    const ParityFn incl = compose(before, inc);
+    PFn2 before = id;
+    for (int w = 0; w < wave; ++w) before = compose2(before, wave_total[w]);
+    const PFn2 excl = compose2(before, wave_shift_right1(inc));
+    const PFn2 incl = compose2(before, inc);
     const unsigned p_start = m & 1u;
-    const unsigned mt_start = m + (p_start ? excl.s1 : excl.s0);
-    const unsigned mt_end = m + (p_start ? incl.s1 : incl.s0);
+    const unsigned mt_start = m + apply2(excl, p_start);
+    const unsigned mt_end = m + apply2(incl, p_start);
     if (tid == kScanThreads - 1) sh_total = mt_end - m;
-    if (begin < end && mt_end >= (1u << 24) && mt_start < (1u << 24)) atomicMin(&sh_cross_t, static_cast<unsigned>(tid));
-    __syncthreads();
-    if (sh_mismatch_t < sh_cross_t || (sh_cross_t == 0xFFFFFFFFu && sh_mismatch_t != 0xFFFFFFFFu)) {
+    const bool crosses = in_window && mt_end >= (1u << 24) && mt_start < (1u << 24);
+    if (crosses) atomicMin(&sh_cross_t, static_cast<unsigned>(tid));
+    __syncthreads();  // (2) first crossing chunk, first chunk without a function, total
+    const unsigned cross_t = sh_cross_t, mismatch_t = sh_mismatch_t;
+    if (mismatch_t < cross_t || (cross_t == 0xFFFFFFFFu && mismatch_t != 0xFFFFFFFFu)) {
       __syncthreads();  // everyone has read the verdict
       if (tid == 0) sh_force_serial = 1u;
       __syncthreads();
       continue;  // same (m, e, i0), chunks without a function opened serially
     }
-    if (static_cast<unsigned>(tid) == sh_cross_t) {
-      sh_cross_begin = begin;
-      sh_cross_end = end;
-      sh_cross_m = mt_start;
-    }
-    __syncthreads();
-    if (sh_cross_t != 0xFFFFFFFFu && wave == 0) {  // open the crossing chunk: lane per element
-      const unsigned cb = sh_cross_begin, ce = sh_cross_end, ms = sh_cross_m;
+    if (cross_t == 0xFFFFFFFFu) {
+      if (tid == 0) {  // the cloud ended inside this binade
+        sh_m = m + sh_total;
+        sh_i0 = i_lim;
+      }
+    } else if (static_cast<unsigned>(wave) == (cross_t >> 6)) {  // open the crossing chunk: lane per element, by its wave
+      const int cl = static_cast<int>(cross_t & 63u);
+      const unsigned cb = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(begin), cl));
+      const unsigned ce = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(end), cl));
+      const unsigned ms = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(mt_start), cl));
       const unsigned i = cb + static_cast<unsigned>(lane);
-      const ParityFn ef = i < ce ? element_fn(fixed(i), e) : id;
-      const ParityFn sc = wave_inclusive_scan(ef, lane);
-      ParityFn ex = shfl_up_fn(sc, 1);
-      if (lane == 0) ex = id;
+      const PFn2 sc = wave_inclusive_scan2(i < ce ? pack_fn(element_fn(fixed(i), e)) : id);
+      const PFn2 ex = wave_shift_right1(sc);
       const unsigned ps = ms & 1u;
-      const unsigned m_before = ms + (ps ? ex.s1 : ex.s0);
-      const unsigned m_after = ms + (ps ? sc.s1 : sc.s0);
+      const unsigned m_before = ms + apply2(ex, ps);
+      const unsigned m_after = ms + apply2(sc, ps);
       const unsigned long long crossed = __ballot(i < ce && m_after >= (1u << 24));
       const int first = __ffsll(static_cast<long long>(crossed)) - 1;
       if (lane == first) {
-        sh_cross_i = i;
-        sh_cross_before = m_before;
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      if (sh_cross_t == 0xFFFFFFFFu) {  // the cloud ended inside this binade
-        sh_m = m + sh_total;
-        sh_i0 = i_lim;
-      } else {
         // exact sum of the crossing addition, rounded once to the next binade's ulp (2U)
-        const unsigned long long X = (static_cast<unsigned long long>(sh_cross_before) << e) + fixed(sh_cross_i);
+        const unsigned long long X = (static_cast<unsigned long long>(m_before) << e) + fixed(i);
         const unsigned e2 = e + 1u;
         const unsigned long long q2 = X >> e2, f2 = X & ((1ull << e2) - 1ull), h2 = 1ull << e;
         const unsigned long long up = (f2 > h2 || (f2 == h2 && (q2 & 1ull))) ? 1ull : 0ull;
         sh_m = static_cast<unsigned>(q2 + up);
         sh_e = e2;
-        sh_i0 = sh_cross_i + 1u;
+        sh_i0 = i + 1u;
       }
     }
-    __syncthreads();
+    __syncthreads();  // (3) the next pass's state
   }
   if (tid == 0) sums[blockIdx.x] = __uint_as_float(((sh_e + 123u) << 23) | (sh_m & 0x7FFFFFu));
 }
@@ -1075,9 +1121,38 @@ struct DeviceCandidates {
   float4* trans4;  // T x (x,y,z,0): 16-byte rows for the rotation-per-lane kernel
   float* t_norm;
   float* r_angle;
+  const float4* rot_src;  // where a kernel that runs BEFORE the pending copy (PrepArgs) finds the rotations: the pinned
+                          // staging copy while the upload is pending, `rot` itself otherwise
 };
 
-static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidates* d) {
+// ---- pending copies / fills of a match (device_common.h: PrepArgs) --------------------------------------------------
+static bool prep_add(PrepArgs* prep, void* dst, const void* src, size_t bytes, unsigned value) {
+  if (prep == nullptr || prep->n >= kMaxPrepJobs || (bytes & 3u) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15u) != 0 ||
+      (reinterpret_cast<uintptr_t>(src) & 15u) != 0 || bytes / 16 > 0xFFFFFFFFull)
+    return false;
+  PrepJob& j = prep->job[prep->n++];
+  j.dst = static_cast<uint4*>(dst);
+  j.src = static_cast<const uint4*>(src);
+  j.vec = static_cast<unsigned>(bytes / 16);
+  j.tail_words = static_cast<unsigned>((bytes % 16) / 4);
+  j.value = value;
+  return true;
+}
+__global__ __launch_bounds__(256) void rtcsm_prep_kernel(PrepArgs a) { prep_block(a, blockIdx.x, gridDim.x, threadIdx.x, blockDim.x); }
+// The pending jobs as a launch of their own (score kernels other than the LDS-box one, whose pre-pass carries them).
+static int prep_flush(dliom_ctx* ctx, PrepArgs* prep) {
+  if (prep == nullptr || prep->n == 0) return DLIOM_OK;
+  unsigned most = 1;
+  for (int j = 0; j < prep->n; ++j) most = std::max(most, prep->job[j].vec);
+  hipLaunchKernelGGL(rtcsm_prep_kernel, dim3(std::min(512u, (most + 255u) / 256u)), dim3(256), 0, ctx->stream, *prep);
+  DLIOM_HIP_TRY(hipGetLastError());
+  prep->n = 0;
+  return DLIOM_OK;
+}
+
+// prep != null: the H2D copy becomes a pending job (the staged tables stay in the pinned block until the kernel that
+// carries the jobs has run -- every entry point that gets here synchronises the stream before it returns).
+static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidates* d, PrepArgs* prep = nullptr) {
   const size_t R = c.rot.size(), T = c.trans.size();
   const size_t Tpad = T;
   const size_t bytes_rot = (R * 16 + 255) & ~static_cast<size_t>(255);
@@ -1112,11 +1187,15 @@ static int upload_candidates(dliom_ctx* ctx, const Candidates& c, DeviceCandidat
     h4[4 * i + 3] = 0.f;
   }
   char* base = static_cast<char*>(ctx->cand.p);
+  d->rot_src = reinterpret_cast<const float4*>(base);
   if (total + 81920 <= ctx->pinned_bytes) {  // the last 80 KB stage the box-kernel tables and the readbacks
     // Pinned staging: truly asynchronous.  Every entry point that gets here synchronises the
     // stream before it returns, so the block is free again at the next call.
     std::memcpy(ctx->pinned, host.data(), total);
-    DLIOM_HIP_TRY(hipMemcpyAsync(base, ctx->pinned, total, hipMemcpyHostToDevice, ctx->stream));
+    if (prep_add(prep, base, ctx->pinned, total, 0u))
+      d->rot_src = static_cast<const float4*>(ctx->pinned);
+    else
+      DLIOM_HIP_TRY(hipMemcpyAsync(base, ctx->pinned, total, hipMemcpyHostToDevice, ctx->stream));
   } else {
     DLIOM_HIP_TRY(hipMemcpyAsync(base, host.data(), total, hipMemcpyHostToDevice, ctx->stream));
     DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `host` dies at scope exit
@@ -1136,7 +1215,7 @@ static int env_int(const char* name, int fallback) { return tuning_int(name, fal
 // kernel): boxes that cannot hold a typical point's lookups, or coordinates beyond the scaled range.
 static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const GridView& g, const Candidates& c,
                             const DeviceCandidates& d, int r_first, int r_last, unsigned long long* d_sums,
-                            unsigned* d_error) {
+                            unsigned* d_error, PrepArgs* prep) {
   using namespace box;
   const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
   const int n = static_cast<int>(cloud.n);
@@ -1316,6 +1395,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   const size_t pass_bytes = pass_only_bytes + group_bytes + bitmap_bytes;  // [passes | groups | bitmaps]
   DLIOM_TRY(ctx->box_tables.reserve(tau_bytes + pass_bytes));
   char* base = static_cast<char*>(ctx->box_tables.p);
+  const Group* group_src = reinterpret_cast<const Group*>(base + tau_bytes + pass_only_bytes);  // for the pre-pass (below)
   // small (a few KB): staged through the pinned block when it fits, else a synchronous copy
   if (tau_bytes + pass_bytes <= 65536 && ctx->pinned_bytes >= 81920) {
     char* h = static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 81920;
@@ -1323,7 +1403,10 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
     std::memcpy(h + tau_bytes, pass.data(), pass.size() * sizeof(Pass));
     std::memcpy(h + tau_bytes + pass_only_bytes, groups.data(), groups.size() * sizeof(Group));
     std::memcpy(h + tau_bytes + pass_only_bytes + group_bytes, bitmap.data(), bitmap.size() * 4);
-    DLIOM_HIP_TRY(hipMemcpyAsync(base, h, tau_bytes + pass_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (prep_add(prep, base, h, tau_bytes + pass_bytes, 0u))  // rides in the pre-pass, which reads its groups from the staging copy
+      group_src = reinterpret_cast<const Group*>(h + tau_bytes + pass_only_bytes);
+    else
+      DLIOM_HIP_TRY(hipMemcpyAsync(base, h, tau_bytes + pass_bytes, hipMemcpyHostToDevice, ctx->stream));
   } else {
     DLIOM_HIP_TRY(hipMemcpyAsync(base, tau.data(), tau.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     DLIOM_HIP_TRY(hipMemcpyAsync(base + tau_bytes, pass.data(), pass.size() * sizeof(Pass), hipMemcpyHostToDevice, ctx->stream));
@@ -1390,22 +1473,47 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   p.slots = slot_quads;
   p.units = passes * rot_blocks;
   DLIOM_TRY(ctx->box_counters.reserve(static_cast<size_t>(passes) * rot_blocks * 4 + 256));
-  DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_counters.p, 0, static_cast<size_t>(passes) * rot_blocks * 4, ctx->stream));
+  if (!prep_add(prep, ctx->box_counters.p, nullptr, static_cast<size_t>(passes) * rot_blocks * 4, 0u))
+    DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_counters.p, 0, static_cast<size_t>(passes) * rot_blocks * 4, ctx->stream));
   p.counters = ctx->box_counters.as<unsigned>();
   // per-(rotation block, point) extents of the lookups: the boxes' bounding boxes are reductions over these
   p.ext_stride = static_cast<int>(cloud.n_padded);
-  DLIOM_TRY(ctx->box_extents.reserve(static_cast<size_t>(rot_blocks) * 6 * static_cast<size_t>(cloud.n_padded) * 4));
+  // ... and behind them the plan: kPlanMax 16-byte records per (unit, chunk) (rtcsm_box_plan_kernel)
+  const size_t ext_bytes = (static_cast<size_t>(rot_blocks) * 6 * static_cast<size_t>(cloud.n_padded) * 4 + 255) & ~static_cast<size_t>(255);
+  const size_t plan_bytes = static_cast<size_t>(p.units) * static_cast<size_t>(p.point_chunks) * kPlanMax * sizeof(int4);
+#if DLIOM_BOX_PLAN
+  static const int use_plan = env_int("DLIOM_BOX_USE_PLAN", 1);  // experiments builds: 0 = every box planned in the score kernel
+#else
+  const int use_plan = 0;
+#endif
+  DLIOM_TRY(ctx->box_extents.reserve(ext_bytes + (use_plan ? plan_bytes : 0)));
   p.ext = ctx->box_extents.as<float>();
-  hipLaunchKernelGGL(rtcsm_box_extent_kernel, dim3(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(rot_blocks)), dim3(256),
-                     0, ctx->stream, p, g.inv_resolution, cloud.d_xs, cloud.d_ys, cloud.d_zs, ctx->box_extents.as<float>());
+  int4* d_plan = use_plan ? reinterpret_cast<int4*>(static_cast<char*>(ctx->box_extents.p) + ext_bytes) : nullptr;
+  p.plan = d_plan;
+  {
+    // the pre-pass is the first kernel of the match: one more row of workgroups carries the pending copies and fills
+    PrepArgs none;
+    none.n = 0;
+    const PrepArgs& jobs = prep != nullptr ? *prep : none;
+    const unsigned prep_rows = jobs.n > 0 ? 1u : 0u;
+    hipLaunchKernelGGL(rtcsm_box_extent_kernel, dim3(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(rot_blocks) + prep_rows),
+                       dim3(256), 0, ctx->stream, p, g.inv_resolution, cloud.d_xs, cloud.d_ys, cloud.d_zs, ctx->box_extents.as<float>(),
+                       group_src, d.rot_src, jobs);
+    if (prep != nullptr) prep->n = 0;
+  }
+  if (d_plan != nullptr)  // the boxes of every (unit, chunk), once: one wave each
+    hipLaunchKernelGGL(rtcsm_box_plan_kernel, dim3(static_cast<unsigned>(p.point_chunks), static_cast<unsigned>(p.units)), dim3(64), 0,
+                       ctx->stream, g, p, d_plan);
   const unsigned blocks = static_cast<unsigned>(slot_quads) * passes * rot_blocks;
   hipLaunchKernelGGL(rtcsm_score_box_kernel, dim3(blocks), dim3(64 * nw), lds, ctx->stream, g, p, cloud.d_xs,
                      cloud.d_ys, cloud.d_zs);
   DLIOM_HIP_TRY(hipGetLastError());
-  if (ctx->tuning[DLIOM_TUNE_INJECT_BOX_FAULT] != 0) {  // test hook: as if the kernel had flagged an inconsistency
-    ctx->tuning[DLIOM_TUNE_INJECT_BOX_FAULT] = 0;
+#ifdef DLIOM_TEST_HOOKS  // libdliom_hooks.so only (make hooks): as if the kernel had flagged an inconsistency
+  if (ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] != 0) {
+    ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] = 0;
     DLIOM_HIP_TRY(hipMemsetAsync(static_cast<char*>(ctx->box_error.p) + 4, 1, 1, ctx->stream));
   }
+#endif
   return DLIOM_OK;
 }
 
@@ -1414,14 +1522,20 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
 static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dliom_grid* grid,
                             const Candidates& c, int r_first, int r_last, DeviceCandidates* d,
                             unsigned long long** d_sums, int64_t* pad_processed, const FillJob* also_fill = nullptr) {
-  DLIOM_TRY(upload_candidates(ctx, c, d));
+  // candidate tables, the zeroed score volume (and the caller's fill): pending jobs that the first kernel of the chain
+  // carries (the box kernel's pre-pass) or one launch of their own (prep_flush) -- not a packet each
+  PrepArgs prep;
+  prep.n = 0;
+  DLIOM_TRY(upload_candidates(ctx, c, d, &prep));
   const int64_t C = c.w.num_candidates;
   DLIOM_TRY(ctx->sums.reserve(static_cast<size_t>(C) * 8));
   *d_sums = ctx->sums.as<unsigned long long>();
   {
     FillJob fills[2] = {{*d_sums, static_cast<size_t>(C) * 8, 0u}, {nullptr, 0, 0u}};
-    if (also_fill != nullptr) fills[1] = *also_fill;
-    DLIOM_TRY(fill_multi(ctx, fills, also_fill != nullptr ? 2 : 1));  // one dispatch
+    int nf = 1;
+    if (also_fill != nullptr) fills[nf++] = *also_fill;
+    for (int k = 0; k < nf; ++k)
+      if (!prep_add(&prep, fills[k].p, nullptr, fills[k].bytes, fills[k].value)) DLIOM_TRY(fill_multi(ctx, &fills[k], 1));
   }
   const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
   const int n = static_cast<int>(cloud.n);
@@ -1475,7 +1589,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
         DLIOM_HIP_TRY(hipMemsetAsync(ctx->box_error.p, 0, kBoxErrorBytes, ctx->stream));
         ctx->box_error_zeroed = true;
       }
-      s3 = launch_score_box(ctx, cloud, g, c, *d, r_first, r_last, *d_sums, ctx->box_error.as<unsigned>());
+      s3 = launch_score_box(ctx, cloud, g, c, *d, r_first, r_last, *d_sums, ctx->box_error.as<unsigned>(), &prep);
     }
     if (s3 == DLIOM_OK) {
       *pad_processed = 0;
@@ -1486,6 +1600,7 @@ static int run_score_volume(dliom_ctx* ctx, const dliom_cloud& cloud, const dlio
     if (s3 != DLIOM_ERR_CAPACITY) return s3;
     mapping = windowed ? 1 : 2;
   }
+  DLIOM_TRY(prep_flush(ctx, &prep));  // the kernels below read the device copies
   static const int forced_ppt = env_int("DLIOM_SCORE_PPT", 0);   // tuning knobs
   static const int target_blocks = env_int("DLIOM_SCORE_BLOCKS", 8192);
   const int Rs = r_last - r_first;  // rotations of this shard
@@ -1758,7 +1873,8 @@ struct RtcsmState {
 // exact cell more than one cell away from the fast one contradicts the error budget of score_box.h ("cannot
 // happen").  If it ever does, the kernel sets box_error[0] (sticky, dliom_rtcsm3d_box_error) and box_error[1]: the
 // sums are then not trusted and the match is redone with the dense kernel, which has no fast path.
-// DLIOM_TUNE_INJECT_BOX_FAULT sets the word from the host so that a test can walk this path.
+// A test walks this path in a build with -DDLIOM_TEST_HOOKS (libdliom_hooks.so), where knob 2 of dliom_ctx_set_tuning sets the
+// word from the host; the library that ships has no such switch.
 // `err1` is the word as read back; clears it on the device.
 static int box_overflowed(dliom_ctx* ctx, unsigned err1, bool* overflow) {
   *overflow = err1 != 0u;

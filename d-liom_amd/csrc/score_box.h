@@ -93,6 +93,12 @@ constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4
 #endif
 constexpr int kPipe = DLIOM_BOX_PIPE;            // steps between a gather and the accumulation of its value
 constexpr bool kLateAcc = DLIOM_BOX_LATE_ACC != 0;  // accumulate after the step's address arithmetic (else: anywhere)
+constexpr int kPlanMax = 4;    // planned boxes per (unit, chunk) (rtcsm_box_plan_kernel); a chunk that needs more, or holds a
+                               // point that fits no box, is planned by the score kernel itself as before
+#if !defined(DLIOM_EXPERIMENTS) || !defined(DLIOM_BOX_PLAN)
+#undef DLIOM_BOX_PLAN
+#define DLIOM_BOX_PLAN 1       // 0 (experiments builds): every box planned inside the score kernel (round 3/4 behaviour)
+#endif
 constexpr int kRecords = 8;    // ring of chunk records (lo[3], first point) the level-1 entries refer to
 constexpr int kListTrash = kL1Cap + kL2Cap + 4 * kRecords;  // a word nobody reads: where unlisted lanes "append"
 constexpr int kListWords = kListTrash + 4;
@@ -124,6 +130,8 @@ struct Params {
   const float* ext;        // [rot_blocks][6][ext_stride]: per point, lower / upper end per axis of its lookups under the
                            // block's rotations, in cells, before the pass's translation (rtcsm_box_extent_kernel)
   int ext_stride;
+  const int4* plan;        // [units][point_chunks][kPlanMax]: (lo[3], dim0 | dim1 << 8 | dim2 << 16 | n << 24) per planned box of the
+                           // chunk, in order; .w == -1 in the first record: not planned (rtcsm_box_plan_kernel); null: no plan
   unsigned long long* sums;
   const unsigned* order;   // ticket -> chunk (most expensive chunks first, core.hip chunk_order_kernel) or null: identity
   unsigned* counters;      // one chunk dispenser per unit = (pass, rotation block), zeroed by the host before the launch
@@ -533,6 +541,92 @@ __device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsig
   }
 }
 
+// Bounding box of every lookup of the points held by lanes [0, n) (per-lane interval ends l3 / h3, in cells, pass centre
+// included) under a workgroup's rotations and a pass's translations: wave-uniform geometry of the LDS box, false if it
+// does not fit.  Shared by the score kernel (chunks without a plan) and rtcsm_box_plan_kernel: the same instructions,
+// the same boxes.
+__device__ __forceinline__ bool box_geometry(const GridView& g, const Params& p, const Pass& ps, const float (&l3)[3],
+                                             const float (&h3)[3], int n, int lane, Geometry& geo) {
+  const bool have = lane < n;
+  bool fits = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    // clamp far outliers: a box that large is rejected below anyway
+    const float l = fmaxf(wave_min_f(have ? l3[a] : 3.0e38f) - ps.reach[a], -1.0e6f);
+    const float h = fminf(wave_max_f(have ? h3[a] : -3.0e38f) + ps.reach[a], 1.0e6f);
+    geo.lo[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(l)));
+    geo.dim[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(h))) - geo.lo[a] + 1;
+  }
+  {  // x: whole 4-cell groups of the bricked mirror (mirror coordinate = index + dense_off)
+    const int m_lo = (geo.lo[0] + g.dense_off[0]) & ~3;
+    const int m_hi = geo.lo[0] + g.dense_off[0] + geo.dim[0];  // exclusive
+    geo.lo[0] = m_lo - g.dense_off[0];
+    geo.dim[0] = ((m_hi - m_lo) + 3) & ~3;
+  }
+  geo.sx = static_cast<unsigned>(geo.dim[0]);
+  if (((geo.sx >> 2) & 1u) == 0u) geo.sx += 4u;  // row stride = 2 * odd dwords: rows spread over banks
+  const unsigned sy = static_cast<unsigned>(geo.dim[1]) | 1u;
+  geo.sxy = geo.sx * sy;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    fits = fits && geo.dim[a] <= kMaxDim && abs(ps.gi[a] - geo.lo[a]) < 1000;
+    geo.kb[a] = static_cast<float>(ps.gi[a] - geo.lo[a]) + ps.f[a];
+  }
+  fits = fits && static_cast<long long>(geo.sxy) * geo.dim[2] <= p.cells && geo.sxy <= 32767u;
+  return fits;
+}
+// the per-lane interval ends of box_geometry for point `i` (pre-pass table + the pass's centre)
+__device__ __forceinline__ void point_interval(const Params& p, const Pass& ps, const float* __restrict__ ext_rb, int i,
+                                               float (&l3)[3], float (&h3)[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    // 0.0502 instead of the 0.05 of the fused form fma(c -+ he, inv, uc): two more roundings of values < 1024
+    l3[a] = (ext_rb[static_cast<size_t>(2 * a) * p.ext_stride + i] + ps.uc[a]) - 0.0502f;
+    h3[a] = (ext_rb[static_cast<size_t>(2 * a + 1) * p.ext_stride + i] + ps.uc[a]) + 0.0502f;
+  }
+}
+
+// Round 5: the boxes of a chunk planned ONCE, outside the score kernel.  There every one of a workgroup's four waves
+// computed the same bounding box -- six wave reductions and the fit test, ~390 vector instructions an attempt, 10 % of
+// everything the kernel issued, on the critical path between two boxes -- and a retry with fewer points when it did not
+// fit.  One wave per (unit, chunk) here walks the chunk exactly as the score kernel would (same box_geometry, same
+// halving rule) and writes up to kPlanMax records; the score kernel then reads a record (16 bytes, uniform) per box.
+// Chunks that need more boxes or hold a point that fits no box keep the in-kernel planning (first record's w = -1).
+__global__ __launch_bounds__(64) void rtcsm_box_plan_kernel(GridView g, Params p, int4* __restrict__ plan) {
+  const int lane = threadIdx.x, c = blockIdx.x, unit = blockIdx.y;
+  const int rb = unit % p.rot_blocks, tp = unit / p.rot_blocks;
+  const Pass ps = p.pass[tp];
+  const float* ext_rb = p.ext + static_cast<size_t>(rb) * 6 * p.ext_stride;
+  int4* out = plan + (static_cast<size_t>(unit) * p.point_chunks + c) * kPlanMax;
+  const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
+  int lo = c_begin, nrec = 0, n_guess = p.chunk;
+  bool bad = false;
+  int4 rec0 = make_int4(0, 0, 0, -1);
+  while (lo < c_end) {
+    int n = min(c_end - lo, n_guess);
+    float l3[3], h3[3];
+    point_interval(p, ps, ext_rb, lo + (lane < n ? lane : 0), l3, h3);
+    Geometry geo;
+    bool fits;
+    for (;;) {
+      fits = box_geometry(g, p, ps, l3, h3, n, lane, geo);
+      if (fits || n == 1) break;
+      n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
+    }
+    if (!fits || nrec == kPlanMax) {
+      bad = true;
+      break;
+    }
+    n_guess = min(p.chunk, n >= 4 ? 2 * n : 4);
+    const int4 rec = make_int4(geo.lo[0], geo.lo[1], geo.lo[2], geo.dim[0] | (geo.dim[1] << 8) | (geo.dim[2] << 16) | (n << 24));
+    if (nrec == 0) rec0 = rec;
+    else if (lane == 0) out[nrec] = rec;
+    ++nrec;
+    lo += n;
+  }
+  if (lane == 0) out[0] = bad ? make_int4(0, 0, 0, -1) : rec0;
+}
+
 // Pre-pass of a launch: for every (rotation block, point) the interval per axis, in cells and before the pass's
 // translation, that contains the point's image under every rotation of the block:
 //   R_c (p + dc x p)  +-  |R_c| (hd (x) |p|)  +-  theta2 |p|      (metres)
@@ -540,13 +634,22 @@ __device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsig
 // double).  The score kernel used to compute this per box in every wave (~390 vector instructions an attempt, 10 % of
 // everything it issued, and on the critical path of a workgroup between two boxes); now a box's extent is six loads
 // and the reductions.  One thread per point, blockIdx.y = rotation block.
+// Round 5: the workgroups with blockIdx.y == rot_blocks carry the match's pending copies and fills (PrepArgs,
+// device_common.h) -- the candidate and box tables out of pinned host memory, the zeroed score volume and counters -- so
+// this kernel is the first of the chain and therefore reads ITS OWN inputs (groups, rotations) from the staged copies
+// (`group_src`, `rot_src`: the same bytes the prep workgroups are copying).
 __global__ __launch_bounds__(256) void rtcsm_box_extent_kernel(Params p, float inv, const float* __restrict__ px,
                                                                const float* __restrict__ py, const float* __restrict__ pz,
-                                                               float* __restrict__ ext) {
+                                                               float* __restrict__ ext, const Group* __restrict__ group_src,
+                                                               const float4* __restrict__ rot_src, PrepArgs prep) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, rb = blockIdx.y;
+  if (rb >= p.rot_blocks) {
+    prep_block(prep, blockIdx.x, gridDim.x, threadIdx.x, blockDim.x);
+    return;
+  }
   if (i >= p.n) return;
-  const Group grp = p.group[rb];
-  const float4 qcc = p.rot[p.r_first + rb * p.nw * 64 + grp.c_lane];
+  const Group grp = group_src[rb];
+  const float4 qcc = rot_src[p.r_first + rb * p.nw * 64 + grp.c_lane];
   const Quat4 qc{qcc.x, qcc.y, qcc.z, qcc.w};
   float rabs[9];  // |R(qc)|, row major
   {
@@ -675,59 +778,49 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
       ++stamp_tickets;
 #endif
       {
-        const int c = chunk_id;
+        const int c = __builtin_amdgcn_readfirstlane(chunk_id);
         const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
         int lo = c_begin;
+        // this chunk's plan: in order, one record per box (first record's w == -1: planned here, as before)
+        const int4* plan_c = p.plan + (static_cast<size_t>(unit) * p.point_chunks + c) * kPlanMax;
+        const bool chunk_planned = DLIOM_BOX_PLAN && p.plan != nullptr && __builtin_amdgcn_readfirstlane(plan_c[0].w) != -1;
+        int box_i = 0;
         while (lo < c_end) {
-          int n = min(c_end - lo, n_guess);
+          int n;
           Geometry geo;
           bool fits_out = false;
-          // ---- bounding box of every lookup of (these points) x (the workgroup's rotations) x (this pass): the
-          //      per-point extents come from the pre-pass (lanes = POINTS here), every wave reduces the same values;
-          //      a box that does not fit is retried with fewer points -- only the reductions are redone
-          float l3[3], h3[3];
-          {
-            const int i = lo + (lane < n ? lane : 0);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              // 0.0502 instead of the 0.05 of the fused form fma(c -+ he, inv, uc): two more roundings of values < 1024
-              l3[a] = (ext_rb[static_cast<size_t>(2 * a) * p.ext_stride + i] + ps.uc[a]) - 0.0502f;
-              h3[a] = (ext_rb[static_cast<size_t>(2 * a + 1) * p.ext_stride + i] + ps.uc[a]) + 0.0502f;
-            }
-          }
-          for (;;) {
-            const bool have = lane < n;
-            bool fits = true;
-            fits_out = false;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              // clamp far outliers: a box that large is rejected below anyway
-              const float l = fmaxf(wave_min_f(have ? l3[a] : 3.0e38f) - ps.reach[a], -1.0e6f);
-              const float h = fminf(wave_max_f(have ? h3[a] : -3.0e38f) + ps.reach[a], 1.0e6f);
-              geo.lo[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(l)));
-              geo.dim[a] = __builtin_amdgcn_readfirstlane(static_cast<int>(floorf(h))) - geo.lo[a] + 1;
-            }
-            {  // x: whole 4-cell groups of the bricked mirror (mirror coordinate = index + dense_off)
-              const int m_lo = (geo.lo[0] + g.dense_off[0]) & ~3;
-              const int m_hi = geo.lo[0] + g.dense_off[0] + geo.dim[0];  // exclusive
-              geo.lo[0] = m_lo - g.dense_off[0];
-              geo.dim[0] = ((m_hi - m_lo) + 3) & ~3;
-            }
+          if (DLIOM_BOX_PLAN && chunk_planned) {
+            // ---- the box comes from the plan (rtcsm_box_plan_kernel): one uniform 16-byte record
+            const int4 rec = plan_c[box_i];
+            ++box_i;
+            const int w = __builtin_amdgcn_readfirstlane(rec.w);
+            geo.lo[0] = __builtin_amdgcn_readfirstlane(rec.x);
+            geo.lo[1] = __builtin_amdgcn_readfirstlane(rec.y);
+            geo.lo[2] = __builtin_amdgcn_readfirstlane(rec.z);
+            geo.dim[0] = w & 0xff;
+            geo.dim[1] = (w >> 8) & 0xff;
+            geo.dim[2] = (w >> 16) & 0xff;
+            n = (w >> 24) & 0x7f;
             geo.sx = static_cast<unsigned>(geo.dim[0]);
-            if (((geo.sx >> 2) & 1u) == 0u) geo.sx += 4u;  // row stride = 2 * odd dwords: rows spread over banks
-            const unsigned sy = static_cast<unsigned>(geo.dim[1]) | 1u;
-            geo.sxy = geo.sx * sy;
+            if (((geo.sx >> 2) & 1u) == 0u) geo.sx += 4u;
+            geo.sxy = geo.sx * (static_cast<unsigned>(geo.dim[1]) | 1u);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              fits = fits && geo.dim[a] <= kMaxDim && abs(ps.gi[a] - geo.lo[a]) < 1000;
-              geo.kb[a] = static_cast<float>(ps.gi[a] - geo.lo[a]) + ps.f[a];
+            for (int a = 0; a < 3; ++a) geo.kb[a] = static_cast<float>(ps.gi[a] - geo.lo[a]) + ps.f[a];
+            fits_out = true;
+          } else {
+            // ---- bounding box of every lookup of (these points) x (the workgroup's rotations) x (this pass): the
+            //      per-point extents come from the pre-pass (lanes = POINTS here), every wave reduces the same values;
+            //      a box that does not fit is retried with fewer points -- only the reductions are redone
+            n = min(c_end - lo, n_guess);
+            float l3[3], h3[3];
+            point_interval(p, ps, ext_rb, lo + (lane < n ? lane : 0), l3, h3);
+            for (;;) {
+              fits_out = box_geometry(g, p, ps, l3, h3, n, lane, geo);
+              DLIOM_BOX_STAT(p, threadIdx.x == 0, 7, 1);  // bounding boxes computed
+              if (fits_out) break;
+              if (n == 1) break;
+              n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
             }
-            fits = fits && static_cast<long long>(geo.sxy) * geo.dim[2] <= p.cells && geo.sxy <= 32767u;
-            fits_out = fits;
-            DLIOM_BOX_STAT(p, threadIdx.x == 0, 7, 1);  // bounding boxes computed
-            if (fits) break;
-            if (n == 1) break;
-            n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
           }
           n_guess = min(p.chunk, n >= 4 ? 2 * n : 4);
           if (since_flush + n > kFlushPoints) {

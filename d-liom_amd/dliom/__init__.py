@@ -40,7 +40,8 @@ ERR_EMPTY_CLOUD = -8
 ERR_CAPACITY = -9
 ERR_SOLVER = -10
 ERR_PEER_FAILED = -12
-TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_INJECT_BOX_FAULT, TUNE_CSM_GRID_SYNC = 0, 1, 2, 3
+TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_RESERVED_TEST_HOOK, TUNE_CSM_GRID_SYNC = 0, 1, 2, 3
+HOOKS_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdliom_hooks.so")  # -DDLIOM_TEST_HOOKS build (tests only)
 
 KERNEL_RTCSM_SCORE, KERNEL_RTCSM_SELECT, KERNEL_RTCSM_RESCORE, KERNEL_CSM_EVAL, KERNEL_INSERT = range(5)
 
@@ -402,7 +403,8 @@ class Context:
         return int(n.value)
 
     def set_tuning(self, knob, value):
-        """dliom_ctx_set_tuning: TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_INJECT_BOX_FAULT, TUNE_CSM_GRID_SYNC."""
+        """dliom_ctx_set_tuning: TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_CSM_GRID_SYNC (knob 2 is reserved: refused by
+        the shipped library, the fault injection of libdliom_hooks.so)."""
         _check(self._L.dliom_ctx_set_tuning(self.h, int(knob), int(value)), "set_tuning")
 
     def get_tuning(self, knob):

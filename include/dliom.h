@@ -730,10 +730,11 @@ enum {
                                          the leaf table, 0 point-per-lane over the leaf table */
   DLIOM_TUNE_CSM_ONE_LAUNCH_MAX = 1,  /* CeresScanMatcher3D: clouds up to this many points (sum over grids) run the whole
                                          trust-region loop in one launch (default 4096, 0 = never) */
-  DLIOM_TUNE_INJECT_BOX_FAULT = 2,    /* test hook: the next match treats the box kernel's consistency word as set, i.e.
-                                         takes the "redo on the dense kernel" path once (same result by construction);
-                                         it sets only the per-match word, never the sticky flags that
-                                         dliom_rtcsm3d_box_error reports */
+  DLIOM_TUNE_RESERVED_TEST_HOOK = 2,  /* reserved: dliom_ctx_set_tuning refuses it (DLIOM_ERR_INVALID_ARGUMENT).  Only a
+                                         test build of the library (-DDLIOM_TEST_HOOKS, `make hooks` ->
+                                         libdliom_hooks.so, loaded by one GPU test) accepts it: the next match then
+                                         treats the box kernel's consistency word as set and takes the "redo on the
+                                         dense kernel" path once.  The shipped library contains no fault injection. */
   DLIOM_TUNE_CSM_GRID_SYNC = 3,       /* CeresScanMatcher3D on large clouds: 1 = the whole loop in one launch with grid
                                          barriers, 0 = one launch per evaluation (default: measured 0.27 ms against
                                          0.35 ms per 131 072-point match -- the barrier, the final reduction and the

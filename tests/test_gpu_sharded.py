@@ -1,5 +1,6 @@
-"""BASELINE config 4 through the C entry points: dliom_rtcsm3d_match_sharded with a gloo collective between two
-processes (both on GPU 0 -- the collective is the caller's, so a one-GPU box can run the two-rank protocol), and
+"""BASELINE config 4 through the C entry points: dliom_rtcsm3d_match_sharded with a gloo collective between two and
+between EIGHT processes (all on GPU 0 -- the collective is the caller's, so a one-GPU box can run the N-rank protocol,
+including the rank that fails before the exchange), and
 dliom_rtcsm3d_match_sharded_rccl on a one-rank RCCL communicator (ncclAllReduce really runs)."""
 import ctypes as C
 import os
@@ -52,23 +53,26 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_collective_through_the_c_entry_point():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_one_collective_through_the_c_entry_point(world):
+    """world = 8 is the control flow of the driver's 8-GPU run (eight shards of the rotations, one exchange) with every
+    rank on GPU 0: the collective is the caller's, so a one-GPU box can run it."""
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     ret = mpc.Manager().dict()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    assert ret.get(0) is True and ret.get(1) is True
+    assert all(ret.get(r) is True for r in range(world)), dict(ret)
 
 
 def _failing_worker(rank, world, port, ret):
-    """Rank 1 hands in an empty cloud (DLIOM_ERR_EMPTY_CLOUD before any kernel): it must still join the collective,
-    and rank 0 must come back with DLIOM_ERR_PEER_FAILED instead of hanging in the all-reduce."""
+    """The last rank hands in an empty cloud (DLIOM_ERR_EMPTY_CLOUD before any kernel): it must still join the collective,
+    and every other rank must come back with DLIOM_ERR_PEER_FAILED instead of hanging in the all-reduce."""
     for p in (ROOT, os.path.join(ROOT, "d-liom_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -79,7 +83,7 @@ def _failing_worker(rank, world, port, ret):
     from dliom import sharded
     ctx = dl.Context(0)
     orc, og, dg, pts, init, opts = _scene(dl, ctx)
-    cloud = dl.PointCloud(ctx, pts if rank == 0 else pts[:0])
+    cloud = dl.PointCloud(ctx, pts if rank != world - 1 else pts[:0])  # the LAST rank fails
     shard = dl.RtcsmShard(ctx, opts, rank, world)
     try:
         sharded.sharded_match(shard, init, cloud, dg, dist=dist)
@@ -90,19 +94,20 @@ def _failing_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_a_failing_rank_still_joins_the_collective():
+@pytest.mark.parametrize("world", [2, 8])
+def test_a_failing_rank_still_joins_the_collective(world):
     import torch.multiprocessing as mp
     import dliom as dl
     mpc = mp.get_context("spawn")
     ret = mpc.Manager().dict()
     port = _free_port()
-    procs = [mpc.Process(target=_failing_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [mpc.Process(target=_failing_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(300)
         assert p.exitcode == 0, "a rank hung or crashed"
-    assert ret.get(0) == dl.ERR_PEER_FAILED and ret.get(1) == dl.ERR_EMPTY_CLOUD, dict(ret)
+    assert all(ret.get(r) == dl.ERR_PEER_FAILED for r in range(world - 1)) and ret.get(world - 1) == dl.ERR_EMPTY_CLOUD, dict(ret)
 
 
 def _rccl_one_rank_main():

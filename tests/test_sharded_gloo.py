@@ -1,6 +1,6 @@
-"""World-size-2 gloo test (CPU) of the candidate-sharding protocol of dliom.sharded: two ranks,
-each owning half of the candidate rotations, reach the unsharded winner through the two MAX
-all-reduces.  The local shard is backed by the oracle's exact per-candidate scores here (no GPU
+"""World-size-2 and world-size-8 gloo tests (CPU) of the candidate-sharding protocols of dliom.sharded: N ranks,
+each owning a contiguous share of the candidate rotations, reach the unsharded winner through the two MAX
+all-reduces of the two-phase protocol and through the ONE exchange of dliom_rtcsm3d_match_sharded's.  The local shard is backed by the oracle's exact per-candidate scores here (no GPU
 in this container); on a GPU the same protocol function drives dliom.RtcsmShard
 (tests/test_gpu_parity.py::test_sharded_match_single_process)."""
 import os
@@ -63,26 +63,38 @@ def _worker(rank, world, port, ret):
             score, index = sharded.unpack_winner(packed)
             return score, cand[index].astype(np.float64), index
 
+        def match(self, init_, cloud, grid, exchange):
+            """dliom_rtcsm3d_match_sharded's protocol: own exact winner, ONE exchange (a rank whose shard holds no
+            candidate -- more ranks than rotations -- contributes 0)."""
+            self.begin(init_, cloud, grid)
+            local = self.finish(np.float32(0).view(np.uint32)) if self.mine.any() else 0
+            score_, pose_, index_ = self.decode(exchange(local))
+            return score_, pose_, index_
+
     score, pose, index = sharded.sharded_match_two_phase(OracleShard(), init, pts, og, dist=dist)
     ok = (index == ref["best_index"] and np.float32(score) == np.float32(ref["score"]) and
           np.array_equal(pose, ref["pose"]))
+    # ... and the one-collective protocol the C entry points implement
+    score1, pose1, index1 = sharded.sharded_match(OracleShard(), init, pts, og, dist=dist)
+    ok = ok and index1 == index and np.float32(score1) == np.float32(score) and np.array_equal(pose1, pose)
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_protocol_world_size_2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_protocol_world_size(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(300)
         assert p.exitcode == 0
-    assert ret.get(0) is True and ret.get(1) is True
+    assert all(ret.get(r) is True for r in range(world)), dict(ret)
 
 
 def test_pack_winner_orders_like_the_reference():
