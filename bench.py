@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="5 = BASELINE config 5 (128 x 2048 returns, 5 cm voxels, 3 map scans); 2 = the headline config")
     ap.add_argument("--no-pmc", action="store_true", help="skips the rocprofv3 --pmc child runs (roofline counters)")
-    ap.add_argument("--no-config5", action="store_true", help="N > 1: skips the sharded config-5 line")
+    ap.add_argument("--no-config5", action="store_true", help="skips the config-5 line (N = 1: two submaps, four grids, three steps; N > 1: the sharded one)")
     ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skips the one-rank run of the library's RCCL entry point")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: scene + 3 matches, no timing
     a = ap.parse_args()
@@ -91,11 +91,29 @@ def launch_ranks(args):
     os.execv(sys.executable, cmd)
 
 
+SECOND_SUBMAP = []  # --config 5: the (hi, lo) grids of the second active submap, inserted into beside the matched one
+
+
+def insertion_targets(g_hi, g_lo, pf):
+    t = [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)]
+    if SECOND_SUBMAP:
+        t += [(SECOND_SUBMAP[0], [pf], HIGH_RES_MAX_RANGE), (SECOND_SUBMAP[1], [pf], 0.0)]
+    return t
+
+
 def build_scene(args, dl, synth, ctx):
     """Submap (map_scans scans inserted at ground truth) and the scans to match; the same on every rank."""
     ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
     g_hi = dl.HybridGrid(ctx, args.high_resolution)
     g_lo = dl.HybridGrid(ctx, args.low_resolution)
+    second = []
+    if args.config == 5:
+        # BASELINE config 5, "multi-submap insertion": TWO active submaps (submap_3d.cc:303-314) -- the newer one holds the
+        # later half of the map scans -- and beams of +-35 degrees, so that returns reach the cube's corners (26 m) and the
+        # search window is the one BASELINE.md section 3 states: C = 343 x 19^3 = 2 352 637
+        synth.ELEVATION["cube"] = (-35.0, 35.0)
+        second = [dl.HybridGrid(ctx, args.high_resolution), dl.HybridGrid(ctx, args.low_resolution)]
+    SECOND_SUBMAP[:] = second
     centers = synth.bubbles()
     for s in range(args.map_scans):
         pose = synth.trajectory_pose(0.1 * s)
@@ -104,6 +122,9 @@ def build_scene(args, dl, synth, ctx):
         pf = pose.astype(np.float32)
         ins.InsertCloud(g_hi, cloud, poses=[pf], max_range=HIGH_RES_MAX_RANGE)
         ins.InsertCloud(g_lo, cloud, poses=[pf])
+        if second and s >= args.map_scans // 2:
+            ins.InsertCloud(second[0], cloud, poses=[pf], max_range=HIGH_RES_MAX_RANGE)
+            ins.InsertCloud(second[1], cloud, poses=[pf])
         cloud.close()
     scans = []
     for k in range(args.distinct_scans):
@@ -217,7 +238,7 @@ def main():
         c = time.perf_counter()
         pf = p2.astype(np.float32)
         # Submap3D::InsertRangeData: high-resolution grid (range filtered) + low-resolution grid, fused
-        dl.insert_cloud_multi(ins, sc["cloud"], [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)])
+        dl.insert_cloud_multi(ins, sc["cloud"], insertion_targets(g_hi, g_lo, pf))
         d = time.perf_counter()
         if timed and args.dump_steps:
             sys.stderr.write("step %d scan %d: rtcsm %.3f ceres %.3f insert %.3f ms, E %d\n" % (
@@ -375,7 +396,7 @@ def main():
                 "max_scan_range": float(st.window.max_scan_range),
                 "E_mean": float(np.mean(evals)) if evals else 0.0,
                 "rescored_candidates_last": int(st.num_rescored),
-                "map_scans": args.map_scans,
+                "map_scans": args.map_scans, "grids_inserted_into": 2 + len(SECOND_SUBMAP),
                 "parallelism": ("candidate shards x%d (RCCL max all-reduce)" if sharded_mode else "replicas x%d") % world,
             },
             "stage_ms_per_scan": {k: 1e3 * v / args.steps for k, v in stage.items()},
@@ -390,6 +411,11 @@ def main():
             out["sharded_config5"] = config5_line
         if world == 1 and not args.no_wref and args.config == 2:
             out["wref"] = wref_line(dl, ctx, cpu=not args.no_cpu_baseline)
+        if world == 1 and args.config == 2 and not args.no_config5:
+            try:  # BASELINE config 5 in the driver's record: two active submaps, four grids, C = 2 352 637, three steps
+                out["config5"] = config5_line(dl, synth, ctx, steps=3, with_oracle=not args.no_cpu_baseline)
+            except Exception as e:
+                out["config5"] = {"error": ("%s: %s" % (type(e).__name__, e))[:300]}
         if world == 1 and not args.no_cpu_baseline:
             # the oracle leg: checker first (one more step, compared end to end), then the CPU baseline
             parity = parity_check(dl, ctx, scans[1 % len(scans)], g_hi, g_lo, ins, rt, cs)
@@ -425,7 +451,7 @@ def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sh
             _, p1 = sharded.sharded_match(shard, sc["init"], sc["cloud"], g_hi, dist=dist, device=dev)
         p2, _ = cs.Match(sc["init"][:3], p1, [(sc["cloud"], g_hi), (sc["cloud"], g_lo)])
         pf = p2.astype(np.float32)
-        dl.insert_cloud_multi(ins, sc["cloud"], [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)])
+        dl.insert_cloud_multi(ins, sc["cloud"], insertion_targets(g_hi, g_lo, pf))
 
     def fence():
         ctx.synchronize()
@@ -451,6 +477,100 @@ def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sh
             "collective": "dliom_rtcsm3d_match_sharded_rccl" if rccl_comm is not None else "callback",
             "value": steps / float(tt.item()), "unit": "scans/s", "scaling": "strong", "steps": steps,
             "ms_per_step": 1e3 * float(tt.item()) / steps, "C": int(st.window.num_candidates), "N": int(st.num_points)}
+
+
+def config5_line(dl, synth, ctx, steps=3, with_oracle=True):
+    """BASELINE config 5 as BASELINE.json words it -- "128-beam x 2048 dense cloud, 5 cm voxels, multi-submap insertion +
+    scan match" -- short enough for the default N = 1 line, so that the DRIVER times it: two active submaps (four grids:
+    hi + lo of each, submap_3d.cc:303-314), the scan matched against the older submap's 5 cm grid (RTCSM3D over
+    C = 343 x 19^3 candidates + CeresScanMatcher3D hi + lo) and inserted into all four grids by the fused insertion.
+    The sensor's beams span +-35 degrees here so that returns reach the 30 m cube's corners (26 m): the window
+    BASELINE.md section 3 states, C = 2 352 637 (with the +-15 degrees of config 2 the farthest return is 23.5 m away and
+    C = 1 685 159).  Winner checked against the oracle on sampled candidates (the full loop is 6e11 lookups)."""
+    keep = synth.ELEVATION["cube"]
+    synth.ELEVATION["cube"] = (-35.0, 35.0)
+    try:
+        beams, az, res_hi, res_lo, map_scans = 128, 2048, 0.05, 0.45, 3
+        ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
+        grids = [dl.HybridGrid(ctx, r) for r in (res_hi, res_lo, res_hi, res_lo)]  # submap A (hi, lo), submap B (hi, lo)
+        centers = synth.bubbles()
+        for s in range(map_scans):
+            pose = synth.trajectory_pose(0.1 * s)
+            pts, _ = synth.scan(pose, beams, az, centers=centers)
+            cloud = dl.PointCloud(ctx, pts)
+            pf = pose.astype(np.float32)
+            targets = [(grids[0], [pf], HIGH_RES_MAX_RANGE), (grids[1], [pf], 0.0)]
+            if s >= map_scans // 2:  # the newer submap holds the later half of the scans (ActiveSubmaps3D)
+                targets += [(grids[2], [pf], HIGH_RES_MAX_RANGE), (grids[3], [pf], 0.0)]
+            dl.insert_cloud_multi(ins, cloud, targets)
+            cloud.close()
+        truth = synth.trajectory_pose(0.1 * map_scans)
+        pts, _ = synth.scan(truth, beams, az, centers=centers)
+        sc = dict(truth=truth, pts=pts, init=synth.perturb_pose(truth, 0.1, 0.5, seed=13), cloud=dl.PointCloud(ctx, pts))
+    finally:
+        synth.ELEVATION["cube"] = keep
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_OPTS)
+    cs = dl.CeresScanMatcher3D(ctx, CSM_OPTS)
+    stage = {"rtcsm": 0.0, "ceres": 0.0, "insert": 0.0}
+
+    def one(timed):
+        a = time.perf_counter()
+        _, p1 = rt.Match(sc["init"], sc["cloud"], grids[0])
+        b = time.perf_counter()
+        p2, _ = cs.Match(sc["init"][:3], p1, [(sc["cloud"], grids[0]), (sc["cloud"], grids[1])])
+        c = time.perf_counter()
+        pf = p2.astype(np.float32)
+        dl.insert_cloud_multi(ins, sc["cloud"], [(grids[0], [pf], HIGH_RES_MAX_RANGE), (grids[1], [pf], 0.0),
+                                                 (grids[2], [pf], HIGH_RES_MAX_RANGE), (grids[3], [pf], 0.0)])
+        ctx.synchronize()
+        d = time.perf_counter()
+        if timed:
+            stage["rtcsm"] += b - a
+            stage["ceres"] += c - b
+            stage["insert"] += d - c
+
+    one(False)
+    ctx.set_profiling(2)
+    ctx.reset_profiling()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one(True)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n = ctx.kernel_time(dl.KERNEL_RTCSM_SCORE)
+    ctx.set_profiling(0)
+    st = rt.last_stats()
+    C, n = int(st.window.num_candidates), int(st.num_points)
+    rebuilds, mirror_bytes, windowed = grids[0].mirror_stats()
+    out = {"workload": "config5 W-dense: 128x2048 scan (beams +-35 deg: returns to the cube's corners), 5 cm voxels, RTCSM3D + "
+                       "CeresScanMatcher3D(hi+lo) against the older of TWO active submaps, fused insertion into all four grids",
+           "value": steps / elapsed, "unit": "scans/s", "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+           "stage_ms_per_scan": {k: 1e3 * v / steps for k, v in stage.items()},
+           "C": C, "N": n, "angular_window": int(st.window.angular_window_size), "linear_window": int(st.window.linear_window_size),
+           "max_scan_range": float(st.window.max_scan_range), "grids_inserted_into": 4, "hi_grid_bits": int(grids[0].bits),
+           "score_kernel": int(st.score_kernel), "score_kernel_ms": k_ms / max(k_n, 1),
+           "pairs_per_s": float(C) * n / (k_ms / max(k_n, 1) * 1e-3) if k_ms > 0 else None,
+           "frac_useful": (float(C) * n / (k_ms / max(k_n, 1) * 1e-3)) / USEFUL_PAIRS_PER_S if k_ms > 0 else None,
+           "mirror": {"bytes": mirror_bytes, "windowed": windowed, "rebuilds": rebuilds}, "box_kernel_flags": int(rt.box_error())}
+    if with_oracle:
+        from oracle import oracle as orc
+        origins, values = grids[0].download_blocks()
+        og = orc.HybridGrid(res_hi)
+        leaf, cell = np.nonzero(values)
+        xyz = np.stack([origins[leaf, 0] + (cell & 7), origins[leaf, 1] + ((cell >> 3) & 7), origins[leaf, 2] + (cell >> 6)], axis=1).astype(np.int32)
+        og.set_values(xyz, values[leaf, cell])
+        score, p1 = rt.Match(sc["init"], sc["cloud"], grids[0])
+        st = rt.last_stats()
+        threads = min(32, os.cpu_count() or 1)
+        ref, sampled = sampled_oracle_match(orc, rt, sc, grids[0], og, st, threads, sample=1000, top_n=256)
+        out["parity"] = {"ok": bool(sampled["ok"] and int(st.best_index) == ref["best_index"] and
+                                    np.float32(score).tobytes() == np.float32(ref["score"]).tobytes() and np.array_equal(p1, ref["pose"])),
+                         "how": sampled["how"], "oracle_threads": threads}
+    sc["cloud"].close()
+    for g in grids:
+        g.close()
+    return out
 
 
 def score_kernel_counters(args, kernel):
@@ -585,7 +705,7 @@ def parity_check(dl, ctx, sc, g_hi, g_lo, ins, rt, cs):
     dq = float(2.0 * np.arccos(min(1.0, abs(float(np.dot(p2[3:], r2["pose"][3:]))))))
     ceres_ok = dt <= 1e-6 and dq <= 1e-6
     pf = np.asarray(p2, dtype=np.float32)
-    dl.insert_cloud_multi(ins, sc["cloud"], [(g_hi, [pf], HIGH_RES_MAX_RANGE), (g_lo, [pf], 0.0)])
+    dl.insert_cloud_multi(ins, sc["cloud"], insertion_targets(g_hi, g_lo, pf))
     world_pts = orc.transform_points(pf, sc["pts"])
     origin = orc.transform_points(pf, np.zeros((1, 3), np.float32))[0]
     d = (world_pts - origin).astype(np.float32)

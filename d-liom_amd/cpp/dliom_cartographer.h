@@ -499,7 +499,11 @@ class RangeDataSynchronizer {
 
 // proto::LocalTrajectoryBuilderOptions3D: the front end's options plus the AddRangeData / IMU fields
 struct LocalTrajectoryBuilderOptions3D {
-  dliom_front_end_options front_end;     // adaptive filters, matchers, motion filter, submaps
+  // The IMU options start from the library's defaults (trajectory_builder_3d.lua's imu block): a caller overrides fields,
+  // it never has to know every field -- a struct filled by hand would leave fields added later (round 4:
+  // imu.tangent_preintegration, which selects the integrator) indeterminate, and dliom_imu_window_create refuses those.
+  LocalTrajectoryBuilderOptions3D() : front_end() { dliom_imu_window_default_options(&imu); }
+  dliom_front_end_options front_end;     // adaptive filters, matchers, motion filter, submaps (the caller fills it: no defaults)
   dliom_imu_window_options imu;          // imu block + WindowOptimize; imu.graph_reset_every < 0: follow
                                          // front_end.num_range_data like the reference (.cc:750), 0: never reset
   float min_range = 1.f, max_range = 100.f;

@@ -453,11 +453,11 @@ int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* 
   return DLIOM_OK;
 }
 
-int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq) {
+int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq, int max_poll_us) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n(done_word, __ATOMIC_ACQUIRE) == done_seq) return DLIOM_OK;
-    if ((spins & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
+    if ((spins & 63u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(max_poll_us)) break;
   }
   if (ctx != nullptr) ++ctx->poll_fallbacks;  // long kernels in front are expected; a count that grows with every call is not
   DLIOM_HIP_TRY(hipStreamSynchronize(stream));

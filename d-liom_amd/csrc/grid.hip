@@ -10,6 +10,8 @@
 // (hybrid_grid.h:143-409) into one dependent load while keeping its 1 KiB
 // leaves, its index range [-32<<bits, 32<<bits) and its growth rule.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -566,17 +568,42 @@ void dliom_grid::drop_dense() {
 static int build_mirror(dliom_grid* g, const int off[3], int stride, bool windowed) {
   const size_t bricks = static_cast<size_t>((stride + 3) >> 2);
   const size_t cells = bricks * bricks * bricks * 64;
-  if (g->d_dense != nullptr) g->drop_dense();
-  DLIOM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->d_dense), cells * sizeof(uint16_t)));
-  DLIOM_HIP_TRY(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(g->d_dense), 1, cells, g->ctx->stream));
+  // A window rebuilt around a new pose has the size of the old one (the radius is the scan's, clamped): the allocation
+  // is kept -- a 4 GB hipFree synchronises the device and the hipMalloc behind it is no cheaper -- and only refilled.
+  // Every failure below leaves the grid WITHOUT a mirror (d_dense null), never with a half-built one.
+  const bool reuse = g->d_dense != nullptr && g->dense_stride == stride;
+  if (g->d_dense != nullptr && !reuse) g->drop_dense();
+  g->dense_stride = 0;  // not usable until it is filled
+  g->dense_bricks = 0;
+  g->dense_windowed = false;
+  if (!reuse) {
+    if (cells * sizeof(uint16_t) > (size_t{1} << 30)) {  // windows and bits = 4 mirrors: is the memory there at all?
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < cells * sizeof(uint16_t) + (size_t{1} << 30)) {
+        g->d_dense = nullptr;
+        return DLIOM_ERR_GRID_EXTENT;  // the caller falls back to the leaf-table kernels
+      }
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&g->d_dense), cells * sizeof(uint16_t)) != hipSuccess) {
+      (void)hipGetLastError();
+      g->d_dense = nullptr;
+      return DLIOM_ERR_GRID_EXTENT;
+    }
+  }
   int64_t count = 0;
-  DLIOM_TRY(g->refresh_count(&count));
+  int st = hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(g->d_dense), 1, cells, g->ctx->stream) == hipSuccess ? DLIOM_OK : DLIOM_ERR_HIP;
+  if (st == DLIOM_OK) st = g->refresh_count(&count);
   DenseOff o{{off[0], off[1], off[2]}};
-  if (count > 1) {
+  if (st == DLIOM_OK && count > 1) {
     hipLaunchKernelGGL(dense_fill_kernel, dim3(static_cast<unsigned>(count - 1)), dim3(256), 0, g->ctx->stream,
                        g->d_slot_coord, g->d_pool, g->d_dense, o, stride);
-    DLIOM_HIP_TRY(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) st = DLIOM_ERR_HIP;
   }
+  if (st != DLIOM_OK) {
+    g->drop_dense();
+    return st;
+  }
+  ++g->dense_rebuilds;
   g->dense_stride = stride;
   g->dense_bricks = static_cast<int>(bricks);
   for (int a = 0; a < 3; ++a) g->dense_off[a] = off[a];
@@ -741,6 +768,15 @@ int dliom_grid_destroy(dliom_grid* g) {
 int dliom_grid_resolution(const dliom_grid* g, float* resolution) {
   if (g == nullptr || resolution == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   *resolution = g->resolution;
+  return DLIOM_OK;
+}
+
+int dliom_grid_mirror_stats(const dliom_grid* g, int64_t* rebuilds, int64_t* bytes, int* windowed) {
+  if (g == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (rebuilds != nullptr) *rebuilds = g->dense_rebuilds;
+  if (bytes != nullptr)
+    *bytes = g->d_dense != nullptr ? static_cast<int64_t>(g->dense_bricks) * g->dense_bricks * g->dense_bricks * 128 : 0;
+  if (windowed != nullptr) *windowed = g->d_dense != nullptr && g->dense_windowed ? 1 : 0;
   return DLIOM_OK;
 }
 
@@ -1121,6 +1157,19 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
   if (n == 0) return DLIOM_OK;
   if (n > (int64_t{1} << 30)) return DLIOM_ERR_INVALID_ARGUMENT;
   dliom_ctx* ctx = grids[0]->ctx;
+#ifdef DLIOM_EXPERIMENTS
+  static const int timing = tuning_int("DLIOM_TIMING", 0);
+  const auto t_begin = std::chrono::steady_clock::now();
+  struct TimingGuard {
+    std::chrono::steady_clock::time_point t0;
+    int on;
+    const char* path = "scan";
+    ~TimingGuard() {
+      if (on) std::fprintf(stderr, "TIMING insert (%s): %.1f us on the host\n", path,
+                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+  } timing_guard{t_begin, timing};
+#endif
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   MultiInsertArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -1177,6 +1226,9 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
     ctx->end_span(span);
     DLIOM_HIP_TRY(hipGetLastError());
     for (int k = 0; k < num_targets; ++k) grids[k]->used_upper += n * (1 + static_cast<int64_t>(F));
+#ifdef DLIOM_EXPERIMENTS
+    timing_guard.path = "proven";
+#endif
     return DLIOM_OK;
   }
   DLIOM_TRY(ctx->misc.reserve(256));

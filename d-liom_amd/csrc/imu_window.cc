@@ -1201,8 +1201,9 @@ int dliom_imu_window_default_options(dliom_imu_window_options* o) {
 int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out) {
   if (options == nullptr || out == nullptr || options->window_size < 2 || options->window_size > 16 ||
       options->iterations < 1 || !(options->acc_noise > 0) || !(options->gyr_noise > 0) || !(options->acc_bias_noise > 0) ||
-      !(options->gyr_bias_noise > 0) || options->graph_reset_every < 0 || options->graph_reset_every == 1)
-    return DLIOM_ERR_INVALID_ARGUMENT;
+      !(options->gyr_bias_noise > 0) || options->graph_reset_every < 0 || options->graph_reset_every == 1 ||
+      (options->tangent_preintegration != 0 && options->tangent_preintegration != 1))  // a struct filled without
+    return DLIOM_ERR_INVALID_ARGUMENT;  // dliom_imu_window_default_options leaves the (round 4) trailing field indeterminate
   // the gravity factor goes on the state frames_for_online_gravity_estimate keys back (:828): it has to be in the window
   if (options->enable_gravity_factor != 0 &&
       (options->frames_for_online_gravity_estimate < 2 || options->window_size < options->frames_for_online_gravity_estimate + 1))

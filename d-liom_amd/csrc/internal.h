@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <string>
@@ -118,6 +119,8 @@ struct dliom_ctx {
   float aux_rotation[4] = {1.f, 0.f, 0.f, 0.f};
   bool aux_has_rotation = false;
   bool hist_expect_big = true;  // the previous cloud had height slices above 4096 points (rotational_histogram.hip)
+  int hist_poll_us = 150;       // poll window of the histogram's completion word: twice what the previous histogram took
+  std::chrono::steady_clock::time_point hist_enqueued_at;  // ... measured from its enqueue
   // the big slices' kernels (one workgroup per slice, a few hundred microseconds) run on a stream of their own beside the
   // small slices' kernel (256 workgroups): created with the first histogram that needs them
   hipStream_t hist_big_stream = nullptr;
@@ -157,6 +160,7 @@ struct dliom_grid {
   int dense_bricks = 0;
   int dense_off[3] = {0, 0, 0};  // mirror coordinate = cell index + dense_off
   bool dense_windowed = false;   // the mirror covers a cube around a match's initial pose, not the whole grid (bits >= 5)
+  int64_t dense_rebuilds = 0;    // how often the mirror was (re)built: a windowed mirror on a moving sensor (dliom_grid_mirror_stats)
   int ensure_dense();            // the whole grid (bits <= 4), else DLIOM_ERR_GRID_EXTENT
   // the whole grid if it is small enough, else a window that holds the cells [centre - radius, centre + radius] on every
   // axis (kept while the next request still fits; rebuilt around the new centre with a margin otherwise)
@@ -251,7 +255,10 @@ int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* 
 // launch + hipStreamSynchronize 11.8 us, launch + polling a pinned word 6.5 us, and a 4-byte hipMemcpyAsync D2H in
 // front of the synchronise 22.3 us): polls for a short while, then falls back to hipStreamSynchronize (long kernels
 // in front, or an error that keeps the word from ever arriving).
-int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq);
+// max_poll_us: how long to poll before the fallback -- 150 us for the read-backs behind short kernels; a caller whose chain
+// is known to take longer (the histogram of a scan with a floor: 0.4 ms) passes what its last call took (round 4 burnt
+// the 150 us and then synchronised on every such call: `poll_fallbacks: 621` in profiles/r4_hist_bench.json).
+int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq, int max_poll_us = 150);
 // gather_to_pinned on ctx->stream + wait_done: the read-back of a few words without a memcpy and without a full synchronise
 int gather_and_wait(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* pinned_dst);
 // 64 device words that are zero and that nobody writes (zeroed on ctx->stream at first use)

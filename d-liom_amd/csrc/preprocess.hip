@@ -159,14 +159,18 @@ __global__ void split_xyzt_kernel(const float4* __restrict__ aos, int n, float* 
 }
 
 // sensor::TransformPointCloud in float (sensor/point_cloud.cc:25-33): rotation * p + translation.
-__global__ void transform_kernel(Quat4 q, float tx, float ty, float tz, const float* __restrict__ x,
-                                 const float* __restrict__ y, const float* __restrict__ z, int n,
-                                 float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
-                                 unsigned* __restrict__ max_sq) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool have = i < n;  // no early return: the wave reductions below need every lane
-  float rx = 0.f, ry = 0.f, rz = 0.f;
-  if (have) {
+// partial_max[4 * block + k]: per workgroup the largest squared norm (k = 0: the cloud's max ||p||) and the largest
+// |x|, |y|, |z| (bounds only: grid.hip proves "this insertion cannot leave the grid's extent" from them).  No atomics:
+// one atomicMax per point on one word was the whole kernel (11 us for 46 k points; four words at one per wavefront made
+// it 23 -- every one of them serialises at the memory side); the host takes the maximum of <= kTransformBlocks partials.
+constexpr int kTransformBlocks = 128;
+__global__ __launch_bounds__(256) void transform_kernel(Quat4 q, float tx, float ty, float tz, const float* __restrict__ x,
+                                                        const float* __restrict__ y, const float* __restrict__ z, int n,
+                                                        float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
+                                                        float* __restrict__ partial_max) {
+  float m[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float rx, ry, rz;
     rotate_point(q, x[i], y[i], z[i], rx, ry, rz);
     rx += tx;
     ry += ty;
@@ -174,19 +178,22 @@ __global__ void transform_kernel(Quat4 q, float tx, float ty, float tz, const fl
     ox[i] = rx;
     oy[i] = ry;
     oz[i] = rz;
+    m[0] = fmaxf(m[0], rx * rx + (ry * ry + rz * rz));
+    m[1] = fmaxf(m[1], fabsf(rx));
+    m[2] = fmaxf(m[2], fabsf(ry));
+    m[3] = fmaxf(m[3], fabsf(rz));
   }
-  // max_sq[0]: largest squared norm (the cloud's max ||p||); [1..3]: largest |x|, |y|, |z| (bounds only: grid.hip proves
-  // "this insertion cannot leave the grid's extent" from them).  One atomic per wavefront and word, not one per point.
-  float m[4] = {rx * rx + (ry * ry + rz * rz), fabsf(rx), fabsf(ry), fabsf(rz)};
+  __shared__ float part[4][4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], off, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = m[k];
   }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicMax(max_sq + k, __float_as_uint(m[k]));
-  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    partial_max[4 * blockIdx.x + threadIdx.x] =
+        fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
 }
 
 static int make_deskew_args(const double prev_pose[7], const double predicted_pose[7], double scan_period,
@@ -295,9 +302,9 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
                                   float origin_in_tracking[3]) {
   const size_t nn = static_cast<size_t>(std::max<int64_t>(n2, 1));
   auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-  DLIOM_TRY(ctx->rescore.reserve(3 * al(4 * nn) + 256));  // filtered returns | max-norm word (misc holds the inputs)
+  DLIOM_TRY(ctx->rescore.reserve(3 * al(4 * nn) + 16 * kTransformBlocks));  // filtered returns | per-workgroup maxima (misc holds the inputs)
   float* f = ctx->rescore.as<float>();
-  unsigned* d_max_sq = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->rescore.p) + 3 * al(4 * nn));
+  float* d_partial_max = reinterpret_cast<float*>(static_cast<char*>(ctx->rescore.p) + 3 * al(4 * nn));
   const size_t fs = al(4 * nn) / 4;
   int64_t n3 = 0;
   DLIOM_TRY(voxel_filter_arrays(ctx, Soa{rx, ry, rz, nullptr, n2}, voxel_filter_size, f, f + fs, f + 2 * fs, nullptr, &n3));
@@ -315,19 +322,20 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
   int st = DLIOM_OK;
   const int threads = 256;
   if (n3 > 0) {
-    if (hipMemsetAsync(d_max_sq, 0, 16, ctx->stream) != hipSuccess) st = DLIOM_ERR_HIP;
-    hipLaunchKernelGGL(transform_kernel, dim3(static_cast<unsigned>((n3 + threads - 1) / threads)), dim3(threads), 0,
-                       ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y, ti.z, f, f + fs, f + 2 * fs,
-                       static_cast<int>(n3), ox, oy, oz, d_max_sq);
-    unsigned* host = static_cast<unsigned*>(ctx->pinned);
+    const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((n3 + threads - 1) / threads, kTransformBlocks));
+    hipLaunchKernelGGL(transform_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y,
+                       ti.z, f, f + fs, f + 2 * fs, static_cast<int>(n3), ox, oy, oz, d_partial_max);
+    float* host = static_cast<float*>(ctx->pinned);
+    const GatherJob job{d_partial_max, 4 * blocks};
+    st = gather_and_wait(ctx, &job, 1, host);
     if (st == DLIOM_OK) {
-      const GatherJob job{d_max_sq, 4};
-      st = gather_and_wait(ctx, &job, 1, host);
+      float sq = 0.f;
+      for (unsigned b = 0; b < blocks; ++b) {
+        sq = std::max(sq, host[4 * b]);
+        for (int a = 0; a < 3; ++a) abs_max[a] = std::max(abs_max[a], host[4 * b + 1 + a]);
+      }
+      max_norm = std::sqrt(sq);  // sqrt is monotone and correctly rounded: == the maximum of the norms
     }
-    float sq;
-    std::memcpy(&sq, host, 4);
-    max_norm = std::sqrt(sq);
-    if (st == DLIOM_OK) std::memcpy(abs_max, host + 1, 12);
   }
   if (st == DLIOM_OK) st = finish_device_cloud(ctx, *returns_in_tracking, max_norm);
   if (st == DLIOM_OK && n3 > 0)

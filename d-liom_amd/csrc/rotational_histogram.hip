@@ -1436,25 +1436,38 @@ int enqueue_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch
     big_stream = ctx->hist_big_stream;
     DLIOM_HIP_TRY(hipEventRecord(ctx->hist_fork, stream));
     DLIOM_HIP_TRY(hipStreamWaitEvent(big_stream, ctx->hist_fork, 0));
+    // From here on kernels may be running on big_stream: an error return must not leave them unjoined (the next call may
+    // reallocate or reuse the scratch they read and write) -- every failure waits for that stream before it returns.
+    auto forked = [&](hipError_t e) {
+      if (e == hipSuccess) return true;
+      set_last_error("rotational histogram, big-slice chain", e, __FILE__, __LINE__);
+      (void)hipStreamSynchronize(big_stream);
+      return false;
+    };
     hipLaunchKernelGGL(big_prepare_kernel, dim3(kMaxBig), dim3(kThreads), 0, big_stream, rx, ry, keys, n, bin_counts, A, flags);
-    DLIOM_HIP_TRY(hipGetLastError());
-    DLIOM_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sort_temp, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, sort_items, 0,
-                                                     kBigKeyBits, big_stream));
+    if (!forked(hipGetLastError())) return DLIOM_ERR_HIP;
+    if (!forked(hipcub::DeviceRadixSort::SortPairs(sort_temp, temp_bytes, A.key_in, A.key_out, A.val_in, A.val_out, sort_items, 0,
+                                                   kBigKeyBits, big_stream)))
+      return DLIOM_ERR_HIP;
     if ((ctx->func_attr_set & kFuncAttrHistogramBig) == 0u) {
-      DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(big_sort_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(kBigLdsBytes)));
-      DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(big_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(kBigLdsBytes)));
+      if (!forked(hipFuncSetAttribute(reinterpret_cast<const void*>(big_sort_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(kBigLdsBytes))) ||
+          !forked(hipFuncSetAttribute(reinterpret_cast<const void*>(big_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(kBigLdsBytes))))
+        return DLIOM_ERR_HIP;
       ctx->func_attr_set |= kFuncAttrHistogramBig;
     }
     hipLaunchKernelGGL(big_slice_kernel, dim3(kMaxBig), dim3(kThreads), kBigLdsBytes, big_stream, bin_counts, histogram_size, squared_jump, A,
                        c_bucket, c_value, flags);
-    DLIOM_HIP_TRY(hipGetLastError());
-    DLIOM_HIP_TRY(hipEventRecord(ctx->hist_join, big_stream));
+    if (!forked(hipGetLastError())) return DLIOM_ERR_HIP;
+    if (!forked(hipEventRecord(ctx->hist_join, big_stream))) return DLIOM_ERR_HIP;
   }
   hipLaunchKernelGGL(slice_kernel, dim3(256), dim3(kThreads), lds, stream, rx, ry, rz, keys, n, bin_counts, histogram_size,
                      squared_jump, c_bucket, c_value, flags, with_big ? 1 : 0);
-  if (with_big) DLIOM_HIP_TRY(hipStreamWaitEvent(stream, ctx->hist_join, 0));
+  if (with_big && hipStreamWaitEvent(stream, ctx->hist_join, 0) != hipSuccess) {
+    (void)hipStreamSynchronize(ctx->hist_big_stream);  // joined the hard way
+    return DLIOM_ERR_HIP;
+  }
   hipLaunchKernelGGL(accumulate_kernel, dim3(static_cast<unsigned>(histogram_size)), dim3(64 * kAccWaves), acc_lds, stream, c_bucket,
                      c_value, static_cast<int>(n_padded), histogram_size, d_hist);
   DLIOM_HIP_TRY(hipGetLastError());
@@ -1476,6 +1489,15 @@ int read_histogram(const void* pinned_src, int histogram_size, float* histogram,
   return DLIOM_OK;
 }
 
+// The histogram's completion word, polled for twice as long as the previous histogram took from enqueue to arrival (a
+// scan with a floor: ~0.4 ms, a cube scan ~0.14 ms), at least the 150 us of every other read-back and at most 3 ms.
+static int wait_histogram(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned seq) {
+  const int s = wait_done(ctx, stream, done_word, seq, ctx->hist_poll_us);
+  const double took_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ctx->hist_enqueued_at).count();
+  ctx->hist_poll_us = static_cast<int>(std::min(3000.0, std::max(150.0, 2.0 * took_us)));
+  return s;
+}
+
 // One complete histogram on `stream`, waiting for it; runs the cloud a second time when it turns out to need the big
 // path that was not enqueued (the context then expects big slices from the next cloud on).
 int run_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch, void* pinned, unsigned* done_word, unsigned* seq_counter,
@@ -1484,8 +1506,9 @@ int run_histogram(dliom_ctx* ctx, hipStream_t stream, dliom::DevBuf& scratch, vo
     const bool with_big = ctx->hist_expect_big || attempt == 1;
     if (done_word != nullptr) {
       const unsigned seq = ++*seq_counter == 0u ? ++*seq_counter : *seq_counter;
+      ctx->hist_enqueued_at = std::chrono::steady_clock::now();
       DLIOM_TRY(enqueue_histogram(ctx, stream, scratch, pinned, cloud, rotation_wxyz, histogram_size, with_big, done_word, seq));
-      DLIOM_TRY(wait_done(ctx, stream, done_word, seq));
+      DLIOM_TRY(wait_histogram(ctx, stream, done_word, seq));
     } else {
       DLIOM_TRY(enqueue_histogram(ctx, stream, scratch, pinned, cloud, rotation_wxyz, histogram_size, with_big));
       DLIOM_HIP_TRY(hipStreamSynchronize(stream));
@@ -1584,6 +1607,7 @@ extern "C" int dliom_cloud_rotational_histogram_begin(dliom_ctx* ctx, const dlio
   DLIOM_HIP_TRY(hipEventRecord(ctx->aux_fork, ctx->stream));
   DLIOM_HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
   ctx->aux_seq = ++ctx->aux_seq == 0u ? 1u : ctx->aux_seq;
+  ctx->hist_enqueued_at = std::chrono::steady_clock::now();
   DLIOM_TRY(enqueue_histogram(ctx, ctx->aux_stream, ctx->aux_scratch, ctx->aux_pinned, cloud, rotation_wxyz, histogram_size,
                               ctx->hist_expect_big, reinterpret_cast<unsigned*>(static_cast<char*>(ctx->aux_pinned) + 4032), ctx->aux_seq));
   ctx->aux_histogram_size = histogram_size;
@@ -1600,7 +1624,7 @@ extern "C" int dliom_cloud_rotational_histogram_finish(dliom_ctx* ctx, float* hi
   ctx->aux_histogram_size = 0;
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   unsigned* word = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->aux_pinned) + 4032);
-  if (ctx->aux_enqueued) DLIOM_TRY(wait_done(ctx, ctx->aux_stream, word, ctx->aux_seq));
+  if (ctx->aux_enqueued) DLIOM_TRY(wait_histogram(ctx, ctx->aux_stream, word, ctx->aux_seq));
   bool had_big = false;
   const int status = read_histogram(ctx->aux_pinned, size, histogram, &had_big);
   if (ctx->aux_enqueued) ctx->hist_expect_big = had_big;

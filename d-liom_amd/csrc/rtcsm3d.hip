@@ -1440,6 +1440,8 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   p.nw = nw;
   p.thr = thr_units;
   p.cells = cells;
+  static const int split_points = env_int("DLIOM_BOX_SPLIT", 1);  // experiments builds: 0 = idle waves in a short rotation block
+  p.split_points = split_points;
 #ifdef DLIOM_EXPERIMENTS
   static const int box_debug = env_int("DLIOM_BOX_DEBUG", 0);
   p.debug = box_debug;
@@ -1478,18 +1480,8 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   p.counters = ctx->box_counters.as<unsigned>();
   // per-(rotation block, point) extents of the lookups: the boxes' bounding boxes are reductions over these
   p.ext_stride = static_cast<int>(cloud.n_padded);
-  // ... and behind them the plan: kPlanMax 16-byte records per (unit, chunk) (rtcsm_box_plan_kernel)
-  const size_t ext_bytes = (static_cast<size_t>(rot_blocks) * 6 * static_cast<size_t>(cloud.n_padded) * 4 + 255) & ~static_cast<size_t>(255);
-  const size_t plan_bytes = static_cast<size_t>(p.units) * static_cast<size_t>(p.point_chunks) * kPlanMax * sizeof(int4);
-#if DLIOM_BOX_PLAN
-  static const int use_plan = env_int("DLIOM_BOX_USE_PLAN", 1);  // experiments builds: 0 = every box planned in the score kernel
-#else
-  const int use_plan = 0;
-#endif
-  DLIOM_TRY(ctx->box_extents.reserve(ext_bytes + (use_plan ? plan_bytes : 0)));
+  DLIOM_TRY(ctx->box_extents.reserve(static_cast<size_t>(rot_blocks) * 6 * static_cast<size_t>(cloud.n_padded) * 4));
   p.ext = ctx->box_extents.as<float>();
-  int4* d_plan = use_plan ? reinterpret_cast<int4*>(static_cast<char*>(ctx->box_extents.p) + ext_bytes) : nullptr;
-  p.plan = d_plan;
   {
     // the pre-pass is the first kernel of the match: one more row of workgroups carries the pending copies and fills
     PrepArgs none;
@@ -1501,9 +1493,6 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
                        group_src, d.rot_src, jobs);
     if (prep != nullptr) prep->n = 0;
   }
-  if (d_plan != nullptr)  // the boxes of every (unit, chunk), once: one wave each
-    hipLaunchKernelGGL(rtcsm_box_plan_kernel, dim3(static_cast<unsigned>(p.point_chunks), static_cast<unsigned>(p.units)), dim3(64), 0,
-                       ctx->stream, g, p, d_plan);
   const unsigned blocks = static_cast<unsigned>(slot_quads) * passes * rot_blocks;
   hipLaunchKernelGGL(rtcsm_score_box_kernel, dim3(blocks), dim3(64 * nw), lds, ctx->stream, g, p, cloud.d_xs,
                      cloud.d_ys, cloud.d_zs);

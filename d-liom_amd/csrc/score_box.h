@@ -93,12 +93,6 @@ constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4
 #endif
 constexpr int kPipe = DLIOM_BOX_PIPE;            // steps between a gather and the accumulation of its value
 constexpr bool kLateAcc = DLIOM_BOX_LATE_ACC != 0;  // accumulate after the step's address arithmetic (else: anywhere)
-constexpr int kPlanMax = 4;    // planned boxes per (unit, chunk) (rtcsm_box_plan_kernel); a chunk that needs more, or holds a
-                               // point that fits no box, is planned by the score kernel itself as before
-#if !defined(DLIOM_EXPERIMENTS) || !defined(DLIOM_BOX_PLAN)
-#undef DLIOM_BOX_PLAN
-#define DLIOM_BOX_PLAN 1       // 0 (experiments builds): every box planned inside the score kernel (round 3/4 behaviour)
-#endif
 constexpr int kRecords = 8;    // ring of chunk records (lo[3], first point) the level-1 entries refer to
 constexpr int kListTrash = kL1Cap + kL2Cap + 4 * kRecords;  // a word nobody reads: where unlisted lanes "append"
 constexpr int kListWords = kListTrash + 4;
@@ -130,8 +124,6 @@ struct Params {
   const float* ext;        // [rot_blocks][6][ext_stride]: per point, lower / upper end per axis of its lookups under the
                            // block's rotations, in cells, before the pass's translation (rtcsm_box_extent_kernel)
   int ext_stride;
-  const int4* plan;        // [units][point_chunks][kPlanMax]: (lo[3], dim0 | dim1 << 8 | dim2 << 16 | n << 24) per planned box of the
-                           // chunk, in order; .w == -1 in the first record: not planned (rtcsm_box_plan_kernel); null: no plan
   unsigned long long* sums;
   const unsigned* order;   // ticket -> chunk (most expensive chunks first, core.hip chunk_order_kernel) or null: identity
   unsigned* counters;      // one chunk dispenser per unit = (pass, rotation block), zeroed by the host before the launch
@@ -145,6 +137,7 @@ struct Params {
   int units;               // passes * rot_blocks
   unsigned thr;            // unresolved  <=>  (bits(w) & 0xffff) <= thr
   int cells;               // LDS box capacity per workgroup (cells)
+  int split_points;        // 1: waves of a unit with fewer rotation groups than waves share the groups and split the points
   int debug;               // -DDLIOM_EXPERIMENTS builds only (wrong sums): 1 skip the lists, 2 skip staging, 4 skip the
                            // lookups, 8 no work at all, 16 unconditional flush atomics, 32 no flush, 64 no stealing,
                            // 128 work counters in error[8..15] (dliom_exp_box_stats), 256 per-workgroup stamps, 512 chunks in index
@@ -543,8 +536,10 @@ __device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsig
 
 // Bounding box of every lookup of the points held by lanes [0, n) (per-lane interval ends l3 / h3, in cells, pass centre
 // included) under a workgroup's rotations and a pass's translations: wave-uniform geometry of the LDS box, false if it
-// does not fit.  Shared by the score kernel (chunks without a plan) and rtcsm_box_plan_kernel: the same instructions,
-// the same boxes.
+// does not fit.  (Round 5 planned the boxes of every chunk ONCE in a pre-pass instead of in all four waves of every
+// workgroup -- 10 % of the kernel's vector instructions gone -- and the kernel took exactly as long: 0.733 ms against
+// 0.733 ms, A/B in one process, plus 32 us for the planning kernel.  The instructions were never the critical path;
+// reverted)
 __device__ __forceinline__ bool box_geometry(const GridView& g, const Params& p, const Pass& ps, const float (&l3)[3],
                                              const float (&h3)[3], int n, int lane, Geometry& geo) {
   const bool have = lane < n;
@@ -584,47 +579,6 @@ __device__ __forceinline__ void point_interval(const Params& p, const Pass& ps, 
     l3[a] = (ext_rb[static_cast<size_t>(2 * a) * p.ext_stride + i] + ps.uc[a]) - 0.0502f;
     h3[a] = (ext_rb[static_cast<size_t>(2 * a + 1) * p.ext_stride + i] + ps.uc[a]) + 0.0502f;
   }
-}
-
-// Round 5: the boxes of a chunk planned ONCE, outside the score kernel.  There every one of a workgroup's four waves
-// computed the same bounding box -- six wave reductions and the fit test, ~390 vector instructions an attempt, 10 % of
-// everything the kernel issued, on the critical path between two boxes -- and a retry with fewer points when it did not
-// fit.  One wave per (unit, chunk) here walks the chunk exactly as the score kernel would (same box_geometry, same
-// halving rule) and writes up to kPlanMax records; the score kernel then reads a record (16 bytes, uniform) per box.
-// Chunks that need more boxes or hold a point that fits no box keep the in-kernel planning (first record's w = -1).
-__global__ __launch_bounds__(64) void rtcsm_box_plan_kernel(GridView g, Params p, int4* __restrict__ plan) {
-  const int lane = threadIdx.x, c = blockIdx.x, unit = blockIdx.y;
-  const int rb = unit % p.rot_blocks, tp = unit / p.rot_blocks;
-  const Pass ps = p.pass[tp];
-  const float* ext_rb = p.ext + static_cast<size_t>(rb) * 6 * p.ext_stride;
-  int4* out = plan + (static_cast<size_t>(unit) * p.point_chunks + c) * kPlanMax;
-  const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
-  int lo = c_begin, nrec = 0, n_guess = p.chunk;
-  bool bad = false;
-  int4 rec0 = make_int4(0, 0, 0, -1);
-  while (lo < c_end) {
-    int n = min(c_end - lo, n_guess);
-    float l3[3], h3[3];
-    point_interval(p, ps, ext_rb, lo + (lane < n ? lane : 0), l3, h3);
-    Geometry geo;
-    bool fits;
-    for (;;) {
-      fits = box_geometry(g, p, ps, l3, h3, n, lane, geo);
-      if (fits || n == 1) break;
-      n = n > 4 ? (((n >> 1) + 3) & ~3) : (n >> 1);
-    }
-    if (!fits || nrec == kPlanMax) {
-      bad = true;
-      break;
-    }
-    n_guess = min(p.chunk, n >= 4 ? 2 * n : 4);
-    const int4 rec = make_int4(geo.lo[0], geo.lo[1], geo.lo[2], geo.dim[0] | (geo.dim[1] << 8) | (geo.dim[2] << 16) | (n << 24));
-    if (nrec == 0) rec0 = rec;
-    else if (lane == 0) out[nrec] = rec;
-    ++nrec;
-    lo += n;
-  }
-  if (lane == 0) out[0] = bad ? make_int4(0, 0, 0, -1) : rec0;
 }
 
 // Pre-pass of a launch: for every (rotation block, point) the interval per axis, in cells and before the pass's
@@ -686,7 +640,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
   extern __shared__ float4 lds_dyn4[];  // [kTC tau | band bitmap | ticket words | nw x lists | box]
   float4* lds_tau = lds_dyn4;
   unsigned* lds_bitmap = reinterpret_cast<unsigned*>(lds_dyn4 + kTC);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nthreads = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63, nthreads = blockDim.x;
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char*)lds_dyn4));  // LDS byte address of the block
   const unsigned tick_off = static_cast<unsigned>(kTC * sizeof(float4)) + kBitmapWords * 4u;
@@ -757,8 +711,19 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
       loaded_pass = tp;
     }
     const int rot_b0 = p.r_first + rb * p.nw * 64;  // first rotation of the workgroup
-    const int rot0 = rot_b0 + wave * 64;            // ... of this wave
-    const bool wave_active = rot0 < p.r_last;       // surplus waves of the last workgroup only help staging
+    // Round 5: a unit with fewer rotation groups than the workgroup has waves -- the LAST rotation block: 1331 rotations
+    // are five blocks of 256 and one of 51 -- used to run its one group on one wave while three waves idled, and since a
+    // ticket takes as long with one wave as with four, that block's 2048 tickets cost a sixth of the launch's
+    // workgroup-time for 4 % of its lookups.  Now the waves SHARE the groups: with g groups, wave w takes group w % g and
+    // slice w / g of every box's points (nw / g slices), all slices adding into the same candidates' sums (the flush is
+    // an atomic add anyway).
+    const int groups_here = (p.r_last - rot_b0 + 63) >> 6;  // >= 1; more than nw: a full block
+    // (four-wave workgroups only: one group -> four slices, two groups -> two slices each; no divisions here)
+    const int split = (p.split_points != 0 && p.nw == 4) ? (groups_here == 1 ? 4 : (groups_here == 2 ? 2 : 1)) : 1;
+    const int rot_group = split == 4 ? 0 : (split == 2 ? (wave & 1) : wave);
+    const int slice = split == 4 ? wave : (split == 2 ? (wave >> 1) : 0);
+    const int rot0 = rot_b0 + rot_group * 64;       // first rotation of this wave
+    const bool wave_active = rot0 < p.r_last && slice < split;  // surplus waves only help staging
     const Pass ps = p.pass[tp];
     const bool lane_active = rot0 + lane < p.r_last;
     const float4 qq = p.rot[lane_active ? rot0 + lane : (wave_active ? rot0 : rot_b0)];  // idle lanes shadow a real rotation
@@ -781,33 +746,11 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
         const int c = __builtin_amdgcn_readfirstlane(chunk_id);
         const int c_begin = c * p.chunk, c_end = min(c_begin + p.chunk, p.n);
         int lo = c_begin;
-        // this chunk's plan: in order, one record per box (first record's w == -1: planned here, as before)
-        const int4* plan_c = p.plan + (static_cast<size_t>(unit) * p.point_chunks + c) * kPlanMax;
-        const bool chunk_planned = DLIOM_BOX_PLAN && p.plan != nullptr && __builtin_amdgcn_readfirstlane(plan_c[0].w) != -1;
-        int box_i = 0;
         while (lo < c_end) {
           int n;
           Geometry geo;
           bool fits_out = false;
-          if (DLIOM_BOX_PLAN && chunk_planned) {
-            // ---- the box comes from the plan (rtcsm_box_plan_kernel): one uniform 16-byte record
-            const int4 rec = plan_c[box_i];
-            ++box_i;
-            const int w = __builtin_amdgcn_readfirstlane(rec.w);
-            geo.lo[0] = __builtin_amdgcn_readfirstlane(rec.x);
-            geo.lo[1] = __builtin_amdgcn_readfirstlane(rec.y);
-            geo.lo[2] = __builtin_amdgcn_readfirstlane(rec.z);
-            geo.dim[0] = w & 0xff;
-            geo.dim[1] = (w >> 8) & 0xff;
-            geo.dim[2] = (w >> 16) & 0xff;
-            n = (w >> 24) & 0x7f;
-            geo.sx = static_cast<unsigned>(geo.dim[0]);
-            if (((geo.sx >> 2) & 1u) == 0u) geo.sx += 4u;
-            geo.sxy = geo.sx * (static_cast<unsigned>(geo.dim[1]) | 1u);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) geo.kb[a] = static_cast<float>(ps.gi[a] - geo.lo[a]) + ps.f[a];
-            fits_out = true;
-          } else {
+          {
             // ---- bounding box of every lookup of (these points) x (the workgroup's rotations) x (this pass): the
             //      per-point extents come from the pre-pass (lanes = POINTS here), every wave reduces the same values;
             //      a box that does not fit is retried with fewer points -- only the reductions are redone
@@ -831,13 +774,15 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
           if (!fits_out) {
             // a single point whose lookups do not fit the box (huge angular window / far outlier): the exact
             // path straight from the mirror in HBM, every lane its own rotation
-            float rx, ry, rz;
-            rotate_point(q, px[lo], py[lo], pz[lo], rx, ry, rz);
+            if (slice == 0) {  // once per rotation: the waves that share a rotation group split the BOXES' points only
+              float rx, ry, rz;
+              rotate_point(q, px[lo], py[lo], pz[lo], rx, ry, rz);
 #pragma unroll
-            for (int j = 0; j < kTC; ++j) {
-              const float* tr = p.trans + 3 * (ps.j0 + min(j, ps.tc - 1));
-              acc[j] += mirror_value(g, cell_of(rx + tr[0], g.resolution), cell_of(ry + tr[1], g.resolution),
-                                     cell_of(rz + tr[2], g.resolution));
+              for (int j = 0; j < kTC; ++j) {
+                const float* tr = p.trans + 3 * (ps.j0 + min(j, ps.tc - 1));
+                acc[j] += mirror_value(g, cell_of(rx + tr[0], g.resolution), cell_of(ry + tr[1], g.resolution),
+                                       cell_of(rz + tr[2], g.resolution));
+              }
             }
             lo += 1;
             DLIOM_BOX_STAT(p, threadIdx.x == 0, 3, 1);  // points on the exact path
@@ -890,8 +835,11 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
           }
           // ---- all lookups of these points under this wave's rotations
           if (wave_active && !DLIOM_BOX_DBG(p, 4)) {
-            int i = lo;
-            const int e8 = kHotP == 8 ? lo + (n & ~7) : lo, e4 = lo + (n & ~3), e1 = lo + n;
+            // this wave's slice of the box's points (the whole box unless rotation groups are shared): multiples of 4
+            const int part = split > 1 ? ((((n + split - 1) >> (split == 4 ? 2 : 1)) + 3) & ~3) : n;
+            const int s_lo = lo + min(n, slice * part), s_n = min(n, (slice + 1) * part) - min(n, slice * part);
+            int i = s_lo;
+            const int e8 = kHotP == 8 ? s_lo + (s_n & ~7) : s_lo, e4 = s_lo + (s_n & ~3), e1 = s_lo + s_n;
             for (;;) {
               if (kHotP == 8 && i < e8)
                 i = main_loop<kHotP>(g, p, geo, q, px, py, pz, i, e8, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);

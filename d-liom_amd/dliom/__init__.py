@@ -185,6 +185,7 @@ SYMBOLS = [
     ("dliom_grid_destroy", C.c_int, [_vp]),
     ("dliom_grid_resolution", C.c_int, [_vp, _f32p]),
     ("dliom_grid_bits", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("dliom_grid_mirror_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     ("dliom_grid_upload_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64]),
     ("dliom_grid_num_blocks", C.c_int, [_vp, _i64p]),
     ("dliom_grid_download_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64, _i64p]),
@@ -520,6 +521,12 @@ class HybridGrid:
         b = C.c_int()
         _check(self._L.dliom_grid_bits(self.h, C.byref(b)), "grid_bits")
         return b.value
+
+    def mirror_stats(self):
+        """(rebuilds, bytes, windowed) of the correlative matcher's dense mirror of this grid."""
+        r, b, w = C.c_int64(), C.c_int64(), C.c_int()
+        _check(self._L.dliom_grid_mirror_stats(self.h, C.byref(r), C.byref(b), C.byref(w)), "grid_mirror_stats")
+        return int(r.value), int(b.value), bool(w.value)
 
     def upload_blocks(self, origins, values512):
         origins = np.ascontiguousarray(origins, dtype=np.int32).reshape(-1, 3)

@@ -82,6 +82,10 @@ int dliom_grid_resolution(const dliom_grid* grid, float* resolution);
 /* DynamicGrid::bits_ the reference would have after the same writes
  * (hybrid_grid.h:255,387-405). */
 int dliom_grid_bits(const dliom_grid* grid, int* bits);
+/* The correlative matcher's dense mirror of this grid: *rebuilds = how often it was (re)built since the
+ * grid was created -- once for a whole-grid mirror, once per excursion of the search out of the mirrored window for
+ * grids beyond bits = 4 --, *bytes = its current size (0: none), *windowed = 1 if it covers a window of the grid. */
+int dliom_grid_mirror_stats(const dliom_grid* grid, int64_t* rebuilds, int64_t* bytes, int* windowed);
 /* Overwrites whole leaves; grows like mutable_value()/Grow(). */
 int dliom_grid_upload_blocks(dliom_grid* grid, const int32_t* block_origin_xyz,
                              const uint16_t* values512, int64_t num_blocks);

@@ -1,0 +1,222 @@
+"""a16 / f4 made falsifiable.  PARITY UNPINNED against GTSAM itself -- GTSAM 4.0.2 is not in the
+reference tree and the reference holds no test at this boundary -- so what CAN be checked is checked on random input:
+
+  * the preintegration (both of GTSAM's forms) against the CONTINUOUS model: a random smooth motion with closed-form
+    derivatives (tests/imu_motion.py; itself checked against an adaptive Runge-Kutta integration of the rigid-body ODE),
+    sampled 100 x finer than an IMU would, must be reproduced to the discretisation order;
+  * the fixed-lag smoother (d-liom_amd/csrc/imu_window.cc) against the independent numpy solvers of
+    oracle/imu_window_ref.py on >= 500 random streams: random motion, biases, IMU and match noise, rates, window sizes,
+    graph-reset periods, both preintegration forms, gravity factor on and off -- with the tolerances stated below.
+
+Host code: runs without a GPU (the CPU suite)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OPT_NAMES = ("acc_noise", "gyr_noise", "acc_bias_noise", "gyr_bias_noise", "gravity", "integration_sigma",
+             "prior_pose_noise", "prior_velocity_sigma", "prior_bias_sigma", "ceres_pose_noise_t", "ceres_pose_noise_r",
+             "ceres_pose_noise_t_drift", "ceres_pose_noise_r_drift", "prior_gravity_noise", "tangent_preintegration")
+
+# Tolerances of the stream fuzz (product: 2 Gauss-Newton iterations per scan on a fixed-lag window; reference: the batch
+# problem over every key since the last reset, iterated to convergence):
+#   nothing marginalised yet (window >= keys since the reset): the two solve the same problem
+TOL_SAME = dict(p=5e-7, angle=5e-7, v=1e-5, bias=5e-6)
+#   states marginalised (Schur complement at their linearisation point) or a reset behind: the window's approximation
+TOL_LAG = dict(p=5e-5, angle=5e-5, v=1e-3, bias=5e-4)
+
+
+@pytest.fixture(scope="module")
+def dl():
+    import dliom
+    dliom.load_library()
+    return dliom
+
+
+def _angle(qa, qb):
+    return 2.0 * np.arccos(min(1.0, abs(float(np.dot(qa / np.linalg.norm(qa), qb / np.linalg.norm(qb))))))
+
+
+def _quat_of(R):
+    from scipy.spatial.transform import Rotation as Rot
+    q = Rot.from_matrix(R).as_quat()
+    return np.array([q[3], q[0], q[1], q[2]])
+
+
+def test_random_motion_generator_against_a_numerical_integration_of_the_rigid_body_ode():
+    """The fuzz's ground truth must not share a mistake with the product: R' = R [omega]x, v' = R f - G, p' = v integrated
+    by scipy's adaptive Runge-Kutta (rtol 1e-11) from the generator's body rate and specific force lands on the
+    generator's closed-form pose and velocity."""
+    from scipy.integrate import solve_ivp
+    from imu_motion import RandomMotion
+    for seed in (1, 2, 3):
+        m = RandomMotion(seed)
+        t0, t1 = 0.3, 0.8
+
+        def rhs(t, y):
+            R = y[:9].reshape(3, 3)
+            w = m.body_rate(t)
+            K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+            return np.concatenate([(R @ K).ravel(), R @ m.specific_force(t) - m.G, y[9:12]])
+
+        y0 = np.concatenate([m.rotation(t0).ravel(), m.velocity(t0), m.position(t0)])
+        sol = solve_ivp(rhs, (t0, t1), y0, method="DOP853", rtol=1e-11, atol=1e-12)
+        y = sol.y[:, -1]
+        assert np.abs(y[:9].reshape(3, 3) - m.rotation(t1)).max() < 1e-8
+        assert np.linalg.norm(y[9:12] - m.velocity(t1)) < 1e-8
+        assert np.linalg.norm(y[12:15] - m.position(t1)) < 1e-8
+
+
+@pytest.mark.parametrize("tangent", [0, 1])
+def test_preintegration_converges_to_the_continuous_model_when_oversampled(dl, tangent):
+    """One scan interval (0.1 s) of a motion whose rate and acceleration CHANGE within the interval (up to ~5 rad/s and
+    ~15 m/s^2), with constant biases that the window knows: the prediction through the preintegrated measurement against
+    the closed-form state at the end.  GTSAM's update holds the attitude of an interval's START for its acceleration, so
+    the scheme is first order in the step: at an IMU's 200 Hz it is off by its discretisation error, sampled 10 x and
+    100 x finer (20 kHz) the error must fall 10 x and 100 x, and the Richardson extrapolation of the two fine runs --
+    the scheme's limit -- must BE the continuous model."""
+    from imu_motion import RandomMotion
+    T = 0.1
+    for seed in (11, 12, 13):
+        m = RandomMotion(seed, rotation_amplitude=0.3, max_frequency=1.5)
+        rng = np.random.RandomState(seed)
+        ba, bg = rng.uniform(-0.05, 0.05, 3), rng.uniform(-0.01, 0.01, 3)
+        t0 = rng.uniform(0.0, 1.0)
+        truth_p, truth_v, truth_q = m.position(t0 + T), m.velocity(t0 + T), m.pose7(t0 + T)[3:]
+        preds = []
+        for rate in (200.0, 2000.0, 20000.0):
+            w = dl.ImuWindow(tangent_preintegration=tangent)
+            w.initialize(m.pose7(t0), m.velocity(t0), np.concatenate([ba, bg]))
+            dt, acc, gyr = m.imu(t0, t0 + T, rate)
+            w.add_imu_batch(acc + ba, gyr + bg, dt)
+            pose, vel = w.predict()
+            preds.append((pose[:3].copy(), vel.copy(), pose[3:].copy()))
+            w.close()
+        ep = [np.linalg.norm(p - truth_p) for p, _, _ in preds]
+        ev = [np.linalg.norm(v - truth_v) for _, v, _ in preds]
+        ea = [_angle(q, truth_q) for _, _, q in preds]
+        assert ep[0] < 5e-3 and ev[0] < 5e-2 and ea[0] < 1e-4, (seed, ep, ev, ea)  # an IMU's own rate: the discretisation error
+        for e in (ep, ev):  # first order: 10 x finer, 10 x closer
+            assert 7.0 < e[0] / e[1] < 14.0 and 7.0 < e[1] / e[2] < 14.0, (seed, e)
+        # the limit of the scheme is the continuous model (Richardson over the 2 kHz and 20 kHz runs)
+        lim_p = (10.0 * preds[2][0] - preds[1][0]) / 9.0
+        lim_v = (10.0 * preds[2][1] - preds[1][1]) / 9.0
+        assert np.linalg.norm(lim_p - truth_p) < 2e-7 and np.linalg.norm(lim_v - truth_v) < 2e-6, (
+            seed, np.linalg.norm(lim_p - truth_p), np.linalg.norm(lim_v - truth_v))
+        assert ea[2] < 1e-7, (seed, ea)  # the attitude is integrated exactly for a piecewise-constant rate: second order at midpoints
+
+
+# ------------------------------------------------------------------------------------------------ stream fuzz
+def _stream_spec(seed):
+    rng = np.random.RandomState(1000 + seed)
+    gravity_on = seed % 32 == 0  # the batch solver with the gravity factor is slow: a few streams, short ones
+    spec = dict(
+        seed=seed,
+        T=float(rng.choice([0.05, 0.1, 0.2])),
+        rate=float(rng.choice([100.0, 200.0, 400.0])),
+        scans=int(rng.randint(4, 6) if gravity_on else rng.randint(4, 10)),
+        window=int(rng.choice([3, 4, 6, 8])),
+        reset=0 if gravity_on else int(rng.choice([0, 0, 3, 4, 5, 6])),
+        tangent=int(rng.randint(0, 2)),
+        acc_noise=float(rng.choice([0.0, 0.02, 0.1])),
+        gyr_noise=float(rng.choice([0.0, 0.002, 0.01])),
+        ba=rng.uniform(-0.05, 0.05, 3), bg=rng.uniform(-0.005, 0.005, 3),
+        match_t=float(rng.choice([0.0, 0.01, 0.03])), match_r=float(rng.choice([0.0, 0.05, 0.2])),
+        drift_rate=0.1, gravity_on=gravity_on,
+        amplitude=float(rng.choice([0.3, 1.0, 2.0])), rot_amplitude=float(rng.choice([0.1, 0.4, 0.8])))
+    # the smoother's FailureDetection trips at 30 m/s (local_trajectory_builder_3d.cc:896-913): big motions are slow ones
+    spec["max_frequency"] = {0.3: 2.0, 1.0: 0.8, 2.0: 0.4}[spec["amplitude"]]
+    if gravity_on:
+        spec["window"] = 8  # nothing marginalised: window == batch, with the gravity factor's own Jacobian in both
+    return spec
+
+
+def _run_stream(seed):
+    for p in (ROOT, os.path.join(ROOT, "d-liom_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import dliom as dl
+    from dliom import synth
+    from imu_motion import RandomMotion
+    from oracle.imu_window_ref import BatchSmoother, ReferenceRuleSmoother
+    s = _stream_spec(seed)
+    rng = np.random.RandomState(5000 + seed)
+    m = RandomMotion(seed, translation_amplitude=s["amplitude"], rotation_amplitude=s["rot_amplitude"], max_frequency=s["max_frequency"])
+    over = dict(window_size=s["window"], iterations=2, tangent_preintegration=s["tangent"], graph_reset_every=s["reset"])
+    if s["gravity_on"]:
+        # The gravity factor pulls roll and pitch towards level whatever the true attitude (its definition): on
+        # these tilted random motions that is a correction of many degrees, and two Gauss-Newton iterations (the product's
+        # default, like the reference's two ISAM2 updates) stop 1e-2 rad short of the converged batch solution.  The fuzz
+        # compares FORMULATIONS, so these streams run the window to convergence as well (8 iterations: 3e-8 rad).
+        over.update(enable_gravity_factor=1, frames_for_online_gravity_estimate=2, iterations=8)
+    w = dl.ImuWindow(**over)
+    opts = {n: getattr(w.options, n) for n in OPT_NAMES}
+    if s["gravity_on"]:
+        opts.update(enable_gravity_factor=1, frames_for_online_gravity_estimate=2,
+                    lidar_in_imu_translation=tuple(w.options.lidar_in_imu_translation))
+        ref = BatchSmoother(opts)
+    else:
+        ref = ReferenceRuleSmoother(opts, num_range_data=s["reset"] if s["reset"] > 0 else 10 ** 9)
+    t0 = float(rng.uniform(0, 2))
+    init = (m.pose7(t0), m.velocity(t0), np.zeros(6))
+    w.initialize(*init)
+    ref.initialize(*init)
+    worst = dict(p=0.0, angle=0.0, v=0.0, bias=0.0)
+    lagging = False
+    keys_since_reset = 1
+    for k in range(1, s["scans"] + 1):
+        dt, acc, gyr = m.imu(t0 + s["T"] * (k - 1), t0 + s["T"] * k, s["rate"])
+        acc = acc + s["ba"] + s["acc_noise"] * rng.normal(size=acc.shape)
+        gyr = gyr + s["bg"] + s["gyr_noise"] * rng.normal(size=gyr.shape)
+        for a, g in zip(acc, gyr):
+            ref.add_imu(a, g, dt)
+        w.add_imu_batch(acc, gyr, dt)
+        matched = synth.perturb_pose(m.pose7(t0 + s["T"] * k), s["match_t"], s["match_r"], seed=int(rng.randint(1 << 30)))
+        drift = bool(rng.uniform() < s["drift_rate"])
+        pose, vel, bias, status = w.add_pose(matched, is_drift=drift)
+        if s["gravity_on"]:
+            R, p, v, ba, bg = ref.add_pose(matched, is_drift=drift, iterations=8)
+        else:
+            if s["reset"] > 0 and keys_since_reset == s["reset"]:
+                keys_since_reset = 1
+                lagging = True  # a reset behind us: the reference's own approximation, reproduced only approximately
+            R, p, v, ba, bg = ref.add_pose(matched, is_drift=drift, iterations=5)
+        keys_since_reset += 1
+        if keys_since_reset > s["window"]:
+            lagging = True      # the window has marginalised a state the reference still holds
+        if status != 0:
+            return dict(seed=seed, spec=s, error="status %d at scan %d" % (status, k))
+        d = dict(p=float(np.linalg.norm(pose[:3] - p)), angle=float(_angle(pose[3:], _quat_of(R))),
+                 v=float(np.linalg.norm(vel - v)), bias=float(np.linalg.norm(bias - np.concatenate([ba, bg]))))
+        tol = TOL_LAG if lagging else TOL_SAME
+        for kk in worst:
+            worst[kk] = max(worst[kk], d[kk] / tol[kk])
+    factors = w.gravity_estimate()[2] if s["gravity_on"] else 0
+    w.close()
+    return dict(seed=seed, worst=worst, lagging=lagging, gravity=s["gravity_on"], gravity_factors=int(factors))
+
+
+NUM_STREAMS = int(os.environ.get("DLIOM_IMU_FUZZ_STREAMS", "512"))
+
+
+def test_imu_window_against_the_numpy_smoothers_on_random_streams():
+    """>= 500 random streams (NUM_STREAMS; seeds 0 .. NUM_STREAMS - 1, so a failure reproduces with _run_stream(seed)):
+    every scan's smoothed pose, velocity and bias within TOL_SAME of the reference while the two hold the same problem,
+    within TOL_LAG once the window has marginalised a state or a graph reset lies behind."""
+    import multiprocessing as mp
+    workers = min(8, os.cpu_count() or 1)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        results = pool.map(_run_stream, range(NUM_STREAMS), chunksize=4)
+    errors = [r for r in results if "error" in r]
+    assert not errors, errors[:3]
+    ratios = np.array([[r["worst"][k] for k in ("p", "angle", "v", "bias")] for r in results])
+    bad = [(r["seed"], r["worst"]) for r in results if max(r["worst"].values()) > 1.0]
+    assert not bad, (len(bad), bad[:5])
+    assert sum(1 for r in results if r["gravity"]) >= NUM_STREAMS // 40
+    assert sum(1 for r in results if r["gravity_factors"] > 0) >= NUM_STREAMS // 160, "the gravity factor must be exercised"
+    assert all(r["gravity_factors"] == 0 for r in results if not r["gravity"])
+    assert sum(1 for r in results if r["lagging"]) > NUM_STREAMS // 4 and sum(1 for r in results if not r["lagging"]) > NUM_STREAMS // 8
+    print("imu fuzz: %d streams, worst ratio to tolerance p %.3f angle %.3f v %.3f bias %.3f" % ((len(results),) + tuple(ratios.max(axis=0))))

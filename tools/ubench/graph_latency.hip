@@ -17,6 +17,13 @@ __global__ void last(unsigned* data, int k, volatile unsigned* flag, unsigned v)
     *flag = v;
   }
 }
+// the insertion's case: four dependent kernels whose ~0.5 KB by-value argument changes with every call
+struct Big {
+  unsigned v[120];
+};
+__global__ void big_link(Big b, unsigned* data, int k) {
+  if (threadIdx.x == 0) data[k + 1] = data[k] + b.v[k & 63];
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("%s -> %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 int main() {
   hipStream_t s;
@@ -85,6 +92,53 @@ int main() {
     }
     std::printf("K=%2d dependent tiny kernels, launch -> completion word seen: stream launches %.2f us, hipGraph with one node's parameters updated %.2f us, hipGraph unchanged %.2f us\n",
                 K, stream_us, 1e6 * total / (reps - 100), 1e6 * total_fixed / (reps - 100));
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(g);
+  }
+  // ---- HOST time to enqueue four kernels with a 480-byte argument each (no wait inside the timed part): four launches
+  //      against hipGraphExecKernelNodeSetParams x 4 + one hipGraphLaunch
+  {
+    Big b{};
+    const int K = 4, reps2 = 500;
+    double t_stream = 0, t_graph = 0;
+    for (int i = 0; i < reps2; ++i) {
+      b.v[0] = i;
+      auto t0 = std::chrono::steady_clock::now();
+      for (int k = 0; k < K; ++k) hipLaunchKernelGGL(big_link, dim3(256), dim3(256), 0, s, b, data, k);
+      auto t1 = std::chrono::steady_clock::now();
+      CK(hipStreamSynchronize(s));
+      if (i >= 50) t_stream += std::chrono::duration<double>(t1 - t0).count();
+    }
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    for (int k = 0; k < K; ++k) hipLaunchKernelGGL(big_link, dim3(256), dim3(256), 0, s, b, data, k);
+    CK(hipStreamEndCapture(s, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    size_t nn = 0;
+    CK(hipGraphGetNodes(g, nullptr, &nn));
+    std::vector<hipGraphNode_t> nodes(nn);
+    CK(hipGraphGetNodes(g, nodes.data(), &nn));
+    std::vector<hipKernelNodeParams> kps(nn);
+    for (size_t j = 0; j < nn; ++j) CK(hipGraphKernelNodeGetParams(nodes[j], &kps[j]));
+    for (int i = 0; i < reps2; ++i) {
+      b.v[0] = i;
+      auto t0 = std::chrono::steady_clock::now();
+      for (size_t j = 0; j < nn; ++j) {
+        int kk = static_cast<int>(j);
+        void* args[3] = {&b, &data, &kk};
+        hipKernelNodeParams kp = kps[j];
+        kp.kernelParams = args;
+        kp.gridDim = dim3(256 + (i & 1));  // the grid changes with the cloud's size as well
+        CK(hipGraphExecKernelNodeSetParams(ge, nodes[j], &kp));
+      }
+      CK(hipGraphLaunch(ge, s));
+      auto t1 = std::chrono::steady_clock::now();
+      CK(hipStreamSynchronize(s));
+      if (i >= 50) t_graph += std::chrono::duration<double>(t1 - t0).count();
+    }
+    std::printf("host time to enqueue 4 dependent kernels with a 480-byte argument each: 4 launches %.2f us, 4 x SetParams + hipGraphLaunch %.2f us\n",
+                1e6 * t_stream / (reps2 - 50), 1e6 * t_graph / (reps2 - 50));
     hipGraphExecDestroy(ge);
     hipGraphDestroy(g);
   }

@@ -15,7 +15,8 @@ Two option sets:
                          60 m, 100 scans per submap, Ceres weights 6 / 45, gravity factor on, 7-frame estimator)
 
 and the same chain on the CPU oracle (one thread, like the reference runs it; WindowOptimize is the same host code in both
-legs -- GTSAM is not in the tree), with the largest pose difference between the two legs as the parity figure.  The raw
+TIMED legs -- GTSAM is not in the tree), with the largest pose difference between the two legs as the parity figure, plus an
+untimed INDEPENDENT leg whose WindowOptimize is the numpy batch smoother of oracle/imu_window_ref.py (NumpyWindow).  The raw
 scan crosses PCIe inside AddRangeData, as it would in cartographer_ros: these rates are PCIe-inclusive."""
 import argparse
 import json
@@ -78,9 +79,57 @@ def _make_stream(synth, scans, beams, azimuths):
     return T, clouds, imus, synth.trajectory_state(0.0)
 
 
-def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, histogram_size=120, cpu_threads=1):
-    """One pass over the stream; returns (per-scan stage seconds [n x 6], poses [n x 7], histograms, gravity factors)."""
-    window = dl.ImuWindow(acc_noise=NOISE[0], gyr_noise=NOISE[1], acc_bias_noise=NOISE[2], gyr_bias_noise=NOISE[3], **cfg["window"])
+OPT_NAMES = ("acc_noise", "gyr_noise", "acc_bias_noise", "gyr_bias_noise", "gravity", "integration_sigma",
+             "prior_pose_noise", "prior_velocity_sigma", "prior_bias_sigma", "ceres_pose_noise_t", "ceres_pose_noise_r",
+             "ceres_pose_noise_t_drift", "ceres_pose_noise_r_drift", "prior_gravity_noise", "tangent_preintegration")
+
+
+class NumpyWindow:
+    """WindowOptimize of the INDEPENDENT parity leg: oracle/imu_window_ref.py's ReferenceRuleSmoother -- every key since
+    the last reset in one batch problem, numerical Jacobians, solved to convergence -- behind the interface of
+    dl.ImuWindow.  Not the product's imu_window.cc and not derived from it: a difference between the two legs' poses is a
+    difference between two implementations of the IMU window (a16 / f4 stay PARITY UNPINNED against GTSAM itself)."""
+
+    def __init__(self, dl, overrides):
+        from oracle.imu_window_ref import ReferenceRuleSmoother
+        w = dl.ImuWindow(**overrides)  # only to read the option values the product runs with
+        opts = {n: getattr(w.options, n) for n in OPT_NAMES}
+        reset = int(w.options.graph_reset_every)
+        w.close()
+        self.s = ReferenceRuleSmoother(opts, num_range_data=reset if reset > 0 else 10 ** 9)
+
+    def initialize(self, pose7, vel, bias6):
+        self.s.initialize(pose7, vel, bias6)
+
+    def add_imu_batch(self, acc, gyr, dt):
+        for a, g in zip(acc, gyr):
+            self.s.add_imu(a, g, dt)
+
+    @staticmethod
+    def _pose7(R, p):
+        from scipy.spatial.transform import Rotation as Rot
+        q = Rot.from_matrix(R).as_quat()
+        return np.concatenate([p, [q[3], q[0], q[1], q[2]]])
+
+    def predict(self):
+        from oracle.imu_window_ref import BatchSmoother
+        R, p, v, _, _ = BatchSmoother._predict(self.s, self.s.x[-1], self.s.cur)
+        return self._pose7(R, p), v
+
+    def add_pose(self, matched):
+        R, p, v, ba, bg = self.s.add_pose(matched, iterations=5)
+        return self._pose7(R, p), v, np.concatenate([ba, bg]), 0
+
+    def gravity_estimate(self):
+        return np.zeros(3), False, 0
+
+
+def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, histogram_size=120, cpu_threads=1,
+              numpy_window=False):
+    """One pass over the stream; returns (per-scan stage seconds [n x 6], poses [n x 7], histograms, gravity factors).
+    numpy_window: WindowOptimize by NumpyWindow instead of the product's host code (the independent parity leg)."""
+    overrides = dict(acc_noise=NOISE[0], gyr_noise=NOISE[1], acc_bias_noise=NOISE[2], gyr_bias_noise=NOISE[3], **cfg["window"])
+    window = NumpyWindow(dl, overrides) if numpy_window else dl.ImuWindow(**overrides)
     window.initialize(state0[:7], state0[7:10], np.zeros(6))
     fe = dl.LocalTrajectoryBuilder3D(ctx, cfg["front_end"]) if device else orc.FrontEnd(cfg["front_end"])
     if not device and cpu_threads > 1:
@@ -192,6 +241,30 @@ def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=20, beams=64, azimuths=102
                 "what": "the same chain with the RTCSM3D candidate loop on %d threads (BASELINE.md section 2; everything else "
                         "is serial in the reference and stays so)" % threads}
             out["speedup_vs_best_cpu"] = out["scans_per_s"] * min(per_scan, per_scan_mt)
+        # the independent leg: the CPU oracle chain once more, untimed, with WindowOptimize by the numpy
+        # batch solver instead of the product's imu_window.cc -- until now both legs ran the same host code for that stage
+        # and their agreement said nothing about it.  Bounded: the solver's numerical Jacobians cost seconds per dozen
+        # scans, and it has no gravity factor (the compared scans must not have received one).
+        n_ind = min(n, 8 if cfg["window"].get("enable_gravity_factor") else 13)
+        t_ind = time.perf_counter()
+        _, iposes, _, _ = run_chain(dl, cfg, T, clouds[:n_ind], imus[:n_ind], state0, False, orc=orc, numpy_window=True)
+        _, gposes, _, g_ind = (None, poses[:n_ind], None, None)
+        win_probe = dl.ImuWindow(acc_noise=NOISE[0], gyr_noise=NOISE[1], acc_bias_noise=NOISE[2], gyr_bias_noise=NOISE[3], **cfg["window"])
+        out["parity_independent_imu_window"] = {
+            "what": "device leg (product fixed-lag window, imu_window.cc) against the CPU oracle chain whose WindowOptimize is "
+                    "oracle/imu_window_ref.py's numpy batch smoother (every key kept, numerical Jacobians, converged)",
+            "scans_compared": n_ind,
+            "max_translation_difference_m": float(np.max(np.linalg.norm(gposes[:, :3] - iposes[:, :3], axis=1))),
+            "max_rotation_difference_rad": float(np.max([2.0 * np.arccos(min(1.0, abs(float(np.dot(a[3:], b[3:])))))
+                                                         for a, b in zip(gposes, iposes)])),
+            "tolerance_m": 1e-4, "window_size": int(win_probe.options.window_size),
+            "gravity_factor_enabled": bool(cfg["window"].get("enable_gravity_factor")),
+            "note": "PARITY UNPINNED against GTSAM itself (absent from the reference tree); the compared scans precede the first "
+                    "gravity factor (the numpy solver has none)",
+            "seconds": time.perf_counter() - t_ind}
+        win_probe.close()
+        p_ind = out["parity_independent_imu_window"]
+        p_ind["ok"] = bool(p_ind["max_translation_difference_m"] <= 1e-4 and p_ind["max_rotation_difference_rad"] <= 1e-4)
         out["parity"] = {"scans_compared": n, "max_translation_difference_m": dpos, "max_rotation_difference_rad": dang,
                          "tolerance_m": 1e-4, "ok": bool(dpos <= 1e-4 and dang <= 1e-4),
                          "histograms_same_scans": bool(same_presence), "histograms_max_abs_difference": hdiff,
