@@ -314,9 +314,9 @@ def main():
 
     # ... and the search where sharding pays: config 5 (128 x 2048 returns, 5 cm voxels, ~3e6 candidates), whose step
     # is 98 % score volume -- every rank builds the same small submap and takes its share of the rotations
-    config5_line = None
+    config5_sharded = None
     if world > 1 and not sharded_mode and args.config == 2 and not args.no_config5:
-        config5_line = config5_sharded_line(args, dl, synth, ctx, rank, world, dist, coll_device, torch, sharded, rccl_comm)
+        config5_sharded = config5_sharded_line(args, dl, synth, ctx, rank, world, dist, coll_device, torch, sharded, rccl_comm)
 
     extra = max(1, min(5, args.steps))
     ctx.set_profiling(1)
@@ -407,8 +407,8 @@ def main():
             out["sharded_rccl_one_rank"] = rccl_one_rank
         if sharded_line is not None:
             out["sharded"] = sharded_line
-        if config5_line is not None:
-            out["sharded_config5"] = config5_line
+        if config5_sharded is not None:
+            out["sharded_config5"] = config5_sharded
         if world == 1 and not args.no_wref and args.config == 2:
             out["wref"] = wref_line(dl, ctx, cpu=not args.no_cpu_baseline)
         if world == 1 and args.config == 2 and not args.no_config5:

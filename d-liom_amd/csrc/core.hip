@@ -710,6 +710,7 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   ctx->box_tables.release();
   ctx->box_error.release();
   ctx->zero_words.release();
+  ctx->deskew_flags.release();
   ctx->box_counters.release();
   ctx->box_extents.release();
   ctx->csm_arrivals.release();
@@ -751,8 +752,8 @@ int dliom_ctx_set_tuning(dliom_ctx* ctx, int knob, int value) {
       if (value < 0 || value > 4096) return DLIOM_ERR_INVALID_ARGUMENT;
       break;
     case DLIOM_TUNE_RESERVED_TEST_HOOK:
-#ifdef DLIOM_TEST_HOOKS  // libdliom_hooks.so (make hooks): inject the box kernel's inconsistency word once
-      if (value != 0 && value != 1) return DLIOM_ERR_INVALID_ARGUMENT;
+#ifdef DLIOM_TEST_HOOKS  // libdliom_hooks.so (make hooks): 1 injects the box kernel's inconsistency word once; 2 / 3 make
+      if (value < 0 || value > 3) return DLIOM_ERR_INVALID_ARGUMENT;  // the de-skew record every hit / also "fix" every record
       break;
 #else
       return DLIOM_ERR_INVALID_ARGUMENT;  // the shipped library has no fault injection

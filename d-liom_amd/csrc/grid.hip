@@ -350,6 +350,8 @@ struct InsertTarget {
   uint16_t* dense;
   int dense_stride;
   int dense_off[3];
+  unsigned* count_slot;  // pinned [seq, count] of the target's grid (null: none), written by the last pass
+  unsigned count_seq;
 };
 struct MultiInsertArgs {
   InsertTarget tg[kMaxInsertTargets];
@@ -411,6 +413,13 @@ __global__ void multi_insert_kernel(MultiInsertArgs a) {
     }
   }
   if (PASS > 0 && (a.status[2 * tgi] > tg.bits || a.status[2 * tgi + 1] != 0)) return;  // host first
+  if (PASS == 4 && tg.count_slot != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    // the leaf count is final since pass 1: (count, then sequence number) for the host's next ensure_capacity
+    volatile unsigned* slot = tg.count_slot;
+    slot[1] = *tg.count;
+    __threadfence_system();
+    slot[0] = tg.count_seq;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int hx = 0, hy = 0, hz = 0;
   const bool valid = i < a.n && target_hit(a, tg, i, &hx, &hy, &hz);
@@ -522,6 +531,7 @@ int dliom_grid::refresh_count(int64_t* count) {
   DLIOM_HIP_TRY(hipMemcpyAsync(&c, d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
   used_upper = c;
+  applied_seq = insert_seq;  // exact as of now: the pinned count of the last fused insertion is superseded
   if (count != nullptr) *count = c;
   return DLIOM_OK;
 }
@@ -646,6 +656,12 @@ int dliom_grid::ensure_dense_for(const int centre[3], int radius_cells) {
 }
 
 int dliom_grid::ensure_capacity(int64_t additional_slots) {
+  if (h_count_slot != nullptr && insert_seq != 0 && applied_seq != insert_seq &&
+      __atomic_load_n(h_count_slot, __ATOMIC_ACQUIRE) == insert_seq) {
+    // the last fused insertion has finished and left its exact count: tighten the bound without touching the stream
+    used_upper = static_cast<int64_t>(__atomic_load_n(h_count_slot + 1, __ATOMIC_RELAXED)) + (used_upper - upper_at_insert);
+    applied_seq = insert_seq;
+  }
   if (used_upper + additional_slots <= capacity) return DLIOM_OK;
   int64_t count = 0;
   DLIOM_TRY(refresh_count(&count));  // tighten the pessimistic bound first
@@ -742,6 +758,15 @@ int dliom_grid_create(dliom_ctx* ctx, float resolution, dliom_grid** out) {
       break;
     }
     g->used_upper = 1;
+    {
+      void* slot = nullptr;  // optional: without it the leaf count is read back the old way (memcpy + synchronise)
+      if (hipHostMalloc(&slot, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
+        g->h_count_slot = static_cast<unsigned*>(slot);
+        g->h_count_slot[0] = g->h_count_slot[1] = 0u;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     s = g->ensure_capacity(1024);
   } while (false);
   if (s != DLIOM_OK) {
@@ -761,6 +786,7 @@ int dliom_grid_destroy(dliom_grid* g) {
   if (g->d_slot_coord) (void)hipFree(g->d_slot_coord);
   if (g->d_count) (void)hipFree(g->d_count);
   if (g->d_dense) (void)hipFree(g->d_dense);
+  if (g->h_count_slot) (void)hipHostFree(g->h_count_slot);
   delete g;
   return DLIOM_OK;
 }
@@ -1145,6 +1171,19 @@ static void refresh_target(InsertTarget* tg, dliom_grid* g) {
   tg->dense = g->d_dense;
   tg->dense_stride = g->dense_stride;
   for (int k = 0; k < 3; ++k) tg->dense_off[k] = g->dense_off[k];
+  tg->count_slot = g->h_count_slot;
+}
+
+// Accounts for an insertion of n returns into the grids on the host: the pessimistic bound now, the exact count when the
+// last pass has written it (dliom_grid::ensure_capacity).  Call BEFORE the launches (the sequence number rides in them).
+static void account_insertion(MultiInsertArgs* a, dliom_grid* const* grids, int num_targets, int64_t n, int F) {
+  for (int k = 0; k < num_targets; ++k) {
+    dliom_grid* g = grids[k];
+    g->used_upper += n * (1 + static_cast<int64_t>(F));
+    g->insert_seq = g->insert_seq + 1u == 0u ? 1u : g->insert_seq + 1u;
+    g->upper_at_insert = g->used_upper;
+    a->tg[k].count_seq = g->insert_seq;
+  }
 }
 
 int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets, dliom_grid* const* grids,
@@ -1218,6 +1257,7 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
     a.status = reinterpret_cast<int*>(zeros);  // read only: "nothing to report" for every target
     a.host_status = nullptr;
     a.done_word = nullptr;
+    account_insertion(&a, grids, num_targets, n, F);
     const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
     hipLaunchKernelGGL(multi_insert_kernel<1>, grid_dim, block, 0, ctx->stream, a);
     hipLaunchKernelGGL(multi_insert_kernel<2>, grid_dim, block, 0, ctx->stream, a);
@@ -1225,7 +1265,6 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
     hipLaunchKernelGGL(multi_insert_kernel<4>, grid_dim, block, 0, ctx->stream, a);
     ctx->end_span(span);
     DLIOM_HIP_TRY(hipGetLastError());
-    for (int k = 0; k < num_targets; ++k) grids[k]->used_upper += n * (1 + static_cast<int64_t>(F));
 #ifdef DLIOM_EXPERIMENTS
     timing_guard.path = "proven";
 #endif
@@ -1240,6 +1279,7 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
   // when that arrives (the update passes may still be running -- 50 us the caller's next step no longer waits for).
   a.done_word = ctx->done_word;
   a.done_seq = ctx->done_word != nullptr ? (++ctx->done_seq == 0u ? ++ctx->done_seq : ctx->done_seq) : 0u;
+  account_insertion(&a, grids, num_targets, n, F);
   const int span = ctx->begin_span(DLIOM_KERNEL_INSERT);
   hipLaunchKernelGGL(multi_insert_kernel<0>, grid_dim, block, 0, ctx->stream, a);
   int status[2 * kMaxInsertTargets];
@@ -1281,7 +1321,6 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
     }
   }
   ctx->end_span(span);
-  for (int k = 0; k < num_targets; ++k) grids[k]->used_upper += n * (1 + static_cast<int64_t>(F));
   return DLIOM_OK;
 }
 

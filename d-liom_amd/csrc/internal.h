@@ -91,6 +91,9 @@ struct dliom_ctx {
   dliom::DevBuf box_extents;  // per (rotation block, point) extents of its lookups (rtcsm_box_extent_kernel)
   dliom::DevBuf csm_arrivals; // csm_final_reduce_kernel's wave counter (zero between evaluations)
   dliom::DevBuf box_error;  // its 'cannot happen' flag word, read by dliom_rtcsm3d_box_error
+  dliom::DevBuf deskew_flags;  // the de-skew's record buffer (preprocess.hip: hits whose float cast is checked against glibc)
+  unsigned deskew_flag_total = 0;   // its monotonic record counter as last read
+  int64_t deskew_records_checked = 0, deskew_overflows = 0, deskew_fixed_hits = 0;  // dliom_deskew_check_stats
   dliom::DevBuf zero_words; // 256 bytes that stay zero (zeroed once): status words of kernels whose checking pass was
   bool zero_words_ready = false;  // proven unnecessary on the host (grid.hip: insertion without the extent scan)
   bool box_error_zeroed = false;
@@ -155,6 +158,12 @@ struct dliom_grid {
   uint32_t* d_count = nullptr;  // number of used slots including slot 0
   int64_t capacity = 0;         // slots
   int64_t used_upper = 1;       // host-side upper bound of *d_count
+  // The fused insertion's last pass leaves (sequence number, *d_count) in this pinned pair: the next insertion -- a whole
+  // scan later -- finds the exact count there instead of the pessimistic bound (every return and free-space voxel in a
+  // new leaf), which used to run into `capacity` every few scans and then cost a read-back + stream synchronise.
+  unsigned* h_count_slot = nullptr;  // pinned [seq, count], own allocation (null: not available, the old way)
+  unsigned insert_seq = 0, applied_seq = 0;
+  int64_t upper_at_insert = 0;       // used_upper right after the insertion `insert_seq` was accounted for
   uint16_t* d_dense = nullptr;  // optional dense mirror for the correlative matcher (grid.hip)
   int dense_stride = 0;
   int dense_bricks = 0;

@@ -25,10 +25,22 @@ struct DeskewArgs {
   float origins[4][3];          // synchronized_data.origins (RangeDataSynchronizer: up to two lidars; room for 4)
   float min_range, max_range;
   int use_stamps;               // 0: |t_0| < 1e-3, every hit takes the predicted pose
+  // How far the DEVICE's per-hit quaternion (double, before the cast to float) can be from the one the reference's host
+  // computes with glibc: the two differ only through sin / acos (every other operation is a correctly rounded IEEE
+  // operation on both).  q_bound[k]: absolute bound of component k before the normalisation, norm_bound: relative bound
+  // the normalisation adds (make_deskew_args, with the derivation).  A hit whose cast could land on another float under
+  // that bound is RECORDED and checked against glibc on the host (verify_deskew): equality is proven, not sampled.
+  double q_bound[4], norm_bound;
 };
 
-__device__ __forceinline__ void quat_mul_sse_d(const double* a, const double* b, double* r) {
-  // Eigen Quaterniond product, SSE2 evaluation order (host_math.h::qmul_d)
+// Records of hits whose cast is not provably the reference's: a ring in a small persistent buffer of the context,
+// [0..6] the last hit's pose (the read-back the chain had already), [8] records written so far (monotonic, never reset),
+// [16 + 6 r ..) record r % kDeskewRing = (hit index, bits of its time, bits of the four quaternion floats).
+constexpr int kDeskewRing = 160;
+constexpr int kDeskewFlagWords = 16 + 6 * kDeskewRing;  // 976 <= 1024: one job of gather_to_pinned
+
+// Eigen Quaterniond product, SSE2 evaluation order (host_math.h::qmul_d), host and device
+__host__ __device__ inline void quat_mul_sse_hd(const double* a, const double* b, double* r) {
   const double aw = a[0], ax = a[1], ay = a[2], az = a[3];
   const double bw = b[0], bx = b[1], by = b[2], bz = b[3];
   const double t1x = aw * bx + ay * bz, t1y = aw * by + ay * bw;
@@ -41,71 +53,65 @@ __device__ __forceinline__ void quat_mul_sse_d(const double* a, const double* b,
   r[0] = u1w - u2z;
 }
 
-// One hit: pose_i = (prev * [s t_rel, slerp(I, q_rel, s)]).cast<float>() (:437-445,869-877), then
-// hit/origin into the local frame and the range gate (:454-472).
-// out_kind: 0 dropped (range < min_range), 1 return, 2 miss (beyond max_range: cropped ray end).
-// Inputs / outputs are strided so that packed host layouts (xyzt stride 4, xyz stride 3) and the
-// device SoA layout (stride 1) run the same code.
-__global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, const float* __restrict__ in_y,
-                              const float* __restrict__ in_z, const float* __restrict__ in_t,
-                              const float* __restrict__ in_origin, int in_stride, int n,
-                              float* __restrict__ out_x, float* __restrict__ out_y, float* __restrict__ out_z,
-                              int out_stride, unsigned char* __restrict__ out_kind,
-                              float* __restrict__ last_pose7) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const size_t ii = static_cast<size_t>(i) * in_stride;
-  const float4 h = make_float4(in_x[ii], in_y[ii], in_z[ii], in_t[ii]);
-  Quat4 q;
-  float tx, ty, tz;
-  if (a.use_stamps) {
-    const double s = (a.scan_period + static_cast<double>(h.w)) / a.scan_period;
-    // Eigen::Quaterniond::Identity().slerp(s, q_rel)
-    const double one = 1.0 - 2.220446049250313e-16;
-    const double d = a.rel_q[0];
-    const double abs_d = fabs(d);
-    double scale0, scale1;
-    if (abs_d >= one) {
-      scale0 = 1.0 - s;
-      scale1 = s;
-    } else {
-      const double theta = acos(abs_d);
-      const double sin_theta = sin(theta);
-      scale0 = sin((1.0 - s) * theta) / sin_theta;
-      scale1 = sin(s * theta) / sin_theta;
-    }
-    if (d < 0.0) scale1 = -scale1;
-    const double qi[4] = {scale0 * 1.0 + scale1 * a.rel_q[0], scale0 * 0.0 + scale1 * a.rel_q[1],
-                          scale0 * 0.0 + scale1 * a.rel_q[2], scale0 * 0.0 + scale1 * a.rel_q[3]};
-    const double ti[3] = {s * a.rel_t[0], s * a.rel_t[1], s * a.rel_t[2]};
-    // prev * tmp: rotation (prev.q * qi).normalized(), translation prev.q * ti + prev.t
-    double qq[4];
-    quat_mul_sse_d(a.prev_q, qi, qq);
-    const double z2 = (qq[1] * qq[1] + qq[3] * qq[3]) + (qq[2] * qq[2] + qq[0] * qq[0]);
-    if (z2 > 0.0) {
-      const double nrm = sqrt(z2);
-      qq[0] /= nrm;
-      qq[1] /= nrm;
-      qq[2] /= nrm;
-      qq[3] /= nrm;
-    }
-    const double* u = a.prev_q;
-    double uvx = u[2] * ti[2] - u[3] * ti[1], uvy = u[3] * ti[0] - u[1] * ti[2], uvz = u[1] * ti[1] - u[2] * ti[0];
-    uvx += uvx;
-    uvy += uvy;
-    uvz += uvz;
-    const double cx = u[2] * uvz - u[3] * uvy, cy = u[3] * uvx - u[1] * uvz, cz = u[1] * uvy - u[2] * uvx;
-    tx = static_cast<float>(((ti[0] + u[0] * uvx) + cx) + a.prev_t[0]);
-    ty = static_cast<float>(((ti[1] + u[0] * uvy) + cy) + a.prev_t[1]);
-    tz = static_cast<float>(((ti[2] + u[0] * uvz) + cz) + a.prev_t[2]);
-    q = Quat4{static_cast<float>(qq[0]), static_cast<float>(qq[1]), static_cast<float>(qq[2]),
-              static_cast<float>(qq[3])};
+// pose_i = (prev * [s t_rel, slerp(I, q_rel, s)]) (:437-445,869-877) for a hit with relative time t_rel: the rotation as
+// doubles (qq, normalised), the translation already cast.  ONE source for the kernel and for the host's check: `sin` and
+// `acos` are the device's (OCML) there and glibc's here -- the only operations in which the two can differ.
+// *libm_path: the slerp took its sin / acos branch (else every operation is an IEEE operation: nothing to check).
+__host__ __device__ inline void deskew_pose(const DeskewArgs& a, float t_rel, double qq[4], float t[3], bool* libm_path) {
+  const double s = (a.scan_period + static_cast<double>(t_rel)) / a.scan_period;
+  // Eigen::Quaterniond::Identity().slerp(s, q_rel)
+  const double one = 1.0 - 2.220446049250313e-16;
+  const double d = a.rel_q[0];
+  const double abs_d = fabs(d);
+  double scale0, scale1;
+  *libm_path = !(abs_d >= one);
+  if (abs_d >= one) {
+    scale0 = 1.0 - s;
+    scale1 = s;
   } else {
-    q = Quat4{a.cur_q[0], a.cur_q[1], a.cur_q[2], a.cur_q[3]};
-    tx = a.cur_t[0];
-    ty = a.cur_t[1];
-    tz = a.cur_t[2];
+    const double theta = acos(abs_d);
+    const double sin_theta = sin(theta);
+    scale0 = sin((1.0 - s) * theta) / sin_theta;
+    scale1 = sin(s * theta) / sin_theta;
   }
+  if (d < 0.0) scale1 = -scale1;
+  const double qi[4] = {scale0 * 1.0 + scale1 * a.rel_q[0], scale0 * 0.0 + scale1 * a.rel_q[1],
+                        scale0 * 0.0 + scale1 * a.rel_q[2], scale0 * 0.0 + scale1 * a.rel_q[3]};
+  const double ti[3] = {s * a.rel_t[0], s * a.rel_t[1], s * a.rel_t[2]};
+  // prev * tmp: rotation (prev.q * qi).normalized(), translation prev.q * ti + prev.t
+  quat_mul_sse_hd(a.prev_q, qi, qq);
+  const double z2 = (qq[1] * qq[1] + qq[3] * qq[3]) + (qq[2] * qq[2] + qq[0] * qq[0]);
+  if (z2 > 0.0) {
+    const double nrm = sqrt(z2);
+    qq[0] /= nrm;
+    qq[1] /= nrm;
+    qq[2] /= nrm;
+    qq[3] /= nrm;
+  }
+  const double* u = a.prev_q;
+  double uvx = u[2] * ti[2] - u[3] * ti[1], uvy = u[3] * ti[0] - u[1] * ti[2], uvz = u[1] * ti[1] - u[2] * ti[0];
+  uvx += uvx;
+  uvy += uvy;
+  uvz += uvz;
+  const double cx = u[2] * uvz - u[3] * uvy, cy = u[3] * uvx - u[1] * uvz, cz = u[1] * uvy - u[2] * uvx;
+  t[0] = static_cast<float>(((ti[0] + u[0] * uvx) + cx) + a.prev_t[0]);
+  t[1] = static_cast<float>(((ti[1] + u[0] * uvy) + cy) + a.prev_t[1]);
+  t[2] = static_cast<float>(((ti[2] + u[0] * uvz) + cz) + a.prev_t[2]);
+}
+
+// Could the cast of v land on another float if v were off by up to `bound`?
+__host__ __device__ inline bool cast_ambiguous(double v, double bound) {
+  const float f = static_cast<float>(v);
+  return static_cast<float>(v + bound) != f || static_cast<float>(v - bound) != f;
+}
+
+// The float part of one hit under the pose (q, t): hit / origin into the local frame and the range gate (:454-472).
+// out_kind: 0 dropped (range < min_range), 1 return, 2 miss (beyond max_range: cropped ray end).
+__device__ __forceinline__ void deskew_finish_hit(const DeskewArgs& a, const Quat4 q, float tx, float ty, float tz, const float4 h,
+                                                  const float* __restrict__ in_origin, size_t ii, int i, int n,
+                                                  float* __restrict__ out_x, float* __restrict__ out_y, float* __restrict__ out_z,
+                                                  int out_stride, unsigned char* __restrict__ out_kind,
+                                                  float* __restrict__ last_pose7) {
   float hx, hy, hz, ox, oy, oz;
   rotate_point(q, h.x, h.y, h.z, hx, hy, hz);
   hx += tx;
@@ -145,6 +151,95 @@ __global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, cons
     last_pose7[5] = q.y;
     last_pose7[6] = q.z;
   }
+}
+
+// One hit: pose_i = (prev * [s t_rel, slerp(I, q_rel, s)]).cast<float>() (:437-445,869-877), then
+// hit/origin into the local frame and the range gate (:454-472).
+// Inputs / outputs are strided so that packed host layouts (xyzt stride 4, xyz stride 3) and the
+// device SoA layout (stride 1) run the same code.
+// flags: the context's record buffer (kDeskewFlagWords words, layout above); only_flags: write nothing but the records
+// (the overflow pass: `flags` is then [count | records] of room for every hit).
+__global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, const float* __restrict__ in_y,
+                              const float* __restrict__ in_z, const float* __restrict__ in_t,
+                              const float* __restrict__ in_origin, int in_stride, int n,
+                              float* __restrict__ out_x, float* __restrict__ out_y, float* __restrict__ out_z,
+                              int out_stride, unsigned char* __restrict__ out_kind,
+                              unsigned* __restrict__ flags, int only_flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t ii = static_cast<size_t>(i) * in_stride;
+  const float4 h = make_float4(in_x[ii], in_y[ii], in_z[ii], in_t[ii]);
+  Quat4 q;
+  float tx, ty, tz;
+  if (a.use_stamps) {
+    double qq[4];
+    float t3[3];
+    bool libm_path;
+    deskew_pose(a, h.w, qq, t3, &libm_path);
+    tx = t3[0];
+    ty = t3[1];
+    tz = t3[2];
+    q = Quat4{static_cast<float>(qq[0]), static_cast<float>(qq[1]), static_cast<float>(qq[2]),
+              static_cast<float>(qq[3])};
+    if (libm_path) {
+      bool ambiguous = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ambiguous = ambiguous || cast_ambiguous(qq[k], a.q_bound[k] + fabs(qq[k]) * a.norm_bound);
+      if (ambiguous) {
+        if (only_flags) {
+          const unsigned r = atomicAdd(flags, 1u);
+          unsigned* rec = flags + 1 + 6u * r;
+          rec[0] = static_cast<unsigned>(i);
+          rec[1] = __float_as_uint(h.w);
+          rec[2] = __float_as_uint(q.w);
+          rec[3] = __float_as_uint(q.x);
+          rec[4] = __float_as_uint(q.y);
+          rec[5] = __float_as_uint(q.z);
+        } else {
+          const unsigned r = atomicAdd(flags + 8, 1u);
+          unsigned* rec = flags + 16 + 6u * (r % static_cast<unsigned>(kDeskewRing));
+          rec[0] = static_cast<unsigned>(i);
+          rec[1] = __float_as_uint(h.w);
+          rec[2] = __float_as_uint(q.w);
+          rec[3] = __float_as_uint(q.x);
+          rec[4] = __float_as_uint(q.y);
+          rec[5] = __float_as_uint(q.z);
+        }
+      }
+    }
+    if (only_flags) return;
+  } else {
+    if (only_flags) return;
+    q = Quat4{a.cur_q[0], a.cur_q[1], a.cur_q[2], a.cur_q[3]};
+    tx = a.cur_t[0];
+    ty = a.cur_t[1];
+    tz = a.cur_t[2];
+  }
+  deskew_finish_hit(a, q, tx, ty, tz, h, in_origin, ii, i, n, out_x, out_y, out_z, out_stride, out_kind,
+                    reinterpret_cast<float*>(flags));
+}
+
+// The hits the host's check found different (never observed; glibc's value is the reference's by definition): redone
+// with the host's quaternion.  fixes: (hit index, bits of the four floats) x num_fixes.
+__global__ void deskew_fix_kernel(DeskewArgs a, const float* __restrict__ in_x, const float* __restrict__ in_y,
+                                  const float* __restrict__ in_z, const float* __restrict__ in_t,
+                                  const float* __restrict__ in_origin, int in_stride, int n, float* __restrict__ out_x,
+                                  float* __restrict__ out_y, float* __restrict__ out_z, int out_stride,
+                                  unsigned char* __restrict__ out_kind, float* __restrict__ last_pose7,
+                                  const unsigned* __restrict__ fixes, int num_fixes) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= num_fixes) return;
+  const int i = static_cast<int>(fixes[5 * f]);
+  if (i < 0 || i >= n) return;
+  const size_t ii = static_cast<size_t>(i) * in_stride;
+  const float4 h = make_float4(in_x[ii], in_y[ii], in_z[ii], in_t[ii]);
+  double qq[4];
+  float t3[3];
+  bool libm_path;
+  deskew_pose(a, h.w, qq, t3, &libm_path);  // (the translation has no sin / acos in it: identical on host and device)
+  const Quat4 q{__uint_as_float(fixes[5 * f + 1]), __uint_as_float(fixes[5 * f + 2]), __uint_as_float(fixes[5 * f + 3]),
+                __uint_as_float(fixes[5 * f + 4])};
+  deskew_finish_hit(a, q, t3[0], t3[1], t3[2], h, in_origin, ii, i, n, out_x, out_y, out_z, out_stride, out_kind, last_pose7);
 }
 
 __global__ void split_xyzt_kernel(const float4* __restrict__ aos, int n, float* __restrict__ x,
@@ -226,6 +321,155 @@ static int make_deskew_args(const double prev_pose[7], const double predicted_po
   a->min_range = min_range;
   a->max_range = max_range;
   a->use_stamps = std::abs(first_time) < 1e-3 ? 0 : 1;  // hits.front().point_time[3] (:429)
+  // ---- how far the device's quaternion can be from glibc's (DeskewArgs::q_bound).  Assumptions, both documented
+  // library bounds: the device's sin / acos are within 4 ulp (what OpenCL's full profile requires of double sin and acos
+  // and OCML is built to), glibc's within 1 ulp.  Two results for the same argument then differ by <= e = 5 * 2^-52
+  // relative.  Through deskew_pose, every other operation being a correctly rounded IEEE operation on both sides (two
+  // different inputs round to results at most |input difference| + 1 ulp apart):
+  //   theta: e;  sin(theta): <= 2 e (theta cot theta <= 1 on (0, pi/2]);  sin(a theta), a in [0, 1]: <= 2 e + 2^-52
+  //   scale0, scale1 (quotients, both in [0, 1]):  es = 4 e + 2^-51
+  //   qi[0] = scale0 + scale1 d: es (1 + |d|) + 2^-52;   qi[m] = scale1 q_rel[m]: (es + 2^-53) |q_rel[m]|
+  //   qq = prev.q * qi (Hamilton product, |prev.q| ~ 1): sum_j |prev.q[j]| dqi[perm] + 7 roundings of values <= 2
+  //   normalisation: z2 relative 2 * 2 max_k(db) + 2^-50, its square root half of that, the division one more ulp
+  {
+    const double ulp = std::ldexp(1.0, -52), e = 5.0 * ulp, es = 4.0 * e + 2.0 * ulp;
+    const double* r = a->rel_q;
+    const double dq[4] = {es * (1.0 + std::fabs(r[0])) + ulp, (es + 0.5 * ulp) * std::fabs(r[1]), (es + 0.5 * ulp) * std::fabs(r[2]),
+                          (es + 0.5 * ulp) * std::fabs(r[3])};
+    const double p0 = std::fabs(a->prev_q[0]), p1 = std::fabs(a->prev_q[1]), p2 = std::fabs(a->prev_q[2]), p3 = std::fabs(a->prev_q[3]);
+    const double slack = 7.0 * 2.0 * ulp;
+    a->q_bound[0] = p0 * dq[0] + p1 * dq[1] + p2 * dq[2] + p3 * dq[3] + slack;
+    a->q_bound[1] = p0 * dq[1] + p1 * dq[0] + p2 * dq[3] + p3 * dq[2] + slack;
+    a->q_bound[2] = p0 * dq[2] + p1 * dq[3] + p2 * dq[0] + p3 * dq[1] + slack;
+    a->q_bound[3] = p0 * dq[3] + p1 * dq[2] + p2 * dq[1] + p3 * dq[0] + slack;
+    const double mx = std::max(std::max(a->q_bound[0], a->q_bound[1]), std::max(a->q_bound[2], a->q_bound[3]));
+    a->norm_bound = 2.0 * mx + 4.0 * ulp;
+    const double pn = p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+    if (!(pn > 0.99 && pn < 1.01) || !std::isfinite(mx)) {  // not a pose the bound was derived for: every hit is checked
+      for (double& b : a->q_bound) b = 1.0;
+      a->norm_bound = 1.0;
+    }
+  }
+  return DLIOM_OK;
+}
+
+// libdliom_hooks.so only (knob 2 of dliom_ctx_set_tuning = 2 or 3): bounds so wide that EVERY hit is recorded -- the
+// ring overflows and the records-only pass over all hits runs; with 3 every record is also "fixed" (with the host's own
+// floats, equal to the device's): the tests walk both paths and the results must not change.
+static void deskew_test_hook(dliom_ctx* ctx, DeskewArgs* a) {
+#ifdef DLIOM_TEST_HOOKS
+  if (ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] >= 2) {
+    for (double& b : a->q_bound) b = 1.0;
+    a->norm_bound = 1.0;
+  }
+#else
+  (void)ctx;
+  (void)a;
+#endif
+}
+
+// The check itself (DeskewArgs::q_bound): every recorded hit once more on the HOST -- deskew_pose with glibc's sin and
+// acos, the reference's own -- against the floats the device cast.  Returns the hits that differ as fix records (hit
+// index, bits of the four host floats) in *fixes.  recs: `count` records of 6 words.
+static void check_deskew_records(const DeskewArgs& a, const unsigned* recs, size_t count, std::vector<unsigned>* fixes,
+                                 bool force_fix = false) {
+  for (size_t r = 0; r < count; ++r) {
+    const unsigned* rec = recs + 6 * r;
+    float t_rel;
+    std::memcpy(&t_rel, rec + 1, 4);
+    double qq[4];
+    float t3[3];
+    bool libm_path;
+    deskew_pose(a, t_rel, qq, t3, &libm_path);
+    unsigned bits[4];
+    bool same = true;
+    for (int k = 0; k < 4; ++k) {
+      const float f = static_cast<float>(qq[k]);
+      std::memcpy(&bits[k], &f, 4);
+      same = same && bits[k] == rec[2 + k];
+    }
+    if (!same || force_fix) {  // (force_fix: libdliom_hooks.so only -- walks the fix path with the host's own floats)
+      fixes->push_back(rec[0]);
+      for (int k = 0; k < 4; ++k) fixes->push_back(bits[k]);
+    }
+  }
+}
+
+// The context's record buffer (kDeskewFlagWords words, zeroed once; the counter in it only ever grows).
+static int deskew_flag_buffer(dliom_ctx* ctx, unsigned** out) {
+  if (ctx->deskew_flags.p == nullptr) {
+    DLIOM_TRY(ctx->deskew_flags.reserve(4 * kDeskewFlagWords));
+    DLIOM_HIP_TRY(hipMemsetAsync(ctx->deskew_flags.p, 0, 4 * kDeskewFlagWords, ctx->stream));
+    ctx->deskew_flag_total = 0;
+  }
+  *out = ctx->deskew_flags.as<unsigned>();
+  return DLIOM_OK;
+}
+
+// After a de-skew launch whose record buffer `host_flags` (kDeskewFlagWords words) is back on the host: checks the
+// recorded hits against glibc, falls back to a records-only pass over every hit when the ring overflowed, and redoes the
+// hits that differ with the host's quaternion (deskew_fix_kernel).  *fixed: outputs were rewritten (the caller redoes
+// what it derived from them).  Synchronises only on the paths that have something to fix or recount.
+struct DeskewLaunch {
+  const float *in_x, *in_y, *in_z, *in_t, *in_origin;
+  int in_stride, n;
+  float *out_x, *out_y, *out_z;
+  int out_stride;
+  unsigned char* out_kind;
+};
+static int verify_deskew(dliom_ctx* ctx, const DeskewArgs& a, const DeskewLaunch& l, const unsigned* host_flags, unsigned* d_flags,
+                         bool* fixed) {
+  *fixed = false;
+  if (!a.use_stamps) return DLIOM_OK;
+#ifdef DLIOM_TEST_HOOKS
+  const bool force_fix = ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] == 3;
+#else
+  const bool force_fix = false;
+#endif
+  const unsigned total = host_flags[8];
+  const unsigned k = total - ctx->deskew_flag_total;  // records of this launch (the counter wraps like the subtraction)
+  const unsigned first = ctx->deskew_flag_total;
+  ctx->deskew_flag_total = total;
+  ctx->deskew_records_checked += k;
+  if (k == 0) return DLIOM_OK;
+  std::vector<unsigned> fixes;
+  if (k <= static_cast<unsigned>(kDeskewRing)) {
+    std::vector<unsigned> recs(6 * static_cast<size_t>(k));
+    for (unsigned r = 0; r < k; ++r)
+      std::memcpy(&recs[6 * r], host_flags + 16 + 6 * ((first + r) % static_cast<unsigned>(kDeskewRing)), 24);
+    check_deskew_records(a, recs.data(), k, &fixes, force_fix);
+  } else {
+    // more records than the ring holds (orientations with tiny quaternion components make many casts borderline): a
+    // records-only pass over every hit into a list with room for all of them, read back in full
+    ++ctx->deskew_overflows;
+    const size_t words = 1 + 6 * static_cast<size_t>(l.n);
+    DLIOM_TRY(ctx->sort_tmp.reserve(4 * words));
+    unsigned* d_list = ctx->sort_tmp.as<unsigned>();
+    DLIOM_HIP_TRY(hipMemsetAsync(d_list, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((l.n + 255) / 256)), dim3(256), 0, ctx->stream, a, l.in_x, l.in_y,
+                       l.in_z, l.in_t, l.in_origin, l.in_stride, l.n, l.out_x, l.out_y, l.out_z, l.out_stride, l.out_kind, d_list, 1);
+    DLIOM_HIP_TRY(hipGetLastError());
+    unsigned count = 0;
+    DLIOM_HIP_TRY(hipMemcpyAsync(&count, d_list, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned> recs(6 * static_cast<size_t>(count));
+    if (count > 0) {
+      DLIOM_HIP_TRY(hipMemcpy(recs.data(), d_list + 1, 24 * static_cast<size_t>(count), hipMemcpyDeviceToHost));
+      check_deskew_records(a, recs.data(), count, &fixes, force_fix);
+    }
+  }
+  if (fixes.empty()) return DLIOM_OK;
+  // never observed: the device's cast differs from glibc's for these hits -- glibc's is the reference's
+  const int nf = static_cast<int>(fixes.size() / 5);
+  ctx->deskew_fixed_hits += nf;
+  DLIOM_TRY(ctx->sort_tmp.reserve(fixes.size() * 4));
+  DLIOM_HIP_TRY(hipMemcpyAsync(ctx->sort_tmp.p, fixes.data(), fixes.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(deskew_fix_kernel, dim3(static_cast<unsigned>((nf + 63) / 64)), dim3(64), 0, ctx->stream, a, l.in_x, l.in_y, l.in_z,
+                     l.in_t, l.in_origin, l.in_stride, l.n, l.out_x, l.out_y, l.out_z, l.out_stride, l.out_kind,
+                     reinterpret_cast<float*>(d_flags), ctx->sort_tmp.as<unsigned>(), nf);
+  DLIOM_HIP_TRY(hipGetLastError());
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `fixes` dies with this frame
+  *fixed = true;
   return DLIOM_OK;
 }
 
@@ -259,7 +503,9 @@ static int add_range_data_stage_a(dliom_ctx* ctx, const double prev_pose[7], con
   float* e = reinterpret_cast<float*>(base + off_e);
   float* oi_in = reinterpret_cast<float*>(base + off_oi);
   float* oi_f = reinterpret_cast<float*>(base + off_of);
-  float* d_pose = reinterpret_cast<float*>(base + off_pose);
+  (void)off_pose;
+  unsigned* d_flags = nullptr;  // [last hit's pose | record counter | records]: persistent, read back with the compaction's counts
+  DLIOM_TRY(deskew_flag_buffer(ctx, &d_flags));
   const int threads = 256;
   DLIOM_HIP_TRY(hipMemcpyAsync(base + off_raw, ranges_xyzt, 16 * nn, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(split_xyzt_kernel, dim3(static_cast<unsigned>((n + threads - 1) / threads)), dim3(threads), 0,
@@ -280,16 +526,26 @@ static int add_range_data_stage_a(dliom_ctx* ctx, const double prev_pose[7], con
   DeskewArgs a;
   // the first range always survives the filter, so hits.front() is ranges.front()
   DLIOM_TRY(make_deskew_args(prev_pose, predicted_pose, scan_period, origins, min_range, max_range, ranges_xyzt[3], &a));
+  deskew_test_hook(ctx, &a);
   for (int k = 0; k < std::min(num_origins, 4); ++k)
     for (int i = 0; i < 3; ++i) a.origins[k][i] = origins[3 * k + i];
+  const DeskewLaunch launch{c, c + nn, c + 2 * nn, c + 3 * nn, multi ? oi_f : static_cast<const float*>(nullptr), 1, static_cast<int>(n1),
+                            d, d + nn, d + 2 * nn, 1, kind};
   hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n1 + threads - 1) / threads)), dim3(threads), 0,
-                     ctx->stream, a, c, c + nn, c + 2 * nn, c + 3 * nn, multi ? oi_f : static_cast<const float*>(nullptr),
-                     1, static_cast<int>(n1), d, d + nn, d + 2 * nn, 1, kind, d_pose);
+                     ctx->stream, a, launch.in_x, launch.in_y, launch.in_z, launch.in_t, launch.in_origin, 1, launch.n, d, d + nn,
+                     d + 2 * nn, 1, kind, d_flags, 0);
   DLIOM_HIP_TRY(hipGetLastError());
   // returns (kind 1), in hit order; misses (kind 2) are not used by the 3D path.  The compaction's read-back brings the
-  // last hit's pose along (one round trip, no memcpy)
-  DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, num_returns, d_pose, 7,
-                                 current_pose));
+  // last hit's pose and the de-skew's records along (one round trip, no memcpy)
+  std::vector<unsigned> host_flags(kDeskewFlagWords);
+  DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, num_returns, d_flags,
+                                 kDeskewFlagWords, host_flags.data()));
+  bool fixed = false;
+  DLIOM_TRY(verify_deskew(ctx, a, launch, host_flags.data(), d_flags, &fixed));
+  if (fixed)  // hits were redone with the host's quaternion: compact (and read the pose) once more
+    DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, num_returns, d_flags,
+                                   kDeskewFlagWords, host_flags.data()));
+  std::memcpy(current_pose, host_flags.data(), 28);
   *returns = e;
   *stride = nn;
   return DLIOM_OK;
@@ -468,23 +724,41 @@ extern "C" int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const dou
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   DeskewArgs a;
   DLIOM_TRY(make_deskew_args(prev_pose, predicted_pose, scan_period, origin, min_range, max_range, hits_xyzt[3], &a));
+  deskew_test_hook(ctx, &a);
   const size_t in_bytes = static_cast<size_t>(n) * 16;
   const size_t xyz_off = (in_bytes + 255) & ~static_cast<size_t>(255);
   const size_t kind_off = xyz_off + ((static_cast<size_t>(n) * 12 + 255) & ~static_cast<size_t>(255));
   const size_t pose_off = kind_off + ((static_cast<size_t>(n) + 255) & ~static_cast<size_t>(255));
   DLIOM_TRY(ctx->misc.reserve(pose_off + 64));
   char* base = static_cast<char*>(ctx->misc.p);
+  unsigned* d_flags = nullptr;
+  DLIOM_TRY(deskew_flag_buffer(ctx, &d_flags));
   DLIOM_HIP_TRY(hipMemcpyAsync(base, hits_xyzt, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, a,
-                     reinterpret_cast<const float*>(base), reinterpret_cast<const float*>(base) + 1,
-                     reinterpret_cast<const float*>(base) + 2, reinterpret_cast<const float*>(base) + 3,
-                     static_cast<const float*>(nullptr), 4, static_cast<int>(n), reinterpret_cast<float*>(base + xyz_off),
-                     reinterpret_cast<float*>(base + xyz_off) + 1, reinterpret_cast<float*>(base + xyz_off) + 2, 3,
-                     reinterpret_cast<unsigned char*>(base + kind_off), reinterpret_cast<float*>(base + pose_off));
+  const float* in = reinterpret_cast<const float*>(base);
+  float* out = reinterpret_cast<float*>(base + xyz_off);
+  const DeskewLaunch launch{in, in + 1, in + 2, in + 3, nullptr, 4, static_cast<int>(n), out, out + 1, out + 2, 3,
+                            reinterpret_cast<unsigned char*>(base + kind_off)};
+  hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, a, launch.in_x,
+                     launch.in_y, launch.in_z, launch.in_t, launch.in_origin, 4, launch.n, launch.out_x, launch.out_y, launch.out_z, 3,
+                     launch.out_kind, d_flags, 0);
   DLIOM_HIP_TRY(hipGetLastError());
+  std::vector<unsigned> host_flags(kDeskewFlagWords);
+  DLIOM_HIP_TRY(hipMemcpyAsync(host_flags.data(), d_flags, 4 * kDeskewFlagWords, hipMemcpyDeviceToHost, ctx->stream));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  bool fixed = false;
+  DLIOM_TRY(verify_deskew(ctx, a, launch, host_flags.data(), d_flags, &fixed));
+  if (fixed) DLIOM_HIP_TRY(hipMemcpyAsync(host_flags.data(), d_flags, 28, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipMemcpyAsync(out_xyz, base + xyz_off, static_cast<size_t>(n) * 12, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipMemcpyAsync(out_kind, base + kind_off, static_cast<size_t>(n), hipMemcpyDeviceToHost, ctx->stream));
-  DLIOM_HIP_TRY(hipMemcpyAsync(current_pose, base + pose_off, 28, hipMemcpyDeviceToHost, ctx->stream));
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  std::memcpy(current_pose, host_flags.data(), 28);
+  return DLIOM_OK;
+}
+
+extern "C" int dliom_deskew_check_stats(const dliom_ctx* ctx, int64_t* records_checked, int64_t* ring_overflows, int64_t* hits_fixed) {
+  if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (records_checked != nullptr) *records_checked = ctx->deskew_records_checked;
+  if (ring_overflows != nullptr) *ring_overflows = ctx->deskew_overflows;
+  if (hits_fixed != nullptr) *hits_fixed = ctx->deskew_fixed_hits;
   return DLIOM_OK;
 }

@@ -307,6 +307,7 @@ SYMBOLS = [
     ("dliom_ctx_set_tuning", C.c_int, [_vp, C.c_int, C.c_int]),
     ("dliom_ctx_poll_fallbacks", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("dliom_ctx_get_tuning", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    ("dliom_deskew_check_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("dliom_ctx_set_profiling", C.c_int, [_vp, C.c_int]),
     ("dliom_ctx_reset_profiling", C.c_int, [_vp]),
     ("dliom_ctx_kernel_time", C.c_int, [_vp, C.c_int, _f64p, _i64p]),
@@ -407,6 +408,12 @@ class Context:
         """dliom_ctx_set_tuning: TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_CSM_GRID_SYNC (knob 2 is reserved: refused by
         the shipped library, the fault injection of libdliom_hooks.so)."""
         _check(self._L.dliom_ctx_set_tuning(self.h, int(knob), int(value)), "set_tuning")
+
+    def deskew_check_stats(self):
+        """(records checked against glibc on the host, ring overflows, hits whose device cast differed and were redone)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(self._L.dliom_deskew_check_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "deskew_check_stats")
+        return int(a.value), int(b.value), int(c.value)
 
     def get_tuning(self, knob):
         v = C.c_int(0)

@@ -443,6 +443,14 @@ int dliom_adaptive_voxel_filter(const dliom_adaptive_voxel_filter_options* optio
 int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7], double scan_period,
                  const float* hits_xyzt, int64_t n, const float origin[3], float min_range, float max_range,
                  float* out_xyz, uint8_t* out_kind, float current_pose[7]);
+/* The de-skew's float casts are PROVEN equal to the reference's, not sampled: the per-hit pose is computed in double with
+ * the device's sin / acos, which may differ from glibc's in the last bits; a hit whose cast to float could change under
+ * that difference (a bound derived from the libraries' documented errors, preprocess.hip) is recorded, recomputed on the
+ * host with glibc -- the reference's own arithmetic -- and, should the floats differ, redone with the host's value.
+ * *records_checked: hits re-examined on the host so far on this context; *ring_overflows: launches with more records
+ * than ride along in the regular read-back (a second pass collects them); *hits_fixed: hits whose device cast differed
+ * from glibc's (none has ever been observed). */
+int dliom_deskew_check_stats(const dliom_ctx* ctx, int64_t* records_checked, int64_t* ring_overflows, int64_t* hits_fixed);
 
 /* The whole pre-processing chain of AddRangeData on the device (:393-487), one scan per call
  * (num_accumulated_range_data = 1): ranges_xyzt (host, n x (x,y,z,t)) -> VoxelFilter(0.5 *
@@ -738,7 +746,8 @@ enum {
                                          test build of the library (-DDLIOM_TEST_HOOKS, `make hooks` ->
                                          libdliom_hooks.so, loaded by one GPU test) accepts it: the next match then
                                          treats the box kernel's consistency word as set and takes the "redo on the
-                                         dense kernel" path once.  The shipped library contains no fault injection. */
+                                         dense kernel" path once; 2 / 3 force the de-skew check's overflow and fix
+                                         paths.  The shipped library contains no fault injection. */
   DLIOM_TUNE_CSM_GRID_SYNC = 3,       /* CeresScanMatcher3D on large clouds: 1 = the whole loop in one launch with grid
                                          barriers, 0 = one launch per evaluation (default: measured 0.27 ms against
                                          0.35 ms per 131 072-point match -- the barrier, the final reduction and the

@@ -9,8 +9,8 @@ mkdir -p $O
 (cd tools/ubench && ./graph_latency) 2>&1 | tee $O/graph_latency.txt
 timeout 900 python -m pytest tests -m gpu -x -q > $O/gputest.txt 2>&1
 tail -5 $O/gputest.txt
-/usr/bin/time -v timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
-grep -E "Elapsed|Maximum resident" $O/bench.err
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+
 python3 - <<'PY'
 import json
 try:
