@@ -1229,7 +1229,14 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   for (const F3& t : c.trans) tmax = std::max(tmax, static_cast<double>(std::max(std::fabs(t.x), std::max(std::fabs(t.y), std::fabs(t.z)))));
   const double rmax = static_cast<double>(cloud.max_norm) / res + 1.0;
   const double qmax = rmax + tmax / res + 1.0;
-  if (!std::isfinite(qmax) || qmax > 880.0) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_RANGE, DLIOM_ERR_CAPACITY);  // Kb must stay below 1024
+  // Two different limits (round 5 separated them; until then the absolute coordinate was held below 880 cells, i.e. the
+  // kernel only ran within 88 m of a 10 cm grid's origin): (i) Kb = (gi - lo) + f must be exact in a float with its 14
+  // fraction bits, |gi - lo| < 1024 -- gi is the pass's translation and lo the box's origin, both ABSOLUTE cell
+  // coordinates, and their difference is 128 minus the rotated point's cell: a limit on the scan's RANGE (checked below
+  // with taumax, and per box in the kernel); (ii) the absolute coordinate q = (r + t) / res enters only the error budget
+  // (the reference's own float rounding of r + t and of the quotient, 2 |q| 2^-24): the band widens with it, nothing
+  // breaks -- any cell DynamicGrid can address (|q| < 8192 + range) is fine.
+  if (!std::isfinite(qmax) || qmax > 16500.0) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_RANGE, DLIOM_ERR_CAPACITY);
   std::vector<Pass> pass(static_cast<size_t>(passes));
   std::vector<float> tau(static_cast<size_t>(passes) * kTC * 4, 0.f);
   double taumax = 0.0;
@@ -1245,6 +1252,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
       taumax = std::max(taumax, (hi - lo) * 0.5 / res + 1.0);
     }
   }
+  if (rmax + taumax + 130.0 > 1000.0) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_RANGE, DLIOM_ERR_CAPACITY);  // (i)
   const double e16 = 1.0 + (2.0 * qmax + rmax + taumax) / 256.0;
   const int B = static_cast<int>(std::ceil(e16 + 0.25));
   const int s_units = B;
@@ -1276,7 +1284,9 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
         tau[(static_cast<size_t>(tp) * kTC + jj) * 4 + a] = tf;
         reach = std::max(reach, std::fabs(static_cast<double>(tf)));
       }
-      ps.reach[a] = static_cast<float>(reach + 0.02);
+      // + the float roundings of the bounding box's own arithmetic at this distance from the origin (interval end +
+      // pass centre: values up to qmax, four roundings of half an ulp each; 0.0002 of the kernel's slack covers < 1024)
+      ps.reach[a] = static_cast<float>(reach + 0.02 + qmax * std::ldexp(1.0, -22));
     }
   }
   // ---- band bitmap: fractions phi of a scaled coordinate for which SOME translation of the pass gives

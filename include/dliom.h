@@ -241,7 +241,8 @@ enum {
   DLIOM_BOX_NOT_REQUESTED = 1,     /* DLIOM_TUNE_SCORE_KERNEL chose another kernel */
   DLIOM_BOX_REFUSED_SMALL = 2,     /* fewer than 8 translations or 2^24 candidate-point pairs: launch-bound anyway */
   DLIOM_BOX_REFUSED_NO_MIRROR = 3, /* the grid has no dense mirror (bits >= 5, or no memory for it) */
-  DLIOM_BOX_REFUSED_RANGE = 4,     /* scaled coordinates beyond the fast index's range (range / resolution > ~880 cells) */
+  DLIOM_BOX_REFUSED_RANGE = 4,     /* the scan's range beyond the fast index's (max ||p|| / resolution > ~860 cells); the
+                                      POSITION in the grid is not limited (any cell DynamicGrid addresses) */
   DLIOM_BOX_REFUSED_WINDOW = 5,    /* angular window x range: a typical point's lookups do not fit a box */
   DLIOM_BOX_REFUSED_LDS = 6,       /* the box + lists exceed the LDS budget */
   DLIOM_BOX_REFUSED_FLAGGED = 7    /* the box kernel flagged an inconsistency ("cannot happen"): this match was redone

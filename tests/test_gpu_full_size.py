@@ -338,3 +338,49 @@ def test_windowed_mirror_runs_the_box_kernel_on_large_grids(dl, ctx, orc, case):
     assert times[3] < times[1]
     cloud.close()
     grid.close()
+
+
+@pytest.mark.parametrize("offset", [(120.0, -60.0, 10.0), (-300.0, 250.0, -40.0)])
+def test_box_kernel_far_from_the_grid_origin(dl, ctx, orc, offset):
+    """Until round 5 the LDS-box kernel refused searches whose ABSOLUTE cell coordinates exceeded ~880 (88 m from the
+    origin of a 10 cm grid) -- a limit that only the scan's range has to respect (Kb = 128 - rotated point's cell); the
+    position enters the rounding band's width alone.  The yard scene shifted by 120 ... 300 m (cells up to +-3800: bits 6 / 7,
+    windowed mirror): the box kernel runs, and winner, score bits, pose and the whole score volume are the oracle's /
+    the leaf-table kernel's."""
+    from dliom import synth
+    off = np.array(list(offset) + [0.0, 0.0, 0.0, 0.0])
+    ins = dl.RangeDataInserter3D(0.55, 0.49, 2, ctx=ctx)
+    grid = dl.HybridGrid(ctx, 0.10)
+    opts = dict(DEFAULT_RTCSM)
+    opts["angular_search_window"] = float(np.deg2rad(0.35))
+    with synth.scene("ground"):
+        for s in range(3):
+            pose = synth.trajectory_pose(0.25 * s)
+            pts, _ = synth.scan(pose, 32, 512)
+            cloud = dl.PointCloud(ctx, pts)
+            ins.InsertCloud(grid, cloud, poses=[(pose + off).astype(np.float32)])  # the same world, moved by `offset`
+            cloud.close()
+        truth = synth.trajectory_pose(1.0)
+        pts, _ = synth.scan(truth, 32, 512)
+        pts = pts[np.linalg.norm(pts.astype(np.float64), axis=1) <= 40.0]
+        init = synth.perturb_pose(truth, 0.1, 0.3, seed=5) + off
+    assert grid.bits >= 6, grid.bits
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, opts)
+    og = device_grid_to_oracle(orc, grid)
+    score, pose = rt.Match(init, pts, grid)
+    st = rt.last_stats()
+    assert st.score_kernel == 3 and st.box_kernel_status == dl.BOX_RAN, (st.score_kernel, st.box_kernel_status)
+    ref = orc.rtcsm3d_match_parallel(opts, init, pts, og, threads=THREADS)
+    assert st.window.num_candidates == ref["num_candidates"]
+    assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
+    assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes() and np.array_equal(pose, ref["pose"])
+    got = rt.score_volume(init, pts, grid)
+    ctx.set_tuning(dl.TUNE_SCORE_KERNEL, 1)
+    try:
+        leaf = rt.score_volume(init, pts, grid)
+    finally:
+        ctx.set_tuning(dl.TUNE_SCORE_KERNEL, 3)
+    assert np.array_equal(got, leaf), int((got != leaf).sum())
+    assert rt.box_error() == 0
+    assert grid.mirror_stats()[2]  # a window of the grid is mirrored, not the grid
+    grid.close()

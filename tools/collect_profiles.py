@@ -55,12 +55,16 @@ for name, o in (("bench_full.json", "%s_bench.json"), ("wref_full.json", "%s_wre
                 ("stream_gentle.json", "%s_stream_config3_gentle.json"), ("config5_bench.json", "%s_config5_bench.json"),
                 ("bench_gloo2.json", "%s_bench_gloo2.json"), ("fast_csm.json", "%s_fast_csm.json"),
                 ("fast_csm_full.json", "%s_fast_csm_full.json"), ("fast_csm_dense.json", "%s_fast_csm_dense.json"),
-                ("hist_bench.json", "%s_hist_bench.json"), ("bench_rccl_1rank.json", "%s_bench_rccl_1rank.json")):
+                ("hist_bench.json", "%s_hist_bench.json"), ("bench_rccl_1rank.json", "%s_bench_rccl_1rank.json"),
+                ("mirror_window_stream.json", "%s_mirror_window_stream.json")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
         if lines:
             open(os.path.join(dst, o % tag), "w").write(lines[-1] + "\n")
+gl = os.path.join(src, "graph_latency.txt")
+if os.path.exists(gl) and os.path.getsize(gl) > 0:
+    shutil.copy(gl, os.path.join(dst, "%s_graph_latency.txt" % tag))
 h = os.path.join(src, "histogram.txt")
 if os.path.exists(h):
     keep = [l for l in open(h).read().splitlines() if "histogram" in l or "rothist" in l or l.startswith('"Name"') or l.startswith("==")
