@@ -93,6 +93,7 @@ struct dliom_ctx {
   dliom::DevBuf box_error;  // its 'cannot happen' flag word, read by dliom_rtcsm3d_box_error
   dliom::DevBuf deskew_flags;  // the de-skew's record buffer (preprocess.hip: hits whose float cast is checked against glibc)
   unsigned deskew_flag_total = 0;   // its monotonic record counter as last read
+  unsigned deskew_launch_id = 0;    // tags the records of a launch (DeskewArgs::launch_tag)
   int64_t deskew_records_checked = 0, deskew_overflows = 0, deskew_fixed_hits = 0;  // dliom_deskew_check_stats
   dliom::DevBuf zero_words; // 256 bytes that stay zero (zeroed once): status words of kernels whose checking pass was
   bool zero_words_ready = false;  // proven unnecessary on the host (grid.hip: insertion without the extent scan)

@@ -31,6 +31,9 @@ struct DeskewArgs {
   // the normalisation adds (make_deskew_args, with the derivation).  A hit whose cast could land on another float under
   // that bound is RECORDED and checked against glibc on the host (verify_deskew): equality is proven, not sampled.
   double q_bound[4], norm_bound;
+  unsigned launch_tag;  // 0..31, changes with every launch: a record carries it, so that records a FAILED call left behind
+                        // (written, never consumed) are recognised and skipped instead of being checked against another
+                        // call's poses
 };
 
 // Records of hits whose cast is not provably the reference's: a ring in a small persistent buffer of the context,
@@ -189,7 +192,7 @@ __global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, cons
         if (only_flags) {
           const unsigned r = atomicAdd(flags, 1u);
           unsigned* rec = flags + 1 + 6u * r;
-          rec[0] = static_cast<unsigned>(i);
+          rec[0] = static_cast<unsigned>(i) | (a.launch_tag << 27);
           rec[1] = __float_as_uint(h.w);
           rec[2] = __float_as_uint(q.w);
           rec[3] = __float_as_uint(q.x);
@@ -198,7 +201,7 @@ __global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, cons
         } else {
           const unsigned r = atomicAdd(flags + 8, 1u);
           unsigned* rec = flags + 16 + 6u * (r % static_cast<unsigned>(kDeskewRing));
-          rec[0] = static_cast<unsigned>(i);
+          rec[0] = static_cast<unsigned>(i) | (a.launch_tag << 27);
           rec[1] = __float_as_uint(h.w);
           rec[2] = __float_as_uint(q.w);
           rec[3] = __float_as_uint(q.x);
@@ -353,10 +356,11 @@ static int make_deskew_args(const double prev_pose[7], const double predicted_po
   return DLIOM_OK;
 }
 
-// libdliom_hooks.so only (knob 2 of dliom_ctx_set_tuning = 2 or 3): bounds so wide that EVERY hit is recorded -- the
+// Per launch: the record tag; and in libdliom_hooks.so only (knob 2 of dliom_ctx_set_tuning = 2 or 3): bounds so wide that EVERY hit is recorded -- the
 // ring overflows and the records-only pass over all hits runs; with 3 every record is also "fixed" (with the host's own
 // floats, equal to the device's): the tests walk both paths and the results must not change.
 static void deskew_test_hook(dliom_ctx* ctx, DeskewArgs* a) {
+  a->launch_tag = (ctx->deskew_launch_id++) & 31u;
 #ifdef DLIOM_TEST_HOOKS
   if (ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] >= 2) {
     for (double& b : a->q_bound) b = 1.0;
@@ -375,6 +379,7 @@ static void check_deskew_records(const DeskewArgs& a, const unsigned* recs, size
                                  bool force_fix = false) {
   for (size_t r = 0; r < count; ++r) {
     const unsigned* rec = recs + 6 * r;
+    if ((rec[0] >> 27) != a.launch_tag) continue;  // another launch's record (a call that failed before its check)
     float t_rel;
     std::memcpy(&t_rel, rec + 1, 4);
     double qq[4];
@@ -389,7 +394,7 @@ static void check_deskew_records(const DeskewArgs& a, const unsigned* recs, size
       same = same && bits[k] == rec[2 + k];
     }
     if (!same || force_fix) {  // (force_fix: libdliom_hooks.so only -- walks the fix path with the host's own floats)
-      fixes->push_back(rec[0]);
+      fixes->push_back(rec[0] & 0x7FFFFFFu);
       for (int k = 0; k < 4; ++k) fixes->push_back(bits[k]);
     }
   }
@@ -487,6 +492,7 @@ static int add_range_data_stage_a(dliom_ctx* ctx, const double prev_pose[7], con
                                   const float* origins, int num_origins, float min_range, float max_range,
                                   float voxel_filter_size, float current_pose[7], const float** returns,
                                   size_t* stride, int64_t* num_returns) {
+  if (n >= (int64_t{1} << 27)) return DLIOM_ERR_INVALID_ARGUMENT;  // (hit indices share a word with the records' launch tag)
   const size_t nn = static_cast<size_t>(n);
   auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   // scratch: raw AoS | raw SoA (4) | filtered hits SoA (4) | de-skewed SoA (3) + kind | returns (3) | origin index in
@@ -721,6 +727,7 @@ extern "C" int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const dou
       !(scan_period > 0.))
     return DLIOM_ERR_INVALID_ARGUMENT;
   if (n == 0) return DLIOM_ERR_EMPTY_CLOUD;  // CHECK(!synchronized_data.ranges.empty()) (:383)
+  if (n >= (int64_t{1} << 27)) return DLIOM_ERR_INVALID_ARGUMENT;  // (hit indices share a word with the records' launch tag)
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   DeskewArgs a;
   DLIOM_TRY(make_deskew_args(prev_pose, predicted_pose, scan_period, origin, min_range, max_range, hits_xyzt[3], &a));
