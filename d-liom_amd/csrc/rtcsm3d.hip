@@ -893,9 +893,12 @@ __global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_chunk_scan_kernel(
   if (count != nullptr && blockIdx.x >= *count) return;
   __shared__ PFn2 wave_total[kScanThreads / 64];
   __shared__ unsigned sh_m, sh_e, sh_i0, sh_cross_t, sh_total, sh_mismatch_t, sh_force_serial;
+  constexpr int kEarlyChunks = 128;            // the functions of the first chunks, for wave 0's own passes (below)
+  __shared__ ChunkFns early_fns[kEarlyChunks];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const ChunkFns none{0xFFFFFFFFu, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u, 0u};
   const ChunkFns cf = tid < num_chunks ? fns[static_cast<size_t>(blockIdx.x) * num_chunks + tid] : none;  // in flight during the copy
+  if (tid < kEarlyChunks) early_fns[tid] = cf;
   {
     const uint4* src = reinterpret_cast<const uint4*>(values + static_cast<size_t>(blockIdx.x) * n_stride);
     uint4* dst = reinterpret_cast<uint4*>(lds_value);
@@ -919,11 +922,81 @@ __global__ __launch_bounds__(kScanThreads) void rtcsm_rescore_chunk_scan_kernel(
     } else {
       for (int i = 0; i < n0; ++i) s += prob(lds_value[i]);
     }
+    // ---- the first binades by wave 0 ALONE (round 5).  The sum doubles from binade to binade, so the early passes
+    // cover a few dozen chunks each -- and used to cost what the late ones cost, three barriers of sixteen waves (4.4 us
+    // a pass, nine passes).  While a pass's window fits 64 chunks (lane l <-> chunk c0 + l, functions out of LDS) it
+    // needs no other wave: the same steps as the block's pass below on wave-uniform state, no barrier.  Anything
+    // unusual (a chunk without a function for this binade in front of the crossing, a window beyond the early chunks)
+    // leaves the pass to the block.
+    const unsigned b0 = __float_as_uint(s);
+    unsigned m = (b0 & 0x7FFFFFu) | 0x800000u, e = (b0 >> 23) - 123u, i0 = static_cast<unsigned>(n0);
+    const PFn2 idw = pfn2_identity();
+    while (i0 < static_cast<unsigned>(n)) {
+      const unsigned c_min = max(13421772u >> e, 1u);
+      const unsigned window = min(static_cast<unsigned>(n) - i0, ((1u << 24) - m) / c_min + 2u);
+      const unsigned c0 = i0 / kChunk;
+      const unsigned i_lim = min(static_cast<unsigned>(n), ((i0 + window + kChunk - 1u) / kChunk) * kChunk);
+      const unsigned last_chunk = (i_lim - 1u) / kChunk;
+      if (last_chunk - c0 >= 64u || last_chunk >= static_cast<unsigned>(kEarlyChunks)) break;  // the block's job
+      const unsigned c = c0 + static_cast<unsigned>(lane);
+      const unsigned begin = max(i0, c * kChunk), end = min(i_lim, (c + 1u) * kChunk);
+      const bool in_window = begin < end;
+      PFn2 f = idw;
+      bool mismatch = false;
+      if (in_window && lane != 0) {
+        const ChunkFns cw = early_fns[c];
+        if (cw.e0 == e) f = PFn2{cw.s00 | ((cw.pp0 & 1u) << 31), cw.s01 | ((cw.pp0 >> 1) << 31)};
+        else if (cw.e1 == e) f = PFn2{cw.s10 | ((cw.pp1 & 1u) << 31), cw.s11 | ((cw.pp1 >> 1) << 31)};
+        else mismatch = true;
+      }
+      {  // the chunk the walk resumes in is partial: lane per element
+        const unsigned he = min(i_lim, (c0 + 1u) * kChunk);
+        const unsigned i = i0 + static_cast<unsigned>(lane);
+        const PFn2 h = wave_inclusive_scan2(i < he ? pack_fn(element_fn(fixed(i), e)) : idw);
+        const PFn2 whole = lane_of(h, 63);
+        if (lane == 0) f = whole;
+      }
+      const PFn2 inc = wave_inclusive_scan2(f);
+      const PFn2 excl = wave_shift_right1(inc);
+      const unsigned p_start = m & 1u;
+      const unsigned mt_start = m + apply2(excl, p_start), mt_end = m + apply2(inc, p_start);
+      const unsigned long long cross_mask = __ballot(in_window && mt_end >= (1u << 24) && mt_start < (1u << 24));
+      const unsigned long long mism_mask = __ballot(mismatch);
+      const int cross_l = cross_mask != 0ull ? __ffsll(static_cast<long long>(cross_mask)) - 1 : 64;
+      const int mism_l = mism_mask != 0ull ? __ffsll(static_cast<long long>(mism_mask)) - 1 : 64;
+      if (mism_l < cross_l || (cross_l == 64 && mism_l != 64)) break;  // the block's pass knows how to open such chunks
+      if (cross_l == 64) {  // the cloud ended inside this binade
+        m = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(mt_end), 63));
+        i0 = i_lim;
+        continue;
+      }
+      const unsigned cb = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(begin), cross_l));
+      const unsigned ce = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(end), cross_l));
+      const unsigned ms = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(mt_start), cross_l));
+      const unsigned i = cb + static_cast<unsigned>(lane);
+      const unsigned a_i = i < ce ? fixed(i) : 0u;
+      const PFn2 sc = wave_inclusive_scan2(i < ce ? pack_fn(element_fn(a_i, e)) : idw);
+      const PFn2 ex = wave_shift_right1(sc);
+      const unsigned ps = ms & 1u;
+      const unsigned m_before = ms + apply2(ex, ps), m_after = ms + apply2(sc, ps);
+      const unsigned long long crossed = __ballot(i < ce && m_after >= (1u << 24));
+      if (crossed == 0ull) break;  // (cannot happen: the chunk's function said it crosses) -- the block decides
+      const int first = __ffsll(static_cast<long long>(crossed)) - 1;
+      const unsigned mb = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(m_before), first));
+      const unsigned af = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(a_i), first));
+      // exact sum of the crossing addition, rounded once to the next binade's ulp (2U)
+      const unsigned long long X = (static_cast<unsigned long long>(mb) << e) + af;
+      const unsigned e2 = e + 1u;
+      const unsigned long long q2 = X >> e2, f2 = X & ((1ull << e2) - 1ull), h2 = 1ull << e;
+      const unsigned long long up = (f2 > h2 || (f2 == h2 && (q2 & 1ull))) ? 1ull : 0ull;
+      m = static_cast<unsigned>(q2 + up);
+      e = e2;
+      i0 = cb + static_cast<unsigned>(first) + 1u;
+    }
     if (lane == 0) {
-      const unsigned b = __float_as_uint(s);
-      sh_m = (b & 0x7FFFFFu) | 0x800000u;
-      sh_e = (b >> 23) - 123u;
-      sh_i0 = static_cast<unsigned>(n0);
+      sh_m = m;
+      sh_e = e;
+      sh_i0 = i0;
       sh_force_serial = 0u;
     }
   }
