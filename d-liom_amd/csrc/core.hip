@@ -742,6 +742,12 @@ int dliom_ctx_poll_fallbacks(const dliom_ctx* ctx, int64_t* count) {
   return DLIOM_OK;
 }
 
+int dliom_ctx_voxel_filter_reruns(const dliom_ctx* ctx, int64_t* count) {
+  if (ctx == nullptr || count == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *count = ctx->voxel_unpacked_reruns;
+  return DLIOM_OK;
+}
+
 int dliom_ctx_set_tuning(dliom_ctx* ctx, int knob, int value) {
   if (ctx == nullptr || knob < 0 || knob >= DLIOM_TUNE_COUNT) return DLIOM_ERR_INVALID_ARGUMENT;
   switch (knob) {

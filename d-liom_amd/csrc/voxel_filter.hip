@@ -52,6 +52,7 @@ struct VfTables {
   unsigned* counters;        // [num] distinct voxels, [num] in-range points, one overflow flag; kVfCounterStride apart
   unsigned capacity;         // power of two >= 2 n
   int num;
+  int packed;                // the launch's tables hold (key << 24 | min index) words (voxel_insert_kernel<true>)
 };
 
 __host__ __device__ __forceinline__ unsigned long long* table_keys(const VfTables& t, int l) {
@@ -74,11 +75,22 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
 // voxels tens of thousands of threads would hit the same few hundred table slots in the same microsecond (and
 // device-scope atomics are resolved at the memory side, one at a time per address).  The points of a workgroup are
 // therefore folded in an LDS table first -- voxel key -> smallest index -- and only the owner of each LDS entry
-// goes to the global table: one compare-and-swap + one atomicMin per distinct voxel of the workgroup.
+// goes to the global table.
+//
+// What bounds the kernel is the chain of memory-side round trips behind the fold (round 5, timing experiments on a
+// 64 x 1024 scan at 0.15 m, 47 000 voxels: 24.8 us as "look, CAS, look, atomicMin" on a 64-bit key and a 32-bit index
+// word; 17.6 without the two looks; 14.7 with the CAS alone; 6.0 without the global table).  kPacked: key and index
+// share ONE 64-bit word -- 13 bits per axis (|index| <= 4095: 614 m at 0.15 m), 24 bits of point index -- so that the
+// first point of a voxel costs one compare-and-swap and nothing else; a later, smaller index of the same voxel one
+// atomicMin without a return value on top.  A point outside 13 bits raises `unpackable` and the host repeats the launch
+// with the 21-bit keys (kPacked = false: CAS on the key word, atomicMin on the index word).
 constexpr int kVfInsertBlock = 1024;
 constexpr int kVfCounterStride = 32;  // words between two counters
 constexpr unsigned kVfLocalSlots = 2048;  // >= 2 x points: the LDS table is at most half full
+constexpr unsigned kPackedIndexBits = 24, kPackedIndexMask = (1u << kPackedIndexBits) - 1u;
+constexpr int kPackedAxisBits = 13;
 
+template <bool kPacked>
 __global__ __launch_bounds__(kVfInsertBlock) void voxel_insert_kernel(const float* __restrict__ x,
                                                                       const float* __restrict__ y,
                                                                       const float* __restrict__ z, unsigned n,
@@ -102,14 +114,17 @@ __global__ __launch_bounds__(kVfInsertBlock) void voxel_insert_kernel(const floa
     in_range = max_range < 0.f || sqrtf(px * px + (py * py + pz * pz)) <= max_range;
     if (in_range) {
       const float qx = px / size, qy = py / size, qz = pz / size;
-      const float lim = 1048575.f;  // 2^20 - 1: the rounded index stays inside 21 bits
+      // the rounded index stays inside 21 bits (2^20 - 1) / inside 13 bits
+      const float lim = kPacked ? static_cast<float>((1 << (kPackedAxisBits - 1)) - 1) : 1048575.f;
       if (!(fabsf(qx) < lim && fabsf(qy) < lim && fabsf(qz) < lim)) {
         overflow = true;
       } else {
-        const unsigned long long kx = static_cast<unsigned long long>(lround_away(qx) + (1 << 20));
-        const unsigned long long ky = static_cast<unsigned long long>(lround_away(qy) + (1 << 20));
-        const unsigned long long kz = static_cast<unsigned long long>(lround_away(qz) + (1 << 20));
-        key = (kx << 42) | (ky << 21) | kz;
+        constexpr int kOrigin = kPacked ? (1 << (kPackedAxisBits - 1)) : (1 << 20);
+        constexpr int kShift = kPacked ? kPackedAxisBits : 21;
+        const unsigned long long kx = static_cast<unsigned long long>(lround_away(qx) + kOrigin);
+        const unsigned long long ky = static_cast<unsigned long long>(lround_away(qy) + kOrigin);
+        const unsigned long long kz = static_cast<unsigned long long>(lround_away(qz) + kOrigin);
+        key = (kx << (2 * kShift)) | (ky << kShift) | kz;
         has_key = true;
       }
     }
@@ -128,23 +143,38 @@ __global__ __launch_bounds__(kVfInsertBlock) void voxel_insert_kernel(const floa
   }
   __syncthreads();
   if (has_key && s_min[local] == i) {  // this entry's first point: the only one the global table hears of
-    unsigned long long* keys = table_keys(t, l);
-    unsigned* min_index = table_min_index(t, l);
     const unsigned mask = t.capacity - 1;
     unsigned h = static_cast<unsigned>(hash) & mask;
-    for (;;) {
-      // A cached look first: a stale answer can only be "still empty" (slots go from empty to one key, once) or
-      // a min index that is too large, and both just send this thread on to the atomic.
-      unsigned long long prev = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (prev == kEmptyKey) prev = atomicCAS(&keys[h], kEmptyKey, key);
-      if (prev == kEmptyKey || prev == key) {
-        claimed = prev == kEmptyKey;
-        if (__hip_atomic_load(&min_index[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > i) atomicMin(&min_index[h], i);
-        s_slot[local] = h;
-        break;
+    if (kPacked) {
+      unsigned long long* words = table_keys(t, l);
+      const unsigned long long mine = (key << kPackedIndexBits) | i;  // (39 key bits: never the empty word)
+      for (;;) {
+        const unsigned long long prev = atomicCAS(&words[h], kEmptyKey, mine);
+        if (prev == kEmptyKey) {
+          claimed = true;
+          break;
+        }
+        if ((prev >> kPackedIndexBits) == key) {  // the slot's key never changes: the minimum runs over the index bits
+          if (static_cast<unsigned>(prev & kPackedIndexMask) > i)
+            __hip_atomic_fetch_min(&words[h], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        h = (h + 1) & mask;  // load factor <= 1/2: terminates
       }
-      h = (h + 1) & mask;  // load factor <= 1/2: terminates
+    } else {
+      unsigned long long* keys = table_keys(t, l);
+      unsigned* min_index = table_min_index(t, l);
+      for (;;) {
+        const unsigned long long prev = atomicCAS(&keys[h], kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) {
+          claimed = prev == kEmptyKey;
+          __hip_atomic_fetch_min(&min_index[h], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        h = (h + 1) & mask;
+      }
     }
+    s_slot[local] = h;
   }
   __syncthreads();
   if (i < n) t.slot[static_cast<size_t>(l) * n + i] = has_key ? s_slot[local] : kNoSlot;
@@ -157,7 +187,7 @@ __global__ __launch_bounds__(kVfInsertBlock) void voxel_insert_kernel(const floa
     if (num_claimed != 0) atomicAdd(&t.counters[kVfCounterStride * l], static_cast<unsigned>(num_claimed));
     if (max_range >= 0.f && num_in_range != 0)  // uncropped launches know the count: n
       atomicAdd(&t.counters[kVfCounterStride * (t.num + l)], static_cast<unsigned>(num_in_range));
-    if (any_overflow) t.counters[kVfCounterStride * 2 * t.num] = 1u;
+    if (any_overflow) t.counters[kVfCounterStride * 2 * t.num] = 1u;  // kPacked: "unpackable", else: outside 21 bits
   }
 }
 
@@ -170,7 +200,8 @@ __global__ __launch_bounds__(kVfBlock) void voxel_flag_kernel(unsigned n, VfTabl
   bool keep = false;
   if (i < n) {
     const unsigned s = t.slot[static_cast<size_t>(l) * n + i];
-    keep = s != kNoSlot && (mode == 1 || table_min_index(t, l)[s] == i);
+    keep = s != kNoSlot && (mode == 1 || (t.packed ? static_cast<unsigned>(table_keys(t, l)[s] & kPackedIndexMask)
+                                                               : table_min_index(t, l)[s]) == i);
     flags[i] = keep ? 1 : 0;
   }
   const int c = __syncthreads_count(keep ? 1 : 0);
@@ -205,6 +236,7 @@ __global__ __launch_bounds__(kVfBlock) void voxel_compact_kernel(
   __syncthreads();
   unsigned before = 0;
   for (unsigned k = 0; k < wave; ++k) before += sh_wave[k];
+  unsigned sq_bits = 0u;
   if (keep) {
     const unsigned pos = base + before + static_cast<unsigned>(__popcll(m & ((1ull << lane) - 1ull)));
     const float px = x[i], py = y[i], pz = z[i];
@@ -213,7 +245,21 @@ __global__ __launch_bounds__(kVfBlock) void voxel_compact_kernel(
     oz[pos] = pz;
     if (ow != nullptr) ow[pos] = w[i];
     if (out_index != nullptr) out_index[pos] = i;
-    if (out_max_sq != nullptr) atomicMax(out_max_sq, __float_as_uint(px * px + (py * py + pz * pz)));
+    sq_bits = __float_as_uint(px * px + (py * py + pz * pz));
+  }
+  // the largest squared norm: one atomic per workgroup (one per survivor on the one word was 5 of this kernel's 9 us
+  // on a 64 x 1024 scan: device-scope atomics on one address are resolved one at a time)
+  if (out_max_sq != nullptr) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sq_bits = max(sq_bits, static_cast<unsigned>(__shfl_xor(static_cast<int>(sq_bits), d, 64)));
+    __syncthreads();  // (sh_wave's counts have been read)
+    if (lane == 0) sh_wave[wave] = sq_bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned mx = 0u;
+      for (unsigned k = 0; k < kVfBlock / 64; ++k) mx = max(mx, sh_wave[k]);
+      if (mx != 0u) atomicMax(out_max_sq, mx);
+    }
   }
 }
 
@@ -277,23 +323,32 @@ static int run_insert(dliom_ctx* ctx, const Soa& in, const std::vector<float>& s
     lengths.size[k] = sizes[k];
     lengths.max_range[k] = ranges[k];
   }
-  // 0xFF bytes = empty keys, "infinite" min indices; counters start at zero
-  // (one dispatch; `also_zero`: the words the emit step's compaction will atomicMax into)
-  const size_t counter_bytes = static_cast<size_t>(2 * num + 1) * kVfCounterStride * 4;
-  const FillJob fills[3] = {{t->tables, static_cast<size_t>(num) * t->capacity * 12, 0xFFFFFFFFu},
-                            {t->counters, counter_bytes, 0u},
-                            {also_zero, static_cast<size_t>(also_zero_words) * 4, 0u}};
-  DLIOM_TRY(fill_multi(ctx, fills, also_zero != nullptr && also_zero_words > 0 ? 3 : 2));
   const unsigned n = static_cast<unsigned>(in.n);
-  const dim3 grid((n + kVfInsertBlock - 1) / kVfInsertBlock, num);
-  hipLaunchKernelGGL(voxel_insert_kernel, grid, dim3(kVfInsertBlock), 0, ctx->stream, in.x, in.y, in.z, n, lengths, *t);
-  DLIOM_HIP_TRY(hipGetLastError());
-  // the 2 num + 1 counters (kVfCounterStride words apart) packed into pinned memory by a kernel that ends in a completion
-  // word: no memcpy, no full synchronise (internal.h, wait_done)
   unsigned* host = static_cast<unsigned*>(ctx->pinned);
-  const GatherJob job{t->counters, static_cast<unsigned>(2 * num + 1), static_cast<unsigned>(kVfCounterStride)};
-  DLIOM_TRY(gather_and_wait(ctx, &job, 1, host));
-  if (host[2 * num] != 0) return DLIOM_ERR_INVALID_ARGUMENT;  // voxel index outside 21 bits
+  // packed words first (one atomic per voxel); a point outside their 13 bits per axis: once more with the 21-bit keys
+  for (int packed = in.n <= (int64_t{1} << kPackedIndexBits) ? 1 : 0; packed >= 0; --packed) {
+    t->packed = packed;
+    // 0xFF bytes = empty keys, "infinite" min indices; counters start at zero
+    // (one dispatch; `also_zero`: the words the emit step's compaction will atomicMax into)
+    const size_t counter_bytes = static_cast<size_t>(2 * num + 1) * kVfCounterStride * 4;
+    const FillJob fills[3] = {{t->tables, static_cast<size_t>(num) * t->capacity * 12, 0xFFFFFFFFu},
+                              {t->counters, counter_bytes, 0u},
+                              {also_zero, static_cast<size_t>(also_zero_words) * 4, 0u}};
+    DLIOM_TRY(fill_multi(ctx, fills, also_zero != nullptr && also_zero_words > 0 ? 3 : 2));
+    const dim3 grid((n + kVfInsertBlock - 1) / kVfInsertBlock, num);
+    if (packed)
+      hipLaunchKernelGGL(voxel_insert_kernel<true>, grid, dim3(kVfInsertBlock), 0, ctx->stream, in.x, in.y, in.z, n, lengths, *t);
+    else
+      hipLaunchKernelGGL(voxel_insert_kernel<false>, grid, dim3(kVfInsertBlock), 0, ctx->stream, in.x, in.y, in.z, n, lengths, *t);
+    DLIOM_HIP_TRY(hipGetLastError());
+    // the 2 num + 1 counters (kVfCounterStride words apart) packed into pinned memory by a kernel that ends in a
+    // completion word: no memcpy, no full synchronise (internal.h, wait_done)
+    const GatherJob job{t->counters, static_cast<unsigned>(2 * num + 1), static_cast<unsigned>(kVfCounterStride)};
+    DLIOM_TRY(gather_and_wait(ctx, &job, 1, host));
+    if (host[2 * num] == 0) break;
+    if (!packed) return DLIOM_ERR_INVALID_ARGUMENT;  // voxel index outside 21 bits
+    ++ctx->voxel_unpacked_reruns;
+  }
   counts->resize(num);
   in_range->resize(num);
   for (int k = 0; k < num; ++k) {

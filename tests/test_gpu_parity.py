@@ -938,6 +938,40 @@ def test_device_voxel_filter_rejects_out_of_range_indices(dl, ctx):
 
 
 @pytest.mark.gpu
+def test_device_voxel_filter_packed_words_and_their_rerun(dl, ctx, orc):
+    """The hash table's packed words hold 13 bits of voxel index per axis: a cloud inside 4095 edges takes that path
+    (no rerun), one point beyond it sends the whole launch to the 21-bit keys -- same survivors either way, also on
+    the boundary itself (|p / size| just below and at 4095) and with the largest point index the words' 24 bits see here."""
+    rng = np.random.RandomState(77)
+    pts = rng.uniform(-20, 20, size=(30000, 3)).astype(np.float32)
+    pts[::3] = pts[::3].round(1)
+    cloud = dl.PointCloud(ctx, pts)
+    before = ctx.voxel_filter_reruns()
+    out = cloud.voxel_filter(0.15)
+    assert ctx.voxel_filter_reruns() == before
+    assert np.array_equal(out.download().view(np.uint32), pts[orc.voxel_filter(0.15, pts)].view(np.uint32))
+    out.close()
+    out = cloud.voxel_filter(0.004)  # 5000 edges: does not fit
+    assert ctx.voxel_filter_reruns() == before + 1
+    assert np.array_equal(out.download().view(np.uint32), pts[orc.voxel_filter(0.004, pts)].view(np.uint32))
+    out.close()
+    cloud.close()
+    size = np.float32(0.25)
+    for edge, reruns in ((4094, 0), (4094.5, 0), (4094.99, 0), (4095, 1), (4096, 1), (-4094.99, 0), (-4095, 1)):
+        q = pts.copy()
+        q[1234] = [np.float32(edge) * size, 0.1, -0.1]
+        q[20000] = q[1234]
+        q[77, 2] = -q[1234, 0]
+        c = dl.PointCloud(ctx, q)
+        b = ctx.voxel_filter_reruns()
+        o = c.voxel_filter(float(size))
+        assert ctx.voxel_filter_reruns() - b == reruns, edge
+        assert np.array_equal(o.download().view(np.uint32), q[orc.voxel_filter(float(size), q)].view(np.uint32)), edge
+        o.close()
+        c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("opts", [(2.0, 150, 15.0), (4.0, 200, 60.0), (0.5, 20000, 30.0), (2.0, 1e9, 50.0),
                                   (2.0, 10, 1.0), (0.05, 5, 60.0)])
 def test_device_adaptive_voxel_filter_equals_oracle(dl, ctx, orc, opts):

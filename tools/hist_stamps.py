@@ -1,0 +1,56 @@
+"""Cycle stamps of the histogram's big-slice kernels (experiments build: make -C d-liom_amd experiments; DLIOM_LIB is set
+here).  Prints, for the level yard scan (one floor slice of ~10 000 returns), the cycles between the DLIOM_BSTAMP /
+DLIOM_SSTAMP marks of big_prepare_kernel, big_sort_order and big_slice_kernel (block 0).  s_memtime: shader clock cycles (~2.4 GHz)."""
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("DLIOM_LIB", os.path.join(ROOT, "d-liom_amd", "ab", "libdliom_exp.so"))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "d-liom_amd")]
+import numpy as np  # noqa: E402
+
+import dliom as dl  # noqa: E402
+from dliom import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def main():
+    lib = dl.load_library()
+    ctx = dl.Context(0)
+    out = {}
+    for name, beams, azimuths, size in (("yard_64x1024_level", 64, 1024, 0.15), ("yard_128x2048", 128, 2048, 0.15)):
+        with synth.scene("ground"):
+            raw, _ = synth.scan(synth.trajectory_pose(0.5), beams, azimuths)
+        pts = raw[orc.voxel_filter(size, raw)]
+        cloud = dl.PointCloud(ctx, pts)
+        for _ in range(4):
+            dl.cloud_rotational_histogram(ctx, cloud, 120, None)
+        ctx.synchronize()
+        buf = (ctypes.c_ulonglong * (64 * 16))()
+        lib.dliom_exp_rothist_big_stamps.argtypes = [ctypes.c_void_p]
+        lib.dliom_exp_rothist_big_stamps.restype = ctypes.c_int
+        rc = lib.dliom_exp_rothist_big_stamps(ctypes.cast(buf, ctypes.c_void_p))
+        a = np.array(buf[:], dtype=np.uint64).reshape(64, 16).astype(np.int64)
+        rec = {"rc": rc, "points": int(len(pts))}
+        for label, row, marks in (("big_prepare", 0, 5), ("big_slice", 4, 7), ("sort_order", 8, 15)):
+            st = a[row]
+            rec[label] = {"ticks_from_first": [int(st[k] - st[0]) if st[k] else None for k in range(marks)]}
+        es = (ctypes.c_ulonglong * 16)()
+        lib.dliom_exp_exact_sum_stamps.argtypes = [ctypes.c_void_p]
+        lib.dliom_exp_exact_sum_stamps.restype = ctypes.c_int
+        lib.dliom_exp_exact_sum_stamps(ctypes.cast(es, ctypes.c_void_p))
+        e = [int(v) for v in es]
+        # the last call of block 0 (big_slice_kernel's centroid): 0 start, 10 / 11 / 12 loads+prefix / block scans /
+        # element functions of the LAST array, 1 + k array k classified, 8 walk done
+        rec["exact_sum_last_call"] = {str(k): (e[k] - e[0]) for k in (10, 11, 12, 1, 2, 8)}
+        rec["slice_count"] = int(a[4][10])
+        rec["m"] = int(a[4][11])
+        out[name] = rec
+        cloud.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
