@@ -135,20 +135,43 @@ struct Scratch {
   double carry_mx[K];   // largest |real prefix| so far
 };
 
-__device__ __forceinline__ double shfl_up_double(double v, int off) {
+// Wave scans by DPP moves (row_shr inside the rows of 16 lanes, row_bcast:15 / :31 across them): a lane without a source
+// gets `old`, the operation's identity.  (Until round 5 these were six __shfl_up steps of two ds_bpermute each, and the
+// two block scans were 14 000 of the 34 000 cycles an array's classification took: the sixteen waves of the workgroup
+// share four SIMDs, so the phase is bound by instruction issue, not by the shuffles' latency.)
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_or(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, kCtrl, kRowMask, 0xf, false);
+}
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_double_or_zero(double v) {
   const unsigned long long u = static_cast<unsigned long long>(__double_as_longlong(v));
-  const unsigned lo = __shfl_up(static_cast<unsigned>(u), off, 64), hi = __shfl_up(static_cast<unsigned>(u >> 32), off, 64);
+  const unsigned lo = static_cast<unsigned>(dpp_or<kCtrl, kRowMask>(0, static_cast<int>(static_cast<unsigned>(u))));
+  const unsigned hi = static_cast<unsigned>(dpp_or<kCtrl, kRowMask>(0, static_cast<int>(static_cast<unsigned>(u >> 32))));
   return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+}
+// inclusive scan over the wave's lanes: sums, or maxima of NON-NEGATIVE values (identity +0 either way)
+template <bool kMax>
+__device__ __forceinline__ double wave_inclusive_scan_double(double v) {
+#define DLIOM_ES_STEP(ctrl, mask)                                      \
+  {                                                                    \
+    const double o = dpp_double_or_zero<ctrl, mask>(v);                \
+    v = kMax ? fmax(v, o) : v + o;                                     \
+  }
+  DLIOM_ES_STEP(0x111, 0xf)  // row_shr:1
+  DLIOM_ES_STEP(0x112, 0xf)  // row_shr:2
+  DLIOM_ES_STEP(0x114, 0xf)  // row_shr:4
+  DLIOM_ES_STEP(0x118, 0xf)  // row_shr:8
+  DLIOM_ES_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  DLIOM_ES_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3
+#undef DLIOM_ES_STEP
+  return v;
 }
 // Inclusive block scans of one double per thread (1024 threads): sum / maximum of non-negative values.  `part`: 16 doubles of LDS.
 template <bool kMax>
 __device__ __forceinline__ double block_inclusive_scan(double v, double* part, double* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const double o = shfl_up_double(v, off);
-    if (lane >= off) v = kMax ? fmax(v, o) : v + o;
-  }
+  v = wave_inclusive_scan_double<kMax>(v);
   __syncthreads();  // `part` may still be read from an earlier scan
   if (lane == 63) part[wave] = v;
   __syncthreads();
@@ -173,17 +196,51 @@ __device__ __forceinline__ Run join(const Run& x, const Run& y) {  // x in front
   if (x.closed) return x;
   return Run{compose(x.f, y.f), y.end, y.closed};
 }
-__device__ __forceinline__ Run shfl_down_run(const Run& r, int off) {
-  Run o;
-  o.f.s0 = __shfl_down(r.f.s0, off, 64);
-  o.f.s1 = __shfl_down(r.f.s1, off, 64);
-  const unsigned packed = __shfl_down(static_cast<unsigned>(r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.closed) << 2) |
-                                                            (static_cast<unsigned>(r.end) << 3)), off, 64);
-  o.f.p0 = packed & 1u;
-  o.f.p1 = (packed >> 1) & 1u;
-  o.closed = static_cast<int>((packed >> 2) & 1u);
-  o.end = static_cast<int>(packed >> 3);
-  return o;
+// ... in three words, for the scan over the lanes: meta = parity out (bits 0, 1) | closed << 2 | end << 3; kNullRun: no run
+struct RunW {
+  int s0, s1;
+  unsigned meta;
+};
+constexpr unsigned kNullRun = 0xFFFFFFFFu;
+__device__ __forceinline__ RunW pack_run(const Run& r) {
+  return RunW{r.f.s0, r.f.s1, r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.closed) << 2) | (static_cast<unsigned>(r.end) << 3)};
+}
+__device__ __forceinline__ Run unpack_run(const RunW& w) {
+  return Run{Fn{w.s0, w.s1, w.meta & 1u, (w.meta >> 1) & 1u}, static_cast<int>(w.meta >> 3), static_cast<int>((w.meta >> 2) & 1u)};
+}
+__device__ __forceinline__ RunW join_w(const RunW& x, const RunW& y) {  // x in front of y; y may be kNullRun
+  if (y.meta == kNullRun || (x.meta & 4u) != 0u) return x;
+  const unsigned xp0 = x.meta & 1u, xp1 = (x.meta >> 1) & 1u, yp0 = y.meta & 1u, yp1 = (y.meta >> 1) & 1u;
+  RunW r;
+  r.s0 = x.s0 + (xp0 ? y.s1 : y.s0);
+  r.s1 = x.s1 + (xp1 ? y.s1 : y.s0);
+  r.meta = (y.meta & ~3u) | (xp0 ? yp1 : yp0) | ((xp1 ? yp1 : yp0) << 1);
+  return r;
+}
+template <int kCtrl>
+__device__ __forceinline__ RunW dpp_run(const RunW& r) {  // lanes without a source: kNullRun
+  return RunW{dpp_or<kCtrl, 0xf>(0, r.s0), dpp_or<kCtrl, 0xf>(0, r.s1),
+              static_cast<unsigned>(dpp_or<kCtrl, 0xf>(static_cast<int>(kNullRun), static_cast<int>(r.meta)))};
+}
+__device__ __forceinline__ RunW readlane_run(const RunW& r, int lane) {
+  return RunW{__builtin_amdgcn_readlane(r.s0, lane), __builtin_amdgcn_readlane(r.s1, lane),
+              static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(r.meta), lane))};
+}
+// every lane's run joined with the runs of the lanes behind it (a segmented SUFFIX scan): row_shl inside the rows of 16
+// lanes, then the rows behind a lane's own from their first lanes (which hold their whole rows by then)
+__device__ __forceinline__ RunW wave_suffix_scan_runs(RunW r, int lane) {
+  r = join_w(r, dpp_run<0x101>(r));  // row_shl:1
+  r = join_w(r, dpp_run<0x102>(r));  // row_shl:2
+  r = join_w(r, dpp_run<0x104>(r));  // row_shl:4
+  r = join_w(r, dpp_run<0x108>(r));  // row_shl:8
+  const RunW a1 = readlane_run(r, 16), a2 = readlane_run(r, 32), a3 = readlane_run(r, 48);
+  const RunW t1 = join_w(a2, a3), t0 = join_w(a1, t1);
+  const int row = lane >> 4;
+  RunW tail = a3;  // behind row 2
+  if (row == 1) tail = t1;
+  if (row == 0) tail = t0;
+  if (row == 3) tail.meta = kNullRun;
+  return join_w(r, tail);
 }
 
 // All 1024 threads call this; every thread returns with out[k] = the sequential float sum of v[k][0 .. n) started at acc0[k].
@@ -289,12 +346,7 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
       S.desc[k][tid].x = mine ? code : kNoCode;
       __syncthreads();
       const int next_code = (tid + 1 < chunks_here) ? S.desc[k][tid + 1].x : kNoCode;
-      Run r{f, tid, (code == kNoCode || next_code != code) ? 1 : 0};
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const Run o = shfl_down_run(r, off);
-        if (lane + off < 64) r = join(r, o);
-      }
+      Run r = unpack_run(wave_suffix_scan_runs(pack_run(Run{f, tid, (code == kNoCode || next_code != code) ? 1 : 0}), lane));
       if (lane == 0) {
         S.wave_agg[0][wave] = make_int4(r.f.s0, r.f.s1, static_cast<int>(r.f.p0 | (r.f.p1 << 1) | (static_cast<unsigned>(r.closed) << 2)), r.end);
       }
@@ -311,54 +363,90 @@ __device__ void block_sequential_sums(const float* const (&v)[K], int n, const f
       DLIOM_ES_STAMP(1 + k);
     }
     __syncthreads();
-    // the walk: lane 0 of wave k takes array k
-    if (wave < K && lane == 0) {
+    // the walk: wave k takes array k, every lane with the same numbers.  The chunk descriptors are held 64 at a time
+    // across the lanes and the staged values of the chunks that are added one by one lie across the lanes as well (lane j:
+    // the 16 values of stage slot j), so that a step reads registers (v_readlane), not LDS: a step was ~660 cycles of
+    // dependent LDS reads, ~70 steps an array, 45 000 of the 113 000 cycles of a 10 000-point slice's centroid.
+    if (wave < K) {
       float a = S.result[wave];
       const float* vp = v[0];
 #pragma unroll
       for (int k = 1; k < K; ++k)
         if (wave == k) vp = v[k];
-      int cc = 0;
+      float sv[kChunk];
+      {
+        const int staged = static_cast<int>(min(S.stage_count[wave], static_cast<unsigned>(kStageSlots)));
+        static_assert(kStageSlots == 64, "one stage slot per lane");
+#pragma unroll
+        for (int j = 0; j < kChunk; j += 4) {
+          float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (lane < staged) q = *reinterpret_cast<const float4*>(&S.stage[wave][lane][j]);
+          sv[j] = q.x;
+          sv[j + 1] = q.y;
+          sv[j + 2] = q.z;
+          sv[j + 3] = q.w;
+        }
+      }
+      int cc = 0, win = -64;
+      int4 dwin = make_int4(kNoCode, 0, 0, 0);
+#ifdef DLIOM_EXPERIMENTS
+      int dbg_steps = 0, dbg_seq = 0, dbg_far = 0;
+#endif
       while (cc < chunks_here) {
-        const int4 d = S.desc[wave][cc];
-        const unsigned bits = __float_as_uint(a);
-        if (d.x != kNoCode && d.x == code_of(a)) {
+#ifdef DLIOM_EXPERIMENTS
+        ++dbg_steps;
+#endif
+        if (cc >= win + 64) {  // (the walk only moves forward)
+          win = cc;
+          dwin = cc + lane < chunks_here ? S.desc[wave][cc + lane] : make_int4(kNoCode, 0, 0, 0);
+        }
+        const int j = cc - win;
+        const int dx = __builtin_amdgcn_readlane(dwin.x, j), dy = __builtin_amdgcn_readlane(dwin.y, j);
+        const int dz = __builtin_amdgcn_readlane(dwin.z, j), dw = __builtin_amdgcn_readlane(dwin.w, j);
+        const unsigned bits = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(a))));
+        if (dx != kNoCode && dx == code_of(__uint_as_float(bits))) {
           const int kcount = static_cast<int>((bits & 0x7fffffu) | 0x800000u);
-          const int k2 = kcount + ((kcount & 1) ? d.z : d.y);
+          const int k2 = kcount + ((kcount & 1) ? dz : dy);
           if (k2 >= (1 << 23) && k2 < (1 << 24)) {
             a = __uint_as_float((bits & 0xff800000u) | (static_cast<unsigned>(k2) & 0x7fffffu));
-            cc = static_cast<int>((static_cast<unsigned>(d.w) >> 2) & 0x3fffu) + 1;
+            cc = static_cast<int>((static_cast<unsigned>(dw) >> 2) & 0x3fffu) + 1;
             continue;
           }
         }
         // this chunk's values one after the other
         const int j0 = (cb + cc) * kChunk, j1 = min(n, j0 + kChunk);
-        const int slot = static_cast<int>(static_cast<unsigned>(d.w) >> 16) - 1;
+        const int slot = static_cast<int>(static_cast<unsigned>(dw) >> 16) - 1;
+#ifdef DLIOM_EXPERIMENTS
+        ++dbg_seq;
+        if (slot < 0) ++dbg_far;
+#endif
         float x[kChunk];
         if (slot >= 0) {
 #pragma unroll
-          for (int j = 0; j < kChunk; j += 4) {
-            const float4 q = *reinterpret_cast<const float4*>(&S.stage[wave][slot][j]);
-            x[j] = q.x;
-            x[j + 1] = q.y;
-            x[j + 2] = q.z;
-            x[j + 3] = q.w;
-          }
+          for (int t = 0; t < kChunk; ++t)
+            x[t] = __uint_as_float(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(__float_as_uint(sv[t])), slot)));
         } else {
 #pragma unroll
-          for (int j = 0; j < kChunk; ++j) x[j] = j0 + j < j1 ? vp[j0 + j] : 0.f;
+          for (int t = 0; t < kChunk; ++t) x[t] = j0 + t < j1 ? vp[j0 + t] : 0.f;
         }
         if (j1 - j0 == kChunk) {
 #pragma unroll
-          for (int j = 0; j < kChunk; ++j) a += x[j];
+          for (int t = 0; t < kChunk; ++t) a += x[t];
         } else {
 #pragma unroll
-          for (int j = 0; j < kChunk; ++j)
-            if (j0 + j < j1) a += x[j];  // (a padding +0 would turn an accumulator of -0 into +0)
+          for (int t = 0; t < kChunk; ++t)
+            if (j0 + t < j1) a += x[t];  // (a padding +0 would turn an accumulator of -0 into +0)
         }
         cc += 1;
       }
-      S.result[wave] = a;
+      if (lane == 0) S.result[wave] = a;
+#ifdef DLIOM_EXPERIMENTS
+      if (lane == 0 && blockIdx.x == 0 && wave == 0) {
+        dbg_es[13] = S.stage_count[0];
+        dbg_es[14] = static_cast<unsigned long long>(dbg_steps);
+        dbg_es[15] = static_cast<unsigned long long>(dbg_seq) | (static_cast<unsigned long long>(dbg_far) << 32);
+      }
+#endif
     }
     __syncthreads();
     DLIOM_ES_STAMP(8);

@@ -45,10 +45,43 @@ def main():
         # the last call of block 0 (big_slice_kernel's centroid): 0 start, 10 / 11 / 12 loads+prefix / block scans /
         # element functions of the LAST array, 1 + k array k classified, 8 walk done
         rec["exact_sum_last_call"] = {str(k): (e[k] - e[0]) for k in (10, 11, 12, 1, 2, 8)}
+        rec["exact_sum_walk_array0"] = {"unsafe_chunks": e[13], "steps": e[14], "one_by_one": e[15] & 0xffffffff, "from_memory": e[15] >> 32}
         rec["slice_count"] = int(a[4][10])
         rec["m"] = int(a[4][11])
         out[name] = rec
         cloud.close()
+    # slice_kernel (every slice in LDS): the cube scene's scan, per workgroup (= slice) the cycles between the marks
+    with synth.scene("cube"):
+        raw, _ = synth.scan(synth.trajectory_pose(0.7), 64, 1024)
+    pts = raw[orc.voxel_filter(0.15, raw)]
+    cloud = dl.PointCloud(ctx, pts)
+    for _ in range(4):
+        dl.cloud_rotational_histogram(ctx, cloud, 120, None)
+    ctx.synchronize()
+    buf = (ctypes.c_ulonglong * (64 * 16))()
+    lib.dliom_exp_rothist_stamps.argtypes = [ctypes.c_void_p]
+    lib.dliom_exp_rothist_stamps.restype = ctypes.c_int
+    lib.dliom_exp_rothist_stamps(ctypes.cast(buf, ctypes.c_void_p))
+    a = np.array(buf[:], dtype=np.uint64).reshape(64, 16).astype(np.int64)
+    rows = []
+    for b in range(64):
+        st = a[b]
+        if st[7] == 0:
+            continue
+        order = [0, 1, 2, 3, 13, 14, 15, 4, 5, 6, 7]
+        names = ["find", "compact", "centroid", "angles", "bitonic", "replay_in", "replay", "order", "sorted+centroid", "chain+contrib", "write"]
+        prev = st[0]
+        rec = {"count": int(st[10]), "m": int(st[11]), "total": int(st[7] - st[0])}
+        for k, nm in zip(order[1:], names[1:]):
+            if st[k] == 0 or st[k] < prev:
+                continue
+            rec[nm] = int(st[k] - prev)
+            prev = st[k]
+        rows.append(rec)
+    rows.sort(key=lambda r: -r["total"])
+    out["cube_slice_kernel_slowest"] = rows[:4]
+    out["cube_slice_kernel_workgroups"] = len(rows)
+    cloud.close()
     print(json.dumps(out))
 
 
