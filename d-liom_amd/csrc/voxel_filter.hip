@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kVfBlock) void voxel_compact_kernel(
     const float* __restrict__ w, unsigned n, const unsigned char* __restrict__ flags,
     const unsigned* __restrict__ block_counts, float* __restrict__ ox, float* __restrict__ oy,
     float* __restrict__ oz, float* __restrict__ ow, unsigned* __restrict__ out_index,
-    unsigned* __restrict__ out_max_sq) {
+    unsigned* __restrict__ out_max_sq, unsigned* __restrict__ out_total) {
   __shared__ unsigned sh_part[kVfBlock];
   __shared__ unsigned sh_wave[kVfBlock / 64];
   // survivors in the blocks before this one
@@ -236,6 +236,12 @@ __global__ __launch_bounds__(kVfBlock) void voxel_compact_kernel(
   __syncthreads();
   unsigned before = 0;
   for (unsigned k = 0; k < wave; ++k) before += sh_wave[k];
+  // the number of survivors: the last workgroup knows it (no counter to zero, no atomic)
+  if (out_total != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    unsigned all = base;
+    for (unsigned k = 0; k < kVfBlock / 64; ++k) all += sh_wave[k];
+    *out_total = all;
+  }
   unsigned sq_bits = 0u;
   if (keep) {
     const unsigned pos = base + before + static_cast<unsigned>(__popcll(m & ((1ull << lane) - 1ull)));
@@ -370,7 +376,7 @@ static int emit_arrays(dliom_ctx* ctx, const Soa& in, const VfScratch& s, const 
   hipLaunchKernelGGL(voxel_flag_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, n, t, l, mode, s.flags,
                      s.block_counts);
   hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z, in.w, n,
-                     s.flags, s.block_counts, ox, oy, oz, ow, static_cast<unsigned*>(nullptr), max_sq);
+                     s.flags, s.block_counts, ox, oy, oz, ow, static_cast<unsigned*>(nullptr), max_sq, static_cast<unsigned*>(nullptr));
   DLIOM_HIP_TRY(hipGetLastError());
   return DLIOM_OK;
 }
@@ -398,16 +404,12 @@ static int emit_cloud(dliom_ctx* ctx, const Soa& in, const VfScratch& s, const V
 __global__ __launch_bounds__(kVfBlock) void count_flags_kernel(const unsigned char* __restrict__ flags, unsigned n,
                                                                unsigned char want,
                                                                unsigned char* __restrict__ out_flags,
-                                                               unsigned* __restrict__ block_counts,
-                                                               unsigned* __restrict__ total) {
+                                                               unsigned* __restrict__ block_counts) {
   const unsigned i = blockIdx.x * kVfBlock + threadIdx.x;
   const bool keep = i < n && flags[i] == want;
   if (i < n) out_flags[i] = keep ? 1 : 0;
   const int c = __syncthreads_count(keep ? 1 : 0);
-  if (threadIdx.x == 0) {
-    block_counts[blockIdx.x] = static_cast<unsigned>(c);
-    atomicAdd(total, static_cast<unsigned>(c));
-  }
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = static_cast<unsigned>(c);
 }
 
 int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, float* oy, float* oz, float* ow,
@@ -438,12 +440,12 @@ int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kin
   DLIOM_TRY(carve_scratch(ctx, in.n, 1, &s));
   const unsigned n = static_cast<unsigned>(in.n);
   const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
-  DLIOM_HIP_TRY(hipMemsetAsync(s.max_sq, 0, 4, ctx->stream));
+  // (the survivor count comes out of the compaction's last workgroup: until round 5 a memset and one atomic per workgroup)
   hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, kinds, n, want, s.flags,
-                     s.block_counts, s.max_sq);
+                     s.block_counts);
   hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z,
                      static_cast<const float*>(nullptr), n, s.flags, s.block_counts, ox, oy, oz,
-                     static_cast<float*>(nullptr), static_cast<unsigned*>(nullptr), static_cast<unsigned*>(nullptr));
+                     static_cast<float*>(nullptr), static_cast<unsigned*>(nullptr), static_cast<unsigned*>(nullptr), s.max_sq);
   DLIOM_HIP_TRY(hipGetLastError());
   unsigned* host = static_cast<unsigned*>(ctx->pinned);
   const GatherJob jobs[2] = {{s.max_sq, 1}, {also_src, also_words}};
