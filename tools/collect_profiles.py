@@ -49,14 +49,15 @@ if "FETCH_SIZE" in summary:
     out["fetch_bytes_raw"] = summary["FETCH_SIZE"]["mean"] * 1024.0
     out["write_bytes_raw"] = summary.get("WRITE_SIZE", {"mean": 0.0})["mean"] * 1024.0
     out["hbm_bytes_per_launch"] = 2.0 * out["fetch_bytes_raw"] + out["write_bytes_raw"]
-json.dump(out, open(os.path.join(dst, "%s_pmc_score_kernel.json" % tag), "w"), indent=1)
+if summary:  # (a run of selected parts without the PMC passes keeps the file there is)
+    json.dump(out, open(os.path.join(dst, "%s_pmc_score_kernel.json" % tag), "w"), indent=1)
 for name, o in (("bench_full.json", "%s_bench.json"), ("wref_full.json", "%s_wref_full.json"), ("wref.json", "%s_wref.json"),
                 ("wref_stages.json", "%s_wref_stages.json"), ("stream.json", "%s_stream_config3.json"),
                 ("stream_gentle.json", "%s_stream_config3_gentle.json"), ("config5_bench.json", "%s_config5_bench.json"),
                 ("bench_gloo2.json", "%s_bench_gloo2.json"), ("fast_csm.json", "%s_fast_csm.json"),
                 ("fast_csm_full.json", "%s_fast_csm_full.json"), ("fast_csm_dense.json", "%s_fast_csm_dense.json"),
                 ("hist_bench.json", "%s_hist_bench.json"), ("bench_rccl_1rank.json", "%s_bench_rccl_1rank.json"),
-                ("mirror_window_stream.json", "%s_mirror_window_stream.json")):
+                ("mirror_window_stream.json", "%s_mirror_window_stream.json"), ("voxel_filter.json", "%s_voxel_filter.json")):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
@@ -70,7 +71,8 @@ if os.path.exists(h):
     keep = [l for l in open(h).read().splitlines() if "histogram" in l or "rothist" in l or l.startswith('"Name"') or l.startswith("==")
             or l.startswith("{") or "rocprim" in l or "fill_multi" in l or "gather_to_pinned" in l]
     open(os.path.join(dst, "%s_histogram_kernels.txt" % tag), "w").write("\n".join(keep) + "\n")
-for name, o in (("wref_trace", "%s_wref_full_rocprofv3_kernel_stats.csv"), ("wref_trace_yard", "%s_wref_full_yard_rocprofv3_kernel_stats.csv")):
+for name, o in (("wref_trace", "%s_wref_full_rocprofv3_kernel_stats.csv"), ("wref_trace_yard", "%s_wref_full_yard_rocprofv3_kernel_stats.csv"),
+                ("voxel_trace", "%s_voxel_filter_kernel_stats.csv")):
     for f in glob.glob(os.path.join(src, name, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, o % tag))
 g = os.path.join(src, "gputest.log")
