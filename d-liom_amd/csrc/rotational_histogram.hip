@@ -651,6 +651,7 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
       mine += static_cast<unsigned>(__builtin_popcount(h8));
       if (keep_hits) kept_hits |= static_cast<unsigned long long>(h8) << (8 * (blk - blk_lo));
     }
+    DLIOM_STAMP(8);
     // per-wave totals -> where this wave's points start
     unsigned wave_total = mine;
 #pragma unroll
@@ -660,6 +661,7 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
     __syncthreads();
     unsigned at = 0u;
     for (int w = 0; w < wave; ++w) at += wave_sums[w];
+    DLIOM_STAMP(9);
     for (int blk = blk_lo; blk < blk_hi; ++blk) {
       const int i0 = blk * 512 + lane * 8;
       unsigned hits = 0u;

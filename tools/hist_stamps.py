@@ -68,8 +68,8 @@ def main():
         st = a[b]
         if st[7] == 0:
             continue
-        order = [0, 1, 2, 3, 13, 14, 15, 4, 5, 6, 7]
-        names = ["find", "compact", "centroid", "angles", "bitonic", "replay_in", "replay", "order", "sorted+centroid", "chain+contrib", "write"]
+        order = [0, 8, 9, 1, 2, 3, 13, 14, 15, 4, 5, 6, 7]
+        names = ["find", "compact_count", "compact_offsets", "compact_copy", "centroid", "angles", "bitonic", "replay_in", "replay", "order", "sorted+centroid", "chain+contrib", "write"]
         prev = st[0]
         rec = {"count": int(st[10]), "m": int(st[11]), "total": int(st[7] - st[0])}
         for k, nm in zip(order[1:], names[1:]):
