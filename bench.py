@@ -294,12 +294,18 @@ def main():
         for i in range(args.warmup):
             step(args.warmup + args.steps + i, False)
         fence()
+        ctx.set_profiling(2)  # HIP events around the score kernel only, as in the replica run above
+        ctx.reset_profiling()
         t_s = time.perf_counter()
         for i in range(args.steps):
             step(2 * args.warmup + args.steps + i, False)
         fence()
         el = time.perf_counter() - t_s
-        tt = torch.tensor([el], dtype=torch.float64, device=coll_device)
+        shard_score_ms, shard_score_n = ctx.kernel_time(dl.KERNEL_RTCSM_SCORE)
+        ctx.set_profiling(0)
+        # the part of a step that does NOT shrink with the number of ranks: the step minus this rank's score kernel,
+        # the largest over the ranks
+        tt = torch.tensor([el, el - 1e-3 * shard_score_ms], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         use_shards[0] = False
         sharded_line = {"workload": "config4: ONE scan stream, RTCSM3D search window sharded over %d ranks (one 8-byte RCCL "
@@ -307,8 +313,10 @@ def main():
                         "collective": ("dliom_rtcsm3d_match_sharded_rccl (ncclAllReduce inside the library)" if rccl_comm is not None
                                        else "dliom_rtcsm3d_match_sharded + torch.distributed callback (%s)" % backend),
                         "ranks_seen": rccl_comm.ranks_seen if rccl_comm is not None else world,
-                        "value": args.steps / float(tt.item()), "unit": "scans/s", "scaling": "strong",
-                        "ms_per_step": 1e3 * float(tt.item()) / args.steps,
+                        "value": args.steps / float(tt[0].item()), "unit": "scans/s", "scaling": "strong",
+                        "ms_per_step": 1e3 * float(tt[0].item()) / args.steps,
+                        "score_kernel_ms_per_step_this_rank": shard_score_ms / max(1, args.steps),
+                        "serial_remainder_ms_per_step": 1e3 * float(tt[1].item()) / args.steps,
                         "note": "Amdahl: only the score volume (~60 % of a 1-GPU step) shards; Ceres, insertion, the "
                                 "bounds / rescoring kernels and two host synchronisations per scan stay serial"}
 
@@ -462,11 +470,16 @@ def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sh
     steps = 3
     one()
     fence()
+    ctx.set_profiling(2)
+    ctx.reset_profiling()
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
     fence()
-    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    el = time.perf_counter() - t0
+    score_ms, _ = ctx.kernel_time(dl.KERNEL_RTCSM_SCORE)
+    ctx.set_profiling(0)
+    tt = torch.tensor([el, el - 1e-3 * score_ms], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     st = dl.RealTimeCorrelativeScanMatcher3D(ctx, RTCSM_OPTS).last_stats()
     sc["cloud"].close()
@@ -475,8 +488,10 @@ def config5_sharded_line(args, dl, synth, ctx, rank, world, dist, dev, torch, sh
     return {"workload": "config5 W-dense: ONE 128x2048 scan stream @ 5 cm, RTCSM3D window sharded over %d ranks (one 8-byte "
                         "RCCL max all-reduce per scan), Ceres + insertion replicated" % world,
             "collective": "dliom_rtcsm3d_match_sharded_rccl" if rccl_comm is not None else "callback",
-            "value": steps / float(tt.item()), "unit": "scans/s", "scaling": "strong", "steps": steps,
-            "ms_per_step": 1e3 * float(tt.item()) / steps, "C": int(st.window.num_candidates), "N": int(st.num_points)}
+            "value": steps / float(tt[0].item()), "unit": "scans/s", "scaling": "strong", "steps": steps,
+            "ms_per_step": 1e3 * float(tt[0].item()) / steps, "score_kernel_ms_per_step_this_rank": score_ms / steps,
+            "serial_remainder_ms_per_step": 1e3 * float(tt[1].item()) / steps,
+            "C": int(st.window.num_candidates), "N": int(st.num_points)}
 
 
 def config5_line(dl, synth, ctx, steps=3, with_oracle=True):
