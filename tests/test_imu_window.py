@@ -414,6 +414,23 @@ def test_failed_marginalisation_rolls_the_window_back(tmp_path):
     assert "dliom_test_fail_marginalize" not in syms
 
 
+def test_restructured_linear_algebra_gives_the_plain_forms_values(tmp_path):
+    """Round 5 restructured two pieces of the window's host arithmetic for speed (it runs inside the W-ref chain): the
+    banded Cholesky became right-looking and the covariance propagation skips the entries of A, B, C that are always
+    zero.  tests/cpp/imu_window_linear_algebra.cc compiles imu_window.cc by itself and compares both with the plain
+    forms: the factor bit for bit, the covariance with == (a skipped term was an exact zero), at the library's own
+    optimisation level and without optimisation."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for opt in ("-O3", "-O0"):
+        exe = str(tmp_path / ("imu_window_linear_algebra" + opt))
+        subprocess.check_call(["g++", "-std=c++17", opt, "-ffp-contract=off", "-Wall", "-Wno-subobject-linkage", "-o", exe,
+                               os.path.join(root, "tests", "cpp", "imu_window_linear_algebra.cc")])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip().endswith("OK"), opt + ": " + out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("tangent", [0, 1])
 def test_both_preintegration_forms_equal_their_numpy_restatement(dl, tangent):
     """options.tangent_preintegration: 1 = gtsam::TangentPreintegration (what the reference's GTSAM 4.0.2 build holds,
