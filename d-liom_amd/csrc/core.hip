@@ -559,6 +559,41 @@ int alloc_device_cloud(dliom_ctx* ctx, int64_t n, dliom_cloud** out, float** x, 
   return DLIOM_OK;
 }
 
+// [0, n) := the source arrays, [n, n_padded) := 0: finish_cloud's pad_tail_kernel with the copy in front of it
+__global__ void copy_pad_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                int64_t n, int64_t n_padded, float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_padded) return;
+  x[i] = i < n ? sx[i] : 0.f;
+  y[i] = i < n ? sy[i] : 0.f;
+  z[i] = i < n ? sz[i] : 0.f;
+}
+
+// A cloud whose points lie in arrays of the caller (written before their number was known on the host): copied in by the
+// launch that pads the tail anyway.
+int finish_device_cloud_from(dliom_ctx* ctx, dliom_cloud* c, float max_norm, const float* sx, const float* sy, const float* sz) {
+  const CloudLayout l = layout_cloud(static_cast<char*>(c->base), c->n);
+  const int64_t n = c->n, np = pad_points(n);
+  if (np > 0) {
+    hipLaunchKernelGGL(copy_pad_kernel, dim3(static_cast<unsigned>((np + 255) / 256)), dim3(256), 0, ctx->stream, sx, sy, sz, n, np,
+                       l.x, l.y, l.z);
+    DLIOM_HIP_TRY(hipGetLastError());
+  }
+  c->ctx = ctx;
+  c->device = ctx->device;
+  c->n_padded = np;
+  c->d_x = l.x;
+  c->d_y = l.y;
+  c->d_z = l.z;
+  c->d_xs = l.xs;
+  c->d_ys = l.ys;
+  c->d_zs = l.zs;
+  c->morton_ready = false;
+  c->d_chunk_order = nullptr;
+  c->max_norm = max_norm;
+  return DLIOM_OK;
+}
+
 int finish_device_cloud(dliom_ctx* ctx, dliom_cloud* c, float max_norm) {
   const CloudLayout l = layout_cloud(static_cast<char*>(c->base), c->n);
   DLIOM_TRY(finish_cloud(ctx, l, c->n, c));

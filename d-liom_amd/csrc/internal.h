@@ -227,6 +227,7 @@ size_t staged_cloud_bytes(int64_t n);
 // on ctx->stream, finish (padding + Morton copies)
 int alloc_device_cloud(dliom_ctx* ctx, int64_t n, dliom_cloud** out, float** x, float** y, float** z);
 int finish_device_cloud(dliom_ctx* ctx, dliom_cloud* cloud, float max_norm);
+int finish_device_cloud_from(dliom_ctx* ctx, dliom_cloud* cloud, float max_norm, const float* sx, const float* sy, const float* sz);
 // builds the Morton-ordered copies of a cloud on ctx->stream if they are not there yet (a cache of
 // the cloud's contents, hence callable on const clouds)
 int ensure_morton(dliom_ctx* ctx, const dliom_cloud* cloud);
@@ -238,6 +239,12 @@ struct Soa {
 // VoxelFilter(size): survivors into ox..ow (room for n), count in *n_out; synchronises once.
 int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, float* oy, float* oz, float* ow,
                         int64_t* n_out);
+// The same filter, only enqueued (packed table words; DLIOM_ERR_CAPACITY if the cloud is too large for them): no
+// read-back.  *d_total: device word that will hold the survivor count; *d_unpackable: device word that is non-zero if
+// a point did not fit the packed words -- the caller reads both back with its own results and, should the second be
+// set, repeats the filter with voxel_filter_arrays.
+int voxel_filter_arrays_enqueue(dliom_ctx* ctx, const Soa& in, float size, float* ox, float* oy, float* oz, float* ow,
+                                const unsigned** d_total, const unsigned** d_unpackable);
 // Order-preserving compaction of the points with kinds[i] == want; synchronises once.
 int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
                          float* oy, float* oz, int64_t* n_out,

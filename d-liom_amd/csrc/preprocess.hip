@@ -265,7 +265,8 @@ constexpr int kTransformBlocks = 128;
 __global__ __launch_bounds__(256) void transform_kernel(Quat4 q, float tx, float ty, float tz, const float* __restrict__ x,
                                                         const float* __restrict__ y, const float* __restrict__ z, int n,
                                                         float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
-                                                        float* __restrict__ partial_max) {
+                                                        float* __restrict__ partial_max, const unsigned* __restrict__ n_dev) {
+  if (n_dev != nullptr) n = min(n, static_cast<int>(*n_dev));  // the number of points is still on the device (stage B)
   float m[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float rx, ry, rz;
@@ -564,12 +565,12 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
                                   float origin_in_tracking[3]) {
   const size_t nn = static_cast<size_t>(std::max<int64_t>(n2, 1));
   auto al = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-  DLIOM_TRY(ctx->rescore.reserve(3 * al(4 * nn) + 16 * kTransformBlocks));  // filtered returns | per-workgroup maxima (misc holds the inputs)
+  // filtered returns | per-workgroup maxima | transformed returns (misc holds the inputs)
+  DLIOM_TRY(ctx->rescore.reserve(6 * al(4 * nn) + 16 * kTransformBlocks));
   float* f = ctx->rescore.as<float>();
   float* d_partial_max = reinterpret_cast<float*>(static_cast<char*>(ctx->rescore.p) + 3 * al(4 * nn));
+  float* t = reinterpret_cast<float*>(static_cast<char*>(ctx->rescore.p) + 3 * al(4 * nn) + 16 * kTransformBlocks);
   const size_t fs = al(4 * nn) / 4;
-  int64_t n3 = 0;
-  DLIOM_TRY(voxel_filter_arrays(ctx, Soa{rx, ry, rz, nullptr, n2}, voxel_filter_size, f, f + fs, f + 2 * fs, nullptr, &n3));
   // current_pose.inverse() in float (rigid_transform.h:167-171)
   const QF qc{current_pose[3], -current_pose[4], -current_pose[5], -current_pose[6]};
   const F3 rt = qrot(qc, F3{current_pose[0], current_pose[1], current_pose[2]});
@@ -578,16 +579,64 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
   origin_in_tracking[0] = o.x;
   origin_in_tracking[1] = o.y;
   origin_in_tracking[2] = o.z;
+  const int threads = 256;
+  float* host = static_cast<float*>(ctx->pinned);
+  float max_norm = 0.f, abs_max[3] = {0.f, 0.f, 0.f};
+  int64_t n3 = -1;
+  // Round 5: ONE read-back for the stage.  The filter is only enqueued (its survivor count stays on the device), the
+  // transform takes the count from there and writes into scratch arrays of the input's size, and count, "fits the packed
+  // table words" and the transform's maxima come back together; the cloud is allocated then and filled by the launch
+  // that pads its tail anyway.  (Until then: count read-back, transform, maxima read-back.)
+  if (n2 > 0) {
+    const unsigned *d_total = nullptr, *d_unpackable = nullptr;
+    const int fst = voxel_filter_arrays_enqueue(ctx, Soa{rx, ry, rz, nullptr, n2}, voxel_filter_size, f, f + fs, f + 2 * fs, nullptr,
+                                                &d_total, &d_unpackable);
+    if (fst == DLIOM_OK) {
+      const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((n2 + threads - 1) / threads, kTransformBlocks));
+      hipLaunchKernelGGL(transform_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y,
+                         ti.z, f, f + fs, f + 2 * fs, static_cast<int>(n2), t, t + fs, t + 2 * fs, d_partial_max, d_total);
+      const GatherJob jobs[3] = {{d_total, 1}, {d_unpackable, 1}, {d_partial_max, 4 * blocks}};
+      DLIOM_TRY(gather_and_wait(ctx, jobs, 3, host));
+      unsigned head[2];
+      std::memcpy(head, host, 8);
+      if (head[1] == 0u) {
+        n3 = head[0];
+        float sq = 0.f;
+        for (unsigned b = 0; b < blocks; ++b) {
+          sq = std::max(sq, host[2 + 4 * b]);
+          for (int a = 0; a < 3; ++a) abs_max[a] = std::max(abs_max[a], host[2 + 4 * b + 1 + a]);
+        }
+        max_norm = std::sqrt(sq);  // sqrt is monotone and correctly rounded: == the maximum of the norms
+      } else {
+        ++ctx->voxel_unpacked_reruns;  // a return farther than 4095 voxel edges away: the general filter below
+      }
+    } else if (fst != DLIOM_ERR_CAPACITY) {
+      return fst;
+    }
+  } else {
+    n3 = 0;
+  }
+  if (n3 >= 0) {
+    float *cx, *cy, *cz;  // (filled from the scratch arrays by finish_device_cloud_from)
+    DLIOM_TRY(alloc_device_cloud(ctx, n3, returns_in_tracking, &cx, &cy, &cz));
+    int st = finish_device_cloud_from(ctx, *returns_in_tracking, max_norm, t, t + fs, t + 2 * fs);
+    if (st == DLIOM_OK && n3 > 0)
+      for (int a = 0; a < 3; ++a) (*returns_in_tracking)->abs_max[a] = abs_max[a];
+    if (st != DLIOM_OK) {
+      dliom_cloud_destroy(*returns_in_tracking);
+      *returns_in_tracking = nullptr;
+    }
+    return st;
+  }
+  // ---- the general path: read-backs after the filter and after the transform
+  DLIOM_TRY(voxel_filter_arrays(ctx, Soa{rx, ry, rz, nullptr, n2}, voxel_filter_size, f, f + fs, f + 2 * fs, nullptr, &n3));
   float *ox, *oy, *oz;
   DLIOM_TRY(alloc_device_cloud(ctx, n3, returns_in_tracking, &ox, &oy, &oz));
-  float max_norm = 0.f, abs_max[3] = {0.f, 0.f, 0.f};
   int st = DLIOM_OK;
-  const int threads = 256;
   if (n3 > 0) {
     const unsigned blocks = static_cast<unsigned>(std::min<int64_t>((n3 + threads - 1) / threads, kTransformBlocks));
     hipLaunchKernelGGL(transform_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, Quat4{qc.w, qc.x, qc.y, qc.z}, ti.x, ti.y,
-                       ti.z, f, f + fs, f + 2 * fs, static_cast<int>(n3), ox, oy, oz, d_partial_max);
-    float* host = static_cast<float*>(ctx->pinned);
+                       ti.z, f, f + fs, f + 2 * fs, static_cast<int>(n3), ox, oy, oz, d_partial_max, static_cast<const unsigned*>(nullptr));
     const GatherJob job{d_partial_max, 4 * blocks};
     st = gather_and_wait(ctx, &job, 1, host);
     if (st == DLIOM_OK) {
@@ -596,7 +645,7 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
         sq = std::max(sq, host[4 * b]);
         for (int a = 0; a < 3; ++a) abs_max[a] = std::max(abs_max[a], host[4 * b + 1 + a]);
       }
-      max_norm = std::sqrt(sq);  // sqrt is monotone and correctly rounded: == the maximum of the norms
+      max_norm = std::sqrt(sq);
     }
   }
   if (st == DLIOM_OK) st = finish_device_cloud(ctx, *returns_in_tracking, max_norm);

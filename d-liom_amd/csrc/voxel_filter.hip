@@ -425,6 +425,35 @@ int voxel_filter_arrays(dliom_ctx* ctx, const Soa& in, float size, float* ox, fl
   return emit_arrays(ctx, in, s, s.tables[0], 0, 0, ox, oy, oz, ow, nullptr);
 }
 
+int voxel_filter_arrays_enqueue(dliom_ctx* ctx, const Soa& in, float size, float* ox, float* oy, float* oz, float* ow,
+                                const unsigned** d_total, const unsigned** d_unpackable) {
+  if (!(size > 0.f) || in.n <= 0) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (in.n > (int64_t{1} << kPackedIndexBits)) return DLIOM_ERR_CAPACITY;
+  VfScratch s;
+  DLIOM_TRY(carve_scratch(ctx, in.n, 1, &s));
+  VfTables& t = s.tables[0];
+  t.num = 1;
+  t.packed = 1;
+  VfLengths lengths;
+  lengths.count = 1;
+  lengths.size[0] = size;
+  lengths.max_range[0] = -1.f;
+  const size_t counter_bytes = static_cast<size_t>(2 * 1 + 1) * kVfCounterStride * 4;
+  const FillJob fills[2] = {{t.tables, static_cast<size_t>(t.capacity) * 12, 0xFFFFFFFFu}, {t.counters, counter_bytes, 0u}};
+  DLIOM_TRY(fill_multi(ctx, fills, 2));
+  const unsigned n = static_cast<unsigned>(in.n);
+  hipLaunchKernelGGL(voxel_insert_kernel<true>, dim3((n + kVfInsertBlock - 1) / kVfInsertBlock, 1), dim3(kVfInsertBlock), 0, ctx->stream,
+                     in.x, in.y, in.z, n, lengths, t);
+  const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
+  hipLaunchKernelGGL(voxel_flag_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, n, t, 0, 0, s.flags, s.block_counts);
+  hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z, in.w, n, s.flags,
+                     s.block_counts, ox, oy, oz, ow, static_cast<unsigned*>(nullptr), static_cast<unsigned*>(nullptr), s.max_sq);
+  DLIOM_HIP_TRY(hipGetLastError());
+  *d_total = s.max_sq;
+  *d_unpackable = t.counters + kVfCounterStride * 2;  // (2 * num)
+  return DLIOM_OK;
+}
+
 int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
                          float* oy, float* oz, int64_t* n_out, const void* also_src, unsigned also_words, void* also_dst) {
   *n_out = 0;
