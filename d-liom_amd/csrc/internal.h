@@ -250,6 +250,11 @@ int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kin
                          float* oy, float* oz, int64_t* n_out,
                          const void* also_src = nullptr, unsigned also_words = 0, void* also_dst = nullptr);  // also_*: a few
                          // more device words read back in the same round trip
+// ... only enqueued, over in.n entries of which the first *n_dev count (a device word); *d_total: the device word that
+// will hold the number of survivors.  Call it right behind voxel_filter_arrays_enqueue only with that call's d_total as
+// n_dev: the two share the context's scratch words.
+int compact_equal_arrays_enqueue(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
+                                 float* oy, float* oz, const unsigned* n_dev, const unsigned** d_total);
 int needed_bits_for_cell_range(int min_index, int max_index);
 // core.hip: several small device fills / read-backs in ONE dispatch each (a hipMemsetAsync or hipMemcpyAsync is a
 // dispatch of its own: ~3 us of GPU time plus the gap to its neighbours, and the filtered-cloud chain issued ~25 per scan)

@@ -167,7 +167,8 @@ __global__ void deskew_kernel(DeskewArgs a, const float* __restrict__ in_x, cons
                               const float* __restrict__ in_origin, int in_stride, int n,
                               float* __restrict__ out_x, float* __restrict__ out_y, float* __restrict__ out_z,
                               int out_stride, unsigned char* __restrict__ out_kind,
-                              unsigned* __restrict__ flags, int only_flags) {
+                              unsigned* __restrict__ flags, int only_flags, const unsigned* __restrict__ n_dev) {
+  if (n_dev != nullptr) n = min(n, static_cast<int>(*n_dev));  // the hits' number is still on the device (stage A)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t ii = static_cast<size_t>(i) * in_stride;
@@ -453,7 +454,8 @@ static int verify_deskew(dliom_ctx* ctx, const DeskewArgs& a, const DeskewLaunch
     unsigned* d_list = ctx->sort_tmp.as<unsigned>();
     DLIOM_HIP_TRY(hipMemsetAsync(d_list, 0, 4, ctx->stream));
     hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((l.n + 255) / 256)), dim3(256), 0, ctx->stream, a, l.in_x, l.in_y,
-                       l.in_z, l.in_t, l.in_origin, l.in_stride, l.n, l.out_x, l.out_y, l.out_z, l.out_stride, l.out_kind, d_list, 1);
+                       l.in_z, l.in_t, l.in_origin, l.in_stride, l.n, l.out_x, l.out_y, l.out_z, l.out_stride, l.out_kind, d_list, 1,
+                       static_cast<const unsigned*>(nullptr));
     DLIOM_HIP_TRY(hipGetLastError());
     unsigned count = 0;
     DLIOM_HIP_TRY(hipMemcpyAsync(&count, d_list, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -519,34 +521,69 @@ static int add_range_data_stage_a(dliom_ctx* ctx, const double prev_pose[7], con
                      ctx->stream, reinterpret_cast<const float4*>(base + off_raw), static_cast<int>(n), b, b + nn,
                      b + 2 * nn, b + 3 * nn);
   // hits = VoxelFilter(0.5f * voxel_filter_size).Filter(ranges): the time rides along
-  int64_t n1 = 0;
-  DLIOM_TRY(voxel_filter_arrays(ctx, Soa{b, b + nn, b + 2 * nn, b + 3 * nn, n}, 0.5f * voxel_filter_size, c, c + nn,
-                                c + 2 * nn, c + 3 * nn, &n1));
   const bool multi = origin_index != nullptr && num_origins > 1;
-  if (multi) {  // the same filter once more with the origin index as the passenger: same survivors, same order
-    DLIOM_HIP_TRY(hipMemcpyAsync(oi_in, origin_index, 4 * nn, hipMemcpyHostToDevice, ctx->stream));
-    int64_t n1b = 0;
-    DLIOM_TRY(voxel_filter_arrays(ctx, Soa{b, b + nn, b + 2 * nn, oi_in, n}, 0.5f * voxel_filter_size, d, d + nn,
-                                  d + 2 * nn, oi_f, &n1b));
-    if (n1b != n1) return DLIOM_ERR_INVALID_ARGUMENT;
-  }
   DeskewArgs a;
   // the first range always survives the filter, so hits.front() is ranges.front()
   DLIOM_TRY(make_deskew_args(prev_pose, predicted_pose, scan_period, origins, min_range, max_range, ranges_xyzt[3], &a));
   deskew_test_hook(ctx, &a);
   for (int k = 0; k < std::min(num_origins, 4); ++k)
     for (int i = 0; i < 3; ++i) a.origins[k][i] = origins[3 * k + i];
+  std::vector<unsigned> host_flags(kDeskewFlagWords);
+  int64_t n1 = -1;
+  // Round 5: ONE read-back for the stage (single origin).  The filter is only enqueued; the de-skew and the compaction
+  // of the returns run over the INPUT's size and take the hits' number from the device word the filter's compaction
+  // leaves; that number, "fits the packed table words", the number of returns, the last hit's pose and the de-skew's
+  // records come back together.  (Until then: the filter's count read-back, then the compaction's.)
+  if (!multi) {
+    const unsigned *d_hits = nullptr, *d_unpackable = nullptr, *d_returns = nullptr;
+    const int fst = voxel_filter_arrays_enqueue(ctx, Soa{b, b + nn, b + 2 * nn, b + 3 * nn, n}, 0.5f * voxel_filter_size, c, c + nn,
+                                                c + 2 * nn, c + 3 * nn, &d_hits, &d_unpackable);
+    if (fst == DLIOM_OK) {
+      hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n + threads - 1) / threads)), dim3(threads), 0, ctx->stream, a, c,
+                         c + nn, c + 2 * nn, c + 3 * nn, static_cast<const float*>(nullptr), 1, static_cast<int>(n), d, d + nn,
+                         d + 2 * nn, 1, kind, d_flags, 0, d_hits);
+      DLIOM_HIP_TRY(hipGetLastError());
+      DLIOM_TRY(compact_equal_arrays_enqueue(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n}, kind, 1, e, e + nn, e + 2 * nn, d_hits, &d_returns));
+      unsigned* host = static_cast<unsigned*>(ctx->pinned);
+      const GatherJob jobs[4] = {{d_hits, 1}, {d_unpackable, 1}, {d_returns, 1}, {d_flags, static_cast<unsigned>(kDeskewFlagWords)}};
+      DLIOM_TRY(gather_and_wait(ctx, jobs, 4, host));
+      if (host[1] == 0u) {
+        n1 = host[0];
+        *num_returns = host[2];
+        std::memcpy(host_flags.data(), host + 3, 4 * static_cast<size_t>(kDeskewFlagWords));
+      } else {
+        ++ctx->voxel_unpacked_reruns;  // a range farther than 4095 voxel edges away: the general path below
+        // (the de-skew's records of the abandoned launch stay counted: verify_deskew takes the counter's difference)
+        ctx->deskew_flag_total = host[3 + 8];
+      }
+    } else if (fst != DLIOM_ERR_CAPACITY) {
+      return fst;
+    }
+  }
+  const bool merged = n1 >= 0;
+  if (!merged) {
+    DLIOM_TRY(voxel_filter_arrays(ctx, Soa{b, b + nn, b + 2 * nn, b + 3 * nn, n}, 0.5f * voxel_filter_size, c, c + nn,
+                                  c + 2 * nn, c + 3 * nn, &n1));
+    if (multi) {  // the same filter once more with the origin index as the passenger: same survivors, same order
+      DLIOM_HIP_TRY(hipMemcpyAsync(oi_in, origin_index, 4 * nn, hipMemcpyHostToDevice, ctx->stream));
+      int64_t n1b = 0;
+      DLIOM_TRY(voxel_filter_arrays(ctx, Soa{b, b + nn, b + 2 * nn, oi_in, n}, 0.5f * voxel_filter_size, d, d + nn,
+                                    d + 2 * nn, oi_f, &n1b));
+      if (n1b != n1) return DLIOM_ERR_INVALID_ARGUMENT;
+    }
+  }
   const DeskewLaunch launch{c, c + nn, c + 2 * nn, c + 3 * nn, multi ? oi_f : static_cast<const float*>(nullptr), 1, static_cast<int>(n1),
                             d, d + nn, d + 2 * nn, 1, kind};
-  hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n1 + threads - 1) / threads)), dim3(threads), 0,
-                     ctx->stream, a, launch.in_x, launch.in_y, launch.in_z, launch.in_t, launch.in_origin, 1, launch.n, d, d + nn,
-                     d + 2 * nn, 1, kind, d_flags, 0);
-  DLIOM_HIP_TRY(hipGetLastError());
-  // returns (kind 1), in hit order; misses (kind 2) are not used by the 3D path.  The compaction's read-back brings the
-  // last hit's pose and the de-skew's records along (one round trip, no memcpy)
-  std::vector<unsigned> host_flags(kDeskewFlagWords);
-  DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, num_returns, d_flags,
-                                 kDeskewFlagWords, host_flags.data()));
+  if (!merged) {
+    hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n1 + threads - 1) / threads)), dim3(threads), 0,
+                       ctx->stream, a, launch.in_x, launch.in_y, launch.in_z, launch.in_t, launch.in_origin, 1, launch.n, d, d + nn,
+                       d + 2 * nn, 1, kind, d_flags, 0, static_cast<const unsigned*>(nullptr));
+    DLIOM_HIP_TRY(hipGetLastError());
+    // returns (kind 1), in hit order; misses (kind 2) are not used by the 3D path.  The compaction's read-back brings the
+    // last hit's pose and the de-skew's records along (one round trip, no memcpy)
+    DLIOM_TRY(compact_equal_arrays(ctx, Soa{d, d + nn, d + 2 * nn, nullptr, n1}, kind, 1, e, e + nn, e + 2 * nn, num_returns, d_flags,
+                                   kDeskewFlagWords, host_flags.data()));
+  }
   bool fixed = false;
   DLIOM_TRY(verify_deskew(ctx, a, launch, host_flags.data(), d_flags, &fixed));
   if (fixed)  // hits were redone with the host's quaternion: compact (and read the pose) once more
@@ -796,7 +833,7 @@ extern "C" int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const dou
                             reinterpret_cast<unsigned char*>(base + kind_off)};
   hipLaunchKernelGGL(deskew_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, a, launch.in_x,
                      launch.in_y, launch.in_z, launch.in_t, launch.in_origin, 4, launch.n, launch.out_x, launch.out_y, launch.out_z, 3,
-                     launch.out_kind, d_flags, 0);
+                     launch.out_kind, d_flags, 0, static_cast<const unsigned*>(nullptr));
   DLIOM_HIP_TRY(hipGetLastError());
   std::vector<unsigned> host_flags(kDeskewFlagWords);
   DLIOM_HIP_TRY(hipMemcpyAsync(host_flags.data(), d_flags, 4 * kDeskewFlagWords, hipMemcpyDeviceToHost, ctx->stream));

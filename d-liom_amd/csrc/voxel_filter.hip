@@ -404,9 +404,11 @@ static int emit_cloud(dliom_ctx* ctx, const Soa& in, const VfScratch& s, const V
 __global__ __launch_bounds__(kVfBlock) void count_flags_kernel(const unsigned char* __restrict__ flags, unsigned n,
                                                                unsigned char want,
                                                                unsigned char* __restrict__ out_flags,
-                                                               unsigned* __restrict__ block_counts) {
+                                                               unsigned* __restrict__ block_counts,
+                                                               const unsigned* __restrict__ n_dev) {
   const unsigned i = blockIdx.x * kVfBlock + threadIdx.x;
-  const bool keep = i < n && flags[i] == want;
+  const unsigned live = n_dev != nullptr ? min(n, *n_dev) : n;  // entries behind `live` are not part of the input
+  const bool keep = i < live && flags[i] == want;
   if (i < n) out_flags[i] = keep ? 1 : 0;
   const int c = __syncthreads_count(keep ? 1 : 0);
   if (threadIdx.x == 0) block_counts[blockIdx.x] = static_cast<unsigned>(c);
@@ -471,7 +473,7 @@ int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kin
   const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
   // (the survivor count comes out of the compaction's last workgroup: until round 5 a memset and one atomic per workgroup)
   hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, kinds, n, want, s.flags,
-                     s.block_counts);
+                     s.block_counts, static_cast<const unsigned*>(nullptr));
   hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z,
                      static_cast<const float*>(nullptr), n, s.flags, s.block_counts, ox, oy, oz,
                      static_cast<float*>(nullptr), static_cast<unsigned*>(nullptr), static_cast<unsigned*>(nullptr), s.max_sq);
@@ -481,6 +483,23 @@ int compact_equal_arrays(dliom_ctx* ctx, const Soa& in, const unsigned char* kin
   DLIOM_TRY(gather_and_wait(ctx, jobs, also_src != nullptr && also_words > 0 ? 2 : 1, host));
   *n_out = host[0];
   if (also_src != nullptr && also_words > 0) std::memcpy(also_dst, host + 1, static_cast<size_t>(also_words) * 4);
+  return DLIOM_OK;
+}
+
+int compact_equal_arrays_enqueue(dliom_ctx* ctx, const Soa& in, const unsigned char* kinds, unsigned char want, float* ox,
+                                 float* oy, float* oz, const unsigned* n_dev, const unsigned** d_total) {
+  if (in.n <= 0 || n_dev == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  VfScratch s;
+  DLIOM_TRY(carve_scratch(ctx, in.n, 1, &s));  // (the layout voxel_filter_arrays_enqueue had: its count is s.max_sq[0])
+  if (n_dev != s.max_sq) return DLIOM_ERR_INVALID_ARGUMENT;
+  const unsigned n = static_cast<unsigned>(in.n);
+  const unsigned blocks = (n + kVfBlock - 1) / kVfBlock;
+  hipLaunchKernelGGL(count_flags_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, kinds, n, want, s.flags, s.block_counts, n_dev);
+  hipLaunchKernelGGL(voxel_compact_kernel, dim3(blocks), dim3(kVfBlock), 0, ctx->stream, in.x, in.y, in.z,
+                     static_cast<const float*>(nullptr), n, s.flags, s.block_counts, ox, oy, oz,
+                     static_cast<float*>(nullptr), static_cast<unsigned*>(nullptr), static_cast<unsigned*>(nullptr), s.max_sq + 1);
+  DLIOM_HIP_TRY(hipGetLastError());
+  *d_total = s.max_sq + 1;
   return DLIOM_OK;
 }
 

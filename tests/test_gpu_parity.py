@@ -812,6 +812,44 @@ def test_add_range_data_device_chain(dl, ctx, orc, beams, azimuths, k):
     cloud.close()
 
 
+@pytest.mark.gpu
+def test_add_range_data_one_read_back_per_stage_and_its_fallback(dl, ctx, orc):
+    """Round 5: dliom_add_range_data reads back once per stage -- the voxel filters are only enqueued (packed table
+    words) and the kernels behind them take the survivor counts from the device.  A range farther than 4095 filter edges
+    from the origin does not fit those words: the stage notices in the same read-back and repeats itself the general way
+    (counted).  Both against the oracle's AddRangeData restatement, bit for bit; an outlier in the raw scan only (stage A:
+    edge 0.075 m, beyond 307 m; it is gated away, so stage B stays on the fast path) and a gate wide enough to keep it
+    (stage B as well: edge 0.15 m, beyond 614 m)."""
+    prev, cur, ranges = _timed_scan(32, 512, k=9)
+    vfs, T = 0.15, 0.1
+    before = ctx.voxel_filter_reruns()
+    cloud, origin_d, cur_d = dl.add_range_data(ctx, prev, cur, T, ranges, (0, 0, 0), 1.0, 100.0, vfs)
+    ref = orc.deskew_and_filter(T, 1.0, 100.0, vfs, prev, cur, ranges)
+    assert np.array_equal(cloud.download().view(np.uint32), ref["returns_in_tracking"].astype(np.float32).view(np.uint32))
+    assert ctx.voxel_filter_reruns() == before
+    cloud.close()
+    for far, max_r, at_least in ((400.0, 100.0, 1), (700.0, 1000.0, 2)):
+        r2 = ranges.copy()
+        r2[len(r2) // 3, :3] = [far, 3.0, -2.0]
+        r2[len(r2) // 2, :3] = [-far, -1.0, 4.0]
+        b = ctx.voxel_filter_reruns()
+        cloud, origin_d, cur_d = dl.add_range_data(ctx, prev, cur, T, r2, (0, 0, 0), 1.0, max_r, vfs)
+        ref = orc.deskew_and_filter(T, 1.0, max_r, vfs, prev, cur, r2)
+        got = cloud.download()
+        assert got.shape == ref["returns_in_tracking"].shape, (far, got.shape)
+        assert np.array_equal(got.view(np.uint32), ref["returns_in_tracking"].astype(np.float32).view(np.uint32)), far
+        assert np.array_equal(origin_d, ref["origin_in_tracking"].astype(np.float32))
+        assert ctx.voxel_filter_reruns() - b >= at_least, (far, ctx.voxel_filter_reruns() - b)
+        cloud.close()
+    # ... and the next ordinary scan is back on the fast path with the right de-skew record accounting
+    checked = ctx.deskew_check_stats()
+    cloud, _, _ = dl.add_range_data(ctx, prev, cur, T, ranges, (0, 0, 0), 1.0, 100.0, vfs)
+    ref = orc.deskew_and_filter(T, 1.0, 100.0, vfs, prev, cur, ranges)
+    assert np.array_equal(cloud.download().view(np.uint32), ref["returns_in_tracking"].astype(np.float32).view(np.uint32))
+    assert ctx.deskew_check_stats()[1] == checked[1] and ctx.deskew_check_stats()[2] == checked[2]  # no overflow, nothing fixed
+    cloud.close()
+
+
 def test_fused_multi_grid_insertion(dl, ctx, orc):
     """dliom_inserter_insert_cloud_multi: four targets (two resolutions x two submap frames, one with
     a range filter) in one set of launches vs four oracle insertions; extent growth mid-sequence."""
