@@ -439,8 +439,8 @@ int dliom_adaptive_voxel_filter(const dliom_adaptive_voxel_filter_options* optio
  * max_range).  If |t_0| < 1e-3 every hit takes the predicted pose ("not de-skewing", :429-433).
  * current_pose (float, [t,q]) = the last hit's pose (:477).  Slerp coefficients use the device's
  * double-precision sin/acos, which may differ from glibc's in the last ulp of a DOUBLE; the per-hit pose is cast to
- * float right after (:446), which absorbs that unless a value lies within 2^-52 of a float rounding boundary -- the
- * tests assert bit equality with the oracle (0 of 65 129 hits differ on the 64x1024 scan), a proof it is not. */
+ * float right after (:446).  Every hit whose cast could change under that difference is re-examined on the host with
+ * glibc (dliom_deskew_check_stats below): the floats are the reference's by proof, per call. */
 int dliom_deskew(dliom_ctx* ctx, const double prev_pose[7], const double predicted_pose[7], double scan_period,
                  const float* hits_xyzt, int64_t n, const float origin[3], float min_range, float max_range,
                  float* out_xyz, uint8_t* out_kind, float current_pose[7]);
