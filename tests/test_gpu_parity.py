@@ -850,6 +850,24 @@ def test_add_range_data_one_read_back_per_stage_and_its_fallback(dl, ctx, orc):
     cloud.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 65, 257])
+def test_add_range_data_tiny_scans(dl, ctx, orc, n):
+    """The one-read-back stages run their kernels over the input's size with the counts on the device: scans of one,
+    two, three ranges and just over one wave / one workgroup of them, against the oracle, bit for bit."""
+    prev, cur, ranges = _timed_scan(16, 256, k=6)
+    r = np.ascontiguousarray(ranges[::max(1, len(ranges) // n)][:n])
+    assert len(r) == n
+    vfs, T = 0.15, 0.1
+    cloud, origin_d, cur_d = dl.add_range_data(ctx, prev, cur, T, r, (0, 0, 0), 1.0, 100.0, vfs)
+    ref = orc.deskew_and_filter(T, 1.0, 100.0, vfs, prev, cur, r)
+    got = cloud.download()
+    assert got.shape == ref["returns_in_tracking"].shape
+    assert np.array_equal(got.view(np.uint32), ref["returns_in_tracking"].astype(np.float32).view(np.uint32))
+    assert np.array_equal(origin_d, ref["origin_in_tracking"].astype(np.float32))
+    cloud.close()
+
+
 def test_fused_multi_grid_insertion(dl, ctx, orc):
     """dliom_inserter_insert_cloud_multi: four targets (two resolutions x two submap frames, one with
     a range filter) in one set of launches vs four oracle insertions; extent growth mid-sequence."""
