@@ -454,6 +454,7 @@ int gather_to_pinned(dliom_ctx* ctx, const GatherJob* jobs, int num_jobs, void* 
 }
 
 int wait_done(dliom_ctx* ctx, hipStream_t stream, const unsigned* done_word, unsigned done_seq, int max_poll_us) {
+  if (ctx != nullptr) ++ctx->read_backs;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n(done_word, __ATOMIC_ACQUIRE) == done_seq) return DLIOM_OK;
@@ -768,6 +769,12 @@ int dliom_ctx_device(const dliom_ctx* ctx) { return ctx == nullptr ? -1 : ctx->d
 int dliom_ctx_synchronize(dliom_ctx* ctx) {
   if (ctx == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DLIOM_OK;
+}
+
+int dliom_ctx_read_backs(const dliom_ctx* ctx, int64_t* count) {
+  if (ctx == nullptr || count == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  *count = ctx->read_backs;
   return DLIOM_OK;
 }
 

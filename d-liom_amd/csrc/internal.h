@@ -108,6 +108,7 @@ struct dliom_ctx {
   unsigned* done_word = nullptr;  // pinned, own allocation: completion word of the main stream's read-back kernels
   unsigned done_seq = 0;
   int64_t voxel_unpacked_reruns = 0;  // voxel filter launches repeated with 21-bit keys (dliom_ctx_voxel_filter_reruns)
+  int64_t read_backs = 0;         // wait_done() calls: polled host round trips on this context (dliom_ctx_read_backs)
   int64_t poll_fallbacks = 0;     // wait_done() calls that ran out of their polling time (dliom_ctx_poll_fallbacks)
   int num_cus = 256;              // of ctx->device (set at creation)
   unsigned func_attr_set = 0;     // kFuncAttr* bits: hipFuncSetAttribute done for this context's device

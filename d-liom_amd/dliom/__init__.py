@@ -306,6 +306,7 @@ SYMBOLS = [
                                        _i64p, C.POINTER(_vp), _f64p, _f64p, _f64p]),
     ("dliom_ctx_set_tuning", C.c_int, [_vp, C.c_int, C.c_int]),
     ("dliom_ctx_poll_fallbacks", C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    ("dliom_ctx_read_backs", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("dliom_ctx_voxel_filter_reruns", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("dliom_ctx_get_tuning", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("dliom_deskew_check_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -403,6 +404,12 @@ class Context:
         """dliom_ctx_voxel_filter_reruns: voxel filter launches repeated with 21-bit keys (a point beyond 4095 edges)."""
         n = C.c_int64(0)
         _check(self._L.dliom_ctx_voxel_filter_reruns(self.h, C.byref(n)), "voxel_filter_reruns")
+        return int(n.value)
+
+    def read_backs(self):
+        """dliom_ctx_read_backs: polled host round trips on this context so far."""
+        n = C.c_int64(0)
+        _check(self._L.dliom_ctx_read_backs(self.h, C.byref(n)), "read_backs")
         return int(n.value)
 
     def poll_fallbacks(self):

@@ -763,6 +763,9 @@ int dliom_ctx_get_tuning(const dliom_ctx* ctx, int knob, int* value);
  * read-back takes it legitimately; a count that grows with every call means the polling is not seeing the device's
  * writes (10x the latency, same results). */
 int dliom_ctx_poll_fallbacks(const dliom_ctx* ctx, int64_t* count);
+/* *count = polled read-backs on this context so far: the host round trips a caller's chain costs (a W-ref scan of the
+ * front end: 8, profiles/r5_wref_full.json `read_backs_per_scan`). */
+int dliom_ctx_read_backs(const dliom_ctx* ctx, int64_t* count);
 /* The device voxel filter (sensor/internal/voxel_filter.cc:81-131) keeps "voxel -> first point" in a hash table whose
  * entries pack the voxel index (13 bits per axis) and the point index (24 bits) into one word, so that a voxel costs
  * one atomic.  A cloud with a point farther than 4095 voxel edges from the origin (61 m at 1.5 cm) does not fit: the

@@ -184,8 +184,9 @@ def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, hist
         if device:  # the histogram's kernels run beside the insertion (both only read the filtered cloud): begin / finish
             dl.cloud_rotational_histogram_begin(ctx, cloud, histogram_size, rotation_wxyz=est[3:].astype(np.float32))
         ins = fe.insert(int(k * 1e6), est, est[3:])
-        if device:
-            ctx.synchronize()
+        # (no synchronisation here: like the C++ adapter -- histogram begin, InsertIntoSubmap, histogram finish -- the
+        # insertion's launches are only enqueued; the scan's cloud is released below, inside the timing, and releasing it
+        # waits for the device)
         t5 = time.perf_counter()
         hist = None
         inserted = bool(ins["inserted"]) if isinstance(ins, dict) else bool(ins)  # the oracle's insert returns the flag itself
@@ -199,9 +200,9 @@ def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, hist
             else:
                 rot = np.concatenate([np.zeros(3), est[3:]]).astype(np.float32)
                 hist = orc.compute_histogram(orc.transform_points(rot, ref["returns_in_tracking"]), histogram_size)
-        t6 = time.perf_counter()
         if device:
-            cloud.close()
+            cloud.close()  # inside the timing: handing the cloud's block back waits for the device (the scan's last launches)
+        t6 = time.perf_counter()
         state = np.concatenate([est, vel, bias])
         rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5))
         poses.append(est)
@@ -225,7 +226,9 @@ def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=20, beams=64, azimuths=102
     gc.collect()
     gc.disable()  # harness only: a full collection of CPython's cyclic collector is ~35 ms with torch imported
     try:
+        read_backs0 = ctx.read_backs()
         rows, poses, hists, g_factors = run_chain(dl, cfg, T, clouds, imus, state0, True, ctx=ctx)
+        read_backs = ctx.read_backs() - read_backs0
         dev_fed = {k: list(v) for k, v in LAST_RUN.items()}  # what the device leg's window was fed (for the shadow run)
     finally:
         gc.enable()
@@ -233,12 +236,14 @@ def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=20, beams=64, azimuths=102
     out = {"options": name, "scene": scene, "returns_per_scan": int(np.mean([len(c) for c in clouds])),
            "workload": "W-ref complete chain (%s): %dx%d motion-distorted scans at 10 Hz + 200 Hz IMU: AddImuData, AddRangeData, "
                        "adaptive filters + %sCeres, WindowOptimize%s, InsertIntoSubmap, ComputeHistogram; raw scans cross "
-                       "PCIe inside AddRangeData" % (name, beams, azimuths,
+                       "PCIe inside AddRangeData; the C++ adapter's call sequence (histogram begin, insertion, histogram "
+                       "finish, the scan's cloud released -- which waits for the device -- all inside the timing)" % (name, beams, azimuths,
                                                      "RTCSM3D + " if cfg["front_end"]["use_online_correlative_scan_matching"] else "",
                                                      " with gravity factor" if cfg["window"].get("enable_gravity_factor") else ""),
            "scans_per_s": 1.0 / float(np.mean(rows.sum(axis=1))),
            "p50_ms": dict({s: 1e3 * float(np.median(rows[:, i])) for i, s in enumerate(STAGES)},
                           total=1e3 * float(np.median(rows.sum(axis=1)))),
+           "read_backs_per_scan": read_backs / float(len(rows) + warmup),  # polled host round trips (dliom_ctx_read_backs)
            "gravity_factors_added": int(g_factors), "scans": int(len(rows))}
     if cpu:
         from oracle import oracle as orc
