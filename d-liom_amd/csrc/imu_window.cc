@@ -45,6 +45,7 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <vector>
 
 #include "../../include/dliom.h"
@@ -412,7 +413,7 @@ void corrected(const Preint& P, V3 ba, V3 bg, M3* dR, V3* dp, V3* dv, V3* theta 
   *dv = P.dv + P.dv_dba * da + P.dv_dbg * dg;
 }
 
-// ---- small dense linear algebra (symmetric positive definite, n <= 15 * 16)
+// ---- small dense linear algebra (symmetric positive definite; the window's own solver is the chain solver below)
 bool cholesky(std::vector<double>& a, int n) {  // in place, lower
   for (int j = 0; j < n; ++j) {
     double d = a[j * n + j];
@@ -427,46 +428,6 @@ bool cholesky(std::vector<double>& a, int n) {  // in place, lower
     }
   }
   return true;
-}
-// The window's normal equations are block tridiagonal (every factor touches one state or two neighbours; the
-// marginal prior sits on the first block), and so is their Cholesky factor: the same loops as cholesky() /
-// chol_solve() restricted to the entries that can be non-zero -- the skipped terms are exact zeros.
-// (block tridiagonal: row i holds columns from the block in front of its own on.)  Right-looking: column j is
-// finished, then subtracted from the rows of its own block and the next -- every element receives the products of the
-// dot-product form in the same order (k ascending), so the factor is the same to the bit, but the inner loop runs along
-// a row with no sum to carry and the compiler vectorises it: 10.7 us -> 6.5 us for a window of four states (n = 60),
-// twice per scan.
-bool cholesky_chain(std::vector<double>& a, int n, int block) {
-  double col[64];
-  if (2 * block > 64) return false;
-  for (int j = 0; j < n; ++j) {
-    double d = a[j * n + j];
-    if (!(d > 0.0)) return false;
-    d = std::sqrt(d);
-    a[j * n + j] = d;
-    const int i_end = std::min(n, (j / block + 2) * block);  // rows of this block and the next
-    for (int i = j + 1; i < i_end; ++i) col[i - j - 1] = a[i * n + j] = a[i * n + j] / d;
-    for (int i = j + 1; i < i_end; ++i) {
-      const double lij = col[i - j - 1];
-      double* row = &a[i * n + j + 1];
-      const int m = i - j;
-      for (int c = 0; c < m; ++c) row[c] -= lij * col[c];
-    }
-    for (int i = i_end; i < n; ++i) a[i * n + j] = 0.0;
-  }
-  return true;
-}
-void chol_solve_chain(const std::vector<double>& l, int n, int block, double* b) {
-  for (int i = 0; i < n; ++i) {
-    double s = b[i];
-    for (int k = std::max(0, (i / block - 1) * block); k < i; ++k) s -= l[i * n + k] * b[k];
-    b[i] = s / l[i * n + i];
-  }
-  for (int i = n - 1; i >= 0; --i) {
-    double s = b[i];
-    for (int k = i + 1; k < std::min(n, (i / block + 2) * block); ++k) s -= l[k * n + i] * b[k];
-    b[i] = s / l[i * n + i];
-  }
 }
 void chol_solve(const std::vector<double>& l, int n, double* b) {
   for (int i = 0; i < n; ++i) {
@@ -626,6 +587,28 @@ struct dliom_imu_window {
   bool initialized = false;
   int64_t num_states = 0;
   int key = 0;  // key_ of the next state: 1 after initialisation, 1 again after a graph reset (:792)
+  // ---- the chain solver (round 6).  x[i] is the LINEARISATION POINT of state i (ISAM2's theta_), delta its solved
+  // increment (delta_); the estimate is retract(x[i], delta[i]) (calculateEstimate()).  The fixed-lag mode folds delta
+  // into x after every solve (plain Gauss-Newton); the reference-rule mode (window_size == 0) moves a linearisation
+  // point only when its increment exceeds options.relinearize_threshold, like ISAM2 (:676-679), so the elimination of
+  // the older part of the chain is reused from scan to scan.
+  struct ChainFactor {  // ImuFactor + bias BetweenFactor between states i and i + 1, linearised at (x[i], x[i + 1])
+    double Linv[81];    // whitening of the preintegrated covariance: fixed when the factor is created
+    double A[225], B[225], C[225];  // Ja^T Ja, Jb^T Ja (rows: state i + 1, columns: state i), Jb^T Jb
+    double ga[15], gb[15];          // Ja^T r, Jb^T r
+    bool stale = true;
+  };
+  struct ChainBlock {   // block Cholesky of the block-tridiagonal normal equations, state i
+    double L[225];      // S_i = D_i - W_{i-1} W_{i-1}^T = L L^T
+    double W[225];      // B_i L^-T: what state i + 1's rows hold in state i's columns of the factor
+    double y[15];       // forward-substituted right-hand side
+  };
+  std::vector<double> delta;       // 15 per state
+  std::vector<ChainFactor> fac;    // fac[i]: between[i]
+  std::vector<ChainBlock> blk;     // per state
+  int clean_until = 0;             // states [0, clean_until) are eliminated with the factors as they are now
+  bool full_graph() const { return o.window_size == 0; }
+  int64_t relinearizations = 0, blocks_eliminated = 0;  // dliom_imu_window_solver_stats
 };
 
 namespace {
@@ -950,56 +933,223 @@ void accumulate_pose_prior(int ia, const double* r0, const double* J /* 6 x 15 *
     }
 }
 
-// Normal equations of every factor in the window at the current estimate.
-bool build(dliom_imu_window& w, std::vector<double>& H, std::vector<double>& g) {
-  const int N = static_cast<int>(w.x.size()), n = N * kD;
-  H.assign(static_cast<size_t>(n) * n, 0.0);
-  g.assign(n, 0.0);
-  // prior on x[0]
-  double d0[kD];
-  local(w.lin0, w.x[0], d0);
-  for (int i = 0; i < kD; ++i) {
-    double s = w.b0[i];
-    for (int j = 0; j < kD; ++j) {
-      s += w.H0[kD * i + j] * d0[j];
-      H[static_cast<size_t>(i) * n + j] += w.H0[kD * i + j];
+// ---- the chain solver -------------------------------------------------------------------------------------------------
+// The window's normal equations are block tridiagonal (every factor touches one state or two neighbours; the prior sits on
+// the first block): block Cholesky from the oldest state on, S_i = D_i - W_{i-1} W_{i-1}^T = L_i L_i^T, W_i = B_i L_i^-T,
+// y_i = L_i^-1 (-g_i - W_{i-1} y_{i-1}), then delta from the newest state back.  What a state's elimination needs from
+// the older part of the chain is (W_{i-1}, y_{i-1}) only, so a new key, a factor on a recent state or a moved
+// linearisation point re-eliminates the chain from there on and nothing before it: linear in the window for a full
+// Gauss-Newton step, a handful of blocks per scan for the reference's rule.
+#ifdef DLIOM_TEST_HOOKS
+int dliom_test_fail_chain = 0;  // tests/cpp/imu_window_marginalize_fail.cc: the next elimination fails
+#endif
+
+State estimate_at(const dliom_imu_window& w, size_t i) { return retract(w.x[i], &w.delta[kD * i]); }
+
+bool chol15(double* a) {  // in place, lower, row major 15 x 15
+  for (int j = 0; j < kD; ++j) {
+    double d = a[kD * j + j];
+    for (int k = 0; k < j; ++k) d -= a[kD * j + k] * a[kD * j + k];
+    if (!(d > 0)) return false;
+    d = std::sqrt(d);
+    a[kD * j + j] = d;
+    for (int i = j + 1; i < kD; ++i) {
+      double t = a[kD * i + j];
+      for (int k = 0; k < j; ++k) t -= a[kD * i + k] * a[kD * j + k];
+      a[kD * i + j] = t / d;
     }
-    g[i] += s;
-  }
-  for (int i = 0; i + 1 < N; ++i) {
-    std::vector<double> Linv;
-    if (!whitening(w.between[i], &Linv)) return false;
-    const Preint& P = w.between[i];
-    double r[15], J[15 * 30];
-    imu_factor_jacobian(w, P, Linv, w.x[i], w.x[i + 1], r, J);
-    accumulate_imu_factor(i, r, J, H, g, n);
-  }
-  for (const auto& f : w.pose_priors) {
-    double r[6], J[6 * kD];
-    pose_prior_jacobian(f, w.x[f.index], r, J);
-    accumulate_pose_prior(f.index, r, J, H, g, n);
-  }
-  for (const auto& f : w.gravity) {
-    double r[2], J[2 * kD];
-    gravity_residual(f, w.x[f.index], r, J);
-    add_factor_with_jacobian(f.index, 2, r, J, H, g, n);
   }
   return true;
 }
-
-bool gauss_newton(dliom_imu_window& w, int iterations) {
-  const int N = static_cast<int>(w.x.size()), n = N * kD;
-  std::vector<double> H, g;
-  for (int it = 0; it < iterations; ++it) {
-    if (!build(w, H, g)) return false;
-    std::vector<double> L = H;
-    for (int i = 0; i < n; ++i) L[static_cast<size_t>(i) * n + i] += 1e-12;
-    if (!cholesky_chain(L, n, kD)) return false;
-    std::vector<double> d(g);
-    for (double& v : d) v = -v;
-    chol_solve_chain(L, n, kD, d.data());
-    for (int i = 0; i < N; ++i) w.x[i] = retract(w.x[i], d.data() + i * kD);
+inline void lower_solve15(const double* L, double* b) {  // b <- L^-1 b
+  for (int i = 0; i < kD; ++i) {
+    double t = b[i];
+    for (int k = 0; k < i; ++k) t -= L[kD * i + k] * b[k];
+    b[i] = t / L[kD * i + i];
   }
+}
+inline void upper_solve15(const double* L, double* b) {  // b <- L^-T b
+  for (int i = kD - 1; i >= 0; --i) {
+    double t = b[i];
+    for (int k = i + 1; k < kD; ++k) t -= L[kD * k + i] * b[k];
+    b[i] = t / L[kD * i + i];
+  }
+}
+
+void chain_mark(dliom_imu_window& w, int state) {  // something on `state` changed: its block and everything after it
+  w.clean_until = std::min(w.clean_until, std::max(0, state));
+}
+
+// A new key: its increment, its factor to the state in front of it (whitening computed once), its block.
+bool chain_push_state(dliom_imu_window& w) {
+  const int N = static_cast<int>(w.x.size());
+  w.delta.resize(static_cast<size_t>(N) * kD, 0.0);
+  w.blk.resize(static_cast<size_t>(N));
+  if (N >= 2 && static_cast<int>(w.fac.size()) < N - 1) {
+    std::vector<double> Linv;
+    if (!whitening(w.between[static_cast<size_t>(N) - 2], &Linv)) return false;
+    dliom_imu_window::ChainFactor f;
+    std::memcpy(f.Linv, Linv.data(), sizeof f.Linv);
+    f.stale = true;
+    w.fac.push_back(f);
+    chain_mark(w, N - 2);  // the older state's diagonal block gains Ja^T Ja
+  }
+  chain_mark(w, N - 1);
+  return true;
+}
+
+// theta <- theta (+) delta for the states whose increment exceeds the threshold (ISAM2's relinearisation; threshold 0:
+// every state that moved at all = plain Gauss-Newton).  A moved point makes both of its IMU factors stale.
+void chain_relinearize(dliom_imu_window& w, double threshold) {
+  const int N = static_cast<int>(w.x.size());
+  for (int i = 0; i < N; ++i) {
+    double* d = &w.delta[static_cast<size_t>(kD) * i];
+    double m = 0.0;
+    for (int c = 0; c < kD; ++c) m = std::max(m, std::fabs(d[c]));
+    if (!(m > threshold)) continue;
+    w.x[i] = retract(w.x[i], d);
+    std::fill(d, d + kD, 0.0);
+    if (i > 0) w.fac[static_cast<size_t>(i) - 1].stale = true;
+    if (i + 1 < N) w.fac[static_cast<size_t>(i)].stale = true;
+    chain_mark(w, i - 1);
+    ++w.relinearizations;
+  }
+}
+
+// Forward elimination of the states [clean_until, N).
+bool chain_eliminate(dliom_imu_window& w) {
+  const int N = static_cast<int>(w.x.size());
+#ifdef DLIOM_TEST_HOOKS
+  if (dliom_test_fail_chain != 0) return false;
+#endif
+  std::vector<double> H(30 * 30), g(30), D(kD * kD), gd(kD);
+  for (int i = w.clean_until; i < N; ++i) {
+    // the factor in front of state i is fresh (state i - 1 was eliminated with it, or chain_relinearize / chain_push_state
+    // would have marked i - 1); the factor behind it may be stale
+    if (i + 1 < N && w.fac[i].stale) {
+      dliom_imu_window::ChainFactor& f = w.fac[i];
+      const std::vector<double> Linv(f.Linv, f.Linv + 81);
+      double r[15], J[15 * 30];
+      imu_factor_jacobian(w, w.between[i], Linv, w.x[i], w.x[i + 1], r, J);
+      std::fill(H.begin(), H.end(), 0.0);
+      std::fill(g.begin(), g.end(), 0.0);
+      accumulate_imu_factor(0, r, J, H, g, 30);
+      for (int a = 0; a < kD; ++a) {
+        for (int b = 0; b < kD; ++b) {
+          f.A[kD * a + b] = H[30 * a + b];
+          f.B[kD * a + b] = H[30 * (kD + a) + b];
+          f.C[kD * a + b] = H[30 * (kD + a) + kD + b];
+        }
+        f.ga[a] = g[a];
+        f.gb[a] = g[kD + a];
+      }
+      f.stale = false;
+    }
+    // D_i, g_i: the factors on state i alone, the prior (state 0), the two IMU factors' shares
+    std::fill(D.begin(), D.end(), 0.0);
+    std::fill(gd.begin(), gd.end(), 0.0);
+    if (i == 0) {
+      double d0[kD];
+      local(w.lin0, w.x[0], d0);
+      for (int a = 0; a < kD; ++a) {
+        double t = w.b0[a];
+        for (int b = 0; b < kD; ++b) {
+          t += w.H0[kD * a + b] * d0[b];
+          D[kD * a + b] += w.H0[kD * a + b];
+        }
+        gd[a] += t;
+      }
+    }
+    for (const auto& f : w.pose_priors)
+      if (f.index == i) {
+        double r[6], J[6 * kD];
+        pose_prior_jacobian(f, w.x[i], r, J);
+        accumulate_pose_prior(0, r, J, D, gd, kD);
+      }
+    for (const auto& f : w.gravity)
+      if (f.index == i) {
+        double r[2], J[2 * kD];
+        gravity_residual(f, w.x[i], r, J);
+        add_factor_with_jacobian(0, 2, r, J, D, gd, kD);
+      }
+    if (i > 0) {
+      const dliom_imu_window::ChainFactor& f = w.fac[static_cast<size_t>(i) - 1];
+      for (int a = 0; a < kD * kD; ++a) D[a] += f.C[a];
+      for (int a = 0; a < kD; ++a) gd[a] += f.gb[a];
+    }
+    if (i + 1 < N) {
+      const dliom_imu_window::ChainFactor& f = w.fac[i];
+      for (int a = 0; a < kD * kD; ++a) D[a] += f.A[a];
+      for (int a = 0; a < kD; ++a) gd[a] += f.ga[a];
+    }
+    dliom_imu_window::ChainBlock& b = w.blk[i];
+    double rhs[kD];
+    for (int a = 0; a < kD; ++a) rhs[a] = -gd[a];
+    if (i > 0) {
+      const dliom_imu_window::ChainBlock& p = w.blk[static_cast<size_t>(i) - 1];
+      for (int a = 0; a < kD; ++a) {
+        double t = 0.0;
+        for (int k = 0; k < kD; ++k) t += p.W[kD * a + k] * p.y[k];
+        rhs[a] -= t;
+        for (int c = 0; c <= a; ++c) {
+          double u = 0.0;
+          for (int k = 0; k < kD; ++k) u += p.W[kD * a + k] * p.W[kD * c + k];
+          D[kD * a + c] -= u;
+        }
+      }
+    }
+    for (int a = 0; a < kD; ++a) D[kD * a + a] += 1e-12;
+    std::memcpy(b.L, D.data(), sizeof b.L);  // the lower triangle is what chol15 reads
+    if (!chol15(b.L)) return false;
+    lower_solve15(b.L, rhs);
+    std::memcpy(b.y, rhs, sizeof b.y);
+    if (i + 1 < N) {  // W L^T = B: every row of B by forward substitution
+      const double* B = w.fac[i].B;
+      for (int a = 0; a < kD; ++a) {
+        double row[kD];
+        std::memcpy(row, B + kD * a, sizeof row);
+        lower_solve15(b.L, row);
+        std::memcpy(b.W + kD * a, row, sizeof row);
+      }
+    }
+    ++w.blocks_eliminated;
+  }
+  w.clean_until = N;
+  return true;
+}
+
+bool chain_back_substitute(dliom_imu_window& w) {  // false: an increment is not finite (a NaN in a residual)
+  const int N = static_cast<int>(w.x.size());
+  bool finite = true;
+  for (int i = N - 1; i >= 0; --i) {
+    const dliom_imu_window::ChainBlock& b = w.blk[i];
+    double t[kD];
+    std::memcpy(t, b.y, sizeof t);
+    if (i + 1 < N) {
+      const double* dn = &w.delta[static_cast<size_t>(kD) * (i + 1)];
+      for (int c = 0; c < kD; ++c) {
+        double u = 0.0;
+        for (int a = 0; a < kD; ++a) u += b.W[kD * a + c] * dn[a];
+        t[c] -= u;
+      }
+    }
+    upper_solve15(b.L, t);
+    for (int c = 0; c < kD; ++c) finite = finite && std::isfinite(t[c]);
+    std::memcpy(&w.delta[static_cast<size_t>(kD) * i], t, sizeof t);
+  }
+  return finite;
+}
+
+// `iterations` x ISAM2::update(): move the linearisation points that have to move, re-eliminate what changed, solve.
+// Fixed-lag mode: every point moves every time (Gauss-Newton) and the last increment is folded into the states.
+bool gauss_newton(dliom_imu_window& w, int iterations) {
+  const double threshold = w.full_graph() ? w.o.relinearize_threshold : 0.0;
+  for (int it = 0; it < iterations; ++it) {
+    chain_relinearize(w, threshold);
+    if (w.clean_until >= static_cast<int>(w.x.size())) continue;  // nothing changed: the increments stand
+    if (!chain_eliminate(w) || !chain_back_substitute(w)) return false;
+  }
+  if (!w.full_graph()) chain_relinearize(w, 0.0);
   return true;
 }
 
@@ -1077,6 +1227,10 @@ bool marginalize_oldest(dliom_imu_window& w) {
   w.lin0 = w.x[1];
   w.x.erase(w.x.begin());
   w.between.erase(w.between.begin());
+  w.delta.erase(w.delta.begin(), w.delta.begin() + kD);  // folded into x by gauss_newton (fixed-lag mode): zeros
+  w.fac.erase(w.fac.begin());
+  w.blk.erase(w.blk.begin());
+  w.clean_until = 0;  // the new first state carries the marginal prior now
   std::vector<dliom_imu_window::PosePrior> pp;
   for (auto f : w.pose_priors)
     if (f.index > 0) {
@@ -1214,18 +1368,25 @@ int dliom_imu_window_default_options(dliom_imu_window_options* o) {
   o->lidar_in_imu_translation[0] = o->lidar_in_imu_translation[1] = o->lidar_in_imu_translation[2] = 0.0;
   o->graph_reset_every = 0;
   o->tangent_preintegration = 1;  // what the reference's GTSAM 4.0.2 build integrates (README.MD:13-15: no flag, default ON)
+  o->relinearize_threshold = 0.1;  // ISAM2Params::relinearizeThreshold, :676-679 (reference-rule mode only)
   return DLIOM_OK;
 }
 
 int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out) {
-  if (options == nullptr || out == nullptr || options->window_size < 2 || options->window_size > 16 ||
+  // window_size: 0 = the reference's rule (every key kept until the graph reset, which then has to exist) or a fixed lag
+  // of 2 .. 4096 states (the chain solver is linear in it)
+  const bool window_ok = options != nullptr && ((options->window_size == 0 && options->graph_reset_every >= 2 &&
+                                                 options->relinearize_threshold >= 0.0 && options->relinearize_threshold < 1e300) ||
+                                                (options->window_size >= 2 && options->window_size <= 4096));
+  if (options == nullptr || out == nullptr || !window_ok ||
       options->iterations < 1 || !(options->acc_noise > 0) || !(options->gyr_noise > 0) || !(options->acc_bias_noise > 0) ||
       !(options->gyr_bias_noise > 0) || options->graph_reset_every < 0 || options->graph_reset_every == 1 ||
       (options->tangent_preintegration != 0 && options->tangent_preintegration != 1))  // a struct filled without
     return DLIOM_ERR_INVALID_ARGUMENT;  // dliom_imu_window_default_options leaves the (round 4) trailing field indeterminate
   // the gravity factor goes on the state frames_for_online_gravity_estimate keys back (:828): it has to be in the window
   if (options->enable_gravity_factor != 0 &&
-      (options->frames_for_online_gravity_estimate < 2 || options->window_size < options->frames_for_online_gravity_estimate + 1))
+      (options->frames_for_online_gravity_estimate < 2 ||
+       (options->window_size != 0 && options->window_size < options->frames_for_online_gravity_estimate + 1)))
     return DLIOM_ERR_INVALID_ARGUMENT;
   dliom_imu_window* w = new dliom_imu_window;
   w->o = *options;
@@ -1262,6 +1423,10 @@ int dliom_imu_window_initialize(dliom_imu_window* w, const double pose7[7], cons
   for (int i = 6; i < 9; ++i) w->H0[kD * i + i] = 1.0 / (sv * sv);
   for (int i = 9; i < 15; ++i) w->H0[kD * i + i] = 1.0 / (sb * sb);
   w->lin0 = s;
+  w->delta.assign(kD, 0.0);
+  w->fac.clear();
+  w->blk.assign(1, dliom_imu_window::ChainBlock());
+  w->clean_until = 0;
   w->current.reset(s.ba, s.bg);
   w->initialized = true;
   w->num_states = 1;
@@ -1285,7 +1450,7 @@ int dliom_imu_window_add_imu_batch(dliom_imu_window* w, int n, const double* acc
 
 int dliom_imu_window_predict(const dliom_imu_window* w, double pose7[7], double velocity[3]) {
   if (w == nullptr || !w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
-  write_state(predicted(*w, w->x.back(), w->current), pose7, velocity, nullptr);
+  write_state(predicted(*w, estimate_at(*w, w->x.size() - 1), w->current), pose7, velocity, nullptr);
   return DLIOM_OK;
 }
 
@@ -1301,6 +1466,7 @@ int dliom_imu_window_add_gravity(dliom_imu_window* w, int states_back, const dou
   f.bRef = {0, 0, -1};  // g_ref_B, :780,825
   f.sigma = w->o.prior_gravity_noise;
   w->gravity.push_back(f);
+  chain_mark(*w, f.index);
   return DLIOM_OK;
 }
 
@@ -1313,18 +1479,19 @@ namespace {
 // this (its marginal prior keeps the full 15 x 15 block); it is here so that the estimates follow the reference's
 // through its resets: tests/test_imu_window.py compares a 70-scan run against a batch solver with the same rule.
 bool reset_graph(dliom_imu_window& w) {
-  const int N = static_cast<int>(w.x.size()), n = N * kD;
-  std::vector<double> H, g;
-  if (!build(w, H, g)) return false;
-  for (int i = 0; i < n; ++i) H[static_cast<size_t>(i) * n + i] += 1e-12;
-  if (!cholesky_chain(H, n, kD)) return false;
-  double cov[kD][kD];  // marginal covariance of the newest state: the last block of H^-1
+  // marginal covariance of the newest state = inverse of the last block of the chain's factor, taken at the
+  // linearisation points like ISAM2::marginalCovariance (fixed-lag mode: they are the estimates)
+  if (w.clean_until < static_cast<int>(w.x.size()) && !chain_eliminate(w)) return false;
+  const double* L = w.blk.back().L;
+  double cov[kD][kD];
   for (int c = 0; c < kD; ++c) {
-    std::vector<double> e(n, 0.0);
-    e[n - kD + c] = 1.0;
-    chol_solve_chain(H, n, kD, e.data());
-    for (int r = 0; r < kD; ++r) cov[r][c] = e[n - kD + r];
+    double e[kD] = {0};
+    e[c] = 1.0;
+    lower_solve15(L, e);
+    upper_solve15(L, e);
+    for (int r = 0; r < kD; ++r) cov[r][c] = e[r];
   }
+  const State newest = estimate_at(w, w.x.size() - 1);  // prev_pose_ / prev_vel_ / prev_bias_
   std::fill(w.H0, w.H0 + kD * kD, 0.0);
   std::fill(w.b0, w.b0 + kD, 0.0);
   const int first[3] = {0, 6, 9}, size[3] = {6, 3, 6};  // updatedPoseNoise, updatedVelNoise, updatedBiasNoise
@@ -1343,14 +1510,56 @@ bool reset_graph(dliom_imu_window& w) {
   }
   for (int i = 0; i < kD; ++i)
     for (int j = i + 1; j < kD; ++j) w.H0[kD * i + j] = w.H0[kD * j + i] = 0.5 * (w.H0[kD * i + j] + w.H0[kD * j + i]);
-  const State newest = w.x.back();
   w.lin0 = newest;
   w.x.assign(1, newest);
   w.between.clear();
   w.pose_priors.clear();
   w.gravity.clear();
+  w.delta.assign(kD, 0.0);
+  w.fac.clear();
+  w.blk.assign(1, dliom_imu_window::ChainBlock());
+  w.clean_until = 0;
   w.key = 1;
   return true;
+}
+}  // namespace
+
+namespace {
+// What a failed add_pose has to put back.  The fixed-lag window is small: a copy of it.  The reference-rule graph holds
+// up to num_range_data keys with their eliminations (~10 KB a key): copied only on the scan of a graph reset; otherwise
+// the call's own additions are taken back by hand (a linearisation point that moved in the failed call stays where it is
+// with a zero increment -- the same estimate -- and the chain is re-eliminated from the oldest state by the next call).
+struct AddPoseUndo {
+  std::unique_ptr<dliom_imu_window> copy;
+  size_t states = 0, priors = 0, gravity = 0;
+  std::vector<double> delta;
+  std::deque<GFrame> g_frames;
+  std::deque<V3> g_vs;
+  V3 g_est_G{0, 0, 0};
+  bool g_est_valid = false;
+  int64_t relinearizations = 0;
+  std::vector<State> x;  // linearisation points (15 doubles a key: cheap next to the eliminations)
+};
+void take_back(dliom_imu_window& w, AddPoseUndo& u) {
+  if (u.copy) {
+    w = *u.copy;
+    return;
+  }
+  w.x.resize(u.states);
+  w.between.resize(u.states - 1);
+  w.fac.resize(u.states - 1);
+  w.blk.resize(u.states);
+  w.pose_priors.resize(u.priors);
+  w.gravity.resize(u.gravity);
+  w.x = u.x;
+  w.delta = u.delta;
+  for (auto& f : w.fac) f.stale = true;
+  w.clean_until = 0;
+  w.g_frames.swap(u.g_frames);
+  w.g_vs.swap(u.g_vs);
+  w.g_est_G = u.g_est_G;
+  w.g_est_valid = u.g_est_valid;
+  w.relinearizations = u.relinearizations;
 }
 }  // namespace
 
@@ -1360,12 +1569,27 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
                               double velocity[3], double bias6[6]) {
   if (w == nullptr || matched_pose7 == nullptr || !w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
   if (!(w->current.dt > 0)) return DLIOM_ERR_INVALID_ARGUMENT;  // no IMU since the last pose
-  const dliom_imu_window saved = *w;  // a failed solve leaves the window exactly as it was
+  const bool reset_due = w->o.graph_reset_every > 0 && w->key == w->o.graph_reset_every;
+  AddPoseUndo undo;  // a failed solve leaves the window exactly as it was
+  if (!w->full_graph() || reset_due) {
+    undo.copy.reset(new dliom_imu_window(*w));
+  } else {
+    undo.states = w->x.size();
+    undo.priors = w->pose_priors.size();
+    undo.gravity = w->gravity.size();
+    undo.delta = w->delta;
+    undo.x = w->x;
+    undo.g_frames = w->g_frames;
+    undo.g_vs = w->g_vs;
+    undo.g_est_G = w->g_est_G;
+    undo.g_est_valid = w->g_est_valid;
+    undo.relinearizations = w->relinearizations;
+  }
   // prev_state_: the reference predicts from the estimate it read after the previous scan, also across a reset
-  const State prev = w->x.back();
-  if (w->o.graph_reset_every > 0 && w->key == w->o.graph_reset_every) {
+  const State prev = estimate_at(*w, w->x.size() - 1);
+  if (reset_due) {
     if (!reset_graph(*w)) {
-      *w = saved;
+      take_back(*w, undo);
       return DLIOM_ERR_SOLVER;
     }
     if (w->o.enable_gravity_factor != 0) {  // :772-782: EstimateGravity() here too (its deques get this frame twice)
@@ -1379,7 +1603,7 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
         w->gravity.push_back(gf);
         ++w->gravity_factors;
         if (!gauss_newton(*w, 1)) {  // "optimize once" (:788)
-          *w = saved;
+          take_back(*w, undo);
           return DLIOM_ERR_SOLVER;
         }
       }
@@ -1391,6 +1615,10 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
   next.bg = prev.bg;
   w->x.push_back(next);
   w->between.push_back(w->current);
+  if (!chain_push_state(*w)) {
+    take_back(*w, undo);
+    return DLIOM_ERR_SOLVER;
+  }
   dliom_imu_window::PosePrior f;
   f.index = static_cast<int>(w->x.size()) - 1;
   f.R = quat_to_matrix(matched_pose7 + 3);
@@ -1412,6 +1640,7 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
       gf.bRef = {0, 0, -1};
       gf.sigma = w->o.prior_gravity_noise;
       w->gravity.push_back(gf);
+      chain_mark(*w, gf.index);
       gravity_added = true;
     }
   }
@@ -1419,16 +1648,17 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
     // nothing of this scan stays: the new key, its factors, the estimator's entry and a graph reset are taken back and
     // the running preintegration is kept, so that the caller may try again (or re-initialise) without IMU samples
     // counted twice
-    *w = saved;
+    take_back(*w, undo);
     return DLIOM_ERR_SOLVER;
   }
   if (gravity_added) ++w->gravity_factors;
-  while (static_cast<int>(w->x.size()) > w->o.window_size)
-    if (!marginalize_oldest(*w)) {  // a failed Schur complement is a failed solve: nothing of this scan stays either
-      *w = saved;
-      return DLIOM_ERR_SOLVER;
-    }
-  const State& s = w->x.back();
+  if (!w->full_graph())
+    while (static_cast<int>(w->x.size()) > w->o.window_size)
+      if (!marginalize_oldest(*w)) {  // a failed Schur complement is a failed solve: nothing of this scan stays either
+        take_back(*w, undo);
+        return DLIOM_ERR_SOLVER;
+      }
+  const State s = estimate_at(*w, w->x.size() - 1);
   w->current.reset(s.ba, s.bg);  // resetIntegrationAndSetBias(prev_bias_), :852
   ++w->num_states;
   ++w->key;
@@ -1437,6 +1667,13 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
     w->initialized = false;                                          // ResetParams(): the caller re-initialises
     return DLIOM_ERR_DIVERGED;
   }
+  return DLIOM_OK;
+}
+
+int dliom_imu_window_solver_stats(const dliom_imu_window* w, int64_t* relinearizations, int64_t* blocks_eliminated) {
+  if (w == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (relinearizations != nullptr) *relinearizations = w->relinearizations;
+  if (blocks_eliminated != nullptr) *blocks_eliminated = w->blocks_eliminated;
   return DLIOM_OK;
 }
 
@@ -1470,7 +1707,7 @@ int dliom_diag_imu_factor_jacobians(dliom_imu_window* w, double* analytic, doubl
 int dliom_imu_window_state(const dliom_imu_window* w, int states_back, double pose7[7], double velocity[3], double bias6[6]) {
   if (w == nullptr || !w->initialized || states_back < 0 || states_back >= static_cast<int>(w->x.size()))
     return DLIOM_ERR_INVALID_ARGUMENT;
-  write_state(w->x[w->x.size() - 1 - states_back], pose7, velocity, bias6);
+  write_state(estimate_at(*w, w->x.size() - 1 - states_back), pose7, velocity, bias6);
   return DLIOM_OK;
 }
 

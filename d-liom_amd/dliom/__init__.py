@@ -145,7 +145,7 @@ class ImuWindowOptions(C.Structure):
         "ceres_pose_noise_r_drift", "prior_gravity_noise")] + [
             ("window_size", C.c_int), ("iterations", C.c_int), ("enable_gravity_factor", C.c_int),
             ("frames_for_online_gravity_estimate", C.c_int), ("lidar_in_imu_translation", C.c_double * 3),
-            ("graph_reset_every", C.c_int), ("tangent_preintegration", C.c_int)]
+            ("graph_reset_every", C.c_int), ("tangent_preintegration", C.c_int), ("relinearize_threshold", C.c_double)]
 
 
 class ImuPreintegration(C.Structure):
@@ -1446,6 +1446,13 @@ class ImuWindow:
 
     def __len__(self):
         return int(self._L.dliom_imu_window_size(self.h))
+
+    def solver_stats(self):
+        """(linearisation points moved, chain blocks eliminated) so far."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._L.dliom_imu_window_solver_stats.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        _check(self._L.dliom_imu_window_solver_stats(self.h, C.byref(a), C.byref(b)), "dliom_imu_window_solver_stats")
+        return int(a.value), int(b.value)
 
     def gravity_estimate(self):
         """(g_vec_est_G_, passed the reference's gates?, gravity factors added so far) -- EstimateGravity, .cc:1106-1154."""

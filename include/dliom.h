@@ -641,7 +641,10 @@ typedef struct dliom_imu_window_options {
   double ceres_pose_noise_t, ceres_pose_noise_r;                /* lua :96-97 */
   double ceres_pose_noise_t_drift, ceres_pose_noise_r_drift;    /* lua :98-99 (is_drift) */
   double prior_gravity_noise;                                   /* lua :100 */
-  int window_size;  /* states kept; older ones are marginalised (2..16) */
+  int window_size;  /* 0: the reference's rule -- EVERY key since the last graph reset stays in the problem (needs
+                       graph_reset_every >= 2), linearisation points move by relinearize_threshold, nothing is
+                       marginalised (.cc:693-863 with ISAM2 as it is parameterised at :676-679);
+                       2..4096: fixed-lag Gauss-Newton smoother, older states marginalised (Schur complement) */
   int iterations;   /* Gauss-Newton iterations per scan (the reference calls ISAM2::update twice) */
   int enable_gravity_factor;               /* lua :31 (false; dlio/config/basic_config_3d.lua:80 true): EstimateGravity per
                                               scan and, when it succeeds, a Pose3GravityFactor (.cc:819-831) */
@@ -658,6 +661,13 @@ typedef struct dliom_imu_window_options {
                                               integrated in the tangent space of the first state, error = local
                                               coordinates of the predicted state at state j.  0: the manifold form of
                                               Forster et al. (GTSAM with the flag OFF).  Still PARITY UNPINNED either way */
+  double relinearize_threshold;            /* window_size == 0 only: ISAM2Params::relinearizeThreshold (.cc:677, 0.1): a key's
+                                              linearisation point moves to its estimate when an increment component exceeds
+                                              it (checked at each of the `iterations` updates, relinearizeSkip = 1); the
+                                              estimate is linearisation point (+) increment, the increments solving the
+                                              linearised problem exactly.  0 = every update relinearises every key = batch
+                                              Gauss-Newton over the whole graph (oracle/imu_window_ref.py's
+                                              ReferenceRuleSmoother idealisation) */
 } dliom_imu_window_options;
 int dliom_imu_window_default_options(dliom_imu_window_options* options);
 int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out);
@@ -676,6 +686,8 @@ int dliom_imu_window_add_gravity(dliom_imu_window* window, int states_back, cons
 /* WindowOptimize(matched_pose, is_drift): new key, factors, optimisation; outputs prev_pose_ / prev_vel_ / prev_bias_ */
 int dliom_imu_window_add_pose(dliom_imu_window* window, const double matched_pose7[7], int is_drift, double pose7[7],
                               double velocity[3], double bias6[6]);
+/* Work done by the solver so far: linearisation points moved, chain blocks (states) eliminated -- what a scan costs */
+int dliom_imu_window_solver_stats(const dliom_imu_window* window, int64_t* relinearizations, int64_t* blocks_eliminated);
 int dliom_imu_window_state(const dliom_imu_window* window, int states_back, double pose7[7], double velocity[3],
                            double bias6[6]);
 int dliom_imu_window_size(const dliom_imu_window* window);

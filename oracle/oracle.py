@@ -462,6 +462,33 @@ def rtcsm3d_match_range_fair(opts, init7, pts, flat, first, count):
     return s, best.value
 
 
+def rtcsm3d_volume_fair(opts, init7, pts, flat, threads=8, progress=None):
+    """Every candidate's integer value sum and reference score (the whole Match loop, fair-CPU layout) on `threads` host
+    threads: (uint64[C], float32[C]).  The reference's winner is the first maximum of the scores (strict `>`,
+    rtcsm_3d.cc:46-51) = np.argmax."""
+    from concurrent.futures import ThreadPoolExecutor
+    pts = _f32(pts).reshape(-1, 3)
+    o, i7 = _opts4(opts), _f64(init7)
+    L = lib()
+    total = L.orc_rtcsm3d_candidates(_p(o, _f64p), C.c_float(flat.grid.resolution), _p(pts, _f32p), len(pts), _p(i7, _f64p), None, None)
+    sums = np.zeros(total, dtype=np.uint64)
+    scores = np.zeros(total, dtype=np.float32)
+    L.orc_rtcsm3d_range_fair_volume.restype = None
+    done = [0]
+
+    def run(fc):
+        f, c = fc
+        L.orc_rtcsm3d_range_fair_volume(_p(o, _f64p), _p(i7, _f64p), _p(pts, _f32p), len(pts), flat.grid.h, flat.h,
+                                        C.c_int64(f), C.c_int64(c), _p(sums[f:f + c], _u64p), _p(scores[f:f + c], _f32p))
+        done[0] += c
+        if progress is not None:
+            progress(done[0], total)
+    parts = _ranges(total, max(1, threads) * 16)
+    with ThreadPoolExecutor(max(1, threads)) as pool:
+        list(pool.map(run, parts))
+    return sums, scores
+
+
 def _ranges(total, parts):
     step = (total + parts - 1) // parts
     return [(f, min(step, total - f)) for f in range(0, total, step)]

@@ -400,6 +400,44 @@ float orc_rtcsm3d_match_range_fair(const double* opts, const double* init7, cons
   if (best_index != nullptr) *best_index = best_c;
   return best;
 }
+// The whole of RealTimeCorrelativeScanMatcher3D::Match's loop body (real_time_correlative_scan_matcher_3d.cc:40-51 with
+// ScoreCandidate :97-113) for candidates [first, first + count), in the fair-CPU layout, keeping EVERY candidate's
+// reference score and, from the same lookups, its integer value sum (what the HIP score volume holds): the full-size
+// config-5 parity run (tools/config5_full_parity.py) compares all C of both with the device.
+void orc_rtcsm3d_range_fair_volume(const double* opts, const double* init7, const float* pts, int n, void* grid, void* flat,
+                                   int64_t first, int64_t count, uint64_t* value_sums, float* scores) {
+  const RealTimeCorrelativeScanMatcherOptions o{opts[0], opts[1], opts[2], opts[3]};
+  const RealTimeCorrelativeScanMatcher3D m(o);
+  const PointCloud cloud = ToCloud(pts, n);
+  const HybridGrid& g = *G(grid);
+  const FlatGridView& f = *static_cast<FlatGridView*>(flat);
+  const std::vector<Rigid3f> ts = m.GenerateExhaustiveSearchTransforms(g.resolution(), cloud);
+  const Rigid3f init = ToRigid(init7).cast<float>();
+  const int64_t end = std::min<int64_t>(first + count, static_cast<int64_t>(ts.size()));
+  const unsigned gsize = static_cast<unsigned>(2 * f.half);
+  for (int64_t c = first; c < end; ++c) {
+    const Rigid3f candidate = init * ts[c];
+    float score = 0.f;
+    uint64_t sum = 0;
+    for (const Vec3f& p : cloud) {
+      const Vec3i i = g.GetCellIndex(candidate * p);
+      const unsigned sx = static_cast<unsigned>(i.x + f.half), sy = static_cast<unsigned>(i.y + f.half), sz = static_cast<unsigned>(i.z + f.half);
+      uint16 v = 0;
+      if (sx < gsize && sy < gsize && sz < gsize) {
+        const uint16* leaf = f.table[(static_cast<size_t>(sz >> 3) * f.leaves + (sy >> 3)) * f.leaves + (sx >> 3)];
+        if (leaf != nullptr) v = leaf[((sz & 7u) << 6) | ((sy & 7u) << 3) | (sx & 7u)];
+      }
+      score += ValueToProbability(v);
+      const uint16 w = v & 0x7fff;
+      sum += w == 0 ? 1 : w;
+    }
+    score /= static_cast<float>(cloud.size());
+    const float angle = GetAngle(ts[c]);
+    score *= std::exp(-Pow2(ts[c].translation.norm() * o.translation_delta_cost_weight + angle * o.rotation_delta_cost_weight));
+    value_sums[c - first] = sum;
+    scores[c - first] = score;
+  }
+}
 // Per candidate: sum over points of max(value & 0x7fff, 1) (exact integers),
 // the order-independent quantity the HIP score-volume kernel accumulates.
 // Candidates [first, first+count) only (count<0: all).

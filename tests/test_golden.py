@@ -116,3 +116,17 @@ def test_device_reproduces_voxel_filter_fixture(dl, ctx):
     assert np.array_equal(hi.download(), f["adaptive_hi"]) and np.array_equal(lo.download(), f["adaptive_lo"])
     for c in (out, hi, lo, cloud):
         c.close()
+
+
+def test_oracle_fair_volume_equals_reference_layout_loop(orc):
+    """orc_rtcsm3d_range_fair_volume (every candidate's integer sum and reference score from one pass over a flat leaf
+    table -- what tools/config5_full_parity.py runs at full size) against the reference-layout loop of the golden fixture:
+    same sums, same scores to the bit, same first maximum."""
+    f = load("matching.npz")
+    g_hi = oracle_grid_from(orc, 0.1, f["hi_cell_xyz"], f["hi_cell_value"])
+    flat = orc.FlatGridIndex(g_hi)
+    sums, scores = orc.rtcsm3d_volume_fair(DEFAULT_RTCSM, f["initial_pose"], f["points"], flat, threads=3)
+    assert np.array_equal(sums, f["score_volume_sums"])
+    r = orc.rtcsm3d_match(DEFAULT_RTCSM, f["initial_pose"], f["points"], g_hi, want_scores=True)
+    assert scores.tobytes() == r["scores"].tobytes()
+    assert int(np.argmax(scores)) == r["best_index"] and scores[r["best_index"]] == np.float32(f["rtcsm_score"])
