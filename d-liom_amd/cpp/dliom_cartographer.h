@@ -502,10 +502,15 @@ struct LocalTrajectoryBuilderOptions3D {
   // The IMU options start from the library's defaults (trajectory_builder_3d.lua's imu block): a caller overrides fields,
   // it never has to know every field -- a struct filled by hand would leave fields added later (round 4:
   // imu.tangent_preintegration, which selects the integrator) indeterminate, and dliom_imu_window_create refuses those.
-  LocalTrajectoryBuilderOptions3D() : front_end() { dliom_imu_window_default_options(&imu); }
+  LocalTrajectoryBuilderOptions3D() : front_end() {
+    dliom_imu_window_default_options(&imu);
+    imu.graph_reset_every = -1;  // like the reference: reset at submaps.num_range_data, every key kept until then
+  }
   dliom_front_end_options front_end;     // adaptive filters, matchers, motion filter, submaps (the caller fills it: no defaults)
   dliom_imu_window_options imu;          // imu block + WindowOptimize; imu.graph_reset_every < 0: follow
                                          // front_end.num_range_data like the reference (.cc:750), 0: never reset
+  bool keep_imu_window_size = false;     // false: graph reset on => imu.window_size = 0 (the reference's rule: every key
+                                         // until the reset); true: the fixed-lag smoother of imu.window_size states
   float min_range = 1.f, max_range = 100.f;
   int num_accumulated_range_data = 1;
   float voxel_filter_size = 0.15f;
@@ -638,6 +643,10 @@ class LocalTrajectoryBuilder3D {
         synchronizer_(expected_range_sensor_ids) {
     dliom_imu_window_options imu = options.imu;
     if (imu.graph_reset_every < 0) imu.graph_reset_every = options.front_end.num_range_data >= 2 ? options.front_end.num_range_data : 0;
+    // with the graph reset on, WindowOptimize follows the reference's rule: every key stays in the problem until the reset
+    // (window_size 0; .cc:749-797), linearisation points move by ISAM2's threshold (imu.relinearize_threshold, 0.1).  A
+    // caller who wants the fixed-lag smoother between resets sets imu.window_size and keep_imu_window_size.
+    if (imu.graph_reset_every >= 2 && !options.keep_imu_window_size) imu.window_size = 0;
     Check(dliom_imu_window_create(&imu, &window_), "dliom_imu_window_create");
     Check(dliom_range_accumulator_create(context->get(), &accumulator_), "dliom_range_accumulator_create");
   }

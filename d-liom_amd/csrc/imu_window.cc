@@ -602,6 +602,8 @@ struct dliom_imu_window {
     double L[225];      // S_i = D_i - W_{i-1} W_{i-1}^T = L L^T
     double W[225];      // B_i L^-T: what state i + 1's rows hold in state i's columns of the factor
     double y[15];       // forward-substituted right-hand side
+    double Lt[225];     // L^T (row major) and 1 / diag(L): the back substitution walks every key of the graph every scan,
+    double rdiag[15];   // so its inner loops run along rows and multiply instead of dividing
   };
   std::vector<double> delta;       // 15 per state
   std::vector<ChainFactor> fac;    // fac[i]: between[i]
@@ -933,6 +935,36 @@ void accumulate_pose_prior(int ia, const double* r0, const double* J /* 6 x 15 *
     }
 }
 
+// The Gaussian prior on x[0] (the initial priors :712-745, the reset's :756-770, or the fixed-lag window's marginal):
+// 1/2 d^T H0 d + b0^T d with d = local(lin0, x[0]).  Its derivative with respect to an increment of x[0] goes through
+// d(local)/d(increment) = diag(Jr^-1(d_rot), I): Log(R0^T R Exp(e)) = d_rot + Jr^-1(d_rot) e -- what
+// gtsam::PriorFactor<Pose3>::evaluateError returns as H -- so a prior whose state has been pulled away from its mean is
+// linearised like the reference's (round 6; the plain H0 / H0 d used until then is the d_rot -> 0 limit).
+// Adds J^T H0 J to H (row stride n) and J^T (b0 + H0 d) to g, both at offset 0.
+void add_state0_prior(const dliom_imu_window& w, const State& x0, double* H, double* g, int n) {
+  double d0[kD], t[kD];
+  local(w.lin0, x0, d0);
+  const M3 Ji = RightJacobianInverse({d0[0], d0[1], d0[2]});
+  for (int i = 0; i < kD; ++i) {
+    double acc = w.b0[i];
+    for (int j = 0; j < kD; ++j) acc += w.H0[kD * i + j] * d0[j];
+    t[i] = acc;
+  }
+  double HJ[kD * kD];  // H0 J: columns 0..2 mixed by Jr^-1
+  for (int i = 0; i < kD; ++i) {
+    for (int c = 0; c < 3; ++c)
+      HJ[kD * i + c] = w.H0[kD * i + 0] * Ji.m[0 * 3 + c] + w.H0[kD * i + 1] * Ji.m[1 * 3 + c] + w.H0[kD * i + 2] * Ji.m[2 * 3 + c];
+    for (int c = 3; c < kD; ++c) HJ[kD * i + c] = w.H0[kD * i + c];
+  }
+  for (int c = 0; c < kD; ++c) {  // J^T (H0 J): rows 0..2 mixed the same way
+    for (int r = 0; r < 3; ++r)
+      H[static_cast<size_t>(r) * n + c] += Ji.m[0 * 3 + r] * HJ[kD * 0 + c] + Ji.m[1 * 3 + r] * HJ[kD * 1 + c] + Ji.m[2 * 3 + r] * HJ[kD * 2 + c];
+    for (int r = 3; r < kD; ++r) H[static_cast<size_t>(r) * n + c] += HJ[kD * r + c];
+  }
+  for (int r = 0; r < 3; ++r) g[r] += Ji.m[0 * 3 + r] * t[0] + Ji.m[1 * 3 + r] * t[1] + Ji.m[2 * 3 + r] * t[2];
+  for (int r = 3; r < kD; ++r) g[r] += t[r];
+}
+
 // ---- the chain solver -------------------------------------------------------------------------------------------------
 // The window's normal equations are block tridiagonal (every factor touches one state or two neighbours; the prior sits on
 // the first block): block Cholesky from the oldest state on, S_i = D_i - W_{i-1} W_{i-1}^T = L_i L_i^T, W_i = B_i L_i^-T,
@@ -940,10 +972,6 @@ void accumulate_pose_prior(int ia, const double* r0, const double* J /* 6 x 15 *
 // the older part of the chain is (W_{i-1}, y_{i-1}) only, so a new key, a factor on a recent state or a moved
 // linearisation point re-eliminates the chain from there on and nothing before it: linear in the window for a full
 // Gauss-Newton step, a handful of blocks per scan for the reference's rule.
-#ifdef DLIOM_TEST_HOOKS
-int dliom_test_fail_chain = 0;  // tests/cpp/imu_window_marginalize_fail.cc: the next elimination fails
-#endif
-
 State estimate_at(const dliom_imu_window& w, size_t i) { return retract(w.x[i], &w.delta[kD * i]); }
 
 bool chol15(double* a) {  // in place, lower, row major 15 x 15
@@ -1019,9 +1047,6 @@ void chain_relinearize(dliom_imu_window& w, double threshold) {
 // Forward elimination of the states [clean_until, N).
 bool chain_eliminate(dliom_imu_window& w) {
   const int N = static_cast<int>(w.x.size());
-#ifdef DLIOM_TEST_HOOKS
-  if (dliom_test_fail_chain != 0) return false;
-#endif
   std::vector<double> H(30 * 30), g(30), D(kD * kD), gd(kD);
   for (int i = w.clean_until; i < N; ++i) {
     // the factor in front of state i is fresh (state i - 1 was eliminated with it, or chain_relinearize / chain_push_state
@@ -1048,18 +1073,7 @@ bool chain_eliminate(dliom_imu_window& w) {
     // D_i, g_i: the factors on state i alone, the prior (state 0), the two IMU factors' shares
     std::fill(D.begin(), D.end(), 0.0);
     std::fill(gd.begin(), gd.end(), 0.0);
-    if (i == 0) {
-      double d0[kD];
-      local(w.lin0, w.x[0], d0);
-      for (int a = 0; a < kD; ++a) {
-        double t = w.b0[a];
-        for (int b = 0; b < kD; ++b) {
-          t += w.H0[kD * a + b] * d0[b];
-          D[kD * a + b] += w.H0[kD * a + b];
-        }
-        gd[a] += t;
-      }
-    }
+    if (i == 0) add_state0_prior(w, w.x[0], D.data(), gd.data(), kD);
     for (const auto& f : w.pose_priors)
       if (f.index == i) {
         double r[6], J[6 * kD];
@@ -1103,6 +1117,10 @@ bool chain_eliminate(dliom_imu_window& w) {
     if (!chol15(b.L)) return false;
     lower_solve15(b.L, rhs);
     std::memcpy(b.y, rhs, sizeof b.y);
+    for (int a = 0; a < kD; ++a) {
+      b.rdiag[a] = 1.0 / b.L[kD * a + a];
+      for (int c = 0; c < kD; ++c) b.Lt[kD * a + c] = b.L[kD * c + a];
+    }
     if (i + 1 < N) {  // W L^T = B: every row of B by forward substitution
       const double* B = w.fac[i].B;
       for (int a = 0; a < kD; ++a) {
@@ -1118,7 +1136,11 @@ bool chain_eliminate(dliom_imu_window& w) {
   return true;
 }
 
-bool chain_back_substitute(dliom_imu_window& w) {  // false: an increment is not finite (a NaN in a residual)
+// Increments from the newest key back.  `first_changed`: the oldest state whose elimination was redone for this solve;
+// in front of it (L, W, y) are what the previous solve used, so once a key's increment comes out as it was -- to 1e-13 of
+// its tangent units, ten orders below ISAM2's own wildfire threshold of 1e-3 -- the older keys' increments stand and the
+// walk stops: a scan costs the keys its information still reaches, not the graph.
+bool chain_back_substitute(dliom_imu_window& w, int first_changed) {  // false: an increment is not finite (a NaN residual)
   const int N = static_cast<int>(w.x.size());
   bool finite = true;
   for (int i = N - 1; i >= 0; --i) {
@@ -1127,15 +1149,27 @@ bool chain_back_substitute(dliom_imu_window& w) {  // false: an increment is not
     std::memcpy(t, b.y, sizeof t);
     if (i + 1 < N) {
       const double* dn = &w.delta[static_cast<size_t>(kD) * (i + 1)];
-      for (int c = 0; c < kD; ++c) {
-        double u = 0.0;
-        for (int a = 0; a < kD; ++a) u += b.W[kD * a + c] * dn[a];
-        t[c] -= u;
+      for (int a = 0; a < kD; ++a) {
+        const double da = dn[a];
+        const double* row = b.W + kD * a;
+        for (int c = 0; c < kD; ++c) t[c] -= row[c] * da;
       }
     }
-    upper_solve15(b.L, t);
-    for (int c = 0; c < kD; ++c) finite = finite && std::isfinite(t[c]);
-    std::memcpy(&w.delta[static_cast<size_t>(kD) * i], t, sizeof t);
+    for (int r = kD - 1; r >= 0; --r) {  // L^T x = t along the rows of L^T
+      double acc = t[r];
+      const double* row = b.Lt + kD * r;
+      for (int k = r + 1; k < kD; ++k) acc -= row[k] * t[k];
+      t[r] = acc * b.rdiag[r];
+    }
+    double* d = &w.delta[static_cast<size_t>(kD) * i];
+    double change = 0.0;
+    for (int c = 0; c < kD; ++c) {
+      finite = finite && std::isfinite(t[c]);
+      change = std::max(change, std::fabs(t[c] - d[c]));
+    }
+    std::memcpy(d, t, sizeof t);
+    if (!finite) return false;
+    if (i < first_changed && change <= 1e-13) break;
   }
   return finite;
 }
@@ -1147,7 +1181,8 @@ bool gauss_newton(dliom_imu_window& w, int iterations) {
   for (int it = 0; it < iterations; ++it) {
     chain_relinearize(w, threshold);
     if (w.clean_until >= static_cast<int>(w.x.size())) continue;  // nothing changed: the increments stand
-    if (!chain_eliminate(w) || !chain_back_substitute(w)) return false;
+    const int first_changed = w.clean_until;
+    if (!chain_eliminate(w) || !chain_back_substitute(w, first_changed)) return false;
   }
   if (!w.full_graph()) chain_relinearize(w, 0.0);
   return true;
@@ -1168,16 +1203,7 @@ bool marginalize_oldest(dliom_imu_window& w) {
   std::vector<State> x2 = {w.x[0], w.x[1]};
   const int n = 2 * kD;
   std::vector<double> H(static_cast<size_t>(n) * n, 0.0), g(n, 0.0);
-  double d0[kD];
-  local(w.lin0, w.x[0], d0);
-  for (int i = 0; i < kD; ++i) {
-    double s = w.b0[i];
-    for (int j = 0; j < kD; ++j) {
-      s += w.H0[kD * i + j] * d0[j];
-      H[static_cast<size_t>(i) * n + j] += w.H0[kD * i + j];
-    }
-    g[i] += s;
-  }
+  add_state0_prior(w, w.x[0], H.data(), g.data(), n);
   std::vector<double> Linv;
   if (!whitening(w.between[0], &Linv)) return false;
   const Preint P = w.between[0];
@@ -1478,11 +1504,13 @@ namespace {
 // old graph knew about how pose, velocity and bias errors go together is dropped.  A fixed-lag window does not need
 // this (its marginal prior keeps the full 15 x 15 block); it is here so that the estimates follow the reference's
 // through its resets: tests/test_imu_window.py compares a 70-scan run against a batch solver with the same rule.
-bool reset_graph(dliom_imu_window& w) {
+// `old`: the graph that is being replaced -- w itself, or (reference-rule mode) the object w's graph was MOVED into so that
+// a failed call can move it back instead of having copied ~10 KB a key.
+bool reset_graph(dliom_imu_window& w, dliom_imu_window& old) {
   // marginal covariance of the newest state = inverse of the last block of the chain's factor, taken at the
   // linearisation points like ISAM2::marginalCovariance (fixed-lag mode: they are the estimates)
-  if (w.clean_until < static_cast<int>(w.x.size()) && !chain_eliminate(w)) return false;
-  const double* L = w.blk.back().L;
+  if (old.clean_until < static_cast<int>(old.x.size()) && !chain_eliminate(old)) return false;
+  const double* L = old.blk.back().L;
   double cov[kD][kD];
   for (int c = 0; c < kD; ++c) {
     double e[kD] = {0};
@@ -1491,7 +1519,7 @@ bool reset_graph(dliom_imu_window& w) {
     upper_solve15(L, e);
     for (int r = 0; r < kD; ++r) cov[r][c] = e[r];
   }
-  const State newest = estimate_at(w, w.x.size() - 1);  // prev_pose_ / prev_vel_ / prev_bias_
+  const State newest = estimate_at(old, old.x.size() - 1);  // prev_pose_ / prev_vel_ / prev_bias_
   std::fill(w.H0, w.H0 + kD * kD, 0.0);
   std::fill(w.b0, w.b0 + kD, 0.0);
   const int first[3] = {0, 6, 9}, size[3] = {6, 3, 6};  // updatedPoseNoise, updatedVelNoise, updatedBiasNoise
@@ -1542,7 +1570,7 @@ struct AddPoseUndo {
 };
 void take_back(dliom_imu_window& w, AddPoseUndo& u) {
   if (u.copy) {
-    w = *u.copy;
+    w = std::move(*u.copy);
     return;
   }
   w.x.resize(u.states);
@@ -1571,8 +1599,22 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
   if (!(w->current.dt > 0)) return DLIOM_ERR_INVALID_ARGUMENT;  // no IMU since the last pose
   const bool reset_due = w->o.graph_reset_every > 0 && w->key == w->o.graph_reset_every;
   AddPoseUndo undo;  // a failed solve leaves the window exactly as it was
-  if (!w->full_graph() || reset_due) {
+  if (!w->full_graph()) {
     undo.copy.reset(new dliom_imu_window(*w));
+  } else if (reset_due) {
+    // the graph moves into the undo object (vectors change hands, nothing is copied); what outlives a reset -- options,
+    // the running preintegration, the gravity estimator's deques, counters -- is put back into *w right away
+    undo.copy.reset(new dliom_imu_window(std::move(*w)));
+    const dliom_imu_window& old = *undo.copy;
+    w->g_frames = old.g_frames;
+    w->g_vs = old.g_vs;
+    w->x.clear();
+    w->between.clear();
+    w->pose_priors.clear();
+    w->gravity.clear();
+    w->delta.clear();
+    w->fac.clear();
+    w->blk.clear();
   } else {
     undo.states = w->x.size();
     undo.priors = w->pose_priors.size();
@@ -1586,9 +1628,10 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
     undo.relinearizations = w->relinearizations;
   }
   // prev_state_: the reference predicts from the estimate it read after the previous scan, also across a reset
-  const State prev = estimate_at(*w, w->x.size() - 1);
+  dliom_imu_window& graph = (w->full_graph() && reset_due) ? *undo.copy : *w;  // where the graph is right now
+  const State prev = estimate_at(graph, graph.x.size() - 1);
   if (reset_due) {
-    if (!reset_graph(*w)) {
+    if (!reset_graph(*w, graph)) {
       take_back(*w, undo);
       return DLIOM_ERR_SOLVER;
     }

@@ -351,28 +351,46 @@ class BatchSmoother:
 
 
 class ReferenceRuleSmoother:
-    """What LocalTrajectoryBuilder3D::WindowOptimize keeps between scans (:693-863), with ISAM2 idealised as a batch
-    Gauss-Newton solve to convergence over every key since the last reset: the graph grows until key_ == num_range_data,
-    then it is reset to ONE state whose priors are the marginal covariances of X, V and B taken separately (:750-797;
-    the cross-covariances between pose, velocity and bias are dropped there).  Block-sparse numeric Jacobians (every
-    factor touches at most two states), so a run of a hundred scans stays within seconds.  No gravity factor."""
+    """What LocalTrajectoryBuilder3D::WindowOptimize keeps between scans (:693-863): the graph grows until
+    key_ == num_range_data, then it is reset to ONE state whose priors are the marginal covariances of X, V and B taken
+    separately (:750-797; the cross-covariances between pose, velocity and bias are dropped there), with the gravity factor
+    (EstimateGravity + Pose3GravityFactor, :772-782,819-831) when the options enable it.  Two idealisations of ISAM2:
 
-    def __init__(self, opts, num_range_data):
+      relinearize_threshold=None  a batch Gauss-Newton solve to convergence over every key since the last reset;
+      relinearize_threshold=t     ISAM2's own rule as the reference parameterises it (:676-679, t = 0.1, relinearizeSkip 1):
+                                  every key keeps a linearisation point theta and an increment delta, the estimate is
+                                  theta (+) delta (calculateEstimate), `updates` (2: update(graph, values); update();)
+                                  times per scan: move the points whose |delta|_inf exceeds t, linearise EVERY factor at
+                                  the points, solve the linear problem exactly.  (What GTSAM adds on top -- the Bayes tree,
+                                  the wildfire threshold on older keys' deltas, Cayley retraction -- is not restated.)
+
+    Dense normal equations, block-sparse numeric Jacobians (every factor touches at most two states; the gravity factor
+    brings its own Jacobian, as in the reference): independent of imu_window.cc's chain solver and closed forms."""
+
+    def __init__(self, opts, num_range_data, relinearize_threshold=None, updates=2):
         self.o, self.n_reset = opts, int(num_range_data)
+        self.thr, self.updates = relinearize_threshold, int(updates)
 
     def initialize(self, pose7, vel, bias6):
         s = (quat_to_matrix(pose7[3:]), np.array(pose7[:3], float), np.array(vel, float), np.array(bias6[:3], float),
              np.array(bias6[3:], float))
         o = self.o
         self.x, self.pre, self.pose_priors = [s], [], []
+        self.delta = [np.zeros(15)]
+        self.gravity, self.g_frames, self.g_vs, self.g_valid, self.g_est = [], [], [], False, np.zeros(3)
+        self.gravity_factors = 0
         # prior on state 0: mean and the inverse square roots of the three blocks (pose tangent = (rotation, translation
         # in the body frame), like gtsam::Pose3::Logmap to first order)
         self.prior = (s, np.eye(6) / o["prior_pose_noise"], np.eye(3) / o["prior_velocity_sigma"], np.eye(6) / o["prior_bias_sigma"])
         self.cur = make_preintegration(s[3], s[4], o)
         self.resets = 0
+        self.relinearizations = 0
 
     def add_imu(self, acc, gyr, dt):
         self.cur.add(acc, gyr, dt)
+
+    def estimate(self, i=-1):
+        return retract(self.x[i], self.delta[i])
 
     # ---- factors: (state indices, residual function of those states)
     def _factors(self):
@@ -411,37 +429,74 @@ class ReferenceRuleSmoother:
             cols = np.concatenate([np.arange(15 * i, 15 * i + 15) for i in idx])
             H[np.ix_(cols, cols)] += J.T @ J
             b[cols] += J.T @ r0
+        bRef = np.array([0.0, 0.0, -1.0])
+        for idx, nZ in self.gravity:  # the reference factor's own 2 x 3 Jacobian on the rotation block
+            e, Hg = gravity_factor(self.x[idx][0], nZ, bRef, self.o["prior_gravity_noise"])
+            H[15 * idx:15 * idx + 3, 15 * idx:15 * idx + 3] += Hg.T @ Hg
+            b[15 * idx:15 * idx + 3] += Hg.T @ e
         return H, b
 
     def _solve(self, iterations):
+        if self.thr is None:  # batch Gauss-Newton: the points ARE the estimates
+            for _ in range(iterations):
+                H, b = self._normal_equations()
+                step = np.linalg.solve(H, -b)
+                self.x = [retract(s, step[15 * i:15 * i + 15]) for i, s in enumerate(self.x)]
+                if np.linalg.norm(step) < 1e-11:
+                    break
+            return
         for _ in range(iterations):
+            for i in range(len(self.x)):
+                if np.max(np.abs(self.delta[i])) > self.thr:
+                    self.x[i] = retract(self.x[i], self.delta[i])
+                    self.delta[i] = np.zeros(15)
+                    self.relinearizations += 1
             H, b = self._normal_equations()
-            step = np.linalg.solve(H, -b)
-            self.x = [retract(s, step[15 * i:15 * i + 15]) for i, s in enumerate(self.x)]
-            if np.linalg.norm(step) < 1e-10:
-                break
+            d = np.linalg.solve(H, -b)
+            self.delta = [d[15 * i:15 * i + 15].copy() for i in range(len(self.x))]
 
     def add_pose(self, matched7, is_drift=False, iterations=6):
         o = self.o
+        gravity_on = bool(o.get("enable_gravity_factor", 0))
+        updates = iterations if self.thr is None else self.updates
+        prev = self.estimate()  # prev_state_ / prev_bias_: what the reference read after the previous scan
         if len(self.x) == self.n_reset:  # key_ == num_range_data (:750): reset, keep the three marginals apart
             H, _ = self._normal_equations()
-            cov = np.linalg.inv(H)[-15:, -15:]
-            s = self.x[-1]
+            # marginal covariance of the newest key; the information spans 1e-8 (velocity prior) .. 1e10 (bias walk): invert
+            # the symmetrically scaled matrix (unit diagonal) so that the dense inverse keeps its digits
+            d = 1.0 / np.sqrt(np.diag(H))
+            cov = (np.linalg.inv(H * d[:, None] * d[None, :]) * d[:, None] * d[None, :])[-15:, -15:]
+            s = prev
             T = np.eye(6)
             T[3:6, 3:6] = s[0].T  # translation increment: world frame here, body frame in Pose3's tangent
             cov_x = T @ cov[0:6, 0:6] @ T.T
-            sqrt_inv = lambda C: np.linalg.cholesky(np.linalg.inv(C)).T  # W with W^T W = C^-1
+            def sqrt_inv(C):  # W with W^T W = C^-1, through the scaled matrix as above
+                e = 1.0 / np.sqrt(np.diag(C))
+                return np.linalg.cholesky(np.linalg.inv(C * e[:, None] * e[None, :]) * e[:, None] * e[None, :]).T
             self.prior = (s, sqrt_inv(cov_x), sqrt_inv(cov[6:9, 6:9]), sqrt_inv(cov[9:15, 9:15]))
-            self.x, self.pre, self.pose_priors = [s], [], []
+            self.x, self.pre, self.pose_priors, self.delta, self.gravity = [s], [], [], [np.zeros(15)], []
             self.resets += 1
-            self._solve(2)  # "optimize once" (:788)
-        nxt = BatchSmoother._predict(self, self.x[-1], self.cur)
+            if gravity_on:  # :772-782
+                self.g_valid = BatchSmoother._estimate_gravity(self, prev, self.cur)
+                if self.g_valid:
+                    self.gravity.append((0, self.g_est / np.linalg.norm(self.g_est)))
+                    self.gravity_factors += 1
+                    self._solve(updates if self.thr is None else 1)  # "optimize once" (:788)
+        nxt = BatchSmoother._predict(self, prev, self.cur)
+        key = len(self.x)  # key_ of the new state
         self.x.append(nxt)
+        self.delta.append(np.zeros(15))
         self.pre.append(self.cur)
         self.pose_priors.append((len(self.x) - 1, quat_to_matrix(matched7[3:]), np.array(matched7[:3], float),
                                  o["ceres_pose_noise_t_drift"] if is_drift else o["ceres_pose_noise_t"],
                                  o["ceres_pose_noise_r_drift"] if is_drift else o["ceres_pose_noise_r"]))
-        self._solve(iterations)
-        s = self.x[-1]
+        if gravity_on:  # :819-831
+            self.g_valid = BatchSmoother._estimate_gravity(self, prev, self.cur)
+            win = o["frames_for_online_gravity_estimate"]
+            if self.g_valid and key - win >= 0:
+                self.gravity.append((key - win, self.g_est / np.linalg.norm(self.g_est)))
+                self.gravity_factors += 1
+        self._solve(updates)
+        s = self.estimate()
         self.cur = make_preintegration(s[3], s[4], o)
         return s

@@ -1,6 +1,6 @@
-// The two pieces of imu_window.cc's arithmetic that round 5 restructured for speed must give the values of the plain
-// forms they replaced: (1) cholesky_chain -- right-looking on the block-tridiagonal normal matrix -- against the
-// dot-product (left-looking) form, bit for bit; (2) propagate_covariance -- sums over the entries of A, B, C that can
+// The pieces of imu_window.cc's arithmetic that were restructured for speed must give the values of the plain forms they
+// replaced: (1) the chain solver (round 6: block elimination of the block-tridiagonal normal equations from the oldest
+// key on, the older part reused from scan to scan) against ONE dense Cholesky solve of the same factors; (2) propagate_covariance -- sums over the entries of A, B, C that can
 // be non-zero -- against the full 9 x 9 x 9 loops (== on doubles: a skipped term was an exact zero).
 #include "../../d-liom_amd/csrc/imu_window.cc"
 
@@ -12,23 +12,34 @@ static int fail(const char* what) {
   return 1;
 }
 
-static bool cholesky_chain_plain(std::vector<double>& a, int n, int block) {
-  for (int j = 0; j < n; ++j) {
-    const int k0 = std::max(0, (j / block - 1) * block);
-    double d = a[j * n + j];
-    for (int k = k0; k < j; ++k) d -= a[j * n + k] * a[j * n + k];
-    if (!(d > 0.0)) return false;
-    d = std::sqrt(d);
-    a[j * n + j] = d;
-    const int i_end = std::min(n, (j / block + 2) * block);
-    for (int i = j + 1; i < i_end; ++i) {
-      const int ki = std::max(k0, (i / block - 1) * block);
-      double s = a[i * n + j];
-      for (int k = ki; k < j; ++k) s -= a[i * n + k] * a[j * n + k];
-      a[i * n + j] = s / d;
-    }
-    for (int i = i_end; i < n; ++i) a[i * n + j] = 0.0;
+// The window's normal equations as one dense matrix, every factor at the linearisation points w.x, and a dense Cholesky
+// solve: the plain form of what the chain solver (block elimination from the oldest state on, reused between scans) does.
+static bool dense_solve(dliom_imu_window& w, std::vector<double>* delta) {
+  const int N = static_cast<int>(w.x.size()), n = N * kD;
+  std::vector<double> H(static_cast<size_t>(n) * n, 0.0), g(n, 0.0);
+  add_state0_prior(w, w.x[0], H.data(), g.data(), n);
+  for (int i = 0; i + 1 < N; ++i) {
+    std::vector<double> Linv;
+    if (!whitening(w.between[i], &Linv)) return false;
+    double r[15], J[15 * 30];
+    imu_factor_jacobian(w, w.between[i], Linv, w.x[i], w.x[i + 1], r, J);
+    accumulate_imu_factor(i, r, J, H, g, n);
   }
+  for (const auto& f : w.pose_priors) {
+    double r[6], J[6 * kD];
+    pose_prior_jacobian(f, w.x[f.index], r, J);
+    accumulate_pose_prior(f.index, r, J, H, g, n);
+  }
+  for (const auto& f : w.gravity) {
+    double r[2], J[2 * kD];
+    gravity_residual(f, w.x[f.index], r, J);
+    add_factor_with_jacobian(f.index, 2, r, J, H, g, n);
+  }
+  for (int i = 0; i < n; ++i) H[static_cast<size_t>(i) * n + i] += 1e-12;
+  if (!cholesky(H, n)) return false;
+  delta->assign(n, 0.0);
+  for (int i = 0; i < n; ++i) (*delta)[i] = -g[i];
+  chol_solve(H, n, delta->data());
   return true;
 }
 
@@ -56,22 +67,53 @@ int main() {
     seed = seed * 1664525u + 1013904223u;
     return static_cast<double>(seed >> 8) / (1 << 24) - 0.5;
   };
-  // (1) banded Cholesky, windows of 1 .. 8 states, also a matrix that is not positive definite
-  for (int states = 1; states <= 8; ++states)
-    for (int rep = 0; rep < 20; ++rep) {
-      const int n = states * kD;
-      std::vector<double> A(static_cast<size_t>(n) * n, 0.0);
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j)
-          if (i / kD - j / kD <= 1) A[i * n + j] = A[j * n + i] = (i == j ? (rep == 19 ? 1.0 : 30.0) : 0.0) + rnd();
-      std::vector<double> a = A, b = A;
-      const bool oa = cholesky_chain(a, n, kD), ob = cholesky_chain_plain(b, n, kD);
-      if (oa != ob) return fail("cholesky_chain: success differs");
-      if (!oa) continue;
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j)
-          if (std::memcmp(&a[i * n + j], &b[i * n + j], 8) != 0) return fail("cholesky_chain: bits differ");
+  // (1) the chain solver against the dense solve: a graph of up to 40 keys that keeps its linearisation points (threshold
+  // never reached), so that most of every scan's elimination is reused from the scan before; gravity factors reach
+  // three keys back.  The increments are the dense solution's to rounding.
+  {
+    dliom_imu_window_options o;
+    if (dliom_imu_window_default_options(&o) != DLIOM_OK) return fail("default options");
+    o.window_size = 0;
+    o.graph_reset_every = 41;
+    o.relinearize_threshold = 1e6;
+    dliom_imu_window* w = nullptr;
+    if (dliom_imu_window_create(&o, &w) != DLIOM_OK) return fail("create");
+    const double pose0[7] = {0, 0, 0, 1, 0, 0, 0}, v0[3] = {1.0, 0.2, 0}, b0[6] = {0, 0, 0, 0, 0, 0};
+    if (dliom_imu_window_initialize(w, pose0, v0, b0) != DLIOM_OK) return fail("initialize");
+    int64_t eliminated_before = 0;
+    for (int k = 1; k <= 39; ++k) {
+      for (int i = 0; i < 20; ++i) {
+        const double acc[3] = {0.3 * rnd(), 0.3 * rnd(), 9.80511 + 0.1 * rnd()}, gyr[3] = {0.05 * rnd(), 0.05 * rnd(), 0.2 + 0.05 * rnd()};
+        if (dliom_imu_window_add_imu(w, acc, gyr, 0.005) != DLIOM_OK) return fail("add_imu");
+      }
+      double pred[7], vel[3];
+      if (dliom_imu_window_predict(w, pred, vel) != DLIOM_OK) return fail("predict");
+      for (int c = 0; c < 3; ++c) pred[c] += 0.01 * rnd();  // the matcher's correction
+      if (k % 5 == 0 && k >= 3) {
+        const double down[3] = {0.01 * rnd(), 0.01 * rnd(), -1.0};
+        if (dliom_imu_window_add_gravity(w, 3, down) != DLIOM_OK) return fail("add_gravity");
+      }
+      double out[7], ov[3], ob[6];
+      if (dliom_imu_window_add_pose(w, pred, 0, out, ov, ob) != DLIOM_OK) return fail("add_pose");
+      std::vector<double> want;
+      if (!dense_solve(*w, &want)) return fail("dense solve");
+      double worst = 0.0, scale = 0.0;
+      for (size_t i = 0; i < want.size(); ++i) {
+        worst = std::max(worst, std::fabs(want[i] - w->delta[i]));
+        scale = std::max(scale, std::fabs(want[i]));
+      }
+      if (!(worst <= 1e-9 * std::max(scale, 1e-3))) {
+        std::printf("key %d: chain and dense increments differ by %.3g (largest increment %.3g)\n", k, worst, scale);
+        return fail("chain solver");
+      }
+      int64_t relin = 0, eliminated = 0;
+      dliom_imu_window_solver_stats(w, &relin, &eliminated);
+      // a scan re-eliminates the two newest keys (+ the keys back to a gravity factor's), not the graph
+      if (relin != 0 || eliminated - eliminated_before > 5) return fail("chain solver: elimination not reused");
+      eliminated_before = eliminated;
     }
+    dliom_imu_window_destroy(w);
+  }
   // (2) covariance propagation with A, B, C of the shape both preintegration forms produce
   for (int rep = 0; rep < 200; ++rep) {
     double A[81] = {0}, Bm[27] = {0}, Cm[27] = {0}, cov[81], c1[81], c2[81];

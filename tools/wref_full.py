@@ -55,9 +55,12 @@ def option_sets():
     dlio["submaps"].update(high_resolution=0.2, high_resolution_max_range=60.0, num_range_data=100)  # :63-67
     return {
         "trajectory_builder_3d": dict(front_end=base, voxel_filter_size=0.15, min_range=1.0, max_range=100.0,
-                                      window=dict()),
+                                      # WindowOptimize by the reference's rule: every key until the graph reset at
+                                      # submaps.num_range_data (160), ISAM2's relinearisation threshold (0.1)
+                                      window=dict(window_size=0, graph_reset_every=160)),
         "basic_config_3d": dict(front_end=dlio, voxel_filter_size=0.3, min_range=0.5, max_range=100.0,      # :62, :88-89
-                                window=dict(enable_gravity_factor=1, frames_for_online_gravity_estimate=7, window_size=8)),  # :77-81
+                                window=dict(enable_gravity_factor=1, frames_for_online_gravity_estimate=7,  # :77-81
+                                            window_size=0, graph_reset_every=100)),  # the reference's rule, num_range_data 100
     }
 
 
@@ -114,9 +117,14 @@ class NumpyWindow:
         from oracle.imu_window_ref import ReferenceRuleSmoother
         w = dl.ImuWindow(**overrides)  # only to read the option values the product runs with
         opts = {n: getattr(w.options, n) for n in OPT_NAMES}
+        for n in ("enable_gravity_factor", "frames_for_online_gravity_estimate"):
+            opts[n] = int(getattr(w.options, n))
         reset = int(w.options.graph_reset_every)
+        rule = int(w.options.window_size) == 0  # the reference's rule: ISAM2's relinearisation threshold, two updates a scan
+        self.s = ReferenceRuleSmoother(opts, num_range_data=reset if reset > 0 else 10 ** 9,
+                                       relinearize_threshold=float(w.options.relinearize_threshold) if rule else None,
+                                       updates=int(w.options.iterations))
         w.close()
-        self.s = ReferenceRuleSmoother(opts, num_range_data=reset if reset > 0 else 10 ** 9)
 
     def initialize(self, pose7, vel, bias6):
         self.s.initialize(pose7, vel, bias6)
@@ -133,7 +141,7 @@ class NumpyWindow:
 
     def predict(self):
         from oracle.imu_window_ref import BatchSmoother
-        R, p, v, _, _ = BatchSmoother._predict(self.s, self.s.x[-1], self.s.cur)
+        R, p, v, _, _ = BatchSmoother._predict(self.s, self.s.estimate(), self.s.cur)
         return self._pose7(R, p), v
 
     def add_pose(self, matched):
@@ -141,7 +149,7 @@ class NumpyWindow:
         return self._pose7(R, p), v, np.concatenate([ba, bg]), 0
 
     def gravity_estimate(self):
-        return np.zeros(3), False, 0
+        return self.s.g_est, bool(self.s.g_valid), int(self.s.gravity_factors)
 
 
 def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, histogram_size=120, cpu_threads=1,
@@ -274,16 +282,18 @@ def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=20, beams=64, azimuths=102
         # the independent leg: the CPU oracle chain once more, untimed, with WindowOptimize by the numpy
         # batch solver instead of the product's imu_window.cc -- until now both legs ran the same host code for that stage
         # and their agreement said nothing about it.  Bounded: the solver's numerical Jacobians cost seconds per dozen
-        # scans, and it has no gravity factor (the compared scans must not have received one).
-        n_ind = min(n, 8 if cfg["window"].get("enable_gravity_factor") else 13)
+        # scans.  Round 6: it follows the same rule as the product's window (every key kept, ISAM2's relinearisation
+        # threshold, the gravity factor), so the compared scans may carry gravity factors.
+        n_ind = min(n, 13)
         t_ind = time.perf_counter()
         shadow = shadow_window(dl, cfg, imus[:n_ind], state0, dev_fed["matched"][:n_ind], dev_fed["status"][:n_ind], dev_fed["pv"][:n_ind])
         _, iposes, _, _ = run_chain(dl, cfg, T, clouds[:n_ind], imus[:n_ind], state0, False, orc=orc, numpy_window=True)
         _, gposes, _, g_ind = (None, poses[:n_ind], None, None)
         win_probe = dl.ImuWindow(acc_noise=NOISE[0], gyr_noise=NOISE[1], acc_bias_noise=NOISE[2], gyr_bias_noise=NOISE[3], **cfg["window"])
         out["parity_independent_imu_window"] = {
-            "what": "device leg (product fixed-lag window, imu_window.cc) against the CPU oracle chain whose WindowOptimize is "
-                    "oracle/imu_window_ref.py's numpy batch smoother (every key kept, numerical Jacobians, converged)",
+            "what": "device leg (product window, imu_window.cc: the reference's rule -- every key until the graph reset, "
+                    "ISAM2's relinearisation threshold -- on the chain solver) against the CPU oracle chain whose WindowOptimize "
+                    "is oracle/imu_window_ref.py's numpy smoother following the same rule (dense solves, numerical Jacobians)",
             "scans_compared": n_ind,
             "same_inputs": {"what": "the numpy window fed with the device leg's own IMU samples and matched poses (no feedback "
                                     "through the matcher): the difference of the two WINDOWS",
@@ -296,9 +306,10 @@ def line(dl, ctx, name, scans=24, warmup=4, cpu_scans=20, beams=64, azimuths=102
                             "max_rotation_difference_rad": float(np.max([2.0 * np.arccos(min(1.0, abs(float(np.dot(a[3:], b[3:])))))
                                                                          for a, b in zip(gposes, iposes)]))},
             "tolerance_m": 1e-4, "window_size": int(win_probe.options.window_size),
+            "graph_reset_every": int(win_probe.options.graph_reset_every),
+            "relinearize_threshold": float(win_probe.options.relinearize_threshold),
             "gravity_factor_enabled": bool(cfg["window"].get("enable_gravity_factor")),
-            "note": "PARITY UNPINNED against GTSAM itself (absent from the reference tree); the compared scans precede the first "
-                    "gravity factor (the numpy solver has none)",
+            "note": "PARITY UNPINNED against GTSAM itself (absent from the reference tree)",
             "seconds": time.perf_counter() - t_ind}
         win_probe.close()
         p_ind = out["parity_independent_imu_window"]
