@@ -26,7 +26,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <deque>
+#include <map>
 #include <memory>
 #include <set>
 #include <string>
@@ -44,6 +46,69 @@ inline void Check(int status, const char* what) {
     std::abort();  // glog CHECK semantics of the reference
   }
 }
+
+// cartographer/metrics/{gauge,histogram,family_factory}.h: the interfaces LocalTrajectoryBuilder3D::RegisterMetrics
+// (local_trajectory_builder_3d.h:113, .cc:624-649) is written against -- stand-ins like the value types below; inside
+// cartographer the real headers take their place (same names, same virtuals).
+namespace metrics {
+class Gauge {
+ public:
+  static Gauge* Null() {
+    struct NullGauge : Gauge {
+      void Increment() override {}
+      void Increment(double) override {}
+      void Decrement() override {}
+      void Decrement(double) override {}
+      void Set(double) override {}
+    };
+    static NullGauge null_gauge;
+    return &null_gauge;
+  }
+  virtual ~Gauge() = default;
+  virtual void Increment() = 0;
+  virtual void Increment(double by_value) = 0;
+  virtual void Decrement() = 0;
+  virtual void Decrement(double by_value) = 0;
+  virtual void Set(double value) = 0;
+};
+class Histogram {
+ public:
+  using BucketBoundaries = std::vector<double>;
+  static Histogram* Null() {
+    struct NullHistogram : Histogram {
+      void Observe(double) override {}
+    };
+    static NullHistogram null_histogram;
+    return &null_histogram;
+  }
+  static BucketBoundaries FixedWidth(double width, int num_finite_buckets) {  // metrics/histogram.cc:37-46
+    BucketBoundaries result;
+    for (int i = 1; i <= num_finite_buckets; ++i) result.push_back(width * i);
+    return result;
+  }
+  static BucketBoundaries ScaledPowersOf(double base, double scale_factor, double max_value) {  // :48-60
+    BucketBoundaries result;
+    if (!(base > 1) || !(scale_factor > 0)) Check(DLIOM_ERR_INVALID_ARGUMENT, "Histogram::ScaledPowersOf");
+    for (double boundary = scale_factor; boundary < max_value; boundary *= base) result.push_back(boundary);
+    return result;
+  }
+  virtual ~Histogram() = default;
+  virtual void Observe(double value) = 0;
+};
+template <typename MetricType>
+class Family {
+ public:
+  virtual ~Family() = default;
+  virtual MetricType* Add(const std::map<std::string, std::string>& labels) = 0;
+};
+class FamilyFactory {  // (NewCounterFamily is not used on this path)
+ public:
+  virtual ~FamilyFactory() = default;
+  virtual Family<Gauge>* NewGaugeFamily(const std::string& name, const std::string& description) = 0;
+  virtual Family<Histogram>* NewHistogramFamily(const std::string& name, const std::string& description,
+                                                const Histogram::BucketBoundaries& boundaries) = 0;
+};
+}  // namespace metrics
 
 namespace transform {
 struct Vector3d {
@@ -698,6 +763,10 @@ class LocalTrajectoryBuilder3D {
     }
     float current_pose[7];
     int accumulated = 0;
+    if (!accumulating_) {  // num_accumulated_ == 0 (.cc:389-391)
+      accumulation_started_ = std::chrono::steady_clock::now();
+      accumulating_ = true;
+    }
     Check(dliom_range_accumulator_add(accumulator_, prev, predicted, options_.scan_period, xyzt.data(),
                                       sync.origins.size() > 1 ? index.data() : nullptr,
                                       static_cast<int64_t>(sync.ranges.size()), origins.data(),
@@ -705,6 +774,7 @@ class LocalTrajectoryBuilder3D {
                                       options_.voxel_filter_size, current_pose, &accumulated),
           "AddRangeData (de-skew + accumulate)");
     if (accumulated < options_.num_accumulated_range_data) return nullptr;
+    accumulating_ = false;
     dliom_cloud* cloud = nullptr;
     float origin_in_tracking[3];
     Check(dliom_range_accumulator_finish(accumulator_, options_.voxel_filter_size, &cloud, origin_in_tracking),
@@ -713,6 +783,24 @@ class LocalTrajectoryBuilder3D {
   }
 
   const ActiveSubmaps3D& active_submaps() const { return active_submaps_; }
+  // local_trajectory_builder_3d.h:113, .cc:624-649: the same five metrics under the same family names, labels and bucket
+  // boundaries; they are process-wide like the reference's file-scope statics and observe nothing until this is called
+  static void RegisterMetrics(metrics::FamilyFactory* family_factory) {
+    Metrics& m = metrics_();
+    m.latency = family_factory->NewGaugeFamily("mapping_internal_3d_local_trajectory_builder_latency",
+                                               "Duration from first incoming point cloud in accumulation to local slam result")
+                    ->Add({});
+    auto* scores = family_factory->NewHistogramFamily("mapping_internal_3d_local_trajectory_builder_scores",
+                                                      "Local scan matcher scores", metrics::Histogram::FixedWidth(0.05, 20));
+    m.rtcsm_score = scores->Add({{"scan_matcher", "real_time_correlative"}});
+    auto* costs = family_factory->NewHistogramFamily("mapping_internal_3d_local_trajectory_builder_costs",
+                                                     "Local scan matcher costs", metrics::Histogram::ScaledPowersOf(2, 0.01, 100));
+    m.ceres_cost = costs->Add({{"scan_matcher", "ceres"}});
+    auto* residuals = family_factory->NewHistogramFamily("mapping_internal_3d_local_trajectory_builder_residuals",
+                                                         "Local scan matcher residuals", metrics::Histogram::ScaledPowersOf(2, 0.01, 10));
+    m.residual_distance = residuals->Add({{"component", "distance"}});
+    m.residual_angle = residuals->Add({{"component", "angle"}});
+  }
   // g_vec_est_G_ of the last EstimateGravity() (.cc:1106-1154), whether it passed the gates, gravity factors added so far
   // (options.imu.enable_gravity_factor: WindowOptimize adds the Pose3GravityFactor itself, .cc:819-831)
   bool GravityEstimate(transform::Vector3d* gravity_in_global, int64_t* factors_added = nullptr) const {
@@ -722,6 +810,17 @@ class LocalTrajectoryBuilder3D {
   }
 
  private:
+  struct Metrics {  // kLocalSlamLatencyMetric ... kScanMatcherResidualAngleMetric (.cc:36-41)
+    metrics::Gauge* latency = metrics::Gauge::Null();
+    metrics::Histogram* rtcsm_score = metrics::Histogram::Null();
+    metrics::Histogram* ceres_cost = metrics::Histogram::Null();
+    metrics::Histogram* residual_distance = metrics::Histogram::Null();
+    metrics::Histogram* residual_angle = metrics::Histogram::Null();
+  };
+  static Metrics& metrics_() {
+    static Metrics m;
+    return m;
+  }
   // .cc:493-572
   std::unique_ptr<MatchingResult> AddAccumulatedRangeData(int64_t time, const float current_pose[7], const float origin[3],
                                                           dliom_cloud* cloud) {
@@ -737,6 +836,10 @@ class LocalTrajectoryBuilder3D {
     dliom_match_result m;
     Check(dliom_front_end_match_cloud(active_submaps_.get(), prediction, origin, cloud, &m), "AddAccumulatedRangeData (match)");
     if (m.dropped) return nullptr;
+    if (options_.front_end.use_online_correlative_scan_matching) metrics_().rtcsm_score->Observe(m.rtcsm_score);  // :520
+    metrics_().ceres_cost->Observe(m.summary.final_cost);                                                         // :543
+    metrics_().residual_distance->Observe(m.residual_distance);                                                   // :547
+    metrics_().residual_angle->Observe(m.residual_angle);                                                         // :551
     // WindowOptimize(pose_estimate, false) and opt_pose = PoseFromGtsamNavState(prev_state_)
     double opt[7], vel[3], bias[6];
     const int ws = dliom_imu_window_add_pose(window_, m.pose_estimate, 0, opt, vel, bias);
@@ -825,6 +928,9 @@ class LocalTrajectoryBuilder3D {
       }
       result->insertion_result = std::move(ir);
     }
+    // .cc:566-568 (whole seconds, as the reference casts it)
+    metrics_().latency->Set(static_cast<double>(
+        std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - accumulation_started_).count()));
     return result;
   }
   // Rigid3f * Vector3f with Eigen's operation order (rotation * p + translation)
@@ -847,6 +953,8 @@ class LocalTrajectoryBuilder3D {
   int64_t last_imu_time_ = -1;
   bool imu_initialized_ = false;
   bool have_prediction_ = false;
+  bool accumulating_ = false;  // num_accumulated_ > 0
+  std::chrono::steady_clock::time_point accumulation_started_ = std::chrono::steady_clock::now();
   int64_t histogram_host_fallbacks_ = 0;
 
  public:

@@ -772,6 +772,29 @@ int dliom_ctx_synchronize(dliom_ctx* ctx) {
   return DLIOM_OK;
 }
 
+int dliom_ctx_memory_stats(const dliom_ctx* ctx, dliom_memory_stats* out) {
+  if (ctx == nullptr || out == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  std::memset(out, 0, sizeof *out);
+  const dliom::MemoryLedger& l = *ctx->ledger;
+  out->grids = l.grids;
+  out->leaf_table_bytes = l.leaf_table_bytes;
+  out->leaf_pool_bytes = l.leaf_pool_bytes;
+  out->mirror_bytes = l.mirror_bytes;
+  out->mirror_budget_bytes = l.mirror_budget;
+  out->mirrors_refused = l.mirrors_refused;
+  const dliom::DevBuf* bufs[] = {&ctx->points, &ctx->cand, &ctx->sums, &ctx->bounds, &ctx->rescore, &ctx->partials, &ctx->misc,
+                                 &ctx->sort_tmp, &ctx->voxel, &ctx->box_tables, &ctx->box_counters, &ctx->box_extents,
+                                 &ctx->csm_arrivals, &ctx->box_error, &ctx->deskew_flags, &ctx->zero_words, &ctx->aux_scratch};
+  for (const dliom::DevBuf* b : bufs) out->scratch_bytes += static_cast<int64_t>(b->cap);
+  return DLIOM_OK;
+}
+
+int dliom_ctx_set_mirror_budget(dliom_ctx* ctx, int64_t bytes) {
+  if (ctx == nullptr || bytes < 0) return DLIOM_ERR_INVALID_ARGUMENT;
+  ctx->ledger->mirror_budget = bytes;
+  return DLIOM_OK;
+}
+
 int dliom_ctx_read_backs(const dliom_ctx* ctx, int64_t* count) {
   if (ctx == nullptr || count == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   *count = ctx->read_backs;

@@ -150,7 +150,11 @@ __device__ __forceinline__ double dpp_double_or_zero(double v) {
   const unsigned hi = static_cast<unsigned>(dpp_or<kCtrl, kRowMask>(0, static_cast<int>(static_cast<unsigned>(u >> 32))));
   return __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
 }
-// inclusive scan over the wave's lanes: sums, or maxima of NON-NEGATIVE values (identity +0 either way)
+// inclusive scan over the wave's lanes: sums, or maxima of NON-NEGATIVE values (identity +0 either way).
+// EVERY lane of the wave must be active at the call (update_dpp keeps `old` = +0 for a disabled source lane: a partial
+// wave would silently add zeros where neighbours should have been); both callers run with all 1024 threads.  The sum
+// variant adds +0.0 in lanes without a source, so a -0.0 prefix comes out as +0.0: the classification downstream
+// compares magnitudes and parities of non-negative sums, for which the sign of a zero is irrelevant.
 template <bool kMax>
 __device__ __forceinline__ double wave_inclusive_scan_double(double v) {
 #define DLIOM_ES_STEP(ctrl, mask)                                      \

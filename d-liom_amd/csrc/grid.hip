@@ -526,6 +526,19 @@ static size_t table_entries(int bits) {
   return L * L * L + 1;
 }
 
+void dliom_grid::book() {
+  if (!ledger) return;
+  const int64_t table = d_table != nullptr ? static_cast<int64_t>(table_entries(bits) * sizeof(uint32_t)) : 0;
+  const int64_t pool = d_pool != nullptr ? capacity * (1024 + 12) : 0;
+  const int64_t mirror = mirror_bytes();
+  ledger->leaf_table_bytes += table - booked_table;
+  ledger->leaf_pool_bytes += pool - booked_pool;
+  ledger->mirror_bytes += mirror - booked_mirror;
+  booked_table = table;
+  booked_pool = pool;
+  booked_mirror = mirror;
+}
+
 int dliom_grid::refresh_count(int64_t* count) {
   uint32_t c = 0;
   DLIOM_HIP_TRY(hipMemcpyAsync(&c, d_count, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
@@ -557,6 +570,7 @@ int dliom_grid::ensure_bits(int needed_bits) {
   d_table = new_table;
   bits = needed_bits;
   drop_dense();  // wrong extent now; rebuilt lazily by the next match
+  book();
   return DLIOM_OK;
 }
 
@@ -566,6 +580,7 @@ void dliom_grid::drop_dense() {
   dense_stride = 0;
   dense_bricks = 0;
   dense_windowed = false;
+  book();
 }
 
 // Dense mirror of the grid for the correlative matcher: (grid_size + 2)^3 uint16 in 4x4x4 bricks
@@ -587,6 +602,13 @@ static int build_mirror(dliom_grid* g, const int off[3], int stride, bool window
   g->dense_bricks = 0;
   g->dense_windowed = false;
   if (!reuse) {
+    // the caller's cap on mirror memory (dliom_ctx_set_mirror_budget): refused like an allocation that failed -- the
+    // matcher falls back to the leaf-table kernels on this grid
+    if (g->ledger && g->ledger->mirror_budget > 0 &&
+        g->ledger->mirror_bytes + static_cast<int64_t>(cells * sizeof(uint16_t)) > g->ledger->mirror_budget) {
+      ++g->ledger->mirrors_refused;
+      return DLIOM_ERR_GRID_EXTENT;
+    }
     if (cells * sizeof(uint16_t) > (size_t{1} << 30)) {  // windows and bits = 4 mirrors: is the memory there at all?
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < cells * sizeof(uint16_t) + (size_t{1} << 30)) {
@@ -618,6 +640,7 @@ static int build_mirror(dliom_grid* g, const int off[3], int stride, bool window
   g->dense_bricks = static_cast<int>(bricks);
   for (int a = 0; a < 3; ++a) g->dense_off[a] = off[a];
   g->dense_windowed = windowed;
+  g->book();
   return DLIOM_OK;
 }
 
@@ -691,6 +714,7 @@ int dliom_grid::ensure_capacity(int64_t additional_slots) {
   d_pool = new_pool;
   d_slot_coord = new_coord;
   capacity = new_cap;
+  book();
   return DLIOM_OK;
 }
 
@@ -728,6 +752,7 @@ int dliom_grid::shrink_to_fit() {
   d_slot_coord = new_coord;
   capacity = want;
   used_upper = count;
+  book();
   return DLIOM_OK;
 }
 
@@ -739,6 +764,7 @@ int dliom_grid_create(dliom_ctx* ctx, float resolution, dliom_grid** out) {
   DLIOM_HIP_TRY(hipSetDevice(ctx->device));
   dliom_grid* g = new dliom_grid;
   g->ctx = ctx;
+  g->ledger = ctx->ledger;
   g->resolution = resolution;
   g->bits = 1;
   int s = DLIOM_OK;
@@ -769,6 +795,8 @@ int dliom_grid_create(dliom_ctx* ctx, float resolution, dliom_grid** out) {
     }
     s = g->ensure_capacity(1024);
   } while (false);
+  ++g->ledger->grids;  // (dliom_grid_destroy takes it back, also on the failure path below)
+  g->book();
   if (s != DLIOM_OK) {
     dliom_grid_destroy(g);
     return s;
@@ -787,7 +815,30 @@ int dliom_grid_destroy(dliom_grid* g) {
   if (g->d_count) (void)hipFree(g->d_count);
   if (g->d_dense) (void)hipFree(g->d_dense);
   if (g->h_count_slot) (void)hipHostFree(g->h_count_slot);
+  if (g->ledger) {  // the ledger outlives whichever of (context, grid) goes first
+    g->ledger->leaf_table_bytes -= g->booked_table;
+    g->ledger->leaf_pool_bytes -= g->booked_pool;
+    g->ledger->mirror_bytes -= g->booked_mirror;
+    --g->ledger->grids;
+  }
   delete g;
+  return DLIOM_OK;
+}
+
+int dliom_grid_memory_stats(const dliom_grid* g, dliom_memory_stats* out) {
+  if (g == nullptr || out == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  std::memset(out, 0, sizeof *out);
+  out->grids = 1;
+  out->leaf_table_bytes = g->booked_table;
+  out->leaf_pool_bytes = g->booked_pool;
+  out->mirror_bytes = g->booked_mirror;
+  out->mirror_windowed = g->d_dense != nullptr && g->dense_windowed ? 1 : 0;
+  out->leaf_capacity = g->capacity;
+  out->leaf_slots_upper_bound = g->used_upper;
+  if (g->ledger) {
+    out->mirror_budget_bytes = g->ledger->mirror_budget;
+    out->mirrors_refused = g->ledger->mirrors_refused;
+  }
   return DLIOM_OK;
 }
 
@@ -1176,14 +1227,14 @@ static void refresh_target(InsertTarget* tg, dliom_grid* g) {
 
 // Accounts for an insertion of n returns into the grids on the host: the pessimistic bound now, the exact count when the
 // last pass has written it (dliom_grid::ensure_capacity).  Call BEFORE the launches (the sequence number rides in them).
+static void account_insertion_one(MultiInsertArgs* a, dliom_grid* g, int k, int64_t n, int F) {
+  g->used_upper += n * (1 + static_cast<int64_t>(F));
+  g->insert_seq = g->insert_seq + 1u == 0u ? 1u : g->insert_seq + 1u;
+  g->upper_at_insert = g->used_upper;
+  a->tg[k].count_seq = g->insert_seq;
+}
 static void account_insertion(MultiInsertArgs* a, dliom_grid* const* grids, int num_targets, int64_t n, int F) {
-  for (int k = 0; k < num_targets; ++k) {
-    dliom_grid* g = grids[k];
-    g->used_upper += n * (1 + static_cast<int64_t>(F));
-    g->insert_seq = g->insert_seq + 1u == 0u ? 1u : g->insert_seq + 1u;
-    g->upper_at_insert = g->used_upper;
-    a->tg[k].count_seq = g->insert_seq;
-  }
+  for (int k = 0; k < num_targets; ++k) account_insertion_one(a, grids[k], k, n, F);
 }
 
 int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets, dliom_grid* const* grids,
@@ -1310,7 +1361,14 @@ int dliom_inserter_insert_cloud_multi(const dliom_inserter* ins, int num_targets
         if (status[2 * k] > grids[k]->bits) {  // skipped on the device: grow, then run it alone
           DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // (the other targets' passes are done before anything is reallocated)
           DLIOM_TRY(grids[k]->ensure_bits(status[2 * k]));
+          // ensure_bits() read the exact count back (refresh_count: used_upper = the count BEFORE this target's passes,
+          // applied_seq = insert_seq), which drops the pessimistic share account_insertion() added for this insertion --
+          // and the redo passes are about to allocate up to n (1 + F) leaves.  Account for them again, under a new
+          // sequence number, so that used_upper stays an upper bound and pass 4's exact count of the REDO is the one
+          // ensure_capacity() applies later (the invariant was broken until the next insertion).
+          DLIOM_TRY(grids[k]->ensure_capacity(n * (1 + static_cast<int64_t>(F))));
           refresh_target(&a.tg[k], grids[k]);
+          account_insertion_one(&a, grids[k], k, n, F);
           redo |= 1u << k;
         }
       }

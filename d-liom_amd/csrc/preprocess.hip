@@ -263,6 +263,9 @@ __global__ void split_xyzt_kernel(const float4* __restrict__ aos, int n, float* 
 // one atomicMax per point on one word was the whole kernel (11 us for 46 k points; four words at one per wavefront made
 // it 23 -- every one of them serialises at the memory side); the host takes the maximum of <= kTransformBlocks partials.
 constexpr int kTransformBlocks = 128;
+// A maximum that a NaN wins and keeps (fmaxf drops it): a cloud with a non-finite coordinate must end with non-finite
+// bounds, so that grid.hip's insertion_provably_inside() refuses to prove anything about it.
+__host__ __device__ __forceinline__ float max_nan_wins(float a, float b) { return (b > a || b != b) ? b : a; }
 __global__ __launch_bounds__(256) void transform_kernel(Quat4 q, float tx, float ty, float tz, const float* __restrict__ x,
                                                         const float* __restrict__ y, const float* __restrict__ z, int n,
                                                         float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
@@ -278,22 +281,22 @@ __global__ __launch_bounds__(256) void transform_kernel(Quat4 q, float tx, float
     ox[i] = rx;
     oy[i] = ry;
     oz[i] = rz;
-    m[0] = fmaxf(m[0], rx * rx + (ry * ry + rz * rz));
-    m[1] = fmaxf(m[1], fabsf(rx));
-    m[2] = fmaxf(m[2], fabsf(ry));
-    m[3] = fmaxf(m[3], fabsf(rz));
+    m[0] = max_nan_wins(m[0], rx * rx + (ry * ry + rz * rz));
+    m[1] = max_nan_wins(m[1], fabsf(rx));
+    m[2] = max_nan_wins(m[2], fabsf(ry));
+    m[3] = max_nan_wins(m[3], fabsf(rz));
   }
   __shared__ float part[4][4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m[k] = fmaxf(m[k], __shfl_xor(m[k], off, 64));
+    for (int off = 32; off > 0; off >>= 1) m[k] = max_nan_wins(m[k], __shfl_xor(m[k], off, 64));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][k] = m[k];
   }
   __syncthreads();
   if (threadIdx.x < 4)
-    partial_max[4 * blockIdx.x + threadIdx.x] =
-        fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
+    partial_max[4 * blockIdx.x + threadIdx.x] = max_nan_wins(max_nan_wins(part[0][threadIdx.x], part[1][threadIdx.x]),
+                                                             max_nan_wins(part[2][threadIdx.x], part[3][threadIdx.x]));
 }
 
 static int make_deskew_args(const double prev_pose[7], const double predicted_pose[7], double scan_period,
@@ -337,7 +340,9 @@ static int make_deskew_args(const double prev_pose[7], const double predicted_po
   //   qq = prev.q * qi (Hamilton product, |prev.q| ~ 1): sum_j |prev.q[j]| dqi[perm] + 7 roundings of values <= 2
   //   normalisation: z2 relative 2 * 2 max_k(db) + 2^-50, its square root half of that, the division one more ulp
   {
-    const double ulp = std::ldexp(1.0, -52), e = 5.0 * ulp, es = 4.0 * e + 2.0 * ulp;
+    // (e: 5 ulp by the documented bounds; doubled as a margin against an argument range where the shipped OCML is worse
+    //  than its specification -- a few more records per scan)
+    const double ulp = std::ldexp(1.0, -52), e = 2.0 * 5.0 * ulp, es = 4.0 * e + 2.0 * ulp;
     const double* r = a->rel_q;
     const double dq[4] = {es * (1.0 + std::fabs(r[0])) + ulp, (es + 0.5 * ulp) * std::fabs(r[1]), (es + 0.5 * ulp) * std::fabs(r[2]),
                           (es + 0.5 * ulp) * std::fabs(r[3])};
@@ -640,8 +645,8 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
         n3 = head[0];
         float sq = 0.f;
         for (unsigned b = 0; b < blocks; ++b) {
-          sq = std::max(sq, host[2 + 4 * b]);
-          for (int a = 0; a < 3; ++a) abs_max[a] = std::max(abs_max[a], host[2 + 4 * b + 1 + a]);
+          sq = max_nan_wins(sq, host[2 + 4 * b]);
+          for (int a = 0; a < 3; ++a) abs_max[a] = max_nan_wins(abs_max[a], host[2 + 4 * b + 1 + a]);
         }
         max_norm = std::sqrt(sq);  // sqrt is monotone and correctly rounded: == the maximum of the norms
       } else {
@@ -679,8 +684,8 @@ static int add_range_data_stage_b(dliom_ctx* ctx, const float* rx, const float* 
     if (st == DLIOM_OK) {
       float sq = 0.f;
       for (unsigned b = 0; b < blocks; ++b) {
-        sq = std::max(sq, host[4 * b]);
-        for (int a = 0; a < 3; ++a) abs_max[a] = std::max(abs_max[a], host[4 * b + 1 + a]);
+        sq = max_nan_wins(sq, host[4 * b]);
+        for (int a = 0; a < 3; ++a) abs_max[a] = max_nan_wins(abs_max[a], host[4 * b + 1 + a]);
       }
       max_norm = std::sqrt(sq);
     }

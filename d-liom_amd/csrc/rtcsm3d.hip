@@ -1586,7 +1586,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
                      cloud.d_ys, cloud.d_zs);
   DLIOM_HIP_TRY(hipGetLastError());
 #ifdef DLIOM_TEST_HOOKS  // libdliom_hooks.so only (make hooks): as if the kernel had flagged an inconsistency
-  if (ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] != 0) {
+  if (ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] == 1) {  // 1 only: 2 and 3 are the de-skew check's hooks (preprocess.hip)
     ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] = 0;
     DLIOM_HIP_TRY(hipMemsetAsync(static_cast<char*>(ctx->box_error.p) + 4, 1, 1, ctx->stream));
   }

@@ -162,6 +162,15 @@ class MatchResult(C.Structure):
                 ("num_low_resolution_points", C.c_int64), ("matching_submap_index", C.c_int)]
 
 
+class MemoryStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("grids", "leaf_table_bytes", "leaf_pool_bytes", "mirror_bytes", "mirror_budget_bytes",
+                                         "mirrors_refused", "scratch_bytes", "leaf_capacity", "leaf_slots_upper_bound")] + [
+                                             ("mirror_windowed", C.c_int)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class InsertionResult(C.Structure):
     _fields_ = [("inserted", C.c_int), ("num_insertion_submaps", C.c_int), ("insertion_submap_index", C.c_int * 2),
                 ("submap_added", C.c_int), ("submap_finished", C.c_int)]
@@ -186,6 +195,10 @@ SYMBOLS = [
     ("dliom_grid_resolution", C.c_int, [_vp, _f32p]),
     ("dliom_grid_bits", C.c_int, [_vp, C.POINTER(C.c_int)]),
     ("dliom_grid_mirror_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ("dliom_ctx_memory_stats", C.c_int, [_vp, C.POINTER(MemoryStats)]),
+    ("dliom_ctx_set_mirror_budget", C.c_int, [_vp, C.c_int64]),
+    ("dliom_grid_memory_stats", C.c_int, [_vp, C.POINTER(MemoryStats)]),
+    ("dliom_imu_window_solver_stats", C.c_int, [_vp, _i64p, _i64p]),
     ("dliom_grid_upload_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64]),
     ("dliom_grid_num_blocks", C.c_int, [_vp, _i64p]),
     ("dliom_grid_download_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64, _i64p]),
@@ -406,6 +419,16 @@ class Context:
         _check(self._L.dliom_ctx_voxel_filter_reruns(self.h, C.byref(n)), "voxel_filter_reruns")
         return int(n.value)
 
+    def memory_stats(self):
+        """dliom_ctx_memory_stats: HBM held by this context's grids and scratch buffers; no sync."""
+        m = MemoryStats()
+        _check(self._L.dliom_ctx_memory_stats(self.h, C.byref(m)), "ctx_memory_stats")
+        return m.as_dict()
+
+    def set_mirror_budget(self, num_bytes):
+        """dliom_ctx_set_mirror_budget: cap on the sum of this context's dense mirrors (0 = none)."""
+        _check(self._L.dliom_ctx_set_mirror_budget(self.h, int(num_bytes)), "ctx_set_mirror_budget")
+
     def read_backs(self):
         """dliom_ctx_read_backs: polled host round trips on this context so far."""
         n = C.c_int64(0)
@@ -542,6 +565,12 @@ class HybridGrid:
         b = C.c_int()
         _check(self._L.dliom_grid_bits(self.h, C.byref(b)), "grid_bits")
         return b.value
+
+    def memory_stats(self):
+        """dliom_grid_memory_stats: this grid's HBM (leaf table, pool, mirror), capacity and slot upper bound; no sync."""
+        m = MemoryStats()
+        _check(self._L.dliom_grid_memory_stats(self.h, C.byref(m)), "grid_memory_stats")
+        return m.as_dict()
 
     def mirror_stats(self):
         """(rebuilds, bytes, windowed) of the correlative matcher's dense mirror of this grid."""
@@ -1450,7 +1479,6 @@ class ImuWindow:
     def solver_stats(self):
         """(linearisation points moved, chain blocks eliminated) so far."""
         a, b = C.c_int64(0), C.c_int64(0)
-        self._L.dliom_imu_window_solver_stats.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _check(self._L.dliom_imu_window_solver_stats(self.h, C.byref(a), C.byref(b)), "dliom_imu_window_solver_stats")
         return int(a.value), int(b.value)
 

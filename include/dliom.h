@@ -86,6 +86,27 @@ int dliom_grid_bits(const dliom_grid* grid, int* bits);
  * grid was created -- once for a whole-grid mirror, once per excursion of the search out of the mirrored window for
  * grids beyond bits = 4 --, *bytes = its current size (0: none), *windowed = 1 if it covers a window of the grid. */
 int dliom_grid_mirror_stats(const dliom_grid* grid, int64_t* rebuilds, int64_t* bytes, int* windowed);
+/* HBM accounting (no reference counterpart: the reference's grids live in host memory).  What a context's grids hold --
+ * leaf tables ((8 << bits)^3 words), leaf pools (1 KiB + 12 B a leaf slot), the correlative matcher's dense mirrors
+ * (272 MB at bits = 3, 2.2 GB at bits = 4, up to 4.04 GB for a window beyond that) -- and the
+ * context's scratch buffers; nothing here synchronises with the device.  dliom_grid_memory_stats: one grid's share
+ * (grids = 1, scratch_bytes = 0) with its leaf capacity and the host's upper bound of the slots in use.
+ * dliom_ctx_set_mirror_budget: a cap on the sum of the context's mirrors (0 = none, the default).  A mirror that would
+ * exceed it is not built and RealTimeCorrelativeScanMatcher3D runs its leaf-table kernel on that grid -- the same
+ * results, several times slower (dliom_rtcsm_stats.box_kernel_status = DLIOM_BOX_REFUSED_NO_MIRROR, mirrors_refused
+ * counts); mirrors that exist stay. */
+typedef struct dliom_memory_stats {
+  int64_t grids;
+  int64_t leaf_table_bytes, leaf_pool_bytes, mirror_bytes;
+  int64_t mirror_budget_bytes, mirrors_refused;
+  int64_t scratch_bytes;           /* context only */
+  int64_t leaf_capacity;           /* grid only: slots of the pool */
+  int64_t leaf_slots_upper_bound;  /* grid only: >= slots in use (exact after dliom_grid_num_blocks) */
+  int mirror_windowed;             /* grid only */
+} dliom_memory_stats;
+int dliom_ctx_memory_stats(const dliom_ctx* ctx, dliom_memory_stats* out);
+int dliom_ctx_set_mirror_budget(dliom_ctx* ctx, int64_t bytes);
+int dliom_grid_memory_stats(const dliom_grid* grid, dliom_memory_stats* out);
 /* Overwrites whole leaves; grows like mutable_value()/Grow(). */
 int dliom_grid_upload_blocks(dliom_grid* grid, const int32_t* block_origin_xyz,
                              const uint16_t* values512, int64_t num_blocks);

@@ -5,6 +5,7 @@
 // MatchingResult with the local pose, compared there with the Python-driven chain.
 //   g++ -std=c++17 ltb3d_adapter.cc -L../../d-liom_amd -ldliom
 #include <cstdio>
+#include <map>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,47 @@
 #include "../../d-liom_amd/cpp/dliom_cartographer.h"
 
 using namespace dliom;
+
+namespace {
+// a recording metrics::FamilyFactory (cartographer/metrics/family_factory.h)
+struct RecH : metrics::Histogram {
+  std::vector<double> seen;
+  void Observe(double v) override { seen.push_back(v); }
+};
+struct RecG : metrics::Gauge {
+  int sets = 0;
+  void Increment() override {}
+  void Increment(double) override {}
+  void Decrement() override {}
+  void Decrement(double) override {}
+  void Set(double) override { ++sets; }
+};
+template <typename Base, typename Impl>
+struct RecFamily : metrics::Family<Base> {
+  std::map<std::string, std::unique_ptr<Impl>> by_label;
+  Base* Add(const std::map<std::string, std::string>& labels) override {
+    std::string key;
+    for (const auto& kv : labels) key += kv.first + "=" + kv.second + ";";
+    by_label[key].reset(new Impl);
+    return by_label[key].get();
+  }
+};
+struct Recorder : metrics::FamilyFactory {
+  std::map<std::string, std::unique_ptr<RecFamily<metrics::Histogram, RecH>>> histograms;
+  std::map<std::string, std::unique_ptr<RecFamily<metrics::Gauge, RecG>>> gauges;
+  std::map<std::string, size_t> buckets;
+  metrics::Family<metrics::Gauge>* NewGaugeFamily(const std::string& name, const std::string&) override {
+    gauges[name].reset(new RecFamily<metrics::Gauge, RecG>);
+    return gauges[name].get();
+  }
+  metrics::Family<metrics::Histogram>* NewHistogramFamily(const std::string& name, const std::string&,
+                                                          const metrics::Histogram::BucketBoundaries& b) override {
+    histograms[name].reset(new RecFamily<metrics::Histogram, RecH>);
+    buckets[name] = b.size();
+    return histograms[name].get();
+  }
+};
+}  // namespace
 
 static bool read_all(FILE* f, void* p, size_t bytes) { return std::fread(p, 1, bytes, f) == bytes; }
 
@@ -44,6 +86,8 @@ int main(int argc, char** argv) {
   options.max_range = 100.f;
   options.voxel_filter_size = 0.15f;
   options.scan_period = 0.1;
+  Recorder recorder;  // LocalTrajectoryBuilder3D::RegisterMetrics (local_trajectory_builder_3d.h:113)
+  mapping::LocalTrajectoryBuilder3D::RegisterMetrics(&recorder);
   mapping::LocalTrajectoryBuilder3D builder(&context, options, {"lidar"});
   builder.SetInitialState(transform::Rigid3d::FromArray(init), transform::Vector3d{{init[7], init[8], init[9]}}, init + 10);
   int64_t t = 0;
@@ -102,6 +146,22 @@ int main(int argc, char** argv) {
                 submaps[0]->num_range_data(), fin, submaps[0]->finished() ? 1 : 0, static_cast<long long>(hs),
                 static_cast<long long>(ls));
     if (st != 0 || num != submaps[0]->num_range_data() || fin != (submaps[0]->finished() ? 1 : 0) || hs <= 0 || ls <= 0) return 3;
+  }
+  {
+    const auto n = [&](const char* family, const char* label) {
+      return recorder.histograms.at(family)->by_label.at(label)->seen.size();
+    };
+    const size_t ceres = n("mapping_internal_3d_local_trajectory_builder_costs", "scan_matcher=ceres;");
+    const size_t score = n("mapping_internal_3d_local_trajectory_builder_scores", "scan_matcher=real_time_correlative;");
+    const size_t dist = n("mapping_internal_3d_local_trajectory_builder_residuals", "component=distance;");
+    const size_t angle = n("mapping_internal_3d_local_trajectory_builder_residuals", "component=angle;");
+    const int latency = recorder.gauges.at("mapping_internal_3d_local_trajectory_builder_latency")->by_label.at("")->sets;
+    std::printf("METRICS ceres %zu score %zu distance %zu angle %zu latency %d buckets %zu %zu %zu\n", ceres, score, dist, angle, latency,
+                recorder.buckets.at("mapping_internal_3d_local_trajectory_builder_scores"),
+                recorder.buckets.at("mapping_internal_3d_local_trajectory_builder_costs"),
+                recorder.buckets.at("mapping_internal_3d_local_trajectory_builder_residuals"));
+    const size_t want_score = options.front_end.use_online_correlative_scan_matching ? static_cast<size_t>(results) : 0u;
+    if (ceres != static_cast<size_t>(results) || dist != ceres || angle != ceres || score != want_score || latency != results) return 6;
   }
   std::printf("LTB3D ADAPTER DONE\n");
   return 0;

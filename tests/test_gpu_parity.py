@@ -1355,6 +1355,9 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
                            "-L", libdir, "-ldliom", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe, path] + (["gravity"] if gravity else []), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "LTB3D ADAPTER DONE" in out.stdout, out.stdout + out.stderr
+    # RegisterMetrics (local_trajectory_builder_3d.cc:624-649): every result observed once per histogram (the adapter
+    # returns 6 otherwise); bucket counts of FixedWidth(0.05, 20), ScaledPowersOf(2, 0.01, 100), ScaledPowersOf(2, 0.01, 10)
+    assert [ln for ln in out.stdout.splitlines() if ln.startswith("METRICS")][0].endswith("buckets 20 14 10"), out.stdout
     got = {int(l.split()[1]): np.array([float(v) for v in l.split()[2:9]]) for l in out.stdout.splitlines() if l.startswith("RESULT")}
     # the same stream through the Python binding
     g_opts = dict(enable_gravity_factor=1, frames_for_online_gravity_estimate=3, window_size=8) if gravity else {}
@@ -1767,3 +1770,74 @@ def test_device_rotational_histogram_in_two_halves(dl, ctx, orc):
         c.close()
     g_hi.close()
     g_lo.close()
+
+
+def test_leaf_slot_bound_survives_growth_in_the_middle_of_an_insertion(dl, ctx, orc):
+    """when a target of the fused insertion needs more bits, ensure_bits() reads the exact leaf
+    count back -- the count BEFORE the redo passes -- and used to leave it as the host's bound although the redo then
+    allocates up to n (1 + F) leaves.  The host-side bound (dliom_grid_memory_stats.leaf_slots_upper_bound, read without a
+    synchronisation) must stay >= the slots in use after every insertion, growth or not, and the grids stay the oracle's."""
+    from dliom import synth
+    ins = dl.RangeDataInserter3D(HIT_P, MISS_P, FREE, ctx=ctx)
+    og, dg = orc.HybridGrid(0.1), dl.HybridGrid(ctx, 0.1)
+    grown = 0
+    for s, (beams, az, scale) in enumerate([(8, 64, 0.05), (16, 128, 0.2), (32, 512, 0.45), (64, 1024, 1.0), (64, 1024, 1.0)]):
+        truth = synth.trajectory_pose(0.1 * s)
+        pts, _ = synth.scan(truth, beams, az)
+        pts = (pts * np.float32(scale)).astype(np.float32)  # the scan's reach grows from 1.3 m to 26 m: bits 1 -> 3
+        pf = truth.astype(np.float32)
+        cloud = dl.PointCloud(ctx, pts)
+        bits_before = dg.bits
+        dl.insert_cloud_multi(ins, cloud, [(dg, [pf], 0.0)])
+        cloud.close()
+        bound = dg.memory_stats()["leaf_slots_upper_bound"]  # no synchronisation, no read-back
+        grown += int(dg.bits > bits_before)
+        origin = orc.transform_points(pf, np.zeros((1, 3), np.float32))[0]
+        og.insert_tables(origin, orc.transform_points(pf, pts), ins.hit_table, ins.miss_table, FREE)
+        used = dg.num_blocks() + 1  # slot 0 is the null leaf
+        assert bound >= used, (s, bound, used)
+        assert dg.memory_stats()["leaf_capacity"] >= used
+    assert grown >= 2
+    assert dg.cells() == oracle_cells_dict(og)
+    dg.close()
+    ins.close()
+
+
+def test_memory_accounting_and_the_mirror_budget(dl, orc):
+    """dliom_ctx_memory_stats / dliom_grid_memory_stats report what the grids hold (leaf tables, pools, dense mirrors)
+    without touching the device, and dliom_ctx_set_mirror_budget turns the correlative matcher's mirror off for a
+    context that cannot afford it: the match then runs on the leaf-table kernel with the SAME result."""
+    from dliom import synth
+    c = dl.Context(0)
+    g_oracle = build_oracle_submap(orc, 0.1, num_scans=4, beams=16, azimuths=256)
+    g1, g2 = to_device_grid(dl, c, g_oracle), to_device_grid(dl, c, g_oracle)
+    m = c.memory_stats()
+    assert m["grids"] == 2 and m["mirror_bytes"] == 0 and m["leaf_pool_bytes"] > 0 and m["leaf_table_bytes"] > 0
+    one = g1.memory_stats()
+    assert one["grids"] == 1 and 2 * one["leaf_table_bytes"] == m["leaf_table_bytes"]
+    truth = synth.trajectory_pose(0.4)
+    pts, _ = synth.scan(truth, 64, 1024)  # large enough for the box kernel (which wants the mirror)
+    init = synth.perturb_pose(truth, 0.1, 0.5, seed=3)
+    rt = dl.RealTimeCorrelativeScanMatcher3D(c, DEFAULT_RTCSM)
+    score1, pose1 = rt.Match(init, pts, g1)
+    kernel_with_mirror = int(rt.last_stats().score_kernel)
+    mirror = g1.memory_stats()["mirror_bytes"]
+    assert mirror > 100e6 and c.memory_stats()["mirror_bytes"] == mirror and g1.mirror_stats()[1] == mirror
+    c.set_mirror_budget(mirror + 1024)  # room for the one that exists, not for a second
+    score2, pose2 = rt.Match(init, pts, g2)
+    st = rt.last_stats()
+    m = c.memory_stats()
+    assert g2.memory_stats()["mirror_bytes"] == 0 and m["mirror_bytes"] == mirror and m["mirrors_refused"] >= 1
+    assert int(st.score_kernel) != kernel_with_mirror and int(st.score_kernel) in (0, 1)  # a leaf-table kernel
+    assert np.float32(score1) == np.float32(score2) and np.array_equal(pose1, pose2)
+    ref = orc.rtcsm3d_match_parallel(DEFAULT_RTCSM, init, pts, g_oracle, threads=8)
+    assert np.array_equal(pose1, ref["pose"]) and np.float32(score1) == np.float32(ref["score"])
+    c.set_mirror_budget(0)
+    rt.Match(init, pts, g2)
+    assert g2.memory_stats()["mirror_bytes"] == mirror
+    g1.close()
+    assert c.memory_stats()["grids"] == 1 and c.memory_stats()["mirror_bytes"] == mirror
+    g2.close()
+    assert c.memory_stats()["mirror_bytes"] == 0 and c.memory_stats()["leaf_pool_bytes"] == 0
+    assert c.memory_stats()["scratch_bytes"] > 0
+    c.close()
