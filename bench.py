@@ -37,6 +37,7 @@ from benchlib import (RTCSM_OPTS, CSM_OPTS, SECOND_SUBMAP, build_scene, insertio
 from benchlib.config5 import config5_line, config5_sharded_line  # noqa: E402
 from benchlib.roofline import roofline_block  # noqa: E402
 from benchlib.wref import wref_line  # noqa: E402
+from benchlib import multigpu  # noqa: E402
 
 
 def parse():
@@ -168,10 +169,13 @@ def main():
     from dliom import sharded
     dev = coll_device
 
+    coll_clock = multigpu.CollectiveClock(dl, ctx, uses_rccl=rccl_comm is not None)
+
     def sharded_rtcsm(shard_, sc_, grid_):
         if rccl_comm is not None:  # ncclAllReduce(max, uint64, count 1) on the context's stream, inside the library
             return shard_.match_rccl(sc_["init"], sc_["cloud"], grid_, rccl_comm.handle)
-        return sharded.sharded_match(shard_, sc_["init"], sc_["cloud"], grid_, dist=dist, device=dev)
+        return shard_.match(sc_["init"], sc_["cloud"], grid_,
+                            coll_clock.wrap(lambda v: sharded.all_reduce_max_int(v, dist, dev)))
     stage = {"rtcsm": 0.0, "ceres": 0.0, "insert": 0.0}
     evals = []
     use_shards = [sharded_mode]  # flipped for the second (config 4) line of an N > 1 replica run
@@ -245,31 +249,44 @@ def main():
         for i in range(args.warmup):
             step(args.warmup + args.steps + i, False)
         fence()
-        ctx.set_profiling(2)  # HIP events around the score kernel only, as in the replica run above
+        ctx.set_profiling(2 | 64)  # HIP events around the score kernel and the library's all-reduce (DLIOM_KERNEL_ALLREDUCE)
         ctx.reset_profiling()
+        coll_clock.reset()
         t_s = time.perf_counter()
         for i in range(args.steps):
             step(2 * args.warmup + args.steps + i, False)
         fence()
         el = time.perf_counter() - t_s
         shard_score_ms, shard_score_n = ctx.kernel_time(dl.KERNEL_RTCSM_SCORE)
+        allreduce_ms = coll_clock.ms_per_match(args.steps)
         ctx.set_profiling(0)
         # the part of a step that does NOT shrink with the number of ranks: the step minus this rank's score kernel,
         # the largest over the ranks
-        tt = torch.tensor([el, el - 1e-3 * shard_score_ms], dtype=torch.float64, device=coll_device)
+        tt = torch.tensor([el, el - 1e-3 * shard_score_ms, allreduce_ms if allreduce_ms is not None else -1.0],
+                          dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        # every rank's view of the communicator, every rank's sharded winner against rank 0's UNSHARDED match, the
+        # replicas' grids after all of the above (benchlib/multigpu.py); collective, untimed
+        mg_checks = multigpu.checks(dl, ctx, dist, world, rank, rt, shard, scans, g_hi, g_lo, sharded_rtcsm,
+                                    rccl_comm.ranks_seen if rccl_comm is not None else dist.get_world_size())
         use_shards[0] = False
         sharded_line = {"workload": "config4: ONE scan stream, RTCSM3D search window sharded over %d ranks (one 8-byte RCCL "
                                     "max all-reduce per scan), Ceres + insertion replicated" % world,
                         "collective": ("dliom_rtcsm3d_match_sharded_rccl (ncclAllReduce inside the library)" if rccl_comm is not None
                                        else "dliom_rtcsm3d_match_sharded + torch.distributed callback (%s)" % backend),
                         "ranks_seen": rccl_comm.ranks_seen if rccl_comm is not None else world,
+                        "allreduce_ms_per_match_this_rank": allreduce_ms,
+                        "allreduce_ms_per_match_max_over_ranks": float(tt[2].item()) if float(tt[2].item()) >= 0 else None,
+                        "allreduce_timed_by": "HIP events inside the library around copy + ncclAllReduce + copy" if rccl_comm is not None
+                                              else "host clock around the torch.distributed callback",
+                        "checks": mg_checks,
                         "value": args.steps / float(tt[0].item()), "unit": "scans/s", "scaling": "strong",
                         "ms_per_step": 1e3 * float(tt[0].item()) / args.steps,
                         "score_kernel_ms_per_step_this_rank": shard_score_ms / max(1, args.steps),
                         "serial_remainder_ms_per_step": 1e3 * float(tt[1].item()) / args.steps,
                         "note": "Amdahl: only the score volume (~60 % of a 1-GPU step) shards; Ceres, insertion, the "
-                                "bounds / rescoring kernels and two host synchronisations per scan stay serial"}
+                                "bounds / rescoring kernels and two host synchronisations per scan stay serial: config 2 "
+                                "strong-scales <= 1 / (0.4 + 0.6 / N) = 2.1x at N = 8; read the 8-GPU number off sharded_config5"}
 
     # ... and the search where sharding pays: config 5 (128 x 2048 returns, 5 cm voxels, ~3e6 candidates), whose step
     # is 98 % score volume -- every rank builds the same small submap and takes its share of the rotations
@@ -354,11 +371,13 @@ def main():
                 "angular_window": int(st.window.angular_window_size),
                 "max_scan_range": float(st.window.max_scan_range),
                 "E_mean": float(np.mean(evals)) if evals else 0.0,
-                "rescored_candidates_last": int(st.num_rescored),
+                "rescored_candidates_last": int(st.num_rescored), "box_kernel_variant": int(st.box_kernel_variant),
                 "map_scans": args.map_scans, "grids_inserted_into": 2 + len(SECOND_SUBMAP),
                 "parallelism": ("candidate shards x%d (RCCL max all-reduce)" if sharded_mode else "replicas x%d") % world,
             },
             "stage_ms_per_scan": {k: 1e3 * v / args.steps for k, v in stage.items()},
+            # the part of a step that does not shard (config 4's Amdahl ceiling): the step minus this rank's score kernel
+            "serial_remainder_ms_per_step": 1e3 * elapsed / args.steps - k_ms,
             "kernel_ms_per_scan": breakdown,
             "roofline": roofline_block(args, pairs, k_ms, int(score_n), alg_bytes, int(st.score_kernel)),
         }

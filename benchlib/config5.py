@@ -155,7 +155,8 @@ def config5_line(dl, synth, ctx, steps=3, with_oracle=True):
            "stage_ms_per_scan": {k: 1e3 * v / steps for k, v in stage.items()},
            "C": C, "N": n, "angular_window": int(st.window.angular_window_size), "linear_window": int(st.window.linear_window_size),
            "max_scan_range": float(st.window.max_scan_range), "grids_inserted_into": 4, "hi_grid_bits": int(grids[0].bits),
-           "score_kernel": int(st.score_kernel), "score_kernel_ms": k_ms / max(k_n, 1),
+           "score_kernel": int(st.score_kernel), "box_kernel_variant": int(st.box_kernel_variant),
+           "score_kernel_ms": k_ms / max(k_n, 1),
            "pairs_per_s": float(C) * n / (k_ms / max(k_n, 1) * 1e-3) if k_ms > 0 else None,
            "frac_useful": (float(C) * n / (k_ms / max(k_n, 1) * 1e-3)) / USEFUL_PAIRS_PER_S if k_ms > 0 else None,
            "mirror": {"bytes": mirror_bytes, "windowed": windowed, "rebuilds": rebuilds}, "box_kernel_flags": int(rt.box_error())}

@@ -132,19 +132,23 @@ __global__ void gather_sorted_kernel(const float* __restrict__ x, const float* _
 // window, with their range.  Chunks that straddle a jump of the Morton curve need several boxes and take up to five
 // times as long as a compact one; the kernel's dispenser hands chunks out in the order built here -- most expensive
 // first -- so that the last tickets of a launch are short ones.  Only an ORDER of independent work items: results
-// never depend on it.  One half-wave per chunk.
+// never depend on it.  CH = 32: one half-wave per chunk (the narrow box kernel's chunks); CH = 64: one wave per chunk
+// (the big-box variants' chunks, round 6).
+template <int CH>
 __global__ void chunk_cost_kernel(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
                                   int64_t n, int chunks, unsigned char* __restrict__ cls) {
-  const int lane = threadIdx.x & 63, l = lane & 31;
-  const int chunk = 2 * static_cast<int>((static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6) + (lane >> 5);
-  const int64_t i = static_cast<int64_t>(chunk) * kCostChunk + l;
+  static_assert(CH == 32 || CH == 64, "one half-wave or one wave per chunk");
+  const int lane = threadIdx.x & 63, l = lane & (CH - 1);
+  const int wave_id = static_cast<int>((static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6);
+  const int chunk = CH == 32 ? 2 * wave_id + (lane >> 5) : wave_id;
+  const int64_t i = static_cast<int64_t>(chunk) * CH + l;
   const bool have = chunk < chunks && i < n;
   const float x = have ? xs[i] : 0.f, y = have ? ys[i] : 0.f, z = have ? zs[i] : 0.f;
   float lo[3] = {have ? x : 3.0e38f, have ? y : 3.0e38f, have ? z : 3.0e38f};
   float hi[3] = {have ? x : -3.0e38f, have ? y : -3.0e38f, have ? z : -3.0e38f};
   float r = fabsf(x) + fabsf(y) + fabsf(z);
 #pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) {
+  for (int m = CH / 2; m >= 1; m >>= 1) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       lo[a] = fminf(lo[a], __shfl_xor(lo[a], m));
@@ -269,6 +273,7 @@ static int finish_cloud(dliom_ctx* ctx, const CloudLayout& l, int64_t n, dliom_c
   out->d_zs = l.zs;
   out->morton_ready = false;
   out->d_chunk_order = nullptr;
+  out->d_chunk_order_big = nullptr;
   return DLIOM_OK;
 }
 
@@ -300,10 +305,23 @@ int ensure_morton(dliom_ctx* ctx, const dliom_cloud* cloud) {
       const int chunks = static_cast<int>((n + kCostChunk - 1) / kCostChunk);
       if (chunks <= 65535) {  // 16-bit counters in chunk_order_kernel (2 M points)
         unsigned char* cls = reinterpret_cast<unsigned char*>(l.keys_out);
-        hipLaunchKernelGGL(chunk_cost_kernel, dim3((chunks + 7) / 8), dim3(256), 0, ctx->stream, l.xs, l.ys, l.zs, n, chunks, cls);
+        hipLaunchKernelGGL(chunk_cost_kernel<kCostChunk>, dim3((chunks + 7) / 8), dim3(256), 0, ctx->stream, l.xs, l.ys, l.zs, n, chunks, cls);
         DLIOM_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(chunk_order_kernel, dim3(1), dim3(256), 0, ctx->stream, cls, chunks, l.keys_in);
         c->d_chunk_order = l.keys_in;
+        // ... and of the 64-point chunks of the big-box variants, behind the first table (the key buffers hold 4 bytes a
+        // point; the two tables take 1/8 + 1/16 of that).  Only clouds those variants are chosen for: several passes
+        // need more than 27 translations, a search that small on a small cloud never reaches the box kernel.
+        const int chunks64 = static_cast<int>((n + kCostChunkBig - 1) / kCostChunkBig);
+        if (n >= 16384) {
+          unsigned char* cls64 = cls + ((static_cast<size_t>(chunks) + 255) & ~static_cast<size_t>(255));
+          unsigned* order64 = l.keys_in + ((static_cast<size_t>(chunks) + 63) & ~static_cast<size_t>(63));
+          hipLaunchKernelGGL(chunk_cost_kernel<kCostChunkBig>, dim3((chunks64 + 3) / 4), dim3(256), 0, ctx->stream, l.xs, l.ys, l.zs, n,
+                             chunks64, cls64);
+          DLIOM_HIP_TRY(hipGetLastError());
+          hipLaunchKernelGGL(chunk_order_kernel, dim3(1), dim3(256), 0, ctx->stream, cls64, chunks64, order64);
+          c->d_chunk_order_big = order64;
+        }
       }
     }
     DLIOM_HIP_TRY(hipGetLastError());
@@ -591,6 +609,7 @@ int finish_device_cloud_from(dliom_ctx* ctx, dliom_cloud* c, float max_norm, con
   c->d_zs = l.zs;
   c->morton_ready = false;
   c->d_chunk_order = nullptr;
+  c->d_chunk_order_big = nullptr;
   c->max_norm = max_norm;
   return DLIOM_OK;
 }

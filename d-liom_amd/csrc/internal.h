@@ -114,6 +114,7 @@ struct dliom_ctx {
   bool last_score_used_box = false;
   int last_score_mapping = -1;     // 3 box, 2 dense mirror, 1 / 0 leaf table kernels
   int last_box_refusal = 0;        // DLIOM_BOX_* of the last score volume (dliom_rtcsm_stats.box_kernel_status)
+  int last_box_variant = -1;       // which instantiation of the box kernel ran last (dliom_rtcsm_stats.box_kernel_variant)
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
   unsigned* done_word = nullptr;  // pinned, own allocation: completion word of the main stream's read-back kernels
@@ -151,8 +152,8 @@ struct dliom_ctx {
   };
   std::vector<Span> spans;
   std::vector<hipEvent_t> event_pool;
-  double kernel_ms[DLIOM_KERNEL_COUNT] = {0, 0, 0, 0, 0};
-  int64_t kernel_launches[DLIOM_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  double kernel_ms[DLIOM_KERNEL_COUNT] = {};
+  int64_t kernel_launches[DLIOM_KERNEL_COUNT] = {};
   dliom_rtcsm_stats last_rtcsm = {};
   void* rtcsm_state = nullptr;              // state between the phases of a match (rtcsm3d.hip)
   void (*rtcsm_state_free)(void*) = nullptr;
@@ -219,6 +220,7 @@ struct dliom_cloud {
   int device = 0;
   bool morton_ready = false;  // d_xs/d_ys/d_zs are built on first use (ensure_morton)
   unsigned* d_chunk_order = nullptr;  // chunks of kCostChunk Morton-ordered points, most expensive first (or null)
+  unsigned* d_chunk_order_big = nullptr;  // the same for chunks of kCostChunkBig points (or null)
 };
 
 struct dliom_inserter {
@@ -230,9 +232,11 @@ struct dliom_inserter {
 
 namespace dliom {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per context, not per thread or process
-enum : unsigned { kFuncAttrScoreBox = 1u, kFuncAttrHistogram = 2u, kFuncAttrStdSortDiag = 4u, kFuncAttrHistogramBig = 8u };
+enum : unsigned { kFuncAttrScoreBox = 1u, kFuncAttrHistogram = 2u, kFuncAttrStdSortDiag = 4u, kFuncAttrHistogramBig = 8u,
+                  kFuncAttrScoreBoxW3 = 16u, kFuncAttrScoreBoxWide = 32u };
 // Coordinate of the padding points of the Morton-ordered arrays: far outside any grid extent.
 constexpr int kCostChunk = 32;  // points per chunk of dliom_cloud::d_chunk_order (= the box score kernel's chunk)
+constexpr int kCostChunkBig = 64;  // ... of d_chunk_order_big (the big-box variants' chunk)
 constexpr float kPadCoordinate = 1.0e7f;  // cell index ~1e7/res: no int overflow for res >= 0.005 m
 // host-pointer cloud staged in ctx->points (valid until the next staging call)
 int stage_cloud(dliom_ctx* ctx, const float* points_xyz, int64_t n, dliom_cloud* out,

@@ -1297,11 +1297,29 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   using namespace box;
   const int R = static_cast<int>(c.w.num_rotations), T = static_cast<int>(c.w.num_translations);
   const int n = static_cast<int>(cloud.n);
-  static const int cells = env_int("DLIOM_BOX_CELLS", 14336);
-  static const int chunk_pts = env_int("DLIOM_BOX_CHUNK", 32);
+  // Which instantiation (score_box.h; round 6, A/B on BASELINE configs 2 and 5 in one process each):
+  //   0  27 translations per pass, four waves per SIMD, 14 336-cell boxes: a window of ONE pass (config 2: 0.69 ms; the
+  //      same kernel at three waves per SIMD 0.71, with 21 000-cell boxes 0.70, with 64-point chunks 0.70-0.72)
+  //   1  the same at three waves per SIMD (168 registers) with 21 000-cell boxes: windows of several passes, whose
+  //      translations reach further and make the boxes larger (config 5: 221 -> 195 ms)
+  //   2  54 translations per pass at three waves per SIMD, 21 000-cell boxes: one staged box and one rotation per point
+  //      serve two narrow passes (config 5: 186 ms) -- where its padding (the last pass is filled up to 54) costs less
+  //      than the 15 % of vector instructions per lookup it saves
+  static const int forced_variant = env_int("DLIOM_BOX_VARIANT", -1);
+  const auto padded = [T](int tc) { return ((T + tc - 1) / tc) * tc; };
+  const int variant = forced_variant >= 0 && forced_variant <= 2
+                          ? forced_variant
+                          : (T <= kTC ? 0 : (0.85 * padded(kTCWide) < padded(kTC) ? 2 : 1));
+  const int TC = variant == 2 ? kTCWide : kTC;
+  static const int forced_cells = env_int("DLIOM_BOX_CELLS", 0);
+  const int cells = forced_cells > 0 ? forced_cells : (variant == 0 ? 14336 : 21000);
+  // 64-point chunks where the boxes are large (config 5, same runs: 195 -> 189 ms at 27 translations per pass, 187 -> 181
+  // at 54); on config 2's narrow kernel they cost 1-3 % (0.70-0.72 against 0.69 ms)
+  static const int forced_chunk = env_int("DLIOM_BOX_CHUNK", 0);
+  const int chunk_pts = forced_chunk > 0 ? forced_chunk : (variant == 0 ? kCostChunk : kCostChunkBig);
   static const int target_waves = env_int("DLIOM_BOX_WAVES", 0);
   const double res = static_cast<double>(g.resolution);
-  const int passes = (T + kTC - 1) / kTC;
+  const int passes = (T + TC - 1) / TC;
   // ---- error budget (score_box.h): E / u = 1 + (2 qmax + rmax + taumax) / 256
   double tmax = 0.0;
   for (const F3& t : c.trans) tmax = std::max(tmax, static_cast<double>(std::max(std::fabs(t.x), std::max(std::fabs(t.y), std::fabs(t.z)))));
@@ -1316,10 +1334,10 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   // breaks -- any cell DynamicGrid can address (|q| < 8192 + range) is fine.
   if (!std::isfinite(qmax) || qmax > 16500.0) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_RANGE, DLIOM_ERR_CAPACITY);
   std::vector<Pass> pass(static_cast<size_t>(passes));
-  std::vector<float> tau(static_cast<size_t>(passes) * kTC * 4, 0.f);
+  std::vector<float> tau(static_cast<size_t>(passes) * TC * 4, 0.f);
   double taumax = 0.0;
   for (int tp = 0; tp < passes; ++tp) {  // pass centres first: taumax enters the band
-    const int j0 = tp * kTC, tc = std::min(kTC, T - j0);
+    const int j0 = tp * TC, tc = std::min(TC, T - j0);
     for (int a = 0; a < 3; ++a) {
       double lo = 1e300, hi = -1e300;
       for (int j = j0; j < j0 + tc; ++j) {
@@ -1337,8 +1355,8 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   const double u = 1.0 / 65536.0;
   for (int tp = 0; tp < passes; ++tp) {
     Pass& ps = pass[static_cast<size_t>(tp)];
-    ps.j0 = tp * kTC;
-    ps.tc = std::min(kTC, T - ps.j0);
+    ps.j0 = tp * TC;
+    ps.tc = std::min(TC, T - ps.j0);
     ps.pad[0] = ps.pad[1] = 0;
     for (int a = 0; a < 3; ++a) {
       auto comp = [&](int j) { return static_cast<double>(a == 0 ? c.trans[j].x : (a == 1 ? c.trans[j].y : c.trans[j].z)); };
@@ -1355,11 +1373,11 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
       ps.f[a] = static_cast<float>(f);
       ps.uc[a] = static_cast<float>(tcen / res + 0.5);
       double reach = 0.0;
-      for (int jj = 0; jj < kTC; ++jj) {
+      for (int jj = 0; jj < TC; ++jj) {
         const int j = ps.j0 + std::min(jj, ps.tc - 1);  // short pass: padding repeats the last translation
         const double tv = comp(j) / res + 128.5 + s_units * u - (gi + f);
         const float tf = static_cast<float>(tv);
-        tau[(static_cast<size_t>(tp) * kTC + jj) * 4 + a] = tf;
+        tau[(static_cast<size_t>(tp) * TC + jj) * 4 + a] = tf;
         reach = std::max(reach, std::fabs(static_cast<double>(tf)));
       }
       // + the float roundings of the bounding box's own arithmetic at this distance from the origin (interval end +
@@ -1376,7 +1394,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
     for (int a = 0; a < 3; ++a) {
       unsigned* words = bitmap.data() + static_cast<size_t>(tp) * kBitmapWords + static_cast<size_t>(a) * (kBuckets / 32);
       for (int jj = 0; jj < ps.tc; ++jj) {
-        const double tv = static_cast<double>(tau[(static_cast<size_t>(tp) * kTC + jj) * 4 + a]);
+        const double tv = static_cast<double>(tau[(static_cast<size_t>(tp) * TC + jj) * 4 + a]);
         const double af = tv - std::floor(tv);
         const double L = -af - 1.5 * u, H = -af + (thr_units + 1.5) * u;
         const long long b0 = static_cast<long long>(std::floor(L * kBuckets)), b1 = static_cast<long long>(std::floor(H * kBuckets));
@@ -1404,7 +1422,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
                      : std::min(rot_groups_all, kWaves);  // four waves = one per SIMD: measured 2-3 % faster than three even
                                                           // when that leaves idle waves in the last rotation block
   const int rot_blocks = (rot_groups_all + nw - 1) / nw;
-  if (kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 + static_cast<size_t>(cells) * 2 >
+  if (TC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 + static_cast<size_t>(cells) * 2 >
       160 * 1024)
     return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_LDS, DLIOM_ERR_CAPACITY);  // LDS budget (checked again where the launch is sized)
   struct GroupCache {  // depends on the window and the shard only: cached per thread across matches
@@ -1520,7 +1538,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   p.passes = passes;
   p.n = n;
   p.chunk = std::min(kMaxChunk, std::max(4, chunk_pts & ~3));
-  p.order = p.chunk == kCostChunk ? cloud.d_chunk_order : nullptr;
+  p.order = p.chunk == kCostChunk ? cloud.d_chunk_order : (p.chunk == kCostChunkBig ? cloud.d_chunk_order_big : nullptr);
   p.point_chunks = (n + p.chunk - 1) / p.chunk;
   const int rot_groups = (r_last - r_first + 63) / 64;
   p.rot_groups = rot_groups;
@@ -1537,22 +1555,25 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
 #else
   p.debug = 0;
 #endif
-  const size_t lds = kTC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 +
+  const size_t lds = TC * sizeof(float4) + kBitmapWords * 4 + 16 + static_cast<size_t>(nw) * kListWords * 4 +
                      static_cast<size_t>(cells) * 2;
   if (lds > 160 * 1024) return (ctx->last_box_refusal = DLIOM_BOX_REFUSED_LDS, DLIOM_ERR_CAPACITY);
-  if ((ctx->func_attr_set & kFuncAttrScoreBox) == 0u) {
-    DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rtcsm_score_box_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ctx->func_attr_set |= kFuncAttrScoreBox;
+  typedef void (*BoxKernel)(GridView, Params, const float*, const float*, const float*);
+  const BoxKernel kernel = variant == 0 ? rtcsm_score_box_kernel : (variant == 1 ? rtcsm_score_box_kernel_w3 : rtcsm_score_box_kernel_wide);
+  const unsigned attr_bit = variant == 0 ? kFuncAttrScoreBox : (variant == 1 ? kFuncAttrScoreBoxW3 : kFuncAttrScoreBoxWide);
+  if ((ctx->func_attr_set & attr_bit) == 0u) {
+    DLIOM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ctx->func_attr_set |= attr_bit;
   }
+  ctx->last_box_variant = variant;
   // workgroups: one round of residents (every wave walks an equal share of the point chunks, so a second,
   // partly filled round would only idle); `target_waves` overrides
   static thread_local size_t resident_lds = 0;
-  static thread_local int resident = 0, resident_nw = 0;
-  if (resident_lds != lds || resident_nw != nw) {
+  static thread_local int resident = 0, resident_nw = 0, resident_variant = -1;
+  if (resident_lds != lds || resident_nw != nw || resident_variant != variant) {
     resident_nw = nw;
-    DLIOM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(rtcsm_score_box_kernel),
-                                                                64 * nw, lds));
+    resident_variant = variant;
+    DLIOM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, reinterpret_cast<const void*>(kernel), 64 * nw, lds));
     resident_lds = lds;
   }
   const int num_cus = ctx->num_cus;
@@ -1582,8 +1603,7 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
     if (prep != nullptr) prep->n = 0;
   }
   const unsigned blocks = static_cast<unsigned>(slot_quads) * passes * rot_blocks;
-  hipLaunchKernelGGL(rtcsm_score_box_kernel, dim3(blocks), dim3(64 * nw), lds, ctx->stream, g, p, cloud.d_xs,
-                     cloud.d_ys, cloud.d_zs);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * nw), lds, ctx->stream, g, p, cloud.d_xs, cloud.d_ys, cloud.d_zs);
   DLIOM_HIP_TRY(hipGetLastError());
 #ifdef DLIOM_TEST_HOOKS  // libdliom_hooks.so only (make hooks): as if the kernel had flagged an inconsistency
   if (ctx->tuning[DLIOM_TUNE_RESERVED_TEST_HOOK] == 1) {  // 1 only: 2 and 3 are the de-skew check's hooks (preprocess.hip)
@@ -2156,6 +2176,7 @@ static int match_finish(dliom_ctx* ctx, const unsigned* global_best_lo_bits, uin
   ctx->last_rtcsm.num_rescored = K;
   ctx->last_rtcsm.score_kernel = ctx->last_score_mapping;
   ctx->last_rtcsm.box_kernel_status = ctx->last_box_refusal;
+  ctx->last_rtcsm.box_kernel_variant = ctx->last_box_refusal == DLIOM_BOX_RAN ? ctx->last_box_variant : -1;
   ctx->last_rtcsm.best_index = st->best_c;
   if (local_best_packed != nullptr) {
     uint64_t packed = 0;  // a shard without a positive-score survivor contributes nothing
@@ -2402,9 +2423,12 @@ int rccl_exchange(uint64_t* value, void* user) {
   uint64_t* d = ctx->misc.as<uint64_t>();
   uint64_t* h = reinterpret_cast<uint64_t*>(static_cast<char*>(ctx->pinned) + ctx->pinned_bytes - 4096 + 3072);
   *h = *value;
-  if (hipMemcpyAsync(d, h, 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 1;
-  if (rccl_api().AllReduce(d, d, 1, ncclUint64, ncclMax, x->comm, ctx->stream) != ncclSuccess) return 1;
-  if (hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 1;
+  const int span = ctx->begin_span(DLIOM_KERNEL_ALLREDUCE);  // (profiling on: HIP events around the collective)
+  bool ok = hipMemcpyAsync(d, h, 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+            rccl_api().AllReduce(d, d, 1, ncclUint64, ncclMax, x->comm, ctx->stream) == ncclSuccess &&
+            hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  ctx->end_span(span);
+  if (!ok) return 1;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 1;
   *value = *h;
   return 0;

@@ -54,7 +54,8 @@
 namespace dliom {
 namespace box {
 
-constexpr int kTC = 27;        // translations per pass (register accumulators)
+constexpr int kTC = 27;        // translations per pass of the narrow kernels (register accumulators)
+constexpr int kTCWide = 54;    // ... of the wide kernel (round 6): two narrow passes' accumulators, one box, one rotation per point
 #if !defined(DLIOM_EXPERIMENTS) || !defined(DLIOM_BOX_MAX_WAVES)
 #undef DLIOM_BOX_MAX_WAVES
 #define DLIOM_BOX_MAX_WAVES 4
@@ -346,13 +347,13 @@ __device__ __forceinline__ void drain_l1(const GridView& g, const Params& p, con
 // ---- the hot loop --------------------------------------------------------------------------------------
 // Returns the first point NOT processed: the loop stops early when the level-1 list could not take the
 // worst case of another iteration (every lane listed for every point) -- the caller drains it and re-enters.
-template <int P>
+template <int P, int TC>
 __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, const Geometry& geo, const Quat4 q,
                                           const float* __restrict__ px, const float* __restrict__ py,
                                           const float* __restrict__ pz, int i_begin, int i_end, int chunk_lo,
                                           const float4* lds_tau, const unsigned* lds_bitmap, unsigned box_base,
                                           Lists& ls, unsigned rec_id, bool lane_active, int lane,
-                                          unsigned (&acc)[kTC]) {
+                                          unsigned (&acc)[TC]) {
   const float inv = to_vgpr_f(g.inv_resolution);
   const float kbx = to_vgpr_f(geo.kb[0]), kby = to_vgpr_f(geo.kb[1]), kbz = to_vgpr_f(geo.kb[2]);
   const unsigned s1 = 2u * geo.sx, s2 = 2u * geo.sxy;
@@ -438,11 +439,11 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
       for (int k = 0; k < P; ++k) pv[d][k] = 0u;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < kTC; ++j) {
+    for (int j = 0; j < TC; ++j) {
 #if DLIOM_BOX_EXP == 3
       const float4 tn = t;  // timing experiment: no translation fetch
 #else
-      const float4 tn = lds_tau[j + 1 < kTC ? j + 1 : j];  // same address in every lane: LDS broadcast
+      const float4 tn = lds_tau[j + 1 < TC ? j + 1 : j];  // same address in every lane: LDS broadcast
 #endif
       unsigned a[P];
 #if DLIOM_BOX_EXP == 2
@@ -515,8 +516,8 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
       unsigned s = pv[d][0];
 #pragma unroll
       for (int k = 1; k < P; ++k) s += pv[d][k];
-      acc[kTC - 1 - d] += s;
-      asm volatile("" : "+v"(acc[kTC - 1 - d]));
+      acc[TC - 1 - d] += s;
+      asm volatile("" : "+v"(acc[TC - 1 - d]));
     }
   }
   return i;
@@ -525,9 +526,10 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
 // The register accumulators are 32 bits wide and a value is at most 32767: after kFlushPoints points they are
 // added to the 64-bit score volume and cleared (large clouds: 128 x 2048 returns and up).
 constexpr int kFlushPoints = 131072;  // 131072 * 32767 < 2^32
-__device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsigned (&acc)[kTC], int r, bool lane_active) {
+template <int TC>
+__device__ __forceinline__ void flush_acc(const Params& p, const Pass& ps, unsigned (&acc)[TC], int r, bool lane_active) {
 #pragma unroll
-  for (int j = 0; j < kTC; ++j) {
+  for (int j = 0; j < TC; ++j) {
     if (lane_active && j < ps.tc && acc[j] != 0u)
       atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + r], static_cast<unsigned long long>(acc[j]));
     acc[j] = 0u;
@@ -635,15 +637,21 @@ __global__ __launch_bounds__(256) void rtcsm_box_extent_kernel(Params p, float i
   }
 }
 
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rtcsm_score_box_kernel(
-    GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
+// The kernel's body for TC translations per pass.  Three instantiations (round 6, measured on BASELINE configs 2 and 5,
+// DESIGN.md 3.1): <27> at four waves per SIMD (128 registers, 14 336-cell boxes: the fastest where one pass holds the
+// whole translation window -- config 2: 0.69 ms against 0.71 at three waves, with or without larger boxes);
+// <27> at three waves per SIMD (168 registers, 21 000-cell boxes) and <54> at three waves per SIMD for windows of
+// several passes, where the translations' reach makes the boxes larger (config 5: 221 -> 195 -> 186 ms).
+template <int TC>
+__device__ __forceinline__ void score_box_body(const GridView& g, const Params& p, const float* __restrict__ px,
+                                               const float* __restrict__ py, const float* __restrict__ pz) {
   extern __shared__ float4 lds_dyn4[];  // [kTC tau | band bitmap | ticket words | nw x lists | box]
   float4* lds_tau = lds_dyn4;
-  unsigned* lds_bitmap = reinterpret_cast<unsigned*>(lds_dyn4 + kTC);
+  unsigned* lds_bitmap = reinterpret_cast<unsigned*>(lds_dyn4 + TC);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)), lane = threadIdx.x & 63, nthreads = blockDim.x;
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_char*)lds_dyn4));  // LDS byte address of the block
-  const unsigned tick_off = static_cast<unsigned>(kTC * sizeof(float4)) + kBitmapWords * 4u;
+  const unsigned tick_off = static_cast<unsigned>(TC * sizeof(float4)) + kBitmapWords * 4u;
   const unsigned lists_off = tick_off + 16u;
   const unsigned box_off = lists_off + static_cast<unsigned>(p.nw) * kListWords * 4u;  // lists of the waves present
   const unsigned box_base = lds0 + box_off;
@@ -655,9 +663,9 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
   ls.rec = reinterpret_cast<int*>(ls.l2 + kL2Cap);
   ls.n1 = 0;
   ls.seq = 0;
-  unsigned acc[kTC];
+  unsigned acc[TC];
 #pragma unroll
-  for (int j = 0; j < kTC; ++j) acc[j] = 0u;
+  for (int j = 0; j < TC; ++j) acc[j] = 0u;
   const int S = g.dense_stride, B = g.dense_bricks;
   // Work units are (pass, rotation block); each has its own chunk dispenser.  A workgroup starts in its HOME unit
   // (blockIdx -> unit as evenly as the launch allows; its first ticket is its own slot, no atomic: same-address
@@ -705,7 +713,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     const int tp = unit / p.rot_blocks;
     if (tp != loaded_pass) {
       __syncthreads();  // nobody still reads the previous pass's tables
-      if (threadIdx.x < kTC) lds_tau[threadIdx.x] = p.tau[tp * kTC + threadIdx.x];
+      if (threadIdx.x < TC) lds_tau[threadIdx.x] = p.tau[tp * TC + threadIdx.x];
       for (int w = threadIdx.x; w < kBitmapWords; w += nthreads) lds_bitmap[w] = p.bitmap[tp * kBitmapWords + w];
       __syncthreads();
       loaded_pass = tp;
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
               float rx, ry, rz;
               rotate_point(q, px[lo], py[lo], pz[lo], rx, ry, rz);
 #pragma unroll
-              for (int j = 0; j < kTC; ++j) {
+              for (int j = 0; j < TC; ++j) {
                 const float* tr = p.trans + 3 * (ps.j0 + min(j, ps.tc - 1));
                 acc[j] += mirror_value(g, cell_of(rx + tr[0], g.resolution), cell_of(ry + tr[1], g.resolution),
                                        cell_of(rz + tr[2], g.resolution));
@@ -842,11 +850,11 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
             const int e8 = kHotP == 8 ? s_lo + (s_n & ~7) : s_lo, e4 = s_lo + (s_n & ~3), e1 = s_lo + s_n;
             for (;;) {
               if (kHotP == 8 && i < e8)
-                i = main_loop<kHotP>(g, p, geo, q, px, py, pz, i, e8, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+                i = main_loop<kHotP, TC>(g, p, geo, q, px, py, pz, i, e8, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
               if (i >= e8 && i < e4)
-                i = main_loop<4>(g, p, geo, q, px, py, pz, i, e4, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+                i = main_loop<4, TC>(g, p, geo, q, px, py, pz, i, e4, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
               if (i >= e4 && i < e1)
-                i = main_loop<1>(g, p, geo, q, px, py, pz, i, e1, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
+                i = main_loop<1, TC>(g, p, geo, q, px, py, pz, i, e1, lo, lds_tau, lds_bitmap, box_base, ls, rec_id, lane_active, lane, acc);
               if (i >= e1) break;
               drain_l1(g, p, ps, lds_tau, px, py, pz, ls, false, rot0, lane);  // the list was too full to go on
             }
@@ -877,7 +885,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     ls.n1 = 0;
     if (DLIOM_BOX_DBG(p, 16)) {  // timing experiment: unconditional atomics of the accumulators' flush, even for zeros
 #pragma unroll
-      for (int j = 0; j < kTC; ++j) {
+      for (int j = 0; j < TC; ++j) {
         if (lane_active && j < ps.tc)
           atomicAdd(&p.sums[static_cast<size_t>(ps.j0 + j) * p.R + rot0 + lane], static_cast<unsigned long long>(acc[j]));
         acc[j] = 0u;
@@ -897,6 +905,20 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 
     st[3] = xcc;
   }
 #endif
+}
+
+
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(4, 8))) void rtcsm_score_box_kernel(
+    GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
+  score_box_body<kTC>(g, p, px, py, pz);
+}
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(3, 8))) void rtcsm_score_box_kernel_w3(
+    GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
+  score_box_body<kTC>(g, p, px, py, pz);
+}
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(3, 8))) void rtcsm_score_box_kernel_wide(
+    GridView g, Params p, const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz) {
+  score_box_body<kTCWide>(g, p, px, py, pz);
 }
 
 }  // namespace box

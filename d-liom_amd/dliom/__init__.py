@@ -43,7 +43,7 @@ ERR_PEER_FAILED = -12
 TUNE_SCORE_KERNEL, TUNE_CSM_ONE_LAUNCH_MAX, TUNE_RESERVED_TEST_HOOK, TUNE_CSM_GRID_SYNC = 0, 1, 2, 3
 HOOKS_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdliom_hooks.so")  # -DDLIOM_TEST_HOOKS build (tests only)
 
-KERNEL_RTCSM_SCORE, KERNEL_RTCSM_SELECT, KERNEL_RTCSM_RESCORE, KERNEL_CSM_EVAL, KERNEL_INSERT = range(5)
+KERNEL_RTCSM_SCORE, KERNEL_RTCSM_SELECT, KERNEL_RTCSM_RESCORE, KERNEL_CSM_EVAL, KERNEL_INSERT, KERNEL_ALLREDUCE = range(6)
 
 _f32p = C.POINTER(C.c_float)
 _f64p = C.POINTER(C.c_double)
@@ -68,7 +68,8 @@ class RtcsmWindow(C.Structure):
 
 class RtcsmStats(C.Structure):
     _fields_ = [("window", RtcsmWindow), ("num_points", C.c_int64), ("num_rescored", C.c_int64),
-                ("best_index", C.c_int64), ("score_kernel", C.c_int64), ("box_kernel_status", C.c_int64)]
+                ("best_index", C.c_int64), ("score_kernel", C.c_int64), ("box_kernel_status", C.c_int64),
+                ("box_kernel_variant", C.c_int64)]
 
 
 BOX_RAN, BOX_NOT_REQUESTED, BOX_REFUSED_SMALL, BOX_REFUSED_NO_MIRROR = 0, 1, 2, 3

@@ -256,6 +256,9 @@ typedef struct dliom_rtcsm_stats {
                              table, 0 point per lane over the leaf table */
   int64_t box_kernel_status; /* why: DLIOM_BOX_* below (a refusal is not an error -- the other kernels give the same
                                 bits 1.9 to 4.4 times slower -- but it should not go unnoticed) */
+  int64_t box_kernel_variant; /* score_kernel == 3: which instantiation ran -- 0: 27 translations per pass at four waves per
+                                 SIMD (one-pass windows), 1: the same at three waves per SIMD with larger boxes, 2: 54
+                                 translations per pass (windows of many passes); -1 otherwise */
 } dliom_rtcsm_stats;
 enum {
   DLIOM_BOX_RAN = 0,               /* the LDS-box kernel scored the volume */
@@ -812,10 +815,13 @@ enum {
   DLIOM_KERNEL_RTCSM_RESCORE = 2,
   DLIOM_KERNEL_CSM_EVAL = 3,
   DLIOM_KERNEL_INSERT = 4,
-  DLIOM_KERNEL_COUNT = 5
+  DLIOM_KERNEL_ALLREDUCE = 5,   /* dliom_rtcsm3d_match_sharded_rccl: copy in, ncclAllReduce(max, u64), copy out -- the
+                                   collective's own time on this rank's stream, the wait for the slowest peer included */
+  DLIOM_KERNEL_COUNT = 6
 };
 /* enabled: 0 off, 1 every kernel id, otherwise a mask with bit (id + 1) per timed kernel id
- * (2 = the score kernel only: what bench.py's timed region uses). */
+ * (2 = the score kernel only: what bench.py's timed region uses; 2 | 64 = score kernel and the sharded match's
+ * all-reduce). */
 int dliom_ctx_set_profiling(dliom_ctx* ctx, int enabled);
 int dliom_ctx_reset_profiling(dliom_ctx* ctx);
 int dliom_ctx_kernel_time(dliom_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);

@@ -58,6 +58,7 @@ def test_config2_full_oracle_match(dl, ctx, orc, bench_scene):
     st = rt.last_stats()
     assert st.window.num_candidates == 35937 == ref["num_candidates"] and st.num_points == 65536
     assert st.score_kernel == 3 and st.box_kernel_status == dl.BOX_RAN  # the LDS-box kernel is what bench.py times
+    assert st.box_kernel_variant == 0  # one pass of 27 translations: the four-waves-per-SIMD instantiation
     assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
     assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
     assert np.array_equal(pose, ref["pose"])
@@ -195,6 +196,7 @@ def test_config5_reduced_window(dl, ctx, orc):
     st = rt.last_stats()
     assert st.window.num_translations == 343 and st.num_points == 262144
     assert st.score_kernel == 3  # LDS-box kernel; N > box::kFlushPoints exercises the accumulator flush
+    assert st.box_kernel_variant == 2  # 343 translations: 54 per pass (round 6)
     ref = orc.rtcsm3d_match_parallel(opts, sc["init"], sc["pts"], og_hi, threads=THREADS)
     assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
     assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
@@ -207,6 +209,32 @@ def test_config5_reduced_window(dl, ctx, orc):
     sc["cloud"].close()
     g_hi.close()
     g_lo.close()
+
+
+@pytest.mark.parametrize("linear_window,translations,variant", [(0.25, 125, 1), (0.35, 343, 2), (0.45, 729, 2)])
+def test_box_kernel_instantiations_for_windows_of_several_passes(dl, ctx, orc, bench_scene, linear_window, translations, variant):
+    """Round 6: a translation window of more than one 27-translation pass runs the box kernel at three waves per SIMD with
+    21 000-cell boxes and 64-point chunks -- 27 translations per pass (variant 1) or 54 (variant 2: one staged box and one
+    rotation per point for two narrow passes' accumulators; short last passes are padded).  On the config-2 scene with a
+    0.2 degree angular window so that the oracle's FULL loop is seconds: every candidate's integer sum, the winner's
+    index, score bits and pose."""
+    g_hi, sc, og_hi = bench_scene["g_hi"], bench_scene["sc"], bench_scene["og_hi"]
+    opts = dict(DEFAULT_RTCSM, linear_search_window=linear_window, angular_search_window=float(np.deg2rad(0.2)))
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, opts)
+    score, pose = rt.Match(sc["init"], sc["cloud"], g_hi)
+    st = rt.last_stats()
+    assert st.window.num_translations == translations and st.num_points == 65536
+    assert st.score_kernel == 3 and st.box_kernel_status == dl.BOX_RAN and st.box_kernel_variant == variant, (
+        st.score_kernel, st.box_kernel_status, st.box_kernel_variant)
+    flat = orc.FlatGridIndex(og_hi)
+    want_sums, want_scores = orc.rtcsm3d_volume_fair(opts, sc["init"], sc["pts"], flat, threads=THREADS_BIG)
+    sums = rt.score_volume(sc["init"], sc["pts"], g_hi)
+    assert np.array_equal(sums.astype(np.uint64), want_sums)
+    best = int(np.argmax(want_scores))
+    _, ca = orc.rtcsm3d_candidates(opts, 0.1, sc["pts"], sc["init"])
+    assert st.best_index == best and np.float32(score).tobytes() == want_scores[best].tobytes()
+    assert np.array_equal(pose, ca[best].astype(np.float64))
+    assert rt.box_error() == 0
 
 
 def test_config5_benchmarked_window_sampled(dl, ctx, orc):

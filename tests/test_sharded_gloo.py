@@ -1,8 +1,14 @@
-"""World-size-2 and world-size-8 gloo tests (CPU) of the candidate-sharding protocols of dliom.sharded: N ranks,
-each owning a contiguous share of the candidate rotations, reach the unsharded winner through the two MAX
-all-reduces of the two-phase protocol and through the ONE exchange of dliom_rtcsm3d_match_sharded's.  The local shard is backed by the oracle's exact per-candidate scores here (no GPU
-in this container); on a GPU the same protocol function drives dliom.RtcsmShard
-(tests/test_gpu_parity.py::test_sharded_match_single_process)."""
+"""World-size-2 and world-size-8 gloo tests (CPU) of the candidate-sharding PROTOCOL (dliom/sharded.py): N ranks, each
+owning a contiguous share of the candidate rotations, reach the unsharded winner through the two MAX all-reduces of the
+two-phase protocol and through the ONE exchange of the one-collective protocol.
+
+What this file does NOT cover: the product's C entry points.  There is no GPU in this container, so the local shard
+here is an oracle-backed stand-in (OracleShard: the oracle's exact per-candidate scores behind the interface of
+dliom.RtcsmShard) -- the packing, the tie rule, the failing-rank word and the collectives' control flow are what is
+tested.  dliom_rtcsm3d_match_sharded / _sharded_rccl themselves run in tests/test_gpu_sharded.py (eight processes
+through the C entry point on one GPU, a failing rank, a one-rank RCCL communicator) and
+tests/test_gpu_parity.py::test_sharded_match_single_process; bench.py --gpus N adds the per-rank winner check against
+rank 0's unsharded match (benchlib/multigpu.py)."""
 import os
 import socket
 import sys

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "d-liom_amd")):
     sys.path.insert(0, p)
-import bench  # noqa: E402
+import benchlib as bench  # noqa: E402  (constants + build_scene)
 import dliom as dl  # noqa: E402
 from dliom import synth  # noqa: E402
 
