@@ -488,6 +488,10 @@ class RangeDataSynchronizer {
       : expected_sensor_ids_(expected_range_sensor_ids.begin(), expected_range_sensor_ids.end()),
         prior_sensor_id_(expected_range_sensor_ids.empty() ? std::string() : expected_range_sensor_ids.front()) {}
 
+  // true: `sensor_id` is the only expected range sensor (no secondary cloud can be pending)
+  bool SingleSensor(const std::string& sensor_id) const {
+    return expected_sensor_ids_.size() == 1 && sensor_id == prior_sensor_id_ && secondary_cloud_.empty();
+  }
   sensor::TimedPointCloudOriginData AddRangeData(const std::string& sensor_id, const sensor::TimedPointCloudData& data,
                                                  bool descrew) {
     if (expected_sensor_ids_.count(sensor_id) == 0)
@@ -740,6 +744,29 @@ class LocalTrajectoryBuilder3D {
   void AddOdometryData(const sensor::OdometryData&) {}
 
   std::unique_ptr<MatchingResult> AddRangeData(const std::string& sensor_id, const sensor::TimedPointCloudData& unsynchronized) {
+    // One range sensor, its own time stamps, one scan per result -- D-LIOM's configurations: the synchronizer would hand
+    // the scan back as it came (range_data_synchronizer.cc: no secondary cloud -> ToOriginData) and the accumulation holds
+    // one scan.  The scan goes to the device as it lies in the caller's vector (TimedPoint = packed x, y, z, t) and
+    // AddRangeData is ONE library call; the copies the general path makes (the synchronizer's cloud, its origin-tagged
+    // ranges, the packed staging vector: ~3 MB of host traffic and two reallocating push_back loops per 64 x 1024 scan)
+    // were a quarter of the adapter's time per scan (round 6, tools/wref_cpp.cc).
+    if (synchronizer_.SingleSensor(sensor_id) && !options_.enable_manual_descrew && options_.num_accumulated_range_data == 1) {
+      if (unsynchronized.ranges.empty() || !imu_initialized_ || !have_prediction_) return nullptr;
+      if (unsynchronized.ranges.back().t > 0.1f) Check(DLIOM_ERR_INVALID_ARGUMENT, "CHECK_LE(ranges.back().point_time[3], 0.1f)");
+      static_assert(sizeof(sensor::TimedPoint) == 16, "packed x, y, z, t");
+      double prev[7], vel[3], bias[6], predicted[7], pvel[3];
+      Check(dliom_imu_window_state(window_, 0, prev, vel, bias), "dliom_imu_window_state");
+      Check(dliom_imu_window_predict(window_, predicted, pvel), "dliom_imu_window_predict");
+      accumulation_started_ = std::chrono::steady_clock::now();
+      const float origin[3] = {unsynchronized.origin.x, unsynchronized.origin.y, unsynchronized.origin.z};
+      dliom_cloud* cloud = nullptr;
+      float origin_in_tracking[3], current_pose[7];
+      Check(dliom_add_range_data(context_->get(), prev, predicted, options_.scan_period, &unsynchronized.ranges[0].x,
+                                 static_cast<int64_t>(unsynchronized.ranges.size()), origin, options_.min_range, options_.max_range,
+                                 options_.voxel_filter_size, &cloud, origin_in_tracking, current_pose),
+            "AddRangeData (de-skew, filters, tracking frame)");
+      return AddAccumulatedRangeData(unsynchronized.time, current_pose, origin_in_tracking, cloud);
+    }
     const sensor::TimedPointCloudOriginData sync =
         synchronizer_.AddRangeData(sensor_id, unsynchronized, options_.enable_manual_descrew);
     if (sync.ranges.empty() || !imu_initialized_ || !have_prediction_) return nullptr;
@@ -854,14 +881,14 @@ class LocalTrajectoryBuilder3D {
     result->time = time;
     result->local_pose = transform::Rigid3d::FromArray(opt);
     // filtered_range_data_in_local = TransformRangeData(in_tracking, opt_pose.cast<float>())
-    std::vector<float> pts(3 * static_cast<size_t>(n));
-    Check(dliom_cloud_download(cloud, pts.data()), "dliom_cloud_download");
+    // (on the device, where the cloud is: one kernel writes the moved points into pinned memory -- a download followed by
+    // a host loop over ~30 000 returns was a third of the adapter's time per scan, round 6)
     float pf[7];
     for (int i = 0; i < 7; ++i) pf[i] = static_cast<float>(opt[i]);
     result->range_data_in_local.origin = TransformPoint(pf, origin[0], origin[1], origin[2]);
     result->range_data_in_local.returns.resize(static_cast<size_t>(n));
-    for (int64_t i = 0; i < n; ++i)
-      result->range_data_in_local.returns[static_cast<size_t>(i)] = TransformPoint(pf, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    static_assert(sizeof(sensor::Vector3f) == 12, "packed xyz");
+    Check(dliom_cloud_download_transformed(cloud, pf, &result->range_data_in_local.returns[0].x), "TransformRangeData");
     // ComputeHistogram (.cc:605-610) reads the same filtered cloud as the insertion and writes nothing the insertion
     // reads: its kernels are started first, on the context's auxiliary stream, and run beside the insertion's
     const float rot_wxyz[4] = {pf[3], pf[4], pf[5], pf[6]};
@@ -904,13 +931,8 @@ class LocalTrajectoryBuilder3D {
         if (hs == DLIOM_ERR_CAPACITY) {
           ++histogram_host_fallbacks_;
           const float rot[7] = {0.f, 0.f, 0.f, pf[3], pf[4], pf[5], pf[6]};
-          std::vector<float> aligned(3 * static_cast<size_t>(n));
-          for (int64_t i = 0; i < n; ++i) {
-            const sensor::Vector3f a = TransformPoint(rot, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-            aligned[3 * i] = a.x;
-            aligned[3 * i + 1] = a.y;
-            aligned[3 * i + 2] = a.z;
-          }
+          std::vector<float> aligned(3 * static_cast<size_t>(n));  // (rare path: the rotation on the device all the same)
+          Check(dliom_cloud_download_transformed(cloud, rot, aligned.data()), "TransformPointCloud (gravity alignment)");
           hs = dliom_rotational_histogram(aligned.data(), n, options_.rotational_histogram_size,
                                           ir->rotational_scan_matcher_histogram.data());
         }

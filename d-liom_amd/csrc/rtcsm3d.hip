@@ -1302,14 +1302,15 @@ static int launch_score_box(dliom_ctx* ctx, const dliom_cloud& cloud, const Grid
   //      same kernel at three waves per SIMD 0.71, with 21 000-cell boxes 0.70, with 64-point chunks 0.70-0.72)
   //   1  the same at three waves per SIMD (168 registers) with 21 000-cell boxes: windows of several passes, whose
   //      translations reach further and make the boxes larger (config 5: 221 -> 195 ms)
-  //   2  54 translations per pass at three waves per SIMD, 21 000-cell boxes: one staged box and one rotation per point
-  //      serve two narrow passes (config 5: 186 ms) -- where its padding (the last pass is filled up to 54) costs less
-  //      than the 15 % of vector instructions per lookup it saves
+  //   2  49 translations per pass at three waves per SIMD, 21 000-cell boxes: one staged box and one rotation per point
+  //      serve 49 translations (a whole z-plane of config 5's 7^3 window: 159 ms; with 54 per pass 180) -- where its
+  //      padding costs less than the 13 % of vector instructions per lookup it saves, by a margin (the wide kernel is
+  //      measured at 343 translations only)
   static const int forced_variant = env_int("DLIOM_BOX_VARIANT", -1);
   const auto padded = [T](int tc) { return ((T + tc - 1) / tc) * tc; };
   const int variant = forced_variant >= 0 && forced_variant <= 2
                           ? forced_variant
-                          : (T <= kTC ? 0 : (0.85 * padded(kTCWide) < padded(kTC) ? 2 : 1));
+                          : (T <= kTC ? 0 : (0.87 * padded(kTCWide) < 0.9 * padded(kTC) ? 2 : 1));
   const int TC = variant == 2 ? kTCWide : kTC;
   static const int forced_cells = env_int("DLIOM_BOX_CELLS", 0);
   const int cells = forced_cells > 0 ? forced_cells : (variant == 0 ? 14336 : 21000);

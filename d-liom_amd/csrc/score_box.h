@@ -55,7 +55,14 @@ namespace dliom {
 namespace box {
 
 constexpr int kTC = 27;        // translations per pass of the narrow kernels (register accumulators)
-constexpr int kTCWide = 54;    // ... of the wide kernel (round 6): two narrow passes' accumulators, one box, one rotation per point
+#if !defined(DLIOM_EXPERIMENTS) || !defined(DLIOM_BOX_TC_WIDE)
+#undef DLIOM_BOX_TC_WIDE
+#define DLIOM_BOX_TC_WIDE 49
+#endif
+// ... of the wide kernel (round 6): one staged box and one rotation per point serve 49 translations.  49 = 7 x 7: with a
+// linear window of three cells (BASELINE config 5) a pass is one z-plane of the 7^3 translations -- no padding (54 fills
+// the last pass of 343 up to 378: measured 180 ms against 159 on config 5) and a reach of one cell along z
+constexpr int kTCWide = DLIOM_BOX_TC_WIDE;
 #if !defined(DLIOM_EXPERIMENTS) || !defined(DLIOM_BOX_MAX_WAVES)
 #undef DLIOM_BOX_MAX_WAVES
 #define DLIOM_BOX_MAX_WAVES 4
@@ -640,8 +647,8 @@ __global__ __launch_bounds__(256) void rtcsm_box_extent_kernel(Params p, float i
 // The kernel's body for TC translations per pass.  Three instantiations (round 6, measured on BASELINE configs 2 and 5,
 // DESIGN.md 3.1): <27> at four waves per SIMD (128 registers, 14 336-cell boxes: the fastest where one pass holds the
 // whole translation window -- config 2: 0.69 ms against 0.71 at three waves, with or without larger boxes);
-// <27> at three waves per SIMD (168 registers, 21 000-cell boxes) and <54> at three waves per SIMD for windows of
-// several passes, where the translations' reach makes the boxes larger (config 5: 221 -> 195 -> 186 ms).
+// <27> at three waves per SIMD (168 registers, 21 000-cell boxes, 64-point chunks) and <49> at three waves per SIMD for
+// windows of several passes, where the translations' reach makes the boxes larger (config 5: 221 -> 188 -> 159 ms).
 template <int TC>
 __device__ __forceinline__ void score_box_body(const GridView& g, const Params& p, const float* __restrict__ px,
                                                const float* __restrict__ py, const float* __restrict__ pz) {

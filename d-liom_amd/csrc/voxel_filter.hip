@@ -748,6 +748,31 @@ int adaptive_voxel_filter_cloud(dliom_ctx* ctx, const dliom_cloud& in, const dli
 
 using namespace dliom;
 
+namespace dliom {
+struct DownloadPose {
+  Quat4 q;
+  float t[3];
+  int apply;
+};
+__global__ __launch_bounds__(256) void download_packed_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ z, int n, DownloadPose p,
+                                                              float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float px = x[i], py = y[i], pz = z[i];
+  if (p.apply) {
+    float rx, ry, rz;
+    rotate_point(p.q, px, py, pz, rx, ry, rz);
+    px = rx + p.t[0];
+    py = ry + p.t[1];
+    pz = rz + p.t[2];
+  }
+  out[3 * i] = px;
+  out[3 * i + 1] = py;
+  out[3 * i + 2] = pz;
+}
+}  // namespace dliom
+
 extern "C" {
 
 int dliom_cloud_voxel_filter(dliom_ctx* ctx, const dliom_cloud* in, float size, dliom_cloud** out) {
@@ -779,21 +804,48 @@ int dliom_cloud_adaptive_voxel_filter_pair(dliom_ctx* ctx, const dliom_cloud* in
   return st;
 }
 
-int dliom_cloud_download(const dliom_cloud* cloud, float* points_xyz) {
-  if (cloud == nullptr || (cloud->n > 0 && points_xyz == nullptr)) return DLIOM_ERR_INVALID_ARGUMENT;
+// dliom_cloud_download / _transformed: the points interleaved (and, for the second, moved by a float pose:
+// sensor::TransformPointCloud's rotation * p + translation, point_cloud.cc:25-33, in Eigen's operation order) by ONE
+// kernel that writes packed xyz straight into the context's pinned, device-visible staging block, in pieces of what that
+// block holds.  Until round 6 a download was a stream synchronise, three pageable hipMemcpy and a host loop -- ~0.1 ms
+// for the 300 points of a filtered cloud, and LocalTrajectoryBuilder3D's result needs three downloads a scan.
+static int download_packed(const dliom_cloud* cloud, const float* pose7, float* points_xyz) {
   const size_t n = static_cast<size_t>(cloud->n);
   if (n == 0) return DLIOM_OK;
-  std::vector<float> soa(3 * n);
-  DLIOM_HIP_TRY(hipStreamSynchronize(cloud->ctx->stream));
-  DLIOM_HIP_TRY(hipMemcpy(soa.data(), cloud->d_x, n * 4, hipMemcpyDeviceToHost));
-  DLIOM_HIP_TRY(hipMemcpy(soa.data() + n, cloud->d_y, n * 4, hipMemcpyDeviceToHost));
-  DLIOM_HIP_TRY(hipMemcpy(soa.data() + 2 * n, cloud->d_z, n * 4, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < n; ++i) {
-    points_xyz[3 * i] = soa[i];
-    points_xyz[3 * i + 1] = soa[n + i];
-    points_xyz[3 * i + 2] = soa[2 * n + i];
+  dliom_ctx* ctx = cloud->ctx;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t room = (ctx->pinned_bytes - 8192) / 12;  // (the block's last 4 KB hold other calls' words)
+  DownloadPose dp;
+  dp.apply = pose7 != nullptr ? 1 : 0;
+  if (pose7 != nullptr) {
+    dp.q = Quat4{pose7[3], pose7[4], pose7[5], pose7[6]};
+    dp.t[0] = pose7[0];
+    dp.t[1] = pose7[1];
+    dp.t[2] = pose7[2];
+  } else {
+    dp.q = Quat4{1.f, 0.f, 0.f, 0.f};
+    dp.t[0] = dp.t[1] = dp.t[2] = 0.f;
+  }
+  float* staged = static_cast<float*>(ctx->pinned);
+  for (size_t first = 0; first < n; first += room) {
+    const size_t m = std::min(room, n - first);
+    hipLaunchKernelGGL(download_packed_kernel, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, ctx->stream, cloud->d_x + first,
+                       cloud->d_y + first, cloud->d_z + first, static_cast<int>(m), dp, staged);
+    DLIOM_HIP_TRY(hipGetLastError());
+    DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::memcpy(points_xyz + 3 * first, staged, m * 12);
   }
   return DLIOM_OK;
+}
+
+int dliom_cloud_download(const dliom_cloud* cloud, float* points_xyz) {
+  if (cloud == nullptr || (cloud->n > 0 && points_xyz == nullptr)) return DLIOM_ERR_INVALID_ARGUMENT;
+  return download_packed(cloud, nullptr, points_xyz);
+}
+
+int dliom_cloud_download_transformed(const dliom_cloud* cloud, const float pose[7], float* points_xyz) {
+  if (cloud == nullptr || pose == nullptr || (cloud->n > 0 && points_xyz == nullptr)) return DLIOM_ERR_INVALID_ARGUMENT;
+  return download_packed(cloud, pose, points_xyz);
 }
 
 }  // extern "C"

@@ -225,6 +225,7 @@ SYMBOLS = [
     ("dliom_cloud_adaptive_voxel_filter_pair", C.c_int, [_vp, _vp, C.POINTER(AdaptiveVoxelFilterOptions),
                                                          C.POINTER(AdaptiveVoxelFilterOptions), C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_cloud_download", C.c_int, [_vp, _f32p]),
+    ("dliom_cloud_download_transformed", C.c_int, [_vp, _f32p, _f32p]),
     ("dliom_rtcsm3d_match", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _f64p, _f32p]),
     ("dliom_rtcsm3d_match_cloud", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, _f64p, _f32p]),
     ("dliom_rtcsm3d_shard_begin", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, C.c_int, C.c_int,
@@ -522,9 +523,14 @@ class PointCloud:
                                                               C.byref(hb)), "dliom_cloud_adaptive_voxel_filter_pair")
         return PointCloud(self.ctx, _handle=ha), PointCloud(self.ctx, _handle=hb)
 
-    def download(self):
+    def download(self, pose7=None):
+        """The points, packed xyz; pose7 (float [t, q]): sensor::TransformPointCloud(cloud, pose) applied on the device."""
         out = np.zeros((self.n, 3), dtype=np.float32)
-        _check(self._L.dliom_cloud_download(self.h, _p(out, _f32p)), "dliom_cloud_download")
+        if pose7 is None:
+            _check(self._L.dliom_cloud_download(self.h, _p(out, _f32p)), "dliom_cloud_download")
+        else:
+            _check(self._L.dliom_cloud_download_transformed(self.h, _p(_f32(pose7), _f32p), _p(out, _f32p)),
+                   "dliom_cloud_download_transformed")
         return out
 
     def close(self):

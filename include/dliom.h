@@ -257,7 +257,7 @@ typedef struct dliom_rtcsm_stats {
   int64_t box_kernel_status; /* why: DLIOM_BOX_* below (a refusal is not an error -- the other kernels give the same
                                 bits 1.9 to 4.4 times slower -- but it should not go unnoticed) */
   int64_t box_kernel_variant; /* score_kernel == 3: which instantiation ran -- 0: 27 translations per pass at four waves per
-                                 SIMD (one-pass windows), 1: the same at three waves per SIMD with larger boxes, 2: 54
+                                 SIMD (one-pass windows), 1: the same at three waves per SIMD with larger boxes, 2: 49
                                  translations per pass (windows of many passes); -1 otherwise */
 } dliom_rtcsm_stats;
 enum {
@@ -447,6 +447,11 @@ int dliom_cloud_adaptive_voxel_filter_pair(dliom_ctx* ctx, const dliom_cloud* in
                                            dliom_cloud** out_second);
 /* The points of a cloud in input order, packed xyz (room for dliom_cloud_size points). */
 int dliom_cloud_download(const dliom_cloud* cloud, float* points_xyz);
+/* ... moved by a float pose [tx, ty, tz, qw, qx, qy, qz]: sensor::TransformPointCloud(cloud, pose) (sensor/point_cloud.cc:25-33,
+ * rotation * p + translation in Eigen's operation order) -- LocalTrajectoryBuilder3D's
+ * filtered_range_data_in_local = TransformRangeData(filtered_range_data_in_tracking, opt_pose.cast<float>())
+ * (local_trajectory_builder_3d.cc:556-559) without a host loop over the returns. */
+int dliom_cloud_download_transformed(const dliom_cloud* cloud, const float pose[7], float* points_xyz);
 /* The same filters on host buffers (the reference's own placement): out_xyz has room for n points;
  * *num_out receives the survivors (first point per voxel). */
 int dliom_voxel_filter(float size, const float* points_xyz, int64_t n, float* out_xyz, int64_t* num_out);

@@ -196,7 +196,7 @@ def test_config5_reduced_window(dl, ctx, orc):
     st = rt.last_stats()
     assert st.window.num_translations == 343 and st.num_points == 262144
     assert st.score_kernel == 3  # LDS-box kernel; N > box::kFlushPoints exercises the accumulator flush
-    assert st.box_kernel_variant == 2  # 343 translations: 54 per pass (round 6)
+    assert st.box_kernel_variant == 2  # 343 translations: 49 per pass, one z-plane of the window (round 6)
     ref = orc.rtcsm3d_match_parallel(opts, sc["init"], sc["pts"], og_hi, threads=THREADS)
     assert st.best_index == ref["best_index"], (st.best_index, ref["best_index"])
     assert np.float32(score).tobytes() == np.float32(ref["score"]).tobytes()
@@ -214,8 +214,8 @@ def test_config5_reduced_window(dl, ctx, orc):
 @pytest.mark.parametrize("linear_window,translations,variant", [(0.25, 125, 1), (0.35, 343, 2), (0.45, 729, 2)])
 def test_box_kernel_instantiations_for_windows_of_several_passes(dl, ctx, orc, bench_scene, linear_window, translations, variant):
     """Round 6: a translation window of more than one 27-translation pass runs the box kernel at three waves per SIMD with
-    21 000-cell boxes and 64-point chunks -- 27 translations per pass (variant 1) or 54 (variant 2: one staged box and one
-    rotation per point for two narrow passes' accumulators; short last passes are padded).  On the config-2 scene with a
+    21 000-cell boxes and 64-point chunks -- 27 translations per pass (variant 1) or 49 (variant 2: one staged box and one
+    rotation per point for 49 accumulators; short last passes are padded).  On the config-2 scene with a
     0.2 degree angular window so that the oracle's FULL loop is seconds: every candidate's integer sum, the winner's
     index, score bits and pose."""
     g_hi, sc, og_hi = bench_scene["g_hi"], bench_scene["sc"], bench_scene["og_hi"]

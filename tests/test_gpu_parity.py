@@ -1841,3 +1841,19 @@ def test_memory_accounting_and_the_mirror_budget(dl, orc):
     assert c.memory_stats()["mirror_bytes"] == 0 and c.memory_stats()["leaf_pool_bytes"] == 0
     assert c.memory_stats()["scratch_bytes"] > 0
     c.close()
+
+
+@pytest.mark.parametrize("n", [1, 333, 100003])
+def test_cloud_download_transformed_equals_transform_point_cloud(dl, ctx, orc, n):
+    """dliom_cloud_download_transformed (round 6: LocalTrajectoryBuilder3D's filtered_range_data_in_local, .cc:556-559, made on
+    the device): sensor::TransformPointCloud in Eigen's operation order, bit for bit the oracle's Rigid3f * point; the
+    plain download is the input; 100 003 points take two pieces of the pinned staging block."""
+    rng = np.random.RandomState(n)
+    pts = (rng.uniform(-40, 40, size=(n, 3))).astype(np.float32)
+    pose = np.concatenate([rng.uniform(-5, 5, 3), orc.angle_axis_quat(0.7, rng.uniform(-1, 1, 3), normalize_axis=True)]).astype(np.float32)
+    cloud = dl.PointCloud(ctx, pts)
+    assert np.array_equal(cloud.download(), pts)
+    got = cloud.download(pose)
+    want = orc.transform_points(pose, pts)
+    assert got.tobytes() == want.tobytes()
+    cloud.close()

@@ -23,7 +23,7 @@ if os.path.exists(bj) and os.path.getsize(bj) > 0:
     shutil.copy(bj, os.path.join(dst, "%s_bench_under_kernel_trace.json" % tag))
 
 counters, kernel = {}, None
-for f in sorted(glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+for f in sorted(glob.glob(os.path.join(src, "pmc[0-9]", "**", "*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):
         if "rtcsm_score" not in row["Kernel_Name"]:
             continue
@@ -51,6 +51,36 @@ if "FETCH_SIZE" in summary:
     out["hbm_bytes_per_launch"] = 2.0 * out["fetch_bytes_raw"] + out["write_bytes_raw"]
 if summary:  # (a run of selected parts without the PMC passes keeps the file there is)
     json.dump(out, open(os.path.join(dst, "%s_pmc_score_kernel.json" % tag), "w"), indent=1)
+# config 5's score kernel (tools/c5bench.py under rocprofv3 --pmc: the wide instantiation, round 6)
+c5 = {}
+for f in sorted(glob.glob(os.path.join(src, "pmc5_*", "**", "*counter_collection.csv"), recursive=True)):
+    for row in csv.DictReader(open(f)):
+        if "rtcsm_score_box" in row["Kernel_Name"]:
+            c5.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            c5_kernel = row["Kernel_Name"].split("(")[0]
+if c5:
+    import re
+    s5 = {k: {"launches": len(v), "mean": sum(v) / len(v)} for k, v in c5.items()}
+    o5 = {"kernel": c5_kernel, "counters": s5, "notes": "rocprofv3 --pmc over tools/c5bench.py (BASELINE config 5's search), per-dispatch means"}
+    for lg in sorted(glob.glob(os.path.join(src, "pmc5_*.log"))):
+        m = re.search(r"score kernel ([\d.]+) ms .* C=(\d+) N=(\d+)", open(lg).read())
+        if m:
+            o5["workload"] = {"num_candidates": int(m.group(2)), "num_points": int(m.group(3)), "score_kernel_ms_under_pmc": float(m.group(1))}
+            break
+    if "workload" in o5 and "SQ_INSTS_VALU" in s5:
+        wp = o5["workload"]["num_points"] * o5["workload"]["num_candidates"] / 64.0
+        o5["valu_instructions_per_wave_pair"] = s5["SQ_INSTS_VALU"]["mean"] / wp
+    if "SQ_ACTIVE_INST_VALU" in s5 and "SQ_BUSY_CYCLES" in s5:
+        o5["sq_active_inst_valu_over_busy_cycles"] = s5["SQ_ACTIVE_INST_VALU"]["mean"] / s5["SQ_BUSY_CYCLES"]["mean"]
+    if "SQ_LDS_BANK_CONFLICT" in s5 and "SQ_LDS_IDX_ACTIVE" in s5:
+        o5["lds_bank_conflict_frac"] = s5["SQ_LDS_BANK_CONFLICT"]["mean"] / s5["SQ_LDS_IDX_ACTIVE"]["mean"]
+    if "FETCH_SIZE" in s5:
+        o5["hbm_bytes_per_launch"] = 2.0 * s5["FETCH_SIZE"]["mean"] * 1024.0 + s5.get("WRITE_SIZE", {"mean": 0.0})["mean"] * 1024.0
+    json.dump(o5, open(os.path.join(dst, "%s_pmc_score_kernel_config5.json" % tag), "w"), indent=1)
+for name, o in (("wref_cpp.json", "%s_wref_cpp.json"), ("imu_window_cost.json", "%s_imu_window_cost.json")):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, os.path.join(dst, o % tag))
 for name, o in (("bench_full.json", "%s_bench.json"), ("wref_full.json", "%s_wref_full.json"), ("wref.json", "%s_wref.json"),
                 ("wref_stages.json", "%s_wref_stages.json"), ("stream.json", "%s_stream_config3.json"),
                 ("stream_gentle.json", "%s_stream_config3_gentle.json"), ("config5_bench.json", "%s_config5_bench.json"),

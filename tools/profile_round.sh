@@ -12,6 +12,9 @@
 #   hist      ComputeHistogram on the device against the oracle, per scene
 #   voxel     the voxel filter's kernels under the kernel trace
 #   tests     the GPU test log
+#   wrefcpp   W-ref through the C++ adapters, timed in C++ (tools/wref_cpp.py)
+#   pmc5      PMC passes over config 5's score kernel (tools/c5bench.py: the wide instantiation)
+#   imucost   WindowOptimize's host cost per scan by mode (tools/imu_window_cost.py)
 # A second argument selects parts (quoted, space separated); without it everything runs and the directory starts empty.
 set -u
 TAG=${1:-r5}
@@ -68,6 +71,19 @@ if want loop; then
   timeout 200 python tools/fast_csm_bench.py --full --reps 9 > $OUT/fast_csm_full.json 2>> $OUT/fast_csm.err
   timeout 300 python tools/mirror_window_stream.py > $OUT/mirror_window_stream.json 2> $OUT/mirror.err
   (cd tools/ubench && ./graph_latency) > $OUT/graph_latency.txt 2>&1
+fi
+if want wrefcpp; then timeout 900 python tools/wref_cpp.py > $OUT/wref_cpp.json 2> $OUT/wref_cpp.err; echo "wrefcpp rc=$?"; fi
+if want imucost; then timeout 300 python tools/imu_window_cost.py > $OUT/imu_window_cost.json 2> $OUT/imu_window_cost.err; fi
+if want pmc5; then
+  cd /tmp
+  i=0
+  for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+    timeout 300 rocprofv3 --pmc $P --kernel-include-regex "rtcsm_score_box" --output-format csv -d $OUT/pmc5_$i -o p -- python $R/tools/c5bench.py --reps 2 --check 0 > $OUT/pmc5_$i.log 2>&1
+    echo "pmc5 pass $i rc=$?"
+    i=$((i+1))
+  done
+  cd $R
 fi
 if want hist; then timeout 300 python tools/hist_bench.py --check > $OUT/hist_bench.json 2> $OUT/hist_bench.err; fi
 if want tests; then timeout 900 python -m pytest tests -q -m gpu > $OUT/gputest.log 2>&1; tail -3 $OUT/gputest.log; fi
