@@ -22,5 +22,17 @@ def wref_line(dl, ctx, cpu):
     # ComputeHistogram, returns to 80 m) -- the cube has neither floor nor far returns inside the beams
     for name in ("trajectory_builder_3d", "basic_config_3d"):
         out[name + "_yard"] = wref_full.line(dl, ctx, name, scans=24, warmup=4, cpu_scans=20, cpu=cpu, scene="ground")
+    # round 6: the same streams through the C++ adapters, timed in C++ (tools/wref_cpp.cc: LocalTrajectoryBuilder3D's
+    # AddImuData / AddRangeData with the whole MatchingResult assembled -- what a cartographer process calls; the lines
+    # above drive the C ABI from Python, whose per-call overhead is in their figures).  One run per stream here.
+    try:
+        import wref_cpp
+        from dliom import synth
+        cpp = wref_cpp.measure(dl, synth, scans=24, warmup=4, runs=1)
+        for k, v in cpp.items():
+            if k in out:
+                out[k]["cpp_adapter"] = {x: v[x] for x in ("harness", "scans_per_s", "p50_ms", "p99_ms", "read_backs_per_scan", "results", "inserted")}
+    except Exception as e:  # g++ missing on the box, ...: the Python-driven lines stand
+        out["cpp_adapter_error"] = ("%s: %s" % (type(e).__name__, e))[:300]
     return out
 

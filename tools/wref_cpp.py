@@ -49,6 +49,41 @@ def write_stream(dl, path, cfg, T, clouds, imus, state0, warmup, histogram_size=
     w.close()
 
 
+def measure(dl, synth, scans=24, warmup=4, runs=3, compare=False):
+    """{options[_yard]: line} for both option sets on both scenes; the harness is compiled once."""
+    import wref_full
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build(tmp)
+        for scene in ("cube", "ground"):
+            with synth.scene(scene):
+                if scene == "cube":
+                    synth.set_trajectory(10.0, 0.4)
+                T, clouds, imus, state0 = wref_full.make_stream(synth, scans, 64, 1024)
+            for name, cfg in wref_full.option_sets().items():
+                path, poses_path = os.path.join(tmp, "stream.bin"), os.path.join(tmp, "poses.bin")
+                write_stream(dl, path, cfg, T, clouds, imus, state0, warmup)
+                got_runs = []
+                for _ in range(runs):  # a fresh process each: the best run is the harness's figure, all of them are printed
+                    r = subprocess.run([exe, path, poses_path], capture_output=True, text=True, timeout=600)
+                    if r.returncode != 0:
+                        raise RuntimeError("wref_cpp failed: " + (r.stdout + r.stderr)[-400:])
+                    got_runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+                best = max(got_runs, key=lambda x: x["scans_per_s"])
+                line = dict(best, options=name, scene=scene, returns_per_scan=int(np.mean([len(c) for c in clouds])),
+                            scans_per_s_all_runs=[x["scans_per_s"] for x in got_runs], imu_window=cfg["window"])
+                if compare:
+                    ctx = dl.Context(0)
+                    _, poses, _, _ = wref_full.run_chain(dl, cfg, T, clouds, imus, state0, True, ctx=ctx)
+                    got = np.fromfile(poses_path, dtype=np.float64).reshape(-1, 7)
+                    have = np.linalg.norm(got[:, 3:], axis=1) > 0  # scans the adapter returned a result for
+                    line["pose_difference_to_python_driven_chain_m"] = float(np.max(np.linalg.norm(got[have, :3] - poses[have, :3], axis=1)))
+                    line["results_compared"] = int(have.sum())
+                    ctx.close()
+                out[name + ("" if scene == "cube" else "_yard")] = line
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=24)  # the cube scene's arc leaves its room after ~30 scans (wref_full.py uses 24 too)
@@ -59,35 +94,7 @@ def main():
     from dliom import synth
     import wref_full
     dl.load_library()
-    out = {}
-    with tempfile.TemporaryDirectory() as tmp:
-        exe = build(tmp)
-        for scene in ("cube", "ground"):
-            with synth.scene(scene):
-                if scene == "cube":
-                    synth.set_trajectory(10.0, 0.4)
-                T, clouds, imus, state0 = wref_full.make_stream(synth, a.scans, 64, 1024)
-            for name, cfg in wref_full.option_sets().items():
-                path, poses_path = os.path.join(tmp, "stream.bin"), os.path.join(tmp, "poses.bin")
-                write_stream(dl, path, cfg, T, clouds, imus, state0, a.warmup)
-                runs = []
-                for _ in range(3):  # a fresh process each: the best of three is the harness's figure, all three are printed
-                    r = subprocess.run([exe, path, poses_path], capture_output=True, text=True, timeout=600)
-                    if r.returncode != 0:
-                        raise SystemExit("wref_cpp failed: " + r.stdout + r.stderr)
-                    runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-                best = max(runs, key=lambda x: x["scans_per_s"])
-                line = dict(best, options=name, scene=scene, returns_per_scan=int(np.mean([len(c) for c in clouds])),
-                            scans_per_s_all_runs=[x["scans_per_s"] for x in runs], imu_window=cfg["window"])
-                if a.compare:
-                    ctx = dl.Context(0)
-                    _, poses, _, _ = wref_full.run_chain(dl, cfg, T, clouds, imus, state0, True, ctx=ctx)
-                    got = np.fromfile(poses_path, dtype=np.float64).reshape(-1, 7)
-                    have = np.linalg.norm(got[:, 3:], axis=1) > 0  # scans the adapter returned a result for
-                    line["pose_difference_to_python_driven_chain_m"] = float(np.max(np.linalg.norm(got[have, :3] - poses[have, :3], axis=1)))
-                    line["results_compared"] = int(have.sum())
-                    ctx.close()
-                out[name + ("" if scene == "cube" else "_yard")] = line
+    out = measure(dl, synth, a.scans, a.warmup, runs=3, compare=a.compare)
     print(json.dumps(out))
 
 
