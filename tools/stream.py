@@ -53,7 +53,10 @@ def main():
     state = synth.trajectory_state(0.0)  # initialised like the reference's static initialisation would
 
     def make_window():
-        w = dl.ImuWindow(acc_noise=noise[0], gyr_noise=noise[1], acc_bias_noise=noise[2], gyr_bias_noise=noise[3])
+        # WindowOptimize by the reference's rule (round 6, what the C++ adapter runs by default): every key until the graph
+        # reset at submaps.num_range_data (160), ISAM2's relinearisation threshold
+        w = dl.ImuWindow(acc_noise=noise[0], gyr_noise=noise[1], acc_bias_noise=noise[2], gyr_bias_noise=noise[3],
+                         window_size=0, graph_reset_every=160)
         w.initialize(state[:7], state[7:10], np.zeros(6))
         return w
 
