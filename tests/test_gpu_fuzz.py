@@ -46,3 +46,11 @@ def test_fuzz_round3_slice(capsys):
     std::sort's order of equal keys up to 30 000 keys, AddRangeData under random motion (tools/fuzz_round3.py)."""
     out = _run("fuzz_round3", ["--cases", "300", "--seed", "93000", "--seconds", "75"], capsys)
     assert "round-3 fuzz ok" in out
+
+
+def test_fuzz_box_variants_slice(capsys):
+    """The box score kernel's three instantiations (round 6) against the oracle's FULL candidate loop on random scenes:
+    linear windows of 1 to 4 cells, random resolutions and initial orientations, 20 000 - 70 000 returns
+    (tools/fuzz_box_variants.py): every integer sum, winner index, score bits, pose."""
+    out = _run("fuzz_box_variants", ["--cases", "40", "--seed", "96000", "--seconds", "60"], capsys)
+    assert "box variant fuzz ok" in out
