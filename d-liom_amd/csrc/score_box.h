@@ -80,7 +80,7 @@ constexpr int kL2Cap = 128;    // level-2 list: (level-1 slot, translation)
 constexpr int kHotP = DLIOM_BOX_HOT_P;  // points per hot-loop iteration (8 or 4)
 #if !defined(DLIOM_EXPERIMENTS) || !defined(DLIOM_BOX_EXP)
 #undef DLIOM_BOX_EXP
-#define DLIOM_BOX_EXP 0  // 1, 2, 3: timing experiments of the hot loop (wrong sums; -DDLIOM_EXPERIMENTS builds only)
+#define DLIOM_BOX_EXP 0  // 1, 2, 3, 4: timing experiments of the hot loop (wrong sums; -DDLIOM_EXPERIMENTS builds only)
 #endif
 #ifdef DLIOM_EXPERIMENTS
 #define DLIOM_BOX_DBG(p, bit) (((p).debug & (bit)) != 0)
@@ -399,7 +399,13 @@ __device__ __forceinline__ int main_loop(const GridView& g, const Params& p, con
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       float rx, ry, rz;
+#if DLIOM_BOX_EXP == 4
+      // timing experiment (wrong sums): no rotation in the loop -- the ceiling of any scheme that takes the 33-instruction
+      // quaternion rotation off the vector ALU (a matrix-core rotation, a pre-rotated table); q.w keeps the lanes apart
+      rx = cx[k] + q.w, ry = cy[k] + q.x, rz = cz[k] + q.y;
+#else
       rotate_point(q, cx[k], cy[k], cz[k], rx, ry, rz);
+#endif
       wx[k] = __builtin_fmaf(rx, inv, kbx);
       wy[k] = __builtin_fmaf(ry, inv, kby);
       wz[k] = __builtin_fmaf(rz, inv, kbz);
