@@ -158,6 +158,37 @@ def test_config2_eight_candidate_shards(dl, ctx, orc, bench_scene):
         c.close()
 
 
+@pytest.mark.parametrize("angular_deg,num_shards", [(0.2, 8), (1.0, 8), (1.0, 3)])
+def test_wide_window_candidate_shards(dl, ctx, orc, bench_scene, angular_deg, num_shards):
+    """Config 4's split on a window of 343 translations (the big-box instantiations, round 6): shards of 3-4 rotations
+    (27 rotations over 8 shards: one wave per workgroup) and of 166 / 444 (1 331 rotations: three- and four-wave
+    workgroups, the last block short) -- the max of the shards' words is the unsharded device winner; with the small
+    window also the oracle's full loop."""
+    s = bench_scene
+    sc = s["sc"]
+    opts = dict(DEFAULT_RTCSM, linear_search_window=0.35, angular_search_window=float(np.deg2rad(angular_deg)))
+    rt = dl.RealTimeCorrelativeScanMatcher3D(ctx, opts)
+    ref_score, ref_pose = rt.Match(sc["init"], sc["cloud"], s["g_hi"])
+    st = rt.last_stats()
+    assert st.window.num_translations == 343 and st.score_kernel == 3 and st.box_kernel_variant == 2
+    ctxs = [dl.Context(0) for _ in range(num_shards)]
+    clouds = [dl.PointCloud(c, sc["pts"]) for c in ctxs]
+    shards = [dl.RtcsmShard(c, opts, k, num_shards) for k, c in enumerate(ctxs)]
+    glo = max(sh.begin(sc["init"], cl, s["g_hi"]) for sh, cl in zip(shards, clouds))
+    gbest = max(sh.finish(glo) for sh in shards)
+    for sh in shards:
+        score, pose = sh.decode(gbest)
+        assert np.float32(score).tobytes() == np.float32(ref_score).tobytes() and np.array_equal(pose, ref_pose)
+    if angular_deg < 0.5:
+        flat = orc.FlatGridIndex(s["og_hi"])
+        _, want = orc.rtcsm3d_volume_fair(opts, sc["init"], sc["pts"], flat, threads=THREADS_BIG)
+        assert st.best_index == int(np.argmax(want)) and np.float32(ref_score).tobytes() == want[int(np.argmax(want))].tobytes()
+    for c in clouds:
+        c.close()
+    for c in ctxs:
+        c.close()
+
+
 def test_config2_ceres_and_insertion(dl, ctx, orc, bench_scene):
     s = bench_scene
     sc, ref = s["sc"], s["ref"]
