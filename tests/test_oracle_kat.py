@@ -376,6 +376,45 @@ def test_rtcsm2d_scores(orc):
     assert np.allclose(r["pose"], 0.0, atol=1e-9)
 
 
+# ---------------------------------------------------------------- (vii-b) the 2D helpers under RTCSM2D (a18)
+def test_probability_grid_get_cell_index_kat(orc):
+    """mapping/2d/probability_grid_test.cc:139-166 (GetCellIndex): MapLimits(2, max (8, 14), CellLimits(14, 8)) -- the nine
+    golden cells, corners and around the origin: x grows with -y and y with -x (map_limits.h:69-76)."""
+    pg = orc.ProbabilityGrid(2.0, (8.0, 14.0), 14, 8)
+    for (px, py), want in [((7, 13), (0, 0)), ((7, -13), (13, 0)), ((-7, 13), (0, 7)), ((-7, -13), (13, 7)),
+                           ((0.5, 0.5), (6, 3)), ((1.5, 1.5), (6, 3)), ((0.5, -0.5), (7, 3)), ((-0.5, 0.5), (6, 4)),
+                           ((-0.5, -0.5), (7, 4))]:
+        assert tuple(pg.cell_index(px, py)) == want, ((px, py), want)
+
+
+def test_probability_grid_get_probability_kat(orc):
+    """probability_grid_test.cc:112-137 (GetProbability): a 2 x 2 grid, kMaxProbability set at the cell of (-0.5, 0.5); the
+    other three cells are inside the limits and unknown (value 0)."""
+    pg = orc.ProbabilityGrid(1.0, (1.0, 2.0), 2, 2)
+    cx, cy = (int(v) for v in pg.cell_index(-0.5, 0.5))
+    pg.set_probability(cx, cy, 0.9)
+    assert abs(pg.get_probability(cx, cy) - 0.9) < 1e-6
+    cells = pg.cells()
+    for px, py in ((-0.5, 1.5), (0.5, 0.5), (0.5, 1.5)):
+        x, y = (int(v) for v in pg.cell_index(px, py))
+        assert 0 <= x < 2 and 0 <= y < 2 and cells[y, x] == 0
+
+
+def test_correlative_scan_matcher_2d_discretize_and_rotate_kat(orc):
+    """scan_matching/correlative_scan_matcher_test.cc:53-98: GenerateRotatedScans (rotations about z by -pi/2, 0, +pi/2 of
+    (-1, 1, 0)) and DiscretizeScans (the seven cells of the reference's L-shaped scan on MapLimits(0.05, (0.05, 0.25),
+    CellLimits(6, 6))) -- the two helpers RealTimeCorrelativeScanMatcher2D::Match is made of."""
+    p = np.array([[-1.0, 1.0, 0.0]], dtype=np.float32)
+    for angle, want in ((-np.pi / 2, (1.0, 1.0)), (0.0, (-1.0, 1.0)), (np.pi / 2, (-1.0, -1.0))):
+        pose = np.array([0, 0, 0, np.float32(np.cos(np.float32(0.5 * angle))), 0, 0, np.float32(np.sin(np.float32(0.5 * angle)))], dtype=np.float32)
+        got = orc.transform_points(pose, p)[0]
+        assert abs(got[0] - want[0]) < 1e-6 and abs(got[1] - want[1]) < 1e-6
+    pg = orc.ProbabilityGrid(0.05, (0.05, 0.25), 6, 6)
+    pc = [(0.025, 0.175), (-0.025, 0.175), (-0.075, 0.175), (-0.125, 0.175), (-0.125, 0.125), (-0.125, 0.075), (-0.125, 0.025)]
+    want = [(1, 0), (1, 1), (1, 2), (1, 3), (2, 3), (3, 3), (4, 3)]
+    assert [tuple(pg.cell_index(np.float32(x), np.float32(y))) for x, y in pc] == want
+
+
 # ---------------------------------------------------------------------------------------------
 # FastCorrelativeScanMatcher3D / PrecomputationGrid3D known-answer tests of the reference, run
 # natively inside the oracle because they interleave std::mt19937 draws of two distributions.
