@@ -1026,21 +1026,34 @@ bool chain_push_state(dliom_imu_window& w) {
   return true;
 }
 
-// theta <- theta (+) delta for the states whose increment exceeds the threshold (ISAM2's relinearisation; threshold 0:
-// every state that moved at all = plain Gauss-Newton).  A moved point makes both of its IMU factors stale.
+// theta <- theta (+) delta for the KEYS whose increment exceeds the threshold -- ISAM2's relinearisation, which looks at
+// every variable by itself: X (rotation, translation), V and B of a state are three keys there (X(i), V(i), B(i),
+// local_trajectory_builder_3d.cc:703-707), each moved when ITS increment's largest component reaches the threshold
+// (threshold 0: every key that moved at all = plain Gauss-Newton).  The retraction acts on the components separately, so
+// a state may hold a moved pose next to an unmoved velocity.  A moved key makes both of its state's IMU factors stale.
 void chain_relinearize(dliom_imu_window& w, double threshold) {
   const int N = static_cast<int>(w.x.size());
+  const int first[3] = {0, 6, 9}, size[3] = {6, 3, 6};  // X, V, B
   for (int i = 0; i < N; ++i) {
     double* d = &w.delta[static_cast<size_t>(kD) * i];
-    double m = 0.0;
-    for (int c = 0; c < kD; ++c) m = std::max(m, std::fabs(d[c]));
-    if (!(m > threshold)) continue;
-    w.x[i] = retract(w.x[i], d);
-    std::fill(d, d + kD, 0.0);
+    double part[kD] = {0};
+    bool any = false;
+    for (int k = 0; k < 3; ++k) {
+      double m = 0.0;
+      for (int c = first[k]; c < first[k] + size[k]; ++c) m = std::max(m, std::fabs(d[c]));
+      if (!(m > threshold)) continue;
+      for (int c = first[k]; c < first[k] + size[k]; ++c) {
+        part[c] = d[c];
+        d[c] = 0.0;
+      }
+      any = true;
+      ++w.relinearizations;
+    }
+    if (!any) continue;
+    w.x[i] = retract(w.x[i], part);
     if (i > 0) w.fac[static_cast<size_t>(i) - 1].stale = true;
     if (i + 1 < N) w.fac[static_cast<size_t>(i)].stale = true;
     chain_mark(w, i - 1);
-    ++w.relinearizations;
   }
 }
 

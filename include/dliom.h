@@ -691,8 +691,9 @@ typedef struct dliom_imu_window_options {
                                               coordinates of the predicted state at state j.  0: the manifold form of
                                               Forster et al. (GTSAM with the flag OFF).  Still PARITY UNPINNED either way */
   double relinearize_threshold;            /* window_size == 0 only: ISAM2Params::relinearizeThreshold (.cc:677, 0.1): a key's
-                                              linearisation point moves to its estimate when an increment component exceeds
-                                              it (checked at each of the `iterations` updates, relinearizeSkip = 1); the
+                                              linearisation point -- X(i), V(i) and B(i) each by itself -- moves to its estimate
+                                              when a component of ITS increment exceeds it (checked at each of the `iterations`
+                                              updates, relinearizeSkip = 1); the
                                               estimate is linearisation point (+) increment, the increments solving the
                                               linearised problem exactly.  0 = every update relinearises every key = batch
                                               Gauss-Newton over the whole graph (oracle/imu_window_ref.py's

@@ -360,8 +360,8 @@ class ReferenceRuleSmoother:
       relinearize_threshold=t     ISAM2's own rule as the reference parameterises it (:676-679, t = 0.1, relinearizeSkip 1):
                                   every key keeps a linearisation point theta and an increment delta, the estimate is
                                   theta (+) delta (calculateEstimate), `updates` (2: update(graph, values); update();)
-                                  times per scan: move the points whose |delta|_inf exceeds t, linearise EVERY factor at
-                                  the points, solve the linear problem exactly.  (What GTSAM adds on top -- the Bayes tree,
+                                  times per scan: move the KEYS (X(i), V(i), B(i) one by one) whose |delta|_inf exceeds t,
+                                  linearise EVERY factor at the points, solve the linear problem exactly.  (What GTSAM adds on top -- the Bayes tree,
                                   the wildfire threshold on older keys' deltas, Cayley retraction -- is not restated.)
 
     Dense normal equations, block-sparse numeric Jacobians (every factor touches at most two states; the gravity factor
@@ -447,10 +447,14 @@ class ReferenceRuleSmoother:
             return
         for _ in range(iterations):
             for i in range(len(self.x)):
-                if np.max(np.abs(self.delta[i])) > self.thr:
-                    self.x[i] = retract(self.x[i], self.delta[i])
-                    self.delta[i] = np.zeros(15)
-                    self.relinearizations += 1
+                part = np.zeros(15)
+                for lo, hi in ((0, 6), (6, 9), (9, 15)):  # X(i), V(i), B(i): ISAM2 looks at every key by itself
+                    if np.max(np.abs(self.delta[i][lo:hi])) > self.thr:
+                        part[lo:hi] = self.delta[i][lo:hi]
+                        self.delta[i][lo:hi] = 0.0
+                        self.relinearizations += 1
+                if np.any(part != 0.0):
+                    self.x[i] = retract(self.x[i], part)
             H, b = self._normal_equations()
             d = np.linalg.solve(H, -b)
             self.delta = [d[15 * i:15 * i + 15].copy() for i in range(len(self.x))]
