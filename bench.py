@@ -59,11 +59,15 @@ def parse():
     ap.add_argument("--no-wref", action="store_true", help="skips the W-ref (reference-faithful filter chain) line")
     ap.add_argument("--dump-steps", action="store_true", help="per-step stage times on stderr (debugging)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
-                    help="5 = BASELINE config 5 (128 x 2048 returns, 5 cm voxels, 3 map scans); 2 = the headline config")
+                    help="5 = BASELINE config 5 (128 x 2048 returns, 5 cm voxels, 3 map scans); "
+                         "2 = the headline config")
     ap.add_argument("--no-pmc", action="store_true", help="skips the rocprofv3 --pmc child runs (roofline counters)")
-    ap.add_argument("--no-config5", action="store_true", help="skips the config-5 line (N = 1: two submaps, four grids, three steps; N > 1: the sharded one)")
-    ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skips the one-rank run of the library's RCCL entry point")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # internal: scene + 3 matches, no timing
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skips the config-5 line (N = 1: two submaps, four grids, three steps; N > 1: the sharded one)")
+    ap.add_argument("--no-rccl-check", action="store_true",
+                    help="N = 1: skips the one-rank run of the library's RCCL entry point")
+    # internal: scene + 3 matches, no timing
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.config == 5:
         a.beams, a.azimuths, a.high_resolution = 128, 2048, 0.05
@@ -249,7 +253,8 @@ def main():
         for i in range(args.warmup):
             step(args.warmup + args.steps + i, False)
         fence()
-        ctx.set_profiling(2 | 64)  # HIP events around the score kernel and the library's all-reduce (DLIOM_KERNEL_ALLREDUCE)
+        # HIP events around the score kernel and the library's all-reduce (DLIOM_KERNEL_ALLREDUCE)
+        ctx.set_profiling(2 | 64)
         ctx.reset_profiling()
         coll_clock.reset()
         t_s = time.perf_counter()
@@ -276,23 +281,27 @@ def main():
                                        else "dliom_rtcsm3d_match_sharded + torch.distributed callback (%s)" % backend),
                         "ranks_seen": rccl_comm.ranks_seen if rccl_comm is not None else world,
                         "allreduce_ms_per_match_this_rank": allreduce_ms,
-                        "allreduce_ms_per_match_max_over_ranks": float(tt[2].item()) if float(tt[2].item()) >= 0 else None,
-                        "allreduce_timed_by": "HIP events inside the library around copy + ncclAllReduce + copy" if rccl_comm is not None
-                                              else "host clock around the torch.distributed callback",
+                        "allreduce_ms_per_match_max_over_ranks": (float(tt[2].item()) if float(tt[2].item()) >= 0
+                                                                  else None),
+                        "allreduce_timed_by": ("HIP events inside the library around copy + ncclAllReduce + copy"
+                                               if rccl_comm is not None else
+                                               "host clock around the torch.distributed callback"),
                         "checks": mg_checks,
                         "value": args.steps / float(tt[0].item()), "unit": "scans/s", "scaling": "strong",
                         "ms_per_step": 1e3 * float(tt[0].item()) / args.steps,
                         "score_kernel_ms_per_step_this_rank": shard_score_ms / max(1, args.steps),
                         "serial_remainder_ms_per_step": 1e3 * float(tt[1].item()) / args.steps,
                         "note": "Amdahl: only the score volume (~60 % of a 1-GPU step) shards; Ceres, insertion, the "
-                                "bounds / rescoring kernels and two host synchronisations per scan stay serial: config 2 "
-                                "strong-scales <= 1 / (0.4 + 0.6 / N) = 2.1x at N = 8; read the 8-GPU number off sharded_config5"}
+                                "bounds / rescoring kernels and two host synchronisations per scan stay serial: "
+                                "config 2 strong-scales <= 1 / (0.4 + 0.6 / N) = 2.1x at N = 8; read the 8-GPU "
+                                "number off sharded_config5"}
 
     # ... and the search where sharding pays: config 5 (128 x 2048 returns, 5 cm voxels, ~3e6 candidates), whose step
     # is 98 % score volume -- every rank builds the same small submap and takes its share of the rotations
     config5_sharded = None
     if world > 1 and not sharded_mode and args.config == 2 and not args.no_config5:
-        config5_sharded = config5_sharded_line(args, dl, synth, ctx, rank, world, dist, coll_device, torch, sharded, rccl_comm)
+        config5_sharded = config5_sharded_line(args, dl, synth, ctx, rank, world, dist, coll_device, torch, sharded,
+                                               rccl_comm)
 
     extra = max(1, min(5, args.steps))
     ctx.set_profiling(1)
@@ -330,7 +339,8 @@ def main():
                 rt.Match(sc["init"], sc["cloud"], g_hi)
             ctx.synchronize()
             rccl_one_rank = {"entry_point": "dliom_rtcsm3d_match_sharded_rccl", "ranks_seen": comm1.ranks_seen,
-                             "same_winner": bool(np.array_equal(p_ref, p_got) and np.float32(s_ref) == np.float32(s_got)),
+                             "same_winner": bool(np.array_equal(p_ref, p_got) and
+                                                 np.float32(s_ref) == np.float32(s_got)),
                              "ms_per_match": ms_rccl, "unsharded_ms_per_match": 1e3 * (time.perf_counter() - t_r) / 5}
             comm1.close()
         except Exception as e:  # RCCL's bootstrap is the environment's, not the product's
@@ -346,7 +356,8 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         pairs = float(C) * n_pts / (world if sharded_mode else 1)
         out = {
-            "metric": "scans/sec (%d-beam x %d pts -> %g cm 3D submap)" % (args.beams, args.azimuths, 100 * args.high_resolution),
+            "metric": "scans/sec (%d-beam x %d pts -> %g cm 3D submap)" % (args.beams, args.azimuths,
+                                                                           100 * args.high_resolution),
             "value": value,
             "unit": "scans/s",
             "n_gpus": world,
@@ -373,7 +384,8 @@ def main():
                 "E_mean": float(np.mean(evals)) if evals else 0.0,
                 "rescored_candidates_last": int(st.num_rescored), "box_kernel_variant": int(st.box_kernel_variant),
                 "map_scans": args.map_scans, "grids_inserted_into": 2 + len(SECOND_SUBMAP),
-                "parallelism": ("candidate shards x%d (RCCL max all-reduce)" if sharded_mode else "replicas x%d") % world,
+                "parallelism": ("candidate shards x%d (RCCL max all-reduce)" if sharded_mode
+                                else "replicas x%d") % world,
             },
             "stage_ms_per_scan": {k: 1e3 * v / args.steps for k, v in stage.items()},
             # the part of a step that does not shard (config 4's Amdahl ceiling): the step minus this rank's score kernel
