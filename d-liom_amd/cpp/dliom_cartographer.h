@@ -727,8 +727,18 @@ class LocalTrajectoryBuilder3D {
   LocalTrajectoryBuilder3D& operator=(const LocalTrajectoryBuilder3D&) = delete;
 
   // prev_state_ / prev_bias_ as InitializeIMU() leaves them (.cc:322-345)
-  void SetInitialState(const transform::Rigid3d& pose, const transform::Vector3d& velocity, const double bias6[6]) {
+  // start_graph: the reference starts its factor graph at the FIRST WindowOptimize call after InitializeIMU (.cc:712-745),
+  // i.e. the first scan after the initialisation only starts the graph and is reported (and inserted) at the initial pose --
+  // harmless on the platform at rest D-LIOM's static initialisation assumes, and what this adapter does by default.  true
+  // starts the graph here instead: for a caller whose initial state IS the state at the time of the call (a replay that
+  // begins in motion), so that the first scan is fused like every later one.
+  void SetInitialState(const transform::Rigid3d& pose, const transform::Vector3d& velocity, const double bias6[6],
+                       bool start_graph = false) {
     Check(dliom_imu_window_initialize(window_, pose.ToArray().data(), velocity.v, bias6), "dliom_imu_window_initialize");
+    if (start_graph) {
+      double p[7], v[3], b[6];
+      Check(dliom_imu_window_window_optimize(window_, pose.ToArray().data(), 0, p, v, b), "WindowOptimize (graph start)");
+    }
     last_imu_time_ = -1;
     imu_initialized_ = true;
     have_prediction_ = false;
@@ -869,7 +879,8 @@ class LocalTrajectoryBuilder3D {
     metrics_().residual_angle->Observe(m.residual_angle);                                                         // :551
     // WindowOptimize(pose_estimate, false) and opt_pose = PoseFromGtsamNavState(prev_state_)
     double opt[7], vel[3], bias[6];
-    const int ws = dliom_imu_window_add_pose(window_, m.pose_estimate, 0, opt, vel, bias);
+    // (its first call after SetInitialState only starts the graph and returns the initial state, like the reference's)
+    const int ws = dliom_imu_window_window_optimize(window_, m.pose_estimate, 0, opt, vel, bias);
     if (ws == DLIOM_ERR_DIVERGED) {
       imu_initialized_ = false;  // ResetParams(): the caller re-initialises (SetInitialState)
       have_prediction_ = false;

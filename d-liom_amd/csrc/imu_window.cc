@@ -610,6 +610,7 @@ struct dliom_imu_window {
   std::vector<ChainBlock> blk;     // per state
   int clean_until = 0;             // states [0, clean_until) are eliminated with the factors as they are now
   bool full_graph() const { return o.window_size == 0; }
+  bool graph_started = false;  // gtsam_initialized_: false between InitializeIMU and the first WindowOptimize (:712-745)
   int64_t relinearizations = 0, blocks_eliminated = 0;  // dliom_imu_window_solver_stats
 };
 
@@ -1468,6 +1469,7 @@ int dliom_imu_window_initialize(dliom_imu_window* w, const double pose7[7], cons
   w->clean_until = 0;
   w->current.reset(s.ba, s.bg);
   w->initialized = true;
+  w->graph_started = false;
   w->num_states = 1;
   w->key = 1;
   return DLIOM_OK;
@@ -1610,6 +1612,7 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
                               double velocity[3], double bias6[6]) {
   if (w == nullptr || matched_pose7 == nullptr || !w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
   if (!(w->current.dt > 0)) return DLIOM_ERR_INVALID_ARGUMENT;  // no IMU since the last pose
+  w->graph_started = true;
   const bool reset_due = w->o.graph_reset_every > 0 && w->key == w->o.graph_reset_every;
   AddPoseUndo undo;  // a failed solve leaves the window exactly as it was
   if (!w->full_graph()) {
@@ -1723,6 +1726,22 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
     w->initialized = false;                                          // ResetParams(): the caller re-initialises
     return DLIOM_ERR_DIVERGED;
   }
+  return DLIOM_OK;
+}
+
+// LocalTrajectoryBuilder3D::WindowOptimize(matched_pose, is_drift) as the reference calls it once per scan (:693-863),
+// its first call included: while gtsam_initialized_ is false (:712-745) the call only STARTS the graph -- priors on X(0),
+// V(0), B(0) at prev_state_ / prev_bias_ as InitializeIMU left them, the preintegration since then dropped
+// (resetIntegrationAndSetBias, :739), key_ = 1 -- and the scan's matched pose is not used: the caller's opt_pose is
+// prev_state_ (:555-557).  Every later call is dliom_imu_window_add_pose.
+int dliom_imu_window_window_optimize(dliom_imu_window* w, const double matched_pose7[7], int is_drift, double pose7[7],
+                                     double velocity[3], double bias6[6]) {
+  if (w == nullptr || matched_pose7 == nullptr || !w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
+  if (w->graph_started) return dliom_imu_window_add_pose(w, matched_pose7, is_drift, pose7, velocity, bias6);
+  const State s = estimate_at(*w, w->x.size() - 1);
+  w->current.reset(s.ba, s.bg);
+  w->graph_started = true;
+  write_state(s, pose7, velocity, bias6);
   return DLIOM_OK;
 }
 

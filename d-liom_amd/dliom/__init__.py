@@ -200,6 +200,7 @@ SYMBOLS = [
     ("dliom_ctx_set_mirror_budget", C.c_int, [_vp, C.c_int64]),
     ("dliom_grid_memory_stats", C.c_int, [_vp, C.POINTER(MemoryStats)]),
     ("dliom_imu_window_solver_stats", C.c_int, [_vp, _i64p, _i64p]),
+    ("dliom_imu_window_window_optimize", C.c_int, [_vp, _f64p, C.c_int, _f64p, _f64p, _f64p]),
     ("dliom_grid_upload_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64]),
     ("dliom_grid_num_blocks", C.c_int, [_vp, _i64p]),
     ("dliom_grid_download_blocks", C.c_int, [_vp, _i32p, _u16p, C.c_int64, _i64p]),
@@ -1472,6 +1473,16 @@ class ImuWindow:
                                               _p(vel, _f64p), _p(bias, _f64p))
         if s not in (ERR_DIVERGED, ERR_SOLVER):
             _check(s, "dliom_imu_window_add_pose")
+        return pose, vel, bias, s
+
+    def window_optimize(self, matched_pose7, is_drift=False):
+        """LocalTrajectoryBuilder3D::WindowOptimize as the reference calls it: the first call after initialize() only starts
+        the graph and returns the initial state; every later one is add_pose.  Returns (pose7, velocity, bias6, status)."""
+        pose, vel, bias = np.zeros(7), np.zeros(3), np.zeros(6)
+        s = self._L.dliom_imu_window_window_optimize(self.h, _p(_f64(matched_pose7), _f64p), int(bool(is_drift)), _p(pose, _f64p),
+                                                     _p(vel, _f64p), _p(bias, _f64p))
+        if s not in (ERR_DIVERGED, ERR_SOLVER):
+            _check(s, "dliom_imu_window_window_optimize")
         return pose, vel, bias, s
 
     def state(self, states_back=0):

@@ -702,7 +702,8 @@ typedef struct dliom_imu_window_options {
 int dliom_imu_window_default_options(dliom_imu_window_options* options);
 int dliom_imu_window_create(const dliom_imu_window_options* options, dliom_imu_window** out);
 int dliom_imu_window_destroy(dliom_imu_window* window);
-/* gtsam_initialized_ == false branch (:712-745): X(0), V(0), B(0) with their priors */
+/* InitializeIMU (:331-356) + the priors of the gtsam_initialized_ == false branch (:712-745): prev_state_ / prev_bias_,
+ * X(0), V(0), B(0) with their priors */
 int dliom_imu_window_initialize(dliom_imu_window* window, const double pose7[7], const double velocity[3],
                                 const double bias6[6]);
 /* imu_integrator_opt_->integrateMeasurement(acc, gyr, dt) (:188-196) */
@@ -718,6 +719,12 @@ int dliom_imu_window_add_pose(dliom_imu_window* window, const double matched_pos
                               double velocity[3], double bias6[6]);
 /* Work done by the solver so far: linearisation points moved, chain blocks (states) eliminated -- what a scan costs */
 int dliom_imu_window_solver_stats(const dliom_imu_window* window, int64_t* relinearizations, int64_t* blocks_eliminated);
+/* WindowOptimize as the reference calls it, once per scan, the first call after _initialize included: that call only
+ * starts the graph (gtsam_initialized_ == false, .cc:712-745: priors at the initial state, the preintegration since
+ * InitializeIMU dropped) and returns the initial state -- the scan's matched pose is not used, as in the reference; every
+ * later call is dliom_imu_window_add_pose.  (_add_pose alone adds a key on every call: the primitive the solver tests use.) */
+int dliom_imu_window_window_optimize(dliom_imu_window* window, const double matched_pose7[7], int is_drift, double pose7[7],
+                                     double velocity[3], double bias6[6]);
 int dliom_imu_window_state(const dliom_imu_window* window, int states_back, double pose7[7], double velocity[3],
                            double bias6[6]);
 int dliom_imu_window_size(const dliom_imu_window* window);

@@ -1379,7 +1379,7 @@ def test_cpp_local_trajectory_builder_adapter(dl, ctx, orc, tmp_path, num_accumu
             continue
         cloud, origin = acc_dev.finish(0.15)
         r = fe.match_cloud(cur.astype(np.float64), origin, cloud)
-        est, vel, bias, status = window.add_pose(r["pose_estimate"])
+        est, vel, bias, status = window.window_optimize(r["pose_estimate"])  # like the adapter: the first call starts the graph
         assert status == 0 and not r["dropped"]
         ins = fe.insert(ticks, est, est[3:])
         if ins["inserted"]:

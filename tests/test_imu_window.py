@@ -633,3 +633,41 @@ def test_reference_rule_mode_options_and_rollback(dl):
         assert status == 0 and status_t == 0 and len(w) == len(twin)
         # the failed call left nothing behind: same estimates as the window that never saw it
         assert np.linalg.norm(pose - pose_t) < 1e-12 and np.linalg.norm(vel - vel_t) < 1e-11 and np.linalg.norm(bias - bias_t) < 1e-12
+
+
+def test_window_optimize_first_call_only_starts_the_graph(dl):
+    """dliom_imu_window_window_optimize = LocalTrajectoryBuilder3D::WindowOptimize as the reference calls it: while
+    gtsam_initialized_ is false (the first call after InitializeIMU, local_trajectory_builder_3d.cc:712-745) the call puts
+    the priors on X(0), V(0), B(0), drops the preintegration accumulated so far and returns the INITIAL state -- the scan's
+    matched pose is not used; every later call adds a key like add_pose."""
+    from dliom import synth
+    w = dl.ImuWindow(window_size=0, graph_reset_every=50)
+    twin = dl.ImuWindow(window_size=0, graph_reset_every=50)
+    st = synth.trajectory_state(0.0)
+    for s in (w, twin):
+        s.initialize(st[:7], st[7:10], np.zeros(6))
+    T = 0.1
+    dt, acc, gyr = synth.imu_samples(0.0, T, 200.0, None, seed=3)
+    for a, g in zip(acc[:-1], gyr[:-1]):
+        w.add_imu(a, g, dt)
+    moved, _ = w.predict()
+    assert np.linalg.norm(moved[:3] - st[:3]) > 0.01  # the preintegration has carried the prediction away
+    far = synth.perturb_pose(synth.trajectory_pose(T), 0.5, 5.0, seed=1)  # a matched pose that would be felt if it were used
+    pose, vel, bias, status = w.window_optimize(far)
+    assert status == 0 and len(w) == 1
+    assert np.array_equal(pose, st[:7] / np.concatenate([np.ones(3), np.full(4, np.linalg.norm(st[3:7]))])) or np.allclose(pose, st[:7], atol=1e-15)
+    assert np.array_equal(vel, st[7:10]) and np.array_equal(bias, np.zeros(6))
+    back, _ = w.predict()
+    assert np.allclose(back, st[:7], atol=1e-15)  # resetIntegrationAndSetBias: nothing integrated any more
+    # from here on both windows see the same samples: window_optimize == add_pose
+    twin.window_optimize(st[:7])
+    for k in range(2, 6):
+        dt, acc, gyr = synth.imu_samples(T * (k - 1), T * k, 200.0, (0.02, 0.002), seed=11 + k)
+        for a, g in zip(acc[:-1], gyr[:-1]):
+            w.add_imu(a, g, dt)
+            twin.add_imu(a, g, dt)
+        m = synth.perturb_pose(synth.trajectory_pose(T * k), 0.02, 0.1, seed=70 + k)
+        p1, v1, b1, s1 = w.window_optimize(m)
+        p2, v2, b2, s2 = twin.add_pose(m)
+        assert s1 == 0 and s2 == 0 and len(w) == len(twin) == k
+        assert np.array_equal(p1, p2) and np.array_equal(v1, v2) and np.array_equal(b1, b2)

@@ -58,6 +58,7 @@ def main():
         w = dl.ImuWindow(acc_noise=noise[0], gyr_noise=noise[1], acc_bias_noise=noise[2], gyr_bias_noise=noise[3],
                          window_size=0, graph_reset_every=160)
         w.initialize(state[:7], state[7:10], np.zeros(6))
+        w.window_optimize(state[:7])  # the graph starts at the initial state (the stream begins in motion)
         return w
 
     window = None if args.no_window else make_window()
@@ -82,7 +83,7 @@ def main():
         t3 = time.perf_counter()
         matched = r["pose_estimate"] if not r["dropped"] else pred[:7]
         if window is not None:
-            est, vel, bias, status = window.add_pose(matched)
+            est, vel, bias, status = window.window_optimize(matched)
             if status != 0:  # FailureDetection: re-initialise at the matched pose
                 state = np.concatenate([matched, pred[7:10], np.zeros(6)])
                 window = make_window()
@@ -125,7 +126,7 @@ def main():
             ref = orc.deskew_and_filter(T, 1.0, 100.0, 0.15, ostate[:7], pred[:7], scans[k - 1])
             r = ofe.match(ref["current_pose"].astype(np.float64), ref["origin_in_tracking"], ref["returns_in_tracking"])
             if owin is not None:
-                est, vel, bias, _ = owin.add_pose(r["pose_estimate"])
+                est, vel, bias, _ = owin.window_optimize(r["pose_estimate"])
             else:
                 est, vel, bias = r["pose_estimate"], pred[7:10], ostate[10:]
             ofe.insert(int(k * 1e6), est, gravity)

@@ -37,7 +37,8 @@ int main(int argc, char** argv) {
   options.rotational_histogram_size = header[3];
   Context context(0);
   mapping::LocalTrajectoryBuilder3D builder(&context, options, {"lidar"});
-  builder.SetInitialState(transform::Rigid3d::FromArray(init), transform::Vector3d{{init[7], init[8], init[9]}}, init + 10);
+  // (the stream begins in motion and its initial state is the state at its first instant: the graph starts there)
+  builder.SetInitialState(transform::Rigid3d::FromArray(init), transform::Vector3d{{init[7], init[8], init[9]}}, init + 10, true);
   const int scans = header[0], per = header[1], warmup = header[2];
   std::vector<std::vector<double>> imus(static_cast<size_t>(scans));
   std::vector<sensor::TimedPointCloudData> clouds(static_cast<size_t>(scans));

@@ -96,12 +96,14 @@ def shadow_window(dl, cfg, imus, state0, matched, status, pv):
     which on a scene like the yard turns a 1e-5 m difference of the prediction into another 10 cm candidate."""
     w = NumpyWindow(dl, dict(acc_noise=NOISE[0], gyr_noise=NOISE[1], acc_bias_noise=NOISE[2], gyr_bias_noise=NOISE[3], **cfg["window"]))
     w.initialize(state0[:7], state0[7:10], np.zeros(6))
+    w.window_optimize(state0[:7])  # the graph starts at the initial state, as in run_chain
     out = []
     for (dt, acc, gyr), m, st, v in zip(imus, matched, status, pv):
         w.add_imu_batch(acc[:-1], gyr[:-1], dt)
-        est, _, _, _ = w.add_pose(m)
+        est, _, _, _ = w.window_optimize(m)
         if st != 0:
             w.initialize(m, v, np.zeros(6))
+            w.window_optimize(m)
             est = m
         out.append(est)
     return np.array(out)
@@ -128,6 +130,7 @@ class NumpyWindow:
 
     def initialize(self, pose7, vel, bias6):
         self.s.initialize(pose7, vel, bias6)
+        self._started = False
 
     def add_imu_batch(self, acc, gyr, dt):
         for a, g in zip(acc, gyr):
@@ -148,6 +151,17 @@ class NumpyWindow:
         R, p, v, ba, bg = self.s.add_pose(matched, iterations=5)
         return self._pose7(R, p), v, np.concatenate([ba, bg]), 0
 
+    def window_optimize(self, matched):
+        """WindowOptimize as the reference calls it: the first call after initialize() only starts the graph (the
+        preintegration since then is dropped, the initial state is returned, .cc:712-745); later ones add a key."""
+        if not getattr(self, "_started", False):
+            from oracle.imu_window_ref import make_preintegration
+            self._started = True
+            R, p, v, ba, bg = self.s.estimate()
+            self.s.cur = make_preintegration(ba, bg, self.s.o)
+            return self._pose7(R, p), v, np.concatenate([ba, bg]), 0
+        return self.add_pose(matched)
+
     def gravity_estimate(self):
         return self.s.g_est, bool(self.s.g_valid), int(self.s.gravity_factors)
 
@@ -159,6 +173,10 @@ def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, hist
     overrides = dict(acc_noise=NOISE[0], gyr_noise=NOISE[1], acc_bias_noise=NOISE[2], gyr_bias_noise=NOISE[3], **cfg["window"])
     window = NumpyWindow(dl, overrides) if numpy_window else dl.ImuWindow(**overrides)
     window.initialize(state0[:7], state0[7:10], np.zeros(6))
+    # The reference starts its factor graph at the first WindowOptimize call after InitializeIMU and reports that scan at
+    # the initial pose (.cc:712-745).  The stream begins in motion and state0 IS the state at its first instant: the graph
+    # is started here, so that every streamed scan is fused (the adapter's SetInitialState(..., start_graph = true)).
+    window.window_optimize(state0[:7])
     fe = dl.LocalTrajectoryBuilder3D(ctx, cfg["front_end"]) if device else orc.FrontEnd(cfg["front_end"])
     if not device and cpu_threads > 1:
         fe.set_threads(cpu_threads)  # the candidate loop on 8 threads (the reference's is serial)
@@ -181,12 +199,13 @@ def run_chain(dl, cfg, T, clouds, imus, state0, device, ctx=None, orc=None, hist
             r = fe.match(ref["current_pose"].astype(np.float64), ref["origin_in_tracking"], ref["returns_in_tracking"])
         t3 = time.perf_counter()
         matched = r["pose_estimate"] if not r["dropped"] else pp
-        est, vel, bias, status = window.add_pose(matched)
+        est, vel, bias, status = window.window_optimize(matched)  # (the first call only starts the graph, like the reference's)
         LAST_RUN["matched"].append(np.array(matched, dtype=np.float64))
         LAST_RUN["status"].append(int(status))
         LAST_RUN["pv"].append(np.array(pv, dtype=np.float64))
         if status != 0:  # FailureDetection / solver: re-initialise at the matched pose like ResetParams() + InitializeIMU
             window.initialize(matched, pv, np.zeros(6))
+            window.window_optimize(matched)
             est, vel, bias = matched, pv, np.zeros(6)
         t4 = time.perf_counter()
         if device:  # the histogram's kernels run beside the insertion (both only read the filtered cloud): begin / finish
