@@ -881,12 +881,12 @@ class LocalTrajectoryBuilder3D {
     double opt[7], vel[3], bias[6];
     // (its first call after SetInitialState only starts the graph and returns the initial state, like the reference's)
     const int ws = dliom_imu_window_window_optimize(window_, m.pose_estimate, 0, opt, vel, bias);
-    if (ws == DLIOM_ERR_DIVERGED) {
-      imu_initialized_ = false;  // ResetParams(): the caller re-initialises (SetInitialState)
-      have_prediction_ = false;
-      return nullptr;
-    }
-    Check(ws, "WindowOptimize");
+    // FailureDetection (.cc:856-859): ResetParams() and on with the scan -- opt_pose is what the diverged solve left in
+    // prev_state_, and the next WindowOptimize starts a new graph there (the library does; failure_detections() counts)
+    if (ws == DLIOM_ERR_DIVERGED)
+      ++failure_detections_;
+    else
+      Check(ws, "WindowOptimize");
     have_prediction_ = false;
     std::unique_ptr<MatchingResult> result(new MatchingResult);
     result->time = time;
@@ -986,6 +986,7 @@ class LocalTrajectoryBuilder3D {
   int64_t last_imu_time_ = -1;
   bool imu_initialized_ = false;
   bool have_prediction_ = false;
+  int64_t failure_detections_ = 0;
   bool accumulating_ = false;  // num_accumulated_ > 0
   std::chrono::steady_clock::time_point accumulation_started_ = std::chrono::steady_clock::now();
   int64_t histogram_host_fallbacks_ = 0;
@@ -993,6 +994,8 @@ class LocalTrajectoryBuilder3D {
  public:
   // ComputeHistogram calls that the device entry point refused and the host one served
   int64_t histogram_host_fallbacks() const { return histogram_host_fallbacks_; }
+  // scans after which FailureDetection fired (large velocity / bias: "reset IMU-preintegration!")
+  int64_t failure_detections() const { return failure_detections_; }
 };
 
 }  // namespace mapping

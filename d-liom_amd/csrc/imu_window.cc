@@ -1440,22 +1440,18 @@ int dliom_imu_window_destroy(dliom_imu_window* w) {
   return DLIOM_OK;
 }
 
-int dliom_imu_window_initialize(dliom_imu_window* w, const double pose7[7], const double velocity[3], const double bias6[6]) {
-  if (w == nullptr || pose7 == nullptr || velocity == nullptr || bias6 == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
-  State s;
-  s.R = quat_to_matrix(pose7 + 3);
-  s.p = {pose7[0], pose7[1], pose7[2]};
-  s.v = {velocity[0], velocity[1], velocity[2]};
-  s.ba = {bias6[0], bias6[1], bias6[2]};
-  s.bg = {bias6[3], bias6[4], bias6[5]};
+}  // extern "C"
+
+namespace {
+// ResetGTSAM + the priors of the gtsam_initialized_ == false branch (:674-686,712-745): the graph becomes ONE state with
+// PriorFactor<Pose3> (prior_pose_noise x 6), PriorFactor<Vector3> (1e4), PriorFactor<ConstantBias> (1e-2) at `s`, the
+// running preintegration starts over at its biases, key_ = 1.  EstimateGravity's deques are the caller's business: the
+// reference never clears them (a fresh dliom_imu_window_initialize does).
+void restart_graph_at(dliom_imu_window* w, const State& s) {
   w->x.assign(1, s);
   w->between.clear();
   w->pose_priors.clear();
   w->gravity.clear();
-  w->g_frames.clear();  // ResetParams() / a fresh start: the estimator's window starts over
-  w->g_vs.clear();
-  w->g_est_valid = false;
-  // PriorFactor<Pose3> (prior_pose_noise x 6), PriorFactor<Vector3> (1e4), PriorFactor<ConstantBias> (1e-2): :712-745
   std::memset(w->H0, 0, sizeof w->H0);
   std::memset(w->b0, 0, sizeof w->b0);
   const double sp = w->o.prior_pose_noise, sv = w->o.prior_velocity_sigma, sb = w->o.prior_bias_sigma;
@@ -1468,10 +1464,27 @@ int dliom_imu_window_initialize(dliom_imu_window* w, const double pose7[7], cons
   w->blk.assign(1, dliom_imu_window::ChainBlock());
   w->clean_until = 0;
   w->current.reset(s.ba, s.bg);
+  w->key = 1;
+}
+}  // namespace
+
+extern "C" {
+
+int dliom_imu_window_initialize(dliom_imu_window* w, const double pose7[7], const double velocity[3], const double bias6[6]) {
+  if (w == nullptr || pose7 == nullptr || velocity == nullptr || bias6 == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  State s;
+  s.R = quat_to_matrix(pose7 + 3);
+  s.p = {pose7[0], pose7[1], pose7[2]};
+  s.v = {velocity[0], velocity[1], velocity[2]};
+  s.ba = {bias6[0], bias6[1], bias6[2]};
+  s.bg = {bias6[3], bias6[4], bias6[5]};
+  w->g_frames.clear();  // a fresh start: the estimator's window starts over
+  w->g_vs.clear();
+  w->g_est_valid = false;
+  restart_graph_at(w, s);
   w->initialized = true;
   w->graph_started = false;
   w->num_states = 1;
-  w->key = 1;
   return DLIOM_OK;
 }
 
@@ -1722,8 +1735,11 @@ int dliom_imu_window_add_pose(dliom_imu_window* w, const double matched_pose7[7]
   ++w->num_states;
   ++w->key;
   write_state(s, pose7, velocity, bias6);
-  if (norm(s.v) > 30.0 || norm(s.ba) > 1.0 || norm(s.bg) > 1.0) {  // FailureDetection, :896-913
-    w->initialized = false;                                          // ResetParams(): the caller re-initialises
+  if (norm(s.v) > 30.0 || norm(s.ba) > 1.0 || norm(s.bg) > 1.0) {  // FailureDetection, :856-859,896-913
+    // ResetParams(): gtsam_initialized_ = false and nothing else -- prev_state_ / prev_bias_ stay what this scan made them,
+    // and the next WindowOptimize starts a new graph there (dliom_imu_window_window_optimize does; a caller of the add_pose
+    // primitive re-initialises, or goes on adding keys to the graph as it is)
+    w->graph_started = false;
     return DLIOM_ERR_DIVERGED;
   }
   return DLIOM_OK;
@@ -1738,8 +1754,8 @@ int dliom_imu_window_window_optimize(dliom_imu_window* w, const double matched_p
                                      double velocity[3], double bias6[6]) {
   if (w == nullptr || matched_pose7 == nullptr || !w->initialized) return DLIOM_ERR_INVALID_ARGUMENT;
   if (w->graph_started) return dliom_imu_window_add_pose(w, matched_pose7, is_drift, pose7, velocity, bias6);
-  const State s = estimate_at(*w, w->x.size() - 1);
-  w->current.reset(s.ba, s.bg);
+  const State s = estimate_at(*w, w->x.size() - 1);  // prev_state_ / prev_bias_: InitializeIMU's, or what a diverged scan left
+  restart_graph_at(w, s);
   w->graph_started = true;
   write_state(s, pose7, velocity, bias6);
   return DLIOM_OK;

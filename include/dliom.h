@@ -656,7 +656,10 @@ int dliom_imu_integrator_predict(const dliom_imu_integrator* integrator, const d
  * in place of ISAM2.  Poses are [x, y, z, qw, qx, qy, qz], biases [ax, ay, az, gx, gy, gz].
  * Call order per scan, as the reference's AddImuData / AddRangeData / WindowOptimize:
  *   _add_imu (every IMU sample) ... _predict (initial pose for the matchers) ... _add_pose (matched pose)
- * DLIOM_ERR_DIVERGED mirrors FailureDetection (:896-913): |v| > 30 m/s or a bias norm > 1 -- re-initialise. */
+ * DLIOM_ERR_DIVERGED mirrors FailureDetection (:856-859,896-913): |v| > 30 m/s or a bias norm > 1 after a scan.  The
+ * outputs hold that scan's estimate and, like ResetParams(), the window only forgets that its graph was started: the next
+ * _window_optimize starts a new graph at that estimate with the initial priors (the reference does exactly this and goes
+ * on); a caller may re-initialise instead. */
 #define DLIOM_ERR_DIVERGED (-11)
 /* add_pose returns DLIOM_ERR_SOLVER when the normal equations cannot be factorised: the window is then exactly as before
  * the call (the new key, its factors and the gravity estimator's entry are taken back, the running preintegration kept). */
