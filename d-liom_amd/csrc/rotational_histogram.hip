@@ -277,9 +277,13 @@ struct SortScratch {
   const unsigned char* tied;      // by position in the slice (the items' low 16 bits)
   struct Queue* queue;
 };
-constexpr int kQueueCap = 1024;  // segments ever queued: every one has > 16 elements and they nest, so <= 2 m / 17
+// A ring: the queue is served level by level, the segments of one level are disjoint and every one has > 16 elements, so
+// the entries alive at any time (the rest of this level + the children appended so far) are <= 2 m / 17.  The segments
+// EVER queued are not: a path of lopsided partitions queues one per level (round 6's soak: 1 277 for 9 716 descending
+// keys in tied pairs against the 1 207 = 2 m / 17 + 64 this used to hold in all).
+constexpr int kQueueCap = 1024;
 struct Queue {
-  unsigned reserved, capacity, pending, overflow;  // capacity: entries of seg[] in use (kQueueCap unless the owner has more room)
+  unsigned reserved, capacity, level_begin, overflow;  // capacity: entries of seg[] in use (kQueueCap unless the owner has more room)
   uint2 seg[kQueueCap];  // x = first | last << 16, y = partitions left on this path
 };
 
@@ -353,31 +357,34 @@ __device__ __forceinline__ void queue_init(Queue* q, unsigned capacity = kQueueC
   if (threadIdx.x == 0) {
     q->reserved = 0u;
     q->capacity = capacity;
-    q->pending = 0u;
+    q->level_begin = 0u;
     q->overflow = 0u;
   }
 }
 __device__ __forceinline__ void queue_push(Queue* q, int first, int last, int depth) {  // one lane
   const unsigned slot = atomicAdd(&q->reserved, 1u);
-  if (slot < q->capacity)
-    q->seg[slot] = make_uint2(static_cast<unsigned>(first) | (static_cast<unsigned>(last) << 16), static_cast<unsigned>(depth));
+  if (slot - q->level_begin < q->capacity)
+    q->seg[slot % q->capacity] = make_uint2(static_cast<unsigned>(first) | (static_cast<unsigned>(last) << 16), static_cast<unsigned>(depth));
   else
     atomicExch(&q->overflow, 1u);
 }
 
 // std::__introsort_loop on the queued segments (see above).  All threads of the workgroup call this after the queue has
-// been filled and a barrier; returns after a barrier, false if the queue overflowed (cannot happen for m <= kMaxSlice).
+// been filled and a barrier; returns after a barrier, false if the ring overflowed (cannot happen with a capacity of
+// 2 m / 17 or more).
 template <class Item>
 __device__ bool wave_sort_arrangement(Item* a, const SortScratch& sc) {
   Queue* q = sc.queue;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned level_begin = 0u;
   for (int level = 0; level < 4 * 64; ++level) {  // (a path has at most 2 lg n partitions; the bound only guards the loop)
-    const unsigned level_end = min(q->reserved, q->capacity);
+    const unsigned level_end = q->reserved;
+    const bool overflowed = q->overflow != 0u;  // (read here, where nobody appends: the same answer in every thread)
+    if (threadIdx.x == 0) q->level_begin = level_begin;
     __syncthreads();  // everybody has read the level's end before anybody appends to the queue
-    if (level_begin >= level_end) break;
+    if (level_begin >= level_end || overflowed) break;
     for (unsigned e = level_begin + static_cast<unsigned>(wave); e < level_end; e += kThreads / 64) {
-    const uint2 entry = q->seg[e];
+    const uint2 entry = q->seg[e % q->capacity];
     const int first = static_cast<int>(entry.x & 0xffffu), last = static_cast<int>(entry.x >> 16);
     const int depth = static_cast<int>(entry.y);
     if (depth == 0) {
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(kThreads) void slice_kernel(const float* __restrict
       DLIOM_STAMP(14);
       const bool done = wave_sort_arrangement(replay, sort_scratch);
       DLIOM_STAMP(15);
-      if (!done) {  // the queue overflowed (cannot happen for m <= kMaxSlice): refuse, the host path takes the cloud
+      if (!done) {  // the ring overflowed (cannot happen for m <= kMaxSlice): refuse, the host path takes the cloud
         if (threadIdx.x == 0) atomicOr(flags, 4u);
         continue;
       }

@@ -195,7 +195,7 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
     const size_t arr_bytes = (static_cast<size_t>(m) + 2) / 2 * 8;               // u32 [m + 1], 8-byte aligned end
     const size_t stop_bytes = (static_cast<size_t>(m) + 8 + 3) / 4 * 8;          // u16 [m + 8]
     const size_t tied_bytes = (static_cast<size_t>(count) + 8 + 15) / 16 * 16;   // u8 [count + 8]
-    // the queue of the wave-per-segment stage: every queued segment has more than 16 elements and they nest
+    // the ring of the wave-per-segment stage: the segments of a level are disjoint and have more than 16 elements each
     const size_t queue_entries = 2 * static_cast<size_t>(m) / 17 + 64;
     const size_t need = arr_bytes + 2 * stop_bytes + tied_bytes + 16 + queue_entries * sizeof(uint2) + 16;
     if (need <= kBigLdsBytes && count < 65536 && 2 * stop_bytes >= 2 * static_cast<size_t>(count)) {

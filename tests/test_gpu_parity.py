@@ -1640,6 +1640,41 @@ def test_device_std_sort_order_above_4096_keys(dl, ctx, orc):
 
 
 @pytest.mark.gpu
+def test_device_std_sort_order_on_paths_of_lopsided_partitions(dl, ctx, orc):
+    """Descending keys in runs of ties make introsort partition lopsidedly: one segment queued per level on many paths,
+    1 277 segments in all for 9 716 keys in tied pairs -- more than the 2 m / 17 + 64 the device's segment queue held
+    when it kept every segment ever queued (found by round 6's soak of tools/fuzz_round3.py, seed 4401690: refused with
+    DLIOM_ERR_CAPACITY; the histogram took its host fallback for such a slice).  The queue is a ring now: what is alive
+    at a time is bounded by 2 m / 17, what was ever queued is not."""
+    for n in (9716, 4096, 3000, 15800, 30000):
+        for run in (2, 3, 5, 8):
+            keys = (-np.arange(n) // run).astype(np.float32)
+            got = dl.diag_std_sort_order(ctx, keys)
+            assert np.array_equal(got, orc.std_sort_order(keys)), (n, run)
+    # ... and a cloud whose one slice holds such angles: the histogram itself, without the host's help
+    n = 9716
+
+    def ring(index):
+        ang = np.pi - index.astype(np.float64) * (2 * np.pi / (n // 2 + 2))
+        return np.stack([5.0 * np.cos(ang), 5.0 * np.sin(ang), np.full(n, 0.05)], axis=1).astype(np.float32)
+
+    pts = ring((np.arange(n) + 1) // 2)  # pairs of equal angles, descending: 1 273 segments, no depth limit
+    cloud = dl.PointCloud(ctx, pts)
+    got = dl.cloud_rotational_histogram(ctx, cloud, 120)
+    want = np.asarray(orc.compute_histogram(pts, 120), np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    cloud.close()
+    # The same pairs one position over (x0 == x1 > x2 == x3 ...) send libstdc++'s median-of-three down a path that strips
+    # two elements a partition: the depth limit on a 9 663-element segment, and std::sort heap-sorts it -- one thread's
+    # work, which the device refuses (DESIGN 8): DLIOM_ERR_CAPACITY, and the adapters compute that cloud on the host.
+    cloud = dl.PointCloud(ctx, ring(np.arange(n) // 2))
+    with pytest.raises(dl.DliomError) as e:
+        dl.cloud_rotational_histogram(ctx, cloud, 120)
+    assert e.value.status == dl.ERR_CAPACITY
+    cloud.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["64x1024", "64x1024_noise_rotated", "64x1024_raw", "128x2048", "128x2048_noise_free", "flat_5000", "two_floors"])
 def test_device_rotational_histogram_on_scans_with_a_floor(dl, ctx, orc, case):
     """every real scan has a floor, and a floor puts 15 000 (64 x 1024, 0.15 m filter) to 60 000
