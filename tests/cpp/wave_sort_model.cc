@@ -2,7 +2,10 @@
 // still hold two tied elements, one "wave" (64 lanes, emulated by loops: ballots become bit masks, lane ranks become
 // prefix counts) per segment, the segments served level by level from a queue; then a stable sort by (key, arrangement
 // position).  Checked against this machine's std::sort on arrays full of ties and on the files of slice angles the other
-// models use.  Usage: wave_sort_model [cases] [slices.txt] -> "mismatches: 0 of N".
+// models use.  The queue is the device's RING of 2 n / 17 + 64 entries (1024 up to 4096 keys): what is alive at a time --
+// the rest of the level being served and the children appended so far, disjoint segments of more than 16 elements each --
+// fits; what was EVER queued need not (paths of lopsided partitions: descending keys in tied runs, the soak's finding of
+// round 6).  Usage: wave_sort_model [cases] [slices.txt] -> "mismatches: 0 of N ... ring overflows 0".
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -31,10 +34,22 @@ static void heap_sort(Item* first, int len) {
   for (int last = len; last > 1;) { --last; const Item v = first[last]; first[last] = first[0]; heap_adjust(first, 0, last, v); }
 }
 struct Seg { int first, last, depth; };
-static long g_levels = 0, g_heaps = 0;
+static long g_levels = 0, g_heaps = 0, g_overflows = 0, g_most_alive_permille = 0, g_ever_above_capacity = 0;
+struct Ring {  // Queue of rotational_histogram.hip: queue_push / the reads of wave_sort_arrangement
+  std::vector<Seg> seg;
+  size_t reserved = 0, level_begin = 0;
+  explicit Ring(size_t capacity) : seg(capacity) {}
+  void push_back(const Seg& s) {
+    const size_t slot = reserved++;
+    if (slot - level_begin < seg.size()) seg[slot % seg.size()] = s; else ++g_overflows;
+    const long permille = static_cast<long>(1000 * (slot - level_begin + 1) / seg.size());
+    if (permille > g_most_alive_permille) g_most_alive_permille = permille;
+  }
+  const Seg& at(size_t e) const { return seg[e % seg.size()]; }
+};
 
 static void wave_partition(std::vector<Item>& a, const std::vector<char>& tied, const Seg& s, std::vector<int>& tmp_l, std::vector<int>& tmp_r,
-                           std::vector<Seg>* queue) {
+                           Ring* queue) {
   const int first = s.first, last = s.last, depth = s.depth;
   if (depth == 0) { ++g_heaps; heap_sort(a.data() + first, last - first); return; }
   {  // lane 0
@@ -96,17 +111,19 @@ static std::vector<int> model_order(const std::vector<float>& keys) {
   for (int j = 0; j + 1 < n; ++j) if (sorted[j].key == sorted[j + 1].key) tied[sorted[j].id] = tied[sorted[j + 1].id] = 1, any = true;
   std::vector<int> order(n);
   if (!any) { for (int j = 0; j < n; ++j) order[j] = sorted[j].id; return order; }
-  std::vector<Seg> queue;
+  Ring queue(n <= 4096 ? 1024 : 2 * static_cast<size_t>(n) / 17 + 64);  // kQueueCap / rothist_big.h's queue_entries
   std::vector<int> tmp_l(n + 8), tmp_r(n + 8);
   if (n > 16) { int depth = 0; for (int v = n; v > 1; v >>= 1) ++depth; queue.push_back(Seg{0, n, 2 * depth}); }
   size_t level_begin = 0;
   for (;;) {
-    const size_t level_end = queue.size();
+    const size_t level_end = queue.reserved;
+    queue.level_begin = level_begin;
     if (level_begin >= level_end) break;
     ++g_levels;
-    for (size_t e = level_begin; e < level_end; ++e) { const Seg s = queue[e]; wave_partition(a, tied, s, tmp_l, tmp_r, &queue); }
+    for (size_t e = level_begin; e < level_end; ++e) { const Seg s = queue.at(e); wave_partition(a, tied, s, tmp_l, tmp_r, &queue); }
     level_begin = level_end;
   }
+  if (queue.reserved > queue.seg.size()) ++g_ever_above_capacity;
   std::vector<std::pair<std::pair<unsigned, int>, int>> fin(n);
   for (int q = 0; q < n; ++q) fin[q] = {{a[q].key, q}, a[q].id};
   std::sort(fin.begin(), fin.end());
@@ -144,6 +161,17 @@ int main(int argc, char** argv) {
     if (kind == 3 && n > 8) for (int r = 0; r < 3; ++r) k[rng() % n] = k[rng() % n];
     if (!check(k)) { ++bad; if (bad < 5) std::printf("MISMATCH n=%d kind=%d\n", n, kind); }
   }
+  // paths of lopsided partitions: descending keys in runs of ties, beyond 4096 keys as well (there the device serves the
+  // largest segments by the whole workgroup first; the ring's bound does not depend on who partitions)
+  long lopsided = 0;
+  for (int n : {9716, 4096, 3000, 12000, 15800})
+    for (int run : {2, 3, 5, 8})
+      for (int shift : {0, 1}) {
+        std::vector<float> k(n);
+        for (int i = 0; i < n; ++i) k[i] = -static_cast<float>((i + shift) / run);
+        ++lopsided;
+        if (!check(k)) { ++bad; std::printf("MISMATCH lopsided n=%d run=%d shift=%d\n", n, run, shift); }
+      }
   long file_cases = 0;
   if (argc > 2) {
     FILE* f = std::fopen(argv[2], "r");
@@ -155,6 +183,8 @@ int main(int argc, char** argv) {
     }
     if (f != nullptr) std::fclose(f);
   }
-  std::printf("mismatches: %ld of %ld (+ %ld from the file); levels %ld, heap sorts %ld\n", bad, cases, file_cases, g_levels, g_heaps);
-  return bad == 0 ? 0 : 1;
+  std::printf("mismatches: %ld of %ld (+ %ld from the file, + %ld lopsided); levels %ld, heap sorts %ld; ring overflows %ld, most alive %ld permille of the ring, "
+              "arrays that queued more segments than the ring holds: %ld\n",
+              bad, cases, file_cases, lopsided, g_levels, g_heaps, g_overflows, g_most_alive_permille, g_ever_above_capacity);
+  return bad == 0 && g_overflows == 0 ? 0 : 1;
 }

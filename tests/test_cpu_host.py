@@ -658,7 +658,7 @@ def test_wave_per_segment_replay_of_std_sort_model(tmp_path, orc):
     """tests/cpp/wave_sort_model.cc: wave_sort_arrangement's formulation (one 64-lane wave partitions one segment with
     ballots and lane ranks; only segments that hold two tied elements; the queue served level by level; heap sort at the
     depth limit; a stable sort at the end) against this machine's std::sort: 3 000 arrays full of ties + the slices of a
-    cube scan and a yard scan."""
+    cube scan and a yard scan + 40 arrays of descending tied runs (paths of lopsided partitions) up to 15 800 keys."""
     from dliom import synth
     from helpers import slice_angle_arrays
     exe = str(tmp_path / "wave_sort_model")
@@ -675,6 +675,10 @@ def test_wave_per_segment_replay_of_std_sort_model(tmp_path, orc):
     out = subprocess.run([exe, "3000", str(slices)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "mismatches: 0 of 3000" in out.stdout, out.stdout
     assert int(re.search(r"heap sorts (\d+)", out.stdout).group(1)) >= 1, out.stdout  # the depth limit is exercised
+    # the segment queue is the device's ring (2 n / 17 + 64 entries): never overflowed, although arrays of descending tied
+    # runs queue more segments in all than it holds (round 6's soak: that used to be a refusal)
+    assert "ring overflows 0," in out.stdout, out.stdout
+    assert int(re.search(r"more segments than the ring holds: (\d+)", out.stdout).group(1)) >= 1, out.stdout
 
 
 def test_blocked_chain_walk_model(tmp_path):
