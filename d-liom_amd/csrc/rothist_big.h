@@ -589,9 +589,15 @@ __device__ bool big_sort_order(const unsigned long long* __restrict__ sk, const 
       // With a handful of tied pairs the segments that matter halve with every partition: a few workgroup-wide
       // partitions (~9 us each) until everything left fits LDS at once beat several LDS batches (~40 us each).  With ties
       // everywhere nothing shrinks: then the segments go through LDS in batches as soon as they are small enough.
+      // A segment at std::sort's depth limit is heap-sorted, which wave_sort_arrangement does (one lane) for what fits LDS:
+      // such a segment goes with a batch however much else is waiting.  (Round 6's soak, 18 865 keys with a fifth of
+      // them tied: a path of lopsided partitions reached the limit on 1 203 elements while 5 000 others waited, the
+      // workgroup-wide branch was chosen for it and refused.)
       int mode = 0;
-      if (wl_n > 0)
-        mode = ((best > kMaxSlice || (total > kMaxSlice && best > kMaxSlice / 4)) && wl_n < kWorkListCap - 2) ? 1 : 2;
+      if (wl_n > 0) {
+        const bool by_workgroup = best > kMaxSlice || (total > kMaxSlice && best > kMaxSlice / 4 && wl_depth[pick] > 0);
+        mode = (by_workgroup && wl_n < kWorkListCap - 2) ? 1 : 2;
+      }
       if (mode == 2) {  // the batch: entries in list order while they fit; the chosen ones move to the END of the list
         int at = 0, taken = 0, n = wl_n;
         for (int e = 0; e < n - taken;) {

@@ -50,6 +50,7 @@ def main():
     st = rt.last_stats()
     C, n = int(st.window.num_candidates), int(st.num_points)
     dev_best = int(st.best_index)
+    variant_match = int(st.box_kernel_variant)
     dev_sums = rt.score_volume(sc["init"], sc["pts"], grids[0])
     flags = int(rt.box_error())
     og = device_grid_to_oracle(orc, grids[0], res_hi)
@@ -83,7 +84,9 @@ def main():
         "volume_mismatches": mism, "winner_equal": winner_equal,
         "device": {"best_index": dev_best, "score": float(score), "score_bits": int(np.float32(score).view(np.uint32)),
                    "pose": [float(x) for x in pose], "match_seconds_first_call": t_match, "box_kernel_flags": flags,
-                   "score_kernel": int(st.score_kernel), "rescored_candidates": int(st.num_rescored)},
+                   "score_kernel": int(st.score_kernel), "rescored_candidates": int(st.num_rescored),
+                   "box_kernel_variant": variant_match,  # 2 = 49 translations per pass; the volume comes from the same launch path
+                   },
         "oracle": {"best_index": ref_best, "score": top, "score_bits": int(ref_scores[ref_best].view(np.uint32)),
                    "pose": [float(x) for x in ref_pose], "threads": threads, "seconds": t_cpu,
                    "lookups_per_second": float(C) * n / t_cpu,

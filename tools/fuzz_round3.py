@@ -20,6 +20,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: run for --seconds)")
+    ap.add_argument("--big-sorts", action="store_true", help="kind 1: every array above 4096 keys (the big slices' sort), up to 40 000")
     ap.add_argument("--kinds", default="0,1,2", help="which case kinds run (0 histogram, 1 std::sort order, 2 AddRangeData); the others are skipped")
     args = ap.parse_args(argv)
     import dliom as dl
@@ -86,6 +87,8 @@ def main(argv=None):
             counts["histogram"] += 1
         elif kind == 1:  # std::sort's order
             n = int(rng.randint(1, 4097)) if rng.rand() < 0.85 else int(rng.randint(4097, 30000))  # above 4096: the HBM path
+            if args.big_sorts:
+                n = int(rng.randint(4097, 40000))
             choice = int(rng.randint(0, 5))
             if choice == 0:
                 keys = rng.randint(0, max(1, n // int(rng.randint(1, 40))), n)
