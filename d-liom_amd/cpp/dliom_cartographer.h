@@ -899,7 +899,6 @@ class LocalTrajectoryBuilder3D {
     result->range_data_in_local.origin = TransformPoint(pf, origin[0], origin[1], origin[2]);
     result->range_data_in_local.returns.resize(static_cast<size_t>(n));
     static_assert(sizeof(sensor::Vector3f) == 12, "packed xyz");
-    Check(dliom_cloud_download_transformed(cloud, pf, &result->range_data_in_local.returns[0].x), "TransformRangeData");
     // ComputeHistogram (.cc:605-610) reads the same filtered cloud as the insertion and writes nothing the insertion
     // reads: its kernels are started first, on the context's auxiliary stream, and run beside the insertion's
     const float rot_wxyz[4] = {pf[3], pf[4], pf[5], pf[6]};
@@ -918,6 +917,8 @@ class LocalTrajectoryBuilder3D {
         if (*pending) (void)dliom_cloud_rotational_histogram_finish(c, discard);
       }
     } pending_guard{context_->get(), &histogram_pending};
+    // (the returns come down while the histogram's kernels run on their stream: in front of them this wait was exposed)
+    Check(dliom_cloud_download_transformed(cloud, pf, &result->range_data_in_local.returns[0].x), "TransformRangeData");
     // InsertIntoSubmap (.cc:584-622): gravity_alignment = opt_pose.rotation()
     dliom_insertion_result ins;
     Check(dliom_front_end_insert(active_submaps_.get(), time, opt, opt + 3, &ins), "InsertIntoSubmap");
@@ -928,6 +929,17 @@ class LocalTrajectoryBuilder3D {
       ir->local_pose = result->local_pose;
       for (int i = 0; i < ins.num_insertion_submaps; ++i) ir->insertion_submap_indices.push_back(ins.insertion_submap_index[i]);
       ir->submap_finished = ins.submap_finished != 0;
+      // (the two adaptively filtered clouds first: their downloads overlap what is left of the histogram)
+      const dliom_cloud* filtered[2] = {nullptr, nullptr};
+      Check(dliom_front_end_matched_clouds(active_submaps_.get(), &filtered[0], &filtered[1]), "matched clouds");
+      sensor::PointCloud* const dst[2] = {&ir->high_resolution_point_cloud, &ir->low_resolution_point_cloud};
+      for (int k = 0; k < 2; ++k) {
+        int64_t m_points = 0;
+        if (filtered[k] == nullptr) continue;
+        Check(dliom_cloud_size(filtered[k], &m_points), "dliom_cloud_size");
+        dst[k]->resize(static_cast<size_t>(m_points));
+        if (m_points > 0) Check(dliom_cloud_download(filtered[k], &(*dst[k])[0].x), "dliom_cloud_download");
+      }
       // ComputeHistogram(TransformPointCloud(filtered_range_data_in_tracking.returns, Rotation(gravity_alignment.cast<float>())), size)
       // on the device, where the filtered cloud already is (rotation fused; slices of any size -- the floor of a real scan
       // puts 15 000 returns into one 0.2 m slice); the host version only for what the device one refuses (|z| beyond
@@ -948,16 +960,6 @@ class LocalTrajectoryBuilder3D {
                                           ir->rotational_scan_matcher_histogram.data());
         }
         Check(hs, "RotationalScanMatcher::ComputeHistogram");
-      }
-      const dliom_cloud* filtered[2] = {nullptr, nullptr};
-      Check(dliom_front_end_matched_clouds(active_submaps_.get(), &filtered[0], &filtered[1]), "matched clouds");
-      sensor::PointCloud* const dst[2] = {&ir->high_resolution_point_cloud, &ir->low_resolution_point_cloud};
-      for (int k = 0; k < 2; ++k) {
-        int64_t m_points = 0;
-        if (filtered[k] == nullptr) continue;
-        Check(dliom_cloud_size(filtered[k], &m_points), "dliom_cloud_size");
-        dst[k]->resize(static_cast<size_t>(m_points));
-        if (m_points > 0) Check(dliom_cloud_download(filtered[k], &(*dst[k])[0].x), "dliom_cloud_download");
       }
       result->insertion_result = std::move(ir);
     }
