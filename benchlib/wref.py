@@ -28,10 +28,12 @@ def wref_line(dl, ctx, cpu):
     try:
         import wref_cpp
         from dliom import synth
-        cpp = wref_cpp.measure(dl, synth, scans=24, warmup=4, runs=1)
+        cpp = wref_cpp.measure(dl, synth, scans=24, warmup=4, runs=1, pinned_scans=True)
         for k, v in cpp.items():
             if k in out:
                 out[k]["cpp_adapter"] = {x: v[x] for x in ("harness", "scans_per_s", "p50_ms", "p99_ms", "read_backs_per_scan", "results", "inserted")}
+                if "scans_per_s_with_pinned_scans" in v:  # the caller's scan buffers page-locked (dliom_host_register): the upload is one DMA
+                    out[k]["cpp_adapter"]["scans_per_s_with_pinned_scans"] = v["scans_per_s_with_pinned_scans"]
     except Exception as e:  # g++ missing on the box, ...: the Python-driven lines stand
         out["cpp_adapter_error"] = ("%s: %s" % (type(e).__name__, e))[:300]
     return out

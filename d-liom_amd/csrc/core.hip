@@ -820,6 +820,31 @@ int dliom_ctx_read_backs(const dliom_ctx* ctx, int64_t* count) {
   return DLIOM_OK;
 }
 
+int dliom_host_register(dliom_ctx* ctx, void* buffer, size_t bytes) {
+  if (ctx == nullptr || buffer == nullptr || bytes == 0) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  const hipError_t e = hipHostRegister(buffer, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    set_last_error("hipHostRegister", e, __FILE__, __LINE__);
+    (void)hipGetLastError();  // the runtime keeps the error for the next hipGetLastError(): a later launch check must not find it
+    return e == hipErrorHostMemoryAlreadyRegistered ? DLIOM_ERR_INVALID_ARGUMENT : DLIOM_ERR_HIP;
+  }
+  return DLIOM_OK;
+}
+
+int dliom_host_unregister(dliom_ctx* ctx, void* buffer) {
+  if (ctx == nullptr || buffer == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
+  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
+  DLIOM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // nothing of this context still reads it
+  const hipError_t e = hipHostUnregister(buffer);
+  if (e != hipSuccess) {
+    set_last_error("hipHostUnregister", e, __FILE__, __LINE__);
+    (void)hipGetLastError();
+    return e == hipErrorHostMemoryNotRegistered ? DLIOM_ERR_INVALID_ARGUMENT : DLIOM_ERR_HIP;
+  }
+  return DLIOM_OK;
+}
+
 int dliom_ctx_poll_fallbacks(const dliom_ctx* ctx, int64_t* count) {
   if (ctx == nullptr || count == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
   *count = ctx->poll_fallbacks;

@@ -324,6 +324,8 @@ SYMBOLS = [
     ("dliom_ctx_poll_fallbacks", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("dliom_ctx_read_backs", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("dliom_ctx_voxel_filter_reruns", C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    ("dliom_host_register", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("dliom_host_unregister", C.c_int, [_vp, _vp]),
     ("dliom_ctx_get_tuning", C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     ("dliom_deskew_check_stats", C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("dliom_ctx_set_profiling", C.c_int, [_vp, C.c_int]),
@@ -431,6 +433,13 @@ class Context:
     def set_mirror_budget(self, num_bytes):
         """dliom_ctx_set_mirror_budget: cap on the sum of this context's dense mirrors (0 = none)."""
         _check(self._L.dliom_ctx_set_mirror_budget(self.h, int(num_bytes)), "ctx_set_mirror_budget")
+
+    def host_register(self, array):
+        """dliom_host_register: page-locks a numpy array the caller keeps (uploads from it become one asynchronous DMA)."""
+        _check(self._L.dliom_host_register(self.h, C.c_void_p(array.ctypes.data), C.c_size_t(array.nbytes)), "host_register")
+
+    def host_unregister(self, array):
+        _check(self._L.dliom_host_unregister(self.h, C.c_void_p(array.ctypes.data)), "host_unregister")
 
     def read_backs(self):
         """dliom_ctx_read_backs: polled host round trips on this context so far."""

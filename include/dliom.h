@@ -26,6 +26,7 @@
 #ifndef DLIOM_H_
 #define DLIOM_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -823,6 +824,14 @@ int dliom_ctx_read_backs(const dliom_ctx* ctx, int64_t* count);
  * one atomic.  A cloud with a point farther than 4095 voxel edges from the origin (61 m at 1.5 cm) does not fit: the
  * launch is repeated with 21-bit keys (same result).  *count = how often that happened on this context. */
 int dliom_ctx_voxel_filter_reruns(const dliom_ctx* ctx, int64_t* count);
+/* Page-locks a host buffer the caller keeps (a LiDAR driver's ring of scan buffers, the vector a
+ * sensor::TimedPointCloudData is filled into): uploads from it -- dliom_add_range_data's scan, dliom_cloud_create's
+ * points -- are then one asynchronous DMA instead of the runtime's staged copy of pageable memory (a 64 x 1024 scan of
+ * 1 MB: ~38 us of a 0.55 ms W-ref scan, tools/wref_cpp.py --pinned-scans).  Registering costs hundreds of microseconds:
+ * for buffers that live across scans, not per call.  Results do not depend on it.  Every entry point that takes such a
+ * buffer has consumed it when it returns, pinned or not.  The reference has no counterpart (its data never leaves the host). */
+int dliom_host_register(dliom_ctx* ctx, void* buffer, size_t bytes);
+int dliom_host_unregister(dliom_ctx* ctx, void* buffer);
 
 /* Kernel timing (HIP events on the context's stream). */
 enum {

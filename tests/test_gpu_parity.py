@@ -813,6 +813,49 @@ def test_add_range_data_device_chain(dl, ctx, orc, beams, azimuths, k):
 
 
 @pytest.mark.gpu
+def test_page_locked_caller_buffers_change_nothing_but_the_upload(dl, ctx, orc):
+    """dliom_host_register / dliom_host_unregister (round 6): a scan buffer the caller keeps page-locked is uploaded by
+    one asynchronous DMA (tools/wref_cpp.py --pinned-scans: +6 % scans/s through the C++ adapters).  Same survivors, same
+    bits, from the registered buffer, from a cloud created out of one, and again after the buffer is released; the
+    entry points have consumed the buffer when they return (it is overwritten right after the call here)."""
+    prev, cur, ranges = _timed_scan(64, 1024, k=5)
+    ranges = np.ascontiguousarray(ranges, dtype=np.float32)
+    vfs, min_r, max_r, T = 0.15, 1.0, 100.0, 0.1
+    plain, origin_p, cur_p = dl.add_range_data(ctx, prev, cur, T, ranges, (0, 0, 0), min_r, max_r, vfs)
+    want = plain.download()
+    plain.close()
+    pinned = ranges.copy()
+    ctx.host_register(pinned)
+    for _ in range(3):
+        pinned[:] = ranges
+        cloud, origin_d, cur_d = dl.add_range_data(ctx, prev, cur, T, pinned, (0, 0, 0), min_r, max_r, vfs)
+        pinned[:] = 0.0  # consumed: the call has read it
+        assert np.array_equal(cloud.download().view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(origin_d, origin_p) and np.array_equal(cur_d, cur_p)
+        cloud.close()
+    pts = np.ascontiguousarray(ranges[:, :3])
+    ctx.host_register(pts)
+    c = dl.PointCloud(ctx, pts)
+    pts_copy = pts.copy()
+    pts[:] = -1.0
+    assert np.array_equal(c.download(), pts_copy)
+    c.close()
+    ctx.host_unregister(pts)
+    ctx.host_unregister(pinned)
+    pinned[:] = ranges
+    again, _, _ = dl.add_range_data(ctx, prev, cur, T, pinned, (0, 0, 0), min_r, max_r, vfs)
+    assert np.array_equal(again.download().view(np.uint32), want.view(np.uint32))
+    again.close()
+    with pytest.raises(dl.DliomError) as e:
+        ctx.host_unregister(pinned)  # not registered (any more)
+    assert e.value.status == dl.ERR_INVALID_ARGUMENT
+    # ... and the refused call leaves nothing behind for the next launch check to find
+    c = dl.PointCloud(ctx, pts_copy)
+    assert np.array_equal(c.download(), pts_copy)
+    c.close()
+
+
+@pytest.mark.gpu
 def test_add_range_data_one_read_back_per_stage_and_its_fallback(dl, ctx, orc):
     """Round 5: dliom_add_range_data reads back once per stage -- the voxel filters are only enqueued (packed table
     words) and the kernels behind them take the survivor counts from the device.  A range farther than 4095 filter edges

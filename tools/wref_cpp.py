@@ -49,7 +49,7 @@ def write_stream(dl, path, cfg, T, clouds, imus, state0, warmup, histogram_size=
     w.close()
 
 
-def measure(dl, synth, scans=24, warmup=4, runs=3, compare=False):
+def measure(dl, synth, scans=24, warmup=4, runs=3, compare=False, pinned_scans=False):
     """{options[_yard]: line} for both option sets on both scenes; the harness is compiled once."""
     import wref_full
     out = {}
@@ -72,6 +72,10 @@ def measure(dl, synth, scans=24, warmup=4, runs=3, compare=False):
                 best = max(got_runs, key=lambda x: x["scans_per_s"])
                 line = dict(best, options=name, scene=scene, returns_per_scan=int(np.mean([len(c) for c in clouds])),
                             scans_per_s_all_runs=[x["scans_per_s"] for x in got_runs], imu_window=cfg["window"])
+                if pinned_scans:  # the same stream with the scans in page-locked memory (dliom_host_register before the clock starts)
+                    r = subprocess.run([exe, path, poses_path, "pinned"], capture_output=True, text=True, timeout=600)
+                    if r.returncode == 0:
+                        line["scans_per_s_with_pinned_scans"] = json.loads(r.stdout.strip().splitlines()[-1])["scans_per_s"]
                 if compare:
                     ctx = dl.Context(0)
                     _, poses, _, _ = wref_full.run_chain(dl, cfg, T, clouds, imus, state0, True, ctx=ctx)
@@ -89,12 +93,13 @@ def main():
     ap.add_argument("--scans", type=int, default=24)  # the cube scene's arc leaves its room after ~30 scans (wref_full.py uses 24 too)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--compare", action="store_true", help="also run the Python-driven chain and print the pose difference (the two feed their IMU samples with different first time steps: centimetres through the matcher, not a parity figure)")
+    ap.add_argument("--pinned-scans", action="store_true", help="one more run per stream with the scans in page-locked memory")
     a = ap.parse_args()
     import dliom as dl
     from dliom import synth
     import wref_full
     dl.load_library()
-    out = measure(dl, synth, a.scans, a.warmup, runs=3, compare=a.compare)
+    out = measure(dl, synth, a.scans, a.warmup, runs=3, compare=a.compare, pinned_scans=a.pinned_scans)
     print(json.dumps(out))
 
 
