@@ -37,6 +37,31 @@
 
 #include "../../include/dliom.h"
 
+// -DDLIOM_ADAPTER_STAGE_TIMES (tools/wref_cpp.py --stages): microseconds between the marks of AddRangeData's single-sensor
+// path, summed per mark.  Nothing of it exists in a normal build.
+#ifdef DLIOM_ADAPTER_STAGE_TIMES
+namespace dliom {
+namespace stage_times {
+inline double* table() {
+  static double t[16] = {0};
+  return t;
+}
+inline std::chrono::steady_clock::time_point& last() {
+  static std::chrono::steady_clock::time_point p = std::chrono::steady_clock::now();
+  return p;
+}
+inline void mark(int i) {
+  const auto now = std::chrono::steady_clock::now();
+  table()[i] += std::chrono::duration<double, std::micro>(now - last()).count();
+  last() = now;
+}
+}  // namespace stage_times
+}  // namespace dliom
+#define DLIOM_ADAPTER_STAGE(i) ::dliom::stage_times::mark(i)
+#else
+#define DLIOM_ADAPTER_STAGE(i)
+#endif
+
 namespace dliom {
 
 inline void Check(int status, const char* what) {
@@ -764,6 +789,7 @@ class LocalTrajectoryBuilder3D {
       if (unsynchronized.ranges.empty() || !imu_initialized_ || !have_prediction_) return nullptr;
       if (unsynchronized.ranges.back().t > 0.1f) Check(DLIOM_ERR_INVALID_ARGUMENT, "CHECK_LE(ranges.back().point_time[3], 0.1f)");
       static_assert(sizeof(sensor::TimedPoint) == 16, "packed x, y, z, t");
+      DLIOM_ADAPTER_STAGE(0);  // since the last result: the caller, AddImuData
       double prev[7], vel[3], bias[6], predicted[7], pvel[3];
       Check(dliom_imu_window_state(window_, 0, prev, vel, bias), "dliom_imu_window_state");
       Check(dliom_imu_window_predict(window_, predicted, pvel), "dliom_imu_window_predict");
@@ -775,6 +801,7 @@ class LocalTrajectoryBuilder3D {
                                  static_cast<int64_t>(unsynchronized.ranges.size()), origin, options_.min_range, options_.max_range,
                                  options_.voxel_filter_size, &cloud, origin_in_tracking, current_pose),
             "AddRangeData (de-skew, filters, tracking frame)");
+      DLIOM_ADAPTER_STAGE(1);
       return AddAccumulatedRangeData(unsynchronized.time, current_pose, origin_in_tracking, cloud);
     }
     const sensor::TimedPointCloudOriginData sync =
@@ -872,6 +899,7 @@ class LocalTrajectoryBuilder3D {
     for (int i = 0; i < 7; ++i) prediction[i] = static_cast<double>(current_pose[i]);  // current_pose.cast<double>()
     dliom_match_result m;
     Check(dliom_front_end_match_cloud(active_submaps_.get(), prediction, origin, cloud, &m), "AddAccumulatedRangeData (match)");
+    DLIOM_ADAPTER_STAGE(2);
     if (m.dropped) return nullptr;
     if (options_.front_end.use_online_correlative_scan_matching) metrics_().rtcsm_score->Observe(m.rtcsm_score);  // :520
     metrics_().ceres_cost->Observe(m.summary.final_cost);                                                         // :543
@@ -887,6 +915,7 @@ class LocalTrajectoryBuilder3D {
       ++failure_detections_;
     else
       Check(ws, "WindowOptimize");
+    DLIOM_ADAPTER_STAGE(3);
     have_prediction_ = false;
     std::unique_ptr<MatchingResult> result(new MatchingResult);
     result->time = time;
@@ -899,6 +928,7 @@ class LocalTrajectoryBuilder3D {
     result->range_data_in_local.origin = TransformPoint(pf, origin[0], origin[1], origin[2]);
     result->range_data_in_local.returns.resize(static_cast<size_t>(n));
     static_assert(sizeof(sensor::Vector3f) == 12, "packed xyz");
+    DLIOM_ADAPTER_STAGE(4);
     // ComputeHistogram (.cc:605-610) reads the same filtered cloud as the insertion and writes nothing the insertion
     // reads: its kernels are started first, on the context's auxiliary stream, and run beside the insertion's
     const float rot_wxyz[4] = {pf[3], pf[4], pf[5], pf[6]};
@@ -917,11 +947,14 @@ class LocalTrajectoryBuilder3D {
         if (*pending) (void)dliom_cloud_rotational_histogram_finish(c, discard);
       }
     } pending_guard{context_->get(), &histogram_pending};
+    DLIOM_ADAPTER_STAGE(5);
     // (the returns come down while the histogram's kernels run on their stream: in front of them this wait was exposed)
     Check(dliom_cloud_download_transformed(cloud, pf, &result->range_data_in_local.returns[0].x), "TransformRangeData");
+    DLIOM_ADAPTER_STAGE(6);
     // InsertIntoSubmap (.cc:584-622): gravity_alignment = opt_pose.rotation()
     dliom_insertion_result ins;
     Check(dliom_front_end_insert(active_submaps_.get(), time, opt, opt + 3, &ins), "InsertIntoSubmap");
+    DLIOM_ADAPTER_STAGE(7);
     if (ins.inserted) {
       std::unique_ptr<InsertionResult> ir(new InsertionResult);
       ir->time = time;
@@ -940,6 +973,7 @@ class LocalTrajectoryBuilder3D {
         dst[k]->resize(static_cast<size_t>(m_points));
         if (m_points > 0) Check(dliom_cloud_download(filtered[k], &(*dst[k])[0].x), "dliom_cloud_download");
       }
+      DLIOM_ADAPTER_STAGE(8);
       // ComputeHistogram(TransformPointCloud(filtered_range_data_in_tracking.returns, Rotation(gravity_alignment.cast<float>())), size)
       // on the device, where the filtered cloud already is (rotation fused; slices of any size -- the floor of a real scan
       // puts 15 000 returns into one 0.2 m slice); the host version only for what the device one refuses (|z| beyond
@@ -961,8 +995,10 @@ class LocalTrajectoryBuilder3D {
         }
         Check(hs, "RotationalScanMatcher::ComputeHistogram");
       }
+      DLIOM_ADAPTER_STAGE(9);
       result->insertion_result = std::move(ir);
     }
+    DLIOM_ADAPTER_STAGE(10);
     // .cc:566-568 (whole seconds, as the reference casts it)
     metrics_().latency->Set(static_cast<double>(
         std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - accumulation_started_).count()));

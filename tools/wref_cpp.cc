@@ -71,6 +71,12 @@ int main(int argc, char** argv) {
   std::vector<double> poses;  // every result's pose, for the Python side's comparison
   for (int s = 0; s < scans; ++s) {
     if (s == warmup) Check(dliom_ctx_read_backs(context.get(), &read_backs0), "read_backs");
+#ifdef DLIOM_ADAPTER_STAGE_TIMES
+    if (s == warmup) {
+      for (int i = 0; i < 16; ++i) stage_times::table()[i] = 0.0;
+      stage_times::last() = std::chrono::steady_clock::now();
+    }
+#endif
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < per; ++k) {
       sensor::ImuData d;
@@ -104,6 +110,16 @@ int main(int argc, char** argv) {
               sorted.back(), results, inserted, static_cast<double>(read_backs1 - read_backs0) / ms.size(),
               static_cast<long long>(builder.histogram_host_fallbacks()), last_pose[0], last_pose[1], last_pose[2], last_pose[3],
               last_pose[4], last_pose[5], last_pose[6]);
+#ifdef DLIOM_ADAPTER_STAGE_TIMES
+  {
+    static const char* const names[11] = {"caller + AddImuData", "dliom_add_range_data", "front_end_match_cloud", "window_optimize",
+                                          "result + resize", "histogram begin", "download returns (transformed)", "front_end_insert",
+                                          "download filtered clouds", "histogram finish", "assemble"};
+    std::fprintf(stderr, "stages, us per scan over the %d timed scans:", scans - warmup);
+    for (int i = 0; i < 11; ++i) std::fprintf(stderr, " %s %.1f;", names[i], stage_times::table()[i] / (scans - warmup));
+    std::fprintf(stderr, "\n");
+  }
+#endif
   if (pinned)
     for (auto& c : clouds) Check(dliom_host_unregister(context.get(), c.ranges.data()), "dliom_host_unregister");
   if (argc > 2) {  // poses for the comparison with the Python-driven chain

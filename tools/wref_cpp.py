@@ -21,10 +21,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def build(tmp):
+def build(tmp, stages=False):
     exe = os.path.join(tmp, "wref_cpp")
     libdir = os.path.join(ROOT, "d-liom_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(ROOT, "tools", "wref_cpp.cc"), "-L", libdir, "-ldliom",
+    subprocess.check_call(["g++", "-std=c++17", "-O2"] + (["-DDLIOM_ADAPTER_STAGE_TIMES"] if stages else []) + ["-o", exe, os.path.join(ROOT, "tools", "wref_cpp.cc"), "-L", libdir, "-ldliom",
                            "-Wl,-rpath," + libdir])
     return exe
 
@@ -49,12 +49,12 @@ def write_stream(dl, path, cfg, T, clouds, imus, state0, warmup, histogram_size=
     w.close()
 
 
-def measure(dl, synth, scans=24, warmup=4, runs=3, compare=False, pinned_scans=False):
+def measure(dl, synth, scans=24, warmup=4, runs=3, compare=False, pinned_scans=False, stages=False):
     """{options[_yard]: line} for both option sets on both scenes; the harness is compiled once."""
     import wref_full
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        exe = build(tmp)
+        exe = build(tmp, stages)
         for scene in ("cube", "ground"):
             with synth.scene(scene):
                 if scene == "cube":
@@ -69,6 +69,8 @@ def measure(dl, synth, scans=24, warmup=4, runs=3, compare=False, pinned_scans=F
                     if r.returncode != 0:
                         raise RuntimeError("wref_cpp failed: " + (r.stdout + r.stderr)[-400:])
                     got_runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+                    if stages:
+                        got_runs[-1]["stages"] = [l for l in r.stderr.splitlines() if l.startswith("stages")][-1:]
                 best = max(got_runs, key=lambda x: x["scans_per_s"])
                 line = dict(best, options=name, scene=scene, returns_per_scan=int(np.mean([len(c) for c in clouds])),
                             scans_per_s_all_runs=[x["scans_per_s"] for x in got_runs], imu_window=cfg["window"])
@@ -93,13 +95,14 @@ def main():
     ap.add_argument("--scans", type=int, default=24)  # the cube scene's arc leaves its room after ~30 scans (wref_full.py uses 24 too)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--compare", action="store_true", help="also run the Python-driven chain and print the pose difference (the two feed their IMU samples with different first time steps: centimetres through the matcher, not a parity figure)")
+    ap.add_argument("--stages", action="store_true", help="build the adapter with -DDLIOM_ADAPTER_STAGE_TIMES: microseconds per scan between its marks")
     ap.add_argument("--pinned-scans", action="store_true", help="one more run per stream with the scans in page-locked memory")
     a = ap.parse_args()
     import dliom as dl
     from dliom import synth
     import wref_full
     dl.load_library()
-    out = measure(dl, synth, a.scans, a.warmup, runs=3, compare=a.compare, pinned_scans=a.pinned_scans)
+    out = measure(dl, synth, a.scans, a.warmup, runs=3, compare=a.compare, pinned_scans=a.pinned_scans, stages=a.stages)
     print(json.dumps(out))
 
 
