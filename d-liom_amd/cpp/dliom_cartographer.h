@@ -172,6 +172,8 @@ class Rigid3d {
 namespace sensor {
 struct Vector3f {
   float x, y, z;
+  Vector3f() {}  // uninitialised like Eigen::Vector3f's: resizing a cloud that a download fills does not zero it first
+  Vector3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
 };
 static_assert(sizeof(Vector3f) == 12, "packed xyz like Eigen::Vector3f");
 using PointCloud = std::vector<Vector3f>;
