@@ -931,15 +931,6 @@ class LocalTrajectoryBuilder3D {
     result->range_data_in_local.returns.resize(static_cast<size_t>(n));
     static_assert(sizeof(sensor::Vector3f) == 12, "packed xyz");
     DLIOM_ADAPTER_STAGE(4);
-    // (the returns' one kernel is enqueued first: it runs while the host enqueues the histogram's dozen launches)
-    Check(dliom_cloud_download_begin(cloud, pf), "TransformRangeData (begin)");
-    struct PendingDownload {  // never leave one pending on the context, whatever path leaves this function
-      const dliom_cloud* c;
-      bool pending;
-      ~PendingDownload() {
-        if (pending) (void)dliom_cloud_download_finish(c, nullptr);
-      }
-    } download_guard{cloud, true};
     // ComputeHistogram (.cc:605-610) reads the same filtered cloud as the insertion and writes nothing the insertion
     // reads: its kernels are started first, on the context's auxiliary stream, and run beside the insertion's
     const float rot_wxyz[4] = {pf[3], pf[4], pf[5], pf[6]};
@@ -960,8 +951,7 @@ class LocalTrajectoryBuilder3D {
     } pending_guard{context_->get(), &histogram_pending};
     DLIOM_ADAPTER_STAGE(5);
     // (the returns come down while the histogram's kernels run on their stream: in front of them this wait was exposed)
-    download_guard.pending = false;
-    Check(dliom_cloud_download_finish(cloud, &result->range_data_in_local.returns[0].x), "TransformRangeData");
+    Check(dliom_cloud_download_transformed(cloud, pf, &result->range_data_in_local.returns[0].x), "TransformRangeData");
     DLIOM_ADAPTER_STAGE(6);
     // InsertIntoSubmap (.cc:584-622): gravity_alignment = opt_pose.rotation()
     dliom_insertion_result ins;

@@ -776,8 +776,6 @@ int dliom_ctx_destroy(dliom_ctx* ctx) {
   if (ctx->hist_fork != nullptr) (void)hipEventDestroy(ctx->hist_fork);
   if (ctx->hist_join != nullptr) (void)hipEventDestroy(ctx->hist_join);
   if (ctx->hist_big_stream != nullptr) (void)hipStreamDestroy(ctx->hist_big_stream);
-  if (ctx->download_pinned != nullptr) (void)hipHostFree(ctx->download_pinned);
-  if (ctx->download_done != nullptr) (void)hipEventDestroy(ctx->download_done);
   if (ctx->pinned != nullptr) (void)hipHostFree(ctx->pinned);
   if (ctx->done_word != nullptr) (void)hipHostFree(ctx->done_word);
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);

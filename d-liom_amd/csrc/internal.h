@@ -117,12 +117,6 @@ struct dliom_ctx {
   int last_box_variant = -1;       // which instantiation of the box kernel ran last (dliom_rtcsm_stats.box_kernel_variant)
   void* pinned = nullptr;   // small pinned host staging block
   size_t pinned_bytes = 0;
-  // dliom_cloud_download_begin / _finish: a download in flight beside whatever the caller enqueues next; its own
-  // page-locked block (no other call touches it) and an event behind its one kernel
-  void* download_pinned = nullptr;
-  size_t download_pinned_bytes = 0;
-  hipEvent_t download_done = nullptr;
-  const dliom_cloud* download_pending = nullptr;
   unsigned* done_word = nullptr;  // pinned, own allocation: completion word of the main stream's read-back kernels
   unsigned done_seq = 0;
   int64_t voxel_unpacked_reruns = 0;  // voxel filter launches repeated with 21-bit keys (dliom_ctx_voxel_filter_reruns)

@@ -838,47 +838,6 @@ static int download_packed(const dliom_cloud* cloud, const float* pose7, float* 
   return DLIOM_OK;
 }
 
-int dliom_cloud_download_begin(const dliom_cloud* cloud, const float pose[7]) {
-  if (cloud == nullptr) return DLIOM_ERR_INVALID_ARGUMENT;
-  dliom_ctx* ctx = cloud->ctx;
-  if (ctx->download_pending != nullptr) return DLIOM_ERR_INVALID_ARGUMENT;  // one at a time per context
-  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  const size_t n = static_cast<size_t>(cloud->n);
-  if (ctx->download_done == nullptr) DLIOM_HIP_TRY(hipEventCreateWithFlags(&ctx->download_done, hipEventDisableTiming));
-  if (n * 12 > ctx->download_pinned_bytes) {
-    if (ctx->download_pinned != nullptr) (void)hipHostFree(ctx->download_pinned);
-    ctx->download_pinned = nullptr;
-    ctx->download_pinned_bytes = 0;
-    const size_t want = (n * 12 + n * 3 + 4095) & ~static_cast<size_t>(4095);
-    DLIOM_HIP_TRY(hipHostMalloc(&ctx->download_pinned, want, hipHostMallocCoherent | hipHostMallocMapped));
-    ctx->download_pinned_bytes = want;
-  }
-  if (n > 0) {
-    DownloadPose dp;
-    dp.apply = pose != nullptr ? 1 : 0;
-    dp.q = pose != nullptr ? Quat4{pose[3], pose[4], pose[5], pose[6]} : Quat4{1.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < 3; ++i) dp.t[i] = pose != nullptr ? pose[i] : 0.f;
-    hipLaunchKernelGGL(download_packed_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, cloud->d_x, cloud->d_y,
-                       cloud->d_z, static_cast<int>(n), dp, static_cast<float*>(ctx->download_pinned));
-    DLIOM_HIP_TRY(hipGetLastError());
-    DLIOM_HIP_TRY(hipEventRecord(ctx->download_done, ctx->stream));
-  }
-  ctx->download_pending = cloud;
-  return DLIOM_OK;
-}
-
-int dliom_cloud_download_finish(const dliom_cloud* cloud, float* points_xyz) {
-  if (cloud == nullptr || cloud->ctx->download_pending != cloud) return DLIOM_ERR_INVALID_ARGUMENT;
-  dliom_ctx* ctx = cloud->ctx;
-  ctx->download_pending = nullptr;
-  if (cloud->n == 0) return DLIOM_OK;
-  DLIOM_HIP_TRY(hipSetDevice(ctx->device));
-  DLIOM_HIP_TRY(hipEventSynchronize(ctx->download_done));
-  if (points_xyz != nullptr)  // (null: the caller gives the download up -- waited for, nothing copied)
-    std::memcpy(points_xyz, ctx->download_pinned, static_cast<size_t>(cloud->n) * 12);
-  return DLIOM_OK;
-}
-
 int dliom_cloud_download(const dliom_cloud* cloud, float* points_xyz) {
   if (cloud == nullptr || (cloud->n > 0 && points_xyz == nullptr)) return DLIOM_ERR_INVALID_ARGUMENT;
   return download_packed(cloud, nullptr, points_xyz);

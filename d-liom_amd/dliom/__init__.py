@@ -227,8 +227,6 @@ SYMBOLS = [
                                                          C.POINTER(AdaptiveVoxelFilterOptions), C.POINTER(_vp), C.POINTER(_vp)]),
     ("dliom_cloud_download", C.c_int, [_vp, _f32p]),
     ("dliom_cloud_download_transformed", C.c_int, [_vp, _f32p, _f32p]),
-    ("dliom_cloud_download_begin", C.c_int, [_vp, _f32p]),
-    ("dliom_cloud_download_finish", C.c_int, [_vp, _f32p]),
     ("dliom_rtcsm3d_match", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _f32p, C.c_int64, _vp, _f64p, _f32p]),
     ("dliom_rtcsm3d_match_cloud", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, _f64p, _f32p]),
     ("dliom_rtcsm3d_shard_begin", C.c_int, [_vp, C.POINTER(RtcsmOptions), _f64p, _vp, _vp, C.c_int, C.c_int,
@@ -534,16 +532,6 @@ class PointCloud:
         _check(self._L.dliom_cloud_adaptive_voxel_filter_pair(self.ctx.h, self.h, C.byref(a), C.byref(b), C.byref(ha),
                                                               C.byref(hb)), "dliom_cloud_adaptive_voxel_filter_pair")
         return PointCloud(self.ctx, _handle=ha), PointCloud(self.ctx, _handle=hb)
-
-    def download_begin(self, pose7=None):
-        """dliom_cloud_download_begin: the download's kernel is enqueued (pose7 as in download()); download_finish() collects."""
-        pose = None if pose7 is None else _p(_f32(pose7), _f32p)
-        _check(self._L.dliom_cloud_download_begin(self.h, pose), "dliom_cloud_download_begin")
-
-    def download_finish(self):
-        out = np.zeros((self.n, 3), dtype=np.float32)
-        _check(self._L.dliom_cloud_download_finish(self.h, _p(out, _f32p)), "dliom_cloud_download_finish")
-        return out
 
     def download(self, pose7=None):
         """The points, packed xyz; pose7 (float [t, q]): sensor::TransformPointCloud(cloud, pose) applied on the device."""

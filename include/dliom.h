@@ -453,14 +453,6 @@ int dliom_cloud_download(const dliom_cloud* cloud, float* points_xyz);
  * filtered_range_data_in_local = TransformRangeData(filtered_range_data_in_tracking, opt_pose.cast<float>())
  * (local_trajectory_builder_3d.cc:556-559) without a host loop over the returns. */
 int dliom_cloud_download_transformed(const dliom_cloud* cloud, const float pose[7], float* points_xyz);
-/* The same download in two halves: _begin enqueues the one kernel (pose: null = the points as they are) writing into a
- * page-locked block of the context's own and returns; _finish waits for that kernel only and copies into points_xyz.
- * What the caller enqueues in between -- LocalTrajectoryBuilder3D starts ComputeHistogram's kernels there -- costs the
- * download nothing and the other way round.  One pending download per context; the cloud outlives the pair;
- * destroying the cloud in between is the caller's error.  _finish(cloud, NULL) gives the download up (waits, copies
- * nothing): what an error path calls. */
-int dliom_cloud_download_begin(const dliom_cloud* cloud, const float pose[7]);
-int dliom_cloud_download_finish(const dliom_cloud* cloud, float* points_xyz);
 /* The same filters on host buffers (the reference's own placement): out_xyz has room for n points;
  * *num_out receives the survivors (first point per voxel). */
 int dliom_voxel_filter(float size, const float* points_xyz, int64_t n, float* out_xyz, int64_t* num_out);

@@ -1932,39 +1932,6 @@ def test_memory_accounting_and_the_mirror_budget(dl, orc):
     c.close()
 
 
-def test_cloud_download_in_two_halves(dl, ctx, orc):
-    """dliom_cloud_download_begin / _finish (round 6: LocalTrajectoryBuilder3D enqueues the returns' download, starts
-    ComputeHistogram's kernels, then collects): the same bits as the one-call download whatever runs in between -- calls
-    that use the context's staging block and read-backs included --, one pending download per context, and a download
-    given up (finish with a null buffer) leaves the context free for the next."""
-    rng = np.random.RandomState(77)
-    pts = rng.uniform(-30, 30, size=(40000, 3)).astype(np.float32)
-    pose = np.concatenate([rng.uniform(-5, 5, 3), orc.angle_axis_quat(0.4, rng.uniform(-1, 1, 3), normalize_axis=True)]).astype(np.float32)
-    cloud = dl.PointCloud(ctx, pts)
-    want = orc.transform_points(pose, pts)
-    cloud.download_begin(pose)
-    with pytest.raises(dl.DliomError):
-        cloud.download_begin(pose)  # one at a time
-    dl.cloud_rotational_histogram_begin(ctx, cloud, 120)
-    filtered = cloud.voxel_filter(0.5)  # read-backs through the context's own staging block
-    hist = dl.cloud_rotational_histogram_finish(ctx, 120)
-    got = cloud.download_finish()
-    assert got.tobytes() == want.tobytes()
-    assert np.array_equal(hist.view(np.uint32), np.asarray(orc.compute_histogram(pts, 120), np.float32).view(np.uint32))
-    filtered.close()
-    with pytest.raises(dl.DliomError):
-        cloud.download_finish()  # nothing pending
-    cloud.download_begin()  # no pose: the points as they are
-    assert np.array_equal(cloud.download_finish(), pts)
-    cloud.download_begin(pose)
-    dl._check(dl.load_library().dliom_cloud_download_finish(cloud.h, None), "give up")
-    small = dl.PointCloud(ctx, pts[:5])
-    small.download_begin(pose)
-    assert small.download_finish().tobytes() == want[:5].tobytes()
-    small.close()
-    cloud.close()
-
-
 @pytest.mark.parametrize("n", [1, 333, 100003])
 def test_cloud_download_transformed_equals_transform_point_cloud(dl, ctx, orc, n):
     """dliom_cloud_download_transformed (round 6: LocalTrajectoryBuilder3D's filtered_range_data_in_local, .cc:556-559, made on
