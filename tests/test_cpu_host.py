@@ -681,6 +681,49 @@ def test_wave_per_segment_replay_of_std_sort_model(tmp_path, orc):
     assert int(re.search(r"more segments than the ring holds: (\d+)", out.stdout).group(1)) >= 1, out.stdout
 
 
+def test_big_slice_sort_work_list_model(tmp_path):
+    """tests/cpp/big_sort_worklist_model.cc: the control flow of big_sort_order (rothist_big.h) -- which segments of
+    introsort's replay the whole workgroup partitions, which go through LDS in batches, the work list of 256, the ring of
+    the wave-per-segment stage, the depth limit -- on 600 arrays of 4 097 .. 40 000 keys full of ties: the order equals
+    std::sort's and NOTHING is refused (40 000 such arrays in round 6, by hand: none either).  The two refusals round 6's
+    soaks found on the device come back under the rules they met ("old"): the ring that held every segment ever queued
+    (9 716 descending keys in tied pairs) and the workgroup-wide branch chosen for a 1 203-element segment at the depth
+    limit (seed 5872952 of tools/fuzz_round3.py).  What is still refused, by design: the depth limit on a segment above
+    4 096 elements (std::sort heap-sorts it on one thread) -- the ring of aligned tied pairs of
+    test_device_std_sort_order_on_paths_of_lopsided_partitions."""
+    from helpers import slice_angle_arrays
+    exe = str(tmp_path / "big_sort_worklist_model")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "big_sort_worklist_model.cc")])
+    rng = np.random.RandomState(5872952)  # fuzz_round3.py's case, as its generator made it
+    rng.rand()
+    n = int(rng.randint(1, 4097)) if rng.rand() < 0.85 else int(rng.randint(4097, 30000))
+    assert n == 18865 and int(rng.randint(0, 5)) == 1
+    second = np.sort(rng.uniform(-3, 3, n))
+    second[rng.randint(0, n, n // 5)] = second[rng.randint(0, n, n // 5)]
+    m = 9716
+    ang = np.pi - (np.arange(m) // 2).astype(np.float64) * (2 * np.pi / (m // 2 + 2))
+    ring = np.stack([5.0 * np.cos(ang), 5.0 * np.sin(ang), np.full(m, 0.05)], axis=1).astype(np.float32)
+    aligned = slice_angle_arrays(ring)
+    assert len(aligned) == 1 and len(aligned[0]) == m
+    arrays = tmp_path / "arrays.txt"
+    with open(arrays, "w") as f:
+        for a in (second.astype(np.float32), aligned[0]):
+            f.write("%d\n%s\n" % (len(a), " ".join("%08x" % b for b in np.asarray(a, np.float32).view(np.uint32))))
+    out = subprocess.run([exe, "600", "new", str(arrays)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    assert "from the file: 2 arrays, 1 refused at the depth limit" in out.stdout, out.stdout
+    assert "mismatches 0;" in out.stdout and "list 0, ring 0 " in out.stdout and "stuck 0" in out.stdout, out.stdout
+    assert "refusals: depth 1 (" in out.stdout, out.stdout  # the aligned ring and nothing else
+    old = subprocess.run([exe, "0", "old", str(arrays)], capture_output=True, text=True, timeout=600)
+    assert "from the file: 2 arrays, 2 refused at the depth limit" in old.stdout, old.stdout
+    assert "ring 1 (1 on the soak's 9 716 keys)" in old.stdout, old.stdout
+    # the constants the model copies
+    hdr = open(os.path.join(ROOT, "d-liom_amd", "csrc", "rothist_big.h")).read()
+    hip = open(os.path.join(ROOT, "d-liom_amd", "csrc", "rotational_histogram.hip")).read()
+    assert "constexpr int kWorkListCap = 256;" in hdr and "constexpr size_t kBigLdsBytes = 150 * 1024;" in hdr
+    assert "constexpr int kQueueCap = 1024;" in hip and "2 * static_cast<size_t>(m) / 17 + 64" in hdr
+
+
 def test_blocked_chain_walk_model(tmp_path):
     """tests/cpp/chain_walk_model.cc: the blocked walk that marks the nodes of the `last_point` chain 0 -> next(0) -> ...
     in rothist_big.h (per-thread exits, per-wave exits from the last block to the first, the waves' entries, the blocks'
