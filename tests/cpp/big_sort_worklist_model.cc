@@ -10,7 +10,7 @@
 //   stuck   a work list without an entry that fits LDS                                      must not happen
 // Round 6's soaks found two refusals this model reproduces with the rules they met (argument "old"): the ring that held
 // every segment ever queued, and the workgroup-wide branch chosen for a 1 203-element segment at the depth limit.
-// Usage: big_sort_worklist_model [cases] [new|old] [arrays.txt] -> "... refusals: depth D, list 0, ring 0, stuck 0".
+// Usage: big_sort_worklist_model [cases] [new|old] [arrays.txt|-] [seed] -> "... refusals: depth D, list 0, ring 0, stuck 0".
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -194,7 +194,7 @@ int main(int argc, char** argv) {
     check(k, &c);
   }
   const long after_first = c.ring;
-  std::mt19937_64 rng(20261001);
+  std::mt19937_64 rng(argc > 4 ? static_cast<unsigned long long>(atoll(argv[4])) : 20261001ull);
   auto uniform = [&](double lo, double hi) { return lo + (hi - lo) * (static_cast<double>(rng() >> 11) / 9007199254740992.0); };
   long lopsided_depth = 0;
   for (long t = 0; t < cases; ++t) {

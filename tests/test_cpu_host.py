@@ -685,7 +685,7 @@ def test_big_slice_sort_work_list_model(tmp_path):
     """tests/cpp/big_sort_worklist_model.cc: the control flow of big_sort_order (rothist_big.h) -- which segments of
     introsort's replay the whole workgroup partitions, which go through LDS in batches, the work list of 256, the ring of
     the wave-per-segment stage, the depth limit -- on 600 arrays of 4 097 .. 40 000 keys full of ties: the order equals
-    std::sort's and NOTHING is refused (40 000 such arrays in round 6, by hand: none either).  The two refusals round 6's
+    std::sort's and NOTHING is refused (240 000 such arrays in round 6, by hand, five seeds: none either).  The two refusals round 6's
     soaks found on the device come back under the rules they met ("old"): the ring that held every segment ever queued
     (9 716 descending keys in tied pairs) and the workgroup-wide branch chosen for a 1 203-element segment at the depth
     limit (seed 5872952 of tools/fuzz_round3.py).  What is still refused, by design: the depth limit on a segment above
